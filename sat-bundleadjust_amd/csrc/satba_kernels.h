@@ -1,0 +1,627 @@
+// satba_kernels.h -- HIP kernels of the bundle-adjustment hot path (gfx950, wave64).
+//
+// Work decomposition.  Observations are point-major (ref:bundle_adjust/ba_params.py:142-147): all
+// observations of a point are contiguous.  The host cuts the observation stream into WAVE TILES of whole
+// points with at most 64 observations; one wavefront processes one tile, lane = observation.  Every
+// global read of the observation arrays is then a coalesced 64-lane access, per-point sums (V_p, g_p,
+// W^T dc) are segmented wave reductions with no atomics, and per-camera sums (U_c, g_c) are accumulated
+// with LDS atomics in a per-workgroup table that is flushed once per workgroup.
+// A point with more than 64 observations is split over several tiles flagged `split`: those use
+// global atomics for the per-point sums (rare slow path).
+//
+// Nothing here is GEMM shaped (2x3, 2x6, 3x3, 6x6 blocks): MFMA is not used; the kernels are bound by HBM
+// traffic (residual / linearize / back-substitution / Jv products) or fp64 VALU + atomics (Schur).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "satba_models.h"
+
+namespace satba {
+
+constexpr int TILE_THREADS = 512;  // 8 waves per workgroup for the tile kernels
+constexpr int TILE_WAVES = TILE_THREADS / 64;
+constexpr int MAX_TILE_GRID = 512;  // persistent grid: 2 workgroups per CU
+
+__host__ __device__ constexpr int cam_acc_len(int np) { return np * (np + 1) / 2 + np; }
+
+struct ObsArgs {
+    const double2* __restrict__ obs;   // K observed (col, row)
+    const double* __restrict__ w;      // K weights
+    const int* __restrict__ cam;       // K camera index
+    const int* __restrict__ pt;        // K local point index
+    const int* __restrict__ tile_start;       // n_tiles + 1
+    const unsigned char* __restrict__ tile_split;  // n_tiles
+    const double* __restrict__ x;      // variable vector whose POINT part is used
+    const double* __restrict__ camc;   // M x CAMC camera constants built from the same vector
+    const double* __restrict__ rpc;    // M x 90 or null
+    long long K;
+    int n_tiles, M, N, n_c, n_cam_fix, n_pts_fix, loss, f32;
+    double f_scale;
+};
+
+// weighted, robust-scaled residual and (optionally) Jacobian blocks of observation o
+template <int MODEL, int NP, bool JAC>
+struct ObsEval {
+    double ftrue[2];  // w * (proj - obs)
+    double fs[2];     // robust-scaled residual
+    double rho;       // contribution to 2 * cost
+    double Jc[2][NP];
+    double Jp[2][3];
+
+    __device__ inline void eval(const ObsArgs& a, long long o, int cam, int pt) {
+        const double2 ob = a.obs[o];
+        const double w = a.w[o];
+        const double* px = a.x + a.n_c + 3 * (size_t)pt;
+        const double X = px[0], Y = px[1], Z = px[2];
+        const double* cc = a.camc + (size_t)cam * CAMC;
+        const double* tab = (MODEL == RPC) ? a.rpc + (size_t)cam * 90 : nullptr;
+        double u, v;
+        project<MODEL, NP, JAC>(cc, tab, X, Y, Z, a.f32 != 0, u, v, Jc, Jp);
+        ftrue[0] = w * (u - ob.x);
+        ftrue[1] = w * (v - ob.y);
+        double r0, r1, js0, js1;
+        robust(a.loss, a.f_scale, ftrue[0], r0, fs[0], js0);
+        robust(a.loss, a.f_scale, ftrue[1], r1, fs[1], js1);
+        rho = r0 + r1;
+        if (JAC) {
+            const double mc = (cam >= a.n_cam_fix) ? 1.0 : 0.0;
+            const double mp = (pt >= a.n_pts_fix) ? 1.0 : 0.0;
+            const double s0 = w * js0, s1 = w * js1;
+#pragma unroll
+            for (int i = 0; i < NP; ++i) { Jc[0][i] *= s0 * mc; Jc[1][i] *= s1 * mc; }
+#pragma unroll
+            for (int j = 0; j < 3; ++j) { Jp[0][j] *= s0 * mp; Jp[1][j] *= s1 * mp; }
+        }
+    }
+};
+
+__device__ inline double wave_sum(double v) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v += __shfl_down(v, d);
+    return v;
+}
+__device__ inline double wave_max(double v) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v = fmax(v, __shfl_down(v, d));
+    return v;
+}
+
+// sum v[] over the lanes that share `pt` (contiguous runs); the total lands in the first lane of each run
+template <int NV>
+__device__ inline void seg_reduce(double (&v)[NV], int pt, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int opt = __shfl_down(pt, d);
+        const bool ok = (lane + d < 64) && (opt == pt);
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const double o = __shfl_down(v[k], d);
+            if (ok) v[k] += o;
+        }
+    }
+}
+
+__device__ inline void atomic_max_pos(double* addr, double v) {  // v >= 0
+    atomicMax(reinterpret_cast<unsigned long long*>(addr), (unsigned long long)__double_as_longlong(v));
+}
+
+// ------------------------------------------------------------------------------------------------ camera constants
+__global__ void k_cam_consts(int model, int M, int n_p, int c_p, const double* __restrict__ x,
+                             const double* __restrict__ cam_static, double* __restrict__ camc) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= M) return;
+    double full[11];
+    for (int i = 0; i < c_p; ++i) full[i] = cam_static[(size_t)c * c_p + i];
+    for (int i = 0; i < n_p; ++i) full[i] = x[(size_t)c * n_p + i];
+    cam_constants(model, full, camc + (size_t)c * CAMC);
+}
+
+// ------------------------------------------------------------------------------------------------ K1 residuals
+// ba_core.fun (ref:bundle_adjust/ba_core.py:157-183): one thread per observation, grid-stride.
+// hdr_cost += 0.5 * sum rho.  f may be null (cost only).
+template <int MODEL, int NP>
+__global__ __launch_bounds__(256) void k_residual(ObsArgs a, double2* __restrict__ f, double* __restrict__ hdr_cost) {
+    double acc = 0.0;
+    for (long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x; o < a.K; o += (long long)gridDim.x * blockDim.x) {
+        ObsEval<MODEL, NP, false> e;
+        e.eval(a, o, a.cam[o], a.pt[o]);
+        if (f) f[o] = make_double2(e.ftrue[0], e.ftrue[1]);
+        acc += e.rho;
+    }
+    acc = wave_sum(acc);
+    __shared__ double s[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) s[wave] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(hdr_cost, 0.5 * (s[0] + s[1] + s[2] + s[3]));
+}
+
+// ------------------------------------------------------------------------------------------------ K2 linearize
+// residual + analytic Jacobian -> normal-equation blocks (replaces scipy's finite differences,
+// scipy:optimize/_numdiff.py:628-705, and compute_grad, scipy:optimize/_lsq/common.py:590-595):
+//   f[o]            true residual pair                        (16 B / obs written)
+//   V[pt] (6), g_p  per-point blocks, plain stores by the run's first lane   (72 B / point written)
+//   part[block][M][cam_acc_len]   per-workgroup camera partials (upper triangle of U_c, then g_c)
+//   hdr[0] += cost;  hdr[slot] = max |g_p|
+template <int MODEL, int NP>
+__global__ __launch_bounds__(TILE_THREADS) void k_linearize(ObsArgs a, double2* __restrict__ f, double* __restrict__ V,
+                                                            double* __restrict__ gp, double* __restrict__ part,
+                                                            double* __restrict__ hdr_cost, double* __restrict__ hdr_gpmax) {
+    constexpr int CU = cam_acc_len(NP);
+    extern __shared__ double s_acc[];  // M * CU
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < a.M * CU; i += TILE_THREADS) s_acc[i] = 0.0;
+    __syncthreads();
+
+    double cost = 0.0, gmax = 0.0;
+    for (int tile = blockIdx.x * TILE_WAVES + wave; tile < a.n_tiles; tile += gridDim.x * TILE_WAVES) {
+        const int o0 = a.tile_start[tile], o1 = a.tile_start[tile + 1];
+        const long long o = (long long)o0 + lane;
+        const bool active = o < o1;
+        int pt = -1 - lane, cam = 0;
+        double v[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        if (active) {
+            cam = a.cam[o];
+            pt = a.pt[o];
+            ObsEval<MODEL, NP, true> e;
+            e.eval(a, o, cam, pt);
+            f[o] = make_double2(e.ftrue[0], e.ftrue[1]);
+            cost += e.rho;
+            v[0] = e.Jp[0][0] * e.Jp[0][0] + e.Jp[1][0] * e.Jp[1][0];
+            v[1] = e.Jp[0][0] * e.Jp[0][1] + e.Jp[1][0] * e.Jp[1][1];
+            v[2] = e.Jp[0][0] * e.Jp[0][2] + e.Jp[1][0] * e.Jp[1][2];
+            v[3] = e.Jp[0][1] * e.Jp[0][1] + e.Jp[1][1] * e.Jp[1][1];
+            v[4] = e.Jp[0][1] * e.Jp[0][2] + e.Jp[1][1] * e.Jp[1][2];
+            v[5] = e.Jp[0][2] * e.Jp[0][2] + e.Jp[1][2] * e.Jp[1][2];
+            v[6] = e.Jp[0][0] * e.fs[0] + e.Jp[1][0] * e.fs[1];
+            v[7] = e.Jp[0][1] * e.fs[0] + e.Jp[1][1] * e.fs[1];
+            v[8] = e.Jp[0][2] * e.fs[0] + e.Jp[1][2] * e.fs[1];
+            // camera block: LDS atomics (ds_add_f64) into this workgroup's table
+            double* acc = s_acc + (size_t)cam * CU;
+            int k = 0;
+#pragma unroll
+            for (int i = 0; i < NP; ++i)
+#pragma unroll
+                for (int j = i; j < NP; ++j) atomicAdd(acc + (k++), e.Jc[0][i] * e.Jc[0][j] + e.Jc[1][i] * e.Jc[1][j]);
+#pragma unroll
+            for (int i = 0; i < NP; ++i) atomicAdd(acc + (k++), e.Jc[0][i] * e.fs[0] + e.Jc[1][i] * e.fs[1]);
+        }
+        seg_reduce<9>(v, pt, lane);
+        const int prev = __shfl_up(pt, 1);
+        const bool head = active && (lane == 0 || prev != pt);
+        if (head) {
+            double* Vp = V + 6 * (size_t)pt;
+            double* gq = gp + 3 * (size_t)pt;
+            if (a.tile_split[tile]) {
+#pragma unroll
+                for (int k = 0; k < 6; ++k) atomicAdd(Vp + k, v[k]);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) atomicAdd(gq + k, v[6 + k]);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 6; ++k) Vp[k] = v[k];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) gq[k] = v[6 + k];
+            }
+            gmax = fmax(gmax, fmax(fabs(v[6]), fmax(fabs(v[7]), fabs(v[8]))));
+        }
+    }
+    // per-workgroup epilogue
+    __shared__ double s_red[2][TILE_WAVES];
+    cost = wave_sum(cost);
+    gmax = wave_max(gmax);
+    if (lane == 0) { s_red[0][wave] = cost; s_red[1][wave] = gmax; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double c = 0.0, g = 0.0;
+        for (int i = 0; i < TILE_WAVES; ++i) { c += s_red[0][i]; g = fmax(g, s_red[1][i]); }
+        atomicAdd(hdr_cost, 0.5 * c);
+        atomic_max_pos(hdr_gpmax, g);
+    }
+    double* out = part + (size_t)blockIdx.x * a.M * CU;
+    for (int i = threadIdx.x; i < a.M * CU; i += TILE_THREADS) out[i] = s_acc[i];
+}
+
+// sum the per-workgroup camera partials and expand to the exchange payload: U (M x NP x NP, full), g_c (M x NP)
+__global__ void k_lin_finish(int M, int NP, int nblocks, const double* __restrict__ part, double* __restrict__ U,
+                             double* __restrict__ gc) {
+    const int CU = cam_acc_len(NP);
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= M * CU) return;
+    double s = 0.0;
+    for (int b = 0; b < nblocks; ++b) s += part[(size_t)b * M * CU + idx];
+    const int cam = idx / CU, k = idx % CU;
+    const int ntri = NP * (NP + 1) / 2;
+    if (k >= ntri) {
+        gc[cam * NP + (k - ntri)] = s;
+        return;
+    }
+    int i = 0, rem = k;
+    while (rem >= NP - i) { rem -= NP - i; ++i; }
+    const int j = i + rem;
+    U[(size_t)cam * NP * NP + i * NP + j] = s;
+    U[(size_t)cam * NP * NP + j * NP + i] = s;
+}
+
+// per-point sums of a split point have been accumulated with atomics: its |g_p| still has to reach the header
+__global__ void k_gpmax(int N, const double* __restrict__ gp, double* __restrict__ hdr_gpmax) {
+    double m = 0.0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 3 * N; i += gridDim.x * blockDim.x) m = fmax(m, fabs(gp[i]));
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) atomic_max_pos(hdr_gpmax, m);
+}
+
+// ------------------------------------------------------------------------------------------------ prepare
+// x_scale="jac" (scipy:optimize/_lsq/common.py:598-610): scale_inv = column norms of J = sqrt(diag(J^T J)),
+// zeros -> 1 on the first evaluation, running maximum afterwards; g_h = g / scale_inv.
+// hdr[1] += |g_h|^2, hdr[3] += |x * scale_inv|^2 (camera part only if lead), hdr[4] = lead * |g_c|_inf
+__global__ __launch_bounds__(256) void k_prepare_vec(int n, int n_c, int NP, int first, double lead,
+                                                     const double* __restrict__ U, const double* __restrict__ gc_red,
+                                                     const double* __restrict__ V, const double* __restrict__ x,
+                                                     double* __restrict__ g, double* __restrict__ scale_inv,
+                                                     double* __restrict__ gh, double* __restrict__ hdr) {
+    double s_gh = 0.0, s_xs = 0.0, m_gc = 0.0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        double diag, gi, wgt;
+        if (i < n_c) {
+            const int cam = i / NP, k = i % NP;
+            diag = U[(size_t)cam * NP * NP + k * NP + k];
+            gi = gc_red[i];
+            g[i] = gi;
+            wgt = lead;
+            m_gc = fmax(m_gc, fabs(gi));
+        } else {
+            const int j = i - n_c, p = j / 3, k = j % 3;
+            diag = V[6 * (size_t)p + (k == 0 ? 0 : (k == 1 ? 3 : 5))];
+            gi = g[i];
+            wgt = 1.0;
+        }
+        double si = sqrt(diag);
+        if (first) si = (si == 0.0) ? 1.0 : si;
+        else si = fmax(si, scale_inv[i]);
+        scale_inv[i] = si;
+        const double h = gi / si;
+        gh[i] = h;
+        s_gh += wgt * h * h;
+        const double xs = x[i] * si;
+        s_xs += wgt * xs * xs;
+    }
+    s_gh = wave_sum(s_gh);
+    s_xs = wave_sum(s_xs);
+    m_gc = wave_max(m_gc);
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(hdr + 1, s_gh);
+        atomicAdd(hdr + 3, s_xs);
+        atomic_max_pos(hdr + 4, lead * m_gc);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ Jacobian-vector products
+// For NV vectors given in scaled variables (v = q / scale_inv): sums of (J v_a) . (J v_b) over the observations.
+// NV = 1: out[0] += |J v1|^2.   NV = 2: out[0] += |J v1|^2, out[1] += (J v1).(J v2), out[2] += |J v2|^2.
+template <int MODEL, int NP, int NV>
+__global__ __launch_bounds__(256) void k_jvp(ObsArgs a, const double* __restrict__ q1, const double* __restrict__ q2,
+                                             const double* __restrict__ scale_inv, double* __restrict__ out) {
+    double s11 = 0.0, s12 = 0.0, s22 = 0.0;
+    for (long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x; o < a.K; o += (long long)gridDim.x * blockDim.x) {
+        const int cam = a.cam[o], pt = a.pt[o];
+        ObsEval<MODEL, NP, true> e;
+        e.eval(a, o, cam, pt);
+        const size_t ic = (size_t)cam * NP, ip = (size_t)a.n_c + 3 * (size_t)pt;
+        double j1[2] = {0, 0}, j2[2] = {0, 0};
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const double si = 1.0 / scale_inv[ic + i];
+            const double v1 = q1[ic + i] * si;
+            j1[0] += e.Jc[0][i] * v1; j1[1] += e.Jc[1][i] * v1;
+            if (NV == 2) { const double v2 = q2[ic + i] * si; j2[0] += e.Jc[0][i] * v2; j2[1] += e.Jc[1][i] * v2; }
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const double si = 1.0 / scale_inv[ip + j];
+            const double v1 = q1[ip + j] * si;
+            j1[0] += e.Jp[0][j] * v1; j1[1] += e.Jp[1][j] * v1;
+            if (NV == 2) { const double v2 = q2[ip + j] * si; j2[0] += e.Jp[0][j] * v2; j2[1] += e.Jp[1][j] * v2; }
+        }
+        s11 += j1[0] * j1[0] + j1[1] * j1[1];
+        if (NV == 2) {
+            s12 += j1[0] * j2[0] + j1[1] * j2[1];
+            s22 += j2[0] * j2[0] + j2[1] * j2[1];
+        }
+    }
+    s11 = wave_sum(s11);
+    if (NV == 2) { s12 = wave_sum(s12); s22 = wave_sum(s22); }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(out, s11);
+        if (NV == 2) { atomicAdd(out + 1, s12); atomicAdd(out + 2, s22); }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ K3 Schur complement
+// (V_p + lam Dp^2)^-1 per point, symmetric 3x3 stored as xx xy xz yy yz zz
+__global__ void k_vinv(int N, double lam, const double* __restrict__ V, const double* __restrict__ scale_inv_p,
+                       double* __restrict__ Vinv) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= N) return;
+    const double* v = V + 6 * (size_t)p;
+    const double* s = scale_inv_p + 3 * (size_t)p;
+    const double a = v[0] + lam * s[0] * s[0], b = v[1], c = v[2];
+    const double d = v[3] + lam * s[1] * s[1], e = v[4], f = v[5] + lam * s[2] * s[2];
+    const double c00 = d * f - e * e, c01 = c * e - b * f, c02 = b * e - c * d;
+    const double idet = 1.0 / (a * c00 + b * c01 + c * c02);
+    double* o = Vinv + 6 * (size_t)p;
+    o[0] = c00 * idet;
+    o[1] = c01 * idet;
+    o[2] = c02 * idet;
+    o[3] = (a * f - c * c) * idet;
+    o[4] = (b * c - a * e) * idet;
+    o[5] = (a * d - b * b) * idet;
+}
+
+// S <- (lead) * blockdiag(U_c + lam Dc^2), rhs <- (lead) * g_c ; S column-major n_c x n_c (already zeroed)
+__global__ void k_schur_init(int M, int NP, double lam, double lead, const double* __restrict__ U,
+                             const double* __restrict__ gc, const double* __restrict__ scale_inv,
+                             double* __restrict__ S, double* __restrict__ rhs) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n_c = M * NP;
+    if (idx < M * NP * NP) {
+        const int cam = idx / (NP * NP), r = (idx / NP) % NP, c = idx % NP;
+        double v = U[idx];
+        if (r == c) { const double s = scale_inv[cam * NP + r]; v += lam * s * s; }
+        S[(size_t)(cam * NP + r) + (size_t)(cam * NP + c) * n_c] = lead * v;
+    }
+    if (idx < n_c) rhs[idx] = lead * gc[idx];
+}
+
+// Local Schur contributions of every point:  S -= W_a Vinv W_b^T for the observation pairs (a, b), a <= b, of
+// the point (cameras ascend inside a point, so cam_a <= cam_b: block (cam_b, cam_a) of the column-major lower
+// triangle);  rhs -= W_a Vinv g_p.   W = Jc^T Jp (NP x 3).
+// v1: W of the tile staged in LDS, S accumulated with global float64 atomics.
+template <int MODEL, int NP>
+__global__ __launch_bounds__(256) void k_schur(ObsArgs a, const double* __restrict__ Vinv, const double* __restrict__ gp,
+                                               double* __restrict__ S, double* __restrict__ rhs) {
+    constexpr int WL = NP * 3;
+    extern __shared__ double s_mem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double* sW = s_mem + (size_t)wave * 64 * WL;  // [64][WL]
+    double* s_rhs = s_mem + (size_t)4 * 64 * WL;  // [n_c]
+    for (int i = threadIdx.x; i < a.n_c; i += 256) s_rhs[i] = 0.0;
+    __syncthreads();
+    for (int tile = blockIdx.x * 4 + wave; tile < a.n_tiles; tile += gridDim.x * 4) {
+        if (a.tile_split[tile]) continue;  // handled by k_schur_split
+        const int o0 = a.tile_start[tile], o1 = a.tile_start[tile + 1];
+        const long long o = (long long)o0 + lane;
+        const bool active = o < o1;
+        int pt = -1 - lane, cam = 0;
+        double T[NP][3];
+        if (active) {
+            cam = a.cam[o];
+            pt = a.pt[o];
+            ObsEval<MODEL, NP, true> e;
+            e.eval(a, o, cam, pt);
+            double W[NP][3];
+#pragma unroll
+            for (int i = 0; i < NP; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    W[i][j] = e.Jc[0][i] * e.Jp[0][j] + e.Jc[1][i] * e.Jp[1][j];
+                    sW[lane * WL + i * 3 + j] = W[i][j];
+                }
+            const double* vi = Vinv + 6 * (size_t)pt;
+            const double i00 = vi[0], i01 = vi[1], i02 = vi[2], i11 = vi[3], i12 = vi[4], i22 = vi[5];
+            const double* g = gp + 3 * (size_t)pt;
+            const double g0 = g[0], g1 = g[1], g2 = g[2];
+#pragma unroll
+            for (int i = 0; i < NP; ++i) {
+                T[i][0] = W[i][0] * i00 + W[i][1] * i01 + W[i][2] * i02;
+                T[i][1] = W[i][0] * i01 + W[i][1] * i11 + W[i][2] * i12;
+                T[i][2] = W[i][0] * i02 + W[i][1] * i12 + W[i][2] * i22;
+                atomicAdd(s_rhs + cam * NP + i, -(T[i][0] * g0 + T[i][1] * g1 + T[i][2] * g2));
+            }
+        }
+        // run boundaries: this lane pairs with lanes lane .. end-1 of its run
+        const int prev = __shfl_up(pt, 1);
+        const unsigned long long heads = __ballot(lane == 0 || prev != pt);
+        const unsigned long long above = (lane == 63) ? 0ull : (heads >> (lane + 1));
+        const int end = above ? lane + 1 + __ffsll((long long)above) - 1 : 64;
+        int span = active ? end - lane : 0;
+        int maxspan = span;
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) maxspan = max(maxspan, __shfl_xor(maxspan, d));
+        // the shuffle of cam must be executed by every lane, so it sits outside the divergent branch
+        for (int off = 0; off < maxspan; ++off) {
+            const int b = min(lane + off, 63);
+            const int camb = __shfl(cam, b);
+            if (off < span) {
+                const double* Wb = sW + b * WL;
+                double* Sblk = S + (size_t)(camb * NP) + (size_t)(cam * NP) * a.n_c;
+#pragma unroll
+                for (int j = 0; j < NP; ++j) {
+                    const double w0 = Wb[j * 3 + 0], w1 = Wb[j * 3 + 1], w2 = Wb[j * 3 + 2];
+#pragma unroll
+                    for (int i = 0; i < NP; ++i)
+                        atomicAdd(Sblk + j + (size_t)i * a.n_c, -(T[i][0] * w0 + T[i][1] * w1 + T[i][2] * w2));
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < a.n_c; i += 256)
+        if (s_rhs[i] != 0.0) atomicAdd(rhs + i, s_rhs[i]);
+}
+
+// slow path: one wave per point with more than 64 observations; pairs (a, b) over ALL its observations
+template <int MODEL, int NP>
+__global__ __launch_bounds__(64) void k_schur_split(ObsArgs a, int n_split, const int* __restrict__ split_pts,
+                                                    const int* __restrict__ split_obs0, const int* __restrict__ split_obs1,
+                                                    const double* __restrict__ Vinv, const double* __restrict__ gp,
+                                                    double* __restrict__ S, double* __restrict__ rhs) {
+    const int lane = threadIdx.x;
+    for (int sidx = blockIdx.x; sidx < n_split; sidx += gridDim.x) {
+        const int pt = split_pts[sidx];
+        const int o0 = split_obs0[sidx], o1 = split_obs1[sidx];
+        const double* vi = Vinv + 6 * (size_t)pt;
+        const double i00 = vi[0], i01 = vi[1], i02 = vi[2], i11 = vi[3], i12 = vi[4], i22 = vi[5];
+        const double g0 = gp[3 * (size_t)pt], g1 = gp[3 * (size_t)pt + 1], g2 = gp[3 * (size_t)pt + 2];
+        for (int base = o0; base < o1; base += 64) {
+            const int oa = base + lane;
+            const bool active = oa < o1;
+            int cam = 0;
+            double T[NP][3];
+            if (active) {
+                cam = a.cam[oa];
+                ObsEval<MODEL, NP, true> e;
+                e.eval(a, oa, cam, pt);
+#pragma unroll
+                for (int i = 0; i < NP; ++i) {
+                    double W[3];
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) W[j] = e.Jc[0][i] * e.Jp[0][j] + e.Jc[1][i] * e.Jp[1][j];
+                    T[i][0] = W[0] * i00 + W[1] * i01 + W[2] * i02;
+                    T[i][1] = W[0] * i01 + W[1] * i11 + W[2] * i12;
+                    T[i][2] = W[0] * i02 + W[1] * i12 + W[2] * i22;
+                    atomicAdd(rhs + cam * NP + i, -(T[i][0] * g0 + T[i][1] * g1 + T[i][2] * g2));
+                }
+            }
+            for (int ob = base; ob < o1; ++ob) {  // uniform over the wave
+                const int camb = a.cam[ob];
+                ObsEval<MODEL, NP, true> eb;
+                eb.eval(a, ob, camb, pt);
+                if (active && ob >= oa) {
+                    double* Sblk = S + (size_t)(camb * NP) + (size_t)(cam * NP) * a.n_c;
+#pragma unroll
+                    for (int j = 0; j < NP; ++j) {
+                        const double w0 = eb.Jc[0][j] * eb.Jp[0][0] + eb.Jc[1][j] * eb.Jp[1][0];
+                        const double w1 = eb.Jc[0][j] * eb.Jp[0][1] + eb.Jc[1][j] * eb.Jp[1][1];
+                        const double w2 = eb.Jc[0][j] * eb.Jp[0][2] + eb.Jc[1][j] * eb.Jp[1][2];
+#pragma unroll
+                        for (int i = 0; i < NP; ++i)
+                            atomicAdd(Sblk + j + (size_t)i * a.n_c, -(T[i][0] * w0 + T[i][1] * w1 + T[i][2] * w2));
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ K5 back-substitution
+// t_p = sum_obs Jp^T (Jc dc[cam])  per point (segmented wave reduction)
+template <int MODEL, int NP>
+__global__ __launch_bounds__(256) void k_backsub(ObsArgs a, const double* __restrict__ dc, double* __restrict__ tbuf) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int tile = blockIdx.x * 4 + wave; tile < a.n_tiles; tile += gridDim.x * 4) {
+        const int o0 = a.tile_start[tile], o1 = a.tile_start[tile + 1];
+        const long long o = (long long)o0 + lane;
+        const bool active = o < o1;
+        int pt = -1 - lane;
+        double v[3] = {0, 0, 0};
+        if (active) {
+            const int cam = a.cam[o];
+            pt = a.pt[o];
+            ObsEval<MODEL, NP, true> e;
+            e.eval(a, o, cam, pt);
+            double u0 = 0.0, u1 = 0.0;
+#pragma unroll
+            for (int i = 0; i < NP; ++i) {
+                const double d = dc[cam * NP + i];
+                u0 += e.Jc[0][i] * d;
+                u1 += e.Jc[1][i] * d;
+            }
+#pragma unroll
+            for (int j = 0; j < 3; ++j) v[j] = e.Jp[0][j] * u0 + e.Jp[1][j] * u1;
+        }
+        seg_reduce<3>(v, pt, lane);
+        const int prev = __shfl_up(pt, 1);
+        if (active && (lane == 0 || prev != pt)) {
+            double* t = tbuf + 3 * (size_t)pt;
+            if (a.tile_split[tile]) {
+                atomicAdd(t, v[0]); atomicAdd(t + 1, v[1]); atomicAdd(t + 2, v[2]);
+            } else {
+                t[0] = v[0]; t[1] = v[1]; t[2] = v[2];
+            }
+        }
+    }
+}
+
+// gn_h = scale_inv * [dc ; Vinv (g_p - t)]  and the Gram matrix of (g_h, gn_h): hdr[1..3] += a, b, c
+__global__ __launch_bounds__(256) void k_backsub_finish(int n_c, int N, double lead, const double* __restrict__ dc,
+                                                        const double* __restrict__ Vinv, const double* __restrict__ g,
+                                                        const double* __restrict__ tbuf, const double* __restrict__ scale_inv,
+                                                        const double* __restrict__ gh, double* __restrict__ gn,
+                                                        double* __restrict__ hdr) {
+    double sa = 0.0, sb = 0.0, sc = 0.0;
+    const int total = n_c + N;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        if (i < n_c) {
+            const double v = dc[i] * scale_inv[i], h = gh[i];
+            gn[i] = v;
+            sa += lead * h * h; sb += lead * h * v; sc += lead * v * v;
+        } else {
+            const size_t p = i - n_c;
+            const double* vi = Vinv + 6 * p;
+            const size_t base = (size_t)n_c + 3 * p;
+            const double r0 = g[base] - tbuf[3 * p], r1 = g[base + 1] - tbuf[3 * p + 1], r2 = g[base + 2] - tbuf[3 * p + 2];
+            const double d[3] = {vi[0] * r0 + vi[1] * r1 + vi[2] * r2, vi[1] * r0 + vi[3] * r1 + vi[4] * r2,
+                                 vi[2] * r0 + vi[4] * r1 + vi[5] * r2};
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const double v = d[k] * scale_inv[base + k], h = gh[base + k];
+                gn[base + k] = v;
+                sa += h * h; sb += h * v; sc += v * v;
+            }
+        }
+    }
+    sa = wave_sum(sa); sb = wave_sum(sb); sc = wave_sum(sc);
+    if ((threadIdx.x & 63) == 0) { atomicAdd(hdr + 1, sa); atomicAdd(hdr + 2, sb); atomicAdd(hdr + 3, sc); }
+}
+
+// ------------------------------------------------------------------------------------------------ subspace / trial vectors
+// q1 = s g_h, w = gn_h - alpha g_h;  hdr[1] += w.w, hdr[2] += w.q1, hdr[6] += g_h.w
+__global__ __launch_bounds__(256) void k_subspace_vec(int n, int n_c, double lead, double alpha, double s,
+                                                      const double* __restrict__ gh, const double* __restrict__ gn,
+                                                      double* __restrict__ q1, double* __restrict__ wv,
+                                                      double* __restrict__ hdr) {
+    double ww = 0.0, wq = 0.0, gw = 0.0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const double h = gh[i], q = s * h, w = gn[i] - alpha * h;
+        q1[i] = q;
+        wv[i] = w;
+        const double wgt = (i < n_c) ? lead : 1.0;
+        ww += wgt * w * w; wq += wgt * w * q; gw += wgt * h * w;
+    }
+    ww = wave_sum(ww); wq = wave_sum(wq); gw = wave_sum(gw);
+    if ((threadIdx.x & 63) == 0) { atomicAdd(hdr + 1, ww); atomicAdd(hdr + 2, wq); atomicAdd(hdr + 6, gw); }
+}
+
+// x_new = x + (p0 q1 + p1 w) / scale_inv;  hdr[2] += |step|^2, hdr[3] += |x|^2
+__global__ __launch_bounds__(256) void k_trial_vec(int n, int n_c, double lead, double p0, double p1,
+                                                   const double* __restrict__ x, const double* __restrict__ q1,
+                                                   const double* __restrict__ wv, const double* __restrict__ scale_inv,
+                                                   double* __restrict__ x_new, double* __restrict__ hdr) {
+    double ss = 0.0, xx = 0.0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const double step = (p0 * q1[i] + p1 * wv[i]) / scale_inv[i];
+        const double xi = x[i];
+        x_new[i] = xi + step;
+        const double wgt = (i < n_c) ? lead : 1.0;
+        ss += wgt * step * step; xx += wgt * xi * xi;
+    }
+    ss = wave_sum(ss); xx = wave_sum(xx);
+    if ((threadIdx.x & 63) == 0) { atomicAdd(hdr + 2, ss); atomicAdd(hdr + 3, xx); }
+}
+
+// ------------------------------------------------------------------------------------------------ inspection
+template <int MODEL, int NP>
+__global__ void k_jacobian(ObsArgs a, double* __restrict__ Jc, double* __restrict__ Jp) {
+    for (long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x; o < a.K; o += (long long)gridDim.x * blockDim.x) {
+        ObsEval<MODEL, NP, true> e;
+        e.eval(a, o, a.cam[o], a.pt[o]);
+        for (int r = 0; r < 2; ++r) {
+            for (int i = 0; i < NP; ++i) Jc[(o * 2 + r) * NP + i] = e.Jc[r][i];
+            for (int j = 0; j < 3; ++j) Jp[(o * 2 + r) * 3 + j] = e.Jp[r][j];
+        }
+    }
+}
+
+}  // namespace satba

@@ -1,0 +1,308 @@
+// satba_models.h -- device-side camera models: projection and analytic Jacobian blocks of one observation.
+//
+// Math: SURVEY.md appendix B.  Reference statements of the three projections:
+//   affine       ref:bundle_adjust/ba_core.py:59-81
+//   perspective  ref:bundle_adjust/ba_core.py:84-107
+//   rpc          ref:bundle_adjust/ba_core.py:110-154 -> ref:bundle_adjust/cam_utils.py:217-231
+//                -> ref:bundle_adjust/geo_utils.py:236-255 -> rpcm.RPCModel.projection
+//                (polynomial order ref:bundle_adjust/ba_rpcfit.py:17-44, ref:c/rpc.c:279-298)
+// The reference differentiates these numerically (scipy 2-point differences); the derivatives here are
+// analytic and are validated against 3-point differences of the reference's `fun` (tests/golden/fun_*.npz).
+//
+// Rotation convention R = Rz(g) Ry(b) Rx(a) (ref:bundle_adjust/ba_rotate.py:85-94), applied as three plane
+// rotations in the order of ref:bundle_adjust/ba_core.py:47-55 so the residuals round like the reference's.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace satba {
+
+enum { AFFINE = 0, PERSPECTIVE = 1, RPC = 2 };
+
+// per-camera constant record, rebuilt from x before every pass over the observations
+//   [0..5]   cos a, sin a, cos b, sin b, cos g, sin g
+//   [6..14]  R row-major
+//   [15..]   affine: t0 t1 fx fy skew | perspective: t0 t1 t2 fx fy skew cx cy | rpc: T(3) C(3)
+constexpr int CAMC = 24;
+
+constexpr double WGS84_A = 6378137.0;
+constexpr double WGS84_E = 8.1819190842622e-2;  // as hard-coded at ref:bundle_adjust/geo_utils.py:241
+
+__device__ inline void cam_constants(int model, const double* full, double* cc) {
+    double sa, ca, sb, cb, sg, cg;
+    sincos(full[0], &sa, &ca);
+    sincos(full[1], &sb, &cb);
+    sincos(full[2], &sg, &cg);
+    cc[0] = ca; cc[1] = sa; cc[2] = cb; cc[3] = sb; cc[4] = cg; cc[5] = sg;
+    cc[6] = cg * cb;  cc[7] = cg * sb * sa - sg * ca;   cc[8] = cg * sb * ca + sg * sa;
+    cc[9] = sg * cb;  cc[10] = sg * sb * sa + cg * ca;  cc[11] = sg * sb * ca - cg * sa;
+    cc[12] = -sb;     cc[13] = cb * sa;                 cc[14] = cb * ca;
+    const int n_extra = model == AFFINE ? 5 : (model == PERSPECTIVE ? 8 : 6);
+    for (int i = 0; i < n_extra; ++i) cc[15 + i] = full[3 + i];
+    for (int i = 15 + n_extra; i < CAMC; ++i) cc[i] = 0.0;
+}
+
+// y3 = Rz Ry Rx X and the three angle derivatives of y3
+struct Rot {
+    double y3[3], da[3], db[3], dg[3];
+};
+
+template <bool JAC>
+__device__ inline void rotate(const double* __restrict__ cc, double X, double Y, double Z, Rot& r) {
+    const double ca = cc[0], sa = cc[1], cb = cc[2], sb = cc[3], cg = cc[4], sg = cc[5];
+    const double y1y = ca * Y - sa * Z, y1z = sa * Y + ca * Z;
+    const double y2x = cb * X + sb * y1z, y2z = -sb * X + cb * y1z;
+    r.y3[0] = cg * y2x - sg * y1y;
+    r.y3[1] = sg * y2x + cg * y1y;
+    r.y3[2] = y2z;
+    if (JAC) {
+        // d/da: Rz Ry (0, -y1z, y1y)
+        const double ax = sb * y1y, az = cb * y1y;
+        r.da[0] = cg * ax + sg * y1z;
+        r.da[1] = sg * ax - cg * y1z;
+        r.da[2] = az;
+        // d/db: Rz (y2z, 0, -y2x)
+        r.db[0] = cg * y2z;
+        r.db[1] = sg * y2z;
+        r.db[2] = -y2x;
+        // d/dg: (-y3y, y3x, 0)
+        r.dg[0] = -r.y3[1];
+        r.dg[1] = r.y3[0];
+        r.dg[2] = 0.0;
+    }
+}
+
+// (lat_deg, lon_deg, alt) of an ECEF point by the closed form of ref:bundle_adjust/geo_utils.py:236-255 and,
+// if JAC, G[i][j] = d out_i / d X_j obtained by differentiating exactly that formula.
+template <bool JAC>
+__device__ inline void geodetic(double x, double y, double z, double out[3], double G[3][3]) {
+    const double a = WGS84_A, esq = WGS84_E * WGS84_E;
+    const double b = sqrt(a * a * (1.0 - esq));
+    const double ep2 = (a * a - b * b) / (b * b);
+    const double rad2deg = 180.0 / M_PI;
+    const double p2 = x * x + y * y;
+    const double p = sqrt(p2);
+    const double u = a * z, w = b * p;
+    const double th = atan2(u, w);
+    double s, c;
+    sincos(th, &s, &c);
+    const double num = z + ep2 * b * s * s * s;
+    const double den = p - esq * a * c * c * c;
+    const double lat = atan2(num, den);
+    const double lon = atan2(y, x);
+    double sl, cl;
+    sincos(lat, &sl, &cl);
+    const double t = 1.0 - esq * sl * sl;
+    const double rt = sqrt(t);
+    const double Nv = a / rt;
+    out[0] = lat * rad2deg;
+    out[1] = lon * rad2deg;
+    out[2] = p / cl - Nv;
+    if (JAC) {
+        const double ip = 1.0 / p;
+        const double dp[3] = {x * ip, y * ip, 0.0};
+        const double iuw = 1.0 / (u * u + w * w);
+        const double kn = ep2 * b * 3.0 * s * s * c, kd = esq * a * 3.0 * c * c * s;
+        const double ind = 1.0 / (num * num + den * den);
+        const double kN = a * esq * sl * cl / (t * rt);
+        const double kalt = p * sl / (cl * cl);
+        for (int j = 0; j < 3; ++j) {
+            const double du = (j == 2) ? a : 0.0;
+            const double dth = (w * du - u * b * dp[j]) * iuw;
+            const double dnum = ((j == 2) ? 1.0 : 0.0) + kn * dth;
+            const double dden = dp[j] + kd * dth;
+            const double dlat = (den * dnum - num * dden) * ind;
+            G[0][j] = dlat * rad2deg;
+            G[2][j] = dp[j] / cl + kalt * dlat - kN * dlat;
+        }
+        const double ip2 = 1.0 / p2;
+        G[1][0] = -y * ip2 * rad2deg;
+        G[1][1] = x * ip2 * rad2deg;
+        G[1][2] = 0.0;
+    }
+}
+
+// 20-term cubic (RPC00B order, L = lon, P = lat, H = alt, all normalised) and its gradient
+template <bool JAC>
+__device__ inline void rpc_poly(const double* __restrict__ c, const double* m, const double* mL, const double* mP,
+                                const double* mH, double& val, double& dL, double& dP, double& dH) {
+    double v = 0.0, a = 0.0, b = 0.0, h = 0.0;
+#pragma unroll
+    for (int i = 0; i < 20; ++i) {
+        const double ci = c[i];
+        v += ci * m[i];
+        if (JAC) {
+            a += ci * mL[i];
+            b += ci * mP[i];
+            h += ci * mH[i];
+        }
+    }
+    val = v; dL = a; dP = b; dH = h;
+}
+
+// projection of an already-adjusted ECEF point through one RPC record; D = d(col,row)/dX' if JAC
+template <bool JAC>
+__device__ inline void rpc_project(const double* __restrict__ tab, double x, double y, double z, double& col,
+                                   double& row, double D[2][3]) {
+    double geo[3], G[3][3];
+    geodetic<JAC>(x, y, z, geo, G);
+    const double ilon = 1.0 / tab[81], ilat = 1.0 / tab[83], ialt = 1.0 / tab[85];
+    const double L = (geo[1] - tab[80]) * ilon;
+    const double P = (geo[0] - tab[82]) * ilat;
+    const double H = (geo[2] - tab[84]) * ialt;
+    double m[20], mL[20], mP[20], mH[20];
+    const double LL = L * L, PP = P * P, HH = H * H;
+    m[0] = 1.0; m[1] = L; m[2] = P; m[3] = H; m[4] = L * P; m[5] = L * H; m[6] = P * H; m[7] = LL; m[8] = PP;
+    m[9] = HH; m[10] = P * L * H; m[11] = LL * L; m[12] = L * PP; m[13] = L * HH; m[14] = LL * P; m[15] = PP * P;
+    m[16] = P * HH; m[17] = LL * H; m[18] = PP * H; m[19] = HH * H;
+    if (JAC) {
+        const double dl[20] = {0, 1, 0, 0, P, H, 0, 2 * L, 0, 0, P * H, 3 * LL, PP, HH, 2 * L * P, 0, 0, 2 * L * H, 0, 0};
+        const double dp[20] = {0, 0, 1, 0, L, 0, H, 0, 2 * P, 0, L * H, 0, 2 * L * P, 0, LL, 3 * PP, HH, 0, 2 * P * H, 0};
+        const double dh[20] = {0, 0, 0, 1, 0, L, P, 0, 0, 2 * H, P * L, 0, 0, 2 * L * H, 0, 0, 2 * P * H, LL, PP, 3 * HH};
+        for (int i = 0; i < 20; ++i) { mL[i] = dl[i]; mP[i] = dp[i]; mH[i] = dh[i]; }
+    }
+    double n, nL, nP, nH, d, dL, dP, dH;
+    // col = tab[0..19] / tab[20..39]; row = tab[40..59] / tab[60..79]
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        rpc_poly<JAC>(tab + 40 * k, m, mL, mP, mH, n, nL, nP, nH);
+        rpc_poly<JAC>(tab + 40 * k + 20, m, mL, mP, mH, d, dL, dP, dH);
+        const double id = 1.0 / d;
+        const double q = n * id;
+        const double scale = tab[87 + 2 * k], off = tab[86 + 2 * k];
+        (k == 0 ? col : row) = q * scale + off;
+        if (JAC) {
+            // derivative w.r.t. (lat_deg, lon_deg, alt), then chain through G
+            const double gP = scale * (nP - q * dP) * id * ilat;
+            const double gL = scale * (nL - q * dL) * id * ilon;
+            const double gH = scale * (nH - q * dH) * id * ialt;
+            for (int j = 0; j < 3; ++j) D[k][j] = gP * G[0][j] + gL * G[1][j] + gH * G[2][j];
+        }
+    }
+}
+
+// One observation: projection (u, v) and, if JAC, Jc (2 x NP) w.r.t. [angles(3), T(NP-3)] and Jp (2 x 3).
+template <int MODEL, int NP, bool JAC>
+__device__ inline void project(const double* __restrict__ cc, const double* __restrict__ rpc_tab, double X, double Y,
+                               double Z, bool f32, double& u, double& v, double Jc[2][NP], double Jp[2][3]) {
+    Rot r;
+    if constexpr (MODEL == AFFINE) {
+        rotate<JAC>(cc, X, Y, Z, r);
+        const double t0 = cc[15], t1 = cc[16], fx = cc[17], fy = cc[18], sk = cc[19];
+        const double q0 = r.y3[0] + t0, q1 = r.y3[1] + t1;
+        u = fx * q0 + sk * q1;
+        v = fy * q1;
+        if (JAC) {
+            const double* d[3] = {r.da, r.db, r.dg};
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                Jc[0][i] = fx * d[i][0] + sk * d[i][1];
+                Jc[1][i] = fy * d[i][1];
+            }
+            if constexpr (NP == 5) {  // d/dt = A
+                Jc[0][3] = fx; Jc[0][4] = sk;
+                Jc[1][3] = 0.0; Jc[1][4] = fy;
+            }
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                Jp[0][j] = fx * cc[6 + j] + sk * cc[9 + j];
+                Jp[1][j] = fy * cc[9 + j];
+            }
+        }
+    } else if constexpr (MODEL == PERSPECTIVE) {
+        rotate<JAC>(cc, X, Y, Z, r);
+        const double fx = cc[18], fy = cc[19], sk = cc[20], cx = cc[21], cy = cc[22];
+        const double q0 = r.y3[0] + cc[15], q1 = r.y3[1] + cc[16], q2 = r.y3[2] + cc[17];
+        const double un = fx * q0 + sk * q1 + cx * q2;
+        const double vn = fy * q1 + cy * q2;
+        u = un / q2;
+        v = vn / q2;
+        if (JAC) {
+            const double iz = 1.0 / q2;
+            const double D[2][3] = {{fx * iz, sk * iz, (cx - u) * iz}, {0.0, fy * iz, (cy - v) * iz}};
+            const double* d[3] = {r.da, r.db, r.dg};
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                Jc[0][i] = D[0][0] * d[i][0] + D[0][1] * d[i][1] + D[0][2] * d[i][2];
+                Jc[1][i] = D[1][1] * d[i][1] + D[1][2] * d[i][2];
+            }
+            if constexpr (NP == 6) {  // d/dt = D
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    Jc[0][3 + j] = D[0][j];
+                    Jc[1][3 + j] = D[1][j];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                Jp[0][j] = D[0][0] * cc[6 + j] + D[0][1] * cc[9 + j] + D[0][2] * cc[12 + j];
+                Jp[1][j] = D[1][1] * cc[9 + j] + D[1][2] * cc[12 + j];
+            }
+        }
+    } else {
+        // X' = R (X - T - C) + C   (ref:bundle_adjust/ba_core.py:126-130)
+        const double C0 = cc[18], C1 = cc[19], C2 = cc[20];
+        rotate<JAC>(cc, X - cc[15] - C0, Y - cc[16] - C1, Z - cc[17] - C2, r);
+        double D[2][3];
+        rpc_project<JAC>(rpc_tab, r.y3[0] + C0, r.y3[1] + C1, r.y3[2] + C2, u, v, D);
+        if (f32) {  // ref:bundle_adjust/ba_core.py:150 stores the projections in a float32 array
+            u = (double)(float)u;
+            v = (double)(float)v;
+        }
+        if (JAC) {
+            const double* d[3] = {r.da, r.db, r.dg};
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                Jc[0][i] = D[0][0] * d[i][0] + D[0][1] * d[i][1] + D[0][2] * d[i][2];
+                Jc[1][i] = D[1][0] * d[i][0] + D[1][1] * d[i][1] + D[1][2] * d[i][2];
+            }
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                Jp[0][j] = D[0][0] * cc[6 + j] + D[0][1] * cc[9 + j] + D[0][2] * cc[12 + j];
+                Jp[1][j] = D[1][0] * cc[6 + j] + D[1][1] * cc[9 + j] + D[1][2] * cc[12 + j];
+            }
+            if constexpr (NP == 6) {  // d/dT = -D R
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    Jc[0][3 + j] = -Jp[0][j];
+                    Jc[1][3 + j] = -Jp[1][j];
+                }
+            }
+        }
+    }
+}
+
+// Robust loss of one scalar residual, scipy semantics
+// (scipy:optimize/_lsq/least_squares.py:172-227, scipy:optimize/_lsq/common.py:720-731):
+//   rho0 = f_scale^2 rho(z), z = (f / f_scale)^2;  js = sqrt(max(rho' + 2 rho'' z, eps));  fs = f rho' / js
+__device__ inline void robust(int loss, double f_scale, double f, double& rho0, double& fs, double& js) {
+    if (loss == 0) {
+        rho0 = f * f;
+        fs = f;
+        js = 1.0;
+        return;
+    }
+    const double q = f / f_scale;
+    const double z = q * q;
+    double r0, r1, r2;
+    if (loss == 1) {  // soft_l1
+        const double t = 1.0 + z, st = sqrt(t);
+        r0 = 2.0 * (st - 1.0); r1 = 1.0 / st; r2 = -0.5 / (t * st);
+    } else if (loss == 2) {  // huber
+        if (z <= 1.0) { r0 = z; r1 = 1.0; r2 = 0.0; }
+        else { const double sz = sqrt(z); r0 = 2.0 * sz - 1.0; r1 = 1.0 / sz; r2 = -0.5 / (z * sz); }
+    } else if (loss == 3) {  // cauchy
+        const double t = 1.0 + z;
+        r0 = log1p(z); r1 = 1.0 / t; r2 = -1.0 / (t * t);
+    } else {  // arctan
+        const double t = 1.0 + z * z;
+        r0 = atan(z); r1 = 1.0 / t; r2 = -2.0 * z / (t * t);
+    }
+    rho0 = f_scale * f_scale * r0;
+    // rho[2] /= f_scale^2 and J_scale = rho1 + 2 rho2 f^2  ==  r1 + 2 r2 z
+    double j2 = r1 + 2.0 * r2 * z;
+    j2 = j2 < 2.220446049250313e-16 ? 2.220446049250313e-16 : j2;
+    js = sqrt(j2);
+    fs = f * r1 / js;
+}
+
+}  // namespace satba

@@ -1,0 +1,236 @@
+"""
+Bundle-adjustment core on MI355X: drop-in for the names of ref:bundle_adjust/ba_core.py.
+
+`fun` and `run_ba_optimization` keep the reference's signatures and return values but run on the GPU:
+residuals, analytic Jacobian blocks, Schur complement and the trust-region loop are HIP kernels behind
+libsatba_hip.so (include/satba.h), driven by satba/trf.py.  Nothing here falls back to the CPU: without the
+library or a HIP device these two functions raise.
+
+The projection helpers (`rotate_euler`, `project_*`, `adjust_pts3d`) are kept as small numpy functions because
+code outside the hot path calls them on a handful of points (e.g. ref:bundle_adjust/ba_rpcfit.py:331); the
+device path does not use them.
+
+Differences from the reference, all deliberate:
+  * the Jacobian is analytic; `build_jacobian_sparsity` is kept for API compatibility only;
+  * `ls_params` accepts three extra optional keys -- "gtol" (default 1e-8, scipy's default), "rpc_store_f32"
+    (default True: round RPC projections to float32 like ref:bundle_adjust/ba_core.py:150) and "return_result"
+    -- without changing any default of ref:bundle_adjust/ba_core.py:233-234;
+  * when torch.distributed is initialised with world_size > 1, `run_ba_optimization` shards the points over
+    the ranks (satba/sharding.py) and every rank returns the full vectors;
+  * the figure helpers of ref:bundle_adjust/ba_core.py:373-567 are not provided (plotting only).
+"""
+import time
+
+import numpy as np
+
+from . import sharding, trf
+from .loader import display_dict, flush_print
+
+_ENGINE_ATTR = "_satba_engines"
+
+
+# ----------------------------------------------------------------------------- host projection helpers
+
+def rotate_euler(pts, euler_angles):
+    """Rotate each row of pts by R = Rz Ry Rx of the matching row of euler_angles (ref:bundle_adjust/ba_core.py:36-56)."""
+    c, s = np.cos(euler_angles), np.sin(euler_angles)
+    x, y, z = pts[:, 0], pts[:, 1], pts[:, 2]
+    y, z = c[:, 0] * y - s[:, 0] * z, s[:, 0] * y + c[:, 0] * z
+    x, z = c[:, 1] * x + s[:, 1] * z, -s[:, 1] * x + c[:, 1] * z
+    x, y = c[:, 2] * x - s[:, 2] * y, s[:, 2] * x + c[:, 2] * y
+    return np.column_stack((x, y, z))
+
+
+def project_affine(pts3d, cam_params, pts_ind, cam_ind):
+    """(col, row) of each observation under affine cameras [a, b, g, t0, t1, fx, fy, skew] (ref:bundle_adjust/ba_core.py:59-81)."""
+    cp = cam_params[cam_ind]
+    q = rotate_euler(pts3d[pts_ind], cp[:, :3])[:, :2] + cp[:, 3:5]
+    return np.column_stack((cp[:, 5] * q[:, 0] + cp[:, 7] * q[:, 1], cp[:, 6] * q[:, 1]))
+
+
+def project_perspective(pts3d, cam_params, pts_ind, cam_ind):
+    """Perspective cameras [a, b, g, t0, t1, t2, fx, fy, skew, cx, cy] (ref:bundle_adjust/ba_core.py:84-107)."""
+    cp = cam_params[cam_ind]
+    q = rotate_euler(pts3d[pts_ind], cp[:, :3]) + cp[:, 3:6]
+    u = cp[:, 6] * q[:, 0] + cp[:, 8] * q[:, 1] + cp[:, 9] * q[:, 2]
+    v = cp[:, 7] * q[:, 1] + cp[:, 10] * q[:, 2]
+    return np.column_stack((u, v)) / q[:, 2:3]
+
+
+def adjust_pts3d(pts3d, Rt_vec):
+    """X' = R (X - T - C) + C with rows [angles, T, C] (ref:bundle_adjust/ba_core.py:110-130)."""
+    C = Rt_vec[:, 6:9]
+    return rotate_euler(pts3d - Rt_vec[:, 3:6] - C, Rt_vec[:, :3]) + C
+
+
+def project_rpc(pts3d, rpcs, cam_params, pts_ind, cam_ind):
+    """Corrected points through each camera's RPC, float32 like the reference (ref:bundle_adjust/ba_core.py:133-154)."""
+    from .cam_utils import apply_rpc_projection
+
+    X = adjust_pts3d(pts3d[pts_ind], cam_params[cam_ind])
+    out = np.zeros((pts_ind.shape[0], 2), dtype=np.float32)
+    order = np.argsort(cam_ind, kind="stable")
+    bounds = np.searchsorted(cam_ind[order], np.arange(len(rpcs) + 1))
+    for c in range(len(rpcs)):
+        sel = order[bounds[c]: bounds[c + 1]]
+        if sel.size:
+            out[sel] = apply_rpc_projection(rpcs[c], X[sel])
+    return out
+
+
+# ----------------------------------------------------------------------------- device plumbing
+
+def _fingerprint(p):
+    return (p.cam_model, p.n_cam, p.n_pts, p.n_obs, p.n_params, int(p.n_cam_fix), int(p.n_pts_fix),
+            id(p.pts_ind), id(p.cam_ind), id(p.pts2d), id(p.pts2d_w), id(p.cam_params),
+            float(p.pts2d_w.sum()), float(p.pts2d.sum()), float(p.cam_params.sum()), float(np.sum(p.pts3d[: int(p.n_pts_fix)])))
+
+
+def _distributed():
+    try:
+        import torch.distributed as dist
+
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            return trf.TorchComm()
+    except ImportError:
+        pass
+    return trf.SingleComm()
+
+
+def get_engine(p, comm=None, rpc_f32=True):
+    """The (cached) device engine of a BundleAdjustmentParameters object for this rank's shard."""
+    from .engine_hip import HipEngine
+
+    comm = comm or trf.SingleComm()
+    cache = p.__dict__.setdefault(_ENGINE_ATTR, {})
+    fp = _fingerprint(p)
+    for k in [k for k in cache if k[1] != fp]:  # the object was modified: drop engines built from the old state
+        cache.pop(k).close()
+    key = ((comm.rank, comm.world, bool(rpc_f32)), fp)
+    if key not in cache:
+        cache[key] = HipEngine(p, sharding.make_shard(p, comm.rank, comm.world), rpc_f32=rpc_f32)
+    return cache[key]
+
+
+def _frozen_vars(v, p):
+    """
+    Variable vector with frozen cameras / points restored to their initial values, as
+    BundleAdjustmentParameters.get_vars_ready_for_fun does (ref:bundle_adjust/ba_params.py:240-249) -- including
+    the reference's side effect of writing the frozen camera rows into the caller's v.
+    """
+    n_c = p.n_cam * p.n_params
+    if p.n_cam_fix > 0:
+        v[: p.n_cam_fix * p.n_params] = p.cam_params[: p.n_cam_fix, : p.n_params].ravel()
+    if p.n_pts_fix > 0:
+        v = v.copy()
+        v[n_c: n_c + 3 * int(p.n_pts_fix)] = np.asarray(p.pts3d[: int(p.n_pts_fix)], dtype=np.float64).ravel()
+    return v
+
+
+def fun(v, p):
+    """
+    Bundle-adjustment residuals [x0, y0, x1, y1, ...] = w * (projection - observation), float64, on the GPU
+    (ref:bundle_adjust/ba_core.py:157-183).  Always evaluates the whole problem on this process's device.
+    """
+    v = np.asarray(v)
+    if v.dtype != np.float64 or not v.flags.c_contiguous:
+        v = np.ascontiguousarray(v, dtype=np.float64)
+    eng = get_engine(p)
+    eng.configure("linear", 1.0)
+    eng.set_x(_frozen_vars(v, p))
+    return eng.residuals()
+
+
+def build_jacobian_sparsity(p):
+    """
+    Sparsity structure of the Jacobian (ref:bundle_adjust/ba_core.py:186-219): rows 2k, 2k+1 have ones in the
+    n_params columns of observation k's camera and the 3 columns of its point.  The device solver does not need
+    it (the Jacobian blocks are analytic and never assembled); kept for callers that expect the function.
+    Returned as CSR rather than LIL.
+    """
+    from scipy.sparse import csr_matrix
+
+    K, n_p = p.pts_ind.size, p.n_params
+    cols = np.hstack((p.cam_ind[:, None] * n_p + np.arange(n_p), p.n_cam * n_p + p.pts_ind[:, None] * 3 + np.arange(3)))
+    cols = np.repeat(cols, 2, axis=0).ravel()
+    indptr = np.arange(0, 2 * K * (n_p + 3) + 1, n_p + 3)
+    return csr_matrix((np.ones(cols.size, dtype=int), cols, indptr), shape=(2 * K, p.n_cam * n_p + p.n_pts * 3))
+
+
+def init_optimization_config(config=None):
+    """Solver options with the reference's defaults (ref:bundle_adjust/ba_core.py:222-241)."""
+    out = {"loss": "linear", "ftol": 1e-4, "xtol": 1e-10, "f_scale": 1.0, "max_iter": 300, "verbose": 1}
+    if config is not None:
+        out.update({k: config[k] for k in out if k in config})
+    return out
+
+
+def run_ba_optimization(p, ls_params=None, verbose=False, plots=True):
+    """
+    Solve the bundle adjustment problem on the GPU (ref:bundle_adjust/ba_core.py:244-332).
+
+    Returns (vars_init, vars_ba, err_init, err_ba, iterations) where, as in the reference, `iterations` is the
+    number of residual evaluations (`nfev`).  `plots` is accepted and ignored.
+    """
+    extra = ls_params or {}
+    cfg = init_optimization_config(ls_params)
+    if verbose:
+        print("\nRunning bundle adjustment...")
+        display_dict(cfg)
+
+    comm = _distributed()
+    eng = get_engine(p, comm, rpc_f32=extra.get("rpc_store_f32", True))
+    vars_init = p.params_opt.copy()
+    x0 = _frozen_vars(np.array(vars_init, dtype=np.float64), p)
+    eng.configure("linear", 1.0)
+    eng.set_x(eng.shard.local_x(p, x0))
+    residuals_init = sharding.assemble_residuals(p, eng.shard, eng.residuals(), comm)
+    if verbose:
+        flush_print("Shape of Jacobian sparsity: {}x{}".format(2 * p.n_obs, p.n_cam * p.n_params + 3 * p.n_pts))
+
+    t0 = time.time()
+    res = trf.trf_solve(eng, comm, ftol=cfg["ftol"], xtol=cfg["xtol"], gtol=extra.get("gtol", 1e-8),
+                        max_nfev=cfg["max_iter"], loss=cfg["loss"], f_scale=cfg["f_scale"],
+                        verbose=cfg["verbose"] if comm.rank == 0 else 0)
+    vars_ba = sharding.assemble_x(p, eng.shard, eng.get_x(), comm)
+    residuals_ba = sharding.assemble_residuals(p, eng.shard, eng.residuals(), comm)
+    if verbose:
+        flush_print("Optimization took {:.2f} seconds\n".format(time.time() - t0))
+
+    iterations = res.nfev
+    err_init = compute_reprojection_error(residuals_init, p.pts2d_w)
+    err_ba = compute_reprojection_error(residuals_ba, p.pts2d_w)
+    if verbose:
+        flush_print("Reprojection error before BA (mean / median): {:.2f} / {:.2f}".format(
+            np.mean(err_init), np.median(err_init)))
+        flush_print("Reprojection error after  BA (mean / median): {:.2f} / {:.2f}\n".format(
+            np.mean(err_ba), np.median(err_ba)))
+        n_per_cam = np.bincount(p.cam_ind, minlength=p.n_cam)
+        mean_init = np.bincount(p.cam_ind, weights=err_init, minlength=p.n_cam) / np.maximum(n_per_cam, 1)
+        mean_ba = np.bincount(p.cam_ind, weights=err_ba, minlength=p.n_cam) / np.maximum(n_per_cam, 1)
+        for c in range(p.n_cam):
+            flush_print("    - cam {:3} - {:5} obs - (mean before / mean after): {:.2f} / {:.2f}".format(
+                c, n_per_cam[c], mean_init[c], mean_ba[c]))
+        print("\n")
+
+    if extra.get("return_result", False):
+        res["x"], res["fun"] = vars_ba, residuals_ba
+        return vars_init, vars_ba, err_init, err_ba, iterations, res
+    return vars_init, vars_ba, err_init, err_ba, iterations
+
+
+def compute_reprojection_error(residuals, pts2d_w=None):
+    """Per-observation reprojection error: L2 norm of the unweighted residual pair (ref:bundle_adjust/ba_core.py:335-349)."""
+    r = np.asarray(residuals).reshape(-1, 2)
+    if pts2d_w is not None:
+        r = r / np.asarray(pts2d_w)[:, None]
+    return np.hypot(r[:, 0], r[:, 1])
+
+
+def compute_mean_reprojection_error_per_track(err, pts_ind, cam_ind):
+    """Mean reprojection error of each track, float32 (ref:bundle_adjust/ba_core.py:352-370); tracks without observations give NaN."""
+    n_pts = pts_ind.max() + 1
+    count = np.bincount(pts_ind, minlength=n_pts)
+    total = np.bincount(pts_ind, weights=err, minlength=n_pts)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        return (total / count).astype(np.float32)

@@ -1,0 +1,274 @@
+"""
+ctypes binding of libsatba_hip.so (include/satba.h) and the device engine the solver loop drives.
+
+There is no CPU fallback: if the shared library is missing, or no HIP device is usable, constructing a
+HipEngine raises.  PyTorch is used only as plumbing -- the exchange buffer is a torch CUDA tensor so that
+torch.distributed (RCCL) can all-reduce it in place, and kernels are launched on torch's current stream so
+they order naturally with those collectives.  With no torch CUDA runtime the library's own buffer and the
+default stream are used (single GPU only).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from .rpc_model import rpc_to_table
+from .sharding import Shard
+
+_LIB = None
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libsatba_hip.so")
+
+CAM_MODELS = {"affine": 0, "perspective": 1, "rpc": 2}
+LOSSES = {"linear": 0, "soft_l1": 1, "huber": 2, "cauchy": 3, "arctan": 4}
+HDR_FIXED = 16
+
+# every symbol include/satba.h declares (tests check that the library exports all of them)
+SYMBOLS = [
+    "satba_last_error", "satba_version", "satba_problem_create", "satba_problem_destroy", "satba_set_stream",
+    "satba_exchange_len", "satba_header_len", "satba_bind_exchange", "satba_configure", "satba_set_x", "satba_get_x",
+    "satba_residuals", "satba_linearize", "satba_prepare", "satba_schur", "satba_solve", "satba_subspace", "satba_trial",
+    "satba_accept", "satba_read_header", "satba_get_blocks", "satba_get_jacobian", "satba_get_exchange",
+    "satba_set_exchange", "satba_get_vector", "satba_time_kernel",
+]
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int32)
+
+
+class ProblemDesc(C.Structure):
+    _fields_ = [
+        ("cam_model", C.c_int32), ("n_cam", C.c_int32), ("n_pts", C.c_int32), ("n_params", C.c_int32),
+        ("cam_param_len", C.c_int32), ("n_cam_fix", C.c_int32), ("n_pts_fix", C.c_int32), ("rank", C.c_int32),
+        ("world", C.c_int32), ("rpc_store_f32", C.c_int32), ("device", C.c_int32), ("reserved", C.c_int32),
+        ("n_obs", C.c_int64), ("n_total", C.c_int64),
+        ("cam_params", _dp), ("rpc_tables", _dp), ("cam_ind", _ip), ("pts_ind", _ip), ("pts2d", _dp), ("weights", _dp),
+    ]
+
+
+def load_library(path=None):
+    """dlopen libsatba_hip.so and declare the prototypes.  Raises OSError if it has not been built."""
+    global _LIB
+    if _LIB is not None and path is None:
+        return _LIB
+    path = path or LIB_PATH
+    if not os.path.exists(path):
+        raise OSError("libsatba_hip.so not found at {}: build it with `make -C sat-bundleadjust_amd/csrc` "
+                      "(or __graft_entry__.build()); there is no CPU fallback".format(path))
+    lib = C.CDLL(path)
+    h = C.c_void_p
+    lib.satba_last_error.restype = C.c_char_p
+    lib.satba_version.restype = C.c_int
+    lib.satba_problem_create.argtypes = [C.POINTER(ProblemDesc), C.POINTER(h)]
+    lib.satba_problem_destroy.argtypes = [h]
+    lib.satba_problem_destroy.restype = None
+    lib.satba_set_stream.argtypes = [h, C.c_void_p]
+    lib.satba_exchange_len.argtypes = [h]
+    lib.satba_exchange_len.restype = C.c_int64
+    lib.satba_header_len.argtypes = [h]
+    lib.satba_header_len.restype = C.c_int64
+    lib.satba_bind_exchange.argtypes = [h, C.c_void_p, C.c_int64]
+    lib.satba_configure.argtypes = [h, C.c_int32, C.c_double]
+    lib.satba_set_x.argtypes = [h, _dp]
+    lib.satba_get_x.argtypes = [h, _dp]
+    lib.satba_residuals.argtypes = [h, _dp, _dp]
+    for name in ("satba_linearize", "satba_solve", "satba_accept"):
+        getattr(lib, name).argtypes = [h]
+    lib.satba_prepare.argtypes = [h, C.c_int32]
+    lib.satba_schur.argtypes = [h, C.c_double]
+    lib.satba_subspace.argtypes = [h, C.c_double, C.c_double]
+    lib.satba_trial.argtypes = [h, C.c_double, C.c_double]
+    lib.satba_read_header.argtypes = [h, _dp]
+    lib.satba_get_blocks.argtypes = [h, _dp, _dp, _dp, _dp]
+    lib.satba_get_jacobian.argtypes = [h, _dp, _dp]
+    lib.satba_get_exchange.argtypes = [h, C.c_int64, C.c_int64, _dp]
+    lib.satba_set_exchange.argtypes = [h, C.c_int64, C.c_int64, _dp]
+    lib.satba_get_vector.argtypes = [h, C.c_int32, _dp]
+    lib.satba_time_kernel.argtypes = [h, C.c_int32, C.c_int32, C.POINTER(C.c_float)]
+    if path == LIB_PATH:
+        _LIB = lib
+    return lib
+
+
+def _ptr(a, typ=_dp):
+    return a.ctypes.data_as(typ)
+
+
+class SatbaError(RuntimeError):
+    pass
+
+
+def _check(lib, rc):
+    if rc == 0:
+        return
+    msg = (lib.satba_last_error() or b"").decode()
+    if rc in (-1, -4):
+        raise ValueError(msg)
+    raise SatbaError("libsatba_hip: {} (code {})".format(msg, rc))
+
+
+class HipEngine:
+    """Device-resident solver state of one shard (see satba/trf.py for the phase contract)."""
+
+    HDR_FIXED = HDR_FIXED
+
+    def __init__(self, p, shard=None, device=None, rpc_f32=True, use_torch=None):
+        self.lib = load_library()
+        self.p = p
+        self.shard = shard or Shard(p)
+        sh = self.shard
+        self.rank, self.world = sh.rank, sh.world
+        self.n_cam, self.n_p, self.n_pts = p.n_cam, p.n_params, sh.n_pts
+        self.n_c = self.n_cam * self.n_p
+        self.n = self.n_c + 3 * self.n_pts
+        self.n_total = p.n_cam * p.n_params + 3 * p.n_pts
+        self.n_obs = sh.o1 - sh.o0
+
+        self._torch = None
+        if use_torch is None or use_torch:
+            try:
+                import torch
+
+                if torch.cuda.is_available():
+                    self._torch = torch
+            except ImportError:
+                pass
+            if use_torch and self._torch is None:
+                raise SatbaError("torch with a usable HIP device was requested but is not available")
+        if device is None:
+            device = self._torch.cuda.current_device() if self._torch else 0
+        self.device = int(device)
+
+        cam_params = np.ascontiguousarray(p.cam_params, dtype=np.float64)
+        cam_ind = np.ascontiguousarray(p.cam_ind[sh.o0: sh.o1], dtype=np.int32)
+        pts_ind = np.ascontiguousarray(p.pts_ind[sh.o0: sh.o1] - sh.p0, dtype=np.int32)
+        pts2d = np.ascontiguousarray(p.pts2d[sh.o0: sh.o1], dtype=np.float64)
+        w = np.ascontiguousarray(p.pts2d_w[sh.o0: sh.o1], dtype=np.float64)
+        rpc = None
+        if p.cam_model == "rpc":
+            rpc = np.ascontiguousarray(np.stack([rpc_to_table(c) for c in p.cameras]), dtype=np.float64)
+        d = ProblemDesc(
+            cam_model=CAM_MODELS[p.cam_model], n_cam=p.n_cam, n_pts=sh.n_pts, n_params=p.n_params,
+            cam_param_len=cam_params.shape[1], n_cam_fix=int(p.n_cam_fix), n_pts_fix=sh.n_pts_fix, rank=sh.rank,
+            world=sh.world, rpc_store_f32=int(bool(rpc_f32)), device=self.device, reserved=0, n_obs=self.n_obs,
+            n_total=self.n_total, cam_params=_ptr(cam_params), rpc_tables=_ptr(rpc) if rpc is not None else None,
+            cam_ind=_ptr(cam_ind, _ip), pts_ind=_ptr(pts_ind, _ip), pts2d=_ptr(pts2d), weights=_ptr(w))
+        self._h = C.c_void_p()
+        _check(self.lib, self.lib.satba_problem_create(C.byref(d), C.byref(self._h)))
+
+        self.hdr = int(self.lib.satba_header_len(self._h))
+        self.xb_len = int(self.lib.satba_exchange_len(self._h))
+        self.len_lin = self.hdr + self.n_cam * self.n_p ** 2 + self.n_c
+        self.len_schur = self.hdr + self.n_c ** 2 + self.n_c
+        self.xb = None
+        if self._torch is not None:
+            torch = self._torch
+            self.xb = torch.zeros(self.xb_len, dtype=torch.float64, device="cuda:{}".format(self.device))
+            _check(self.lib, self.lib.satba_bind_exchange(self._h, C.c_void_p(self.xb.data_ptr()), self.xb_len))
+            self.use_stream(torch.cuda.current_stream(self.device))
+        self._hdr_host = np.zeros(self.hdr)
+        self.set_x(sh.local_x(p, np.asarray(p.params_opt, dtype=np.float64)))
+
+    # -- lifetime
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self.lib.satba_problem_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def use_stream(self, stream):
+        """Launch on a torch.cuda.Stream (or None for the default stream)."""
+        handle = stream.cuda_stream if stream is not None else 0
+        _check(self.lib, self.lib.satba_set_stream(self._h, C.c_void_p(handle)))
+
+    # -- state transfer
+    def configure(self, loss, f_scale):
+        if loss not in LOSSES:
+            raise ValueError("`loss` must be one of {}".format(list(LOSSES)))
+        _check(self.lib, self.lib.satba_configure(self._h, LOSSES[loss], float(f_scale)))
+
+    def set_x(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        if x.size != self.n:
+            raise ValueError("x has {} entries, expected {}".format(x.size, self.n))
+        _check(self.lib, self.lib.satba_set_x(self._h, _ptr(x)))
+
+    def get_x(self):
+        x = np.empty(self.n)
+        _check(self.lib, self.lib.satba_get_x(self._h, _ptr(x)))
+        return x
+
+    def residuals(self, with_cost=False):
+        r = np.empty(2 * self.n_obs)
+        cost = C.c_double()
+        _check(self.lib, self.lib.satba_residuals(self._h, _ptr(r), C.byref(cost)))
+        return (r, cost.value) if with_cost else r
+
+    def read_header(self):
+        _check(self.lib, self.lib.satba_read_header(self._h, _ptr(self._hdr_host)))
+        return self._hdr_host.copy()
+
+    # -- phases
+    def linearize(self):
+        _check(self.lib, self.lib.satba_linearize(self._h))
+
+    def prepare(self, first):
+        _check(self.lib, self.lib.satba_prepare(self._h, int(bool(first))))
+
+    def schur(self, lam):
+        _check(self.lib, self.lib.satba_schur(self._h, float(lam)))
+
+    def solve(self):
+        _check(self.lib, self.lib.satba_solve(self._h))
+
+    def subspace(self, alpha, inv_norm_g):
+        _check(self.lib, self.lib.satba_subspace(self._h, float(alpha), float(inv_norm_g)))
+
+    def trial(self, p0, p1):
+        _check(self.lib, self.lib.satba_trial(self._h, float(p0), float(p1)))
+
+    def accept(self):
+        _check(self.lib, self.lib.satba_accept(self._h))
+
+    # -- inspection (parity tests)
+    def get_blocks(self):
+        U = np.empty((self.n_cam, self.n_p, self.n_p))
+        gc = np.empty((self.n_cam, self.n_p))
+        V = np.empty((self.n_pts, 6))
+        gp = np.empty((self.n_pts, 3))
+        _check(self.lib, self.lib.satba_get_blocks(self._h, _ptr(U), _ptr(gc), _ptr(V), _ptr(gp)))
+        return U, gc, V, gp
+
+    def get_jacobian(self):
+        Jc = np.empty((self.n_obs, 2, self.n_p))
+        Jp = np.empty((self.n_obs, 2, 3))
+        _check(self.lib, self.lib.satba_get_jacobian(self._h, _ptr(Jc), _ptr(Jp)))
+        return Jc, Jp
+
+    def get_exchange(self, offset, n):
+        out = np.empty(n)
+        _check(self.lib, self.lib.satba_get_exchange(self._h, int(offset), int(n), _ptr(out)))
+        return out
+
+    def set_exchange(self, offset, values):
+        values = np.ascontiguousarray(values, dtype=np.float64)
+        _check(self.lib, self.lib.satba_set_exchange(self._h, int(offset), values.size, _ptr(values)))
+
+    VECTORS = {"g": 0, "scale_inv": 1, "gn_h": 2, "q1": 3, "w": 4, "x_new": 5, "g_h": 6}
+
+    def get_vector(self, name):
+        out = np.empty(self.n)
+        _check(self.lib, self.lib.satba_get_vector(self._h, self.VECTORS[name], _ptr(out)))
+        return out
+
+    KERNELS = {"residual": 0, "linearize": 1, "schur": 2, "cholesky": 3, "backsub": 4, "jvp": 5}
+
+    def time_kernel(self, name, reps=10):
+        """Average milliseconds per launch, HIP events on the engine's stream (see satba_time_kernel)."""
+        ms = C.c_float()
+        _check(self.lib, self.lib.satba_time_kernel(self._h, self.KERNELS[name], int(reps), C.byref(ms)))
+        return ms.value

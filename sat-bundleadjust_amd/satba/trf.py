@@ -1,0 +1,286 @@
+"""
+Trust-region / Levenberg-Marquardt outer loop with scipy's semantics, driving a device engine.
+
+This replaces `scipy.optimize.least_squares(method="trf", tr_solver="lsmr", x_scale="jac")` as the reference
+calls it (ref:bundle_adjust/ba_core.py:284-297).  The control flow, trust-radius update, termination tests, nfev
+accounting and status codes restate scipy:optimize/_lsq/trf.py:401-560 (`trf_no_bounds`) and
+scipy:optimize/_lsq/common.py:171-245, 302-322, 705-717; what changes is where the arithmetic happens:
+
+  * every vector and matrix lives on the device inside an *engine* (satba/engine_hip.py); the host sees a
+    handful of scalars per iteration;
+  * the Jacobian is analytic and never materialised: the engine forms the normal-equation blocks directly;
+  * scipy's inexact LSMR solve of the damped Gauss-Newton system  (J_h^T J_h + reg I) p = g_h  (trf.py:473-480)
+    is replaced by an exact one: per-point 3x3 elimination (Schur complement), a dense Cholesky of the reduced
+    camera system and back-substitution.  reg is scipy's own Cauchy-step regulariser, so in unscaled variables
+    this is the Levenberg-Marquardt system (J^T J + reg diag(scale_inv^2)) x = g;
+  * the step is then chosen in span{g_h, gn_h} under the trust radius exactly as scipy does (trf.py:481-496).
+
+Multi-GPU: one engine per rank holds a contiguous shard of points; camera-side sums are combined by an
+all-reduce of the engine's exchange buffer after each phase (`comm.allreduce`); every rank runs this same loop
+on identical scalars and therefore takes identical decisions.
+
+Engine contract (implemented by engine_hip.HipEngine; tests use a CPU stand-in built on the oracle):
+    xb                  exchange buffer, float64 torch tensor: [header (hdr) | payload] (None without torch, 1 GPU)
+    hdr, len_lin, len_schur, HDR_FIXED
+    configure(loss, f_scale); set_x(x); get_x(); read_header() -> host copy of xb[:hdr]; residuals()
+    linearize()         normal blocks at x          -> header[COST], slot[rank] = |g_p|_inf, payload U | g_c
+    prepare(first)      scaling, g_h, |J_h g_h|^2   -> header[GH_SQ, JG_SQ, XS_SQ, GC_INF]
+    schur(lam)          local reduced system        -> payload S | rhs
+    solve()             Cholesky + back-substitute  -> header[A, B, C, FAIL]   (Gram matrix of g_h, gn_h)
+    subspace(alpha, s)  q1 = s g_h, w = gn_h - alpha g_h, J_h products -> header[WW, WQ1, B11, B12, B22, GHW]
+    trial(p0, p1)       x_new = x + scale (p0 q1 + p1 w); cost there -> header[COST_NEW, STEP_SQ, X_SQ]
+    accept()            x <- x_new
+"""
+import numpy as np
+
+# header slots, per phase (the header is zeroed by each phase before it writes)
+COST = 0
+GH_SQ, JG_SQ, XS_SQ, GC_INF = 1, 2, 3, 4
+GRAM_A, GRAM_B, GRAM_C, CHOL_FAIL = 1, 2, 3, 4
+WW, WQ1, B11, B12, B22, GHW = 1, 2, 3, 4, 5, 6
+COST_NEW, STEP_SQ, X_SQ = 1, 2, 3
+
+TERMINATION_MESSAGES = {
+    -1: "Improper input parameters status returned from `leastsq`",
+    0: "The maximum number of function evaluations is exceeded.",
+    1: "`gtol` termination condition is satisfied.",
+    2: "`ftol` termination condition is satisfied.",
+    3: "`xtol` termination condition is satisfied.",
+    4: "Both `ftol` and `xtol` termination conditions are satisfied.",
+}
+
+
+class SingleComm:
+    """No exchange: one engine holds the whole problem."""
+    rank, world = 0, 1
+
+    def allreduce(self, engine, n):
+        pass
+
+    def sum_array(self, a):
+        return a
+
+
+class TorchComm:
+    """Sum all-reduce over torch.distributed (backend nccl == RCCL on ROCm, gloo in the CPU tests)."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+
+        self.dist, self.group = dist, group
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+
+    def allreduce(self, engine, n):
+        """Sum the first n doubles of the engine's exchange buffer over all ranks, in place."""
+        if self.world > 1:
+            self.dist.all_reduce(engine.xb[:n], op=self.dist.ReduceOp.SUM, group=self.group)
+
+    def sum_array(self, a):
+        """Element-wise sum of a host float64 array over all ranks (used to assemble sharded results)."""
+        import torch
+
+        if self.world == 1:
+            return a
+        dev = "cuda" if self.dist.get_backend(self.group) == "nccl" else "cpu"
+        t = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+        return t.cpu().numpy()
+
+
+class Result(dict):
+    """Subset of scipy's OptimizeResult: x, cost, fun, optimality, nfev, njev, status, message, success."""
+    __getattr__ = dict.__getitem__
+    __setattr__ = dict.__setitem__
+
+
+# ----------------------------------------------------------------------------- scalar helpers (scipy semantics)
+
+def solve_trust_region_2d(B, g, Delta):
+    """min 0.5 p^T B p + g^T p  s.t. |p| <= Delta in two dimensions (scipy:optimize/_lsq/common.py:171-219)."""
+    a, b, c = B[0, 0], B[0, 1], B[1, 1]
+    det = a * c - b * b
+    if a > 0 and det > 0:  # positive definite: try the Newton step
+        p = -np.array([c * g[0] - b * g[1], a * g[1] - b * g[0]]) / det
+        if p @ p <= Delta ** 2:
+            return p, True
+    # boundary solution: p = Delta (2t, 1 - t^2) / (1 + t^2); stationarity is a quartic in t
+    a, b, c = a * Delta ** 2, b * Delta ** 2, c * Delta ** 2
+    d, f = g[0] * Delta, g[1] * Delta
+    t = np.roots(np.array([-b + d, 2 * (a - c + f), 6 * b, 2 * (-a + c + f), -b - d]))
+    t = np.real(t[np.isreal(t)])
+    p = Delta * np.vstack((2 * t / (1 + t ** 2), (1 - t ** 2) / (1 + t ** 2)))
+    value = 0.5 * np.sum(p * B.dot(p), axis=0) + np.dot(g, p)
+    return p[:, np.argmin(value)], False
+
+
+def update_tr_radius(Delta, actual_reduction, predicted_reduction, step_norm, bound_hit):
+    """scipy:optimize/_lsq/common.py:222-245."""
+    if predicted_reduction > 0:
+        ratio = actual_reduction / predicted_reduction
+    elif predicted_reduction == actual_reduction == 0:
+        ratio = 1
+    else:
+        ratio = 0
+    if ratio < 0.25:
+        Delta = 0.25 * step_norm
+    elif ratio > 0.75 and bound_hit:
+        Delta *= 2.0
+    return Delta, ratio
+
+
+def minimize_quadratic_1d(a, b, lb, ub):
+    """Minimum of a t^2 + b t on [lb, ub] (scipy:optimize/_lsq/common.py:302-322)."""
+    t = [lb, ub]
+    if a != 0:
+        ext = -0.5 * b / a
+        if lb < ext < ub:
+            t.append(ext)
+    t = np.asarray(t)
+    y = t * (a * t + b)
+    i = np.argmin(y)
+    return t[i], y[i]
+
+
+def check_termination(dF, F, dx_norm, x_norm, ratio, ftol, xtol):
+    """scipy:optimize/_lsq/common.py:705-717."""
+    ftol_ok = dF < ftol * F and ratio > 0.25
+    xtol_ok = dx_norm < xtol * (xtol + x_norm)
+    if ftol_ok and xtol_ok:
+        return 4
+    if ftol_ok:
+        return 2
+    if xtol_ok:
+        return 3
+    return None
+
+
+def _print_header():
+    print("{:^15}{:^15}{:^15}{:^15}{:^15}{:^15}".format(
+        "Iteration", "Total nfev", "Cost", "Cost reduction", "Step norm", "Optimality"))
+
+
+def _print_iteration(iteration, nfev, cost, cost_reduction, step_norm, optimality):
+    cr = " " * 15 if cost_reduction is None else f"{cost_reduction:^15.2e}"
+    sn = " " * 15 if step_norm is None else f"{step_norm:^15.2e}"
+    print(f"{iteration:^15}{nfev:^15}{cost:^15.4e}{cr}{sn}{optimality:^15.2e}")
+
+
+# ----------------------------------------------------------------------------- the loop
+
+def trf_solve(engine, comm=None, ftol=1e-8, xtol=1e-8, gtol=1e-8, max_nfev=None, loss="linear", f_scale=1.0,
+              verbose=0, timers=None):
+    """
+    Run the loop on `engine` from its current x.  Returns a Result; the solution stays in the engine
+    (engine.get_x(), engine.residuals()).  `timers`, if a dict, accumulates per-phase call counts.
+    """
+    comm = comm or SingleComm()
+    hdr = engine.hdr
+    slots = slice(engine.HDR_FIXED, engine.HDR_FIXED + comm.world)
+    if max_nfev is None:
+        max_nfev = engine.n_total * 100
+
+    def exchange(n):
+        comm.allreduce(engine, n)
+        return engine.read_header()
+
+    def linearize(first):
+        engine.linearize()
+        h = exchange(engine.len_lin)
+        cost, gp_inf = h[COST], np.max(h[slots])
+        engine.prepare(first)
+        h = exchange(hdr)
+        return cost, max(gp_inf, h[GC_INF]), h[GH_SQ], h[JG_SQ], h[XS_SQ]
+
+    engine.configure(loss, f_scale)
+    cost, g_norm, gh_sq, jg_sq, xs_sq = linearize(True)
+    if not np.isfinite(cost):
+        raise ValueError("Residuals are not finite in the initial point.")
+    nfev = njev = 1
+    initial_cost = cost
+    Delta = np.sqrt(xs_sq)
+    if Delta == 0:
+        Delta = 1.0
+
+    status, iteration, step_norm, actual_reduction = None, 0, None, None
+    lm_iterations = 0
+    if verbose == 2:
+        _print_header()
+
+    while True:
+        if g_norm < gtol:
+            status = 1
+        if verbose == 2:
+            _print_iteration(iteration, nfev, cost, actual_reduction, step_norm, g_norm)
+        if status is not None or nfev == max_nfev:
+            break
+
+        # Cauchy-step regulariser of the Gauss-Newton system (scipy trf.py:473-477)
+        gh_norm = np.sqrt(gh_sq)
+        _, ag_value = minimize_quadratic_1d(0.5 * jg_sq, -gh_sq, 0.0, Delta / gh_norm)
+        reg = -ag_value / Delta ** 2
+
+        for attempt in range(8):
+            engine.schur(reg)
+            comm.allreduce(engine, engine.len_schur)
+            engine.solve()
+            h = exchange(hdr)
+            if h[CHOL_FAIL] == 0 and np.isfinite(h[GRAM_C]):
+                break
+            reg *= 10.0  # reduced system not numerically positive definite: damp harder
+        else:
+            raise RuntimeError("reduced camera system could not be factorised")
+        ga, gb, gc = h[GRAM_A], h[GRAM_B], h[GRAM_C]
+
+        # orthonormal basis of span{g_h, gn_h} and the model restricted to it (scipy trf.py:481-485)
+        engine.subspace(gb / ga, 1.0 / np.sqrt(ga))
+        h = exchange(hdr)
+        ww = h[WW]
+        if ww > 1e-24 * gc and ww > 0:
+            nw = np.sqrt(ww)
+            B_S = np.array([[h[B11], h[B12] / nw], [h[B12] / nw, h[B22] / ww]])
+            g_S = np.array([np.sqrt(ga), h[GHW] / nw])
+        else:  # gn_h parallel to g_h: one-dimensional subspace
+            nw = np.inf
+            B_S = np.array([[h[B11], 0.0], [0.0, 1.0]])
+            g_S = np.array([np.sqrt(ga), 0.0])
+
+        actual_reduction = -1
+        while actual_reduction <= 0 and nfev < max_nfev:
+            p_S, _ = solve_trust_region_2d(B_S, g_S, Delta)
+            predicted_reduction = -(0.5 * p_S @ B_S @ p_S + g_S @ p_S)
+            engine.trial(p_S[0], p_S[1] / nw)
+            h = exchange(hdr)
+            cost_new = h[COST_NEW]
+            nfev += 1
+            step_h_norm = np.linalg.norm(p_S)
+            if not np.isfinite(cost_new):
+                Delta = 0.25 * step_h_norm
+                continue
+            actual_reduction = cost - cost_new
+            Delta_new, ratio = update_tr_radius(Delta, actual_reduction, predicted_reduction, step_h_norm,
+                                                step_h_norm > 0.95 * Delta)
+            step_norm = np.sqrt(h[STEP_SQ])
+            status = check_termination(actual_reduction, cost, step_norm, np.sqrt(h[X_SQ]), ratio, ftol, xtol)
+            if status is not None:
+                break
+            Delta = Delta_new
+
+        if actual_reduction > 0:
+            engine.accept()
+            cost, g_norm, gh_sq, jg_sq, xs_sq = linearize(False)
+            njev += 1
+        else:
+            step_norm = 0
+            actual_reduction = 0
+        iteration += 1
+        lm_iterations += 1
+
+    if status is None:
+        status = 0
+    res = Result(cost=cost, optimality=g_norm, nfev=nfev, njev=njev, status=status, success=status > 0,
+                 message=TERMINATION_MESSAGES[status], iterations=lm_iterations, initial_cost=initial_cost)
+    if verbose >= 1:
+        print(res.message)
+        print("Function evaluations {}, initial cost {:.4e}, final cost {:.4e}, first-order optimality {:.2e}."
+              .format(nfev, initial_cost, cost, g_norm))
+    return res

@@ -1,0 +1,40 @@
+"""Seeded scenes shared by the tests and tools/gen_golden.py (keep the two in sync)."""
+import os
+
+import numpy as np
+
+from satba import synth
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+FUN_CASES = {
+    "affine_RT": ("affine", 4, 50, 3, {"correction_params": ["R", "T"], "n_cam_fix": 0}),
+    "affine_R_fix": ("affine", 6, 120, 4, {"correction_params": ["R"], "n_cam_fix": 1, "n_pts_fix": 7,
+                                           "ref_cam_weight": 2.5}),
+    "persp_RT": ("perspective", 4, 50, 3, {"correction_params": ["R", "T"], "n_cam_fix": 1}),
+    "rpc_RT": ("rpc", 4, 60, 3, {"correction_params": ["R", "T"], "n_cam_fix": 0}),
+    "rpc_R": ("rpc", 3, 40, 2, {"correction_params": ["R"], "n_cam_fix": 1}),
+}
+
+SOLVE_CASES = {
+    "affine_small_R": ("affine", 6, 400, 4, 2, {"correction_params": ["R"], "n_cam_fix": 1}, ["linear", "soft_l1"]),
+    "affine_small_RT": ("affine", 6, 400, 4, 2, {"correction_params": ["R", "T"], "n_cam_fix": 1}, ["linear"]),
+    "persp_small_R": ("perspective", 5, 300, 4, 4, {"correction_params": ["R"], "n_cam_fix": 1}, ["linear"]),
+    "affine_C2_R": ("affine", 10, 5000, 6, 1, {"correction_params": ["R"], "n_cam_fix": 1}, ["linear", "soft_l1"]),
+}
+
+
+def golden(name):
+    return np.load(os.path.join(GOLDEN, name + ".npz"))
+
+
+def fun_case(name, dense=False):
+    model, M, N, opp, d = FUN_CASES[name]
+    scene = synth.make_scene(model, M, N, opp, seed=7)
+    return scene, synth.make_params(scene, dict(d, reduce=False), dense=dense), golden("fun_" + name)
+
+
+def solve_case(name):
+    model, M, N, opp, seed, d, losses = SOLVE_CASES[name]
+    scene = synth.make_scene(model, M, N, opp, seed=seed)
+    return scene, (lambda: synth.make_params(scene, dict(d, reduce=False))), golden("solve_" + name), losses

@@ -1,0 +1,349 @@
+"""
+Parity tests proper: the HIP path, called through the C ABI (satba.engine_hip -> libsatba_hip.so), against
+(a) golden vectors captured from the reference itself (tests/golden, tools/gen_golden.py) and
+(b) the CPU oracle (oracle/) on the same seeded inputs.
+
+Tolerances (floating point, float64 arithmetic):
+  residuals `fun`        affine / perspective: 1e-8 px absolute (values ~10 px built from 6e6 m coordinates);
+                         rpc with the reference's float32 store: one float32 ulp of a pixel coordinate (2.5e-4 px),
+                         without it: 1e-7 px
+  Jacobian blocks        1e-9 relative to the largest entry vs the analytic oracle; 1e-6 vs 3-point finite
+                         differences of the reference's fun
+  normal blocks / phases 1e-10 relative to the largest entry of each quantity
+  solved camera params   1e-6 relative (north star); reprojection errors 1e-6 relative to their mean
+"""
+import numpy as np
+import pytest
+
+import cases
+from oracle import ba_oracle as O
+from oracle import lm_oracle as L
+from satba import ba_core, synth, trf
+from satba.engine_hip import HipEngine
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+# ----------------------------------------------------------------------------- fun
+
+@pytest.mark.parametrize("name", list(cases.FUN_CASES))
+def test_fun_matches_reference_golden(gpu, name):
+    _, p, g = cases.fun_case(name)
+    for k in range(3):
+        r = ba_core.fun(g["v"][k].copy(), p)
+        assert r.dtype == np.float64 and r.shape == g["r"][k].shape
+        tol = 2.5e-4 * p.pts2d_w.max() if p.cam_model == "rpc" else 1e-8
+        assert np.abs(r - g["r"][k]).max() < tol, name
+        # the oracle was pinned on the same vectors: all three must agree
+        assert np.abs(r - O.fun(g["v"][k], p)).max() < tol
+
+
+@pytest.mark.parametrize("name", ["rpc_RT", "rpc_R"])
+def test_fun_rpc_without_float32_store(gpu, name):
+    _, p, g = cases.fun_case(name)
+    eng = HipEngine(p, rpc_f32=False)
+    eng.configure("linear", 1.0)
+    for k in range(3):
+        eng.set_x(ba_core._frozen_vars(g["v"][k].copy(), p))
+        assert np.abs(eng.residuals() - g["r64"][k]).max() < 1e-7
+    eng.close()
+
+
+def test_fun_mutates_frozen_camera_rows_like_reference(gpu):
+    _, p, g = cases.fun_case("affine_R_fix")
+    v = g["v"][1].copy()
+    v[:3] += 1.0  # camera 0 is frozen: the reference overwrites these entries in the caller's vector
+    r = ba_core.fun(v, p)
+    assert np.array_equal(v[:3], p.cam_params[0, :3])
+    assert np.abs(r - g["r"][1]).max() < 1e-8
+
+
+def test_fun_cost_matches_residual_norm(gpu):
+    _, p, g = cases.fun_case("affine_RT")
+    eng = ba_core.get_engine(p)
+    eng.configure("linear", 1.0)
+    eng.set_x(g["v"][2])
+    r, cost = eng.residuals(with_cost=True)
+    assert abs(cost - 0.5 * r @ r) < 1e-10 * cost
+    for loss in L.LOSSES[1:]:
+        eng.configure(loss, 0.7)
+        _, cost = eng.residuals(with_cost=True)
+        assert abs(cost - L.robust_cost(r, loss, 0.7)) < 1e-12 * cost, loss
+
+
+# ----------------------------------------------------------------------------- Jacobian and normal blocks
+
+@pytest.mark.parametrize("name", list(cases.FUN_CASES))
+@pytest.mark.parametrize("loss", ["linear", "soft_l1", "huber", "cauchy", "arctan"])
+def test_jacobian_blocks(gpu, name, loss):
+    _, p, g = cases.fun_case(name)
+    v = g["v"][1]
+    eng = HipEngine(p, rpc_f32=False)
+    eng.configure(loss, 1.3)
+    eng.set_x(v)
+    Jc, Jp = eng.get_jacobian()
+    _, _, _, Jc_o, Jp_o = L.weighted_system(v, p, loss, 1.3, rpc_f32=False)
+    assert rel(Jc, Jc_o) < 1e-9 and rel(Jp, Jp_o) < 1e-9
+    if loss == "linear":  # finite differences of the REFERENCE's fun
+        assert rel(Jc, g["Jc"]) < 1e-6 and rel(Jp, g["Jp"]) < 1e-6
+    eng.close()
+
+
+@pytest.mark.parametrize("name", list(cases.FUN_CASES))
+@pytest.mark.parametrize("loss", ["linear", "soft_l1"])
+def test_normal_blocks(gpu, name, loss):
+    _, p, g = cases.fun_case(name)
+    v = g["v"][2]
+    eng = HipEngine(p)
+    eng.configure(loss, 1.0)
+    eng.set_x(v)
+    eng.linearize()
+    U, gc, V, gp = eng.get_blocks()
+    hdr = eng.read_header()
+    f, cost, fs, Jc, Jp = L.weighted_system(v, p, loss, 1.0)
+    U_o, gc_o, V_o, gp_o = L.normal_blocks(fs, Jc, Jp, p)
+    V_o6 = V_o[:, [0, 0, 0, 1, 1, 2], [0, 1, 2, 1, 2, 2]]
+    tol = 1e-10 if p.cam_model != "rpc" else 1e-8  # float32-rounded residuals enter g; rounding flips are rare but real
+    assert rel(U, U_o) < tol and rel(V, V_o6) < tol
+    assert rel(gc, gc_o) < 1e-6 and rel(gp, gp_o) < 1e-6
+    assert abs(hdr[trf.COST] - cost) < 1e-6 * cost
+    assert abs(hdr[eng.HDR_FIXED] - np.abs(gp_o).max()) < 1e-6 * np.abs(gp_o).max()
+    assert np.abs(eng.residuals() - f).max() < (2.5e-4 * p.pts2d_w.max() if p.cam_model == "rpc" else 1e-8)
+    eng.close()
+
+
+# ----------------------------------------------------------------------------- phase-by-phase against the oracle engine
+
+def _run_phases(eng, lam_override=None):
+    """One outer iteration's phases; returns the headers / vectors after each."""
+    out = {}
+    eng.linearize()
+    out["lin"] = eng.read_header()
+    eng.prepare(True)
+    h = eng.read_header()
+    out["prep"] = h
+    gh_sq, jg_sq, xs_sq = h[trf.GH_SQ], h[trf.JG_SQ], h[trf.XS_SQ]
+    Delta = np.sqrt(xs_sq)
+    _, ag = trf.minimize_quadratic_1d(0.5 * jg_sq, -gh_sq, 0.0, Delta / np.sqrt(gh_sq))
+    lam = -ag / Delta ** 2 if lam_override is None else lam_override
+    out["lam"] = lam
+    eng.schur(lam)
+    eng.solve()
+    h = eng.read_header()
+    out["solve"] = h
+    ga, gb = h[trf.GRAM_A], h[trf.GRAM_B]
+    eng.subspace(gb / ga, 1.0 / np.sqrt(ga))
+    h = eng.read_header()
+    out["sub"] = h
+    p0 = -0.5 * np.sqrt(ga) / h[trf.B11]  # half the minimiser along q1, plus a bit of the second direction
+    eng.trial(p0, 0.3 * p0 / np.sqrt(h[trf.WW]))
+    out["trial"] = eng.read_header()
+    return out
+
+
+@pytest.mark.parametrize("name", list(cases.FUN_CASES))
+@pytest.mark.parametrize("loss", ["linear", "soft_l1"])
+def test_phases_match_oracle_engine(gpu, name, loss):
+    _, p, g = cases.fun_case(name)
+    v = ba_core._frozen_vars(g["v"][1].copy(), p)
+    f32 = False  # compare the smooth functions; the float32 store is covered by the fun / solve tests
+    dev, ora = HipEngine(p, rpc_f32=f32), L.OracleEngine(p, rpc_f32=f32)
+    for e in (dev, ora):
+        e.configure(loss, 1.0)
+        e.set_x(v)
+    a, b = _run_phases(dev), _run_phases(ora)
+    assert abs(a["lam"] - b["lam"]) < 1e-8 * b["lam"]
+    for phase, slots in (("lin", [trf.COST, dev.HDR_FIXED]), ("prep", [trf.GH_SQ, trf.JG_SQ, trf.XS_SQ, trf.GC_INF]),
+                         ("solve", [trf.GRAM_A, trf.GRAM_B, trf.GRAM_C, trf.CHOL_FAIL]),
+                         ("sub", [trf.WW, trf.B11, trf.B12, trf.B22]), ("trial", [trf.COST_NEW, trf.STEP_SQ, trf.X_SQ])):
+        for s in slots:
+            assert abs(a[phase][s] - b[phase][s]) <= 1e-7 * abs(b[phase][s]) + 1e-300, (phase, s, a[phase][s], b[phase][s])
+    # vectors
+    assert rel(dev.get_vector("scale_inv"), ora.scale_inv) < 1e-10
+    assert rel(dev.get_vector("g_h"), ora.g_h) < 1e-8
+    assert rel(dev.get_vector("gn_h"), ora.gn_h) < 1e-6
+    assert rel(dev.get_vector("q1"), ora.q1) < 1e-8
+    assert rel(dev.get_vector("x_new"), ora.x_new) < 1e-12
+    dev.close()
+
+
+def test_schur_matrix_and_rhs(gpu):
+    _, p, g = cases.fun_case("affine_RT")
+    v = g["v"][1]
+    dev, ora = HipEngine(p), L.OracleEngine(p)
+    for e in (dev, ora):
+        e.configure("linear", 1.0)
+        e.set_x(v)
+        e.linearize()
+        e.prepare(True)
+        e.schur(0.37)
+    n_c = dev.n_c
+    S = dev.get_exchange(dev.hdr, n_c * n_c).reshape(n_c, n_c).T  # column-major on the device
+    rhs = dev.get_exchange(dev.hdr + n_c * n_c, n_c)
+    S_o = ora._xb[ora.hdr: ora.hdr + n_c * n_c].reshape(n_c, n_c)
+    rhs_o = ora._xb[ora.hdr + n_c * n_c: ora.len_schur]
+    low = np.tril_indices(n_c)
+    assert rel(S[low], S_o[low]) < 1e-10  # the device fills the lower triangle (column-major) only
+    assert rel(rhs, rhs_o) < 1e-10
+    dev.close()
+
+
+@pytest.mark.parametrize("n_cam,n_p", [(3, 3), (13, 5), (60, 5), (200, 5), (150, 6)])
+def test_dense_cholesky_solve(gpu, n_cam, n_p):
+    """The reduced-system solver alone: plant a random SPD system in the exchange payload and solve it."""
+    rng = np.random.default_rng(n_cam)
+    model = "perspective" if n_p == 6 else "affine"
+    corr = ["R"] if n_p == 3 else ["R", "T"]
+    scene = synth.make_scene(model, n_cam, 4 * n_cam, min(n_cam, 4), seed=3)
+    p = synth.make_params(scene, {"correction_params": corr})
+    eng = HipEngine(p)
+    eng.configure("linear", 1.0)
+    eng.linearize()
+    eng.prepare(True)
+    eng.schur(1.0)
+    n = eng.n_c
+    A = rng.normal(size=(n, n))
+    S = A @ A.T + n * np.eye(n)
+    rhs = rng.normal(size=n)
+    eng.set_exchange(eng.hdr, np.tril(S).T.ravel())  # column-major lower triangle; the strict upper is ignored
+    eng.set_exchange(eng.hdr + n * n, rhs)
+    eng.solve()
+    h = eng.read_header()
+    assert h[trf.CHOL_FAIL] == 0
+    dc = eng.get_vector("gn_h")[:n] / eng.get_vector("scale_inv")[:n]
+    assert rel(dc, np.linalg.solve(S, rhs)) < 1e-10
+    # a matrix that is not positive definite must raise the flag instead of producing NaNs silently
+    S[0, 0] = -1.0
+    eng.set_exchange(eng.hdr, np.tril(S).T.ravel())
+    eng.set_exchange(eng.hdr + n * n, rhs)
+    eng.solve()
+    assert eng.read_header()[trf.CHOL_FAIL] == 1
+    eng.close()
+
+
+# ----------------------------------------------------------------------------- full solves
+
+@pytest.mark.parametrize("name", list(cases.SOLVE_CASES))
+def test_tight_solve_matches_tight_scipy_reference(gpu, name):
+    """SURVEY.md section 8c protocol: reference run with ftol=xtol=gtol=1e-15, LSMR atol=btol=1e-12, gauge fixed."""
+    _, make_p, g, losses = cases.solve_case(name)
+    for loss in losses:
+        p = make_p()
+        out = ba_core.run_ba_optimization(p, {"loss": loss, "ftol": 1e-15, "xtol": 1e-15, "gtol": 1e-15, "max_iter": 300,
+                                              "verbose": 0, "return_result": True}, False, False)
+        vars_ba, err_ba, res = out[1], out[3], out[5]
+        xt, ft, st = g["tight_x_" + loss], g["tight_fun_" + loss], g["tight_stats_" + loss]
+        n_c = p.n_cam * p.n_params
+        assert res.status in (2, 3, 4)
+        assert abs(res.cost - st[0]) < 1e-9 * st[0]
+        err_t = O.reprojection_error(ft, p.pts2d_w)
+        assert np.abs(err_ba - err_t).max() < 1e-6 * err_t.mean() * 10  # per-observation, see DESIGN.md on FD noise
+        assert np.linalg.norm(res.fun - ft) < 5e-6 * np.linalg.norm(ft)
+        if name != "affine_small_RT":  # R+T on affine cameras with one frozen camera is a flat valley
+            assert rel(vars_ba[:n_c], xt[:n_c]) < 1e-6
+
+
+@pytest.mark.parametrize("name", ["affine_small_R", "persp_small_R", "affine_C2_R"])
+def test_default_tolerances_behave_like_reference(gpu, name):
+    """As shipped (ftol 1e-4): both solvers stop early and path-dependently; compare statistics, not parameters."""
+    _, make_p, g, losses = cases.solve_case(name)
+    for loss in losses:
+        p = make_p()
+        vars_init, vars_ba, err_init, err_ba, iters = ba_core.run_ba_optimization(p, {"loss": loss, "verbose": 0}, False, False)
+        assert np.array_equal(vars_init, p.params_opt)
+        assert np.allclose(err_init, g["ship_err_init_" + loss], rtol=0, atol=1e-8)
+        assert abs(err_ba.mean() - g["ship_err_" + loss].mean()) < 1e-2
+        assert abs(np.median(err_ba) - np.median(g["ship_err_" + loss])) < 1e-2
+        assert iters <= 2 * int(g["ship_iters_" + loss]) + 10
+
+
+def test_max_iter_one_only_evaluates(gpu):
+    """ba_pipeline.py:579 uses max_iter=1 to get the initial errors: no step may be taken."""
+    _, make_p, g, _ = cases.solve_case("affine_small_R")
+    p = make_p()
+    vars_init, vars_ba, err_init, err_ba, iters = ba_core.run_ba_optimization(p, {"max_iter": 1, "verbose": 0}, False, False)
+    assert iters == 1 and np.array_equal(vars_ba, vars_init) and np.array_equal(err_init, err_ba)
+
+
+def test_rpc_pipeline_sequence_config1(gpu):
+    """BASELINE config 1 counterpart: soft-L1 solve then L2 solve on two shipped RPCs (ba_pipeline.py:706-712)."""
+    g = cases.golden("solve_rpc_config1")
+    scene = synth.make_rpc_scene(2, 2000, 2, seed=1, sigma_theta=5e-6)
+    p = synth.make_params(scene, {"correction_params": ["R"], "reduce": False})
+    _, v1, e0, e1, it1 = ba_core.run_ba_optimization(p, {"loss": "soft_l1", "f_scale": 1.0, "max_iter": 300, "verbose": 0},
+                                                     False, False)
+    p.params_opt = v1.copy()
+    _, v2, _, e2, it2 = ba_core.run_ba_optimization(p, {"verbose": 0}, False, False)
+    assert np.abs(e0 - g["err_init"]).max() < 2.5e-4
+    assert abs(e1.mean() - g["err_softl1"].mean()) < 5e-3 and abs(e2.mean() - g["err_l2"].mean()) < 5e-3
+    assert e2.mean() < 0.05 * e0.mean()
+    pts3d, cams = p.reconstruct_vars(v2, scene.pts3d, scene.cameras)
+    assert len(p.estimated_params) == 2 and set(p.estimated_params[0]) == {"R", "C"}
+
+
+# ----------------------------------------------------------------------------- edge cases
+
+def test_points_with_more_than_64_observations(gpu):
+    """Tracks longer than a wavefront take the split-tile path (global atomics + k_schur_split)."""
+    scene = synth.make_affine_scene(90, 40, 80, seed=5)  # ~80 of 90 cameras see every point
+    p = synth.make_params(scene, {"correction_params": ["R", "T"], "n_cam_fix": 1})
+    assert np.bincount(p.pts_ind).max() > 64
+    v = p.params_opt.copy()
+    dev, ora = HipEngine(p), L.OracleEngine(p)
+    for e in (dev, ora):
+        e.configure("linear", 1.0)
+        e.set_x(v)
+    a, b = _run_phases(dev), _run_phases(ora)
+    for phase, slots in (("lin", [trf.COST, dev.HDR_FIXED]), ("prep", [trf.GH_SQ, trf.JG_SQ]),
+                         ("solve", [trf.GRAM_A, trf.GRAM_B, trf.GRAM_C]), ("sub", [trf.WW, trf.B11, trf.B12, trf.B22])):
+        for s in slots:
+            assert abs(a[phase][s] - b[phase][s]) <= 1e-7 * abs(b[phase][s]), (phase, s)
+    assert rel(dev.get_vector("gn_h"), ora.gn_h) < 1e-6
+    dev.close()
+
+
+def test_ragged_and_tiny_problems(gpu):
+    """2 cameras x 3 points, every point seen twice; and a problem whose tiles end exactly on 64 observations."""
+    scene = synth.make_affine_scene(2, 3, 2, seed=9)
+    p = synth.make_params(scene, {"correction_params": ["R"], "n_cam_fix": 1})
+    r = ba_core.fun(p.params_opt.copy(), p)
+    assert np.abs(r - O.fun(p.params_opt, p)).max() < 1e-8
+    scene = synth.make_affine_scene(4, 64, 4, seed=9)  # 4 obs per point -> tiles of exactly 64
+    p = synth.make_params(scene, {"correction_params": ["R"], "n_cam_fix": 1})
+    assert np.all(np.bincount(p.pts_ind) == 4)
+    eng = HipEngine(p)
+    eng.configure("linear", 1.0)
+    eng.linearize()
+    U, gc, V, gp = eng.get_blocks()
+    f, cost, fs, Jc, Jp = L.weighted_system(p.params_opt, p)
+    U_o, gc_o, V_o, gp_o = L.normal_blocks(fs, Jc, Jp, p)
+    assert rel(U, U_o) < 1e-10 and rel(gp, gp_o) < 1e-8
+    eng.close()
+
+
+def test_bad_arguments_raise(gpu):
+    scene = synth.make_affine_scene(3, 20, 3, seed=9)
+    p = synth.make_params(scene, {"correction_params": ["R"]})
+    eng = HipEngine(p)
+    with pytest.raises(ValueError):
+        eng.configure("no_such_loss", 1.0)
+    with pytest.raises(ValueError):
+        eng.set_x(np.zeros(3))
+    with pytest.raises(ValueError):
+        eng.configure("linear", -1.0)
+    eng.close()
+    p.pts_ind = p.pts_ind[::-1].copy()  # not point-major any more
+    with pytest.raises(ValueError):
+        HipEngine(p)
+
+
+def test_nonfinite_initial_residuals_raise_like_scipy(gpu):
+    scene = synth.make_affine_scene(3, 20, 3, seed=9)
+    p = synth.make_params(scene, {"correction_params": ["R"]})
+    p.params_opt[-1] = np.nan
+    with pytest.raises(ValueError):
+        ba_core.run_ba_optimization(p, {"verbose": 0}, False, False)

@@ -1,0 +1,233 @@
+"""
+Golden-vector generator -- runs ONLY in the build container, where /root/reference is mounted.
+
+Imports the reference's own hot-path modules in place (never copied; recipe of SURVEY.md appendix A: stub
+the third-party modules that are imported at module level but unused on the path) and records their outputs
+on seeded synthetic scenes into tests/golden/*.npz.  Inputs are rebuilt at test time from the same seeds by
+`satba.synth`; the small ones are also stored so a generator change cannot silently move the vectors.
+
+    MPLBACKEND=Agg PYTHONDONTWRITEBYTECODE=1 python tools/gen_golden.py
+"""
+import importlib
+import os
+import sys
+import types
+
+import numpy as np
+
+sys.dont_write_bytecode = True
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "sat-bundleadjust_amd"))
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def import_reference():
+    for name in ["rpcm", "rasterio", "rasterio.crs", "rasterio.errors", "pyproj", "utm", "srtm4"]:
+        sys.modules[name] = types.ModuleType(name)
+    sys.modules["rasterio"].errors = sys.modules["rasterio.errors"]
+    sys.modules["rasterio.errors"].NotGeoreferencedWarning = type("NotGeoreferencedWarning", (Warning,), {})
+    pkg = types.ModuleType("bundle_adjust")
+    pkg.__path__ = ["/root/reference/bundle_adjust"]
+    sys.modules["bundle_adjust"] = pkg
+    mods = {}
+    for m in ["ba_core", "ba_params", "ba_rotate", "cam_utils", "geo_utils"]:
+        mods[m] = importlib.import_module("bundle_adjust." + m)
+    return types.SimpleNamespace(**mods)
+
+
+ref = import_reference()
+from satba import synth  # noqa: E402  (own generator; the reference has none)
+
+
+def ref_params(scene, d):
+    d = dict({"verbose": False}, **d)
+    return ref.ba_params.BundleAdjustmentParameters(
+        scene.to_dense_C(), scene.pts3d, scene.cameras, scene.cam_model, scene.pairs_to_triangulate,
+        scene.camera_centers, d)
+
+
+def fd3_jacobian_blocks(f, v, p, n_p):
+    """3-point finite differences of a residual function, gathered into per-observation blocks."""
+    K = p.pts_ind.size
+    n_c = p.n_cam * n_p
+    Jc = np.zeros((K, 2, n_p))
+    Jp = np.zeros((K, 2, 3))
+    h = np.cbrt(np.finfo(float).eps) * np.maximum(1.0, np.abs(v))
+    # columns of different cameras (points) never share an observation: perturb one slot of all of them at once
+    for s in range(n_p):
+        dv = np.zeros_like(v)
+        idx = np.arange(p.n_cam) * n_p + s
+        dv[idx] = h[idx]
+        d = (f(v + dv) - f(v - dv)).reshape(K, 2) / (2 * h[idx][p.cam_ind])[:, None]
+        Jc[:, :, s] = d
+    for s in range(3):
+        dv = np.zeros_like(v)
+        idx = n_c + np.arange(p.n_pts) * 3 + s
+        dv[idx] = h[idx]
+        d = (f(v + dv) - f(v - dv)).reshape(K, 2) / (2 * h[idx][p.pts_ind])[:, None]
+        Jp[:, :, s] = d
+    return Jc, Jp
+
+
+def tight_solve(p, loss="linear", f_scale=1.0, max_nfev=100):
+    from scipy.optimize import least_squares
+
+    A = ref.ba_core.build_jacobian_sparsity(p)
+    return least_squares(ref.ba_core.fun, p.params_opt.copy(), jac_sparsity=A, x_scale="jac", method="trf",
+                         loss=loss, f_scale=f_scale, ftol=1e-15, xtol=1e-15, gtol=1e-15, max_nfev=max_nfev,
+                         tr_options={"atol": 1e-12, "btol": 1e-12}, args=(p,))
+
+
+def save(name, **arrays):
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print("wrote", path, {k: np.asarray(v).shape for k, v in arrays.items()})
+
+
+def golden_fun_and_jac():
+    """G1 (fun at 3 random v), G2 (3-point FD Jacobian blocks of the reference fun), G3 (sparsity), per model."""
+    cases = {
+        "affine_RT": ("affine", 4, 50, 3, {"correction_params": ["R", "T"], "n_cam_fix": 0}),
+        "affine_R_fix": ("affine", 6, 120, 4, {"correction_params": ["R"], "n_cam_fix": 1, "n_pts_fix": 7,
+                                                "ref_cam_weight": 2.5}),
+        "persp_RT": ("perspective", 4, 50, 3, {"correction_params": ["R", "T"], "n_cam_fix": 1}),
+        "rpc_RT": ("rpc", 4, 60, 3, {"correction_params": ["R", "T"], "n_cam_fix": 0}),
+        "rpc_R": ("rpc", 3, 40, 2, {"correction_params": ["R"], "n_cam_fix": 1}),
+    }
+    for name, (model, M, N, opp, d) in cases.items():
+        scene = synth.make_scene(model, M, N, opp, seed=7)
+        p = ref_params(scene, dict(d, reduce=False))
+        rng = np.random.default_rng(11)
+        n_c = p.n_cam * p.n_params
+        vs, rs = [], []
+        for k in range(3):
+            v = p.params_opt.copy()
+            v[:n_c] += rng.normal(0, 1e-6, n_c) * (k > 0)
+            v[n_c:] += rng.normal(0, 1.0, v.size - n_c) * (k > 0)
+            vs.append(v.copy())
+            rs.append(ref.ba_core.fun(v.copy(), p))
+        out = dict(v=np.array(vs), r=np.array(rs), params_opt=p.params_opt, cam_params=p.cam_params,
+                   pts_ind=p.pts_ind, cam_ind=p.cam_ind, pts2d=p.pts2d, pts2d_w=p.pts2d_w,
+                   pts3d=scene.pts3d, n_params=p.n_params)
+        if model == "rpc":
+            # float64 re-evaluation of the same chain (the reference stores float32, ba_core.py:150) for Jacobian checks
+            def f64(v, p=p):
+                pts3d, cam_params = p.get_vars_ready_for_fun(v.copy())
+                X = ref.ba_core.adjust_pts3d(pts3d[p.pts_ind], cam_params[p.cam_ind])
+                proj = np.zeros((p.pts_ind.size, 2))
+                for c in np.unique(p.cam_ind).tolist():
+                    sel = p.cam_ind == c
+                    proj[sel] = ref.cam_utils.apply_rpc_projection(p.cameras[c], X[sel])
+                return np.repeat(p.pts2d_w, 2) * (proj - p.pts2d).ravel()
+            fref = f64
+            out["r64"] = np.array([f64(v) for v in vs])
+        else:
+            fref = lambda v, p=p: ref.ba_core.fun(v.copy(), p)  # noqa: E731
+        Jc, Jp = fd3_jacobian_blocks(fref, vs[1], p, p.n_params)
+        A = ref.ba_core.build_jacobian_sparsity(p).tocsr()
+        out.update(Jc=Jc, Jp=Jp, A_indices=A.indices, A_indptr=A.indptr, A_shape=np.array(A.shape))
+        save("fun_" + name, **out)
+
+
+def golden_params():
+    """G4 / G5: packing incl. reduce, fixed cams / points, ref_cam_weight; unpack / reconstruct round trip."""
+    scene = synth.make_affine_scene(7, 80, 3, seed=3)
+    # make the reduce step do something: cameras 0-2 are frozen; blank a few tracks out of the free cameras,
+    # and give camera 1 no observation at all
+    C = scene.to_dense_C()
+    C[8:, :10] = np.nan
+    C[2:4, :] = np.nan
+    n_pts_fix = 10
+    d = {"n_cam_fix": 3, "n_pts_fix": n_pts_fix, "reduce": True, "verbose": False, "correction_params": ["R", "T"],
+         "ref_cam_weight": 3.0}
+    pairs = [(0, 1), (0, 2), (2, 5), (4, 6)]
+    p = ref.ba_params.BundleAdjustmentParameters(C, scene.pts3d.astype(np.float32), scene.cameras, "affine", pairs,
+                                                 scene.camera_centers, d)
+    v = p.params_opt.copy()
+    rng = np.random.default_rng(5)
+    v += rng.normal(0, 1e-3, v.size)
+    v_in = v.copy()
+    pts3d_u, cam_params_u = p.get_vars_ready_for_fun(v)
+    corrected_pts3d, corrected_cameras = p.reconstruct_vars(v.copy(), scene.pts3d.astype(np.float32), scene.cameras)
+    save("params_affine_reduce", C=C, pts3d=scene.pts3d.astype(np.float32), cameras=np.array(scene.cameras),
+         pairs=np.array(pairs), C_red=p.C, pts3d_red=p.pts3d, cam_params=p.cam_params, pts_ind=p.pts_ind,
+         cam_ind=p.cam_ind, pts2d=p.pts2d, pts2d_w=p.pts2d_w, params_opt=p.params_opt,
+         counters=np.array([p.n_cam, p.n_pts, p.n_cam_fix, p.n_pts_fix, p.n_cam_opt, p.n_pts_opt, p.n_obs, p.n_params]),
+         cam_prev=p.cam_prev_indices, pts_prev=p.pts_prev_indices, pairs_red=np.array(p.pairs_to_triangulate),
+         v_in=v_in, v_after=v, pts3d_u=pts3d_u, cam_params_u=cam_params_u, corrected_pts3d=corrected_pts3d,
+         corrected_cameras=np.array(corrected_cameras), cameras_ba=np.array(p.cameras_ba),
+         est_R=np.array([e["R"] for e in p.estimated_params]), est_T=np.array([e["T"] for e in p.estimated_params]))
+
+    # perspective + rpc camera packing (G8 includes the matrices of ref:tests/test_functions.py:20-38)
+    P_persp = np.array([[7.29623172e-02, -5.17799277e-02, -1.02734764e-02, -9.62027582e04],
+                        [-5.01011603e-02, -6.23291457e-02, -4.15721807e-02, -2.59250341e05],
+                        [2.78193760e-08, 7.15619726e-08, -1.43761111e-07, 1.00000000e00]])
+    P_aff = np.array([[7.61064055e-01, -9.35843155e-01, -1.00554841e-01, -1.13554311e06],
+                      [6.65950776e-02, -7.40405784e-02, 1.36333044e00, 4.07093217e06],
+                      [0.0, 0.0, 0.0, 1.0]])
+    cp_persp = ref.ba_params.load_cam_params_from_camera(P_persp, None, "perspective")
+    cp_aff = ref.ba_params.load_cam_params_from_camera(P_aff, None, "affine")
+    cp_rpc = ref.ba_params.load_cam_params_from_camera(None, np.array([1.0, 2.0, 3.0]), "rpc")
+    save("cam_params", P_persp=P_persp, P_aff=P_aff, cp_persp=cp_persp, cp_aff=cp_aff, cp_rpc=cp_rpc,
+         P_persp_back=ref.ba_params.load_camera_from_cam_params(cp_persp, "perspective"),
+         P_aff_back=ref.ba_params.load_camera_from_cam_params(cp_aff, "affine"),
+         rpc_back=ref.ba_params.load_camera_from_cam_params(cp_rpc, "rpc"))
+    r = np.arange(12, dtype=float) - 5.5
+    w = np.array([1.0, 2.0, 1.0, 4.0, 1.0, 0.5])
+    save("reproj_err", r=r, w=w, err_w=ref.ba_core.compute_reprojection_error(r, w),
+         err=ref.ba_core.compute_reprojection_error(r),
+         track_err=ref.ba_core.compute_mean_reprojection_error_per_track(
+             np.array([1.0, 2.0, 3.0, 4.0, 5.0]), np.array([0, 0, 1, 2, 2]), np.array([0, 1, 1, 0, 2])))
+
+
+def golden_solves():
+    """G6 (tight protocol) and G7 (as-shipped run_ba_optimization) on small and C2-shape problems."""
+    import io
+    from contextlib import redirect_stdout
+
+    specs = [
+        # name, model, M, N, obs/pt, seed, d, losses
+        ("affine_small_R", "affine", 6, 400, 4, 2, {"correction_params": ["R"], "n_cam_fix": 1}, ["linear", "soft_l1"]),
+        ("affine_small_RT", "affine", 6, 400, 4, 2, {"correction_params": ["R", "T"], "n_cam_fix": 1}, ["linear"]),
+        ("persp_small_R", "perspective", 5, 300, 4, 4, {"correction_params": ["R"], "n_cam_fix": 1}, ["linear"]),
+        ("affine_C2_R", "affine", 10, 5000, 6, 1, {"correction_params": ["R"], "n_cam_fix": 1}, ["linear", "soft_l1"]),
+    ]
+    for name, model, M, N, opp, seed, d, losses in specs:
+        scene = synth.make_scene(model, M, N, opp, seed=seed)
+        out = dict(n_obs=scene.n_obs)
+        for loss in losses:
+            p = ref_params(scene, dict(d, reduce=False))
+            res = tight_solve(p, loss=loss, max_nfev=200)
+            print(name, loss, "tight: status", res.status, "nfev", res.nfev, "cost %.10f" % res.cost)
+            out.update({"tight_x_" + loss: res.x, "tight_fun_" + loss: res.fun,
+                        "tight_stats_" + loss: np.array([res.cost, res.nfev, res.status, res.optimality])})
+            p = ref_params(scene, dict(d, reduce=False))
+            with redirect_stdout(io.StringIO()):
+                vars_init, vars_ba, err_init, err_ba, iters = ref.ba_core.run_ba_optimization(
+                    p, {"loss": loss, "verbose": 0}, False, False)
+            print(name, loss, "as shipped: nfev", iters, "mean err %.6f -> %.6f" % (err_init.mean(), err_ba.mean()))
+            out.update({"ship_x_" + loss: vars_ba, "ship_err_init_" + loss: err_init, "ship_err_" + loss: err_ba,
+                        "ship_iters_" + loss: iters})
+        save("solve_" + name, **out)
+
+    # RPC: config-1-like plumbing case (2 shipped RPCs, synthetic tracks), as-shipped soft_l1 then L2 (ba_pipeline.py:706-712)
+    scene = synth.make_rpc_scene(2, 2000, 2, seed=1, sigma_theta=5e-6)
+    p = ref_params(scene, {"correction_params": ["R"], "reduce": False})
+    with redirect_stdout(io.StringIO()):
+        _, v1, e0, e1, it1 = ref.ba_core.run_ba_optimization(p, {"loss": "soft_l1", "f_scale": 1.0, "max_iter": 300,
+                                                                 "verbose": 0}, False, False)
+        p.params_opt = v1.copy()
+        _, v2, _, e2, it2 = ref.ba_core.run_ba_optimization(p, {"verbose": 0}, False, False)
+    print("rpc config1-like: err %.4f -> %.4f -> %.4f, nfev %d + %d" % (e0.mean(), e1.mean(), e2.mean(), it1, it2))
+    save("solve_rpc_config1", x_softl1=v1, x_l2=v2, err_init=e0, err_softl1=e1, err_l2=e2, iters=np.array([it1, it2]))
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    which = sys.argv[1:] or ["fun", "params", "solves"]
+    if "fun" in which:
+        golden_fun_and_jac()
+    if "params" in which:
+        golden_params()
+    if "solves" in which:
+        golden_solves()
