@@ -54,6 +54,13 @@ def load_library(path=None):
     if not os.path.exists(path):
         raise OSError("libsatba_hip.so not found at {}: build it with `make -C sat-bundleadjust_amd/csrc` "
                       "(or __graft_entry__.build()); there is no CPU fallback".format(path))
+    try:
+        # torch bundles its own libamdhip64 under the same soname: when torch is going to be used in this process
+        # it must be loaded first so that this library binds to the same HIP runtime (two runtimes in one
+        # process do not both see the device)
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(path)
     h = C.c_void_p
     lib.satba_last_error.restype = C.c_char_p

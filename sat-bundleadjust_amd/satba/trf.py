@@ -219,14 +219,17 @@ def trf_solve(engine, comm=None, ftol=1e-8, xtol=1e-8, gtol=1e-8, max_nfev=None,
         _, ag_value = minimize_quadratic_1d(0.5 * jg_sq, -gh_sq, 0.0, Delta / gh_norm)
         reg = -ag_value / Delta ** 2
 
-        for attempt in range(8):
+        # In scaled variables the system matrix has a unit diagonal, so reg is relative to 1.  Where scipy's LSMR
+        # copes with a numerically singular system (gauge freedom, flat valleys), a Cholesky needs a floor:
+        # escalate the damping until the factorisation goes through.
+        for attempt in range(10):
             engine.schur(reg)
             comm.allreduce(engine, engine.len_schur)
             engine.solve()
             h = exchange(hdr)
             if h[CHOL_FAIL] == 0 and np.isfinite(h[GRAM_C]):
                 break
-            reg *= 10.0  # reduced system not numerically positive definite: damp harder
+            reg = max(reg, 1e-16) * 100.0
         else:
             raise RuntimeError("reduced camera system could not be factorised")
         ga, gb, gc = h[GRAM_A], h[GRAM_B], h[GRAM_C]
