@@ -1,0 +1,208 @@
+"""
+bench.py -- Levenberg-Marquardt iterations per second of the device bundle-adjustment solver on synthetic
+tracks of BASELINE.json's headline shape (200 cameras x 1 M points x ~10 M observations, affine, R+T).
+
+    python bench.py --gpus 1 --steps 10 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A step is ONE LM iteration of the whole problem: one linearisation (residual + analytic Jacobian -> normal
+blocks), the x_scale="jac" update and Cauchy-step regulariser, one damped solve (Schur complement, dense
+Cholesky, back-substitution), the 2-D subspace model and one trial-point evaluation with the accept / reject
+decision -- exactly the phases satba/trf.py runs per iteration, with the same all-reduces and the same host
+readbacks.  Inputs are resident in HBM before the timed region.  With N > 1 the SAME problem is sharded by
+points over the ranks (strong scaling); value = steps / max-over-ranks wall time.
+
+One JSON line is printed by rank 0; see DESIGN.md for `roofline` (fused residual+Jacobian kernel, algorithmic
+bytes 48 K + 96 N per launch) and `cpu_baseline` (the reference's scipy path restated in oracle/, timed on a
+bounded sub-problem on this host and scaled linearly in the number of observations).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for path in (os.path.join(ROOT, "sat-bundleadjust_amd"), ROOT):
+    if path not in sys.path:
+        sys.path.insert(0, path)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+
+
+def lm_step(eng, comm, st, trf):
+    """One fixed-work LM iteration (see module docstring).  `st` carries cost, Delta between steps."""
+    hdr = eng.hdr
+    eng.linearize()
+    comm.allreduce(eng, eng.len_lin)
+    h = eng.read_header()
+    cost = h[trf.COST]
+    eng.prepare(st["first"])
+    comm.allreduce(eng, hdr)
+    h = eng.read_header()
+    gh_sq, jg_sq = h[trf.GH_SQ], h[trf.JG_SQ]
+    if st["first"]:
+        st["Delta"] = np.sqrt(h[trf.XS_SQ]) or 1.0
+        st["first"] = False
+    Delta = st["Delta"]
+    gh_norm = np.sqrt(gh_sq)
+    _, ag = trf.minimize_quadratic_1d(0.5 * jg_sq, -gh_sq, 0.0, Delta / max(gh_norm, 1e-300))
+    reg = max(-ag / Delta ** 2, 1e-14)
+    eng.schur(reg)
+    comm.allreduce(eng, eng.len_schur)
+    eng.solve()
+    comm.allreduce(eng, hdr)
+    h = eng.read_header()
+    ga, gb = h[trf.GRAM_A], h[trf.GRAM_B]
+    eng.subspace(gb / ga, 1.0 / np.sqrt(ga))
+    comm.allreduce(eng, hdr)
+    h = eng.read_header()
+    ww = h[trf.WW]
+    if ww > 0:
+        nw = np.sqrt(ww)
+        B_S = np.array([[h[trf.B11], h[trf.B12] / nw], [h[trf.B12] / nw, h[trf.B22] / ww]])
+        g_S = np.array([np.sqrt(ga), h[trf.GHW] / nw])
+    else:
+        nw = np.inf
+        B_S = np.array([[h[trf.B11], 0.0], [0.0, 1.0]])
+        g_S = np.array([np.sqrt(ga), 0.0])
+    p_S, _ = trf.solve_trust_region_2d(B_S, g_S, Delta)
+    predicted = -(0.5 * p_S @ B_S @ p_S + g_S @ p_S)
+    eng.trial(p_S[0], p_S[1] / nw)
+    comm.allreduce(eng, hdr)
+    h = eng.read_header()
+    cost_new = h[trf.COST_NEW]
+    step_h_norm = np.linalg.norm(p_S)
+    actual = cost - cost_new if np.isfinite(cost_new) else -1.0
+    st["Delta"], _ = trf.update_tr_radius(Delta, actual, predicted, step_h_norm, step_h_norm > 0.95 * Delta)
+    if actual > 0:
+        eng.accept()
+        st["accepted"] += 1
+    st["cost"] = cost_new if actual > 0 else cost
+
+
+def cpu_baseline(scene, n_pts_sample, seed_note):
+    """
+    The reference's scipy path (oracle/ba_oracle.solve_scipy == ref ba_core.py:284-297 on the numpy restatement of
+    fun) on the first n_pts_sample points of the same scene: one LM iteration = max_nfev 2 (initial evaluation +
+    one trial), which includes one finite-difference Jacobian and one LSMR solve.  Scaled linearly in the number of
+    observations to the full workload (FD Jacobian and LSMR matvecs are both linear in nnz).
+    """
+    from oracle import ba_oracle as O
+    from satba import synth
+    from satba.ba_params import BundleAdjustmentParameters
+
+    keep = scene.pts_ind < n_pts_sample
+    p = BundleAdjustmentParameters.from_observations(
+        scene.pts_ind[keep], scene.cam_ind[keep], scene.pts2d[keep], scene.pts3d[:n_pts_sample], scene.cameras,
+        scene.cam_model, scene.pairs_to_triangulate, scene.camera_centers,
+        {"verbose": False, "correction_params": ["R", "T"], "n_cam_fix": 1})
+    t0 = time.perf_counter()
+    res = O.solve_scipy(p, {"verbose": 0}, max_nfev=2)
+    dt = time.perf_counter() - t0
+    full = scene.pts_ind.size
+    t_full = dt * full / p.n_obs
+    return {"value": 1.0 / t_full, "unit": "LM iters/sec", "cores": 1, "kind": "port",
+            "sample": "scipy least_squares(trf, lsmr, 2-point FD Jacobian) max_nfev=2 (1 LM iteration) on the first "
+                      "{} points / {} obs of the same scene: {:.1f} s, scaled linearly to {} obs; host has {} cores, "
+                      "the scipy path uses one".format(n_pts_sample, p.n_obs, dt, full, os.cpu_count()),
+            "seconds_on_sample": dt, "nfev": int(res.nfev)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--shape", default="C4", help="C2 | C3 | C4 (SURVEY.md section 8d)")
+    ap.add_argument("--sigma-theta", type=float, default=1e-4, help="initial camera angle error [rad]")
+    ap.add_argument("--cpu-sample-pts", type=int, default=4000, help="points of the CPU-baseline sub-problem (0 = skip)")
+    ap.add_argument("--kernel-reps", type=int, default=20)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, "--gpus must equal the number of launched ranks"
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from satba import sharding, synth, trf
+    from satba.engine_hip import HipEngine
+
+    n_cam, n_pts, opp = synth.SHAPES[args.shape]
+    t_gen = time.perf_counter()
+    scene = synth.make_affine_scene(n_cam, n_pts, opp, seed=1, sigma_theta=args.sigma_theta)
+    p = synth.make_params(scene, {"correction_params": ["R", "T"], "n_cam_fix": 1})
+    t_gen = time.perf_counter() - t_gen
+    comm = trf.TorchComm() if world > 1 else trf.SingleComm()
+    eng = HipEngine(p, sharding.make_shard(p, rank, world))
+    eng.configure("linear", 1.0)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    st = {"first": True, "accepted": 0, "fail": 0, "cost": None}
+    for _ in range(args.warmup):
+        lm_step(eng, comm, st, trf)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        lm_step(eng, comm, st, trf)
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # dominant kernels, HIP events on the launch stream (rank-local shard)
+    eng.linearize()
+    comm.allreduce(eng, eng.len_lin)
+    eng.prepare(False)
+    eng.schur(1e-6)
+    kern = {}
+    for name in ("linearize", "residual", "jvp", "backsub", "schur", "cholesky"):
+        eng.linearize(); eng.prepare(False); eng.schur(1e-6)
+        kern[name] = eng.time_kernel(name, args.kernel_reps if name not in ("schur", "cholesky") else max(2, args.kernel_reps // 5))
+    torch.cuda.synchronize()
+
+    if rank == 0:
+        K_loc, N_loc = eng.n_obs, eng.n_pts
+        alg_bytes = 48.0 * K_loc + 96.0 * N_loc
+        t_lin = kern["linearize"] * 1e-3
+        achieved = alg_bytes / t_lin / 1e9
+        out = {
+            "metric": "LM iters/sec at 200 cams x 1M pts x 10M obs (affine, R+T)",
+            "value": args.steps / dt, "unit": "LM iters/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "{}: {} cams x {} pts x {} obs, affine, correction R+T, 1 fixed camera, seed 1"
+                       .format(args.shape, n_cam, n_pts, p.n_obs), "sharding": "points over {} rank(s)".format(world),
+                       "obs_per_rank0": K_loc},
+            "obs_per_sec_residual_jacobian": world * K_loc / t_lin,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "kernel": "k_linearize",
+                         "algorithmic_bytes_per_launch": alg_bytes, "ms_per_launch": kern["linearize"]},
+            "kernel_ms": kern,
+            "accepted_steps": st["accepted"], "final_cost": st["cost"], "scene_gen_s": t_gen,
+        }
+        if args.cpu_sample_pts > 0 and world == 1:
+            out["cpu_baseline"] = cpu_baseline(scene, min(args.cpu_sample_pts, n_pts), "seed 1")
+            out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -42,9 +42,13 @@ def _visibility(rng, n_cam, n_pts, obs_per_pt, chunk=200000):
     """Bernoulli(obs_per_pt / n_cam) mask per (point, camera), at least two observations per point."""
     p = min(1.0, obs_per_pt / n_cam)
     pts_ind, cam_ind = [], []
+    # one reusable draw buffer: first-touch page faults on fresh 300 MB arrays cost far more than the RNG itself
+    draws = np.empty((min(chunk, n_pts), n_cam))
+    mask_buf = np.empty(draws.shape, dtype=bool)
     for start in range(0, n_pts, chunk):
         n = min(chunk, n_pts - start)
-        mask = rng.random((n, n_cam)) < p
+        rng.random(out=draws[:n])
+        mask = np.less(draws[:n], p, out=mask_buf[:n])
         short = np.nonzero(mask.sum(axis=1) < 2)[0]
         for i in short:  # rare: force two distinct cameras
             mask[i, rng.choice(n_cam, size=2, replace=False)] = True
@@ -52,6 +56,15 @@ def _visibility(rng, n_cam, n_pts, obs_per_pt, chunk=200000):
         pts_ind.append(pi + start)
         cam_ind.append(ci)
     return np.concatenate(pts_ind), np.concatenate(cam_ind)
+
+
+def _project_linear(Ps, rows, cam_ind, X, chunk=1000000):
+    """Ps[cam, :rows, :3] @ X + Ps[cam, :rows, 3] per observation, in chunks (bounded temporaries)."""
+    out = np.empty((cam_ind.size, rows))
+    for s in range(0, cam_ind.size, chunk):
+        c = cam_ind[s: s + chunk]
+        out[s: s + chunk] = np.einsum("kij,kj->ki", Ps[c][:, :rows, :3], X[s: s + chunk]) + Ps[c][:, :rows, 3]
+    return out
 
 
 def rotate_points(X, angles):
@@ -84,8 +97,7 @@ def make_affine_scene(n_cam, n_pts, obs_per_pt, seed=1, sigma_theta=2e-6, noise_
         cams_true.append(cam_utils.compose_affine_camera(K, R, T))
         cams_init.append(cam_utils.compose_affine_camera(K, ba_rotate.euler_angles_to_R(*(angles[i] + dtheta[i])), T))
     pts_ind, cam_ind = _visibility(rng, n_cam, n_pts, obs_per_pt)
-    Ps = np.stack(cams_true)
-    proj = np.einsum("kij,kj->ki", Ps[cam_ind][:, :2, :3], pts_true[pts_ind]) + Ps[cam_ind][:, :2, 3]
+    proj = _project_linear(np.stack(cams_true), 2, cam_ind, pts_true[pts_ind])
     pts2d = proj + rng.normal(0.0, noise_px, proj.shape)
     pts_init = pts_true + rng.normal(0.0, pts_noise_m, pts_true.shape)
     if pts_float32:
@@ -120,8 +132,7 @@ def make_perspective_scene(n_cam, n_pts, obs_per_pt, seed=1, sigma_theta=2e-6, n
             out.append(P / P[2, 3])
         centers.append(oC)
     pts_ind, cam_ind = _visibility(rng, n_cam, n_pts, obs_per_pt)
-    Ps = np.stack(cams_true)
-    h = np.einsum("kij,kj->ki", Ps[cam_ind][:, :, :3], pts_true[pts_ind]) + Ps[cam_ind][:, :, 3]
+    h = _project_linear(np.stack(cams_true), 3, cam_ind, pts_true[pts_ind])
     pts2d = h[:, :2] / h[:, 2:3] + rng.normal(0.0, noise_px, (h.shape[0], 2))
     pts_init = pts_true + rng.normal(0.0, pts_noise_m, pts_true.shape)
     return Scene(cam_model="perspective", n_cam=n_cam, n_pts=n_pts, cameras=cams_init, cameras_true=cams_true,
