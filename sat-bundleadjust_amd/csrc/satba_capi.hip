@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -51,6 +52,10 @@ struct satba_problem {
     unsigned char* d_tile_split = nullptr;
     int n_tiles = 0, n_split = 0;
     int *d_split_pts = nullptr, *d_split_o0 = nullptr, *d_split_o1 = nullptr;
+    int *d_cam_ofs = nullptr, *d_cam_obs = nullptr, *d_pt_ofs = nullptr;  // camera-major lists, point CSR
+    int sch_T = 0, sch_ctiles = 0, sch_chunks = 0, sch_camc_lds = 0;       // Schur panel configuration (T == 0: v1 kernel)
+    size_t sch_lds = 0;
+    double *d_S_part = nullptr, *d_rhs_part = nullptr;
     double *d_cam_static = nullptr, *d_rpc = nullptr;
     // solver state
     double *d_x = nullptr, *d_xnew = nullptr, *d_camc = nullptr, *d_camc_new = nullptr;
@@ -134,8 +139,8 @@ static int zero_header(satba_problem* p) {
 
 static int launch_residual(satba_problem* p, bool at_new, double2* f, double* hdr_slot) {
     ObsArgs a = obs_args(p, at_new);
-    const int grid = grid_for(p->K, 256, 2048);
-    SATBA_DISPATCH(p, hipLaunchKernelGGL((k_residual<MODEL, NP>), dim3(grid), dim3(256), 0, p->stream, a, f, hdr_slot));
+    const int grid = grid_for(p->K, 512, 512);
+    SATBA_DISPATCH(p, hipLaunchKernelGGL((k_residual<MODEL, NP>), dim3(grid), dim3(512), 0, p->stream, a, f, hdr_slot));
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -156,6 +161,19 @@ static int launch_schur_kernel(satba_problem* p) {
     ObsArgs a = obs_args(p, false);
     double* S = p->payload();
     double* rhs = S + (size_t)p->n_c * p->n_c;
+    if (p->sch_T > 0) {  // v2: LDS column panels, no global atomics
+        SchurArgs s;
+        s.cam_ofs = p->d_cam_ofs; s.cam_obs = p->d_cam_obs; s.pt_ofs = p->d_pt_ofs;
+        s.Vinv = p->d_Vinv; s.gp = p->d_g + p->n_c; s.S_part = p->d_S_part; s.rhs_part = p->d_rhs_part;
+        s.T = p->sch_T; s.n_ctiles = p->sch_ctiles; s.n_chunks = p->sch_chunks; s.camc_in_lds = p->sch_camc_lds;
+        SATBA_DISPATCH(p, hipLaunchKernelGGL((k_schur_panel<MODEL, NP>), dim3(p->sch_ctiles * p->sch_chunks),
+                                             dim3(SCHUR_THREADS), p->sch_lds, p->stream, a, s));
+        HIP_TRY(hipGetLastError());
+        hipLaunchKernelGGL(k_schur_reduce, dim3(grid_for((long long)p->n_c * p->n_c, 256, 2048)), dim3(256), 0, p->stream,
+                           p->n_c, p->sch_chunks, p->d_S_part, p->d_rhs_part, S, rhs);
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
     const int grid = grid_for(p->n_tiles, 4, 2048);
     SATBA_DISPATCH(p, hipLaunchKernelGGL((k_schur<MODEL, NP>), dim3(grid), dim3(256), schur_lds(p), p->stream, a, p->d_Vinv,
                                           p->d_g + p->n_c, S, rhs));
@@ -179,12 +197,12 @@ static int launch_backsub_kernel(satba_problem* p) {
 
 static int launch_jvp(satba_problem* p, int nv, const double* q1, const double* q2, double* out) {
     ObsArgs a = obs_args(p, false);
-    const int grid = grid_for(p->K, 256, 2048);
+    const int grid = grid_for(p->K, 512, 512);
     if (nv == 1) {
-        SATBA_DISPATCH(p, hipLaunchKernelGGL((k_jvp<MODEL, NP, 1>), dim3(grid), dim3(256), 0, p->stream, a, q1, q2,
+        SATBA_DISPATCH(p, hipLaunchKernelGGL((k_jvp<MODEL, NP, 1>), dim3(grid), dim3(512), 0, p->stream, a, q1, q2,
                                               p->d_scale_inv, out));
     } else {
-        SATBA_DISPATCH(p, hipLaunchKernelGGL((k_jvp<MODEL, NP, 2>), dim3(grid), dim3(256), 0, p->stream, a, q1, q2,
+        SATBA_DISPATCH(p, hipLaunchKernelGGL((k_jvp<MODEL, NP, 2>), dim3(grid), dim3(512), 0, p->stream, a, q1, q2,
                                               p->d_scale_inv, out));
     }
     HIP_TRY(hipGetLastError());
@@ -258,6 +276,16 @@ int satba_problem_create(const satba_problem_desc* d, satba_problem** out) {
         if (fill > 0) { tile_start.push_back((int)K); tile_split.push_back(0); }
     }
 
+    // camera-major observation lists and point CSR offsets (Schur panel kernel)
+    std::vector<int> cam_ofs(d->n_cam + 1, 0), cam_obs(K), pt_ofs(d->n_pts + 1, 0);
+    for (long long o = 0; o < K; ++o) { ++cam_ofs[d->cam_ind[o] + 1]; ++pt_ofs[d->pts_ind[o] + 1]; }
+    for (int c = 0; c < d->n_cam; ++c) cam_ofs[c + 1] += cam_ofs[c];
+    for (int q = 0; q < d->n_pts; ++q) pt_ofs[q + 1] += pt_ofs[q];
+    {
+        std::vector<int> fill(cam_ofs.begin(), cam_ofs.end() - 1);
+        for (long long o = 0; o < K; ++o) cam_obs[fill[d->cam_ind[o]]++] = (int)o;
+    }
+
     satba_problem* p = new (std::nothrow) satba_problem();
     if (!p) return fail(SATBA_E_ARG, "out of host memory");
     p->model = d->cam_model; p->M = d->n_cam; p->N = d->n_pts; p->NP = d->n_params; p->c_p = d->cam_param_len;
@@ -276,6 +304,33 @@ int satba_problem_create(const satba_problem_desc* d, satba_problem** out) {
             return fail(SATBA_E_ARG, "n_cam = %d exceeds the LDS-resident camera table of this build", p->M);
         SATBA_DISPATCH(p, TRY(raise_lds_limit(k_linearize<MODEL, NP>, lin_lds)));
         SATBA_DISPATCH(p, TRY(raise_lds_limit(k_schur<MODEL, NP>, schur_lds(p))));
+        {   // Schur panel configuration: T cameras per panel so that panel (+ camera table) fit the 160 KB LDS
+            const size_t budget = 160 * 1024 - 1024;  // static LDS of the kernel and alignment slack
+            const size_t col_bytes = sizeof(double) * ((size_t)p->NP * p->n_c + p->NP);  // per camera of the tile
+            const size_t camc_bytes = sizeof(double) * (size_t)p->M * CAMC;
+            int T = 0, camc_lds = 0;
+            if (camc_bytes + col_bytes <= budget) { camc_lds = 1; T = (int)((budget - camc_bytes) / col_bytes); }
+            else if (col_bytes <= budget) T = (int)(budget / col_bytes);
+            if (T > SCHUR_MAX_T) T = SCHUR_MAX_T;
+            if (T > p->M) T = p->M;
+            if (getenv("SATBA_SCHUR_V1")) T = 0;
+            p->sch_T = T;
+            if (T > 0) {
+                p->sch_camc_lds = camc_lds;
+                p->sch_ctiles = (p->M + T - 1) / T;
+                int chunks = (512 + p->sch_ctiles - 1) / p->sch_ctiles;  // ~2 workgroups' worth of work per CU
+                if (chunks > 16) chunks = 16;
+                if (chunks < 1) chunks = 1;
+                while (chunks > 1 && (size_t)chunks * p->n_c * p->n_c * sizeof(double) > ((size_t)1 << 30)) --chunks;
+                p->sch_chunks = chunks;
+                p->sch_lds = col_bytes * T + (camc_lds ? camc_bytes : 0);
+                SATBA_DISPATCH(p, TRY(raise_lds_limit(k_schur_panel<MODEL, NP>, p->sch_lds)));
+                TRY(dev_alloc(p, &p->d_S_part, (size_t)chunks * p->n_c * p->n_c));
+                TRY(dev_alloc(p, &p->d_rhs_part, (size_t)chunks * p->n_c));
+            }
+        }
+        TRY(dev_alloc(p, &p->d_cam_ofs, cam_ofs.size())); TRY(dev_alloc(p, &p->d_cam_obs, cam_obs.size()));
+        TRY(dev_alloc(p, &p->d_pt_ofs, pt_ofs.size()));
         TRY(dev_alloc(p, &p->d_obs, K)); TRY(dev_alloc(p, &p->d_w, K)); TRY(dev_alloc(p, &p->d_cam, K)); TRY(dev_alloc(p, &p->d_pt, K));
         TRY(dev_alloc(p, &p->d_f, K));
         TRY(dev_alloc(p, &p->d_tile_start, tile_start.size())); TRY(dev_alloc(p, &p->d_tile_split, tile_split.size()));
@@ -308,6 +363,9 @@ int satba_problem_create(const satba_problem_desc* d, satba_problem** out) {
         HIP_TRY(hipMemcpy(p->d_w, d->weights, sizeof(double) * K, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(p->d_cam, d->cam_ind, sizeof(int) * K, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(p->d_pt, d->pts_ind, sizeof(int) * K, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(p->d_cam_ofs, cam_ofs.data(), sizeof(int) * cam_ofs.size(), hipMemcpyHostToDevice));
+        if (K) HIP_TRY(hipMemcpy(p->d_cam_obs, cam_obs.data(), sizeof(int) * K, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(p->d_pt_ofs, pt_ofs.data(), sizeof(int) * pt_ofs.size(), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(p->d_tile_start, tile_start.data(), sizeof(int) * tile_start.size(), hipMemcpyHostToDevice));
         if (!tile_split.empty())
             HIP_TRY(hipMemcpy(p->d_tile_split, tile_split.data(), tile_split.size(), hipMemcpyHostToDevice));
@@ -417,7 +475,7 @@ int satba_linearize(satba_problem* p) {
     double* U = p->payload();
     double* gc = U + (size_t)p->M * p->NP * p->NP;
     const int total = p->M * cam_acc_len(p->NP);
-    hipLaunchKernelGGL(k_lin_finish, dim3((total + 255) / 256), dim3(256), 0, p->stream, p->M, p->NP, p->lin_grid, p->d_part, U, gc);
+    hipLaunchKernelGGL(k_lin_finish, dim3((total + 63) / 64), dim3(1024), 0, p->stream, p->M, p->NP, p->lin_grid, p->d_part, U, gc);
     HIP_TRY(hipGetLastError());
     p->linearized = true; p->have_step = false;
     return 0;
@@ -431,7 +489,7 @@ int satba_prepare(satba_problem* p, int32_t first) {
     HIP_TRY(hipMemcpyAsync(p->d_U, p->payload(), sizeof(double) * nU, hipMemcpyDeviceToDevice, p->stream));
     HIP_TRY(hipMemcpyAsync(p->d_gc, p->payload() + nU, sizeof(double) * p->n_c, hipMemcpyDeviceToDevice, p->stream));
     TRY(zero_header(p));
-    hipLaunchKernelGGL(k_prepare_vec, dim3(grid_for(p->n, 256, 1024)), dim3(256), 0, p->stream, p->n, p->n_c, p->NP, first,
+    hipLaunchKernelGGL(k_prepare_vec, dim3(grid_for(p->n, 256, 512)), dim3(256), 0, p->stream, p->n, p->n_c, p->NP, first,
                        p->lead, p->d_U, p->d_gc, p->d_V, p->d_x, p->d_g, p->d_scale_inv, p->d_gh, p->d_xb);
     HIP_TRY(hipGetLastError());
     TRY(launch_jvp(p, 1, p->d_gh, p->d_gh, p->d_xb + 2));
@@ -469,7 +527,7 @@ int satba_solve(satba_problem* p) {
     if (p->n_split > 0) HIP_TRY(hipMemsetAsync(p->d_tbuf, 0, sizeof(double) * 3 * p->N, p->stream));
     if (p->K > 0) TRY(launch_backsub_kernel(p));
     TRY(zero_header(p));
-    hipLaunchKernelGGL(k_backsub_finish, dim3(grid_for(p->n_c + p->N, 256, 1024)), dim3(256), 0, p->stream, p->n_c, p->N, p->lead,
+    hipLaunchKernelGGL(k_backsub_finish, dim3(grid_for(p->n_c + p->N, 256, 512)), dim3(256), 0, p->stream, p->n_c, p->N, p->lead,
                        p->d_dc, p->d_Vinv, p->d_g, p->d_tbuf, p->d_scale_inv, p->d_gh, p->d_gn, p->d_xb);
     HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(k_flag_to_header, dim3(1), dim3(1), 0, p->stream, p->d_fail, p->lead, p->d_xb + 4);
@@ -483,7 +541,7 @@ int satba_subspace(satba_problem* p, double alpha, double inv_norm_g) {
     if (!p->have_step) return fail(SATBA_E_STATE, "subspace before solve");
     HIP_TRY(hipSetDevice(p->device));
     TRY(zero_header(p));
-    hipLaunchKernelGGL(k_subspace_vec, dim3(grid_for(p->n, 256, 1024)), dim3(256), 0, p->stream, p->n, p->n_c, p->lead, alpha,
+    hipLaunchKernelGGL(k_subspace_vec, dim3(grid_for(p->n, 256, 512)), dim3(256), 0, p->stream, p->n, p->n_c, p->lead, alpha,
                        inv_norm_g, p->d_gh, p->d_gn, p->d_q1, p->d_wv, p->d_xb);
     HIP_TRY(hipGetLastError());
     TRY(launch_jvp(p, 2, p->d_q1, p->d_wv, p->d_xb + 3));
@@ -495,7 +553,7 @@ int satba_trial(satba_problem* p, double p0, double p1) {
     if (!p->have_step) return fail(SATBA_E_STATE, "trial before solve");
     HIP_TRY(hipSetDevice(p->device));
     TRY(zero_header(p));
-    hipLaunchKernelGGL(k_trial_vec, dim3(grid_for(p->n, 256, 1024)), dim3(256), 0, p->stream, p->n, p->n_c, p->lead, p0, p1,
+    hipLaunchKernelGGL(k_trial_vec, dim3(grid_for(p->n, 256, 512)), dim3(256), 0, p->stream, p->n, p->n_c, p->lead, p0, p1,
                        p->d_x, p->d_q1, p->d_wv, p->d_scale_inv, p->d_xnew, p->d_xb);
     HIP_TRY(hipGetLastError());
     TRY(launch_cam_consts(p, true));

@@ -50,11 +50,15 @@ struct ObsEval {
     double Jp[2][3];
 
     __device__ inline void eval(const ObsArgs& a, long long o, int cam, int pt) {
+        eval(a, o, cam, pt, a.camc + (size_t)cam * CAMC);
+    }
+
+    // cc: the camera's constant record (global memory, or a copy staged in LDS)
+    __device__ inline void eval(const ObsArgs& a, long long o, int cam, int pt, const double* cc) {
         const double2 ob = a.obs[o];
         const double w = a.w[o];
         const double* px = a.x + a.n_c + 3 * (size_t)pt;
         const double X = px[0], Y = px[1], Z = px[2];
-        const double* cc = a.camc + (size_t)cam * CAMC;
         const double* tab = (MODEL == RPC) ? a.rpc + (size_t)cam * 90 : nullptr;
         double u, v;
         project<MODEL, NP, JAC>(cc, tab, X, Y, Z, a.f32 != 0, u, v, Jc, Jp);
@@ -102,6 +106,25 @@ __device__ inline void seg_reduce(double (&v)[NV], int pt, int lane) {
     }
 }
 
+// Sum NV per-thread values over the workgroup and add each total to *dst[k] with ONE atomic per workgroup
+// (same-address atomics serialise at ~12 ns each on gfx950: one per wave was costing 150-300 us per kernel).
+template <int NV>
+__device__ inline void block_sum_atomic(double (&v)[NV], double* const (&dst)[NV]) {
+    __shared__ double s_part[NV][16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const double t = wave_sum(v[k]);
+        if (lane == 0) s_part[k][wave] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x < NV) {
+        double t = 0.0;
+        for (int w = 0; w < nw; ++w) t += s_part[threadIdx.x][w];
+        atomicAdd(dst[threadIdx.x], t);
+    }
+}
+
 __device__ inline void atomic_max_pos(double* addr, double v) {  // v >= 0
     atomicMax(reinterpret_cast<unsigned long long*>(addr), (unsigned long long)__double_as_longlong(v));
 }
@@ -121,7 +144,7 @@ __global__ void k_cam_consts(int model, int M, int n_p, int c_p, const double* _
 // ba_core.fun (ref:bundle_adjust/ba_core.py:157-183): one thread per observation, grid-stride.
 // hdr_cost += 0.5 * sum rho.  f may be null (cost only).
 template <int MODEL, int NP>
-__global__ __launch_bounds__(256) void k_residual(ObsArgs a, double2* __restrict__ f, double* __restrict__ hdr_cost) {
+__global__ __launch_bounds__(512) void k_residual(ObsArgs a, double2* __restrict__ f, double* __restrict__ hdr_cost) {
     double acc = 0.0;
     for (long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x; o < a.K; o += (long long)gridDim.x * blockDim.x) {
         ObsEval<MODEL, NP, false> e;
@@ -129,12 +152,9 @@ __global__ __launch_bounds__(256) void k_residual(ObsArgs a, double2* __restrict
         if (f) f[o] = make_double2(e.ftrue[0], e.ftrue[1]);
         acc += e.rho;
     }
-    acc = wave_sum(acc);
-    __shared__ double s[4];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (lane == 0) s[wave] = acc;
-    __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(hdr_cost, 0.5 * (s[0] + s[1] + s[2] + s[3]));
+    double v[1] = {0.5 * acc};
+    double* const dst[1] = {hdr_cost};
+    block_sum_atomic<1>(v, dst);
 }
 
 // ------------------------------------------------------------------------------------------------ K2 linearize
@@ -223,14 +243,23 @@ __global__ __launch_bounds__(TILE_THREADS) void k_linearize(ObsArgs a, double2* 
     for (int i = threadIdx.x; i < a.M * CU; i += TILE_THREADS) out[i] = s_acc[i];
 }
 
-// sum the per-workgroup camera partials and expand to the exchange payload: U (M x NP x NP, full), g_c (M x NP)
-__global__ void k_lin_finish(int M, int NP, int nblocks, const double* __restrict__ part, double* __restrict__ U,
-                             double* __restrict__ gc) {
+// sum the per-workgroup camera partials and expand to the exchange payload: U (M x NP x NP, full), g_c (M x NP).
+// 64 outputs per workgroup, 16 waves each summing a strided subset of the workgroups, combined through LDS.
+__global__ __launch_bounds__(1024) void k_lin_finish(int M, int NP, int nblocks, const double* __restrict__ part,
+                                                     double* __restrict__ U, double* __restrict__ gc) {
     const int CU = cam_acc_len(NP);
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= M * CU) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int idx = blockIdx.x * 64 + lane;
+    __shared__ double s_sum[16][64];
     double s = 0.0;
-    for (int b = 0; b < nblocks; ++b) s += part[(size_t)b * M * CU + idx];
+    if (idx < M * CU)
+        for (int b = wave; b < nblocks; b += 16) s += part[(size_t)b * M * CU + idx];
+    s_sum[wave][lane] = s;
+    __syncthreads();
+    if (wave != 0 || idx >= M * CU) return;
+    s = 0.0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) s += s_sum[w][lane];
     const int cam = idx / CU, k = idx % CU;
     const int ntri = NP * (NP + 1) / 2;
     if (k >= ntri) {
@@ -287,21 +316,18 @@ __global__ __launch_bounds__(256) void k_prepare_vec(int n, int n_c, int NP, int
         const double xs = x[i] * si;
         s_xs += wgt * xs * xs;
     }
-    s_gh = wave_sum(s_gh);
-    s_xs = wave_sum(s_xs);
+    double v[2] = {s_gh, s_xs};
+    double* const dst[2] = {hdr + 1, hdr + 3};
+    block_sum_atomic<2>(v, dst);
     m_gc = wave_max(m_gc);
-    if ((threadIdx.x & 63) == 0) {
-        atomicAdd(hdr + 1, s_gh);
-        atomicAdd(hdr + 3, s_xs);
-        atomic_max_pos(hdr + 4, lead * m_gc);
-    }
+    if ((threadIdx.x & 63) == 0 && m_gc > 0.0) atomic_max_pos(hdr + 4, lead * m_gc);
 }
 
 // ------------------------------------------------------------------------------------------------ Jacobian-vector products
 // For NV vectors given in scaled variables (v = q / scale_inv): sums of (J v_a) . (J v_b) over the observations.
 // NV = 1: out[0] += |J v1|^2.   NV = 2: out[0] += |J v1|^2, out[1] += (J v1).(J v2), out[2] += |J v2|^2.
 template <int MODEL, int NP, int NV>
-__global__ __launch_bounds__(256) void k_jvp(ObsArgs a, const double* __restrict__ q1, const double* __restrict__ q2,
+__global__ __launch_bounds__(512) void k_jvp(ObsArgs a, const double* __restrict__ q1, const double* __restrict__ q2,
                                              const double* __restrict__ scale_inv, double* __restrict__ out) {
     double s11 = 0.0, s12 = 0.0, s22 = 0.0;
     for (long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x; o < a.K; o += (long long)gridDim.x * blockDim.x) {
@@ -330,11 +356,14 @@ __global__ __launch_bounds__(256) void k_jvp(ObsArgs a, const double* __restrict
             s22 += j2[0] * j2[0] + j2[1] * j2[1];
         }
     }
-    s11 = wave_sum(s11);
-    if (NV == 2) { s12 = wave_sum(s12); s22 = wave_sum(s22); }
-    if ((threadIdx.x & 63) == 0) {
-        atomicAdd(out, s11);
-        if (NV == 2) { atomicAdd(out + 1, s12); atomicAdd(out + 2, s22); }
+    if (NV == 2) {
+        double v[3] = {s11, s12, s22};
+        double* const dst[3] = {out, out + 1, out + 2};
+        block_sum_atomic<3>(v, dst);
+    } else {
+        double v[1] = {s11};
+        double* const dst[1] = {out};
+        block_sum_atomic<1>(v, dst);
     }
 }
 
@@ -505,6 +534,138 @@ __global__ __launch_bounds__(64) void k_schur_split(ObsArgs a, int n_split, cons
     }
 }
 
+
+// ---- Schur complement v2: camera-tile column panels of S privatised in LDS, no global atomics ----------------
+// A workgroup owns the columns of S that belong to T consecutive cameras (NP * T columns x n_c rows of the
+// column-major lower triangle = up to ~120 KB of LDS) and a chunk of the observation stream.  It walks the
+// camera-major observation lists of its cameras inside the chunk; for an observation (i, p) it visits the
+// observations (j, p), j >= i, of the same point (they follow it in the point-major stream), re-evaluates their
+// Jacobian blocks and accumulates   -Jc_i^T (Jp_i Vinv_p Jp_j^T) Jc_j   into the panel with LDS atomics
+// (ds_add_f64).  The panel is then stored, coalesced, into this chunk's private copy of S; k_schur_reduce sums
+// the copies.  Points with any number of observations are handled uniformly (no wave tiles involved).
+struct SchurArgs {
+    const int* __restrict__ cam_ofs;   // M + 1: camera-major lists
+    const int* __restrict__ cam_obs;   // K observation ids, ascending inside a camera
+    const int* __restrict__ pt_ofs;    // N + 1: observations of point p are [pt_ofs[p], pt_ofs[p+1])
+    const double* __restrict__ Vinv;   // N x 6
+    const double* __restrict__ gp;     // N x 3
+    double* __restrict__ S_part;       // n_chunks x n_c x n_c
+    double* __restrict__ rhs_part;     // n_chunks x n_c
+    int T, n_ctiles, n_chunks, camc_in_lds;
+};
+
+constexpr int SCHUR_THREADS = 1024;
+constexpr int SCHUR_MAX_T = 16;
+
+template <int MODEL, int NP>
+__global__ __launch_bounds__(SCHUR_THREADS) void k_schur_panel(ObsArgs a, SchurArgs s) {
+    extern __shared__ double s_lds[];
+    const int n_c = a.n_c;
+    const int tile = blockIdx.x % s.n_ctiles, chunk = blockIdx.x / s.n_ctiles;
+    const int i0 = tile * s.T, nt = min(s.T, a.M - i0);
+    double* panel = s_lds;                               // [nt * NP][n_c]
+    double* s_rhs = panel + (size_t)s.T * NP * n_c;      // [T * NP]
+    double* s_camc = s_rhs + s.T * NP;                   // [M][CAMC] if camc_in_lds
+    __shared__ int s_lo[SCHUR_MAX_T], s_cnt[SCHUR_MAX_T + 1];
+
+    for (int i = threadIdx.x; i < s.T * NP * n_c + s.T * NP; i += SCHUR_THREADS) panel[i] = 0.0;
+    if (s.camc_in_lds)
+        for (int i = threadIdx.x; i < a.M * CAMC; i += SCHUR_THREADS) s_camc[i] = a.camc[i];
+    const long long obs_lo = a.K * chunk / s.n_chunks, obs_hi = a.K * (chunk + 1) / s.n_chunks;
+    if (threadIdx.x < nt) {  // sub-range of camera i0 + t's list that falls into this chunk (binary searches)
+        const int b = s.cam_ofs[i0 + threadIdx.x], e = s.cam_ofs[i0 + threadIdx.x + 1];
+        int lo = b, hi = e;
+        while (lo < hi) { const int m = (lo + hi) >> 1; if (s.cam_obs[m] < obs_lo) lo = m + 1; else hi = m; }
+        const int first = lo;
+        hi = e;
+        while (lo < hi) { const int m = (lo + hi) >> 1; if (s.cam_obs[m] < obs_hi) lo = m + 1; else hi = m; }
+        s_lo[threadIdx.x] = first;
+        s_cnt[threadIdx.x + 1] = lo - first;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        s_cnt[0] = 0;
+        for (int t = 0; t < nt; ++t) s_cnt[t + 1] += s_cnt[t];
+    }
+    __syncthreads();
+    const int total = s_cnt[nt];
+    const double* cbase = s.camc_in_lds ? s_camc : a.camc;
+
+    for (int idx = threadIdx.x; idx < total; idx += SCHUR_THREADS) {
+        int t = 0;
+        while (idx >= s_cnt[t + 1]) ++t;
+        const int o = s.cam_obs[s_lo[t] + idx - s_cnt[t]];
+        const int cam_i = i0 + t;
+        const int p = a.pt[o];
+        ObsEval<MODEL, NP, true> ei;
+        ei.eval(a, o, cam_i, p, cbase + (size_t)cam_i * CAMC);
+        const double* vi = s.Vinv + 6 * (size_t)p;
+        const double v00 = vi[0], v01 = vi[1], v02 = vi[2], v11 = vi[3], v12 = vi[4], v22 = vi[5];
+        double A[2][3];  // Jp_i Vinv
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            A[r][0] = ei.Jp[r][0] * v00 + ei.Jp[r][1] * v01 + ei.Jp[r][2] * v02;
+            A[r][1] = ei.Jp[r][0] * v01 + ei.Jp[r][1] * v11 + ei.Jp[r][2] * v12;
+            A[r][2] = ei.Jp[r][0] * v02 + ei.Jp[r][1] * v12 + ei.Jp[r][2] * v22;
+        }
+        {
+            const double* g = s.gp + 3 * (size_t)p;
+            const double ag0 = A[0][0] * g[0] + A[0][1] * g[1] + A[0][2] * g[2];
+            const double ag1 = A[1][0] * g[0] + A[1][1] * g[1] + A[1][2] * g[2];
+#pragma unroll
+            for (int r = 0; r < NP; ++r) atomicAdd(s_rhs + t * NP + r, -(ei.Jc[0][r] * ag0 + ei.Jc[1][r] * ag1));
+        }
+        const int o_end = s.pt_ofs[p + 1];
+        double* prow = panel + (size_t)(t * NP) * n_c;
+        for (int o2 = o; o2 < o_end; ++o2) {
+            ObsEval<MODEL, NP, true> ej;
+            int cam_j = cam_i;
+            if (o2 == o) {
+                ej = ei;
+            } else {
+                cam_j = a.cam[o2];
+                ej.eval(a, o2, cam_j, p, cbase + (size_t)cam_j * CAMC);
+            }
+            // Mm = A Jp_j^T (2 x 2), Y = Mm Jc_j (2 x NP)
+            const double m00 = A[0][0] * ej.Jp[0][0] + A[0][1] * ej.Jp[0][1] + A[0][2] * ej.Jp[0][2];
+            const double m01 = A[0][0] * ej.Jp[1][0] + A[0][1] * ej.Jp[1][1] + A[0][2] * ej.Jp[1][2];
+            const double m10 = A[1][0] * ej.Jp[0][0] + A[1][1] * ej.Jp[0][1] + A[1][2] * ej.Jp[0][2];
+            const double m11 = A[1][0] * ej.Jp[1][0] + A[1][1] * ej.Jp[1][1] + A[1][2] * ej.Jp[1][2];
+            double* dst = prow + cam_j * NP;
+#pragma unroll
+            for (int c = 0; c < NP; ++c) {
+                const double y0 = m00 * ej.Jc[0][c] + m01 * ej.Jc[1][c];
+                const double y1 = m10 * ej.Jc[0][c] + m11 * ej.Jc[1][c];
+#pragma unroll
+                for (int r = 0; r < NP; ++r) atomicAdd(dst + (size_t)r * n_c + c, -(ei.Jc[0][r] * y0 + ei.Jc[1][r] * y1));
+            }
+        }
+    }
+    __syncthreads();
+    double* out = s.S_part + (size_t)chunk * n_c * n_c + (size_t)(i0 * NP) * n_c;
+    for (int i = threadIdx.x; i < nt * NP * n_c; i += SCHUR_THREADS) out[i] = panel[i];
+    for (int i = threadIdx.x; i < nt * NP; i += SCHUR_THREADS) s.rhs_part[(size_t)chunk * n_c + i0 * NP + i] = s_rhs[i];
+}
+
+// S += sum over chunks of S_part, rhs += sum of rhs_part
+__global__ __launch_bounds__(256) void k_schur_reduce(int n_c, int n_chunks, const double* __restrict__ S_part,
+                                                      const double* __restrict__ rhs_part, double* __restrict__ S,
+                                                      double* __restrict__ rhs) {
+    const size_t nn = (size_t)n_c * n_c;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nn + n_c; i += (size_t)gridDim.x * blockDim.x) {
+        if (i < nn) {
+            double t = 0.0;
+            for (int c = 0; c < n_chunks; ++c) t += S_part[(size_t)c * nn + i];
+            S[i] += t;
+        } else {
+            const size_t k = i - nn;
+            double t = 0.0;
+            for (int c = 0; c < n_chunks; ++c) t += rhs_part[(size_t)c * n_c + k];
+            rhs[k] += t;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ K5 back-substitution
 // t_p = sum_obs Jp^T (Jc dc[cam])  per point (segmented wave reduction)
 template <int MODEL, int NP>
@@ -572,8 +733,9 @@ __global__ __launch_bounds__(256) void k_backsub_finish(int n_c, int N, double l
             }
         }
     }
-    sa = wave_sum(sa); sb = wave_sum(sb); sc = wave_sum(sc);
-    if ((threadIdx.x & 63) == 0) { atomicAdd(hdr + 1, sa); atomicAdd(hdr + 2, sb); atomicAdd(hdr + 3, sc); }
+    double v[3] = {sa, sb, sc};
+    double* const dst[3] = {hdr + 1, hdr + 2, hdr + 3};
+    block_sum_atomic<3>(v, dst);
 }
 
 // ------------------------------------------------------------------------------------------------ subspace / trial vectors
@@ -590,8 +752,9 @@ __global__ __launch_bounds__(256) void k_subspace_vec(int n, int n_c, double lea
         const double wgt = (i < n_c) ? lead : 1.0;
         ww += wgt * w * w; wq += wgt * w * q; gw += wgt * h * w;
     }
-    ww = wave_sum(ww); wq = wave_sum(wq); gw = wave_sum(gw);
-    if ((threadIdx.x & 63) == 0) { atomicAdd(hdr + 1, ww); atomicAdd(hdr + 2, wq); atomicAdd(hdr + 6, gw); }
+    double v[3] = {ww, wq, gw};
+    double* const dst[3] = {hdr + 1, hdr + 2, hdr + 6};
+    block_sum_atomic<3>(v, dst);
 }
 
 // x_new = x + (p0 q1 + p1 w) / scale_inv;  hdr[2] += |step|^2, hdr[3] += |x|^2
@@ -607,8 +770,9 @@ __global__ __launch_bounds__(256) void k_trial_vec(int n, int n_c, double lead, 
         const double wgt = (i < n_c) ? lead : 1.0;
         ss += wgt * step * step; xx += wgt * xi * xi;
     }
-    ss = wave_sum(ss); xx = wave_sum(xx);
-    if ((threadIdx.x & 63) == 0) { atomicAdd(hdr + 2, ss); atomicAdd(hdr + 3, xx); }
+    double v[2] = {ss, xx};
+    double* const dst[2] = {hdr + 2, hdr + 3};
+    block_sum_atomic<2>(v, dst);
 }
 
 // ------------------------------------------------------------------------------------------------ inspection
