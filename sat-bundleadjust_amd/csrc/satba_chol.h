@@ -1,31 +1,44 @@
 // satba_chol.h -- dense SPD solve of the reduced camera system S dc = rhs on one GPU.
 //
-// S is (M n_p)^2 <= ~1200^2 float64, column-major, lower triangle valid (the Schur kernel only writes camera-block
-// pairs (a, b) with a <= b, which land in the column-major lower triangle).  This replaces the LSMR iteration of
-// scipy:optimize/_lsq/trf.py:479-480 by an exact factorisation.  Blocked right-looking Cholesky:
-//   per 32-column panel: k_potrf_trsm (diagonal block factorised in LDS by every workgroup, panel rows solved
-//   64 per workgroup) then k_syrk (64x64 tiles of the trailing matrix, 4x4 per thread, panel staged in LDS);
-//   then a single-workgroup blocked forward / backward substitution.
-// The matrix is too small for MFMA to matter (fp64 MFMA runs at the vector rate on gfx950) and the whole solve
-// is launch/latency bound; see DESIGN.md.
+// S is (M n_p)^2 <= ~1200^2 float64, column-major, lower triangle valid (the Schur kernels only produce camera
+// block pairs (a, b) with a <= b, which land in the column-major lower triangle).  This replaces the LSMR
+// iteration of scipy:optimize/_lsq/trf.py:479-480 by an exact factorisation.
+//
+// Blocked right-looking Cholesky, 32-column panels, two launches per panel:
+//   k_potrf_trsm  every workgroup factorises the 32x32 diagonal block in LDS (redundantly -- cheaper than a
+//                 separate launch), workgroup 0 writes it back together with its explicit inverse and advances
+//                 the forward substitution of the right-hand side, the others solve 256 panel rows each;
+//   k_syrk        64x64 tiles of the trailing matrix, 4x4 per thread, panel staged in LDS, rows mapped to the
+//                 fast thread index so the read-modify-write of A is coalesced; tiles of the first tile column
+//                 also apply the panel to the right-hand side (forward substitution is thereby folded into the
+//                 factorisation: no separate L y = b pass);
+// then k_trsv_back: one workgroup, right-looking backward substitution that uses the stored inverses of the
+// diagonal blocks (a 32x32 mat-vec instead of a 32-step dependent chain).
+// fp64 MFMA runs at the vector rate on gfx950 and the matrix is tiny: the solve is launch / latency bound
+// (64 dependent launches), not flop bound; see DESIGN.md.
 #pragma once
 #include <hip/hip_runtime.h>
 
 namespace satba {
 
 constexpr int CH_NB = 32;
+constexpr int CH_ROWS = 256;  // panel rows per workgroup in k_potrf_trsm
 
-__global__ __launch_bounds__(64) void k_potrf_trsm(double* __restrict__ A, int n, int k0, int* __restrict__ fail) {
+// dinv: (n / 32 + 1) blocks of 32 x 32 (row-major) receiving inv(L_kk)
+__global__ __launch_bounds__(CH_ROWS) void k_potrf_trsm(double* __restrict__ A, int n, int k0, int* __restrict__ fail,
+                                                        double* __restrict__ b, double* __restrict__ dinv) {
     __shared__ double D[CH_NB][CH_NB + 1];
+    __shared__ double Di[CH_NB][CH_NB + 1];
     const int tid = threadIdx.x;
     const int nb = min(CH_NB, n - k0);
-    for (int idx = tid; idx < nb * nb; idx += 64) {
-        const int r = idx % nb, c = idx / nb;
-        D[r][c] = (r >= c) ? A[(size_t)(k0 + r) + (size_t)(k0 + c) * n] : 0.0;
+    for (int idx = tid; idx < CH_NB * CH_NB; idx += CH_ROWS) {
+        const int r = idx % CH_NB, c = idx / CH_NB;
+        D[r][c] = (r < nb && c < nb && r >= c) ? A[(size_t)(k0 + r) + (size_t)(k0 + c) * n] : ((r == c) ? 1.0 : 0.0);
     }
     __syncthreads();
+    // unblocked Cholesky of the 32 x 32 block, all threads on the rank-1 updates
     for (int j = 0; j < nb; ++j) {
-        if (tid == j) {
+        if (tid == 0) {
             double d = D[j][j];
             if (!(d > 0.0)) {  // not positive definite (or NaN): flag it, keep going with a harmless pivot
                 if (blockIdx.x == 0) atomicOr(fail, 1);
@@ -36,20 +49,38 @@ __global__ __launch_bounds__(64) void k_potrf_trsm(double* __restrict__ A, int n
         __syncthreads();
         if (tid > j && tid < nb) D[tid][j] /= D[j][j];
         __syncthreads();
-        if (tid > j && tid < nb) {
-            const double l = D[tid][j];
-            for (int c = j + 1; c <= tid; ++c) D[tid][c] -= l * D[c][j];
+        for (int idx = tid; idx < CH_NB * CH_NB; idx += CH_ROWS) {
+            const int r = idx % CH_NB, c = idx / CH_NB;
+            if (c > j && r >= c && r < nb) D[r][c] -= D[r][j] * D[c][j];
         }
         __syncthreads();
     }
     if (blockIdx.x == 0) {
-        for (int idx = tid; idx < nb * nb; idx += 64) {
+        for (int idx = tid; idx < nb * nb; idx += CH_ROWS) {
             const int r = idx % nb, c = idx / nb;
             if (r >= c) A[(size_t)(k0 + r) + (size_t)(k0 + c) * n] = D[r][c];
         }
+        // inverse of the lower-triangular block: thread c solves L x = e_c
+        if (tid < CH_NB) {
+            const int c = tid;
+            for (int r = 0; r < CH_NB; ++r) {
+                double s = (r == c) ? 1.0 : 0.0;
+                for (int m = c; m < r; ++m) s -= D[r][m] * Di[m][c];
+                Di[r][c] = (r >= c) ? s / D[r][r] : 0.0;
+            }
+        }
+        __syncthreads();
+        double* out = dinv + (size_t)(k0 / CH_NB) * CH_NB * CH_NB;
+        for (int idx = tid; idx < CH_NB * CH_NB; idx += CH_ROWS) out[idx] = Di[idx / CH_NB][idx % CH_NB];
+        // forward substitution of this block of the right-hand side: y_k = inv(L_kk) b_k
+        double s = 0.0;
+        if (tid < nb)
+            for (int m = 0; m <= tid; ++m) s += Di[tid][m] * b[k0 + m];
+        __syncthreads();
+        if (tid < nb) b[k0 + tid] = s;
         return;
     }
-    const int r = k0 + nb + (blockIdx.x - 1) * 64 + tid;
+    const int r = k0 + nb + (blockIdx.x - 1) * CH_ROWS + tid;
     if (r >= n) return;
     double x[CH_NB];
 #pragma unroll
@@ -68,8 +99,9 @@ __global__ __launch_bounds__(64) void k_potrf_trsm(double* __restrict__ A, int n
         if (c < nb) A[(size_t)r + (size_t)(k0 + c) * n] = x[c];
 }
 
-// trailing update A[base:, base:] -= P P^T (lower tiles only), P = A[base:, k0:k0+nb], base = k0 + nb
-__global__ __launch_bounds__(256) void k_syrk(double* __restrict__ A, int n, int k0, int nb) {
+// trailing update A[base:, base:] -= P P^T (lower tiles only), P = A[base:, k0:k0+nb], base = k0 + nb;
+// the first tile column also applies  b[base:] -= P y_k  with y_k = b[k0:k0+nb] (already final).
+__global__ __launch_bounds__(256) void k_syrk(double* __restrict__ A, int n, int k0, int nb, double* __restrict__ b) {
     const int bi = blockIdx.y, bj = blockIdx.x;
     if (bj > bi) return;
     __shared__ double Pi[CH_NB][64], Pj[CH_NB][64];
@@ -82,97 +114,76 @@ __global__ __launch_bounds__(256) void k_syrk(double* __restrict__ A, int n, int
         Pj[k][r] = (c0 + r < n) ? A[(size_t)(c0 + r) + (size_t)(k0 + k) * n] : 0.0;
     }
     __syncthreads();
+    if (bj == 0 && tid < 64 && r0 + tid < n) {
+        double s = 0.0;
+        for (int k = 0; k < nb; ++k) s += Pi[k][tid] * b[k0 + k];
+        b[r0 + tid] -= s;
+    }
     double acc[4][4] = {};
-    const int ty = threadIdx.y * 4, tx = threadIdx.x * 4;
+    const int tr = threadIdx.x * 4, tc = threadIdx.y * 4;  // rows on the fast index: coalesced A accesses
     for (int k = 0; k < nb; ++k) {
-        double a[4], b[4];
+        double a[4], c[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { a[i] = Pi[k][ty + i]; b[i] = Pj[k][tx + i]; }
+        for (int i = 0; i < 4; ++i) { a[i] = Pi[k][tr + i]; c[i] = Pj[k][tc + i]; }
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] += a[i] * b[j];
+            for (int i = 0; i < 4; ++i) acc[j][i] += a[i] * c[j];
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int r = r0 + ty + i, c = c0 + tx + j;
-            if (r < n && c < n && r >= c) A[(size_t)r + (size_t)c * n] -= acc[i][j];
+            const int r = r0 + tr + i, c = c0 + tc + j;
+            if (r < n && c < n && r >= c) A[(size_t)r + (size_t)c * n] -= acc[j][i];
         }
 }
 
-// L y = b, then L^T z = y, in place in b (length n).  One workgroup of 256 threads.
-__global__ __launch_bounds__(256) void k_trsv2(const double* __restrict__ L, int n, double* __restrict__ b) {
-    __shared__ double D[CH_NB][CH_NB + 1];
-    __shared__ double y[CH_NB];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // ---- forward
-    for (int k0 = 0; k0 < n; k0 += CH_NB) {
-        const int nb = min(CH_NB, n - k0);
-        for (int idx = tid; idx < nb * nb; idx += 256) {
-            const int r = idx % nb, c = idx / nb;
-            D[r][c] = L[(size_t)(k0 + r) + (size_t)(k0 + c) * n];
-        }
-        __syncthreads();
-        if (wave == 0) {
-            double v = (lane < nb) ? b[k0 + lane] : 0.0;
-            for (int j = 0; j < nb; ++j) {
-                const double yj = __shfl(v, j) / D[j][j];
-                if (lane == j) v = yj;
-                else if (lane > j && lane < nb) v -= D[lane][j] * yj;
-            }
-            if (lane < nb) { y[lane] = v; b[k0 + lane] = v; }
-        }
-        __syncthreads();
-        for (int r = k0 + nb + tid; r < n; r += 256) {
-            double s = 0.0;
-            for (int c = 0; c < nb; ++c) s += L[(size_t)r + (size_t)(k0 + c) * n] * y[c];
-            b[r] -= s;
-        }
-        __syncthreads();
-    }
-    // ---- backward: z[k] = (y[k] - sum_{r>k} L[r][k] z[r]) / L[k][k]
+// L^T z = y in place in b (b holds y on entry), right-looking: z_k = inv(L_kk)^T y_k, then every earlier entry
+// gets its contribution y_j -= L[k-block, j]^T z_k.  One workgroup of 1024 threads.
+__global__ __launch_bounds__(1024) void k_trsv_back(const double* __restrict__ L, int n, const double* __restrict__ dinv,
+                                                    double* __restrict__ b) {
+    __shared__ double z[CH_NB];
+    const int tid = threadIdx.x;
     const int nblk = (n + CH_NB - 1) / CH_NB;
     for (int kb = nblk - 1; kb >= 0; --kb) {
         const int k0 = kb * CH_NB;
         const int nb = min(CH_NB, n - k0);
-        // contributions of the already solved tail, one column per wave at a time
-        for (int c = wave; c < nb; c += 4) {
+        if (tid < CH_NB) {
             double s = 0.0;
-            const double* col = L + (size_t)(k0 + c) * n;
-            for (int r = k0 + nb + lane; r < n; r += 64) s += col[r] * b[r];
-            for (int d = 32; d > 0; d >>= 1) s += __shfl_down(s, d);
-            if (lane == 0) y[c] = b[k0 + c] - s;
-        }
-        for (int idx = tid; idx < nb * nb; idx += 256) {
-            const int r = idx % nb, c = idx / nb;
-            D[r][c] = L[(size_t)(k0 + r) + (size_t)(k0 + c) * n];
+            if (tid < nb) {
+                const double* Di = dinv + (size_t)kb * CH_NB * CH_NB;  // row-major inv(L_kk); need its transpose
+                for (int m = tid; m < nb; ++m) s += Di[m * CH_NB + tid] * b[k0 + m];
+            }
+            z[tid] = s;
         }
         __syncthreads();
-        if (wave == 0) {
-            double v = (lane < nb) ? y[lane] : 0.0;
-            for (int j = nb - 1; j >= 0; --j) {
-                const double zj = __shfl(v, j) / D[j][j];
-                if (lane == j) v = zj;
-                else if (lane < j) v -= D[j][lane] * zj;
-            }
-            if (lane < nb) b[k0 + lane] = v;
+        if (tid < nb) b[k0 + tid] = z[tid];
+        for (int j = tid; j < k0; j += 1024) {
+            const double* col = L + (size_t)j * n + k0;  // rows k0 .. k0+nb of column j: contiguous
+            double s = 0.0;
+            for (int r = 0; r < nb; ++r) s += col[r] * z[r];
+            b[j] -= s;
         }
         __syncthreads();
     }
 }
 
+inline size_t cholesky_workspace_doubles(int n) { return (size_t)(n / CH_NB + 1) * CH_NB * CH_NB; }
+
 // Factorise A (n x n, column-major lower, in place) and solve A z = b in place.  *fail != 0 if A was not SPD.
-inline void cholesky_solve(double* A, int n, double* b, int* fail, hipStream_t stream) {
+// dinv: workspace of cholesky_workspace_doubles(n) doubles.
+inline void cholesky_solve(double* A, int n, double* b, int* fail, double* dinv, hipStream_t stream) {
     for (int k0 = 0; k0 < n; k0 += CH_NB) {
         const int nb = n - k0 < CH_NB ? n - k0 : CH_NB;
         const int rest = n - k0 - nb;
-        const int row_blocks = (rest + 63) / 64;
-        hipLaunchKernelGGL(k_potrf_trsm, dim3(1 + row_blocks), dim3(64), 0, stream, A, n, k0, fail);
-        if (rest > 0) hipLaunchKernelGGL(k_syrk, dim3(row_blocks, row_blocks), dim3(16, 16), 0, stream, A, n, k0, nb);
+        hipLaunchKernelGGL(k_potrf_trsm, dim3(1 + (rest + CH_ROWS - 1) / CH_ROWS), dim3(CH_ROWS), 0, stream, A, n, k0, fail, b, dinv);
+        if (rest > 0) {
+            const int tiles = (rest + 63) / 64;
+            hipLaunchKernelGGL(k_syrk, dim3(tiles, tiles), dim3(16, 16), 0, stream, A, n, k0, nb, b);
+        }
     }
-    hipLaunchKernelGGL(k_trsv2, dim3(1), dim3(256), 0, stream, A, n, b);
+    hipLaunchKernelGGL(k_trsv_back, dim3(1), dim3(1024), 0, stream, A, n, dinv, b);
 }
 
 }  // namespace satba
