@@ -57,6 +57,7 @@ struct satba_problem {
     size_t sch_lds = 0;
     double *d_S_part = nullptr, *d_rhs_part = nullptr;
     double* d_dinv = nullptr;  // inverses of the Cholesky diagonal blocks
+    double* d_dch = nullptr;   // camera step in scaled variables
     double *d_cam_static = nullptr, *d_rpc = nullptr;
     // solver state
     double *d_x = nullptr, *d_xnew = nullptr, *d_camc = nullptr, *d_camc_new = nullptr;
@@ -348,6 +349,7 @@ int satba_problem_create(const satba_problem_desc* d, satba_problem** out) {
         TRY(dev_alloc(p, &p->d_V, (size_t)6 * p->N)); TRY(dev_alloc(p, &p->d_Vinv, (size_t)6 * p->N));
         TRY(dev_alloc(p, &p->d_tbuf, (size_t)3 * p->N)); TRY(dev_alloc(p, &p->d_dc, p->n_c));
         TRY(dev_alloc(p, &p->d_fail, 1));
+        TRY(dev_alloc(p, &p->d_dch, p->n_c));
         TRY(dev_alloc(p, &p->d_dinv, cholesky_workspace_doubles(p->n_c)));
         TRY(dev_alloc(p, &p->d_scal, 8));
         p->lin_grid = grid_for(p->n_tiles, TILE_WAVES, MAX_TILE_GRID);
@@ -523,14 +525,19 @@ int satba_solve(satba_problem* p) {
     double* S = p->payload();
     double* rhs = S + (size_t)p->n_c * p->n_c;
     HIP_TRY(hipMemsetAsync(p->d_fail, 0, sizeof(int), p->stream));
-    HIP_TRY(hipMemcpyAsync(p->d_dc, rhs, sizeof(double) * p->n_c, hipMemcpyDeviceToDevice, p->stream));
-    cholesky_solve(S, p->n_c, p->d_dc, p->d_fail, p->d_dinv, p->stream);
+    hipLaunchKernelGGL(k_scale_system, dim3(grid_for((long long)p->n_c * p->n_c, 256, 2048)), dim3(256), 0, p->stream, p->n_c,
+                       p->d_scale_inv, S, rhs);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(p->d_dch, rhs, sizeof(double) * p->n_c, hipMemcpyDeviceToDevice, p->stream));
+    cholesky_solve(S, p->n_c, p->d_dch, p->d_fail, p->d_dinv, p->stream);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(k_unscale, dim3((p->n_c + 255) / 256), dim3(256), 0, p->stream, p->n_c, p->d_scale_inv, p->d_dch, p->d_dc);
     HIP_TRY(hipGetLastError());
     if (p->n_split > 0) HIP_TRY(hipMemsetAsync(p->d_tbuf, 0, sizeof(double) * 3 * p->N, p->stream));
     if (p->K > 0) TRY(launch_backsub_kernel(p));
     TRY(zero_header(p));
     hipLaunchKernelGGL(k_backsub_finish, dim3(grid_for(p->n_c + p->N, 256, 512)), dim3(256), 0, p->stream, p->n_c, p->N, p->lead,
-                       p->d_dc, p->d_Vinv, p->d_g, p->d_tbuf, p->d_scale_inv, p->d_gh, p->d_gn, p->d_xb);
+                       p->d_dch, p->d_Vinv, p->d_g, p->d_tbuf, p->d_scale_inv, p->d_gh, p->d_gn, p->d_xb);
     HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(k_flag_to_header, dim3(1), dim3(1), 0, p->stream, p->d_fail, p->lead, p->d_xb + 4);
     HIP_TRY(hipGetLastError());
@@ -653,7 +660,7 @@ int satba_time_kernel(satba_problem* p, int32_t phase, int32_t reps, float* ms_a
             case 2: return launch_schur_kernel(p);
             case 3: {
                 // factorising an already factorised matrix is meaningless numerically but identical in work
-                cholesky_solve(p->payload(), p->n_c, p->d_dc, p->d_fail, p->d_dinv, p->stream);
+                cholesky_solve(p->payload(), p->n_c, p->d_dch, p->d_fail, p->d_dinv, p->stream);
                 return 0;
             }
             case 4: return launch_backsub_kernel(p);

@@ -23,17 +23,29 @@ namespace satba {
 
 constexpr int CH_NB = 32;
 constexpr int CH_ROWS = 256;  // panel rows per workgroup in k_potrf_trsm
+constexpr int CH_THREADS = 1024;
 
-// dinv: (n / 32 + 1) blocks of 32 x 32 (row-major) receiving inv(L_kk)
-__global__ __launch_bounds__(CH_ROWS) void k_potrf_trsm(double* __restrict__ A, int n, int k0, int* __restrict__ fail,
-                                                        double* __restrict__ b, double* __restrict__ dinv) {
+// dinv: (n / 32 + 1) blocks of 32 x 32 (row-major) receiving inv(L_kk).
+// Workgroup 0: factorise the diagonal block, publish L_kk and inv(L_kk), advance the right-hand side.
+// Workgroups 1..: same factorisation (redundant), then 64 panel rows each as a small GEMM  X = P inv(L_kk)^T
+// (twice the flops of a triangular solve, but no dependent chain and no 32-deep unrolled register array).
+__global__ __launch_bounds__(CH_THREADS) void k_potrf_trsm(double* __restrict__ A, int n, int k0, int* __restrict__ fail,
+                                                    double* __restrict__ b, double* __restrict__ dinv) {
     __shared__ double D[CH_NB][CH_NB + 1];
     __shared__ double Di[CH_NB][CH_NB + 1];
+    __shared__ double Pt[CH_NB][CH_ROWS];
     const int tid = threadIdx.x;
     const int nb = min(CH_NB, n - k0);
-    for (int idx = tid; idx < CH_NB * CH_NB; idx += CH_ROWS) {
+    for (int idx = tid; idx < CH_NB * CH_NB; idx += CH_THREADS) {
         const int r = idx % CH_NB, c = idx / CH_NB;
         D[r][c] = (r < nb && c < nb && r >= c) ? A[(size_t)(k0 + r) + (size_t)(k0 + c) * n] : ((r == c) ? 1.0 : 0.0);
+    }
+    const int r0 = k0 + nb + ((int)blockIdx.x - 1) * CH_ROWS;
+    if (blockIdx.x > 0) {  // stage this workgroup's panel rows (transposed) while the factorisation runs
+        for (int idx = tid; idx < CH_NB * CH_ROWS; idx += CH_THREADS) {
+            const int r = idx % CH_ROWS, k = idx / CH_ROWS;
+            Pt[k][r] = (k < nb && r0 + r < n) ? A[(size_t)(r0 + r) + (size_t)(k0 + k) * n] : 0.0;
+        }
     }
     __syncthreads();
     // unblocked Cholesky of the 32 x 32 block, all threads on the rank-1 updates
@@ -49,29 +61,33 @@ __global__ __launch_bounds__(CH_ROWS) void k_potrf_trsm(double* __restrict__ A, 
         __syncthreads();
         if (tid > j && tid < nb) D[tid][j] /= D[j][j];
         __syncthreads();
-        for (int idx = tid; idx < CH_NB * CH_NB; idx += CH_ROWS) {
+        for (int idx = tid; idx < CH_NB * CH_NB; idx += CH_THREADS) {
             const int r = idx % CH_NB, c = idx / CH_NB;
             if (c > j && r >= c && r < nb) D[r][c] -= D[r][j] * D[c][j];
         }
         __syncthreads();
     }
+    // inv(L_kk): half-wave c owns column c, lane m of it holds Di[m][c] in a register; row r of the column is a
+    // 32-lane dot product (shuffles), so the whole inverse is 32 short steps with no LDS round trips
+    {
+        const int c = tid >> 5, m = tid & 31;
+        double mine = 0.0;  // Di[m][c]
+        for (int r = 0; r < CH_NB; ++r) {
+            double v = (m < r && m >= c) ? D[r][m] * mine : 0.0;
+#pragma unroll
+            for (int d = 16; d > 0; d >>= 1) v += __shfl_xor(v, d);
+            if (m == r) mine = (r >= c) ? (((r == c) ? 1.0 : 0.0) - v) / D[r][r] : 0.0;
+        }
+        Di[m][c] = mine;
+    }
+    __syncthreads();
     if (blockIdx.x == 0) {
-        for (int idx = tid; idx < nb * nb; idx += CH_ROWS) {
+        for (int idx = tid; idx < nb * nb; idx += CH_THREADS) {
             const int r = idx % nb, c = idx / nb;
             if (r >= c) A[(size_t)(k0 + r) + (size_t)(k0 + c) * n] = D[r][c];
         }
-        // inverse of the lower-triangular block: thread c solves L x = e_c
-        if (tid < CH_NB) {
-            const int c = tid;
-            for (int r = 0; r < CH_NB; ++r) {
-                double s = (r == c) ? 1.0 : 0.0;
-                for (int m = c; m < r; ++m) s -= D[r][m] * Di[m][c];
-                Di[r][c] = (r >= c) ? s / D[r][r] : 0.0;
-            }
-        }
-        __syncthreads();
         double* out = dinv + (size_t)(k0 / CH_NB) * CH_NB * CH_NB;
-        for (int idx = tid; idx < CH_NB * CH_NB; idx += CH_ROWS) out[idx] = Di[idx / CH_NB][idx % CH_NB];
+        for (int idx = tid; idx < CH_NB * CH_NB; idx += CH_THREADS) out[idx] = Di[idx / CH_NB][idx % CH_NB];
         // forward substitution of this block of the right-hand side: y_k = inv(L_kk) b_k
         double s = 0.0;
         if (tid < nb)
@@ -80,23 +96,26 @@ __global__ __launch_bounds__(CH_ROWS) void k_potrf_trsm(double* __restrict__ A, 
         if (tid < nb) b[k0 + tid] = s;
         return;
     }
-    const int r = k0 + nb + (blockIdx.x - 1) * CH_ROWS + tid;
-    if (r >= n) return;
-    double x[CH_NB];
+    // X[r][c] = sum_k P[r][k] inv(L)[c][k]; thread = 4 rows x 2 columns
+    const int tr = (tid & 63) * 4, tc = (tid >> 6) * 2;
+    double acc[2][4] = {};
+#pragma unroll 8
+    for (int k = 0; k < CH_NB; ++k) {
+        const double d0 = Di[tc][k], d1 = Di[tc + 1][k];
 #pragma unroll
-    for (int c = 0; c < CH_NB; ++c) x[c] = (c < nb) ? A[(size_t)r + (size_t)(k0 + c) * n] : 0.0;
-#pragma unroll
-    for (int c = 0; c < CH_NB; ++c) {
-        if (c < nb) {
-            double s = x[c];
-#pragma unroll
-            for (int m = 0; m < c; ++m) s -= x[m] * D[c][m];
-            x[c] = s / D[c][c];
+        for (int i = 0; i < 4; ++i) {
+            const double a = Pt[k][tr + i];
+            acc[0][i] += a * d0;
+            acc[1][i] += a * d1;
         }
     }
 #pragma unroll
-    for (int c = 0; c < CH_NB; ++c)
-        if (c < nb) A[(size_t)r + (size_t)(k0 + c) * n] = x[c];
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = r0 + tr + i, c = tc + j;
+            if (r < n && c < nb) A[(size_t)r + (size_t)(k0 + c) * n] = acc[j][i];
+        }
 }
 
 // trailing update A[base:, base:] -= P P^T (lower tiles only), P = A[base:, k0:k0+nb], base = k0 + nb;
@@ -121,6 +140,7 @@ __global__ __launch_bounds__(256) void k_syrk(double* __restrict__ A, int n, int
     }
     double acc[4][4] = {};
     const int tr = threadIdx.x * 4, tc = threadIdx.y * 4;  // rows on the fast index: coalesced A accesses
+#pragma unroll 8
     for (int k = 0; k < nb; ++k) {
         double a[4], c[4];
 #pragma unroll
@@ -139,34 +159,44 @@ __global__ __launch_bounds__(256) void k_syrk(double* __restrict__ A, int n, int
         }
 }
 
-// L^T z = y in place in b (b holds y on entry), right-looking: z_k = inv(L_kk)^T y_k, then every earlier entry
-// gets its contribution y_j -= L[k-block, j]^T z_k.  One workgroup of 1024 threads.
+// L^T z = y in place in b (b holds y on entry), left-looking, one workgroup of 1024 threads:
+// z_k = inv(L_kk)^T (y_k - L[tail, k-block]^T z_tail).
 __global__ __launch_bounds__(1024) void k_trsv_back(const double* __restrict__ L, int n, const double* __restrict__ dinv,
                                                     double* __restrict__ b) {
-    __shared__ double z[CH_NB];
-    const int tid = threadIdx.x;
+    extern __shared__ double yb[];  // n doubles: the right-hand side / solution lives in LDS for the whole solve
+    __shared__ double t[CH_NB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < n; i += 1024) yb[i] = b[i];
+    __syncthreads();
     const int nblk = (n + CH_NB - 1) / CH_NB;
     for (int kb = nblk - 1; kb >= 0; --kb) {
         const int k0 = kb * CH_NB;
         const int nb = min(CH_NB, n - k0);
-        if (tid < CH_NB) {
+        const int tail0 = k0 + nb;
+        // t_c = y_c - sum_{r >= tail0} L[r][k0 + c] z[r]: each wave takes two columns, lanes run down the column
+        // (coalesced), the loads of a column are independent of each other and of the LDS traffic
+        for (int cc = 0; cc < 2; ++cc) {
+            const int c = wave * 2 + cc;
             double s = 0.0;
-            if (tid < nb) {
-                const double* Di = dinv + (size_t)kb * CH_NB * CH_NB;  // row-major inv(L_kk); need its transpose
-                for (int m = tid; m < nb; ++m) s += Di[m * CH_NB + tid] * b[k0 + m];
+            if (c < nb) {
+                const double* col = L + (size_t)(k0 + c) * n;
+                for (int r = tail0 + lane; r < n; r += 64) s += col[r] * yb[r];
             }
-            z[tid] = s;
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) s += __shfl_xor(s, d);
+            if (lane == 0 && c < nb) t[c] = yb[k0 + c] - s;
         }
         __syncthreads();
-        if (tid < nb) b[k0 + tid] = z[tid];
-        for (int j = tid; j < k0; j += 1024) {
-            const double* col = L + (size_t)j * n + k0;  // rows k0 .. k0+nb of column j: contiguous
+        // z_k = inv(L_kk)^T t
+        if (tid < nb) {
+            const double* Di = dinv + (size_t)kb * CH_NB * CH_NB;  // row-major inv(L_kk)
             double s = 0.0;
-            for (int r = 0; r < nb; ++r) s += col[r] * z[r];
-            b[j] -= s;
+            for (int m = tid; m < nb; ++m) s += Di[m * CH_NB + tid] * t[m];
+            yb[k0 + tid] = s;
         }
         __syncthreads();
     }
+    for (int i = tid; i < n; i += 1024) b[i] = yb[i];
 }
 
 inline size_t cholesky_workspace_doubles(int n) { return (size_t)(n / CH_NB + 1) * CH_NB * CH_NB; }
@@ -177,13 +207,13 @@ inline void cholesky_solve(double* A, int n, double* b, int* fail, double* dinv,
     for (int k0 = 0; k0 < n; k0 += CH_NB) {
         const int nb = n - k0 < CH_NB ? n - k0 : CH_NB;
         const int rest = n - k0 - nb;
-        hipLaunchKernelGGL(k_potrf_trsm, dim3(1 + (rest + CH_ROWS - 1) / CH_ROWS), dim3(CH_ROWS), 0, stream, A, n, k0, fail, b, dinv);
+        hipLaunchKernelGGL(k_potrf_trsm, dim3(1 + (rest + CH_ROWS - 1) / CH_ROWS), dim3(CH_THREADS), 0, stream, A, n, k0, fail, b, dinv);
         if (rest > 0) {
             const int tiles = (rest + 63) / 64;
             hipLaunchKernelGGL(k_syrk, dim3(tiles, tiles), dim3(16, 16), 0, stream, A, n, k0, nb, b);
         }
     }
-    hipLaunchKernelGGL(k_trsv_back, dim3(1), dim3(1024), 0, stream, A, n, dinv, b);
+    hipLaunchKernelGGL(k_trsv_back, dim3(1), dim3(1024), sizeof(double) * n, stream, A, n, dinv, b);
 }
 
 }  // namespace satba

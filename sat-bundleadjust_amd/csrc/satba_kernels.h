@@ -666,6 +666,28 @@ __global__ __launch_bounds__(256) void k_schur_reduce(int n_c, int n_chunks, con
     }
 }
 
+// Reduced system in scaled variables: S <- diag(scale) S diag(scale), rhs <- scale * rhs (scale = 1 / scale_inv).
+// x_scale="jac" makes the scaled matrix unit-diagonal up to the damping, which keeps the dense factorisation
+// well conditioned although the raw camera blocks span ~12 orders of magnitude (angles vs translations).
+__global__ __launch_bounds__(256) void k_scale_system(int n_c, const double* __restrict__ scale_inv, double* __restrict__ S,
+                                                      double* __restrict__ rhs) {
+    const size_t nn = (size_t)n_c * n_c;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nn + n_c; i += (size_t)gridDim.x * blockDim.x) {
+        if (i < nn) {
+            const int r = (int)(i % n_c), c = (int)(i / n_c);
+            if (r >= c) S[i] /= scale_inv[r] * scale_inv[c];
+        } else {
+            rhs[i - nn] /= scale_inv[i - nn];
+        }
+    }
+}
+
+// dc = dc_h / scale_inv (unscaled camera step for the back-substitution)
+__global__ void k_unscale(int n_c, const double* __restrict__ scale_inv, const double* __restrict__ dch, double* __restrict__ dc) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_c) dc[i] = dch[i] / scale_inv[i];
+}
+
 // ------------------------------------------------------------------------------------------------ K5 back-substitution
 // t_p = sum_obs Jp^T (Jc dc[cam])  per point (segmented wave reduction)
 template <int MODEL, int NP>
@@ -705,8 +727,8 @@ __global__ __launch_bounds__(256) void k_backsub(ObsArgs a, const double* __rest
     }
 }
 
-// gn_h = scale_inv * [dc ; Vinv (g_p - t)]  and the Gram matrix of (g_h, gn_h): hdr[1..3] += a, b, c
-__global__ __launch_bounds__(256) void k_backsub_finish(int n_c, int N, double lead, const double* __restrict__ dc,
+// gn_h = [dc_h ; scale_inv_p * Vinv (g_p - t)]  and the Gram matrix of (g_h, gn_h): hdr[1..3] += a, b, c
+__global__ __launch_bounds__(256) void k_backsub_finish(int n_c, int N, double lead, const double* __restrict__ dch,
                                                         const double* __restrict__ Vinv, const double* __restrict__ g,
                                                         const double* __restrict__ tbuf, const double* __restrict__ scale_inv,
                                                         const double* __restrict__ gh, double* __restrict__ gn,
@@ -715,7 +737,7 @@ __global__ __launch_bounds__(256) void k_backsub_finish(int n_c, int N, double l
     const int total = n_c + N;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
         if (i < n_c) {
-            const double v = dc[i] * scale_inv[i], h = gh[i];
+            const double v = dch[i], h = gh[i];
             gn[i] = v;
             sa += lead * h * h; sb += lead * h * v; sc += lead * v * v;
         } else {

