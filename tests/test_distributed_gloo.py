@@ -1,0 +1,87 @@
+"""
+The N > 1 path on the CPU: world_size 2 over gloo.  Every rank holds all cameras and a shard of the points; the
+same host loop (satba/trf.py) runs on every rank and the exchange buffer is all-reduced after each phase.  The
+per-shard arithmetic is done by the CPU oracle engine here (the HIP engine needs a GPU); what is under test is the
+product's sharding, the placement of the all-reduces, the rank-0-only camera terms, the header slots and the
+assembly of the sharded result.
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+import cases
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, name, loss, out_dir):
+    import sys
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    root = os.path.dirname(here)
+    sys.path[:0] = [os.path.join(root, "sat-bundleadjust_amd"), root, here]
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import cases as cs
+    from oracle import lm_oracle as L
+    from satba import sharding, trf
+
+    _, make_p, _, _ = cs.solve_case(name)
+    p = make_p()
+    comm = trf.TorchComm()
+    shard = sharding.make_shard(p, comm.rank, comm.world)
+    # a shard is itself a small problem: slice the observation lists, keep all cameras
+    import copy
+
+    q = copy.copy(p)
+    q.pts_ind = p.pts_ind[shard.o0: shard.o1] - shard.p0
+    q.cam_ind = p.cam_ind[shard.o0: shard.o1]
+    q.pts2d = p.pts2d[shard.o0: shard.o1]
+    q.pts2d_w = p.pts2d_w[shard.o0: shard.o1]
+    q.pts3d = p.pts3d[shard.p0: shard.p1]
+    q.n_pts, q.n_obs, q.n_pts_fix = shard.n_pts, shard.o1 - shard.o0, shard.n_pts_fix
+    q.params_opt = shard.local_x(p, p.params_opt)
+    eng = L.OracleEngine(q, rank=comm.rank, world=comm.world)
+    eng.n_total = p.params_opt.size
+    res = trf.trf_solve(eng, comm, ftol=1e-15, xtol=1e-15, gtol=1e-15, max_nfev=300, loss=loss)
+    x = sharding.assemble_x(p, shard, eng.get_x(), comm)
+    r = sharding.assemble_residuals(p, shard, eng.residuals(), comm)
+    np.savez(os.path.join(out_dir, "rank{}.npz".format(rank)), x=x, r=r, cost=res.cost, nfev=res.nfev, status=res.status)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name,loss", [("affine_small_R", "linear"), ("affine_small_R", "soft_l1")])
+def test_two_rank_solve_equals_single_rank_and_reference(tmp_path, name, loss):
+    import torch.multiprocessing as mp
+
+    world, port = 2, _free_port()
+    mp.spawn(_worker, args=(world, port, name, loss, str(tmp_path)), nprocs=world, join=True)
+    outs = [np.load(os.path.join(str(tmp_path), "rank{}.npz".format(r))) for r in range(world)]
+    # every rank took the same decisions and returns the same full vectors
+    assert np.array_equal(outs[0]["x"], outs[1]["x"]) and np.array_equal(outs[0]["r"], outs[1]["r"])
+    assert int(outs[0]["nfev"]) == int(outs[1]["nfev"]) and int(outs[0]["status"]) == int(outs[1]["status"])
+
+    from oracle import lm_oracle as L
+    from satba import trf
+
+    _, make_p, g, _ = cases.solve_case(name)
+    p = make_p()
+    eng = L.OracleEngine(p)
+    res = trf.trf_solve(eng, ftol=1e-15, xtol=1e-15, gtol=1e-15, max_nfev=300, loss=loss)
+    n_c = p.n_cam * p.n_params
+    x2, x1 = outs[0]["x"], eng.get_x()
+    assert abs(float(outs[0]["cost"]) - res.cost) < 1e-10 * res.cost
+    assert np.abs(x2[:n_c] - x1[:n_c]).max() < 1e-7 * np.abs(x1[:n_c]).max()
+    xt = g["tight_x_" + loss]
+    assert np.abs(x2[:n_c] - xt[:n_c]).max() < 1e-6 * np.abs(xt[:n_c]).max()  # and the reference's tight scipy run
+    assert np.linalg.norm(outs[0]["r"] - g["tight_fun_" + loss]) < 5e-6 * np.linalg.norm(g["tight_fun_" + loss])

@@ -1,0 +1,120 @@
+"""Host-side logic: the scalar trust-region helpers against scipy's own, sharding, the C-ABI surface.  No GPU."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+import cases
+from oracle import lm_oracle as L
+from satba import engine_hip, sharding, synth, trf
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_trust_region_helpers_match_scipy():
+    from scipy.optimize._lsq import common as sc
+
+    rng = np.random.default_rng(0)
+    for _ in range(300):
+        A = rng.normal(size=(2, 2))
+        B = A @ A.T if rng.random() < 0.8 else A + A.T  # mostly PD, sometimes indefinite
+        g = rng.normal(size=2) * 10 ** rng.uniform(-3, 3)
+        Delta = 10 ** rng.uniform(-3, 2)
+        p1, n1 = trf.solve_trust_region_2d(B, g, Delta)
+        p2, n2 = sc.solve_trust_region_2d(B, g, Delta)
+        q = lambda p: 0.5 * p @ B @ p + g @ p  # noqa: E731
+        assert n1 == n2 and np.linalg.norm(p1) <= Delta * (1 + 1e-9)
+        assert q(p1) <= q(p2) + 1e-9 * (abs(q(p2)) + 1e-300)
+        a, b, lb, ub = rng.normal(), rng.normal(), 0.0, abs(rng.normal())
+        assert np.allclose(trf.minimize_quadratic_1d(a, b, lb, ub), sc.minimize_quadratic_1d(a, b, lb, ub))
+        args = (abs(rng.normal()), rng.normal(), rng.normal(), abs(rng.normal()), rng.random() < 0.5)
+        assert trf.update_tr_radius(*args) == sc.update_tr_radius(*args)
+        t = (rng.normal() * 1e-6, abs(rng.normal()), abs(rng.normal()) * 1e-8, abs(rng.normal()), rng.random(), 1e-4, 1e-8)
+        assert trf.check_termination(*t) == sc.check_termination(*t)
+
+
+@pytest.mark.parametrize("name,loss", [("affine_small_R", "linear"), ("affine_small_R", "soft_l1"), ("persp_small_R", "linear")])
+def test_trf_driver_on_cpu_engine_converges_to_tight_scipy(name, loss):
+    """The host loop (satba/trf.py) driven by the oracle engine: same minimiser as the reference's tight scipy run."""
+    _, make_p, g, _ = cases.solve_case(name)
+    p = make_p()
+    eng = L.OracleEngine(p)
+    res = trf.trf_solve(eng, ftol=1e-15, xtol=1e-15, gtol=1e-15, max_nfev=300, loss=loss)
+    xt, st = g["tight_x_" + loss], g["tight_stats_" + loss]
+    n_c = p.n_cam * p.n_params
+    assert res.status in (2, 3, 4) and abs(res.cost - st[0]) < 1e-9 * st[0]
+    assert np.abs(eng.get_x()[:n_c] - xt[:n_c]).max() < 1e-6 * np.abs(xt[:n_c]).max()
+
+
+def test_trf_driver_max_nfev_and_status_codes():
+    _, make_p, _, _ = cases.solve_case("affine_small_R")
+    p = make_p()
+    eng = L.OracleEngine(p)
+    res = trf.trf_solve(eng, max_nfev=1)
+    assert res.nfev == 1 and res.status == 0 and not res.success and np.array_equal(eng.get_x(), p.params_opt)
+    res = trf.trf_solve(L.OracleEngine(p), ftol=1e-4, xtol=1e-10, max_nfev=300)
+    assert res.status == 2 and res.success and res.nfev < 10
+    res = trf.trf_solve(L.OracleEngine(p), gtol=1e30)
+    assert res.status == 1 and res.nfev == 1
+    bad = make_p()
+    bad.params_opt[-1] = np.inf
+    with pytest.raises(ValueError):
+        trf.trf_solve(L.OracleEngine(bad))
+
+
+def test_point_sharding_partitions_observations():
+    scene = synth.make_affine_scene(7, 1000, 4, seed=2)
+    p = synth.make_params(scene, {"n_pts_fix": 30})
+    for world in (1, 2, 3, 8):
+        shards = [sharding.make_shard(p, r, world) for r in range(world)]
+        assert shards[0].p0 == 0 and shards[-1].p1 == p.n_pts and shards[0].o0 == 0 and shards[-1].o1 == p.n_obs
+        for a, b in zip(shards, shards[1:]):
+            assert a.p1 == b.p0 and a.o1 == b.o0
+        for s in shards:
+            sel = p.pts_ind[s.o0: s.o1]
+            assert sel.size == 0 or (sel.min() >= s.p0 and sel.max() < s.p1)
+            assert abs((s.o1 - s.o0) - p.n_obs / world) <= np.bincount(p.pts_ind).max()
+        assert sum(s.n_pts_fix for s in shards) == 30 and shards[0].n_pts_fix == min(30, shards[0].n_pts)
+        x = np.arange(p.params_opt.size, dtype=float)
+        n_c = p.n_cam * p.n_params
+        assert np.array_equal(np.concatenate([x[:n_c]] + [s.local_x(p, x)[n_c:] for s in shards]), x)
+
+
+def test_c_abi_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "satba.h")).read()
+    declared = set(re.findall(r"\b(satba_[a-z_]+)\s*\(", header))
+    assert declared == set(engine_hip.SYMBOLS), declared ^ set(engine_hip.SYMBOLS)
+    lib = engine_hip.load_library()  # raises OSError if the library was not built: the build is part of the contract
+    for sym in declared:
+        assert hasattr(lib, sym), sym
+    assert lib.satba_version() >= 1
+    assert engine_hip.HDR_FIXED == int(re.search(r"#define SATBA_HDR_FIXED (\d+)", header).group(1))
+    from satba import rpc_model
+
+    assert rpc_model.RPC_TABLE_LEN == int(re.search(r"#define SATBA_RPC_TABLE_LEN (\d+)", header).group(1))
+    assert ctypes_sizeof_desc() == 12 * 4 + 2 * 8 + 6 * 8
+
+
+def ctypes_sizeof_desc():
+    import ctypes
+
+    return ctypes.sizeof(engine_hip.ProblemDesc)
+
+
+def test_product_path_fails_loudly_without_device_or_library(tmp_path):
+    """No CPU fallback: a missing library is an OSError, a missing device a runtime error -- never a silent result."""
+    with pytest.raises(OSError):
+        engine_hip.load_library(str(tmp_path / "libsatba_hip.so"))
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a HIP device is present")
+    scene = synth.make_affine_scene(3, 20, 3, seed=9)
+    p = synth.make_params(scene, {"correction_params": ["R"]})
+    from satba import ba_core
+
+    with pytest.raises((engine_hip.SatbaError, RuntimeError)):
+        ba_core.fun(p.params_opt.copy(), p)
+    with pytest.raises((engine_hip.SatbaError, RuntimeError)):
+        ba_core.run_ba_optimization(p, {"verbose": 0}, False, False)
