@@ -9,6 +9,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <new>
 #include <string>
@@ -17,6 +18,7 @@
 #include "../../include/satba.h"
 #include "satba_chol.h"
 #include "satba_kernels.h"
+#include "satba_linearize.h"
 
 using namespace satba;
 
@@ -66,6 +68,10 @@ struct satba_problem {
     double2* d_f = nullptr;
     double* d_part = nullptr;
     int lin_grid = 0;
+    // linearize v2 (LDS staging, owner-thread camera reduction); lin2_grid == 0: use v1
+    int lin2_grid = 0, lin2_cap = 0, lin2_camc_lds = 0;
+    size_t lin2_lds = 0;
+    double* d_overflow = nullptr;
     int* d_fail = nullptr;
     double* d_scal = nullptr;  // 8 private scalars (costs of satba_residuals, timing sinks)
     double *d_xb_own = nullptr, *d_xb = nullptr;
@@ -147,8 +153,31 @@ static int launch_residual(satba_problem* p, bool at_new, double2* f, double* hd
     return 0;
 }
 
+template <int MODEL, int NP>
+static int launch_lin2(satba_problem* p, const ObsArgs& a, const Lin2Args& s) {
+    constexpr int BLOCK = Lin2Cfg<NP>::BLOCK;
+    if (p->loss == 0)
+        hipLaunchKernelGGL((k_linearize2<MODEL, NP, false>), dim3(p->lin2_grid), dim3(BLOCK), p->lin2_lds, p->stream, a, s);
+    else
+        hipLaunchKernelGGL((k_linearize2<MODEL, NP, true>), dim3(p->lin2_grid), dim3(BLOCK), p->lin2_lds, p->stream, a, s);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// number of workgroup partials the last linearize launch produced
+static int lin_partials(const satba_problem* p) { return p->lin2_grid > 0 ? p->lin2_grid : p->lin_grid; }
+
 static int launch_linearize_kernel(satba_problem* p) {
     ObsArgs a = obs_args(p, false);
+    if (p->lin2_grid > 0) {
+        Lin2Args s;
+        s.f = p->d_f; s.V = p->d_V; s.gp = p->d_g + p->n_c; s.part = p->d_part; s.overflow = p->d_overflow;
+        s.hdr_cost = p->d_xb + 0; s.hdr_gpmax = p->d_xb + SATBA_HDR_FIXED + p->rank;
+        s.cap = p->lin2_cap; s.camc_in_lds = p->lin2_camc_lds;
+        HIP_TRY(hipMemsetAsync(p->d_overflow, 0, sizeof(double) * p->M * cam_acc_len(p->NP), p->stream));
+        SATBA_DISPATCH(p, TRY((launch_lin2<MODEL, NP>(p, a, s))));
+        return 0;
+    }
     const size_t lds = sizeof(double) * p->M * cam_acc_len(p->NP);
     SATBA_DISPATCH(p, hipLaunchKernelGGL((k_linearize<MODEL, NP>), dim3(p->lin_grid), dim3(TILE_THREADS), lds, p->stream, a,
                                           p->d_f, p->d_V, p->d_g + p->n_c, p->d_part, p->d_xb + 0,
@@ -353,7 +382,41 @@ int satba_problem_create(const satba_problem_desc* d, satba_problem** out) {
         TRY(dev_alloc(p, &p->d_dinv, cholesky_workspace_doubles(p->n_c)));
         TRY(dev_alloc(p, &p->d_scal, 8));
         p->lin_grid = grid_for(p->n_tiles, TILE_WAVES, MAX_TILE_GRID);
-        TRY(dev_alloc(p, &p->d_part, (size_t)p->lin_grid * p->M * cam_acc_len(p->NP)));
+        {   // linearize v2 configuration
+            const int CU = cam_acc_len(p->NP);
+            const int block = CU <= 20 ? 512 : 256, waves = block / 64;
+            const int n_super = (p->n_tiles + waves - 1) / waves;
+            // exact bucket capacity: the largest number of observations one camera has in one super-tile
+            int cap = 1;
+            {
+                std::vector<int> count(p->M, 0), touched;
+                for (int st = 0; st < n_super; ++st) {
+                    const int t0 = st * waves, t1 = std::min(p->n_tiles, t0 + waves);
+                    touched.clear();
+                    for (int o = tile_start[t0]; o < tile_start[t1]; ++o) {
+                        const int cc = d->cam_ind[o];
+                        if (count[cc]++ == 0) touched.push_back(cc);
+                    }
+                    for (int cc : touched) { cap = std::max(cap, count[cc]); count[cc] = 0; }
+                }
+            }
+            if ((size_t)cap * p->M * 2 > 24 * 1024) cap = std::max(8, (int)(24 * 1024 / ((size_t)p->M * 2)));  // rest overflows
+            const size_t fixed = sizeof(double) * (size_t)CU * block + sizeof(unsigned) * 2 * p->M + (size_t)p->M * cap * 2 + 16;
+            const size_t camc_bytes = sizeof(double) * (size_t)p->M * CAMC;
+            const size_t budget = 160 * 1024 - 2048;
+            const bool owners_ok = (size_t)p->M * CU <= (size_t)LIN2_MAXACC * block;
+            if (owners_ok && fixed <= budget && !getenv("SATBA_LIN_V1") && p->n_tiles > 0) {
+                p->lin2_camc_lds = (fixed + camc_bytes <= budget) ? 1 : 0;
+                p->lin2_lds = fixed + (p->lin2_camc_lds ? camc_bytes : 0);
+                p->lin2_cap = cap;
+                const int per_cu = (p->lin2_lds <= 76 * 1024) ? 2 : 1;
+                p->lin2_grid = std::min(n_super, 256 * per_cu);
+                SATBA_DISPATCH(p, TRY(raise_lds_limit(k_linearize2<MODEL, NP, false>, p->lin2_lds)));
+                SATBA_DISPATCH(p, TRY(raise_lds_limit(k_linearize2<MODEL, NP, true>, p->lin2_lds)));
+            }
+            TRY(dev_alloc(p, &p->d_overflow, (size_t)p->M * CU));
+        }
+        TRY(dev_alloc(p, &p->d_part, (size_t)std::max(p->lin_grid, p->lin2_grid) * p->M * cam_acc_len(p->NP)));
         p->xb_len = satba_exchange_len(p);
         TRY(dev_alloc(p, &p->d_xb_own, p->xb_len));
         p->d_xb = p->d_xb_own;
@@ -479,7 +542,8 @@ int satba_linearize(satba_problem* p) {
     double* U = p->payload();
     double* gc = U + (size_t)p->M * p->NP * p->NP;
     const int total = p->M * cam_acc_len(p->NP);
-    hipLaunchKernelGGL(k_lin_finish, dim3((total + 63) / 64), dim3(1024), 0, p->stream, p->M, p->NP, p->lin_grid, p->d_part, U, gc);
+    hipLaunchKernelGGL(k_lin_finish, dim3((total + 63) / 64), dim3(1024), 0, p->stream, p->M, p->NP, lin_partials(p), p->d_part,
+                       p->lin2_grid > 0 ? p->d_overflow : nullptr, U, gc);
     HIP_TRY(hipGetLastError());
     p->linearized = true; p->have_step = false;
     return 0;

@@ -41,7 +41,7 @@ struct ObsArgs {
 };
 
 // weighted, robust-scaled residual and (optionally) Jacobian blocks of observation o
-template <int MODEL, int NP, bool JAC>
+template <int MODEL, int NP, bool JAC, bool ROBUST = true>
 struct ObsEval {
     double ftrue[2];  // w * (proj - obs)
     double fs[2];     // robust-scaled residual
@@ -64,9 +64,14 @@ struct ObsEval {
         project<MODEL, NP, JAC>(cc, tab, X, Y, Z, a.f32 != 0, u, v, Jc, Jp);
         ftrue[0] = w * (u - ob.x);
         ftrue[1] = w * (v - ob.y);
-        double r0, r1, js0, js1;
-        robust(a.loss, a.f_scale, ftrue[0], r0, fs[0], js0);
-        robust(a.loss, a.f_scale, ftrue[1], r1, fs[1], js1);
+        double r0, r1, js0 = 1.0, js1 = 1.0;
+        if constexpr (ROBUST) {
+            robust(a.loss, a.f_scale, ftrue[0], r0, fs[0], js0);
+            robust(a.loss, a.f_scale, ftrue[1], r1, fs[1], js1);
+        } else {  // linear loss, specialised at compile time (no transcendental code, far fewer registers)
+            fs[0] = ftrue[0]; fs[1] = ftrue[1];
+            r0 = ftrue[0] * ftrue[0]; r1 = ftrue[1] * ftrue[1];
+        }
         rho = r0 + r1;
         if (JAC) {
             const double mc = (cam >= a.n_cam_fix) ? 1.0 : 0.0;
@@ -246,7 +251,8 @@ __global__ __launch_bounds__(TILE_THREADS) void k_linearize(ObsArgs a, double2* 
 // sum the per-workgroup camera partials and expand to the exchange payload: U (M x NP x NP, full), g_c (M x NP).
 // 64 outputs per workgroup, 16 waves each summing a strided subset of the workgroups, combined through LDS.
 __global__ __launch_bounds__(1024) void k_lin_finish(int M, int NP, int nblocks, const double* __restrict__ part,
-                                                     double* __restrict__ U, double* __restrict__ gc) {
+                                                     const double* __restrict__ overflow, double* __restrict__ U,
+                                                     double* __restrict__ gc) {
     const int CU = cam_acc_len(NP);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int idx = blockIdx.x * 64 + lane;
@@ -260,6 +266,7 @@ __global__ __launch_bounds__(1024) void k_lin_finish(int M, int NP, int nblocks,
     s = 0.0;
 #pragma unroll
     for (int w = 0; w < 16; ++w) s += s_sum[w][lane];
+    if (overflow) s += overflow[idx];
     const int cam = idx / CU, k = idx % CU;
     const int ntri = NP * (NP + 1) / 2;
     if (k >= ntri) {
