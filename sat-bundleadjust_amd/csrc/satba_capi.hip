@@ -18,7 +18,7 @@
 #include "../../include/satba.h"
 #include "satba_chol.h"
 #include "satba_kernels.h"
-#include "satba_linearize.h"
+#include "satba_linearize3.h"
 
 using namespace satba;
 
@@ -45,6 +45,8 @@ struct satba_problem {
     long long K = 0, n_total = 0;
     int n_c = 0, n = 0, hdr = 0;
     int loss = 0;
+    int camc_lds = 0;          // camera-constant table fits the per-workgroup LDS budget (40 KB)
+    size_t camc_bytes = 0;
     double f_scale = 1.0, lead = 1.0;
     hipStream_t stream = nullptr;
     // observation data
@@ -68,10 +70,12 @@ struct satba_problem {
     double2* d_f = nullptr;
     double* d_part = nullptr;
     int lin_grid = 0;
-    // linearize v2 (LDS staging, owner-thread camera reduction); lin2_grid == 0: use v1
-    int lin2_grid = 0, lin2_cap = 0, lin2_camc_lds = 0;
-    size_t lin2_lds = 0;
-    double* d_overflow = nullptr;
+    // linearize v3 (two register-accumulating passes); lin3_chunks == 0: not used
+    int lin3_chunks = 0, lin3_grid = 0;
+    double2* d_cm_obs = nullptr;
+    double* d_cm_w = nullptr;
+    int* d_cm_pt = nullptr;
+    double* d_part3 = nullptr;
     int* d_fail = nullptr;
     double* d_scal = nullptr;  // 8 private scalars (costs of satba_residuals, timing sinks)
     double *d_xb_own = nullptr, *d_xb = nullptr;
@@ -98,19 +102,26 @@ static int dev_alloc(satba_problem* p, T** out, size_t count) {
         if (rc_) return rc_; \
     } while (0)
 
-// dispatch on (camera model, parameters per camera); valid pairs: affine {3,5}, perspective / rpc {3,6}
-#define SATBA_DISPATCH(p, ...)                                                    \
-    do {                                                                          \
-        const int key_ = (p)->model * 10 + (p)->NP;                               \
-        switch (key_) {                                                           \
-            case 3:  { constexpr int MODEL = AFFINE, NP = 3; __VA_ARGS__; } break;       \
-            case 5:  { constexpr int MODEL = AFFINE, NP = 5; __VA_ARGS__; } break;       \
-            case 13: { constexpr int MODEL = PERSPECTIVE, NP = 3; __VA_ARGS__; } break;  \
-            case 16: { constexpr int MODEL = PERSPECTIVE, NP = 6; __VA_ARGS__; } break;  \
-            case 23: { constexpr int MODEL = RPC, NP = 3; __VA_ARGS__; } break;          \
-            case 26: { constexpr int MODEL = RPC, NP = 6; __VA_ARGS__; } break;          \
-            default: return fail(SATBA_E_ARG, "unsupported (cam_model, n_params) = (%d, %d)", (p)->model, (p)->NP); \
-        }                                                                         \
+// dispatch on (camera model, parameters per camera, camera table in LDS); valid pairs: affine {3,5},
+// perspective / rpc {3,6}
+#define SATBA_DISPATCH(p, ...)                                                                                    \
+    do {                                                                                                          \
+        const int key_ = (p)->model * 10 + (p)->NP + ((p)->camc_lds ? 100 : 0);                                   \
+        switch (key_) {                                                                                           \
+            case 3:   { constexpr int MODEL = AFFINE, NP = 3; constexpr bool CL = false; (void)CL; __VA_ARGS__; } break;      \
+            case 5:   { constexpr int MODEL = AFFINE, NP = 5; constexpr bool CL = false; (void)CL; __VA_ARGS__; } break;      \
+            case 13:  { constexpr int MODEL = PERSPECTIVE, NP = 3; constexpr bool CL = false; (void)CL; __VA_ARGS__; } break; \
+            case 16:  { constexpr int MODEL = PERSPECTIVE, NP = 6; constexpr bool CL = false; (void)CL; __VA_ARGS__; } break; \
+            case 23:  { constexpr int MODEL = RPC, NP = 3; constexpr bool CL = false; (void)CL; __VA_ARGS__; } break;         \
+            case 26:  { constexpr int MODEL = RPC, NP = 6; constexpr bool CL = false; (void)CL; __VA_ARGS__; } break;         \
+            case 103: { constexpr int MODEL = AFFINE, NP = 3; constexpr bool CL = true; (void)CL; __VA_ARGS__; } break;       \
+            case 105: { constexpr int MODEL = AFFINE, NP = 5; constexpr bool CL = true; (void)CL; __VA_ARGS__; } break;       \
+            case 113: { constexpr int MODEL = PERSPECTIVE, NP = 3; constexpr bool CL = true; (void)CL; __VA_ARGS__; } break;  \
+            case 116: { constexpr int MODEL = PERSPECTIVE, NP = 6; constexpr bool CL = true; (void)CL; __VA_ARGS__; } break;  \
+            case 123: { constexpr int MODEL = RPC, NP = 3; constexpr bool CL = true; (void)CL; __VA_ARGS__; } break;          \
+            case 126: { constexpr int MODEL = RPC, NP = 6; constexpr bool CL = true; (void)CL; __VA_ARGS__; } break;          \
+            default: return fail(SATBA_E_ARG, "unsupported (cam_model, n_params) = (%d, %d)", (p)->model, (p)->NP);           \
+        }                                                                                                         \
     } while (0)
 
 static ObsArgs obs_args(const satba_problem* p, bool at_new) {
@@ -148,41 +159,60 @@ static int zero_header(satba_problem* p) {
 static int launch_residual(satba_problem* p, bool at_new, double2* f, double* hdr_slot) {
     ObsArgs a = obs_args(p, at_new);
     const int grid = grid_for(p->K, 512, 512);
-    SATBA_DISPATCH(p, hipLaunchKernelGGL((k_residual<MODEL, NP>), dim3(grid), dim3(512), 0, p->stream, a, f, hdr_slot));
-    HIP_TRY(hipGetLastError());
-    return 0;
-}
-
-template <int MODEL, int NP>
-static int launch_lin2(satba_problem* p, const ObsArgs& a, const Lin2Args& s) {
-    constexpr int BLOCK = Lin2Cfg<NP>::BLOCK;
-    if (p->loss == 0)
-        hipLaunchKernelGGL((k_linearize2<MODEL, NP, false>), dim3(p->lin2_grid), dim3(BLOCK), p->lin2_lds, p->stream, a, s);
-    else
-        hipLaunchKernelGGL((k_linearize2<MODEL, NP, true>), dim3(p->lin2_grid), dim3(BLOCK), p->lin2_lds, p->stream, a, s);
+    SATBA_DISPATCH(p, hipLaunchKernelGGL((k_residual<MODEL, NP, CL>), dim3(grid), dim3(512), p->camc_bytes, p->stream, a, f, hdr_slot));
     HIP_TRY(hipGetLastError());
     return 0;
 }
 
 // number of workgroup partials the last linearize launch produced
-static int lin_partials(const satba_problem* p) { return p->lin2_grid > 0 ? p->lin2_grid : p->lin_grid; }
+static int lin_partials(const satba_problem* p) { return p->lin_grid; }
+
+template <int MODEL, int NP, bool CL>
+static int launch_lin3(satba_problem* p, const ObsArgs& a) {
+    Lin3Args s;
+    s.pt_ofs = p->d_pt_ofs; s.f = p->d_f; s.V = p->d_V; s.gp = p->d_g + p->n_c;
+    s.hdr_cost = p->d_xb + 0; s.hdr_gpmax = p->d_xb + SATBA_HDR_FIXED + p->rank; s.camc_in_lds = p->camc_lds;
+    CamMajor cm;
+    cm.cam_ofs = p->d_cam_ofs; cm.obs = p->d_cm_obs; cm.w = p->d_cm_w; cm.pt = p->d_cm_pt;
+    const size_t lds = p->camc_bytes;
+    if (p->loss == 0) {
+        hipLaunchKernelGGL((k_lin_points<MODEL, NP, false, CL>), dim3(p->lin3_grid), dim3(256), lds, p->stream, a, s);
+        hipLaunchKernelGGL((k_lin_cameras<MODEL, NP, false>), dim3(p->lin3_chunks, p->M), dim3(LINC_THREADS), 0, p->stream, a, cm, p->d_part3);
+    } else {
+        hipLaunchKernelGGL((k_lin_points<MODEL, NP, true, CL>), dim3(p->lin3_grid), dim3(256), lds, p->stream, a, s);
+        hipLaunchKernelGGL((k_lin_cameras<MODEL, NP, true>), dim3(p->lin3_chunks, p->M), dim3(LINC_THREADS), 0, p->stream, a, cm, p->d_part3);
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+static size_t lin1_lds(const satba_problem* p, bool robust) {
+    const int waves = robust ? 8 : 16;
+    return sizeof(double) * ((size_t)p->M * cam_acc_len(p->NP) + (size_t)waves * 9 * 64) + p->camc_bytes;
+}
+
+template <int MODEL, int NP, bool CL>
+static int launch_lin1(satba_problem* p, const ObsArgs& a) {
+    double* gpv = p->d_g + p->n_c;
+    double* cost = p->d_xb + 0;
+    double* gmax = p->d_xb + SATBA_HDR_FIXED + p->rank;
+    if (p->loss == 0)
+        hipLaunchKernelGGL((k_linearize<MODEL, NP, false, CL>), dim3(p->lin_grid), dim3(LinCfg<false>::THREADS), lin1_lds(p, false),
+                           p->stream, a, p->d_f, p->d_V, gpv, p->d_part, cost, gmax);
+    else
+        hipLaunchKernelGGL((k_linearize<MODEL, NP, true, CL>), dim3(p->lin_grid), dim3(LinCfg<true>::THREADS), lin1_lds(p, true),
+                           p->stream, a, p->d_f, p->d_V, gpv, p->d_part, cost, gmax);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
 
 static int launch_linearize_kernel(satba_problem* p) {
     ObsArgs a = obs_args(p, false);
-    if (p->lin2_grid > 0) {
-        Lin2Args s;
-        s.f = p->d_f; s.V = p->d_V; s.gp = p->d_g + p->n_c; s.part = p->d_part; s.overflow = p->d_overflow;
-        s.hdr_cost = p->d_xb + 0; s.hdr_gpmax = p->d_xb + SATBA_HDR_FIXED + p->rank;
-        s.cap = p->lin2_cap; s.camc_in_lds = p->lin2_camc_lds;
-        HIP_TRY(hipMemsetAsync(p->d_overflow, 0, sizeof(double) * p->M * cam_acc_len(p->NP), p->stream));
-        SATBA_DISPATCH(p, TRY((launch_lin2<MODEL, NP>(p, a, s))));
+    if (p->lin3_chunks > 0) {
+        SATBA_DISPATCH(p, TRY((launch_lin3<MODEL, NP, CL>(p, a))));
         return 0;
     }
-    const size_t lds = sizeof(double) * p->M * cam_acc_len(p->NP);
-    SATBA_DISPATCH(p, hipLaunchKernelGGL((k_linearize<MODEL, NP>), dim3(p->lin_grid), dim3(TILE_THREADS), lds, p->stream, a,
-                                          p->d_f, p->d_V, p->d_g + p->n_c, p->d_part, p->d_xb + 0,
-                                          p->d_xb + SATBA_HDR_FIXED + p->rank));
-    HIP_TRY(hipGetLastError());
+    SATBA_DISPATCH(p, TRY((launch_lin1<MODEL, NP, CL>(p, a))));
     return 0;
 }
 
@@ -197,7 +227,7 @@ static int launch_schur_kernel(satba_problem* p) {
         s.cam_ofs = p->d_cam_ofs; s.cam_obs = p->d_cam_obs; s.pt_ofs = p->d_pt_ofs;
         s.Vinv = p->d_Vinv; s.gp = p->d_g + p->n_c; s.S_part = p->d_S_part; s.rhs_part = p->d_rhs_part;
         s.T = p->sch_T; s.n_ctiles = p->sch_ctiles; s.n_chunks = p->sch_chunks; s.camc_in_lds = p->sch_camc_lds;
-        SATBA_DISPATCH(p, hipLaunchKernelGGL((k_schur_panel<MODEL, NP>), dim3(p->sch_ctiles * p->sch_chunks),
+        SATBA_DISPATCH(p, hipLaunchKernelGGL((k_schur_panel<MODEL, NP, CL>), dim3(p->sch_ctiles * p->sch_chunks),
                                              dim3(SCHUR_THREADS), p->sch_lds, p->stream, a, s));
         HIP_TRY(hipGetLastError());
         hipLaunchKernelGGL(k_schur_reduce, dim3(grid_for((long long)p->n_c * p->n_c, 256, 2048)), dim3(256), 0, p->stream,
@@ -221,7 +251,7 @@ static int launch_schur_kernel(satba_problem* p) {
 static int launch_backsub_kernel(satba_problem* p) {
     ObsArgs a = obs_args(p, false);
     const int grid = grid_for(p->n_tiles, 4, 2048);
-    SATBA_DISPATCH(p, hipLaunchKernelGGL((k_backsub<MODEL, NP>), dim3(grid), dim3(256), 0, p->stream, a, p->d_dc, p->d_tbuf));
+    SATBA_DISPATCH(p, hipLaunchKernelGGL((k_backsub<MODEL, NP, CL>), dim3(grid), dim3(256), p->camc_bytes, p->stream, a, p->d_dc, p->d_tbuf));
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -230,10 +260,10 @@ static int launch_jvp(satba_problem* p, int nv, const double* q1, const double* 
     ObsArgs a = obs_args(p, false);
     const int grid = grid_for(p->K, 512, 512);
     if (nv == 1) {
-        SATBA_DISPATCH(p, hipLaunchKernelGGL((k_jvp<MODEL, NP, 1>), dim3(grid), dim3(512), 0, p->stream, a, q1, q2,
+        SATBA_DISPATCH(p, hipLaunchKernelGGL((k_jvp<MODEL, NP, 1, CL>), dim3(grid), dim3(512), p->camc_bytes, p->stream, a, q1, q2,
                                               p->d_scale_inv, out));
     } else {
-        SATBA_DISPATCH(p, hipLaunchKernelGGL((k_jvp<MODEL, NP, 2>), dim3(grid), dim3(512), 0, p->stream, a, q1, q2,
+        SATBA_DISPATCH(p, hipLaunchKernelGGL((k_jvp<MODEL, NP, 2, CL>), dim3(grid), dim3(512), p->camc_bytes, p->stream, a, q1, q2,
                                               p->d_scale_inv, out));
     }
     HIP_TRY(hipGetLastError());
@@ -330,18 +360,26 @@ int satba_problem_create(const satba_problem_desc* d, satba_problem** out) {
 
     int rc = [&]() -> int {
         HIP_TRY(hipSetDevice(p->device));
-        const size_t lin_lds = sizeof(double) * p->M * cam_acc_len(p->NP);
-        if (lin_lds > 160 * 1024 || schur_lds(p) > 160 * 1024)
-            return fail(SATBA_E_ARG, "n_cam = %d exceeds the LDS-resident camera table of this build", p->M);
-        SATBA_DISPATCH(p, TRY(raise_lds_limit(k_linearize<MODEL, NP>, lin_lds)));
+        p->camc_lds = (sizeof(double) * (size_t)p->M * CAMC <= 40 * 1024 && !getenv("SATBA_CAMC_GLOBAL")) ? 1 : 0;
+        p->camc_bytes = p->camc_lds ? sizeof(double) * (size_t)p->M * CAMC : 0;
+        // the fused linearize kernel keeps a per-workgroup camera table in LDS; beyond ~700 cameras the two-pass
+        // variant (satba_linearize3.h), which has no such table, takes over
+        const bool lin1_fits = lin1_lds(p, false) <= 158 * 1024;
+        if (schur_lds(p) > 160 * 1024)
+            return fail(SATBA_E_ARG, "n_cam = %d exceeds the LDS budget of the Schur kernels of this build", p->M);
+        if (lin1_fits) {
+            SATBA_DISPATCH(p, TRY(raise_lds_limit(k_linearize<MODEL, NP, false, CL>, lin1_lds(p, false))));
+            SATBA_DISPATCH(p, TRY(raise_lds_limit(k_linearize<MODEL, NP, true, CL>, lin1_lds(p, true))));
+        }
         SATBA_DISPATCH(p, TRY(raise_lds_limit(k_schur<MODEL, NP>, schur_lds(p))));
         {   // Schur panel configuration: T cameras per panel so that panel (+ camera table) fit the 160 KB LDS
             const size_t budget = 160 * 1024 - 1024;  // static LDS of the kernel and alignment slack
             const size_t col_bytes = sizeof(double) * ((size_t)p->NP * p->n_c + p->NP);  // per camera of the tile
             const size_t camc_bytes = sizeof(double) * (size_t)p->M * CAMC;
-            int T = 0, camc_lds = 0;
-            if (camc_bytes + col_bytes <= budget) { camc_lds = 1; T = (int)((budget - camc_bytes) / col_bytes); }
-            else if (col_bytes <= budget) T = (int)(budget / col_bytes);
+            int T = 0;
+            const int camc_lds = p->camc_lds;
+            const size_t table = camc_lds ? camc_bytes : 0;
+            if (table + col_bytes <= budget) T = (int)((budget - table) / col_bytes);
             if (T > SCHUR_MAX_T) T = SCHUR_MAX_T;
             if (T > p->M) T = p->M;
             if (getenv("SATBA_SCHUR_V1")) T = 0;
@@ -355,7 +393,7 @@ int satba_problem_create(const satba_problem_desc* d, satba_problem** out) {
                 while (chunks > 1 && (size_t)chunks * p->n_c * p->n_c * sizeof(double) > ((size_t)1 << 30)) --chunks;
                 p->sch_chunks = chunks;
                 p->sch_lds = col_bytes * T + (camc_lds ? camc_bytes : 0);
-                SATBA_DISPATCH(p, TRY(raise_lds_limit(k_schur_panel<MODEL, NP>, p->sch_lds)));
+                SATBA_DISPATCH(p, TRY(raise_lds_limit(k_schur_panel<MODEL, NP, CL>, p->sch_lds)));
                 TRY(dev_alloc(p, &p->d_S_part, (size_t)chunks * p->n_c * p->n_c));
                 TRY(dev_alloc(p, &p->d_rhs_part, (size_t)chunks * p->n_c));
             }
@@ -381,42 +419,29 @@ int satba_problem_create(const satba_problem_desc* d, satba_problem** out) {
         TRY(dev_alloc(p, &p->d_dch, p->n_c));
         TRY(dev_alloc(p, &p->d_dinv, cholesky_workspace_doubles(p->n_c)));
         TRY(dev_alloc(p, &p->d_scal, 8));
-        p->lin_grid = grid_for(p->n_tiles, TILE_WAVES, MAX_TILE_GRID);
-        {   // linearize v2 configuration
-            const int CU = cam_acc_len(p->NP);
-            const int block = CU <= 20 ? 512 : 256, waves = block / 64;
-            const int n_super = (p->n_tiles + waves - 1) / waves;
-            // exact bucket capacity: the largest number of observations one camera has in one super-tile
-            int cap = 1;
-            {
-                std::vector<int> count(p->M, 0), touched;
-                for (int st = 0; st < n_super; ++st) {
-                    const int t0 = st * waves, t1 = std::min(p->n_tiles, t0 + waves);
-                    touched.clear();
-                    for (int o = tile_start[t0]; o < tile_start[t1]; ++o) {
-                        const int cc = d->cam_ind[o];
-                        if (count[cc]++ == 0) touched.push_back(cc);
-                    }
-                    for (int cc : touched) { cap = std::max(cap, count[cc]); count[cc] = 0; }
-                }
+        p->lin_grid = grid_for(p->n_tiles, 16, lin1_lds(p, false) <= 78 * 1024 ? 512 : 256);
+        TRY(dev_alloc(p, &p->d_part, (size_t)p->lin_grid * p->M * cam_acc_len(p->NP)));
+        {   // linearize v3 (default): SATBA_LIN=1|2 selects the older variants
+            const char* sel = getenv("SATBA_LIN");
+            const int which = (sel ? atoi(sel) : 1) + (lin1_fits ? 0 : 2);
+            if (which >= 3 && K > 0) {
+                int chunks = (2048 + p->M - 1) / p->M;
+                if (chunks > 64) chunks = 64;
+                while (chunks > 1 && K / ((long long)p->M * chunks) < 512) --chunks;  // keep >= ~2 obs per thread
+                p->lin3_chunks = chunks;
+                p->lin3_grid = grid_for(p->N, 256, 256 * 4);
+                TRY(dev_alloc(p, &p->d_cm_obs, K)); TRY(dev_alloc(p, &p->d_cm_w, K)); TRY(dev_alloc(p, &p->d_cm_pt, K));
+                TRY(dev_alloc(p, &p->d_part3, (size_t)p->M * chunks * cam_acc_len(p->NP)));
+                std::vector<double> tmp(2 * (size_t)K);
+                for (long long i = 0; i < K; ++i) { tmp[2 * i] = d->pts2d[2 * (size_t)cam_obs[i]]; tmp[2 * i + 1] = d->pts2d[2 * (size_t)cam_obs[i] + 1]; }
+                HIP_TRY(hipMemcpy(p->d_cm_obs, tmp.data(), sizeof(double) * 2 * K, hipMemcpyHostToDevice));
+                for (long long i = 0; i < K; ++i) tmp[i] = d->weights[cam_obs[i]];
+                HIP_TRY(hipMemcpy(p->d_cm_w, tmp.data(), sizeof(double) * K, hipMemcpyHostToDevice));
+                std::vector<int> tmpi(K);
+                for (long long i = 0; i < K; ++i) tmpi[i] = d->pts_ind[cam_obs[i]];
+                HIP_TRY(hipMemcpy(p->d_cm_pt, tmpi.data(), sizeof(int) * K, hipMemcpyHostToDevice));
             }
-            if ((size_t)cap * p->M * 2 > 24 * 1024) cap = std::max(8, (int)(24 * 1024 / ((size_t)p->M * 2)));  // rest overflows
-            const size_t fixed = sizeof(double) * (size_t)CU * block + sizeof(unsigned) * 2 * p->M + (size_t)p->M * cap * 2 + 16;
-            const size_t camc_bytes = sizeof(double) * (size_t)p->M * CAMC;
-            const size_t budget = 160 * 1024 - 2048;
-            const bool owners_ok = (size_t)p->M * CU <= (size_t)LIN2_MAXACC * block;
-            if (owners_ok && fixed <= budget && !getenv("SATBA_LIN_V1") && p->n_tiles > 0) {
-                p->lin2_camc_lds = (fixed + camc_bytes <= budget) ? 1 : 0;
-                p->lin2_lds = fixed + (p->lin2_camc_lds ? camc_bytes : 0);
-                p->lin2_cap = cap;
-                const int per_cu = (p->lin2_lds <= 76 * 1024) ? 2 : 1;
-                p->lin2_grid = std::min(n_super, 256 * per_cu);
-                SATBA_DISPATCH(p, TRY(raise_lds_limit(k_linearize2<MODEL, NP, false>, p->lin2_lds)));
-                SATBA_DISPATCH(p, TRY(raise_lds_limit(k_linearize2<MODEL, NP, true>, p->lin2_lds)));
-            }
-            TRY(dev_alloc(p, &p->d_overflow, (size_t)p->M * CU));
         }
-        TRY(dev_alloc(p, &p->d_part, (size_t)std::max(p->lin_grid, p->lin2_grid) * p->M * cam_acc_len(p->NP)));
         p->xb_len = satba_exchange_len(p);
         TRY(dev_alloc(p, &p->d_xb_own, p->xb_len));
         p->d_xb = p->d_xb_own;
@@ -542,8 +567,14 @@ int satba_linearize(satba_problem* p) {
     double* U = p->payload();
     double* gc = U + (size_t)p->M * p->NP * p->NP;
     const int total = p->M * cam_acc_len(p->NP);
+    if (p->lin3_chunks > 0) {
+        hipLaunchKernelGGL(k_lin3_finish, dim3((total + 255) / 256), dim3(256), 0, p->stream, p->M, p->NP, p->lin3_chunks, p->d_part3, U, gc);
+        HIP_TRY(hipGetLastError());
+        p->linearized = true; p->have_step = false;
+        return 0;
+    }
     hipLaunchKernelGGL(k_lin_finish, dim3((total + 63) / 64), dim3(1024), 0, p->stream, p->M, p->NP, lin_partials(p), p->d_part,
-                       p->lin2_grid > 0 ? p->d_overflow : nullptr, U, gc);
+                       nullptr, U, gc);
     HIP_TRY(hipGetLastError());
     p->linearized = true; p->have_step = false;
     return 0;

@@ -85,6 +85,20 @@ struct ObsEval {
     }
 };
 
+// Camera-constant table access.  CL = true: the workgroup stages the whole table in dynamic LDS once and every
+// lookup is a ds_read (the pointer never merges with a global one, so no FLAT instructions are generated);
+// CL = false (table too large for LDS): gathers from global memory through L1.
+template <bool CL>
+__device__ inline const double* cam_table(const ObsArgs& a, double* s_camc, int nthreads) {
+    if constexpr (CL) {
+        for (int i = threadIdx.x; i < a.M * CAMC; i += nthreads) s_camc[i] = a.camc[i];
+        __syncthreads();
+        return s_camc;
+    } else {
+        return a.camc;
+    }
+}
+
 __device__ inline double wave_sum(double v) {
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) v += __shfl_down(v, d);
@@ -148,12 +162,15 @@ __global__ void k_cam_consts(int model, int M, int n_p, int c_p, const double* _
 // ------------------------------------------------------------------------------------------------ K1 residuals
 // ba_core.fun (ref:bundle_adjust/ba_core.py:157-183): one thread per observation, grid-stride.
 // hdr_cost += 0.5 * sum rho.  f may be null (cost only).
-template <int MODEL, int NP>
+template <int MODEL, int NP, bool CL>
 __global__ __launch_bounds__(512) void k_residual(ObsArgs a, double2* __restrict__ f, double* __restrict__ hdr_cost) {
+    extern __shared__ double s_camc_res[];
+    const double* cbase = cam_table<CL>(a, s_camc_res, 512);
     double acc = 0.0;
     for (long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x; o < a.K; o += (long long)gridDim.x * blockDim.x) {
         ObsEval<MODEL, NP, false> e;
-        e.eval(a, o, a.cam[o], a.pt[o]);
+        const int cam = a.cam[o];
+        e.eval(a, o, cam, a.pt[o], cbase + (size_t)cam * CAMC);
         if (f) f[o] = make_double2(e.ftrue[0], e.ftrue[1]);
         acc += e.rho;
     }
@@ -166,86 +183,121 @@ __global__ __launch_bounds__(512) void k_residual(ObsArgs a, double2* __restrict
 // residual + analytic Jacobian -> normal-equation blocks (replaces scipy's finite differences,
 // scipy:optimize/_numdiff.py:628-705, and compute_grad, scipy:optimize/_lsq/common.py:590-595):
 //   f[o]            true residual pair                        (16 B / obs written)
-//   V[pt] (6), g_p  per-point blocks, plain stores by the run's first lane   (72 B / point written)
-//   part[block][M][cam_acc_len]   per-workgroup camera partials (upper triangle of U_c, then g_c)
+//   V[pt] (6), g_p  per-point blocks: the 9 products of a tile are staged in the wave's LDS rows and lane (run, value)
+//                   sums its run -- 9 ds_write + ~10 ds_read per tile instead of 108 ds_bpermute (72 B / point written)
+//   part[block][M][cam_acc_len]   per-workgroup camera partials (upper triangle of U_c, then g_c), accumulated with
+//                   ds_add_f64 in an LDS table (measured ~3 lanes/clk/CU, tools/ubench/lds_atomics.hip)
 //   hdr[0] += cost;  hdr[slot] = max |g_p|
-template <int MODEL, int NP>
-__global__ __launch_bounds__(TILE_THREADS) void k_linearize(ObsArgs a, double2* __restrict__ f, double* __restrict__ V,
-                                                            double* __restrict__ gp, double* __restrict__ part,
-                                                            double* __restrict__ hdr_cost, double* __restrict__ hdr_gpmax) {
+// Camera constants come from an LDS copy of the table (CL); linear loss is specialised at compile time (ROBUST).
+template <bool ROBUST>
+struct LinCfg {
+    static constexpr int THREADS = ROBUST ? 512 : 1024;  // the robust variants need > 128 VGPRs
+    static constexpr int WAVES = THREADS / 64;
+};
+
+// LDS layout (dynamic): camera accumulators [M][CU] | camera constants [M][CAMC] (if CL) | per-wave staging [WAVES][9][64]
+template <int MODEL, int NP, bool ROBUST, bool CL>
+__global__ __launch_bounds__(LinCfg<ROBUST>::THREADS) void k_linearize(ObsArgs a, double2* __restrict__ f, double* __restrict__ V,
+                                                                      double* __restrict__ gp, double* __restrict__ part,
+                                                                      double* __restrict__ hdr_cost, double* __restrict__ hdr_gpmax) {
     constexpr int CU = cam_acc_len(NP);
-    extern __shared__ double s_acc[];  // M * CU
+    constexpr int THREADS = LinCfg<ROBUST>::THREADS, WAVES = LinCfg<ROBUST>::WAVES;
+    extern __shared__ double s_lin[];
+    double* s_acc = s_lin;                                          // M * CU
+    double* s_camc = s_acc + (size_t)a.M * CU;                      // M * CAMC
+    double* s_stage = s_camc + (CL ? (size_t)a.M * CAMC : 0);       // WAVES * 9 * 64
+    __shared__ unsigned char s_seg[WAVES][66];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int i = threadIdx.x; i < a.M * CU; i += TILE_THREADS) s_acc[i] = 0.0;
+    for (int i = threadIdx.x; i < a.M * CU; i += THREADS) s_acc[i] = 0.0;
+    if constexpr (CL)
+        for (int i = threadIdx.x; i < a.M * CAMC; i += THREADS) s_camc[i] = a.camc[i];
     __syncthreads();
+    const double* cbase;
+    if constexpr (CL) cbase = s_camc; else cbase = a.camc;
+    double* stage = s_stage + (size_t)wave * 9 * 64;
 
     double cost = 0.0, gmax = 0.0;
-    for (int tile = blockIdx.x * TILE_WAVES + wave; tile < a.n_tiles; tile += gridDim.x * TILE_WAVES) {
+    for (int tile = blockIdx.x * WAVES + wave; tile < a.n_tiles; tile += gridDim.x * WAVES) {
         const int o0 = a.tile_start[tile], o1 = a.tile_start[tile + 1];
         const long long o = (long long)o0 + lane;
         const bool active = o < o1;
         int pt = -1 - lane, cam = 0;
-        double v[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
         if (active) {
             cam = a.cam[o];
             pt = a.pt[o];
-            ObsEval<MODEL, NP, true> e;
-            e.eval(a, o, cam, pt);
+            ObsEval<MODEL, NP, true, ROBUST> e;
+            e.eval(a, o, cam, pt, cbase + (size_t)cam * CAMC);
             f[o] = make_double2(e.ftrue[0], e.ftrue[1]);
             cost += e.rho;
-            v[0] = e.Jp[0][0] * e.Jp[0][0] + e.Jp[1][0] * e.Jp[1][0];
-            v[1] = e.Jp[0][0] * e.Jp[0][1] + e.Jp[1][0] * e.Jp[1][1];
-            v[2] = e.Jp[0][0] * e.Jp[0][2] + e.Jp[1][0] * e.Jp[1][2];
-            v[3] = e.Jp[0][1] * e.Jp[0][1] + e.Jp[1][1] * e.Jp[1][1];
-            v[4] = e.Jp[0][1] * e.Jp[0][2] + e.Jp[1][1] * e.Jp[1][2];
-            v[5] = e.Jp[0][2] * e.Jp[0][2] + e.Jp[1][2] * e.Jp[1][2];
-            v[6] = e.Jp[0][0] * e.fs[0] + e.Jp[1][0] * e.fs[1];
-            v[7] = e.Jp[0][1] * e.fs[0] + e.Jp[1][1] * e.fs[1];
-            v[8] = e.Jp[0][2] * e.fs[0] + e.Jp[1][2] * e.fs[1];
+            // per-point products into the wave's staging rows (conflict-free 8-byte stores)
+            stage[0 * 64 + lane] = e.Jp[0][0] * e.Jp[0][0] + e.Jp[1][0] * e.Jp[1][0];
+            stage[1 * 64 + lane] = e.Jp[0][0] * e.Jp[0][1] + e.Jp[1][0] * e.Jp[1][1];
+            stage[2 * 64 + lane] = e.Jp[0][0] * e.Jp[0][2] + e.Jp[1][0] * e.Jp[1][2];
+            stage[3 * 64 + lane] = e.Jp[0][1] * e.Jp[0][1] + e.Jp[1][1] * e.Jp[1][1];
+            stage[4 * 64 + lane] = e.Jp[0][1] * e.Jp[0][2] + e.Jp[1][1] * e.Jp[1][2];
+            stage[5 * 64 + lane] = e.Jp[0][2] * e.Jp[0][2] + e.Jp[1][2] * e.Jp[1][2];
+            stage[6 * 64 + lane] = e.Jp[0][0] * e.fs[0] + e.Jp[1][0] * e.fs[1];
+            stage[7 * 64 + lane] = e.Jp[0][1] * e.fs[0] + e.Jp[1][1] * e.fs[1];
+            stage[8 * 64 + lane] = e.Jp[0][2] * e.fs[0] + e.Jp[1][2] * e.fs[1];
             // camera block: LDS atomics (ds_add_f64) into this workgroup's table
             double* acc = s_acc + (size_t)cam * CU;
             int k = 0;
+#ifndef SATBA_ABLATE_CAM_ATOMICS
 #pragma unroll
             for (int i = 0; i < NP; ++i)
 #pragma unroll
                 for (int j = i; j < NP; ++j) atomicAdd(acc + (k++), e.Jc[0][i] * e.Jc[0][j] + e.Jc[1][i] * e.Jc[1][j]);
 #pragma unroll
             for (int i = 0; i < NP; ++i) atomicAdd(acc + (k++), e.Jc[0][i] * e.fs[0] + e.Jc[1][i] * e.fs[1]);
+#else  // ablation build only (tools): keep the products alive with ONE atomic
+            double t = 0.0;
+#pragma unroll
+            for (int i = 0; i < NP; ++i)
+#pragma unroll
+                for (int j = i; j < NP; ++j) t += e.Jc[0][i] * e.Jc[0][j] + e.Jc[1][i] * e.Jc[1][j];
+#pragma unroll
+            for (int i = 0; i < NP; ++i) t += e.Jc[0][i] * e.fs[0] + e.Jc[1][i] * e.fs[1];
+            atomicAdd(acc + k, t);
+#endif
         }
-        seg_reduce<9>(v, pt, lane);
+#ifndef SATBA_ABLATE_POINT_SUMS
+        // runs of equal point index -> lane (q, v) sums value v over run q (7 runs per pass); no shuffles
         const int prev = __shfl_up(pt, 1);
         const bool head = active && (lane == 0 || prev != pt);
-        if (head) {
-            double* Vp = V + 6 * (size_t)pt;
-            double* gq = gp + 3 * (size_t)pt;
-            if (a.tile_split[tile]) {
-#pragma unroll
-                for (int k = 0; k < 6; ++k) atomicAdd(Vp + k, v[k]);
-#pragma unroll
-                for (int k = 0; k < 3; ++k) atomicAdd(gq + k, v[6 + k]);
-            } else {
-#pragma unroll
-                for (int k = 0; k < 6; ++k) Vp[k] = v[k];
-#pragma unroll
-                for (int k = 0; k < 3; ++k) gq[k] = v[6 + k];
+        const unsigned long long heads = __ballot(head);
+        const int n_runs = __popcll(heads);
+        if (head) s_seg[wave][__popcll(heads & ((1ull << lane) - 1ull))] = (unsigned char)lane;
+        if (lane == 0) s_seg[wave][n_runs] = (unsigned char)(o1 - o0);
+        for (int q0 = 0; q0 < n_runs; q0 += 7) {
+            const int q = q0 + lane / 9, v = lane % 9;
+            if (lane < 63 && q < n_runs) {
+                const int b = s_seg[wave][q], en = s_seg[wave][q + 1];
+                const double* col = stage + v * 64;
+                double sum = 0.0;
+                for (int l = b; l < en; ++l) sum += col[l];
+                const int ptq = a.pt[o0 + b];
+                double* dst = (v < 6) ? V + 6 * (size_t)ptq + v : gp + 3 * (size_t)ptq + (v - 6);
+                if (a.tile_split[tile]) atomicAdd(dst, sum);
+                else *dst = sum;
+                if (v >= 6) gmax = fmax(gmax, fabs(sum));
             }
-            gmax = fmax(gmax, fmax(fabs(v[6]), fmax(fabs(v[7]), fabs(v[8]))));
         }
+#endif
     }
     // per-workgroup epilogue
-    __shared__ double s_red[2][TILE_WAVES];
+    __shared__ double s_red[2][WAVES];
     cost = wave_sum(cost);
     gmax = wave_max(gmax);
     if (lane == 0) { s_red[0][wave] = cost; s_red[1][wave] = gmax; }
     __syncthreads();
     if (threadIdx.x == 0) {
         double c = 0.0, g = 0.0;
-        for (int i = 0; i < TILE_WAVES; ++i) { c += s_red[0][i]; g = fmax(g, s_red[1][i]); }
+        for (int i = 0; i < WAVES; ++i) { c += s_red[0][i]; g = fmax(g, s_red[1][i]); }
         atomicAdd(hdr_cost, 0.5 * c);
         atomic_max_pos(hdr_gpmax, g);
     }
     double* out = part + (size_t)blockIdx.x * a.M * CU;
-    for (int i = threadIdx.x; i < a.M * CU; i += TILE_THREADS) out[i] = s_acc[i];
+    for (int i = threadIdx.x; i < a.M * CU; i += THREADS) out[i] = s_acc[i];
 }
 
 // sum the per-workgroup camera partials and expand to the exchange payload: U (M x NP x NP, full), g_c (M x NP).
@@ -333,14 +385,16 @@ __global__ __launch_bounds__(256) void k_prepare_vec(int n, int n_c, int NP, int
 // ------------------------------------------------------------------------------------------------ Jacobian-vector products
 // For NV vectors given in scaled variables (v = q / scale_inv): sums of (J v_a) . (J v_b) over the observations.
 // NV = 1: out[0] += |J v1|^2.   NV = 2: out[0] += |J v1|^2, out[1] += (J v1).(J v2), out[2] += |J v2|^2.
-template <int MODEL, int NP, int NV>
+template <int MODEL, int NP, int NV, bool CL>
 __global__ __launch_bounds__(512) void k_jvp(ObsArgs a, const double* __restrict__ q1, const double* __restrict__ q2,
                                              const double* __restrict__ scale_inv, double* __restrict__ out) {
+    extern __shared__ double s_camc_jvp[];
+    const double* cbase = cam_table<CL>(a, s_camc_jvp, 512);
     double s11 = 0.0, s12 = 0.0, s22 = 0.0;
     for (long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x; o < a.K; o += (long long)gridDim.x * blockDim.x) {
         const int cam = a.cam[o], pt = a.pt[o];
         ObsEval<MODEL, NP, true> e;
-        e.eval(a, o, cam, pt);
+        e.eval(a, o, cam, pt, cbase + (size_t)cam * CAMC);
         const size_t ic = (size_t)cam * NP, ip = (size_t)a.n_c + 3 * (size_t)pt;
         double j1[2] = {0, 0}, j2[2] = {0, 0};
 #pragma unroll
@@ -564,7 +618,7 @@ struct SchurArgs {
 constexpr int SCHUR_THREADS = 1024;
 constexpr int SCHUR_MAX_T = 16;
 
-template <int MODEL, int NP>
+template <int MODEL, int NP, bool CL>
 __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_panel(ObsArgs a, SchurArgs s) {
     extern __shared__ double s_lds[];
     const int n_c = a.n_c;
@@ -576,7 +630,7 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_panel(ObsArgs a, SchurA
     __shared__ int s_lo[SCHUR_MAX_T], s_cnt[SCHUR_MAX_T + 1];
 
     for (int i = threadIdx.x; i < s.T * NP * n_c + s.T * NP; i += SCHUR_THREADS) panel[i] = 0.0;
-    if (s.camc_in_lds)
+    if constexpr (CL)
         for (int i = threadIdx.x; i < a.M * CAMC; i += SCHUR_THREADS) s_camc[i] = a.camc[i];
     const long long obs_lo = a.K * chunk / s.n_chunks, obs_hi = a.K * (chunk + 1) / s.n_chunks;
     if (threadIdx.x < nt) {  // sub-range of camera i0 + t's list that falls into this chunk (binary searches)
@@ -596,7 +650,8 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_panel(ObsArgs a, SchurA
     }
     __syncthreads();
     const int total = s_cnt[nt];
-    const double* cbase = s.camc_in_lds ? s_camc : a.camc;
+    const double* cbase;
+    if constexpr (CL) cbase = s_camc; else cbase = a.camc;
 
     for (int idx = threadIdx.x; idx < total; idx += SCHUR_THREADS) {
         int t = 0;
@@ -697,8 +752,10 @@ __global__ void k_unscale(int n_c, const double* __restrict__ scale_inv, const d
 
 // ------------------------------------------------------------------------------------------------ K5 back-substitution
 // t_p = sum_obs Jp^T (Jc dc[cam])  per point (segmented wave reduction)
-template <int MODEL, int NP>
+template <int MODEL, int NP, bool CL>
 __global__ __launch_bounds__(256) void k_backsub(ObsArgs a, const double* __restrict__ dc, double* __restrict__ tbuf) {
+    extern __shared__ double s_camc_bs[];
+    const double* cbase = cam_table<CL>(a, s_camc_bs, 256);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int tile = blockIdx.x * 4 + wave; tile < a.n_tiles; tile += gridDim.x * 4) {
         const int o0 = a.tile_start[tile], o1 = a.tile_start[tile + 1];
@@ -710,7 +767,7 @@ __global__ __launch_bounds__(256) void k_backsub(ObsArgs a, const double* __rest
             const int cam = a.cam[o];
             pt = a.pt[o];
             ObsEval<MODEL, NP, true> e;
-            e.eval(a, o, cam, pt);
+            e.eval(a, o, cam, pt, cbase + (size_t)cam * CAMC);
             double u0 = 0.0, u1 = 0.0;
 #pragma unroll
             for (int i = 0; i < NP; ++i) {

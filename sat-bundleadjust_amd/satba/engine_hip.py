@@ -16,7 +16,7 @@ from .rpc_model import rpc_to_table
 from .sharding import Shard
 
 _LIB = None
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libsatba_hip.so")
+LIB_PATH = os.environ.get("SATBA_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libsatba_hip.so")
 
 CAM_MODELS = {"affine": 0, "perspective": 1, "rpc": 2}
 LOSSES = {"linear": 0, "soft_l1": 1, "huber": 2, "cauchy": 3, "arctan": 4}
