@@ -19,6 +19,7 @@
 #include "satba_chol.h"
 #include "satba_kernels.h"
 #include "satba_linearize3.h"
+#include "satba_schur3.h"
 
 using namespace satba;
 
@@ -76,6 +77,10 @@ struct satba_problem {
     double* d_cm_w = nullptr;
     int* d_cm_pt = nullptr;
     double* d_part3 = nullptr;
+    // Schur v3 (camera-pair intersection): sch3_chunks == 0: not used
+    int sch3_chunks = 0, NW = 0;
+    unsigned long long* d_bits = nullptr;
+    int* d_rank = nullptr;
     int* d_fail = nullptr;
     double* d_scal = nullptr;  // 8 private scalars (costs of satba_residuals, timing sinks)
     double *d_xb_own = nullptr, *d_xb = nullptr;
@@ -208,7 +213,7 @@ static int launch_lin1(satba_problem* p, const ObsArgs& a) {
 
 static int launch_linearize_kernel(satba_problem* p) {
     ObsArgs a = obs_args(p, false);
-    if (p->lin3_chunks > 0) {
+    if (p->lin3_grid > 0) {
         SATBA_DISPATCH(p, TRY((launch_lin3<MODEL, NP, CL>(p, a))));
         return 0;
     }
@@ -218,10 +223,37 @@ static int launch_linearize_kernel(satba_problem* p) {
 
 static size_t schur_lds(const satba_problem* p) { return sizeof(double) * ((size_t)4 * 64 * p->NP * 3 + p->n_c); }
 
+template <int MODEL, int NP>
+static int launch_schur3(satba_problem* p, const ObsArgs& a, double* S, double* rhs) {
+    CamMajor cm;
+    cm.cam_ofs = p->d_cam_ofs; cm.obs = p->d_cm_obs; cm.w = p->d_cm_w; cm.pt = p->d_cm_pt;
+    Schur3Args s;
+    s.bits = p->d_bits; s.rank = p->d_rank; s.Vinv = p->d_Vinv; s.gp = p->d_g + p->n_c; s.NW = p->NW; s.n_chunks = p->sch3_chunks;
+    const long long items = (long long)p->M * (p->M - 1) / 2 * p->sch3_chunks;
+    const int diag_chunks = p->lin3_chunks;
+    if (p->loss == 0) {
+        if (items > 0) hipLaunchKernelGGL((k_schur_pairs<MODEL, NP, false>), dim3((unsigned)((items + 3) / 4)), dim3(256), 0, p->stream, a, cm, s, S);
+        hipLaunchKernelGGL((k_schur_diag<MODEL, NP, false>), dim3(diag_chunks, p->M), dim3(LINC_THREADS), 0, p->stream, a, cm, s, p->d_part3);
+    } else {
+        if (items > 0) hipLaunchKernelGGL((k_schur_pairs<MODEL, NP, true>), dim3((unsigned)((items + 3) / 4)), dim3(256), 0, p->stream, a, cm, s, S);
+        hipLaunchKernelGGL((k_schur_diag<MODEL, NP, true>), dim3(diag_chunks, p->M), dim3(LINC_THREADS), 0, p->stream, a, cm, s, p->d_part3);
+    }
+    HIP_TRY(hipGetLastError());
+    const int total = p->M * cam_acc_len(p->NP);
+    hipLaunchKernelGGL(k_schur_diag_finish, dim3((total + 255) / 256), dim3(256), 0, p->stream, p->M, p->NP, p->n_c, diag_chunks,
+                       p->d_part3, S, rhs);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 static int launch_schur_kernel(satba_problem* p) {
     ObsArgs a = obs_args(p, false);
     double* S = p->payload();
     double* rhs = S + (size_t)p->n_c * p->n_c;
+    if (p->sch3_chunks > 0) {  // v3: camera-pair intersection, register accumulation
+        SATBA_DISPATCH(p, TRY((launch_schur3<MODEL, NP>(p, a, S, rhs))));
+        return 0;
+    }
     if (p->sch_T > 0) {  // v2: LDS column panels, no global atomics
         SchurArgs s;
         s.cam_ofs = p->d_cam_ofs; s.cam_obs = p->d_cam_obs; s.pt_ofs = p->d_pt_ofs;
@@ -421,26 +453,52 @@ int satba_problem_create(const satba_problem_desc* d, satba_problem** out) {
         TRY(dev_alloc(p, &p->d_scal, 8));
         p->lin_grid = grid_for(p->n_tiles, 16, lin1_lds(p, false) <= 78 * 1024 ? 512 : 256);
         TRY(dev_alloc(p, &p->d_part, (size_t)p->lin_grid * p->M * cam_acc_len(p->NP)));
-        {   // linearize v3 (default): SATBA_LIN=1|2 selects the older variants
+        {   // camera-major copy of the observation data (Schur v3, linearize v3) and chunking of the camera passes
             const char* sel = getenv("SATBA_LIN");
             const int which = (sel ? atoi(sel) : 1) + (lin1_fits ? 0 : 2);
-            if (which >= 3 && K > 0) {
-                int chunks = (2048 + p->M - 1) / p->M;
-                if (chunks > 64) chunks = 64;
-                while (chunks > 1 && K / ((long long)p->M * chunks) < 512) --chunks;  // keep >= ~2 obs per thread
-                p->lin3_chunks = chunks;
-                p->lin3_grid = grid_for(p->N, 256, 256 * 4);
-                TRY(dev_alloc(p, &p->d_cm_obs, K)); TRY(dev_alloc(p, &p->d_cm_w, K)); TRY(dev_alloc(p, &p->d_cm_pt, K));
-                TRY(dev_alloc(p, &p->d_part3, (size_t)p->M * chunks * cam_acc_len(p->NP)));
-                std::vector<double> tmp(2 * (size_t)K);
-                for (long long i = 0; i < K; ++i) { tmp[2 * i] = d->pts2d[2 * (size_t)cam_obs[i]]; tmp[2 * i + 1] = d->pts2d[2 * (size_t)cam_obs[i] + 1]; }
-                HIP_TRY(hipMemcpy(p->d_cm_obs, tmp.data(), sizeof(double) * 2 * K, hipMemcpyHostToDevice));
-                for (long long i = 0; i < K; ++i) tmp[i] = d->weights[cam_obs[i]];
-                HIP_TRY(hipMemcpy(p->d_cm_w, tmp.data(), sizeof(double) * K, hipMemcpyHostToDevice));
-                std::vector<int> tmpi(K);
-                for (long long i = 0; i < K; ++i) tmpi[i] = d->pts_ind[cam_obs[i]];
-                HIP_TRY(hipMemcpy(p->d_cm_pt, tmpi.data(), sizeof(int) * K, hipMemcpyHostToDevice));
+            int chunks = (2048 + p->M - 1) / p->M;
+            if (chunks > 64) chunks = 64;
+            while (chunks > 1 && K / ((long long)p->M * chunks) < 512) --chunks;  // keep >= ~2 obs per thread
+            TRY(dev_alloc(p, &p->d_cm_obs, K)); TRY(dev_alloc(p, &p->d_cm_w, K)); TRY(dev_alloc(p, &p->d_cm_pt, K));
+            TRY(dev_alloc(p, &p->d_part3, (size_t)p->M * chunks * cam_acc_len(p->NP)));
+            std::vector<double> tmp(2 * (size_t)K + 1);
+            for (long long i = 0; i < K; ++i) { tmp[2 * i] = d->pts2d[2 * (size_t)cam_obs[i]]; tmp[2 * i + 1] = d->pts2d[2 * (size_t)cam_obs[i] + 1]; }
+            HIP_TRY(hipMemcpy(p->d_cm_obs, tmp.data(), sizeof(double) * 2 * K, hipMemcpyHostToDevice));
+            for (long long i = 0; i < K; ++i) tmp[i] = d->weights[cam_obs[i]];
+            HIP_TRY(hipMemcpy(p->d_cm_w, tmp.data(), sizeof(double) * K, hipMemcpyHostToDevice));
+            std::vector<int> tmpi(K + 1);
+            for (long long i = 0; i < K; ++i) tmpi[i] = d->pts_ind[cam_obs[i]];
+            HIP_TRY(hipMemcpy(p->d_cm_pt, tmpi.data(), sizeof(int) * K, hipMemcpyHostToDevice));
+            p->lin3_chunks = chunks;  // chunk count of the camera-major passes (also used by k_schur_diag)
+            p->lin3_grid = (which >= 3 && K > 0) ? grid_for(p->N, 256, 256 * 4) : 0;
+
+            // Schur v3: visibility bitmaps and ranks.  Scan cost grows with M^2 N / 64: beyond 512 cameras the
+            // panel kernel (v2) is used instead.  SATBA_SCHUR=1|2 forces the older variants.
+            const char* ssel = getenv("SATBA_SCHUR");
+            const int swhich = ssel ? atoi(ssel) : 3;
+            if (swhich >= 3 && p->M <= 512 && K > 0) {
+                const int NW = (p->N + 63) / 64;
+                p->NW = NW;
+                std::vector<unsigned long long> bits((size_t)p->M * NW, 0ull);
+                for (long long o = 0; o < K; ++o)
+                    bits[(size_t)d->cam_ind[o] * NW + (d->pts_ind[o] >> 6)] |= 1ull << (d->pts_ind[o] & 63);
+                std::vector<int> rank((size_t)p->M * NW);
+                for (int cc = 0; cc < p->M; ++cc) {
+                    int run = 0;
+                    for (int w = 0; w < NW; ++w) { rank[(size_t)cc * NW + w] = run; run += __builtin_popcountll(bits[(size_t)cc * NW + w]); }
+                }
+                TRY(dev_alloc(p, &p->d_bits, bits.size())); TRY(dev_alloc(p, &p->d_rank, rank.size()));
+                HIP_TRY(hipMemcpy(p->d_bits, bits.data(), sizeof(unsigned long long) * bits.size(), hipMemcpyHostToDevice));
+                HIP_TRY(hipMemcpy(p->d_rank, rank.data(), sizeof(int) * rank.size(), hipMemcpyHostToDevice));
+                const long long n_pairs = (long long)p->M * (p->M - 1) / 2;
+                int sc = 1;
+                if (n_pairs > 0) {
+                    sc = (int)std::min<long long>((8192 + n_pairs - 1) / n_pairs, (NW + 63) / 64);
+                    if (sc < 1) sc = 1;
+                }
+                p->sch3_chunks = sc;
             }
+            if (swhich == 1) p->sch_T = 0;
         }
         p->xb_len = satba_exchange_len(p);
         TRY(dev_alloc(p, &p->d_xb_own, p->xb_len));
@@ -567,7 +625,7 @@ int satba_linearize(satba_problem* p) {
     double* U = p->payload();
     double* gc = U + (size_t)p->M * p->NP * p->NP;
     const int total = p->M * cam_acc_len(p->NP);
-    if (p->lin3_chunks > 0) {
+    if (p->lin3_grid > 0) {
         hipLaunchKernelGGL(k_lin3_finish, dim3((total + 255) / 256), dim3(256), 0, p->stream, p->M, p->NP, p->lin3_chunks, p->d_part3, U, gc);
         HIP_TRY(hipGetLastError());
         p->linearized = true; p->have_step = false;

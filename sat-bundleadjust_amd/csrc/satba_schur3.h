@@ -1,0 +1,250 @@
+// satba_schur3.h -- K3 v3: Schur complement by camera-pair intersection.  No atomics on the data path,
+// everything accumulates in registers.
+//
+//   S_ij -= sum over points p seen by BOTH cameras i and j of  W_ip Vinv_p W_jp^T,   W = Jc^T Jp  (NP x 3)
+//
+// v2 (k_schur_panel) walks observation pairs point by point and scatters NP x NP blocks into an LDS panel with
+// ds_add_f64: PMC showed it LDS-atomic bound at 48 % lane utilisation (profiles/r1_pmc_linearize_schur.txt).
+// v3 turns the scatter into a gather: one wavefront owns ONE camera pair (i, j), finds the points the two cameras
+// share by AND-ing their visibility bitmaps (64 points per word, lane = word), compacts the hits into a small
+// per-wave queue, and evaluates 64 hits at a time with every lane busy.  Both cameras are wave-uniform, so their
+// constants sit in scalar registers; the NP x NP block accumulates in registers and is reduced across the wave
+// once, then stored -- each off-diagonal block of S is written exactly once, no zero-fill, no reduction pass.
+// The diagonal blocks and the right-hand side come from a camera-major pass (k_schur_diag) that also
+// accumulates in registers.
+//
+// Index structures (host, once per problem): visibility bitmaps bits[M][NW], rank[M][NW] = number of
+// observations of the camera before word w, and the camera-major copy of the observation data; the position of
+// (camera, point) in that copy is cam_ofs[c] + rank[c][w] + popcount(bits[c][w] below the point's bit).
+#pragma once
+#include "satba_kernels.h"
+#include "satba_linearize3.h"
+
+namespace satba {
+
+struct Schur3Args {
+    const unsigned long long* __restrict__ bits;  // M x NW
+    const int* __restrict__ rank;                 // M x NW
+    const double* __restrict__ Vinv;              // N x 6
+    const double* __restrict__ gp;                // N x 3
+    int NW;                                       // words per camera
+    int n_chunks;                                 // word-range chunks per pair (1: plain stores, >1: atomics)
+};
+
+constexpr int S3_QUEUE = 128;  // per-wave hit queue (entries): < 64 pending + at most 64 added per round
+
+// weighted, scaled Jacobian blocks of one (camera, point) from the camera-major copy
+template <int MODEL, int NP, bool ROBUST>
+__device__ inline void cm_jacobian(const ObsArgs& a, const CamMajor& c, const double* cc, const double* tab, int cam,
+                                   int pos, int pt, double X, double Y, double Z, double Jc[2][NP], double Jp[2][3]) {
+    const double w = c.w[pos];
+    double u, v;
+    project<MODEL, NP, true>(cc, tab, X, Y, Z, a.f32 != 0, u, v, Jc, Jp);
+    double js0 = 1.0, js1 = 1.0;
+    if constexpr (ROBUST) {
+        const double2 ob = c.obs[pos];
+        double r0, r1, fs0, fs1;
+        robust(a.loss, a.f_scale, w * (u - ob.x), r0, fs0, js0);
+        robust(a.loss, a.f_scale, w * (v - ob.y), r1, fs1, js1);
+    }
+    const double mc = (cam >= a.n_cam_fix) ? 1.0 : 0.0, mp = (pt >= a.n_pts_fix) ? 1.0 : 0.0;
+    const double s0 = w * js0, s1 = w * js1;
+#pragma unroll
+    for (int k = 0; k < NP; ++k) { Jc[0][k] *= s0 * mc; Jc[1][k] *= s1 * mc; }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { Jp[0][k] *= s0 * mp; Jp[1][k] *= s1 * mp; }
+}
+
+// grid: one wave per (pair, chunk); 4 waves per workgroup.  pair index -> (i, j), i < j.
+template <int MODEL, int NP, bool ROBUST>
+__global__ __launch_bounds__(256) void k_schur_pairs(ObsArgs a, CamMajor c, Schur3Args s, double* __restrict__ S) {
+    __shared__ int s_q[4][S3_QUEUE][3];  // (point, position in i's list, position in j's list)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long n_pairs = (long long)a.M * (a.M - 1) / 2;
+    const long long item = (long long)blockIdx.x * 4 + wave;
+    if (item >= n_pairs * s.n_chunks) return;
+    const long long pair = item / s.n_chunks;
+    const int chunk = (int)(item % s.n_chunks);
+    // unrank pair -> (i, j): pairs of row i start at i*M - i*(i+1)/2
+    int i = (int)((2.0 * a.M - 1.0 - sqrt((2.0 * a.M - 1.0) * (2.0 * a.M - 1.0) - 8.0 * (double)pair)) * 0.5);
+    while ((long long)i * a.M - (long long)i * (i + 1) / 2 > pair) --i;
+    while ((long long)(i + 1) * a.M - (long long)(i + 1) * (i + 2) / 2 <= pair) ++i;
+    const int j = i + 1 + (int)(pair - ((long long)i * a.M - (long long)i * (i + 1) / 2));
+
+    const unsigned long long* bi = s.bits + (size_t)i * s.NW;
+    const unsigned long long* bj = s.bits + (size_t)j * s.NW;
+    const int* ri = s.rank + (size_t)i * s.NW;
+    const int* rj = s.rank + (size_t)j * s.NW;
+    const int base_i = c.cam_ofs[i], base_j = c.cam_ofs[j];
+    const double* cci = a.camc + (size_t)i * CAMC;  // wave-uniform: scalar loads
+    const double* ccj = a.camc + (size_t)j * CAMC;
+    const double* tabi = (MODEL == RPC) ? a.rpc + (size_t)i * 90 : nullptr;
+    const double* tabj = (MODEL == RPC) ? a.rpc + (size_t)j * 90 : nullptr;
+
+    double acc[NP][NP];
+#pragma unroll
+    for (int r = 0; r < NP; ++r)
+#pragma unroll
+        for (int q = 0; q < NP; ++q) acc[r][q] = 0.0;
+
+    auto process = [&](int slot, bool valid) {
+        if (!valid) return;
+        const int p = s_q[wave][slot][0], pi = s_q[wave][slot][1], pj = s_q[wave][slot][2];
+        const double* px = a.x + a.n_c + 3 * (size_t)p;
+        const double X = px[0], Y = px[1], Z = px[2];
+        double Jci[2][NP], Jpi[2][3], Jcj[2][NP], Jpj[2][3];
+        cm_jacobian<MODEL, NP, ROBUST>(a, c, cci, tabi, i, pi, p, X, Y, Z, Jci, Jpi);
+        cm_jacobian<MODEL, NP, ROBUST>(a, c, ccj, tabj, j, pj, p, X, Y, Z, Jcj, Jpj);
+        const double* vi = s.Vinv + 6 * (size_t)p;
+        const double v00 = vi[0], v01 = vi[1], v02 = vi[2], v11 = vi[3], v12 = vi[4], v22 = vi[5];
+        // Mm = Jp_i Vinv Jp_j^T (2 x 2)
+        double A[2][3];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            A[r][0] = Jpi[r][0] * v00 + Jpi[r][1] * v01 + Jpi[r][2] * v02;
+            A[r][1] = Jpi[r][0] * v01 + Jpi[r][1] * v11 + Jpi[r][2] * v12;
+            A[r][2] = Jpi[r][0] * v02 + Jpi[r][1] * v12 + Jpi[r][2] * v22;
+        }
+        const double m00 = A[0][0] * Jpj[0][0] + A[0][1] * Jpj[0][1] + A[0][2] * Jpj[0][2];
+        const double m01 = A[0][0] * Jpj[1][0] + A[0][1] * Jpj[1][1] + A[0][2] * Jpj[1][2];
+        const double m10 = A[1][0] * Jpj[0][0] + A[1][1] * Jpj[0][1] + A[1][2] * Jpj[0][2];
+        const double m11 = A[1][0] * Jpj[1][0] + A[1][1] * Jpj[1][1] + A[1][2] * Jpj[1][2];
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            const double y0 = m00 * Jcj[0][q] + m01 * Jcj[1][q];
+            const double y1 = m10 * Jcj[0][q] + m11 * Jcj[1][q];
+#pragma unroll
+            for (int r = 0; r < NP; ++r) acc[r][q] -= Jci[0][r] * y0 + Jci[1][r] * y1;
+        }
+    };
+
+    const int w_lo = (int)((long long)s.NW * chunk / s.n_chunks), w_hi = (int)((long long)s.NW * (chunk + 1) / s.n_chunks);
+    int n_q = 0;  // wave-uniform queue fill
+    for (int w0 = w_lo; w0 < w_hi; w0 += 64) {
+        const int w = w0 + lane;
+        unsigned long long wi = 0, wj = 0;
+        if (w < w_hi) { wi = bi[w]; wj = bj[w]; }
+        unsigned long long m = wi & wj;
+        if (__ballot(m != 0) == 0) continue;
+        int rki = 0, rkj = 0;
+        if (m) { rki = ri[w]; rkj = rj[w]; }
+        // rounds: every lane with a remaining hit emits ONE entry; slots come from a ballot + popcount (no scan).
+        // At most 64 entries are added per round and the queue is drained below 64 after each, so it never overflows.
+        for (;;) {
+            const unsigned long long has = __ballot(m != 0);
+            if (has == 0) break;
+            if (m) {
+                const int off = n_q + __popcll(has & ((1ull << lane) - 1ull));
+                const int bit = __ffsll((long long)m) - 1;
+                const unsigned long long below = (1ull << bit) - 1ull;
+                s_q[wave][off][0] = w * 64 + bit;
+                s_q[wave][off][1] = base_i + rki + __popcll(wi & below);
+                s_q[wave][off][2] = base_j + rkj + __popcll(wj & below);
+                m &= m - 1;
+            }
+            n_q += __popcll(has);
+            if (n_q >= 64) {  // evaluate a full wavefront of hits (the most recent 64 keep the queue compact)
+                process(n_q - 64 + lane, true);
+                n_q -= 64;
+            }
+        }
+    }
+    process(lane, lane < n_q);
+
+    // wave reduction of the NP x NP block; block (row j, col i) of the column-major lower triangle
+    double* Sblk = S + (size_t)(j * NP) + (size_t)(i * NP) * a.n_c;
+#pragma unroll
+    for (int r = 0; r < NP; ++r)
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            const double t = wave_sum(acc[r][q]);
+            if (lane == 0) {
+                double* dst = Sblk + q + (size_t)r * a.n_c;  // S[(j,q), (i,r)] = (W_i Vinv W_j^T)[r][q]
+                if (s.n_chunks > 1) atomicAdd(dst, t);
+                else *dst = t;
+            }
+        }
+}
+
+// Diagonal blocks and right-hand side: camera-major pass, registers only.
+//   S_ii -= sum_p W_ip Vinv W_ip^T,   rhs_i -= sum_p W_ip Vinv g_p.   grid (chunks, M); part [M][chunks][CU]
+template <int MODEL, int NP, bool ROBUST>
+__global__ __launch_bounds__(LINC_THREADS) void k_schur_diag(ObsArgs a, CamMajor c, Schur3Args s, double* __restrict__ part) {
+    constexpr int CU = cam_acc_len(NP);
+    const int cam = blockIdx.y, chunk = blockIdx.x, n_chunks = gridDim.x;
+    const int b = c.cam_ofs[cam], e = c.cam_ofs[cam + 1];
+    const long long len = e - b;
+    const int lo = b + (int)(len * chunk / n_chunks), hi = b + (int)(len * (chunk + 1) / n_chunks);
+    const double* cc = a.camc + (size_t)cam * CAMC;
+    const double* tab = (MODEL == RPC) ? a.rpc + (size_t)cam * 90 : nullptr;
+    double acc[CU];
+#pragma unroll
+    for (int k = 0; k < CU; ++k) acc[k] = 0.0;
+    for (int pos = lo + threadIdx.x; pos < hi; pos += LINC_THREADS) {
+        const int p = c.pt[pos];
+        const double* px = a.x + a.n_c + 3 * (size_t)p;
+        double Jc[2][NP], Jp[2][3];
+        cm_jacobian<MODEL, NP, ROBUST>(a, c, cc, tab, cam, pos, p, px[0], px[1], px[2], Jc, Jp);
+        const double* vi = s.Vinv + 6 * (size_t)p;
+        const double v00 = vi[0], v01 = vi[1], v02 = vi[2], v11 = vi[3], v12 = vi[4], v22 = vi[5];
+        double A[2][3];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            A[r][0] = Jp[r][0] * v00 + Jp[r][1] * v01 + Jp[r][2] * v02;
+            A[r][1] = Jp[r][0] * v01 + Jp[r][1] * v11 + Jp[r][2] * v12;
+            A[r][2] = Jp[r][0] * v02 + Jp[r][1] * v12 + Jp[r][2] * v22;
+        }
+        const double m00 = A[0][0] * Jp[0][0] + A[0][1] * Jp[0][1] + A[0][2] * Jp[0][2];
+        const double m01 = A[0][0] * Jp[1][0] + A[0][1] * Jp[1][1] + A[0][2] * Jp[1][2];
+        const double m11 = A[1][0] * Jp[1][0] + A[1][1] * Jp[1][1] + A[1][2] * Jp[1][2];
+        const double* g = s.gp + 3 * (size_t)p;
+        const double ag0 = A[0][0] * g[0] + A[0][1] * g[1] + A[0][2] * g[2];
+        const double ag1 = A[1][0] * g[0] + A[1][1] * g[1] + A[1][2] * g[2];
+        int k = 0;
+#pragma unroll
+        for (int r = 0; r < NP; ++r) {
+            const double y0 = m00 * Jc[0][r] + m01 * Jc[1][r];
+            const double y1 = m01 * Jc[0][r] + m11 * Jc[1][r];
+#pragma unroll
+            for (int q = r; q < NP; ++q) acc[k++] -= Jc[0][q] * y0 + Jc[1][q] * y1;
+        }
+#pragma unroll
+        for (int r = 0; r < NP; ++r) acc[k++] -= Jc[0][r] * ag0 + Jc[1][r] * ag1;
+    }
+    __shared__ double s_red[LINC_THREADS / 64][CU];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < CU; ++k) {
+        const double t = wave_sum(acc[k]);
+        if (lane == 0) s_red[wave][k] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x < CU) {
+        double t = 0.0;
+        for (int wv = 0; wv < LINC_THREADS / 64; ++wv) t += s_red[wv][threadIdx.x];
+        part[((size_t)cam * n_chunks + chunk) * CU + threadIdx.x] = t;
+    }
+}
+
+// S_ii (lower incl. diagonal, both triangles of the block are written) and rhs_i += chunk partials
+__global__ void k_schur_diag_finish(int M, int NP, int n_c, int n_chunks, const double* __restrict__ part, double* __restrict__ S,
+                                    double* __restrict__ rhs) {
+    const int CU = cam_acc_len(NP);
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= M * CU) return;
+    const int cam = idx / CU, k = idx % CU;
+    double t = 0.0;
+    for (int ch = 0; ch < n_chunks; ++ch) t += part[((size_t)cam * n_chunks + ch) * CU + k];
+    const int ntri = NP * (NP + 1) / 2;
+    if (k >= ntri) {
+        rhs[cam * NP + (k - ntri)] += t;
+        return;
+    }
+    int r = 0, rem = k;
+    while (rem >= NP - r) { rem -= NP - r; ++r; }
+    const int q = r + rem;
+    S[(size_t)(cam * NP + q) + (size_t)(cam * NP + r) * n_c] += t;
+    if (q != r) S[(size_t)(cam * NP + r) + (size_t)(cam * NP + q) * n_c] += t;
+}
+
+}  // namespace satba
