@@ -81,6 +81,8 @@ struct satba_problem {
     int sch3_chunks = 0, NW = 0;
     unsigned long long* d_bits = nullptr;
     int* d_rank = nullptr;
+    double* d_PV = nullptr;    // packed per-point records (N x 12)
+    int unit_weights = 0;
     int* d_fail = nullptr;
     double* d_scal = nullptr;  // 8 private scalars (costs of satba_residuals, timing sinks)
     double *d_xb_own = nullptr, *d_xb = nullptr;
@@ -229,13 +231,17 @@ static int launch_schur3(satba_problem* p, const ObsArgs& a, double* S, double* 
     cm.cam_ofs = p->d_cam_ofs; cm.obs = p->d_cm_obs; cm.w = p->d_cm_w; cm.pt = p->d_cm_pt;
     Schur3Args s;
     s.bits = p->d_bits; s.rank = p->d_rank; s.Vinv = p->d_Vinv; s.gp = p->d_g + p->n_c; s.NW = p->NW; s.n_chunks = p->sch3_chunks;
+    s.PV = reinterpret_cast<const double2*>(p->d_PV);
     const long long items = (long long)p->M * (p->M - 1) / 2 * p->sch3_chunks;
     const int diag_chunks = p->lin3_chunks;
-    if (p->loss == 0) {
-        if (items > 0) hipLaunchKernelGGL((k_schur_pairs<MODEL, NP, false>), dim3((unsigned)((items + 3) / 4)), dim3(256), 0, p->stream, a, cm, s, S);
+    if (p->loss == 0 && p->unit_weights) {
+        if (items > 0) hipLaunchKernelGGL((k_schur_pairs<MODEL, NP, false, true>), dim3((unsigned)((items + 3) / 4)), dim3(256), 0, p->stream, a, cm, s, S);
+        hipLaunchKernelGGL((k_schur_diag<MODEL, NP, false>), dim3(diag_chunks, p->M), dim3(LINC_THREADS), 0, p->stream, a, cm, s, p->d_part3);
+    } else if (p->loss == 0) {
+        if (items > 0) hipLaunchKernelGGL((k_schur_pairs<MODEL, NP, false, false>), dim3((unsigned)((items + 3) / 4)), dim3(256), 0, p->stream, a, cm, s, S);
         hipLaunchKernelGGL((k_schur_diag<MODEL, NP, false>), dim3(diag_chunks, p->M), dim3(LINC_THREADS), 0, p->stream, a, cm, s, p->d_part3);
     } else {
-        if (items > 0) hipLaunchKernelGGL((k_schur_pairs<MODEL, NP, true>), dim3((unsigned)((items + 3) / 4)), dim3(256), 0, p->stream, a, cm, s, S);
+        if (items > 0) hipLaunchKernelGGL((k_schur_pairs<MODEL, NP, true, false>), dim3((unsigned)((items + 3) / 4)), dim3(256), 0, p->stream, a, cm, s, S);
         hipLaunchKernelGGL((k_schur_diag<MODEL, NP, true>), dim3(diag_chunks, p->M), dim3(LINC_THREADS), 0, p->stream, a, cm, s, p->d_part3);
     }
     HIP_TRY(hipGetLastError());
@@ -488,6 +494,9 @@ int satba_problem_create(const satba_problem_desc* d, satba_problem** out) {
                     for (int w = 0; w < NW; ++w) { rank[(size_t)cc * NW + w] = run; run += __builtin_popcountll(bits[(size_t)cc * NW + w]); }
                 }
                 TRY(dev_alloc(p, &p->d_bits, bits.size())); TRY(dev_alloc(p, &p->d_rank, rank.size()));
+                TRY(dev_alloc(p, &p->d_PV, (size_t)12 * p->N));
+                p->unit_weights = 1;
+                for (long long o = 0; o < K; ++o) if (d->weights[o] != 1.0) { p->unit_weights = 0; break; }
                 HIP_TRY(hipMemcpy(p->d_bits, bits.data(), sizeof(unsigned long long) * bits.size(), hipMemcpyHostToDevice));
                 HIP_TRY(hipMemcpy(p->d_rank, rank.data(), sizeof(int) * rank.size(), hipMemcpyHostToDevice));
                 const long long n_pairs = (long long)p->M * (p->M - 1) / 2;
@@ -661,7 +670,7 @@ int satba_schur(satba_problem* p, double lam) {
     HIP_TRY(hipMemsetAsync(p->d_xb, 0, sizeof(double) * (p->hdr + nS), p->stream));
     if (p->N > 0) {
         hipLaunchKernelGGL(k_vinv, dim3((p->N + 255) / 256), dim3(256), 0, p->stream, p->N, lam, p->d_V,
-                           p->d_scale_inv + p->n_c, p->d_Vinv);
+                           p->d_scale_inv + p->n_c, p->d_Vinv, p->d_x + p->n_c, p->d_g + p->n_c, p->d_PV);
         HIP_TRY(hipGetLastError());
     }
     double* S = p->payload();

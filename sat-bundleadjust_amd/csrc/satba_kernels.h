@@ -430,8 +430,10 @@ __global__ __launch_bounds__(512) void k_jvp(ObsArgs a, const double* __restrict
 
 // ------------------------------------------------------------------------------------------------ K3 Schur complement
 // (V_p + lam Dp^2)^-1 per point, symmetric 3x3 stored as xx xy xz yy yz zz
+// PV (optional): packed per-point record X(3) | Vinv(6) | g_p(3) for the gather-heavy Schur v3 kernels
 __global__ void k_vinv(int N, double lam, const double* __restrict__ V, const double* __restrict__ scale_inv_p,
-                       double* __restrict__ Vinv) {
+                       double* __restrict__ Vinv, const double* __restrict__ xp, const double* __restrict__ gp,
+                       double* __restrict__ PV) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= N) return;
     const double* v = V + 6 * (size_t)p;
@@ -447,6 +449,13 @@ __global__ void k_vinv(int N, double lam, const double* __restrict__ V, const do
     o[3] = (a * f - c * c) * idet;
     o[4] = (b * c - a * e) * idet;
     o[5] = (a * d - b * b) * idet;
+    if (PV) {
+        double* q = PV + 12 * (size_t)p;
+        q[0] = xp[3 * (size_t)p]; q[1] = xp[3 * (size_t)p + 1]; q[2] = xp[3 * (size_t)p + 2];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) q[3 + k] = o[k];
+        q[9] = gp[3 * (size_t)p]; q[10] = gp[3 * (size_t)p + 1]; q[11] = gp[3 * (size_t)p + 2];
+    }
 }
 
 // S <- (lead) * blockdiag(U_c + lam Dc^2), rhs <- (lead) * g_c ; S column-major n_c x n_c (already zeroed)

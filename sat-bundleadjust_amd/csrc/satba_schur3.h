@@ -27,6 +27,7 @@ struct Schur3Args {
     const int* __restrict__ rank;                 // M x NW
     const double* __restrict__ Vinv;              // N x 6
     const double* __restrict__ gp;                // N x 3
+    const double2* __restrict__ PV;               // N x 6 double2: X0 X1 | X2 v00 | v01 v02 | v11 v12 | v22 g0 | g1 g2
     int NW;                                       // words per camera
     int n_chunks;                                 // word-range chunks per pair (1: plain stores, >1: atomics)
 };
@@ -34,10 +35,12 @@ struct Schur3Args {
 constexpr int S3_QUEUE = 128;  // per-wave hit queue (entries): < 64 pending + at most 64 added per round
 
 // weighted, scaled Jacobian blocks of one (camera, point) from the camera-major copy
-template <int MODEL, int NP, bool ROBUST>
+// UNITW: every observation weight is 1 and the loss is linear -> nothing has to be fetched per observation
+template <int MODEL, int NP, bool ROBUST, bool UNITW = false>
 __device__ inline void cm_jacobian(const ObsArgs& a, const CamMajor& c, const double* cc, const double* tab, int cam,
                                    int pos, int pt, double X, double Y, double Z, double Jc[2][NP], double Jp[2][3]) {
-    const double w = c.w[pos];
+    double w = 1.0;
+    if constexpr (!UNITW) w = c.w[pos];
     double u, v;
     project<MODEL, NP, true>(cc, tab, X, Y, Z, a.f32 != 0, u, v, Jc, Jp);
     double js0 = 1.0, js1 = 1.0;
@@ -56,9 +59,9 @@ __device__ inline void cm_jacobian(const ObsArgs& a, const CamMajor& c, const do
 }
 
 // grid: one wave per (pair, chunk); 4 waves per workgroup.  pair index -> (i, j), i < j.
-template <int MODEL, int NP, bool ROBUST>
+template <int MODEL, int NP, bool ROBUST, bool UNITW>
 __global__ __launch_bounds__(256) void k_schur_pairs(ObsArgs a, CamMajor c, Schur3Args s, double* __restrict__ S) {
-    __shared__ int s_q[4][S3_QUEUE][3];  // (point, position in i's list, position in j's list)
+    __shared__ int s_q[4][S3_QUEUE];  // shared points of the two cameras waiting to be evaluated
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long long n_pairs = (long long)a.M * (a.M - 1) / 2;
     const long long item = (long long)blockIdx.x * 4 + wave;
@@ -89,14 +92,23 @@ __global__ __launch_bounds__(256) void k_schur_pairs(ObsArgs a, CamMajor c, Schu
 
     auto process = [&](int slot, bool valid) {
         if (!valid) return;
-        const int p = s_q[wave][slot][0], pi = s_q[wave][slot][1], pj = s_q[wave][slot][2];
-        const double* px = a.x + a.n_c + 3 * (size_t)p;
-        const double X = px[0], Y = px[1], Z = px[2];
+        const int p = s_q[wave][slot];
+        int pi = 0, pj = 0;
+        if constexpr (!UNITW) {
+            // position of (camera, point) in the camera-major arrays: rank of the word + bits below the point's bit
+            const int w = p >> 6;
+            const unsigned long long below = (1ull << (p & 63)) - 1ull;
+            pi = base_i + ri[w] + __popcll(bi[w] & below);
+            pj = base_j + rj[w] + __popcll(bj[w] & below);
+        }
+        // packed point record: five 16-byte gathers instead of nine 8-byte ones
+        const double2* pv = s.PV + 6 * (size_t)p;
+        const double2 r0 = pv[0], r1 = pv[1], r2 = pv[2], r3 = pv[3], r4 = pv[4];
+        const double X = r0.x, Y = r0.y, Z = r1.x;
+        const double v00 = r1.y, v01 = r2.x, v02 = r2.y, v11 = r3.x, v12 = r3.y, v22 = r4.x;
         double Jci[2][NP], Jpi[2][3], Jcj[2][NP], Jpj[2][3];
-        cm_jacobian<MODEL, NP, ROBUST>(a, c, cci, tabi, i, pi, p, X, Y, Z, Jci, Jpi);
-        cm_jacobian<MODEL, NP, ROBUST>(a, c, ccj, tabj, j, pj, p, X, Y, Z, Jcj, Jpj);
-        const double* vi = s.Vinv + 6 * (size_t)p;
-        const double v00 = vi[0], v01 = vi[1], v02 = vi[2], v11 = vi[3], v12 = vi[4], v22 = vi[5];
+        cm_jacobian<MODEL, NP, ROBUST, UNITW>(a, c, cci, tabi, i, pi, p, X, Y, Z, Jci, Jpi);
+        cm_jacobian<MODEL, NP, ROBUST, UNITW>(a, c, ccj, tabj, j, pj, p, X, Y, Z, Jcj, Jpj);
         // Mm = Jp_i Vinv Jp_j^T (2 x 2)
         double A[2][3];
 #pragma unroll
@@ -122,24 +134,16 @@ __global__ __launch_bounds__(256) void k_schur_pairs(ObsArgs a, CamMajor c, Schu
     int n_q = 0;  // wave-uniform queue fill
     for (int w0 = w_lo; w0 < w_hi; w0 += 64) {
         const int w = w0 + lane;
-        unsigned long long wi = 0, wj = 0;
-        if (w < w_hi) { wi = bi[w]; wj = bj[w]; }
-        unsigned long long m = wi & wj;
-        if (__ballot(m != 0) == 0) continue;
-        int rki = 0, rkj = 0;
-        if (m) { rki = ri[w]; rkj = rj[w]; }
+        unsigned long long m = (w < w_hi) ? (bi[w] & bj[w]) : 0ull;
         // rounds: every lane with a remaining hit emits ONE entry; slots come from a ballot + popcount (no scan).
-        // At most 64 entries are added per round and the queue is drained below 64 after each, so it never overflows.
+        // At most 64 entries are added per round and the queue is drained below 64 after each: no overflow.
         for (;;) {
             const unsigned long long has = __ballot(m != 0);
             if (has == 0) break;
             if (m) {
                 const int off = n_q + __popcll(has & ((1ull << lane) - 1ull));
                 const int bit = __ffsll((long long)m) - 1;
-                const unsigned long long below = (1ull << bit) - 1ull;
-                s_q[wave][off][0] = w * 64 + bit;
-                s_q[wave][off][1] = base_i + rki + __popcll(wi & below);
-                s_q[wave][off][2] = base_j + rkj + __popcll(wj & below);
+                s_q[wave][off] = w * 64 + bit;
                 m &= m - 1;
             }
             n_q += __popcll(has);
@@ -182,11 +186,11 @@ __global__ __launch_bounds__(LINC_THREADS) void k_schur_diag(ObsArgs a, CamMajor
     for (int k = 0; k < CU; ++k) acc[k] = 0.0;
     for (int pos = lo + threadIdx.x; pos < hi; pos += LINC_THREADS) {
         const int p = c.pt[pos];
-        const double* px = a.x + a.n_c + 3 * (size_t)p;
+        const double2* pv = s.PV + 6 * (size_t)p;
+        const double2 r0 = pv[0], r1 = pv[1], r2 = pv[2], r3 = pv[3], r4 = pv[4], r5 = pv[5];
         double Jc[2][NP], Jp[2][3];
-        cm_jacobian<MODEL, NP, ROBUST>(a, c, cc, tab, cam, pos, p, px[0], px[1], px[2], Jc, Jp);
-        const double* vi = s.Vinv + 6 * (size_t)p;
-        const double v00 = vi[0], v01 = vi[1], v02 = vi[2], v11 = vi[3], v12 = vi[4], v22 = vi[5];
+        cm_jacobian<MODEL, NP, ROBUST>(a, c, cc, tab, cam, pos, p, r0.x, r0.y, r1.x, Jc, Jp);
+        const double v00 = r1.y, v01 = r2.x, v02 = r2.y, v11 = r3.x, v12 = r3.y, v22 = r4.x;
         double A[2][3];
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
@@ -197,9 +201,8 @@ __global__ __launch_bounds__(LINC_THREADS) void k_schur_diag(ObsArgs a, CamMajor
         const double m00 = A[0][0] * Jp[0][0] + A[0][1] * Jp[0][1] + A[0][2] * Jp[0][2];
         const double m01 = A[0][0] * Jp[1][0] + A[0][1] * Jp[1][1] + A[0][2] * Jp[1][2];
         const double m11 = A[1][0] * Jp[1][0] + A[1][1] * Jp[1][1] + A[1][2] * Jp[1][2];
-        const double* g = s.gp + 3 * (size_t)p;
-        const double ag0 = A[0][0] * g[0] + A[0][1] * g[1] + A[0][2] * g[2];
-        const double ag1 = A[1][0] * g[0] + A[1][1] * g[1] + A[1][2] * g[2];
+        const double ag0 = A[0][0] * r4.y + A[0][1] * r5.x + A[0][2] * r5.y;
+        const double ag1 = A[1][0] * r4.y + A[1][1] * r5.x + A[1][2] * r5.y;
         int k = 0;
 #pragma unroll
         for (int r = 0; r < NP; ++r) {
