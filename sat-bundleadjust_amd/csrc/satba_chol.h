@@ -22,100 +22,85 @@
 namespace satba {
 
 constexpr int CH_NB = 32;
-constexpr int CH_ROWS = 256;  // panel rows per workgroup in k_potrf_trsm
-constexpr int CH_THREADS = 1024;
 
-// dinv: (n / 32 + 1) blocks of 32 x 32 (row-major) receiving inv(L_kk).
-// Workgroup 0: factorise the diagonal block, publish L_kk and inv(L_kk), advance the right-hand side.
-// Workgroups 1..: same factorisation (redundant), then 64 panel rows each as a small GEMM  X = P inv(L_kk)^T
-// (twice the flops of a triangular solve, but no dependent chain and no 32-deep unrolled register array).
-__global__ __launch_bounds__(CH_THREADS) void k_potrf_trsm(double* __restrict__ A, int n, int k0, int* __restrict__ fail,
-                                                    double* __restrict__ b, double* __restrict__ dinv) {
-    __shared__ double D[CH_NB][CH_NB + 1];
-    __shared__ double Di[CH_NB][CH_NB + 1];
-    __shared__ double Pt[CH_NB][CH_ROWS];
-    const int tid = threadIdx.x;
+__device__ inline double readlane_f64(double v, int src_lane) {  // src_lane must be wave-uniform
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readlane(lo, src_lane);
+    hi = __builtin_amdgcn_readlane(hi, src_lane);
+    return __hiloint2double(hi, lo);
+}
+
+// Panel step, entirely in registers, no LDS and no barriers.  Every wave first factorises the 32 x 32 diagonal
+// block redundantly -- lane r (< 32) holds row r in 32 registers, column values are broadcast with v_readlane --
+// and then solves 64 panel rows (one per lane, also in registers) against it, again through v_readlane
+// broadcasts of L.  The right-hand side is treated as one more panel row (forward substitution folded in).
+// Wave 0 of workgroup 0 writes the factorised diagonal block back.
+// rows handled: base .. n-1 (base = k0 + nb) and the virtual row n = right-hand side b.
+__global__ __launch_bounds__(256) void k_potrf_trsm(double* __restrict__ A, int n, int k0, int* __restrict__ fail,
+                                                    double* __restrict__ b) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nb = min(CH_NB, n - k0);
-    for (int idx = tid; idx < CH_NB * CH_NB; idx += CH_THREADS) {
-        const int r = idx % CH_NB, c = idx / CH_NB;
-        D[r][c] = (r < nb && c < nb && r >= c) ? A[(size_t)(k0 + r) + (size_t)(k0 + c) * n] : ((r == c) ? 1.0 : 0.0);
+    const int base = k0 + nb;
+    const int gw = blockIdx.x * 4 + wave;  // global wave index
+    if (gw * 64 > n - base) return;        // this wave's first row is beyond the virtual row n
+
+    // ---- diagonal block into registers (identity padding beyond nb)
+    double a[CH_NB];
+    const int dr = min(lane, CH_NB - 1);
+#pragma unroll
+    for (int c = 0; c < CH_NB; ++c) {
+        double v = (c == dr) ? 1.0 : 0.0;
+        if (lane < nb && c < nb && c <= lane) v = A[(size_t)(k0 + lane) + (size_t)(k0 + c) * n];
+        a[c] = v;
     }
-    const int r0 = k0 + nb + ((int)blockIdx.x - 1) * CH_ROWS;
-    if (blockIdx.x > 0) {  // stage this workgroup's panel rows (transposed) while the factorisation runs
-        for (int idx = tid; idx < CH_NB * CH_ROWS; idx += CH_THREADS) {
-            const int r = idx % CH_ROWS, k = idx / CH_ROWS;
-            Pt[k][r] = (k < nb && r0 + r < n) ? A[(size_t)(r0 + r) + (size_t)(k0 + k) * n] : 0.0;
+    // ---- Cholesky of the block: after step j, a[j] of lane r >= j holds L[r][j]
+    double my_inv = 1.0;  // 1 / L[lane][lane]
+    bool bad = false;
+#pragma unroll
+    for (int j = 0; j < CH_NB; ++j) {
+        double d = readlane_f64(a[j], j);
+        if (!(d > 0.0)) { bad = true; d = 1.0; }
+        const double sq = sqrt(d), inv = 1.0 / sq;
+        const double l = (lane == j) ? sq : a[j] * inv;
+        a[j] = l;
+        if (lane == j) my_inv = inv;
+#pragma unroll
+        for (int c = j + 1; c < CH_NB; ++c) a[c] -= l * readlane_f64(l, c);
+    }
+    if (gw == 0) {
+        if (bad && lane == 0) atomicOr(fail, 1);
+        if (lane < nb) {
+#pragma unroll
+            for (int c = 0; c < CH_NB; ++c)
+                if (c <= lane && c < nb) A[(size_t)(k0 + lane) + (size_t)(k0 + c) * n] = a[c];
         }
     }
-    __syncthreads();
-    // unblocked Cholesky of the 32 x 32 block, all threads on the rank-1 updates
-    for (int j = 0; j < nb; ++j) {
-        if (tid == 0) {
-            double d = D[j][j];
-            if (!(d > 0.0)) {  // not positive definite (or NaN): flag it, keep going with a harmless pivot
-                if (blockIdx.x == 0) atomicOr(fail, 1);
-                d = 1.0;
+    // ---- this lane's panel row (or the right-hand side): x L_kk^T = p
+    const int r = base + gw * 64 + lane;
+    const bool is_rhs = (r == n), valid = (r <= n);
+    double x[CH_NB];
+#pragma unroll
+    for (int c = 0; c < CH_NB; ++c) {
+        double v = 0.0;
+        if (c < nb && valid) v = is_rhs ? b[k0 + c] : A[(size_t)r + (size_t)(k0 + c) * n];
+        x[c] = v;
+    }
+#pragma unroll
+    for (int m = 0; m < CH_NB; ++m) {
+        const double xm = x[m] * readlane_f64(my_inv, m);
+        x[m] = xm;
+#pragma unroll
+        for (int c = m + 1; c < CH_NB; ++c) x[c] -= xm * readlane_f64(a[m], c);  // L[c][m]
+    }
+    if (valid) {
+#pragma unroll
+        for (int c = 0; c < CH_NB; ++c) {
+            if (c < nb) {
+                if (is_rhs) b[k0 + c] = x[c];
+                else A[(size_t)r + (size_t)(k0 + c) * n] = x[c];
             }
-            D[j][j] = sqrt(d);
-        }
-        __syncthreads();
-        if (tid > j && tid < nb) D[tid][j] /= D[j][j];
-        __syncthreads();
-        for (int idx = tid; idx < CH_NB * CH_NB; idx += CH_THREADS) {
-            const int r = idx % CH_NB, c = idx / CH_NB;
-            if (c > j && r >= c && r < nb) D[r][c] -= D[r][j] * D[c][j];
-        }
-        __syncthreads();
-    }
-    // inv(L_kk): half-wave c owns column c, lane m of it holds Di[m][c] in a register; row r of the column is a
-    // 32-lane dot product (shuffles), so the whole inverse is 32 short steps with no LDS round trips
-    {
-        const int c = tid >> 5, m = tid & 31;
-        double mine = 0.0;  // Di[m][c]
-        for (int r = 0; r < CH_NB; ++r) {
-            double v = (m < r && m >= c) ? D[r][m] * mine : 0.0;
-#pragma unroll
-            for (int d = 16; d > 0; d >>= 1) v += __shfl_xor(v, d);
-            if (m == r) mine = (r >= c) ? (((r == c) ? 1.0 : 0.0) - v) / D[r][r] : 0.0;
-        }
-        Di[m][c] = mine;
-    }
-    __syncthreads();
-    if (blockIdx.x == 0) {
-        for (int idx = tid; idx < nb * nb; idx += CH_THREADS) {
-            const int r = idx % nb, c = idx / nb;
-            if (r >= c) A[(size_t)(k0 + r) + (size_t)(k0 + c) * n] = D[r][c];
-        }
-        double* out = dinv + (size_t)(k0 / CH_NB) * CH_NB * CH_NB;
-        for (int idx = tid; idx < CH_NB * CH_NB; idx += CH_THREADS) out[idx] = Di[idx / CH_NB][idx % CH_NB];
-        // forward substitution of this block of the right-hand side: y_k = inv(L_kk) b_k
-        double s = 0.0;
-        if (tid < nb)
-            for (int m = 0; m <= tid; ++m) s += Di[tid][m] * b[k0 + m];
-        __syncthreads();
-        if (tid < nb) b[k0 + tid] = s;
-        return;
-    }
-    // X[r][c] = sum_k P[r][k] inv(L)[c][k]; thread = 4 rows x 2 columns
-    const int tr = (tid & 63) * 4, tc = (tid >> 6) * 2;
-    double acc[2][4] = {};
-#pragma unroll 8
-    for (int k = 0; k < CH_NB; ++k) {
-        const double d0 = Di[tc][k], d1 = Di[tc + 1][k];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const double a = Pt[k][tr + i];
-            acc[0][i] += a * d0;
-            acc[1][i] += a * d1;
         }
     }
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int r = r0 + tr + i, c = tc + j;
-            if (r < n && c < nb) A[(size_t)r + (size_t)(k0 + c) * n] = acc[j][i];
-        }
 }
 
 // trailing update A[base:, base:] -= P P^T (lower tiles only), P = A[base:, k0:k0+nb], base = k0 + nb;
@@ -160,10 +145,11 @@ __global__ __launch_bounds__(256) void k_syrk(double* __restrict__ A, int n, int
 }
 
 // L^T z = y in place in b (b holds y on entry), left-looking, one workgroup of 1024 threads:
-// z_k = inv(L_kk)^T (y_k - L[tail, k-block]^T z_tail).
-__global__ __launch_bounds__(1024) void k_trsv_back(const double* __restrict__ L, int n, const double* __restrict__ dinv,
-                                                    double* __restrict__ b) {
-    extern __shared__ double yb[];  // n doubles: the right-hand side / solution lives in LDS for the whole solve
+// z_k = L_kk^-T (y_k - L[tail, k-block]^T z_tail).  The right-hand side lives in LDS; each wave takes two columns of
+// the block, lanes run down the column (coalesced) with four independent partial sums in flight; the 32 x 32
+// triangular solve is a readlane loop in wave 0.
+__global__ __launch_bounds__(1024) void k_trsv_back(const double* __restrict__ L, int n, double* __restrict__ b) {
+    extern __shared__ double yb[];  // n doubles
     __shared__ double t[CH_NB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int i = tid; i < n; i += 1024) yb[i] = b[i];
@@ -173,47 +159,57 @@ __global__ __launch_bounds__(1024) void k_trsv_back(const double* __restrict__ L
         const int k0 = kb * CH_NB;
         const int nb = min(CH_NB, n - k0);
         const int tail0 = k0 + nb;
-        // t_c = y_c - sum_{r >= tail0} L[r][k0 + c] z[r]: each wave takes two columns, lanes run down the column
-        // (coalesced), the loads of a column are independent of each other and of the LDS traffic
         for (int cc = 0; cc < 2; ++cc) {
             const int c = wave * 2 + cc;
-            double s = 0.0;
+            double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
             if (c < nb) {
                 const double* col = L + (size_t)(k0 + c) * n;
-                for (int r = tail0 + lane; r < n; r += 64) s += col[r] * yb[r];
+                int r = tail0 + lane;
+                for (; r + 192 < n; r += 256) {
+                    s0 += col[r] * yb[r]; s1 += col[r + 64] * yb[r + 64];
+                    s2 += col[r + 128] * yb[r + 128]; s3 += col[r + 192] * yb[r + 192];
+                }
+                for (; r < n; r += 64) s0 += col[r] * yb[r];
             }
+            double s = (s0 + s1) + (s2 + s3);
 #pragma unroll
             for (int d = 32; d > 0; d >>= 1) s += __shfl_xor(s, d);
             if (lane == 0 && c < nb) t[c] = yb[k0 + c] - s;
         }
         __syncthreads();
-        // z_k = inv(L_kk)^T t
-        if (tid < nb) {
-            const double* Di = dinv + (size_t)kb * CH_NB * CH_NB;  // row-major inv(L_kk)
-            double s = 0.0;
-            for (int m = tid; m < nb; ++m) s += Di[m * CH_NB + tid] * t[m];
-            yb[k0 + tid] = s;
+        if (wave == 0) {  // L_kk^T z = t: lane c holds column c of L_kk (rows >= c), solved from the bottom up
+            double v = (lane < nb) ? t[lane] : 0.0;
+            const int cl = min(lane, nb - 1);
+            for (int j = nb - 1; j >= 0; --j) {
+                // z_j = v_j / L[j][j]; then v_c -= L[j][c] z_j for c < j
+                const double ljj = L[(size_t)(k0 + j) + (size_t)(k0 + j) * n];
+                const double zj = __shfl(v, j) / ljj;
+                const double ljc = (lane < j) ? L[(size_t)(k0 + j) + (size_t)(k0 + cl) * n] : 0.0;
+                if (lane == j) v = zj;
+                else if (lane < j) v -= ljc * zj;
+            }
+            if (lane < nb) yb[k0 + lane] = v;
         }
         __syncthreads();
     }
     for (int i = tid; i < n; i += 1024) b[i] = yb[i];
 }
 
-inline size_t cholesky_workspace_doubles(int n) { return (size_t)(n / CH_NB + 1) * CH_NB * CH_NB; }
+inline size_t cholesky_workspace_doubles(int n) { (void)n; return 1; }
 
 // Factorise A (n x n, column-major lower, in place) and solve A z = b in place.  *fail != 0 if A was not SPD.
-// dinv: workspace of cholesky_workspace_doubles(n) doubles.
-inline void cholesky_solve(double* A, int n, double* b, int* fail, double* dinv, hipStream_t stream) {
+inline void cholesky_solve(double* A, int n, double* b, int* fail, double* /*unused*/, hipStream_t stream) {
     for (int k0 = 0; k0 < n; k0 += CH_NB) {
         const int nb = n - k0 < CH_NB ? n - k0 : CH_NB;
         const int rest = n - k0 - nb;
-        hipLaunchKernelGGL(k_potrf_trsm, dim3(1 + (rest + CH_ROWS - 1) / CH_ROWS), dim3(CH_THREADS), 0, stream, A, n, k0, fail, b, dinv);
+        const int waves = (rest + 1 + 63) / 64;  // panel rows + the right-hand side row
+        hipLaunchKernelGGL(k_potrf_trsm, dim3((waves + 3) / 4), dim3(256), 0, stream, A, n, k0, fail, b);
         if (rest > 0) {
             const int tiles = (rest + 63) / 64;
             hipLaunchKernelGGL(k_syrk, dim3(tiles, tiles), dim3(16, 16), 0, stream, A, n, k0, nb, b);
         }
     }
-    hipLaunchKernelGGL(k_trsv_back, dim3(1), dim3(1024), sizeof(double) * n, stream, A, n, dinv, b);
+    hipLaunchKernelGGL(k_trsv_back, dim3(1), dim3(1024), sizeof(double) * n, stream, A, n, b);
 }
 
 }  // namespace satba
