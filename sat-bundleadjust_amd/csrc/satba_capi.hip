@@ -82,6 +82,8 @@ struct satba_problem {
     unsigned long long* d_bits = nullptr;
     int* d_rank = nullptr;
     double* d_PV = nullptr;    // packed per-point records (N x 12)
+    long long* d_pair_ofs = nullptr;  // per camera pair: list of shared points (null: bitmap scan)
+    int* d_pair_pts = nullptr;
     int unit_weights = 0;
     int* d_fail = nullptr;
     double* d_scal = nullptr;  // 8 private scalars (costs of satba_residuals, timing sinks)
@@ -232,6 +234,7 @@ static int launch_schur3(satba_problem* p, const ObsArgs& a, double* S, double* 
     Schur3Args s;
     s.bits = p->d_bits; s.rank = p->d_rank; s.Vinv = p->d_Vinv; s.gp = p->d_g + p->n_c; s.NW = p->NW; s.n_chunks = p->sch3_chunks;
     s.PV = reinterpret_cast<const double2*>(p->d_PV);
+    s.pair_ofs = p->d_pair_ofs; s.pair_pts = p->d_pair_pts;
     const long long items = (long long)p->M * (p->M - 1) / 2 * p->sch3_chunks;
     const int diag_chunks = p->lin3_chunks;
     if (p->loss == 0 && p->unit_weights) {
@@ -506,6 +509,27 @@ int satba_problem_create(const satba_problem_desc* d, satba_problem** out) {
                     if (sc < 1) sc = 1;
                 }
                 p->sch3_chunks = sc;
+                // shared-point lists per camera pair (static structure; 4 B per pair entry, e.g. 200 MB at 200 x 1M x 10M)
+                if (n_pairs > 0 && !getenv("SATBA_SCHUR_BITMAP")) {
+                    const long long M_ = p->M;
+                    auto pair_index = [M_](long long a, long long b) { return a * M_ - a * (a + 1) / 2 + (b - a - 1); };
+                    std::vector<long long> ofs(n_pairs + 1, 0);
+                    for (int q = 0; q < p->N; ++q)
+                        for (int x0 = pt_ofs[q]; x0 < pt_ofs[q + 1]; ++x0)
+                            for (int x1 = x0 + 1; x1 < pt_ofs[q + 1]; ++x1) ++ofs[pair_index(d->cam_ind[x0], d->cam_ind[x1]) + 1];
+                    for (long long i = 0; i < n_pairs; ++i) ofs[i + 1] += ofs[i];
+                    const long long E = ofs[n_pairs];
+                    if (E > 0 && E < (1ll << 31) && E * 4 < (8ll << 30)) {
+                        std::vector<int> pts(E);
+                        std::vector<long long> fill(ofs.begin(), ofs.end() - 1);
+                        for (int q = 0; q < p->N; ++q)
+                            for (int x0 = pt_ofs[q]; x0 < pt_ofs[q + 1]; ++x0)
+                                for (int x1 = x0 + 1; x1 < pt_ofs[q + 1]; ++x1) pts[fill[pair_index(d->cam_ind[x0], d->cam_ind[x1])]++] = q;
+                        TRY(dev_alloc(p, &p->d_pair_ofs, ofs.size())); TRY(dev_alloc(p, &p->d_pair_pts, pts.size()));
+                        HIP_TRY(hipMemcpy(p->d_pair_ofs, ofs.data(), sizeof(long long) * ofs.size(), hipMemcpyHostToDevice));
+                        HIP_TRY(hipMemcpy(p->d_pair_pts, pts.data(), sizeof(int) * pts.size(), hipMemcpyHostToDevice));
+                    }
+                }
             }
             if (swhich == 1) p->sch_T = 0;
         }
