@@ -5,17 +5,15 @@
 // iteration of scipy:optimize/_lsq/trf.py:479-480 by an exact factorisation.
 //
 // Blocked right-looking Cholesky, 32-column panels, two launches per panel:
-//   k_potrf_trsm  every workgroup factorises the 32x32 diagonal block in LDS (redundantly -- cheaper than a
-//                 separate launch), workgroup 0 writes it back together with its explicit inverse and advances
-//                 the forward substitution of the right-hand side, the others solve 256 panel rows each;
+//   k_potrf_trsm  register-resident: every wave factorises the 32x32 diagonal block redundantly (lane = row,
+//                 column broadcasts by v_readlane, no LDS, no barriers) and solves 64 panel rows against it; the
+//                 right-hand side rides along as one more panel row, so the forward substitution is folded in;
 //   k_syrk        64x64 tiles of the trailing matrix, 4x4 per thread, panel staged in LDS, rows mapped to the
 //                 fast thread index so the read-modify-write of A is coalesced; tiles of the first tile column
-//                 also apply the panel to the right-hand side (forward substitution is thereby folded into the
-//                 factorisation: no separate L y = b pass);
-// then k_trsv_back: one workgroup, right-looking backward substitution that uses the stored inverses of the
-// diagonal blocks (a 32x32 mat-vec instead of a 32-step dependent chain).
-// fp64 MFMA runs at the vector rate on gfx950 and the matrix is tiny: the solve is launch / latency bound
-// (64 dependent launches), not flop bound; see DESIGN.md.
+//                 also apply the panel to the right-hand side;
+// then k_trsv_back: one workgroup, left-looking backward substitution with the right-hand side in LDS.
+// fp64 MFMA runs at the vector rate on gfx950 and the matrix is tiny: the solve is bound by the latency of 64
+// dependent launches (~27 us + ~13 us per panel at n = 1000), not by flops; see DESIGN.md.
 #pragma once
 #include <hip/hip_runtime.h>
 

@@ -355,3 +355,69 @@ def test_nonfinite_initial_residuals_raise_like_scipy(gpu):
     p.params_opt[-1] = np.nan
     with pytest.raises(ValueError):
         ba_core.run_ba_optimization(p, {"verbose": 0}, False, False)
+
+
+# ----------------------------------------------------------------------------- full-size properties (BASELINE shapes)
+
+def _lm_iterations(eng, n):
+    """n fixed-work LM iterations (the loop bench.py times); returns the cost after each accepted / rejected step."""
+    import bench
+
+    st = {"first": True, "accepted": 0, "fail": 0, "cost": None}
+    costs = []
+    for _ in range(n):
+        bench.lm_step(eng, trf.SingleComm(), st, trf)
+        costs.append(st["cost"])
+    return costs, st
+
+
+@pytest.mark.parametrize("shape", ["C3", "C4"])
+def test_full_size_properties(gpu, shape):
+    """
+    At BASELINE.json's sizes the oracle is too slow to be the checker; check size-independent properties instead:
+    cost == 0.5 |fun|^2, a random sample of residuals against the oracle, monotone decrease over LM iterations down
+    to the noise floor of the generator, and two half-shards reproducing the camera blocks of the whole problem.
+    """
+    n_cam, n_pts, opp = synth.SHAPES[shape]
+    scene = synth.make_affine_scene(n_cam, n_pts, opp, seed=1, sigma_theta=2e-5)
+    p = synth.make_params(scene, {"correction_params": ["R", "T"], "n_cam_fix": 1})
+    eng = HipEngine(p)
+    eng.configure("linear", 1.0)
+    r0, cost0 = eng.residuals(with_cost=True)
+    assert abs(cost0 - 0.5 * r0 @ r0) < 1e-9 * cost0
+    # a random sample of observations against the CPU oracle (the whole vector would take minutes at 10 M)
+    rng = np.random.default_rng(0)
+    sel = np.sort(rng.choice(p.n_obs, 5000, replace=False))
+    q = type("P", (), {})()
+    q.__dict__.update(p.__dict__)
+    q.pts_ind, q.cam_ind, q.pts2d, q.pts2d_w = p.pts_ind[sel], p.cam_ind[sel], p.pts2d[sel], p.pts2d_w[sel]
+    assert np.abs(O.fun(p.params_opt, q) - r0.reshape(-1, 2)[sel].ravel()).max() < 1e-8
+
+    # two half-shards of the same problem produce the same camera blocks as the whole
+    eng.linearize()
+    U, gc, V, gp = eng.get_blocks()
+    from satba import sharding
+
+    Us, gcs = np.zeros_like(U), np.zeros_like(gc)
+    for rank in range(2):
+        e2 = HipEngine(p, sharding.make_shard(p, rank, 2))
+        e2.configure("linear", 1.0)
+        e2.linearize()
+        U2, gc2, V2, gp2 = e2.get_blocks()
+        Us += U2
+        gcs += gc2
+        sh = e2.shard
+        assert rel(V2, V[sh.p0: sh.p1]) < 1e-12 and rel(gp2, gp[sh.p0: sh.p1]) < 1e-12
+        e2.close()
+    assert rel(Us, U) < 1e-9 and rel(gcs, gc) < 1e-7
+
+    costs, st = _lm_iterations(eng, 6)
+    assert all(b <= a * (1 + 1e-12) for a, b in zip(costs, costs[1:])) and st["accepted"] >= 3
+    # noise floor: 0.3 px per coordinate -> cost ~ 0.5 * 2K * 0.09 minus the fitted degrees of freedom
+    expected = 0.5 * 0.09 * (2 * p.n_obs - (p.n_cam * p.n_params + 3 * p.n_pts))
+    assert abs(costs[-1] - expected) < 0.02 * expected
+    # reprojection errors are Rayleigh(0.3 px) shrunk by the fitted degrees of freedom
+    err = O.reprojection_error(eng.residuals(), p.pts2d_w)
+    dof = 1.0 - (p.n_cam * p.n_params + 3 * p.n_pts) / (2.0 * p.n_obs)
+    assert abs(err.mean() - 0.3 * np.sqrt(np.pi / 2) * np.sqrt(dof)) < 0.01
+    eng.close()
