@@ -84,7 +84,7 @@ def lm_step(eng, comm, st, trf):
     st["cost"] = cost_new if actual > 0 else cost
 
 
-def cpu_baseline(scene, n_pts_sample, seed_note):
+def cpu_baseline(scene, n_pts_sample, corr):
     """
     The reference's scipy path (oracle/ba_oracle.solve_scipy == ref ba_core.py:284-297 on the numpy restatement of
     fun) on the first n_pts_sample points of the same scene: one LM iteration = max_nfev 2 (initial evaluation +
@@ -99,7 +99,7 @@ def cpu_baseline(scene, n_pts_sample, seed_note):
     p = BundleAdjustmentParameters.from_observations(
         scene.pts_ind[keep], scene.cam_ind[keep], scene.pts2d[keep], scene.pts3d[:n_pts_sample], scene.cameras,
         scene.cam_model, scene.pairs_to_triangulate, scene.camera_centers,
-        {"verbose": False, "correction_params": ["R", "T"], "n_cam_fix": 1})
+        {"verbose": False, "correction_params": corr, "n_cam_fix": 1})
     t0 = time.perf_counter()
     res = O.solve_scipy(p, {"verbose": 0}, max_nfev=2)
     dt = time.perf_counter() - t0
@@ -117,7 +117,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--shape", default="C4", help="C2 | C3 | C4 (SURVEY.md section 8d)")
+    ap.add_argument("--shape", default="C4", help="C2 | C3 | C4 (affine R+T) | C5 (rpc R) | P3 (perspective R+T); SURVEY.md section 8d")
     ap.add_argument("--sigma-theta", type=float, default=1e-4, help="initial camera angle error [rad]")
     ap.add_argument("--cpu-sample-pts", type=int, default=4000, help="points of the CPU-baseline sub-problem (0 = skip)")
     ap.add_argument("--kernel-reps", type=int, default=20)
@@ -137,10 +137,10 @@ def main():
     from satba import sharding, synth, trf
     from satba.engine_hip import HipEngine
 
-    n_cam, n_pts, opp = synth.SHAPES[args.shape]
+    model, corr, n_cam, n_pts, opp = synth.CONFIGS[args.shape]
     t_gen = time.perf_counter()
-    scene = synth.make_affine_scene(n_cam, n_pts, opp, seed=1, sigma_theta=args.sigma_theta)
-    p = synth.make_params(scene, {"correction_params": ["R", "T"], "n_cam_fix": 1})
+    scene = synth.make_scene(model, n_cam, n_pts, opp, seed=1, sigma_theta=args.sigma_theta if model != "rpc" else 1e-6)
+    p = synth.make_params(scene, {"correction_params": corr, "n_cam_fix": 1})
     t_gen = time.perf_counter() - t_gen
     comm = trf.TorchComm() if world > 1 else trf.SingleComm()
     eng = HipEngine(p, sharding.make_shard(p, rank, world))
@@ -182,12 +182,14 @@ def main():
         t_lin = kern["linearize"] * 1e-3
         achieved = alg_bytes / t_lin / 1e9
         out = {
-            "metric": "LM iters/sec at 200 cams x 1M pts x 10M obs (affine, R+T)",
+            "metric": "LM iters/sec at 200 cams x 1M pts x 10M obs (affine, R+T)" if args.shape == "C4" else
+                      "LM iters/sec, config {}".format(args.shape),
             "value": args.steps / dt, "unit": "LM iters/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "{}: {} cams x {} pts x {} obs, affine, correction R+T, 1 fixed camera, seed 1"
-                       .format(args.shape, n_cam, n_pts, p.n_obs), "sharding": "points over {} rank(s)".format(world),
+            "config": {"workload": "{}: {} cams x {} pts x {} obs, {}, correction {}, 1 fixed camera, seed 1"
+                       .format(args.shape, n_cam, n_pts, p.n_obs, model, "+".join(corr)),
+                       "sharding": "points over {} rank(s)".format(world),
                        "obs_per_rank0": K_loc},
             "obs_per_sec_residual_jacobian": world * K_loc / t_lin,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -197,7 +199,7 @@ def main():
             "accepted_steps": st["accepted"], "final_cost": st["cost"], "scene_gen_s": t_gen,
         }
         if args.cpu_sample_pts > 0 and world == 1:
-            out["cpu_baseline"] = cpu_baseline(scene, min(args.cpu_sample_pts, n_pts), "seed 1")
+            out["cpu_baseline"] = cpu_baseline(scene, min(args.cpu_sample_pts, n_pts), corr)
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out))
     if world > 1:

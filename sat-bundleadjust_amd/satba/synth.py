@@ -19,6 +19,10 @@ from .rpc_model import RPCModel
 SCENE_CENTRE = np.array([1.7e6, -5.9e6, 1.2e6])  # ECEF-scale magnitudes, metres
 
 SHAPES = {"C2": (10, 5000, 6), "C3": (50, 100000, 10), "C4": (200, 1000000, 10)}
+# BASELINE.json configs by name: (camera model, correction_params, n_cam, n_pts, obs_per_pt)
+CONFIGS = {"C2": ("affine", ["R", "T"], 10, 5000, 6), "C3": ("affine", ["R", "T"], 50, 100000, 10),
+           "C4": ("affine", ["R", "T"], 200, 1000000, 10), "C5": ("rpc", ["R"], 50, 100000, 10),
+           "P3": ("perspective", ["R", "T"], 50, 100000, 10)}
 
 
 class Scene:

@@ -64,15 +64,16 @@ class SingleComm:
 class TorchComm:
     """Sum all-reduce over torch.distributed (backend nccl == RCCL on ROCm, gloo in the CPU tests)."""
 
-    def __init__(self, group=None):
+    def __init__(self, group=None, always=False):
         import torch.distributed as dist
 
         self.dist, self.group = dist, group
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        self.always = always  # issue the collectives even for a single rank (plumbing tests)
 
     def allreduce(self, engine, n):
         """Sum the first n doubles of the engine's exchange buffer over all ranks, in place."""
-        if self.world > 1:
+        if self.world > 1 or self.always:
             self.dist.all_reduce(engine.xb[:n], op=self.dist.ReduceOp.SUM, group=self.group)
 
     def sum_array(self, a):

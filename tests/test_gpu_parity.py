@@ -421,3 +421,39 @@ def test_full_size_properties(gpu, shape):
     dof = 1.0 - (p.n_cam * p.n_params + 3 * p.n_pts) / (2.0 * p.n_obs)
     assert abs(err.mean() - 0.3 * np.sqrt(np.pi / 2) * np.sqrt(dof)) < 0.01
     eng.close()
+
+
+def test_rccl_plumbing_single_rank(gpu):
+    """
+    One-rank RCCL group: the solver's collectives really run on the exchange buffer (a torch CUDA tensor bound to
+    the C library) and order correctly with the kernels launched on torch's current stream.  The 8-GPU runs are
+    the driver's; this checks everything short of a second device.
+    """
+    import os
+    import socket
+
+    import torch
+    import torch.distributed as dist
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        _, make_p, g, _ = cases.solve_case("affine_small_R")
+        p = make_p()
+        comm = trf.TorchComm(always=True)
+        eng = HipEngine(p)
+        res = trf.trf_solve(eng, comm, ftol=1e-15, xtol=1e-15, gtol=1e-15, max_nfev=300)
+        st = g["tight_stats_linear"]
+        assert abs(res.cost - st[0]) < 1e-9 * st[0]
+        n_c = p.n_cam * p.n_params
+        assert rel(eng.get_x()[:n_c], g["tight_x_linear"][:n_c]) < 1e-6
+        # run_ba_optimization picks the distributed communicator up by itself only for world_size > 1
+        out = ba_core.run_ba_optimization(make_p(), {"verbose": 0}, False, False)
+        assert out[3].mean() < 0.5
+        eng.close()
+    finally:
+        dist.destroy_process_group()
