@@ -17,6 +17,7 @@
 
 #include "../../include/satba.h"
 #include "satba_chol.h"
+#include "satba_chol_dag.h"
 #include "satba_kernels.h"
 #include "satba_linearize3.h"
 #include "satba_schur3.h"
@@ -63,6 +64,7 @@ struct satba_problem {
     double *d_S_part = nullptr, *d_rhs_part = nullptr;
     double* d_dinv = nullptr;  // inverses of the Cholesky diagonal blocks
     double* d_dch = nullptr;   // camera step in scaled variables
+    DagWorkspace dag;          // dataflow Cholesky (dag.n_tasks == 0: blocked multi-launch version)
     double *d_cam_static = nullptr, *d_rpc = nullptr;
     // solver state
     double *d_x = nullptr, *d_xnew = nullptr, *d_camc = nullptr, *d_camc_new = nullptr;
@@ -156,6 +158,21 @@ static int grid_for(long long work, int block, int cap) {
 static int launch_cam_consts(satba_problem* p, bool at_new) {
     hipLaunchKernelGGL(k_cam_consts, dim3((p->M + 63) / 64), dim3(64), 0, p->stream, p->model, p->M, p->NP, p->c_p,
                        at_new ? p->d_xnew : p->d_x, p->d_cam_static, at_new ? p->d_camc_new : p->d_camc);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// S z = rhs for the reduced system (S column-major lower, destroyed; b in place)
+static int dense_solve(satba_problem* p, double* S, double* b) {
+    if (p->dag.n_tasks > 0) {
+        HIP_TRY(hipMemsetAsync(p->dag.d_flags, 0, sizeof(int) * p->dag.flag_ints, p->stream));
+        DagFlags fl = dag_flags(p->dag);
+        hipLaunchKernelGGL(k_chol_dag, dim3(DG_GRID), dim3(DG_THREADS), 0, p->stream, S, p->n_c, b, p->dag.d_tasks, p->dag.n_tasks, fl);
+        hipLaunchKernelGGL(k_dag_status, dim3(1), dim3(1), 0, p->stream, fl.ctr, p->d_fail);
+        hipLaunchKernelGGL(k_trsv_back, dim3(1), dim3(1024), sizeof(double) * p->n_c, p->stream, S, p->n_c, b);
+    } else {
+        cholesky_solve(S, p->n_c, b, p->d_fail, p->d_dinv, p->stream);
+    }
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -458,6 +475,15 @@ int satba_problem_create(const satba_problem_desc* d, satba_problem** out) {
         TRY(dev_alloc(p, &p->d_tbuf, (size_t)3 * p->N)); TRY(dev_alloc(p, &p->d_dc, p->n_c));
         TRY(dev_alloc(p, &p->d_fail, 1));
         TRY(dev_alloc(p, &p->d_dch, p->n_c));
+        if (!getenv("SATBA_CHOL_BLOCKED")) {  // task list and flag words of the dataflow Cholesky
+            std::vector<DagTask> tasks = dag_task_list(p->n_c);
+            p->dag.NT = (p->n_c + DG_T - 1) / DG_T;
+            p->dag.n_tasks = (int)tasks.size();
+            p->dag.flag_ints = dag_flag_ints(p->dag.NT);
+            TRY(dev_alloc(p, &p->dag.d_tasks, tasks.size()));
+            TRY(dev_alloc(p, &p->dag.d_flags, p->dag.flag_ints));
+            HIP_TRY(hipMemcpy(p->dag.d_tasks, tasks.data(), sizeof(DagTask) * tasks.size(), hipMemcpyHostToDevice));
+        }
         TRY(dev_alloc(p, &p->d_dinv, cholesky_workspace_doubles(p->n_c)));
         TRY(dev_alloc(p, &p->d_scal, 8));
         p->lin_grid = grid_for(p->n_tiles, 16, lin1_lds(p, false) <= 78 * 1024 ? 512 : 256);
@@ -715,8 +741,7 @@ int satba_solve(satba_problem* p) {
                        p->d_scale_inv, S, rhs);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(p->d_dch, rhs, sizeof(double) * p->n_c, hipMemcpyDeviceToDevice, p->stream));
-    cholesky_solve(S, p->n_c, p->d_dch, p->d_fail, p->d_dinv, p->stream);
-    HIP_TRY(hipGetLastError());
+    TRY(dense_solve(p, S, p->d_dch));
     hipLaunchKernelGGL(k_unscale, dim3((p->n_c + 255) / 256), dim3(256), 0, p->stream, p->n_c, p->d_scale_inv, p->d_dch, p->d_dc);
     HIP_TRY(hipGetLastError());
     if (p->n_split > 0) HIP_TRY(hipMemsetAsync(p->d_tbuf, 0, sizeof(double) * 3 * p->N, p->stream));
@@ -846,8 +871,7 @@ int satba_time_kernel(satba_problem* p, int32_t phase, int32_t reps, float* ms_a
             case 2: return launch_schur_kernel(p);
             case 3: {
                 // factorising an already factorised matrix is meaningless numerically but identical in work
-                cholesky_solve(p->payload(), p->n_c, p->d_dch, p->d_fail, p->d_dinv, p->stream);
-                return 0;
+                return dense_solve(p, p->payload(), p->d_dch);
             }
             case 4: return launch_backsub_kernel(p);
             default: return launch_jvp(p, 2, p->d_gh, p->d_gn, p->d_scal);
