@@ -475,7 +475,8 @@ int satba_problem_create(const satba_problem_desc* d, satba_problem** out) {
         TRY(dev_alloc(p, &p->d_tbuf, (size_t)3 * p->N)); TRY(dev_alloc(p, &p->d_dc, p->n_c));
         TRY(dev_alloc(p, &p->d_fail, 1));
         TRY(dev_alloc(p, &p->d_dch, p->n_c));
-        if (!getenv("SATBA_CHOL_BLOCKED")) {  // task list and flag words of the dataflow Cholesky
+        if (getenv("SATBA_CHOL_DAG")) {  // experimental dataflow Cholesky (satba_chol_dag.h): correct, but slower
+                                         // than the blocked multi-launch version on MI355X
             std::vector<DagTask> tasks = dag_task_list(p->n_c);
             p->dag.NT = (p->n_c + DG_T - 1) / DG_T;
             p->dag.n_tasks = (int)tasks.size();
@@ -483,6 +484,7 @@ int satba_problem_create(const satba_problem_desc* d, satba_problem** out) {
             TRY(dev_alloc(p, &p->dag.d_tasks, tasks.size()));
             TRY(dev_alloc(p, &p->dag.d_flags, p->dag.flag_ints));
             HIP_TRY(hipMemcpy(p->dag.d_tasks, tasks.data(), sizeof(DagTask) * tasks.size(), hipMemcpyHostToDevice));
+            if (getenv("SATBA_DAG_TIMES")) TRY(dev_alloc(p, &p->dag.d_times, 4 * tasks.size()));
         }
         TRY(dev_alloc(p, &p->d_dinv, cholesky_workspace_doubles(p->n_c)));
         TRY(dev_alloc(p, &p->d_scal, 8));
@@ -842,6 +844,17 @@ int satba_set_exchange(satba_problem* p, int64_t offset, int64_t n, const double
     if (offset < 0 || n < 0 || offset + n > p->xb_len) return fail(SATBA_E_ARG, "exchange range out of bounds");
     HIP_TRY(hipStreamSynchronize(p->stream));
     HIP_TRY(hipMemcpy(p->d_xb + offset, host_in, sizeof(double) * n, hipMemcpyHostToDevice));
+    return 0;
+}
+
+// tools only (not declared in satba.h): per-task timestamps of the last dataflow Cholesky
+int satba_debug_dag_times(satba_problem* p, long long* host_out, int32_t* n_tasks) {
+    if (!p || !n_tasks) return fail(SATBA_E_ARG, "null argument");
+    *n_tasks = p->dag.d_times ? p->dag.n_tasks : 0;
+    if (host_out && p->dag.d_times) {
+        HIP_TRY(hipStreamSynchronize(p->stream));
+        HIP_TRY(hipMemcpy(host_out, p->dag.d_times, sizeof(long long) * 4 * p->dag.n_tasks, hipMemcpyDeviceToHost));
+    }
     return 0;
 }
 

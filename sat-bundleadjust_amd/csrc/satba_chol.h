@@ -149,6 +149,7 @@ __global__ __launch_bounds__(256) void k_syrk(double* __restrict__ A, int n, int
 __global__ __launch_bounds__(1024) void k_trsv_back(const double* __restrict__ L, int n, double* __restrict__ b) {
     extern __shared__ double yb[];  // n doubles
     __shared__ double t[CH_NB];
+    __shared__ double Dk[CH_NB][CH_NB + 1];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int i = tid; i < n; i += 1024) yb[i] = b[i];
     __syncthreads();
@@ -157,34 +158,46 @@ __global__ __launch_bounds__(1024) void k_trsv_back(const double* __restrict__ L
         const int k0 = kb * CH_NB;
         const int nb = min(CH_NB, n - k0);
         const int tail0 = k0 + nb;
-        for (int cc = 0; cc < 2; ++cc) {
-            const int c = wave * 2 + cc;
-            double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-            if (c < nb) {
-                const double* col = L + (size_t)(k0 + c) * n;
-                int r = tail0 + lane;
-                for (; r + 192 < n; r += 256) {
-                    s0 += col[r] * yb[r]; s1 += col[r + 64] * yb[r + 64];
-                    s2 += col[r + 128] * yb[r + 128]; s3 += col[r + 192] * yb[r + 192];
-                }
-                for (; r < n; r += 64) s0 += col[r] * yb[r];
-            }
-            double s = (s0 + s1) + (s2 + s3);
+        // both columns of this wave at once, 8 rows per lane and column in flight (16 independent loads)
+        {
+            const int ca = wave * 2, cb = wave * 2 + 1;
+            const double* cola = L + (size_t)(k0 + min(ca, nb - 1)) * n;
+            const double* colb = L + (size_t)(k0 + min(cb, nb - 1)) * n;
+            double sa = 0.0, sb = 0.0;
+            for (int rb = tail0; rb < n; rb += 512) {
+                double va[8], vb[8];
 #pragma unroll
-            for (int d = 32; d > 0; d >>= 1) s += __shfl_xor(s, d);
-            if (lane == 0 && c < nb) t[c] = yb[k0 + c] - s;
+                for (int u = 0; u < 8; ++u) {
+                    const int r = rb + u * 64 + lane;
+                    va[u] = (r < n) ? cola[r] : 0.0;
+                    vb[u] = (r < n) ? colb[r] : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int r = rb + u * 64 + lane;
+                    const double y = (r < n) ? yb[r] : 0.0;
+                    sa += va[u] * y;
+                    sb += vb[u] * y;
+                }
+            }
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) { sa += __shfl_xor(sa, d); sb += __shfl_xor(sb, d); }
+            if (lane == 0 && ca < nb) t[ca] = yb[k0 + ca] - sa;
+            if (lane == 0 && cb < nb) t[cb] = yb[k0 + cb] - sb;
+        }
+        // diagonal block into LDS (coalesced) while the dot products are in flight
+        for (int idx = tid; idx < CH_NB * CH_NB; idx += 1024) {
+            const int r = idx % CH_NB, c = idx / CH_NB;
+            Dk[r][c] = (r < nb && c < nb && r >= c) ? L[(size_t)(k0 + r) + (size_t)(k0 + c) * n] : ((r == c) ? 1.0 : 0.0);
         }
         __syncthreads();
-        if (wave == 0) {  // L_kk^T z = t: lane c holds column c of L_kk (rows >= c), solved from the bottom up
+        if (wave == 0) {  // L_kk^T z = t: lane c, solved from the bottom up
             double v = (lane < nb) ? t[lane] : 0.0;
-            const int cl = min(lane, nb - 1);
+            const int cl = min(lane, CH_NB - 1);
             for (int j = nb - 1; j >= 0; --j) {
-                // z_j = v_j / L[j][j]; then v_c -= L[j][c] z_j for c < j
-                const double ljj = L[(size_t)(k0 + j) + (size_t)(k0 + j) * n];
-                const double zj = __shfl(v, j) / ljj;
-                const double ljc = (lane < j) ? L[(size_t)(k0 + j) + (size_t)(k0 + cl) * n] : 0.0;
+                const double zj = __shfl(v, j) / Dk[j][j];
                 if (lane == j) v = zj;
-                else if (lane < j) v -= ljc * zj;
+                else if (lane < j) v -= Dk[j][cl] * zj;  // L[j][c]
             }
             if (lane < nb) yb[k0 + lane] = v;
         }

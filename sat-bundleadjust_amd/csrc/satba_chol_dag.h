@@ -44,6 +44,7 @@ struct DagFlags {  // all zeroed before each launch
     int* tb_done;  // NT
     int* updb;     // NT: number of Ub updates applied to block j of the right-hand side
     int* ctr;      // [0] task counter, [1] abort, [2] not-positive-definite
+    long long* times;  // optional (tools): per task draw / ready / done timestamps (s_memtime)
 };
 
 inline std::vector<DagTask> dag_task_list(int n) {
@@ -93,6 +94,7 @@ __global__ __launch_bounds__(DG_THREADS) void k_chol_dag(double* __restrict__ A,
         __syncthreads();
         const int t = s_task;
         if (t >= n_tasks) return;
+        const long long t_draw = fl.times ? (long long)__builtin_readcyclecounter() : 0;
         const DagTask tk = tasks[t];
         const int i = tk.i, j = tk.j, k = tk.k;
         // ---------------------------------------------------------------- wait for the inputs
@@ -112,6 +114,7 @@ __global__ __launch_bounds__(DG_THREADS) void k_chol_dag(double* __restrict__ A,
         }
         __syncthreads();
         if (!s_ok) return;
+        const long long t_ready = fl.times ? (long long)__builtin_readcyclecounter() : 0;
 
         const int r0 = i * DG_T, c0 = j * DG_T, k0 = k * DG_T;
         int* publish = nullptr;
@@ -248,6 +251,12 @@ __global__ __launch_bounds__(DG_THREADS) void k_chol_dag(double* __restrict__ A,
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __hip_atomic_store(publish, publish_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (fl.times) {
+                fl.times[4 * (size_t)t + 0] = t_draw;
+                fl.times[4 * (size_t)t + 1] = t_ready;
+                fl.times[4 * (size_t)t + 2] = (long long)__builtin_readcyclecounter();
+                fl.times[4 * (size_t)t + 3] = ((long long)tk.type << 48) | ((long long)tk.i << 32) | ((long long)tk.j << 16) | tk.k;
+            }
         }
     }
 }
@@ -264,6 +273,7 @@ struct DagWorkspace {
     int* d_flags = nullptr;  // one allocation, carved into DagFlags
     size_t flag_ints = 0;
     int NT = 0;
+    long long* d_times = nullptr;  // only with SATBA_DAG_TIMES (tools/dag_times.py)
 };
 
 inline DagFlags dag_flags(const DagWorkspace& w) {
@@ -275,6 +285,7 @@ inline DagFlags dag_flags(const DagWorkspace& w) {
     f.tb_done = p; p += w.NT;
     f.updb = p; p += w.NT;
     f.ctr = p;
+    f.times = w.d_times;
     return f;
 }
 
