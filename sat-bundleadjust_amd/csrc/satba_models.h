@@ -82,15 +82,16 @@ __device__ inline void geodetic(double x, double y, double z, double out[3], dou
     const double p2 = x * x + y * y;
     const double p = sqrt(p2);
     const double u = a * z, w = b * p;
-    const double th = atan2(u, w);
-    double s, c;
-    sincos(th, &s, &c);
+    // th = atan2(u, w) and lat = atan2(num, den) only enter through their sines and cosines (plus lat itself):
+    // take those from the triangle sides instead of atan2 + sincos (2 atan2 instead of 3, no sincos)
+    const double ihw = 1.0 / sqrt(u * u + w * w);
+    const double s = u * ihw, c = w * ihw;
     const double num = z + ep2 * b * s * s * s;
     const double den = p - esq * a * c * c * c;
     const double lat = atan2(num, den);
     const double lon = atan2(y, x);
-    double sl, cl;
-    sincos(lat, &sl, &cl);
+    const double ihl = 1.0 / sqrt(num * num + den * den);
+    const double sl = num * ihl, cl = den * ihl;
     const double t = 1.0 - esq * sl * sl;
     const double rt = sqrt(t);
     const double Nv = a / rt;
@@ -121,22 +122,24 @@ __device__ inline void geodetic(double x, double y, double z, double out[3], dou
     }
 }
 
-// 20-term cubic (RPC00B order, L = lon, P = lat, H = alt, all normalised) and its gradient
+// 20-term cubic in RPC00B order (L = lon, P = lat, H = alt, all normalised)
+//   1, L, P, H, LP, LH, PH, L2, P2, H2, PLH, L3, LP2, LH2, L2P, P3, PH2, L2H, P2H, H3
+// and its gradient, as straight-line code on ten shared products: no monomial arrays (the array form cost 160
+// VGPRs and pushed every RPC kernel into scratch).
 template <bool JAC>
-__device__ inline void rpc_poly(const double* __restrict__ c, const double* m, const double* mL, const double* mP,
-                                const double* mH, double& val, double& dL, double& dP, double& dH) {
-    double v = 0.0, a = 0.0, b = 0.0, h = 0.0;
-#pragma unroll
-    for (int i = 0; i < 20; ++i) {
-        const double ci = c[i];
-        v += ci * m[i];
-        if (JAC) {
-            a += ci * mL[i];
-            b += ci * mP[i];
-            h += ci * mH[i];
-        }
+__device__ inline void rpc_poly(const double* __restrict__ c, double L, double P, double H, double LL, double PP, double HH,
+                                double LP, double LH, double PH, double& val, double& dL, double& dP, double& dH) {
+    val = c[0] + c[1] * L + c[2] * P + c[3] * H + c[4] * LP + c[5] * LH + c[6] * PH + c[7] * LL + c[8] * PP + c[9] * HH +
+          c[10] * LP * H + c[11] * LL * L + c[12] * L * PP + c[13] * L * HH + c[14] * LL * P + c[15] * PP * P +
+          c[16] * P * HH + c[17] * LL * H + c[18] * PP * H + c[19] * HH * H;
+    if (JAC) {
+        dL = c[1] + c[4] * P + c[5] * H + 2.0 * c[7] * L + c[10] * PH + 3.0 * c[11] * LL + c[12] * PP + c[13] * HH +
+             2.0 * c[14] * LP + 2.0 * c[17] * LH;
+        dP = c[2] + c[4] * L + c[6] * H + 2.0 * c[8] * P + c[10] * LH + 2.0 * c[12] * LP + c[14] * LL + 3.0 * c[15] * PP +
+             c[16] * HH + 2.0 * c[18] * PH;
+        dH = c[3] + c[5] * L + c[6] * P + 2.0 * c[9] * H + c[10] * LP + 2.0 * c[13] * LH + 2.0 * c[16] * PH + c[17] * LL +
+             c[18] * PP + 3.0 * c[19] * HH;
     }
-    val = v; dL = a; dP = b; dH = h;
 }
 
 // projection of an already-adjusted ECEF point through one RPC record; D = d(col,row)/dX' if JAC
@@ -149,23 +152,18 @@ __device__ inline void rpc_project(const double* __restrict__ tab, double x, dou
     const double L = (geo[1] - tab[80]) * ilon;
     const double P = (geo[0] - tab[82]) * ilat;
     const double H = (geo[2] - tab[84]) * ialt;
-    double m[20], mL[20], mP[20], mH[20];
-    const double LL = L * L, PP = P * P, HH = H * H;
-    m[0] = 1.0; m[1] = L; m[2] = P; m[3] = H; m[4] = L * P; m[5] = L * H; m[6] = P * H; m[7] = LL; m[8] = PP;
-    m[9] = HH; m[10] = P * L * H; m[11] = LL * L; m[12] = L * PP; m[13] = L * HH; m[14] = LL * P; m[15] = PP * P;
-    m[16] = P * HH; m[17] = LL * H; m[18] = PP * H; m[19] = HH * H;
-    if (JAC) {
-        const double dl[20] = {0, 1, 0, 0, P, H, 0, 2 * L, 0, 0, P * H, 3 * LL, PP, HH, 2 * L * P, 0, 0, 2 * L * H, 0, 0};
-        const double dp[20] = {0, 0, 1, 0, L, 0, H, 0, 2 * P, 0, L * H, 0, 2 * L * P, 0, LL, 3 * PP, HH, 0, 2 * P * H, 0};
-        const double dh[20] = {0, 0, 0, 1, 0, L, P, 0, 0, 2 * H, P * L, 0, 0, 2 * L * H, 0, 0, 2 * P * H, LL, PP, 3 * HH};
-        for (int i = 0; i < 20; ++i) { mL[i] = dl[i]; mP[i] = dp[i]; mH[i] = dh[i]; }
-    }
-    double n, nL, nP, nH, d, dL, dP, dH;
+    const double LL = L * L, PP = P * P, HH = H * H, LP = L * P, LH = L * H, PH = P * H;
     // col = tab[0..19] / tab[20..39]; row = tab[40..59] / tab[60..79]
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
-        rpc_poly<JAC>(tab + 40 * k, m, mL, mP, mH, n, nL, nP, nH);
-        rpc_poly<JAC>(tab + 40 * k + 20, m, mL, mP, mH, d, dL, dP, dH);
+        double n, nL, nP, nH, d, dL, dP, dH;
+        // compiler barriers: only one polynomial's 20 coefficients are in flight at a time; without them all 80
+        // loads are hoisted to the top and the kernels spill
+        asm volatile("" ::: "memory");
+        rpc_poly<JAC>(tab + 40 * k, L, P, H, LL, PP, HH, LP, LH, PH, n, nL, nP, nH);
+        asm volatile("" ::: "memory");
+        rpc_poly<JAC>(tab + 40 * k + 20, L, P, H, LL, PP, HH, LP, LH, PH, d, dL, dP, dH);
+        asm volatile("" ::: "memory");
         const double id = 1.0 / d;
         const double q = n * id;
         const double scale = tab[87 + 2 * k], off = tab[86 + 2 * k];
