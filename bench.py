@@ -32,6 +32,12 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 
+# HBM bytes per k_linearize launch from rocprofv3 PMC passes of this same command (profiles/r1_final_pmc_hbm_traffic.txt):
+# 2 x FETCH_SIZE (gfx950 counts 128-B requests as 64 B, MI355X_MICROARCH.md section HBM) + WRITE_SIZE, both in KiB.
+# PMC counters cannot be read from inside an unprofiled run, so the committed measurement is quoted for the shape
+# it was taken on (one GPU) and the field is null otherwise.
+PROFILED_TRAFFIC_BYTES = {("C4", 1): (2 * 185657.4 + 239116.9) * 1024.0}
+
 
 def lm_step(eng, comm, st, trf):
     """One fixed-work LM iteration (see module docstring).  `st` carries cost, Delta between steps."""
@@ -193,7 +199,8 @@ def main():
                        "obs_per_rank0": K_loc},
             "obs_per_sec_residual_jacobian": world * K_loc / t_lin,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "kernel": "k_linearize",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": PROFILED_TRAFFIC_BYTES.get((args.shape, world)),
+                         "kernel": "k_linearize",
                          "algorithmic_bytes_per_launch": alg_bytes, "ms_per_launch": kern["linearize"]},
             "kernel_ms": kern,
             "accepted_steps": st["accepted"], "final_cost": st["cost"], "scene_gen_s": t_gen,
