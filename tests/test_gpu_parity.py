@@ -457,3 +457,40 @@ def test_rccl_plumbing_single_rank(gpu):
         eng.close()
     finally:
         dist.destroy_process_group()
+
+
+# ----------------------------------------------------------------------------- alternative kernel paths
+
+ALT_PATHS = [
+    {"SATBA_SCHUR": "2"},            # Schur v2: LDS column panels (taken by default above 512 cameras)
+    {"SATBA_SCHUR": "1"},            # Schur v1: global atomics (panel does not fit LDS)
+    {"SATBA_SCHUR_BITMAP": "1"},     # Schur v3 with the bitmap scan instead of the per-pair lists (lists too large)
+    {"SATBA_LIN": "3"},              # two-pass linearize (camera table larger than the fused kernel's LDS budget)
+    {"SATBA_CAMC_GLOBAL": "1"},      # camera constants gathered from global memory (more than ~210 cameras)
+    {"SATBA_CHOL_DAG": "1"},         # experimental dataflow Cholesky
+]
+
+
+@pytest.mark.parametrize("env", ALT_PATHS, ids=lambda e: "-".join("{}={}".format(k, v) for k, v in e.items()))
+@pytest.mark.parametrize("name,loss", [("affine_RT", "linear"), ("persp_RT", "soft_l1"), ("rpc_R", "linear")])
+def test_alternative_kernel_paths(gpu, monkeypatch, env, name, loss):
+    """The fallback variants selected by problem size (or by these switches) must give the same phases."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)  # read once, when the problem handle is created
+    _, p, g = cases.fun_case(name)
+    # non-unit weights so that the weighted code paths of the Schur kernels are exercised as well
+    p.pts2d_w = p.pts2d_w.copy()
+    p.pts2d_w[::3] = 1.7
+    v = ba_core._frozen_vars(g["v"][1].copy(), p)
+    dev, ora = HipEngine(p, rpc_f32=False), L.OracleEngine(p, rpc_f32=False)
+    for e in (dev, ora):
+        e.configure(loss, 1.0)
+        e.set_x(v)
+    a, b = _run_phases(dev, 1e-3), _run_phases(ora, 1e-3)
+    for phase, slots in (("lin", [trf.COST, dev.HDR_FIXED]), ("prep", [trf.GH_SQ, trf.JG_SQ, trf.XS_SQ, trf.GC_INF]),
+                         ("solve", [trf.GRAM_A, trf.GRAM_B, trf.GRAM_C, trf.CHOL_FAIL]),
+                         ("sub", [trf.WW, trf.B11, trf.B12, trf.B22]), ("trial", [trf.COST_NEW, trf.STEP_SQ, trf.X_SQ])):
+        for s in slots:
+            assert abs(a[phase][s] - b[phase][s]) <= 1e-7 * abs(b[phase][s]) + 1e-300, (phase, s, a[phase][s], b[phase][s])
+    assert rel(dev.get_vector("gn_h"), ora.gn_h) < 1e-7
+    dev.close()
