@@ -412,7 +412,7 @@ def test_full_size_properties(gpu, shape):
     assert rel(Us, U) < 1e-9 and rel(gcs, gc) < 1e-7
 
     costs, st = _lm_iterations(eng, 6)
-    assert all(b <= a * (1 + 1e-12) for a, b in zip(costs, costs[1:])) and st["accepted"] >= 3
+    assert all(b <= a * (1 + 1e-12) for a, b in zip(costs, costs[1:])) and st["accepted"] >= 2  # then at the floor
     # noise floor: 0.3 px per coordinate -> cost ~ 0.5 * 2K * 0.09 minus the fitted degrees of freedom
     expected = 0.5 * 0.09 * (2 * p.n_obs - (p.n_cam * p.n_params + 3 * p.n_pts))
     assert abs(costs[-1] - expected) < 0.02 * expected
