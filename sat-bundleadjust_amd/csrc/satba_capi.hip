@@ -87,6 +87,7 @@ struct satba_problem {
     long long* d_pair_ofs = nullptr;  // per camera pair: list of shared points (null: bitmap scan)
     int* d_pair_pts = nullptr;
     int unit_weights = 0;
+    int u_full = 1;            // linearize accumulates the full U_c blocks (0: diagonal only, Schur v3 adds the rest)
     int* d_fail = nullptr;
     double* d_scal = nullptr;  // 8 private scalars (costs of satba_residuals, timing sinks)
     double *d_xb_own = nullptr, *d_xb = nullptr;
@@ -217,19 +218,24 @@ static size_t lin1_lds(const satba_problem* p, bool robust) {
     return sizeof(double) * ((size_t)p->M * cam_acc_len(p->NP) + (size_t)waves * 9 * 64) + p->camc_bytes;
 }
 
-template <int MODEL, int NP, bool CL>
-static int launch_lin1(satba_problem* p, const ObsArgs& a) {
+template <int MODEL, int NP, bool CL, bool FULLU>
+static int launch_lin1u(satba_problem* p, const ObsArgs& a) {
     double* gpv = p->d_g + p->n_c;
     double* cost = p->d_xb + 0;
     double* gmax = p->d_xb + SATBA_HDR_FIXED + p->rank;
     if (p->loss == 0)
-        hipLaunchKernelGGL((k_linearize<MODEL, NP, false, CL>), dim3(p->lin_grid), dim3(LinCfg<false>::THREADS), lin1_lds(p, false),
-                           p->stream, a, p->d_f, p->d_V, gpv, p->d_part, cost, gmax);
+        hipLaunchKernelGGL((k_linearize<MODEL, NP, false, CL, FULLU>), dim3(p->lin_grid), dim3(LinCfg<false>::THREADS),
+                           lin1_lds(p, false), p->stream, a, p->d_f, p->d_V, gpv, p->d_part, cost, gmax);
     else
-        hipLaunchKernelGGL((k_linearize<MODEL, NP, true, CL>), dim3(p->lin_grid), dim3(LinCfg<true>::THREADS), lin1_lds(p, true),
-                           p->stream, a, p->d_f, p->d_V, gpv, p->d_part, cost, gmax);
+        hipLaunchKernelGGL((k_linearize<MODEL, NP, true, CL, FULLU>), dim3(p->lin_grid), dim3(LinCfg<true>::THREADS),
+                           lin1_lds(p, true), p->stream, a, p->d_f, p->d_V, gpv, p->d_part, cost, gmax);
     HIP_TRY(hipGetLastError());
     return 0;
+}
+
+template <int MODEL, int NP, bool CL>
+static int launch_lin1(satba_problem* p, const ObsArgs& a) {
+    return p->u_full ? launch_lin1u<MODEL, NP, CL, true>(p, a) : launch_lin1u<MODEL, NP, CL, false>(p, a);
 }
 
 static int launch_linearize_kernel(satba_problem* p) {
@@ -244,7 +250,7 @@ static int launch_linearize_kernel(satba_problem* p) {
 
 static size_t schur_lds(const satba_problem* p) { return sizeof(double) * ((size_t)4 * 64 * p->NP * 3 + p->n_c); }
 
-template <int MODEL, int NP>
+template <int MODEL, int NP, bool ADDU>
 static int launch_schur3(satba_problem* p, const ObsArgs& a, double* S, double* rhs) {
     CamMajor cm;
     cm.cam_ofs = p->d_cam_ofs; cm.obs = p->d_cm_obs; cm.w = p->d_cm_w; cm.pt = p->d_cm_pt;
@@ -256,13 +262,13 @@ static int launch_schur3(satba_problem* p, const ObsArgs& a, double* S, double* 
     const int diag_chunks = p->lin3_chunks;
     if (p->loss == 0 && p->unit_weights) {
         if (items > 0) hipLaunchKernelGGL((k_schur_pairs<MODEL, NP, false, true>), dim3((unsigned)((items + 3) / 4)), dim3(256), 0, p->stream, a, cm, s, S);
-        hipLaunchKernelGGL((k_schur_diag<MODEL, NP, false>), dim3(diag_chunks, p->M), dim3(LINC_THREADS), 0, p->stream, a, cm, s, p->d_part3);
+        hipLaunchKernelGGL((k_schur_diag<MODEL, NP, false, ADDU>), dim3(diag_chunks, p->M), dim3(LINC_THREADS), 0, p->stream, a, cm, s, p->d_part3);
     } else if (p->loss == 0) {
         if (items > 0) hipLaunchKernelGGL((k_schur_pairs<MODEL, NP, false, false>), dim3((unsigned)((items + 3) / 4)), dim3(256), 0, p->stream, a, cm, s, S);
-        hipLaunchKernelGGL((k_schur_diag<MODEL, NP, false>), dim3(diag_chunks, p->M), dim3(LINC_THREADS), 0, p->stream, a, cm, s, p->d_part3);
+        hipLaunchKernelGGL((k_schur_diag<MODEL, NP, false, ADDU>), dim3(diag_chunks, p->M), dim3(LINC_THREADS), 0, p->stream, a, cm, s, p->d_part3);
     } else {
         if (items > 0) hipLaunchKernelGGL((k_schur_pairs<MODEL, NP, true, false>), dim3((unsigned)((items + 3) / 4)), dim3(256), 0, p->stream, a, cm, s, S);
-        hipLaunchKernelGGL((k_schur_diag<MODEL, NP, true>), dim3(diag_chunks, p->M), dim3(LINC_THREADS), 0, p->stream, a, cm, s, p->d_part3);
+        hipLaunchKernelGGL((k_schur_diag<MODEL, NP, true, ADDU>), dim3(diag_chunks, p->M), dim3(LINC_THREADS), 0, p->stream, a, cm, s, p->d_part3);
     }
     HIP_TRY(hipGetLastError());
     const int total = p->M * cam_acc_len(p->NP);
@@ -277,7 +283,8 @@ static int launch_schur_kernel(satba_problem* p) {
     double* S = p->payload();
     double* rhs = S + (size_t)p->n_c * p->n_c;
     if (p->sch3_chunks > 0) {  // v3: camera-pair intersection, register accumulation
-        SATBA_DISPATCH(p, TRY((launch_schur3<MODEL, NP>(p, a, S, rhs))));
+        if (p->u_full) SATBA_DISPATCH(p, TRY((launch_schur3<MODEL, NP, false>(p, a, S, rhs))));
+        else SATBA_DISPATCH(p, TRY((launch_schur3<MODEL, NP, true>(p, a, S, rhs))));
         return 0;
     }
     if (p->sch_T > 0) {  // v2: LDS column panels, no global atomics
@@ -426,8 +433,10 @@ int satba_problem_create(const satba_problem_desc* d, satba_problem** out) {
         if (schur_lds(p) > 160 * 1024)
             return fail(SATBA_E_ARG, "n_cam = %d exceeds the LDS budget of the Schur kernels of this build", p->M);
         if (lin1_fits) {
-            SATBA_DISPATCH(p, TRY(raise_lds_limit(k_linearize<MODEL, NP, false, CL>, lin1_lds(p, false))));
-            SATBA_DISPATCH(p, TRY(raise_lds_limit(k_linearize<MODEL, NP, true, CL>, lin1_lds(p, true))));
+            SATBA_DISPATCH(p, TRY(raise_lds_limit(k_linearize<MODEL, NP, false, CL, true>, lin1_lds(p, false))));
+            SATBA_DISPATCH(p, TRY(raise_lds_limit(k_linearize<MODEL, NP, true, CL, true>, lin1_lds(p, true))));
+            SATBA_DISPATCH(p, TRY(raise_lds_limit(k_linearize<MODEL, NP, false, CL, false>, lin1_lds(p, false))));
+            SATBA_DISPATCH(p, TRY(raise_lds_limit(k_linearize<MODEL, NP, true, CL, false>, lin1_lds(p, true))));
         }
         SATBA_DISPATCH(p, TRY(raise_lds_limit(k_schur<MODEL, NP>, schur_lds(p))));
         {   // Schur panel configuration: T cameras per panel so that panel (+ camera table) fit the 160 KB LDS
@@ -560,6 +569,8 @@ int satba_problem_create(const satba_problem_desc* d, satba_problem** out) {
                 }
             }
             if (swhich == 1) p->sch_T = 0;
+            // with Schur v3 and the fused linearize kernel, U_c's off-diagonal entries are formed in k_schur_diag
+            p->u_full = (p->sch3_chunks > 0 && p->lin3_grid == 0 && !getenv("SATBA_FULL_U")) ? 0 : 1;
         }
         p->xb_len = satba_exchange_len(p);
         TRY(dev_alloc(p, &p->d_xb_own, p->xb_len));
@@ -727,7 +738,7 @@ int satba_schur(satba_problem* p, double lam) {
     }
     double* S = p->payload();
     hipLaunchKernelGGL(k_schur_init, dim3((p->M * p->NP * p->NP + 255) / 256), dim3(256), 0, p->stream, p->M, p->NP, lam, p->lead,
-                       p->d_U, p->d_gc, p->d_scale_inv, S, S + (size_t)p->n_c * p->n_c);
+                       p->u_full, p->d_U, p->d_gc, p->d_scale_inv, S, S + (size_t)p->n_c * p->n_c);
     HIP_TRY(hipGetLastError());
     if (p->K > 0) TRY(launch_schur_kernel(p));
     return 0;
@@ -804,7 +815,30 @@ int satba_get_blocks(satba_problem* p, double* U, double* gc, double* V, double*
     if (!p->linearized) return fail(SATBA_E_STATE, "get_blocks before linearize");
     HIP_TRY(hipStreamSynchronize(p->stream));
     const size_t nU = (size_t)p->M * p->NP * p->NP;
-    if (U) HIP_TRY(hipMemcpy(U, p->payload(), sizeof(double) * nU, hipMemcpyDeviceToHost));
+    if (U && !p->u_full) {
+        // the linearize kernel only kept diag(U_c): form the full blocks with the camera-major pass (inspection only)
+        double *dU = nullptr, *dg = nullptr;
+        HIP_TRY(hipMalloc((void**)&dU, sizeof(double) * nU));
+        HIP_TRY(hipMalloc((void**)&dg, sizeof(double) * p->n_c));
+        ObsArgs a = obs_args(p, false);
+        CamMajor cm;
+        cm.cam_ofs = p->d_cam_ofs; cm.obs = p->d_cm_obs; cm.w = p->d_cm_w; cm.pt = p->d_cm_pt;
+        int rc = [&]() -> int {
+            SATBA_DISPATCH(p, hipLaunchKernelGGL((k_lin_cameras<MODEL, NP, true>), dim3(p->lin3_chunks, p->M), dim3(LINC_THREADS), 0,
+                                                 p->stream, a, cm, p->d_part3));
+            const int total = p->M * cam_acc_len(p->NP);
+            hipLaunchKernelGGL(k_lin3_finish, dim3((total + 255) / 256), dim3(256), 0, p->stream, p->M, p->NP, p->lin3_chunks, p->d_part3, dU, dg);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipStreamSynchronize(p->stream));
+            HIP_TRY(hipMemcpy(U, dU, sizeof(double) * nU, hipMemcpyDeviceToHost));
+            return 0;
+        }();
+        (void)hipFree(dU);
+        (void)hipFree(dg);
+        if (rc) return rc;
+    } else if (U) {
+        HIP_TRY(hipMemcpy(U, p->payload(), sizeof(double) * nU, hipMemcpyDeviceToHost));
+    }
     if (gc) HIP_TRY(hipMemcpy(gc, p->payload() + nU, sizeof(double) * p->n_c, hipMemcpyDeviceToHost));
     if (V) HIP_TRY(hipMemcpy(V, p->d_V, sizeof(double) * 6 * p->N, hipMemcpyDeviceToHost));
     if (gp) HIP_TRY(hipMemcpy(gp, p->d_g + p->n_c, sizeof(double) * 3 * p->N, hipMemcpyDeviceToHost));

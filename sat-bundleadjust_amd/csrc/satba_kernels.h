@@ -196,7 +196,10 @@ struct LinCfg {
 };
 
 // LDS layout (dynamic): camera accumulators [M][CU] | camera constants [M][CAMC] (if CL) | per-wave staging [WAVES][9][64]
-template <int MODEL, int NP, bool ROBUST, bool CL>
+// FULLU = false: only diag(U_c) and g_c are accumulated (2 NP atomics per observation instead of NP(NP+3)/2): that
+// is all the solver needs before the Schur phase, whose camera-major pass (k_schur_diag) forms the full J_c^T J_c
+// blocks in registers anyway.
+template <int MODEL, int NP, bool ROBUST, bool CL, bool FULLU>
 __global__ __launch_bounds__(LinCfg<ROBUST>::THREADS) void k_linearize(ObsArgs a, double2* __restrict__ f, double* __restrict__ V,
                                                                       double* __restrict__ gp, double* __restrict__ part,
                                                                       double* __restrict__ hdr_cost, double* __restrict__ hdr_gpmax) {
@@ -246,7 +249,10 @@ __global__ __launch_bounds__(LinCfg<ROBUST>::THREADS) void k_linearize(ObsArgs a
 #pragma unroll
             for (int i = 0; i < NP; ++i)
 #pragma unroll
-                for (int j = i; j < NP; ++j) atomicAdd(acc + (k++), e.Jc[0][i] * e.Jc[0][j] + e.Jc[1][i] * e.Jc[1][j]);
+                for (int j = i; j < NP; ++j) {
+                    if (FULLU || i == j) atomicAdd(acc + k, e.Jc[0][i] * e.Jc[0][j] + e.Jc[1][i] * e.Jc[1][j]);
+                    ++k;
+                }
 #pragma unroll
             for (int i = 0; i < NP; ++i) atomicAdd(acc + (k++), e.Jc[0][i] * e.fs[0] + e.Jc[1][i] * e.fs[1]);
 #else  // ablation build only (tools): keep the products alive with ONE atomic
@@ -459,14 +465,15 @@ __global__ void k_vinv(int N, double lam, const double* __restrict__ V, const do
 }
 
 // S <- (lead) * blockdiag(U_c + lam Dc^2), rhs <- (lead) * g_c ; S column-major n_c x n_c (already zeroed)
-__global__ void k_schur_init(int M, int NP, double lam, double lead, const double* __restrict__ U,
+// use_U = 0: the J_c^T J_c blocks are added by k_schur_diag instead (only the damping goes on the diagonal here)
+__global__ void k_schur_init(int M, int NP, double lam, double lead, int use_U, const double* __restrict__ U,
                              const double* __restrict__ gc, const double* __restrict__ scale_inv,
                              double* __restrict__ S, double* __restrict__ rhs) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     const int n_c = M * NP;
     if (idx < M * NP * NP) {
         const int cam = idx / (NP * NP), r = (idx / NP) % NP, c = idx % NP;
-        double v = U[idx];
+        double v = use_U ? U[idx] : 0.0;
         if (r == c) { const double s = scale_inv[cam * NP + r]; v += lam * s * s; }
         S[(size_t)(cam * NP + r) + (size_t)(cam * NP + c) * n_c] = lead * v;
     }

@@ -181,8 +181,9 @@ __global__ __launch_bounds__(256) void k_schur_pairs(ObsArgs a, CamMajor c, Schu
 }
 
 // Diagonal blocks and right-hand side: camera-major pass, registers only.
-//   S_ii -= sum_p W_ip Vinv W_ip^T,   rhs_i -= sum_p W_ip Vinv g_p.   grid (chunks, M); part [M][chunks][CU]
-template <int MODEL, int NP, bool ROBUST>
+//   S_ii += sum_p (Jc^T Jc [ADDU] - W_ip Vinv W_ip^T),   rhs_i -= sum_p W_ip Vinv g_p.   grid (chunks, M); part [M][chunks][CU]
+// ADDU: also add J_c^T J_c (the U_c block), which the linearize kernel then does not have to accumulate.
+template <int MODEL, int NP, bool ROBUST, bool ADDU>
 __global__ __launch_bounds__(LINC_THREADS) void k_schur_diag(ObsArgs a, CamMajor c, Schur3Args s, double* __restrict__ part) {
     constexpr int CU = cam_acc_len(NP);
     const int cam = blockIdx.y, chunk = blockIdx.x, n_chunks = gridDim.x;
@@ -219,7 +220,11 @@ __global__ __launch_bounds__(LINC_THREADS) void k_schur_diag(ObsArgs a, CamMajor
             const double y0 = m00 * Jc[0][r] + m01 * Jc[1][r];
             const double y1 = m01 * Jc[0][r] + m11 * Jc[1][r];
 #pragma unroll
-            for (int q = r; q < NP; ++q) acc[k++] -= Jc[0][q] * y0 + Jc[1][q] * y1;
+            for (int q = r; q < NP; ++q) {
+                acc[k] -= Jc[0][q] * y0 + Jc[1][q] * y1;
+                if (ADDU) acc[k] += Jc[0][r] * Jc[0][q] + Jc[1][r] * Jc[1][q];
+                ++k;
+            }
         }
 #pragma unroll
         for (int r = 0; r < NP; ++r) acc[k++] -= Jc[0][r] * ag0 + Jc[1][r] * ag1;
