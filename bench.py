@@ -63,18 +63,16 @@ def lm_step(eng, comm, st, trf):
     comm.allreduce(eng, hdr)
     h = eng.read_header()
     ga, gb = h[trf.GRAM_A], h[trf.GRAM_B]
+    gc_ = h[trf.GRAM_C]
     eng.subspace(gb / ga, 1.0 / np.sqrt(ga))
     comm.allreduce(eng, hdr)
     h = eng.read_header()
-    ww = h[trf.WW]
-    if ww > 0:
-        nw = np.sqrt(ww)
-        B_S = np.array([[h[trf.B11], h[trf.B12] / nw], [h[trf.B12] / nw, h[trf.B22] / ww]])
-        g_S = np.array([np.sqrt(ga), h[trf.GHW] / nw])
-    else:
-        nw = np.inf
-        B_S = np.array([[h[trf.B11], 0.0], [0.0, 1.0]])
-        g_S = np.array([np.sqrt(ga), 0.0])
+
+    def exchange(n):
+        comm.allreduce(eng, n)
+        return eng.read_header()
+
+    B_S, g_S, nw = trf.subspace_model(eng, exchange, h, ga, gb, gc_, jg_sq, reg)
     p_S, _ = trf.solve_trust_region_2d(B_S, g_S, Delta)
     predicted = -(0.5 * p_S @ B_S @ p_S + g_S @ p_S)
     eng.trial(p_S[0], p_S[1] / nw)

@@ -110,7 +110,8 @@ int satba_residuals(satba_problem *p, double *host_r, double *host_cost);
 
 /* residuals + analytic Jacobian -> normal-equation blocks at x.  Replaces scipy's finite-difference
  * Jacobian (scipy:optimize/_numdiff.py:628-705), compute_grad (common.py:590-595) and the robust
- * rescaling (common.py:720-731).  Exchange payload: U (M x n_p x n_p) | g_c (M x n_p).                    */
+ * rescaling (common.py:720-731).  Exchange payload: U (M x n_p x n_p) | g_c (M x n_p); only diag(U_c) is
+ * guaranteed (the off-diagonal entries are formed in the Schur phase when its camera-major pass is used).  */
 int satba_linearize(satba_problem *p);
 /* after the all-reduce: x_scale="jac" update (common.py:598-610), g_h, |J_h g_h|^2 for the Cauchy step
  * (trf.py:473-477).                                                                                       */
@@ -120,8 +121,13 @@ int satba_prepare(satba_problem *p, int32_t first);
 int satba_schur(satba_problem *p, double lam);
 /* after the all-reduce: dense Cholesky solve, point back-substitution, Gram matrix of (g_h, gn_h).        */
 int satba_solve(satba_problem *p);
-/* basis of span{g_h, gn_h} and the quadratic model restricted to it (trf.py:481-485).                     */
+/* basis of span{g_h, gn_h} (trf.py:481-482): q1 = inv_norm_g * g_h, w = gn_h - alpha * g_h, and their dots.
+ * The quadratic model on that basis (trf.py:483-485) follows on the host from the normal equations,
+ * J_h^T J_h gn_h = g_h - reg gn_h, without another pass over the observations (satba/trf.py);
+ * satba_subspace_products computes the three products |J_h q1|^2, (J_h q1).(J_h w), |J_h w|^2 explicitly
+ * (header slots 3..5) for the ill-conditioned case and for the tests.                                      */
 int satba_subspace(satba_problem *p, double alpha, double inv_norm_g);
+int satba_subspace_products(satba_problem *p);
 /* x_new = x + scale * (p0 q1 + p1 w); cost at x_new (trf.py:497-512).                                     */
 int satba_trial(satba_problem *p, double p0, double p1);
 int satba_accept(satba_problem *p);

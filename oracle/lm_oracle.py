@@ -362,14 +362,18 @@ class OracleEngine:
     def subspace(self, alpha, inv_norm_g):
         self.q1 = self.g_h * inv_norm_g
         self.w = self.gn_h - alpha * self.g_h
-        j1 = self._jvp(self.scale * self.q1)
-        j2 = self._jvp(self.scale * self.w)
         b = self._xb
         b[: self.hdr] = 0
         b[1] = self._dot(self.w, self.w)
         b[2] = self._dot(self.w, self.q1)
-        b[3], b[4], b[5] = np.sum(j1 * j1), np.sum(j1 * j2), np.sum(j2 * j2)
         b[6] = self._dot(self.g_h, self.w)
+
+    def subspace_products(self):
+        j1 = self._jvp(self.scale * self.q1)
+        j2 = self._jvp(self.scale * self.w)
+        b = self._xb
+        b[: self.hdr] = 0
+        b[3], b[4], b[5] = np.sum(j1 * j1), np.sum(j1 * j2), np.sum(j2 * j2)
 
     def trial(self, p0, p1):
         step = self.scale * (p0 * self.q1 + p1 * self.w)

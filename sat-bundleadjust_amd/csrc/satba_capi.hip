@@ -777,6 +777,14 @@ int satba_subspace(satba_problem* p, double alpha, double inv_norm_g) {
     hipLaunchKernelGGL(k_subspace_vec, dim3(grid_for(p->n, 256, 512)), dim3(256), 0, p->stream, p->n, p->n_c, p->lead, alpha,
                        inv_norm_g, p->d_gh, p->d_gn, p->d_q1, p->d_wv, p->d_xb);
     HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int satba_subspace_products(satba_problem* p) {
+    if (!p) return fail(SATBA_E_ARG, "null handle");
+    if (!p->have_step) return fail(SATBA_E_STATE, "subspace_products before solve");
+    HIP_TRY(hipSetDevice(p->device));
+    TRY(zero_header(p));
     TRY(launch_jvp(p, 2, p->d_q1, p->d_wv, p->d_xb + 3));
     return 0;
 }

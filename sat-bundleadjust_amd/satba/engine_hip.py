@@ -26,7 +26,7 @@ HDR_FIXED = 16
 SYMBOLS = [
     "satba_last_error", "satba_version", "satba_problem_create", "satba_problem_destroy", "satba_set_stream",
     "satba_exchange_len", "satba_header_len", "satba_bind_exchange", "satba_configure", "satba_set_x", "satba_get_x",
-    "satba_residuals", "satba_linearize", "satba_prepare", "satba_schur", "satba_solve", "satba_subspace", "satba_trial",
+    "satba_residuals", "satba_linearize", "satba_prepare", "satba_schur", "satba_solve", "satba_subspace", "satba_subspace_products", "satba_trial",
     "satba_accept", "satba_read_header", "satba_get_blocks", "satba_get_jacobian", "satba_get_exchange",
     "satba_set_exchange", "satba_get_vector", "satba_time_kernel",
 ]
@@ -78,7 +78,7 @@ def load_library(path=None):
     lib.satba_set_x.argtypes = [h, _dp]
     lib.satba_get_x.argtypes = [h, _dp]
     lib.satba_residuals.argtypes = [h, _dp, _dp]
-    for name in ("satba_linearize", "satba_solve", "satba_accept"):
+    for name in ("satba_linearize", "satba_solve", "satba_accept", "satba_subspace_products"):
         getattr(lib, name).argtypes = [h]
     lib.satba_prepare.argtypes = [h, C.c_int32]
     lib.satba_schur.argtypes = [h, C.c_double]
@@ -234,6 +234,9 @@ class HipEngine:
 
     def subspace(self, alpha, inv_norm_g):
         _check(self.lib, self.lib.satba_subspace(self._h, float(alpha), float(inv_norm_g)))
+
+    def subspace_products(self):
+        _check(self.lib, self.lib.satba_subspace_products(self._h))
 
     def trial(self, p0, p1):
         _check(self.lib, self.lib.satba_trial(self._h, float(p0), float(p1)))

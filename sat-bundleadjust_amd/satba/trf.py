@@ -27,7 +27,8 @@ Engine contract (implemented by engine_hip.HipEngine; tests use a CPU stand-in b
     prepare(first)      scaling, g_h, |J_h g_h|^2   -> header[GH_SQ, JG_SQ, XS_SQ, GC_INF]
     schur(lam)          local reduced system        -> payload S | rhs
     solve()             Cholesky + back-substitute  -> header[A, B, C, FAIL]   (Gram matrix of g_h, gn_h)
-    subspace(alpha, s)  q1 = s g_h, w = gn_h - alpha g_h, J_h products -> header[WW, WQ1, B11, B12, B22, GHW]
+    subspace(alpha, s)  q1 = s g_h, w = gn_h - alpha g_h            -> header[WW, WQ1, GHW]
+    subspace_products() |J_h q1|^2, (J_h q1).(J_h w), |J_h w|^2      -> header[B11, B12, B22]  (fallback / tests)
     trial(p0, p1)       x_new = x + scale (p0 q1 + p1 w); cost there -> header[COST_NEW, STEP_SQ, X_SQ]
     accept()            x <- x_new
 """
@@ -166,6 +167,33 @@ def _print_iteration(iteration, nfev, cost, cost_reduction, step_norm, optimalit
     print(f"{iteration:^15}{nfev:^15}{cost:^15.4e}{cr}{sn}{optimality:^15.2e}")
 
 
+def subspace_model(engine, exchange, h, ga, gb, gc, jg_sq, reg):
+    """
+    Quadratic model on the orthonormal basis {q1, w / |w|} of span{g_h, gn_h}: B_S (2 x 2), g_S, |w|.
+    h is the header of the subspace phase (WW, GHW).  Because gn_h solves the damped normal equations exactly,
+    J_h^T J_h gn_h = g_h - reg gn_h, the Gram matrix of (J_h g_h, J_h gn_h) is known without touching the
+    observations again:  |J_h g_h|^2 = jg_sq (from the prepare phase), (J_h g_h).(J_h gn_h) = a - reg b,
+    |J_h gn_h|^2 = b - reg c, with a, b, c the Gram matrix of (g_h, gn_h).  Only when w is a tiny remainder of
+    gn_h (the two directions nearly parallel: cancellation) are the products computed explicitly on the device.
+    """
+    ww = h[WW]
+    if not (ww > 1e-24 * gc and ww > 0):  # gn_h parallel to g_h: one-dimensional subspace
+        return np.array([[jg_sq / ga, 0.0], [0.0, 1.0]]), np.array([np.sqrt(ga), 0.0]), np.inf
+    nw = np.sqrt(ww)
+    alpha = gb / ga
+    if ww > 1e-6 * gc:
+        m11, m12, m22 = jg_sq, ga - reg * gb, gb - reg * gc
+        b11 = m11 / ga
+        b12 = (m12 - alpha * m11) / np.sqrt(ga)
+        b22 = m22 - 2.0 * alpha * m12 + alpha * alpha * m11
+    else:
+        engine.subspace_products()
+        hp = exchange(engine.hdr)
+        b11, b12, b22 = hp[B11], hp[B12], hp[B22]
+    B_S = np.array([[b11, b12 / nw], [b12 / nw, b22 / ww]])
+    return B_S, np.array([np.sqrt(ga), h[GHW] / nw]), nw
+
+
 # ----------------------------------------------------------------------------- the loop
 
 def trf_solve(engine, comm=None, ftol=1e-8, xtol=1e-8, gtol=1e-8, max_nfev=None, loss="linear", f_scale=1.0,
@@ -238,15 +266,7 @@ def trf_solve(engine, comm=None, ftol=1e-8, xtol=1e-8, gtol=1e-8, max_nfev=None,
         # orthonormal basis of span{g_h, gn_h} and the model restricted to it (scipy trf.py:481-485)
         engine.subspace(gb / ga, 1.0 / np.sqrt(ga))
         h = exchange(hdr)
-        ww = h[WW]
-        if ww > 1e-24 * gc and ww > 0:
-            nw = np.sqrt(ww)
-            B_S = np.array([[h[B11], h[B12] / nw], [h[B12] / nw, h[B22] / ww]])
-            g_S = np.array([np.sqrt(ga), h[GHW] / nw])
-        else:  # gn_h parallel to g_h: one-dimensional subspace
-            nw = np.inf
-            B_S = np.array([[h[B11], 0.0], [0.0, 1.0]])
-            g_S = np.array([np.sqrt(ga), 0.0])
+        B_S, g_S, nw = subspace_model(engine, exchange, h, ga, gb, gc, jg_sq, reg)
 
         actual_reduction = -1
         while actual_reduction <= 0 and nfev < max_nfev:

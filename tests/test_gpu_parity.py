@@ -143,7 +143,11 @@ def _run_phases(eng, lam_override=None):
     eng.subspace(gb / ga, 1.0 / np.sqrt(ga))
     h = eng.read_header()
     out["sub"] = h
-    p0 = -0.5 * np.sqrt(ga) / h[trf.B11]  # half the minimiser along q1, plus a bit of the second direction
+    eng.subspace_products()
+    hp = eng.read_header()
+    out["prod"] = hp
+    out["model"] = (ga, gb, h[trf.GRAM_C] if False else out["solve"][trf.GRAM_C], jg_sq, lam)
+    p0 = -0.5 * np.sqrt(ga) / hp[trf.B11]  # half the minimiser along q1, plus a bit of the second direction
     eng.trial(p0, 0.3 * p0 / np.sqrt(h[trf.WW]))
     out["trial"] = eng.read_header()
     return out
@@ -163,7 +167,8 @@ def test_phases_match_oracle_engine(gpu, name, loss):
     assert abs(a["natural_lam"] - b["natural_lam"]) < 1e-7 * b["natural_lam"]
     for phase, slots in (("lin", [trf.COST, dev.HDR_FIXED]), ("prep", [trf.GH_SQ, trf.JG_SQ, trf.XS_SQ, trf.GC_INF]),
                          ("solve", [trf.GRAM_A, trf.GRAM_B, trf.GRAM_C, trf.CHOL_FAIL]),
-                         ("sub", [trf.WW, trf.B11, trf.B12, trf.B22]), ("trial", [trf.COST_NEW, trf.STEP_SQ, trf.X_SQ])):
+                         ("sub", [trf.WW]), ("prod", [trf.B11, trf.B12, trf.B22]),  # GHW = g_h.w is zero up to rounding
+                         ("trial", [trf.COST_NEW, trf.STEP_SQ, trf.X_SQ])):
         for s in slots:
             assert abs(a[phase][s] - b[phase][s]) <= 1e-7 * abs(b[phase][s]) + 1e-300, (phase, s, a[phase][s], b[phase][s])
     # vectors
@@ -307,7 +312,7 @@ def test_points_with_more_than_64_observations(gpu):
         e.set_x(v)
     a, b = _run_phases(dev, 1e-3), _run_phases(ora, 1e-3)
     for phase, slots in (("lin", [trf.COST, dev.HDR_FIXED]), ("prep", [trf.GH_SQ, trf.JG_SQ]),
-                         ("solve", [trf.GRAM_A, trf.GRAM_B, trf.GRAM_C]), ("sub", [trf.WW, trf.B11, trf.B12, trf.B22])):
+                         ("solve", [trf.GRAM_A, trf.GRAM_B, trf.GRAM_C]), ("sub", [trf.WW]), ("prod", [trf.B11, trf.B12, trf.B22])):
         for s in slots:
             assert abs(a[phase][s] - b[phase][s]) <= 1e-7 * abs(b[phase][s]), (phase, s)
     assert rel(dev.get_vector("gn_h"), ora.gn_h) < 1e-6
@@ -489,8 +494,40 @@ def test_alternative_kernel_paths(gpu, monkeypatch, env, name, loss):
     a, b = _run_phases(dev, 1e-3), _run_phases(ora, 1e-3)
     for phase, slots in (("lin", [trf.COST, dev.HDR_FIXED]), ("prep", [trf.GH_SQ, trf.JG_SQ, trf.XS_SQ, trf.GC_INF]),
                          ("solve", [trf.GRAM_A, trf.GRAM_B, trf.GRAM_C, trf.CHOL_FAIL]),
-                         ("sub", [trf.WW, trf.B11, trf.B12, trf.B22]), ("trial", [trf.COST_NEW, trf.STEP_SQ, trf.X_SQ])):
+                         ("sub", [trf.WW]), ("prod", [trf.B11, trf.B12, trf.B22]),  # GHW = g_h.w is zero up to rounding
+                         ("trial", [trf.COST_NEW, trf.STEP_SQ, trf.X_SQ])):
         for s in slots:
             assert abs(a[phase][s] - b[phase][s]) <= 1e-7 * abs(b[phase][s]) + 1e-300, (phase, s, a[phase][s], b[phase][s])
     assert rel(dev.get_vector("gn_h"), ora.gn_h) < 1e-7
     dev.close()
+
+
+@pytest.mark.parametrize("name", ["affine_RT", "persp_RT", "rpc_R"])
+@pytest.mark.parametrize("lam", [1e-6, 1e-2, 10.0])
+def test_subspace_model_from_normal_equations(gpu, name, lam):
+    """
+    The solver takes the 2-D model from J_h^T J_h gn_h = g_h - reg gn_h instead of a pass over the observations
+    (trf.subspace_model); the explicit products computed by the device must agree.
+    """
+    _, p, g = cases.fun_case(name)
+    v = ba_core._frozen_vars(g["v"][1].copy(), p)
+    eng = HipEngine(p, rpc_f32=False)
+    eng.configure("linear", 1.0)
+    eng.set_x(v)
+    out = _run_phases(eng, lam)
+    ga, gb, gc, jg_sq, _ = out["model"]
+    calls = []
+
+    class Spy:  # fail the test if the ill-conditioned fallback (explicit products) is taken for these well-posed cases
+        hdr = eng.hdr
+
+        def subspace_products(self):
+            calls.append(1)
+
+    B_S, g_S, nw = trf.subspace_model(Spy(), None, out["sub"], ga, gb, gc, jg_sq, lam)
+    assert not calls
+    ww = out["sub"][trf.WW]
+    hp = out["prod"]
+    B_dev = np.array([[hp[trf.B11], hp[trf.B12] / nw], [hp[trf.B12] / nw, hp[trf.B22] / ww]])
+    assert np.abs(B_S - B_dev).max() < 1e-6 * np.abs(B_dev).max()
+    eng.close()
