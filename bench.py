@@ -123,7 +123,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--shape", default="C4", help="C2 | C3 | C4 (affine R+T) | C5 (rpc R) | P3 (perspective R+T); SURVEY.md section 8d")
     ap.add_argument("--sigma-theta", type=float, default=1e-4, help="initial camera angle error [rad]")
-    ap.add_argument("--cpu-sample-pts", type=int, default=4000, help="points of the CPU-baseline sub-problem (0 = skip)")
+    ap.add_argument("--cpu-sample-pts", type=int, default=20000,
+                    help="points of the CPU-baseline sub-problem (0 = skip); 20000 points = 200 k observations, ~20 s")
     ap.add_argument("--kernel-reps", type=int, default=20)
     args = ap.parse_args()
 

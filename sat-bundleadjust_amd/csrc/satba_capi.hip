@@ -198,7 +198,7 @@ template <int MODEL, int NP, bool CL>
 static int launch_lin3(satba_problem* p, const ObsArgs& a) {
     Lin3Args s;
     s.pt_ofs = p->d_pt_ofs; s.f = p->d_f; s.V = p->d_V; s.gp = p->d_g + p->n_c;
-    s.hdr_cost = p->d_xb + 0; s.hdr_gpmax = p->d_xb + SATBA_HDR_FIXED + p->rank; s.camc_in_lds = p->camc_lds;
+    s.hdr_cost = p->d_xb + 0; s.hdr_gpmax = p->d_xb + SATBA_HDR_FIXED + p->rank;
     CamMajor cm;
     cm.cam_ofs = p->d_cam_ofs; cm.obs = p->d_cm_obs; cm.w = p->d_cm_w; cm.pt = p->d_cm_pt;
     const size_t lds = p->camc_bytes;

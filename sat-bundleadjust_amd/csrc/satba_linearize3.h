@@ -30,7 +30,6 @@ struct Lin3Args {
     double* __restrict__ gp;          // N x 3
     double* __restrict__ hdr_cost;
     double* __restrict__ hdr_gpmax;
-    int camc_in_lds;
 };
 
 template <int MODEL, int NP, bool ROBUST, bool CL>
