@@ -92,8 +92,14 @@ __global__ __launch_bounds__(256) void k_schur_pairs(ObsArgs a, CamMajor c, Schu
 #pragma unroll
         for (int q = 0; q < NP; ++q) acc[r][q] = 0.0;
 
-    auto process_point = [&](int p, bool valid) {
-        if (!valid) return;
+    struct Rec { double2 r0, r1, r2, r3, r4; };  // packed point record: X0 X1 | X2 v00 | v01 v02 | v11 v12 | v22 g0
+    auto load_rec = [&](int p) {
+        const double2* pv = s.PV + 6 * (size_t)p;  // five 16-byte gathers instead of nine 8-byte ones
+        Rec r;
+        r.r0 = pv[0]; r.r1 = pv[1]; r.r2 = pv[2]; r.r3 = pv[3]; r.r4 = pv[4];
+        return r;
+    };
+    auto compute = [&](int p, const Rec& rc) {
         int pi = 0, pj = 0;
         if constexpr (!UNITW) {
             // position of (camera, point) in the camera-major arrays: rank of the word + bits below the point's bit
@@ -102,11 +108,8 @@ __global__ __launch_bounds__(256) void k_schur_pairs(ObsArgs a, CamMajor c, Schu
             pi = base_i + ri[w] + __popcll(bi[w] & below);
             pj = base_j + rj[w] + __popcll(bj[w] & below);
         }
-        // packed point record: five 16-byte gathers instead of nine 8-byte ones
-        const double2* pv = s.PV + 6 * (size_t)p;
-        const double2 r0 = pv[0], r1 = pv[1], r2 = pv[2], r3 = pv[3], r4 = pv[4];
-        const double X = r0.x, Y = r0.y, Z = r1.x;
-        const double v00 = r1.y, v01 = r2.x, v02 = r2.y, v11 = r3.x, v12 = r3.y, v22 = r4.x;
+        const double X = rc.r0.x, Y = rc.r0.y, Z = rc.r1.x;
+        const double v00 = rc.r1.y, v01 = rc.r2.x, v02 = rc.r2.y, v11 = rc.r3.x, v12 = rc.r3.y, v22 = rc.r4.x;
         double Jci[2][NP], Jpi[2][3], Jcj[2][NP], Jpj[2][3];
         cm_jacobian<MODEL, NP, ROBUST, UNITW>(a, c, cci, tabi, i, pi, p, X, Y, Z, Jci, Jpi);
         cm_jacobian<MODEL, NP, ROBUST, UNITW>(a, c, ccj, tabj, j, pj, p, X, Y, Z, Jcj, Jpj);
@@ -127,8 +130,13 @@ __global__ __launch_bounds__(256) void k_schur_pairs(ObsArgs a, CamMajor c, Schu
             const double y0 = m00 * Jcj[0][q] + m01 * Jcj[1][q];
             const double y1 = m10 * Jcj[0][q] + m11 * Jcj[1][q];
 #pragma unroll
-            for (int r = 0; r < NP; ++r) acc[r][q] -= Jci[0][r] * y0 + Jci[1][r] * y1;
+            for (int r = 0; r < NP; ++r) acc[r][q] = fma(-Jci[0][r], y0, fma(-Jci[1][r], y1, acc[r][q]));
         }
+    };
+    auto process_point = [&](int p, bool valid) {
+        if (!valid) return;
+        const Rec rc = load_rec(p);
+        compute(p, rc);
     };
     auto process = [&](int slot, bool valid) { process_point(valid ? s_q[wave][slot] : 0, valid); };
 
@@ -137,7 +145,19 @@ __global__ __launch_bounds__(256) void k_schur_pairs(ObsArgs a, CamMajor c, Schu
         // coalesced 4-byte stream replaces the bitmap scan (5 GB of bitmap traffic per launch at 200 x 1M)
         const long long b0 = s.pair_ofs[pair], b1 = s.pair_ofs[pair + 1];
         const long long lo = b0 + (b1 - b0) * chunk / s.n_chunks, hi = b0 + (b1 - b0) * (chunk + 1) / s.n_chunks;
-        for (long long idx = lo + lane; idx < hi; idx += 64) process_point(s.pair_pts[idx], true);
+        // software pipeline: the next point's index and record are in flight while the current one is evaluated
+        long long idx = lo + lane;
+        int p_cur = (idx < hi) ? s.pair_pts[idx] : 0;
+        Rec r_cur = load_rec(p_cur);
+        while (idx < hi) {
+            const long long idx_n = idx + 64;
+            const int p_nxt = (idx_n < hi) ? s.pair_pts[idx_n] : p_cur;
+            const Rec r_nxt = load_rec(p_nxt);
+            compute(p_cur, r_cur);
+            p_cur = p_nxt;
+            r_cur = r_nxt;
+            idx = idx_n;
+        }
     } else {
     const int w_lo = (int)((long long)s.NW * chunk / s.n_chunks), w_hi = (int)((long long)s.NW * (chunk + 1) / s.n_chunks);
     int n_q = 0;  // wave-uniform queue fill
