@@ -62,7 +62,6 @@ struct satba_problem {
     int sch_T = 0, sch_ctiles = 0, sch_chunks = 0, sch_camc_lds = 0;       // Schur panel configuration (T == 0: v1 kernel)
     size_t sch_lds = 0;
     double *d_S_part = nullptr, *d_rhs_part = nullptr;
-    double* d_dinv = nullptr;  // inverses of the Cholesky diagonal blocks
     double* d_dch = nullptr;   // camera step in scaled variables
     DagWorkspace dag;          // dataflow Cholesky (dag.n_tasks == 0: blocked multi-launch version)
     double *d_cam_static = nullptr, *d_rpc = nullptr;
@@ -86,9 +85,11 @@ struct satba_problem {
     double* d_PV = nullptr;    // packed per-point records (N x 12)
     long long* d_pair_ofs = nullptr;  // per camera pair: list of shared points (null: bitmap scan)
     int* d_pair_pts = nullptr;
+    double* d_pair_part = nullptr;  // chunk partials of the pair blocks
     int unit_weights = 0;
     int u_full = 1;            // linearize accumulates the full U_c blocks (0: diagonal only, Schur v3 adds the rest)
     int* d_fail = nullptr;
+    bool chol_two_launch = false;
     double* d_scal = nullptr;  // 8 private scalars (costs of satba_residuals, timing sinks)
     double *d_xb_own = nullptr, *d_xb = nullptr;
     long long xb_len = 0;
@@ -172,7 +173,7 @@ static int dense_solve(satba_problem* p, double* S, double* b) {
         hipLaunchKernelGGL(k_dag_status, dim3(1), dim3(1), 0, p->stream, fl.ctr, p->d_fail);
         hipLaunchKernelGGL(k_trsv_back, dim3(1), dim3(1024), sizeof(double) * p->n_c, p->stream, S, p->n_c, b);
     } else {
-        cholesky_solve(S, p->n_c, b, p->d_fail, p->d_dinv, p->stream);
+        cholesky_solve(S, p->n_c, b, p->d_fail, p->d_fail + 1, p->chol_two_launch, p->stream);
     }
     HIP_TRY(hipGetLastError());
     return 0;
@@ -257,7 +258,7 @@ static int launch_schur3(satba_problem* p, const ObsArgs& a, double* S, double* 
     Schur3Args s;
     s.bits = p->d_bits; s.rank = p->d_rank; s.Vinv = p->d_Vinv; s.gp = p->d_g + p->n_c; s.NW = p->NW; s.n_chunks = p->sch3_chunks;
     s.PV = reinterpret_cast<const double2*>(p->d_PV);
-    s.pair_ofs = p->d_pair_ofs; s.pair_pts = p->d_pair_pts;
+    s.pair_ofs = p->d_pair_ofs; s.pair_pts = p->d_pair_pts; s.pair_part = p->d_pair_part;
     const long long items = (long long)p->M * (p->M - 1) / 2 * p->sch3_chunks;
     const int diag_chunks = p->lin3_chunks;
     if (p->loss == 0 && p->unit_weights) {
@@ -271,6 +272,12 @@ static int launch_schur3(satba_problem* p, const ObsArgs& a, double* S, double* 
         hipLaunchKernelGGL((k_schur_diag<MODEL, NP, true, ADDU>), dim3(diag_chunks, p->M), dim3(LINC_THREADS), 0, p->stream, a, cm, s, p->d_part3);
     }
     HIP_TRY(hipGetLastError());
+    if (items > 0 && p->d_pair_ofs && p->sch3_chunks > 1) {
+        const long long outs = (long long)p->M * (p->M - 1) / 2 * p->NP * p->NP;
+        hipLaunchKernelGGL(k_schur_pairs_reduce, dim3((unsigned)((outs + 255) / 256)), dim3(256), 0, p->stream, p->M, p->NP, p->n_c,
+                           p->sch3_chunks, p->d_pair_part, S);
+        HIP_TRY(hipGetLastError());
+    }
     const int total = p->M * cam_acc_len(p->NP);
     hipLaunchKernelGGL(k_schur_diag_finish, dim3((total + 255) / 256), dim3(256), 0, p->stream, p->M, p->NP, p->n_c, diag_chunks,
                        p->d_part3, S, rhs);
@@ -482,7 +489,9 @@ int satba_problem_create(const satba_problem_desc* d, satba_problem** out) {
         TRY(dev_alloc(p, &p->d_U, (size_t)p->M * p->NP * p->NP)); TRY(dev_alloc(p, &p->d_gc, p->n_c));
         TRY(dev_alloc(p, &p->d_V, (size_t)6 * p->N)); TRY(dev_alloc(p, &p->d_Vinv, (size_t)6 * p->N));
         TRY(dev_alloc(p, &p->d_tbuf, (size_t)3 * p->N)); TRY(dev_alloc(p, &p->d_dc, p->n_c));
-        TRY(dev_alloc(p, &p->d_fail, 1));
+        TRY(dev_alloc(p, &p->d_fail, 1 + CH_MAX_STEPS));  // [0] not-SPD flag, then the panel-step flags
+        if (p->n_c > CH_NB * CH_MAX_STEPS) return fail(SATBA_E_ARG, "reduced camera system too large for the dense solver");
+        { const char* cs = getenv("SATBA_CHOL"); p->chol_two_launch = cs && atoi(cs) == 1; }
         TRY(dev_alloc(p, &p->d_dch, p->n_c));
         if (getenv("SATBA_CHOL_DAG")) {  // experimental dataflow Cholesky (satba_chol_dag.h): correct, but slower
                                          // than the blocked multi-launch version on MI355X
@@ -495,7 +504,6 @@ int satba_problem_create(const satba_problem_desc* d, satba_problem** out) {
             HIP_TRY(hipMemcpy(p->dag.d_tasks, tasks.data(), sizeof(DagTask) * tasks.size(), hipMemcpyHostToDevice));
             if (getenv("SATBA_DAG_TIMES")) TRY(dev_alloc(p, &p->dag.d_times, 4 * tasks.size()));
         }
-        TRY(dev_alloc(p, &p->d_dinv, cholesky_workspace_doubles(p->n_c)));
         TRY(dev_alloc(p, &p->d_scal, 8));
         p->lin_grid = grid_for(p->n_tiles, 16, lin1_lds(p, false) <= 78 * 1024 ? 512 : 256);
         TRY(dev_alloc(p, &p->d_part, (size_t)p->lin_grid * p->M * cam_acc_len(p->NP)));
@@ -546,25 +554,47 @@ int satba_problem_create(const satba_problem_desc* d, satba_problem** out) {
                     if (sc < 1) sc = 1;
                 }
                 p->sch3_chunks = sc;
-                // shared-point lists per camera pair (static structure; 4 B per pair entry, e.g. 200 MB at 200 x 1M x 10M)
+                // shared-point lists per camera pair (static structure; 4 B per pair entry, e.g. 200 MB at 200 x 1M x 10M),
+                // cut into point-range chunks sized so that one chunk's packed point records (96 B each) stay in L2
                 if (n_pairs > 0 && !getenv("SATBA_SCHUR_BITMAP")) {
+                    // measured on 200 x 1M x 10M: 12 MB windows (8 chunks) are the optimum between gather locality and
+                    // the fixed cost per (pair, chunk) work item; fewer chunks when the lists are short
+                    long long n_hits = 0;
+                    for (int q = 0; q < p->N; ++q) { const long long dq = pt_ofs[q + 1] - pt_ofs[q]; n_hits += dq * (dq - 1) / 2; }
+                    int C = (int)std::max<long long>(1, ((long long)p->N * 96 + (12 << 20) - 1) / (12 << 20));
+                    C = (int)std::max<long long>(1, std::min<long long>(C, n_hits / n_pairs / 256));
+                    if (const char* cs = getenv("SATBA_SCHUR_CHUNKS")) C = std::max(1, atoi(cs));
+                    while (C > 1 && n_pairs * (long long)(C + 1) > (1ll << 27)) --C;
                     const long long M_ = p->M;
                     auto pair_index = [M_](long long a, long long b) { return a * M_ - a * (a + 1) / 2 + (b - a - 1); };
-                    std::vector<long long> ofs(n_pairs + 1, 0);
-                    for (int q = 0; q < p->N; ++q)
+                    auto chunk_of = [&](int q) { return (int)((long long)q * C / std::max(p->N, 1)); };
+                    // counts per (pair, chunk), then offsets in (pair-major, chunk) order == the order of the lists
+                    std::vector<long long> ofs((size_t)n_pairs * (C + 1) + 1, 0);
+                    for (int q = 0; q < p->N; ++q) {
+                        const int ch = chunk_of(q);
                         for (int x0 = pt_ofs[q]; x0 < pt_ofs[q + 1]; ++x0)
-                            for (int x1 = x0 + 1; x1 < pt_ofs[q + 1]; ++x1) ++ofs[pair_index(d->cam_ind[x0], d->cam_ind[x1]) + 1];
-                    for (long long i = 0; i < n_pairs; ++i) ofs[i + 1] += ofs[i];
-                    const long long E = ofs[n_pairs];
+                            for (int x1 = x0 + 1; x1 < pt_ofs[q + 1]; ++x1)
+                                ++ofs[pair_index(d->cam_ind[x0], d->cam_ind[x1]) * (C + 1) + ch + 1];
+                    }
+                    // ofs[pair*(C+1) + ch + 1] holds count(pair, ch); turn into running offsets, entry [pair*(C+1)] = start
+                    long long run = 0;
+                    for (long long pr = 0; pr < n_pairs; ++pr) {
+                        ofs[pr * (C + 1)] = run;
+                        for (int ch = 0; ch < C; ++ch) { run += ofs[pr * (C + 1) + ch + 1]; ofs[pr * (C + 1) + ch + 1] = run; }
+                    }
+                    const long long E = run;
                     if (E > 0 && E < (1ll << 31) && E * 4 < (8ll << 30)) {
                         std::vector<int> pts(E);
-                        std::vector<long long> fill(ofs.begin(), ofs.end() - 1);
-                        for (int q = 0; q < p->N; ++q)
+                        std::vector<long long> fill((size_t)n_pairs);
+                        for (long long pr = 0; pr < n_pairs; ++pr) fill[pr] = ofs[pr * (C + 1)];
+                        for (int q = 0; q < p->N; ++q)  // ascending q: each pair's list comes out sorted, chunks contiguous
                             for (int x0 = pt_ofs[q]; x0 < pt_ofs[q + 1]; ++x0)
                                 for (int x1 = x0 + 1; x1 < pt_ofs[q + 1]; ++x1) pts[fill[pair_index(d->cam_ind[x0], d->cam_ind[x1])]++] = q;
                         TRY(dev_alloc(p, &p->d_pair_ofs, ofs.size())); TRY(dev_alloc(p, &p->d_pair_pts, pts.size()));
                         HIP_TRY(hipMemcpy(p->d_pair_ofs, ofs.data(), sizeof(long long) * ofs.size(), hipMemcpyHostToDevice));
                         HIP_TRY(hipMemcpy(p->d_pair_pts, pts.data(), sizeof(int) * pts.size(), hipMemcpyHostToDevice));
+                        p->sch3_chunks = C;
+                        if (C > 1) TRY(dev_alloc(p, &p->d_pair_part, (size_t)C * n_pairs * p->NP * p->NP));
                     }
                 }
             }
@@ -897,6 +927,21 @@ int satba_debug_dag_times(satba_problem* p, long long* host_out, int32_t* n_task
         HIP_TRY(hipStreamSynchronize(p->stream));
         HIP_TRY(hipMemcpy(host_out, p->dag.d_times, sizeof(long long) * 4 * p->dag.n_tasks, hipMemcpyDeviceToHost));
     }
+    return 0;
+}
+
+// tools only (tools/chol_times.py): wall-clock stamps (100 MHz) of every panel step of one factorisation of the
+// current reduced system; host_out holds 8 * CH_MAX_STEPS values.  Destroys S.
+int satba_debug_chol_times(satba_problem* p, long long* host_out, int32_t* n_steps) {
+    if (!p || !host_out || !n_steps) return fail(SATBA_E_ARG, "null argument");
+    long long* d_ts = nullptr;
+    HIP_TRY(hipMalloc((void**)&d_ts, sizeof(long long) * 8 * CH_MAX_STEPS));
+    HIP_TRY(hipMemset(d_ts, 0, sizeof(long long) * 8 * CH_MAX_STEPS));
+    cholesky_solve(p->payload(), p->n_c, p->d_dch, p->d_fail, p->d_fail + 1, false, p->stream, d_ts);
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    HIP_TRY(hipMemcpy(host_out, d_ts, sizeof(long long) * 8 * CH_MAX_STEPS, hipMemcpyDeviceToHost));
+    HIP_TRY(hipFree(d_ts));
+    *n_steps = (p->n_c + CH_NB - 1) / CH_NB;
     return 0;
 }
 

@@ -4,16 +4,18 @@
 // block pairs (a, b) with a <= b, which land in the column-major lower triangle).  This replaces the LSMR
 // iteration of scipy:optimize/_lsq/trf.py:479-480 by an exact factorisation.
 //
-// Blocked right-looking Cholesky, 32-column panels, two launches per panel:
-//   k_potrf_trsm  register-resident: every wave factorises the 32x32 diagonal block redundantly (lane = row,
-//                 column broadcasts by v_readlane, no LDS, no barriers) and solves 64 panel rows against it; the
-//                 right-hand side rides along as one more panel row, so the forward substitution is folded in;
-//   k_syrk        64x64 tiles of the trailing matrix, 4x4 per thread, panel staged in LDS, rows mapped to the
-//                 fast thread index so the read-modify-write of A is coalesced; tiles of the first tile column
-//                 also apply the panel to the right-hand side;
-// then k_trsv_back: one workgroup, left-looking backward substitution with the right-hand side in LDS.
-// fp64 MFMA runs at the vector rate on gfx950 and the matrix is tiny: the solve is bound by the latency of 64
-// dependent launches (~27 us + ~13 us per panel at n = 1000), not by flops; see DESIGN.md.
+// Blocked right-looking Cholesky, 32-column panels, ONE launch per panel (k_chol_step): the workgroup that owns
+// 64x64 tile (i, j) of the trailing matrix first applies the previous panel to it (4x4 outputs per thread, panel
+// staged in LDS); the tiles of the first tile column then go on to the current panel.  Tile (0, 0) holds the next
+// diagonal block and 32 panel rows: one wave factorises it in registers (lane = row, column broadcasts by
+// v_readlane, no LDS, no barriers; the panel rows ride along in lanes 32..63), publishes L_kk and raises a flag in
+// global memory; the waves of tiles (i > 0, 0) wait for the flag and solve their 64 panel rows against L_kk, again
+// by readlane broadcasts.  Tile (0, 0) is workgroup 0 of a 1-D grid, so the flag setter is always resident before
+// any waiter.  The right-hand side is carried along (forward substitution folded in).  k_trsv_back finishes with
+// a left-looking backward substitution in one workgroup.
+// The previous version (k_potrf_trsm + k_syrk, two launches per panel, SATBA_CHOL=1) is kept for A/B runs.
+// fp64 MFMA runs at the vector rate on gfx950 and the matrix is tiny: the solve is bound by the latency of the
+// dependent panel chain, not by flops; see DESIGN.md.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -142,6 +144,209 @@ __global__ __launch_bounds__(256) void k_syrk(double* __restrict__ A, int n, int
         }
 }
 
+// sqrt(d) and 1/sqrt(d) together: v_rsq_f64 seed + two coupled Goldschmidt steps and a final residual correction
+// (the library sqrt followed by a division is ~4x as many dependent instructions; this sits on the serial chain of
+// the diagonal-block factorisation 32 times per panel).  d must be a normal positive number.
+__device__ inline void sqrt_and_inverse(double d, double& sq, double& inv) {
+    const double y = __builtin_amdgcn_rsq(d);
+    double g = d * y, h = 0.5 * y;
+    double r = fma(-h, g, 0.5);
+    g = fma(g, r, g); h = fma(h, r, h);
+    r = fma(-h, g, 0.5);
+    g = fma(g, r, g); h = fma(h, r, h);
+    const double e = fma(-g, g, d);
+    sq = fma(e, h, g);
+    inv = h + h;
+}
+
+// One panel step in one launch.  kp: first column of the previous panel (applied to the trailing matrix here; < 0:
+// none), k0: first column of the panel that is factorised (k0 = kp + CH_NB or 0).  1-D grid over the lower 64x64
+// tiles of A[k0:, k0:], tile column 0 first.  flag: one int per launch, zero on entry.
+//
+// Column broadcasts go through LDS (every lane reads the same address: one ds_read, no bank conflicts); the
+// v_readlane version of the same loops took ~2x as long (two readlanes + hazard nops per multiply-add, measured with
+// tools/chol_times.py).
+// FULL: the panel has all CH_NB columns (every step but possibly the last).
+template <bool FULL>
+__global__ __launch_bounds__(256) void k_chol_step(double* __restrict__ A, int n, int kp, int k0, int* __restrict__ fail,
+                                                   int* __restrict__ flag, double* __restrict__ b, long long* __restrict__ ts) {
+    // ts (tools only, normally null): 8 wall-clock stamps of this step -- 0 start of tile (0,0), 1 its update done,
+    // 2 diagonal block factorised (flag raised), 3 its end; 4..7 the same for tile (1, 0): start, update done, flag seen, end
+    __shared__ double Pi[CH_NB][64], Pj[CH_NB][64];  // Pj doubles as the stash X[c][r] of the tile's first 32 columns
+    __shared__ double Lb[CH_NB][CH_NB];              // L_kk, Lb[c][r] = L[r][c] (column-major like A)
+    __shared__ double lcol[2][64];
+    __shared__ double brow[64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int T = (n - k0 + 63) / 64;
+    int bi, bj;
+    if ((int)blockIdx.x < T) { bi = blockIdx.x; bj = 0; }
+    else {  // tiles (bi >= bj >= 1), row by row
+        int idx = blockIdx.x - T;
+        bi = 1;
+        while (idx >= bi) { idx -= bi; ++bi; }
+        bj = idx + 1;
+    }
+    const int r0 = k0 + bi * 64, c0 = k0 + bj * 64;
+    const int tr = (tid & 15) * 4, tc = (tid >> 4) * 4;  // rows on the fast index: coalesced A accesses
+    const bool stamp = ts && bj == 0 && bi < 2 && tid == 0;
+    if (stamp) ts[bi * 4 + 0] = wall_clock64();
+
+    if (kp >= 0) {
+        // ---- trailing update with the previous panel: A[r0.., c0..] -= P_i P_j^T, b[r0..] -= P_i y_prev
+        double old[4][4];  // the tile itself: in flight together with the panel loads
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = r0 + tr + i, c = c0 + tc + j;
+                old[j][i] = (r < n && c < n && r >= c) ? A[(size_t)r + (size_t)c * n] : 0.0;
+            }
+        for (int idx = tid; idx < CH_NB * 64; idx += 256) {
+            const int r = idx & 63, k = idx >> 6;
+            Pi[k][r] = (r0 + r < n) ? A[(size_t)(r0 + r) + (size_t)(kp + k) * n] : 0.0;
+            Pj[k][r] = (c0 + r < n) ? A[(size_t)(c0 + r) + (size_t)(kp + k) * n] : 0.0;
+        }
+        if (bj == 0 && tid < 64) brow[tid] = (r0 + tid < n) ? b[r0 + tid] : 0.0;
+        if (bj == 0 && tid >= 64 && tid < 64 + CH_NB) lcol[0][tid - 64] = b[kp + tid - 64];  // y of the previous panel
+        __syncthreads();
+        if (bj == 0 && tid < 64) {
+            double s = 0.0;
+#pragma unroll 8
+            for (int k = 0; k < CH_NB; ++k) s += Pi[k][tid] * lcol[0][k];
+            const double v = brow[tid] - s;
+            brow[tid] = v;  // only this thread touches brow[tid] until the barrier below
+            if (bi > 0 && r0 + tid < n) b[r0 + tid] = v;  // tile (0, 0): solved and stored below
+        }
+        double acc[4][4] = {};
+#pragma unroll 8
+        for (int k = 0; k < CH_NB; ++k) {
+            double a[4], c[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { a[i] = Pi[k][tr + i]; c[i] = Pj[k][tc + i]; }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[j][i] += a[i] * c[j];
+        }
+        if (bj == 0) __syncthreads();  // everyone is done reading Pj before it becomes the stash
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = r0 + tr + i, c = c0 + tc + j;
+                const double v = old[j][i] - acc[j][i];
+                if (bj == 0 && tc + j < CH_NB) Pj[tc + j][tr + i] = v;  // panel columns are stored after the solve
+                else if (r < n && c < n && r >= c) A[(size_t)r + (size_t)c * n] = v;
+            }
+    } else {
+        for (int idx = tid; idx < CH_NB * 64; idx += 256) {
+            const int r = idx & 63, k = idx >> 6;
+            Pj[k][r] = (r0 + r < n && k0 + k < n && r0 + r >= k0 + k) ? A[(size_t)(r0 + r) + (size_t)(k0 + k) * n] : 0.0;
+        }
+        if (tid < 64) brow[tid] = (r0 + tid < n) ? b[r0 + tid] : 0.0;
+    }
+    if (bj != 0) return;
+    __syncthreads();
+    if (stamp) ts[bi * 4 + 1] = wall_clock64();
+    const int nb = FULL ? CH_NB : min(CH_NB, n - k0);
+
+    if (bi == 0) {
+        // ---- tile (0, 0): lanes 0..31 = rows of the diagonal block, lanes 32..63 = the first 32 panel rows
+        if (wave == 0) {
+            double a[CH_NB];
+#pragma unroll
+            for (int c = 0; c < CH_NB; ++c) {
+                double v = Pj[c][lane];
+                if (lane < CH_NB && (c > lane || lane >= nb || c >= nb)) v = (c == lane) ? 1.0 : 0.0;  // identity padding
+                if (c >= nb && lane >= CH_NB) v = 0.0;
+                a[c] = v;
+            }
+            bool bad = false;
+#pragma unroll
+            for (int j = 0; j < CH_NB; ++j) {
+                double d = readlane_f64(a[j], j);
+                if (!(d > 0.0) || !(d < 1e300)) { bad = true; d = 1.0; }
+                double sq, inv;
+                sqrt_and_inverse(d, sq, inv);
+                const double l = (lane == j) ? sq : a[j] * inv;
+                a[j] = l;
+                if (j + 1 < CH_NB) {
+                    lcol[j & 1][lane] = l;  // single wave: its LDS operations execute in order
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int c = j + 1; c < CH_NB; ++c) a[c] -= l * lcol[j & 1][c];
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            if (bad && lane == 0) atomicOr(fail, 1);
+            const int r = k0 + lane;
+            if (r < n) {
+#pragma unroll
+                for (int c = 0; c < CH_NB; ++c)
+                    if (c < nb && (lane >= CH_NB || c <= lane)) A[(size_t)r + (size_t)(k0 + c) * n] = a[c];
+            }
+            if (lane < CH_NB) {
+#pragma unroll
+                for (int c = 0; c < CH_NB; ++c) Lb[c][lane] = a[c];
+            }
+            __threadfence();
+            if (lane == 0) __atomic_store_n(flag, 1, __ATOMIC_RELEASE);
+            if (stamp) ts[2] = wall_clock64();
+        }
+        __syncthreads();
+        if (wave == 1) {  // right-hand side: y_k = L_kk^-1 b_k, lane = entry
+            double v = (lane < nb) ? brow[lane] : 0.0;
+            const int cl = min(lane, CH_NB - 1);
+            for (int m = 0; m < nb; ++m) {
+                const double ym = __shfl(v, m) / Lb[m][m];
+                if (lane == m) v = ym;
+                else if (lane > m && lane < nb) v -= Lb[m][cl] * ym;
+            }
+            if (lane < nb) b[k0 + lane] = v;
+            else if (k0 + lane < n) b[k0 + lane] = brow[lane];
+        }
+        if (stamp) ts[3] = wall_clock64();
+        return;
+    }
+    // ---- tiles (i > 0, 0): 64 panel rows, x L_kk^T = p  (a partial panel is the last one: it has no rows below)
+    if (!FULL || wave != 0) return;
+    double x[CH_NB];
+#pragma unroll
+    for (int c = 0; c < CH_NB; ++c) x[c] = Pj[c][lane];  // columns >= nb of the stash are zero
+    while (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == 0) __builtin_amdgcn_s_sleep(1);
+    if (stamp) ts[6] = wall_clock64();
+    {   // L_kk: 16 coalesced loads per lane in flight, then into LDS (identity padding)
+        double v[CH_NB * CH_NB / 64];
+#pragma unroll
+        for (int t = 0; t < CH_NB * CH_NB / 64; ++t) {
+            const int idx = t * 64 + lane, r = idx % CH_NB, c = idx / CH_NB;
+            v[t] = (r < nb && c <= r) ? __builtin_nontemporal_load(A + (size_t)(k0 + r) + (size_t)(k0 + c) * n) : ((r == c) ? 1.0 : 0.0);
+        }
+#pragma unroll
+        for (int t = 0; t < CH_NB * CH_NB / 64; ++t) (&Lb[0][0])[t * 64 + lane] = v[t];
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (lane < CH_NB) lcol[0][lane] = 1.0 / Lb[lane][lane];
+    __builtin_amdgcn_wave_barrier();
+    const int r = r0 + lane;
+    if (r >= n) return;  // before the arithmetic: stores under a condition would let the compiler sink all of it below
+                         // the LDS reads (2.5 KB of spills)
+#pragma unroll
+    for (int m = 0; m < CH_NB; ++m) {
+        const double xm = x[m] * lcol[0][m];
+        x[m] = xm;
+#pragma unroll
+        for (int c = m + 1; c < CH_NB; ++c) x[c] -= xm * Lb[m][c];  // L[c][m]
+        asm volatile("" ::: "memory");     // one column of L at a time: hoisting all 528 reads spills
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int c = 0; c < CH_NB; ++c)
+        if (FULL || c < nb) A[(size_t)r + (size_t)(k0 + c) * n] = x[c];
+    if (stamp) ts[7] = wall_clock64();
+}
+
 // L^T z = y in place in b (b holds y on entry), left-looking, one workgroup of 1024 threads:
 // z_k = L_kk^-T (y_k - L[tail, k-block]^T z_tail).  The right-hand side lives in LDS; each wave takes two columns of
 // the block, lanes run down the column (coalesced) with four independent partial sums in flight; the 32 x 32
@@ -206,18 +411,33 @@ __global__ __launch_bounds__(1024) void k_trsv_back(const double* __restrict__ L
     for (int i = tid; i < n; i += 1024) b[i] = yb[i];
 }
 
-inline size_t cholesky_workspace_doubles(int n) { (void)n; return 1; }
+constexpr int CH_MAX_STEPS = 256;  // flags: one per panel step (n <= 8192)
 
 // Factorise A (n x n, column-major lower, in place) and solve A z = b in place.  *fail != 0 if A was not SPD.
-inline void cholesky_solve(double* A, int n, double* b, int* fail, double* /*unused*/, hipStream_t stream) {
-    for (int k0 = 0; k0 < n; k0 += CH_NB) {
-        const int nb = n - k0 < CH_NB ? n - k0 : CH_NB;
-        const int rest = n - k0 - nb;
-        const int waves = (rest + 1 + 63) / 64;  // panel rows + the right-hand side row
-        hipLaunchKernelGGL(k_potrf_trsm, dim3((waves + 3) / 4), dim3(256), 0, stream, A, n, k0, fail, b);
-        if (rest > 0) {
-            const int tiles = (rest + 63) / 64;
-            hipLaunchKernelGGL(k_syrk, dim3(tiles, tiles), dim3(16, 16), 0, stream, A, n, k0, nb, b);
+// flags: CH_MAX_STEPS ints of scratch.  two_launch: the previous k_potrf_trsm + k_syrk pipeline.
+inline void cholesky_solve(double* A, int n, double* b, int* fail, int* flags, bool two_launch, hipStream_t stream,
+                           long long* ts = nullptr) {
+    if (two_launch) {
+        for (int k0 = 0; k0 < n; k0 += CH_NB) {
+            const int nb = n - k0 < CH_NB ? n - k0 : CH_NB;
+            const int rest = n - k0 - nb;
+            const int waves = (rest + 1 + 63) / 64;  // panel rows + the right-hand side row
+            hipLaunchKernelGGL(k_potrf_trsm, dim3((waves + 3) / 4), dim3(256), 0, stream, A, n, k0, fail, b);
+            if (rest > 0) {
+                const int tiles = (rest + 63) / 64;
+                hipLaunchKernelGGL(k_syrk, dim3(tiles, tiles), dim3(16, 16), 0, stream, A, n, k0, nb, b);
+            }
+        }
+    } else {
+        (void)hipMemsetAsync(flags, 0, sizeof(int) * CH_MAX_STEPS, stream);
+        int step = 0;
+        for (int k0 = 0; k0 < n; k0 += CH_NB, ++step) {
+            const int T = (n - k0 + 63) / 64;
+            long long* tsk = ts ? ts + 8 * step : nullptr;
+            if (n - k0 >= CH_NB)
+                hipLaunchKernelGGL(k_chol_step<true>, dim3(T * (T + 1) / 2), dim3(256), 0, stream, A, n, k0 - CH_NB, k0, fail, flags + step, b, tsk);
+            else
+                hipLaunchKernelGGL(k_chol_step<false>, dim3(T * (T + 1) / 2), dim3(256), 0, stream, A, n, k0 - CH_NB, k0, fail, flags + step, b, tsk);
         }
     }
     hipLaunchKernelGGL(k_trsv_back, dim3(1), dim3(1024), sizeof(double) * n, stream, A, n, b);

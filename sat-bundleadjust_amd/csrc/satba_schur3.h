@@ -30,6 +30,7 @@ struct Schur3Args {
     const double2* __restrict__ PV;               // N x 6 double2: X0 X1 | X2 v00 | v01 v02 | v11 v12 | v22 g0 | g1 g2
     const long long* __restrict__ pair_ofs;       // n_pairs + 1 (or null): offsets into pair_pts
     const int* __restrict__ pair_pts;             // points shared by each camera pair, ascending (static per problem)
+    double* __restrict__ pair_part;               // n_chunks x n_pairs x NP*NP partial blocks (list path, n_chunks > 1)
     int NW;                                       // words per camera
     int n_chunks;                                 // word-range chunks per pair (1: plain stores, >1: atomics)
 };
@@ -60,6 +61,37 @@ __device__ inline void cm_jacobian(const ObsArgs& a, const CamMajor& c, const do
     for (int k = 0; k < 3; ++k) { Jp[0][k] *= s0 * mp; Jp[1][k] *= s1 * mp; }
 }
 
+// Wave "reduce-scatter": N (power of two) values per lane are summed over the 64 lanes with N - 1 + (6 - log2 N)
+// shuffles instead of 6 N: at every step a lane keeps one half of its values and trades the other half with its
+// partner.  On return v[0] of the lanes with (lane & (64/N - 1)) == 0 ... holds total number rs_index<N>(lane).
+template <int N>
+__device__ inline double wave_reduce_scatter(const double (&v)[N], int lane, int mask) {
+    if constexpr (N == 1) {
+        double t = v[0];
+        for (int m = mask; m > 0; m >>= 1) t += __shfl_xor(t, m);
+        return t;
+    } else {
+        constexpr int H = N / 2;
+        const bool upper = (lane & mask) != 0;
+        double w[H];
+#pragma unroll
+        for (int k = 0; k < H; ++k) {
+            const double keep = upper ? v[k + H] : v[k];
+            const double send = upper ? v[k] : v[k + H];
+            w[k] = keep + __shfl_xor(send, mask);
+        }
+        return wave_reduce_scatter<H>(w, lane, mask >> 1);
+    }
+}
+// index (in 0 .. N-1) of the total a lane ends up with
+template <int N>
+__device__ inline int rs_index(int lane) {
+    int idx = 0, mask = 32;
+    for (int h = N / 2; h >= 1; h >>= 1, mask >>= 1)
+        if (lane & mask) idx += h;
+    return idx;
+}
+
 // grid: one wave per (pair, chunk); 4 waves per workgroup.  pair index -> (i, j), i < j.
 template <int MODEL, int NP, bool ROBUST, bool UNITW>
 __global__ __launch_bounds__(256) void k_schur_pairs(ObsArgs a, CamMajor c, Schur3Args s, double* __restrict__ S) {
@@ -68,13 +100,17 @@ __global__ __launch_bounds__(256) void k_schur_pairs(ObsArgs a, CamMajor c, Schu
     const long long n_pairs = (long long)a.M * (a.M - 1) / 2;
     const long long item = (long long)blockIdx.x * 4 + wave;
     if (item >= n_pairs * s.n_chunks) return;
-    const long long pair = item / s.n_chunks;
-    const int chunk = (int)(item % s.n_chunks);
+    // list path: chunk-major order, so that the workgroups running at the same time gather point records from
+    // the same slice of the point array (an L2-sized window) instead of the whole 96 MB
+    const long long pair = s.pair_ofs ? item % n_pairs : item / s.n_chunks;
+    const int chunk = s.pair_ofs ? (int)(item / n_pairs) : (int)(item % s.n_chunks);
     // unrank pair -> (i, j): pairs of row i start at i*M - i*(i+1)/2
     int i = (int)((2.0 * a.M - 1.0 - sqrt((2.0 * a.M - 1.0) * (2.0 * a.M - 1.0) - 8.0 * (double)pair)) * 0.5);
     while ((long long)i * a.M - (long long)i * (i + 1) / 2 > pair) --i;
     while ((long long)(i + 1) * a.M - (long long)(i + 1) * (i + 2) / 2 <= pair) ++i;
-    const int j = i + 1 + (int)(pair - ((long long)i * a.M - (long long)i * (i + 1) / 2));
+    int j = i + 1 + (int)(pair - ((long long)i * a.M - (long long)i * (i + 1) / 2));
+    i = __builtin_amdgcn_readfirstlane(i);  // wave-uniform by construction: lets the camera constants use scalar loads
+    j = __builtin_amdgcn_readfirstlane(j);
 
     const unsigned long long* bi = s.bits + (size_t)i * s.NW;
     const unsigned long long* bj = s.bits + (size_t)j * s.NW;
@@ -143,20 +179,26 @@ __global__ __launch_bounds__(256) void k_schur_pairs(ObsArgs a, CamMajor c, Schu
     if (s.pair_ofs) {
         // precomputed list of the points this camera pair shares (the structure is static across iterations): a
         // coalesced 4-byte stream replaces the bitmap scan (5 GB of bitmap traffic per launch at 200 x 1M)
-        const long long b0 = s.pair_ofs[pair], b1 = s.pair_ofs[pair + 1];
-        const long long lo = b0 + (b1 - b0) * chunk / s.n_chunks, hi = b0 + (b1 - b0) * (chunk + 1) / s.n_chunks;
+        // pair_ofs[pair * (n_chunks + 1) + chunk]: start of the pair's points that fall into point-range chunk
+        const long long lo = s.pair_ofs[pair * (s.n_chunks + 1) + chunk], hi = s.pair_ofs[pair * (s.n_chunks + 1) + chunk + 1];
         // software pipeline: the next point's index and record are in flight while the current one is evaluated
         long long idx = lo + lane;
         int p_cur = (idx < hi) ? s.pair_pts[idx] : 0;
+        int p_nxt = (idx + 64 < hi) ? s.pair_pts[idx + 64] : 0;
         Rec r_cur = load_rec(p_cur);
         while (idx < hi) {
-            const long long idx_n = idx + 64;
-            const int p_nxt = (idx_n < hi) ? s.pair_pts[idx_n] : p_cur;
+            // indices run two iterations ahead, records one: neither latency is on the critical path
+            const int p_nn = (idx + 128 < hi) ? s.pair_pts[idx + 128] : 0;
             const Rec r_nxt = load_rec(p_nxt);
+            // keep the gathers above the arithmetic: without the barrier the scheduler sinks them below compute() to
+            // save registers and every iteration pays the full memory latency
+            __builtin_amdgcn_sched_barrier(0);
             compute(p_cur, r_cur);
+            __builtin_amdgcn_sched_barrier(0);
             p_cur = p_nxt;
+            p_nxt = p_nn;
             r_cur = r_nxt;
-            idx = idx_n;
+            idx += 64;
         }
     } else {
     const int w_lo = (int)((long long)s.NW * chunk / s.n_chunks), w_hi = (int)((long long)s.NW * (chunk + 1) / s.n_chunks);
@@ -186,18 +228,43 @@ __global__ __launch_bounds__(256) void k_schur_pairs(ObsArgs a, CamMajor c, Schu
     }
 
     // wave reduction of the NP x NP block; block (row j, col i) of the column-major lower triangle
-    double* Sblk = S + (size_t)(j * NP) + (size_t)(i * NP) * a.n_c;
+    constexpr int NB2 = NP * NP;
+    constexpr int NPAD = NB2 <= 16 ? 16 : (NB2 <= 32 ? 32 : 64);
+    double flat[NPAD];
 #pragma unroll
-    for (int r = 0; r < NP; ++r)
-#pragma unroll
-        for (int q = 0; q < NP; ++q) {
-            const double t = wave_sum(acc[r][q]);
-            if (lane == 0) {
-                double* dst = Sblk + q + (size_t)r * a.n_c;  // S[(j,q), (i,r)] = (W_i Vinv W_j^T)[r][q]
-                if (s.n_chunks > 1) atomicAdd(dst, t);
-                else *dst = t;
-            }
+    for (int e = 0; e < NPAD; ++e) flat[e] = (e < NB2) ? acc[e / NP][e % NP] : 0.0;
+    const double total = wave_reduce_scatter<NPAD>(flat, lane, 32);
+    const int e = rs_index<NPAD>(lane);
+    const bool writer = (lane & (64 / NPAD - 1)) == 0 && e < NB2;  // one lane per total (NPAD = 64: every lane)
+    if (writer) {
+        const int r = e / NP, q = e % NP;
+        if (s.pair_ofs && s.n_chunks > 1) {
+            s.pair_part[((size_t)chunk * n_pairs + pair) * NB2 + e] = total;
+        } else {
+            double* dst = S + (size_t)(j * NP + q) + (size_t)(i * NP + r) * a.n_c;  // S[(j,q), (i,r)] = (W_i Vinv W_j^T)[r][q]
+            if (s.n_chunks > 1) atomicAdd(dst, total);
+            else *dst = total;
         }
+    }
+}
+
+// list path with several point-range chunks: S block of each pair = sum of its chunk partials
+__global__ __launch_bounds__(256) void k_schur_pairs_reduce(int M, int NP, int n_c, int n_chunks, const double* __restrict__ part,
+                                                            double* __restrict__ S) {
+    const long long n_pairs = (long long)M * (M - 1) / 2;
+    const int NB2 = NP * NP;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_pairs * NB2) return;
+    const long long pair = idx / NB2;
+    const int e = (int)(idx % NB2);
+    double t = 0.0;
+    for (int ch = 0; ch < n_chunks; ++ch) t += part[((size_t)ch * n_pairs + pair) * NB2 + e];
+    int i = (int)((2.0 * M - 1.0 - sqrt((2.0 * M - 1.0) * (2.0 * M - 1.0) - 8.0 * (double)pair)) * 0.5);
+    while ((long long)i * M - (long long)i * (i + 1) / 2 > pair) --i;
+    while ((long long)(i + 1) * M - (long long)(i + 1) * (i + 2) / 2 <= pair) ++i;
+    const int j = i + 1 + (int)(pair - ((long long)i * M - (long long)i * (i + 1) / 2));
+    const int r = e / NP, q = e % NP;
+    S[(size_t)(j * NP + q) + (size_t)(i * NP + r) * n_c] = t;
 }
 
 // Diagonal blocks and right-hand side: camera-major pass, registers only.

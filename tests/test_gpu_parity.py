@@ -473,6 +473,9 @@ ALT_PATHS = [
     {"SATBA_LIN": "3"},              # two-pass linearize (camera table larger than the fused kernel's LDS budget)
     {"SATBA_CAMC_GLOBAL": "1"},      # camera constants gathered from global memory (more than ~210 cameras)
     {"SATBA_CHOL_DAG": "1"},         # experimental dataflow Cholesky
+    {"SATBA_CHOL": "1"},             # two-launch-per-panel Cholesky (k_potrf_trsm + k_syrk)
+    {"SATBA_SCHUR_CHUNKS": "3"},     # Schur v3 pair lists cut into point-range chunks + partial reduce
+    {"SATBA_SCHUR_CHUNKS": "1"},     # ... and as one chunk (direct store)
 ]
 
 
