@@ -144,19 +144,16 @@ __global__ __launch_bounds__(256) void k_syrk(double* __restrict__ A, int n, int
         }
 }
 
-// sqrt(d) and 1/sqrt(d) together: v_rsq_f64 seed + two coupled Goldschmidt steps and a final residual correction
-// (the library sqrt followed by a division is ~4x as many dependent instructions; this sits on the serial chain of
-// the diagonal-block factorisation 32 times per panel).  d must be a normal positive number.
-__device__ inline void sqrt_and_inverse(double d, double& sq, double& inv) {
+// h = 0.5 / sqrt(d): v_rsq_f64 seed + two coupled Goldschmidt steps (six dependent operations; the library sqrt
+// followed by a division is ~4x as many, and this sits on the serial chain of the diagonal-block factorisation 32
+// times per panel).  d must be a normal positive number; sqrt(d) = 2 d h to rounding.
+__device__ inline double half_rsqrt(double d) {
     const double y = __builtin_amdgcn_rsq(d);
     double g = d * y, h = 0.5 * y;
     double r = fma(-h, g, 0.5);
     g = fma(g, r, g); h = fma(h, r, h);
     r = fma(-h, g, 0.5);
-    g = fma(g, r, g); h = fma(h, r, h);
-    const double e = fma(-g, g, d);
-    sq = fma(e, h, g);
-    inv = h + h;
+    return fma(h, r, h);
 }
 
 // One panel step in one launch.  kp: first column of the previous panel (applied to the trailing matrix here; < 0:
@@ -171,7 +168,7 @@ template <bool FULL>
 __global__ __launch_bounds__(256) void k_chol_step(double* __restrict__ A, int n, int kp, int k0, int* __restrict__ fail,
                                                    int* __restrict__ flag, double* __restrict__ b, long long* __restrict__ ts) {
     // ts (tools only, normally null): 8 wall-clock stamps of this step -- 0 start of tile (0,0), 1 its update done,
-    // 2 diagonal block factorised (flag raised), 3 its end; 4..7 the same for tile (1, 0): start, update done, flag seen, end
+    // 2 diagonal block factorised (flag raised), 3 its wave done; 4..7 the same for tile (1, 0): start, update done, flag seen, end
     __shared__ double Pi[CH_NB][64], Pj[CH_NB][64];  // Pj doubles as the stash X[c][r] of the tile's first 32 columns
     __shared__ double Lb[CH_NB][CH_NB];              // L_kk, Lb[c][r] = L[r][c] (column-major like A)
     __shared__ double lcol[2][64];
@@ -261,38 +258,54 @@ __global__ __launch_bounds__(256) void k_chol_step(double* __restrict__ A, int n
                 if (c >= nb && lane >= CH_NB) v = 0.0;
                 a[c] = v;
             }
+            // Serial chain per column: l = a_j * inv -> pivot of column j + 1 (own l: a[j+1] - l * l, no LDS round trip)
+            // -> readlane -> rsqrt.  Everything else (broadcast of l through LDS, the other columns) hangs off it.
+            // The positivity test only raises the flag: a failed factorisation is discarded by the caller.
             bool bad = false;
+            double d = readlane_f64(a[0], 0);
+            bad |= !(d > 1e-300) || !(d < 1e300);
+            double h = half_rsqrt(d);
 #pragma unroll
             for (int j = 0; j < CH_NB; ++j) {
-                double d = readlane_f64(a[j], j);
-                if (!(d > 0.0) || !(d < 1e300)) { bad = true; d = 1.0; }
-                double sq, inv;
-                sqrt_and_inverse(d, sq, inv);
-                const double l = (lane == j) ? sq : a[j] * inv;
+                const double a2 = a[j] + a[j];
+                const double l = a2 * h;  // lane j: 2 d h = sqrt(d)
                 a[j] = l;
                 if (j + 1 < CH_NB) {
+                    const double piv = fma(-l, l, a[j + 1]);
+                    d = readlane_f64(piv, j + 1);
+                    bad |= !(d > 1e-300) || !(d < 1e300);
+                    h = half_rsqrt(d);
                     lcol[j & 1][lane] = l;  // single wave: its LDS operations execute in order
                     __builtin_amdgcn_wave_barrier();
 #pragma unroll
                     for (int c = j + 1; c < CH_NB; ++c) a[c] -= l * lcol[j & 1][c];
                     __builtin_amdgcn_wave_barrier();
+                    asm volatile("" ::: "memory");
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
-            if (bad && lane == 0) atomicOr(fail, 1);
-            const int r = k0 + lane;
-            if (r < n) {
+            // publish L_kk first: agent-scope stores (write through to the coherence point) + flag, no release fence --
+            // a fence writes back the whole L2 of this XCD (~2.5 us measured) while the other tiles are still storing
+            if (lane < nb) {
 #pragma unroll
                 for (int c = 0; c < CH_NB; ++c)
-                    if (c < nb && (lane >= CH_NB || c <= lane)) A[(size_t)r + (size_t)(k0 + c) * n] = a[c];
+                    if (c <= lane) __hip_atomic_store(A + (size_t)(k0 + lane) + (size_t)(k0 + c) * n, a[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            __builtin_amdgcn_s_waitcnt(0);  // the stores above are acknowledged
+            if (lane == 0) __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (stamp) ts[2] = wall_clock64();
+            if (bad && lane == 0) atomicOr(fail, 1);
+            const int r = k0 + lane;
+            if (lane >= CH_NB && r < n) {
+#pragma unroll
+                for (int c = 0; c < CH_NB; ++c)
+                    if (c < nb) A[(size_t)r + (size_t)(k0 + c) * n] = a[c];
             }
             if (lane < CH_NB) {
 #pragma unroll
                 for (int c = 0; c < CH_NB; ++c) Lb[c][lane] = a[c];
             }
-            __threadfence();
-            if (lane == 0) __atomic_store_n(flag, 1, __ATOMIC_RELEASE);
-            if (stamp) ts[2] = wall_clock64();
+            if (stamp) ts[3] = wall_clock64();
         }
         __syncthreads();
         if (wave == 1) {  // right-hand side: y_k = L_kk^-1 b_k, lane = entry
@@ -306,7 +319,6 @@ __global__ __launch_bounds__(256) void k_chol_step(double* __restrict__ A, int n
             if (lane < nb) b[k0 + lane] = v;
             else if (k0 + lane < n) b[k0 + lane] = brow[lane];
         }
-        if (stamp) ts[3] = wall_clock64();
         return;
     }
     // ---- tiles (i > 0, 0): 64 panel rows, x L_kk^T = p  (a partial panel is the last one: it has no rows below)
@@ -314,14 +326,15 @@ __global__ __launch_bounds__(256) void k_chol_step(double* __restrict__ A, int n
     double x[CH_NB];
 #pragma unroll
     for (int c = 0; c < CH_NB; ++c) x[c] = Pj[c][lane];  // columns >= nb of the stash are zero
-    while (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == 0) __builtin_amdgcn_s_sleep(1);
+    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(1);
     if (stamp) ts[6] = wall_clock64();
     {   // L_kk: 16 coalesced loads per lane in flight, then into LDS (identity padding)
         double v[CH_NB * CH_NB / 64];
 #pragma unroll
         for (int t = 0; t < CH_NB * CH_NB / 64; ++t) {
             const int idx = t * 64 + lane, r = idx % CH_NB, c = idx / CH_NB;
-            v[t] = (r < nb && c <= r) ? __builtin_nontemporal_load(A + (size_t)(k0 + r) + (size_t)(k0 + c) * n) : ((r == c) ? 1.0 : 0.0);
+            v[t] = (r < nb && c <= r) ? __hip_atomic_load(A + (size_t)(k0 + r) + (size_t)(k0 + c) * n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                      : ((r == c) ? 1.0 : 0.0);
         }
 #pragma unroll
         for (int t = 0; t < CH_NB * CH_NB / 64; ++t) (&Lb[0][0])[t * 64 + lane] = v[t];
@@ -332,14 +345,27 @@ __global__ __launch_bounds__(256) void k_chol_step(double* __restrict__ A, int n
     const int r = r0 + lane;
     if (r >= n) return;  // before the arithmetic: stores under a condition would let the compiler sink all of it below
                          // the LDS reads (2.5 KB of spills)
+    // row m + 1 of L^T is read from LDS while step m is computed; the barriers keep the compiler from hoisting all
+    // 528 reads (spills) or sinking the arithmetic below them
+    double cur[CH_NB], nxt[CH_NB];
+#pragma unroll
+    for (int c = 1; c < CH_NB; ++c) cur[c] = Lb[0][c];
+    cur[0] = lcol[0][0];
 #pragma unroll
     for (int m = 0; m < CH_NB; ++m) {
-        const double xm = x[m] * lcol[0][m];
+        if (m + 1 < CH_NB) {
+#pragma unroll
+            for (int c = m + 2; c < CH_NB; ++c) nxt[c] = Lb[m + 1][c];
+            nxt[m + 1] = lcol[0][m + 1];
+        }
+        const double xm = x[m] * cur[m];  // cur[m] = 1 / L[m][m]
         x[m] = xm;
 #pragma unroll
-        for (int c = m + 1; c < CH_NB; ++c) x[c] -= xm * Lb[m][c];  // L[c][m]
-        asm volatile("" ::: "memory");     // one column of L at a time: hoisting all 528 reads spills
+        for (int c = m + 1; c < CH_NB; ++c) x[c] -= xm * cur[c];  // L[c][m]
+        asm volatile("" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int c = m + 1; c < CH_NB; ++c) cur[c] = nxt[c];
     }
 #pragma unroll
     for (int c = 0; c < CH_NB; ++c)
@@ -411,6 +437,71 @@ __global__ __launch_bounds__(1024) void k_trsv_back(const double* __restrict__ L
     for (int i = tid; i < n; i += 1024) b[i] = yb[i];
 }
 
+// L^T z = y for n <= 1024, right-looking, one workgroup, thread = column.  Per 32-row block (bottom up): wave 0
+// solves the diagonal block (readlane chain, ~20 ns per row), then every thread c < k0 subtracts its 32-term dot
+// product  L[k0:k0+32, c] . z_block  from its own entry.  L is static, so the 256 contiguous bytes a thread needs for
+// a step, and the next diagonal block, are requested BEFORE the solve of that step and arrive behind it.
+__global__ __launch_bounds__(1024) void k_trsv_back_rl(const double* __restrict__ L, int n, double* __restrict__ b) {
+    __shared__ double yb[1024];
+    __shared__ double zs[CH_NB];
+    __shared__ double Dk[2][CH_NB][CH_NB + 1];  // Dk[.][r][c] = L[k0 + r][k0 + c], identity padded
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = tid;
+    const int nblk = (n + CH_NB - 1) / CH_NB;
+    auto load_diag = [&](int kb) {
+        const int k0 = kb * CH_NB, nb = min(CH_NB, n - k0);
+        const int r = tid % CH_NB, cc = tid / CH_NB;
+        Dk[kb & 1][r][cc] = (r < nb && cc <= r) ? L[(size_t)(k0 + r) + (size_t)(k0 + cc) * n] : ((r == cc) ? 1.0 : 0.0);
+    };
+    double yc = (c < n) ? b[c] : 0.0;
+    yb[c] = yc;
+    load_diag(nblk - 1);
+    const bool vec = (n & 1) == 0;  // 16-byte loads when every column starts 16-byte aligned
+    __syncthreads();
+    for (int kb = nblk - 1; kb >= 0; --kb) {
+        const int k0 = kb * CH_NB, nb = min(CH_NB, n - k0);
+        double lv[CH_NB];
+        if (c < k0) {
+            const double* src = L + (size_t)k0 + (size_t)c * n;
+            if (vec && nb == CH_NB) {
+#pragma unroll
+                for (int r = 0; r < CH_NB; r += 2) {
+                    const double2 t = *reinterpret_cast<const double2*>(src + r);
+                    lv[r] = t.x; lv[r + 1] = t.y;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < CH_NB; ++r) lv[r] = (r < nb) ? src[r] : 0.0;
+            }
+        }
+        if (kb > 0) load_diag(kb - 1);
+        if (wave == 0) {  // L_kk^T z = y_k, bottom up; lane = entry
+            const int cl = min(lane, CH_NB - 1);
+            double v = (lane < nb) ? yb[k0 + lane] : 0.0;
+            const double dinv = 1.0 / Dk[kb & 1][cl][cl];
+            double col[CH_NB];  // col[j] = L[j][lane]
+#pragma unroll
+            for (int j = 0; j < CH_NB; ++j) col[j] = Dk[kb & 1][j][cl];
+#pragma unroll
+            for (int j = CH_NB - 1; j >= 0; --j) {
+                const double zj = readlane_f64(v, j) * readlane_f64(dinv, j);
+                v = (lane == j) ? zj : ((lane < j) ? fma(-col[j], zj, v) : v);
+            }
+            if (lane < CH_NB) zs[lane] = v;
+            if (lane < nb) yb[k0 + lane] = v;
+        }
+        __syncthreads();
+        if (c < k0) {
+            double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+            for (int r = 0; r < CH_NB; r += 2) { s0 = fma(lv[r], zs[r], s0); s1 = fma(lv[r + 1], zs[r + 1], s1); }
+            yc -= s0 + s1;
+            yb[c] = yc;
+        }
+        __syncthreads();
+    }
+    if (c < n) b[c] = yb[c];
+}
+
 constexpr int CH_MAX_STEPS = 256;  // flags: one per panel step (n <= 8192)
 
 // Factorise A (n x n, column-major lower, in place) and solve A z = b in place.  *fail != 0 if A was not SPD.
@@ -440,7 +531,8 @@ inline void cholesky_solve(double* A, int n, double* b, int* fail, int* flags, b
                 hipLaunchKernelGGL(k_chol_step<false>, dim3(T * (T + 1) / 2), dim3(256), 0, stream, A, n, k0 - CH_NB, k0, fail, flags + step, b, tsk);
         }
     }
-    hipLaunchKernelGGL(k_trsv_back, dim3(1), dim3(1024), sizeof(double) * n, stream, A, n, b);
+    if (n <= 1024 && !two_launch) hipLaunchKernelGGL(k_trsv_back_rl, dim3(1), dim3(1024), 0, stream, A, n, b);
+    else hipLaunchKernelGGL(k_trsv_back, dim3(1), dim3(1024), sizeof(double) * n, stream, A, n, b);
 }
 
 }  // namespace satba
