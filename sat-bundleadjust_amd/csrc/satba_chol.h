@@ -437,10 +437,37 @@ __global__ __launch_bounds__(1024) void k_trsv_back(const double* __restrict__ L
     for (int i = tid; i < n; i += 1024) b[i] = yb[i];
 }
 
+// Copy the strict lower triangle of A to the upper one (A[c + r n] = A[r + c n], r > c), 32 x 32 tiles through LDS.
+// The Schur kernels never touch the upper triangle; the backward substitution below reads L^T from it so that
+// neighbouring threads (columns) read neighbouring addresses.
+__global__ __launch_bounds__(256) void k_mirror_lower(double* __restrict__ A, int n) {
+    __shared__ double t[32][33];
+    const int T = (n + 31) / 32;
+    int bi = 0, idx = blockIdx.x;  // lower tiles (bi >= bj), row by row
+    while (idx > bi) { idx -= bi + 1; ++bi; }
+    const int bj = idx;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    (void)T;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int r = bi * 32 + tx, c = bj * 32 + ty + 8 * k;
+        t[ty + 8 * k][tx] = (r < n && c < n) ? A[(size_t)r + (size_t)c * n] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = bj * 32 + tx, r = bi * 32 + ty + 8 * k;  // element (r, c) of the lower triangle goes to (c, r)
+        if (r < n && c < n && r > c) A[(size_t)c + (size_t)r * n] = t[tx][ty + 8 * k];
+    }
+}
+
 // L^T z = y for n <= 1024, right-looking, one workgroup, thread = column.  Per 32-row block (bottom up): wave 0
-// solves the diagonal block (readlane chain, ~20 ns per row), then every thread c < k0 subtracts its 32-term dot
-// product  L[k0:k0+32, c] . z_block  from its own entry.  L is static, so the 256 contiguous bytes a thread needs for
-// a step, and the next diagonal block, are requested BEFORE the solve of that step and arrive behind it.
+// solves the diagonal block (readlane chain), then every thread c < k0 subtracts its 32-term dot product
+// L[k0:k0+32, c] . z_block  from its own entry, reading L^T from the mirrored upper triangle (coalesced).
+// L is static, so the operands of a step, and the next diagonal block, are requested BEFORE the solve of that step
+// and arrive behind it.  Measured alternatives that were slower (108 us at n = 1000 for this one): 8- and 16-row
+// blocks with 2-4 steps of operands in flight (145-250 us: the fixed cost per step, two workgroup barriers and the
+// LDS hand-offs, dominates, and the extra registers spill).
 __global__ __launch_bounds__(1024) void k_trsv_back_rl(const double* __restrict__ L, int n, double* __restrict__ b) {
     __shared__ double yb[1024];
     __shared__ double zs[CH_NB];
@@ -455,23 +482,14 @@ __global__ __launch_bounds__(1024) void k_trsv_back_rl(const double* __restrict_
     double yc = (c < n) ? b[c] : 0.0;
     yb[c] = yc;
     load_diag(nblk - 1);
-    const bool vec = (n & 1) == 0;  // 16-byte loads when every column starts 16-byte aligned
     __syncthreads();
     for (int kb = nblk - 1; kb >= 0; --kb) {
         const int k0 = kb * CH_NB, nb = min(CH_NB, n - k0);
         double lv[CH_NB];
         if (c < k0) {
-            const double* src = L + (size_t)k0 + (size_t)c * n;
-            if (vec && nb == CH_NB) {
+            const double* src = L + (size_t)c + (size_t)k0 * n;  // (row c, column k0 + r) of the upper triangle = L[k0 + r][c]
 #pragma unroll
-                for (int r = 0; r < CH_NB; r += 2) {
-                    const double2 t = *reinterpret_cast<const double2*>(src + r);
-                    lv[r] = t.x; lv[r + 1] = t.y;
-                }
-            } else {
-#pragma unroll
-                for (int r = 0; r < CH_NB; ++r) lv[r] = (r < nb) ? src[r] : 0.0;
-            }
+            for (int r = 0; r < CH_NB; ++r) lv[r] = (r < nb) ? src[(size_t)r * n] : 0.0;
         }
         if (kb > 0) load_diag(kb - 1);
         if (wave == 0) {  // L_kk^T z = y_k, bottom up; lane = entry
@@ -531,7 +549,11 @@ inline void cholesky_solve(double* A, int n, double* b, int* fail, int* flags, b
                 hipLaunchKernelGGL(k_chol_step<false>, dim3(T * (T + 1) / 2), dim3(256), 0, stream, A, n, k0 - CH_NB, k0, fail, flags + step, b, tsk);
         }
     }
-    if (n <= 1024 && !two_launch) hipLaunchKernelGGL(k_trsv_back_rl, dim3(1), dim3(1024), 0, stream, A, n, b);
+    if (n <= 1024 && !two_launch) {
+        const int T = (n + 31) / 32;
+        hipLaunchKernelGGL(k_mirror_lower, dim3(T * (T + 1) / 2), dim3(256), 0, stream, A, n);
+        hipLaunchKernelGGL(k_trsv_back_rl, dim3(1), dim3(1024), 0, stream, A, n, b);
+    }
     else hipLaunchKernelGGL(k_trsv_back, dim3(1), dim3(1024), sizeof(double) * n, stream, A, n, b);
 }
 
