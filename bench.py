@@ -42,42 +42,29 @@ PROFILED_TRAFFIC_BYTES = {("C4", 1): (2 * 185657.4 + 239116.9) * 1024.0}
 def lm_step(eng, comm, st, trf):
     """One fixed-work LM iteration (see module docstring).  `st` carries cost, Delta between steps."""
     hdr = eng.hdr
-    eng.linearize()
-    comm.allreduce(eng, eng.len_lin)
-    h = eng.read_header()
-    cost = h[trf.COST]
-    eng.prepare(st["first"])
-    comm.allreduce(eng, hdr)
-    h = eng.read_header()
-    gh_sq, jg_sq = h[trf.GH_SQ], h[trf.JG_SQ]
-    if st["first"]:
-        st["Delta"] = np.sqrt(h[trf.XS_SQ]) or 1.0
-        st["first"] = False
-    Delta = st["Delta"]
-    gh_norm = np.sqrt(gh_sq)
-    _, ag = trf.minimize_quadratic_1d(0.5 * jg_sq, -gh_sq, 0.0, Delta / max(gh_norm, 1e-300))
-    reg = max(-ag / Delta ** 2, 1e-14)
-    eng.schur(reg)
-    comm.allreduce(eng, eng.len_schur)
-    eng.solve()
-    comm.allreduce(eng, hdr)
-    h = eng.read_header()
-    ga, gb = h[trf.GRAM_A], h[trf.GRAM_B]
-    gc_ = h[trf.GRAM_C]
-    eng.subspace(gb / ga, 1.0 / np.sqrt(ga))
-    comm.allreduce(eng, hdr)
-    h = eng.read_header()
 
     def exchange(n):
         comm.allreduce(eng, n)
         return eng.read_header()
 
-    B_S, g_S, nw = trf.subspace_model(eng, exchange, h, ga, gb, gc_, jg_sq, reg)
-    p_S, _ = trf.solve_trust_region_2d(B_S, g_S, Delta)
-    predicted = -(0.5 * p_S @ B_S @ p_S + g_S @ p_S)
-    eng.trial(p_S[0], p_S[1] / nw)
+    # linearize -> prepare -> damped Gauss-Newton step, queued without a host round trip (satba/trf.py: front)
+    eng.linearize()
+    comm.allreduce(eng, eng.len_lin)
+    eng.prepare(st["first"])
     comm.allreduce(eng, hdr)
-    h = eng.read_header()
+    eng.schur_auto(-1.0 if st["first"] else st["Delta"], 1e-14)
+    comm.allreduce(eng, eng.len_schur)
+    eng.solve()
+    h = exchange(hdr)
+    st["first"] = False
+    cost, Delta, reg, jg_sq = h[trf.K_COST], h[trf.K_DELTA], h[trf.K_LAM], h[trf.K_JG_SQ]
+    ga, gb, gc_ = h[trf.GRAM_A], h[trf.GRAM_B], h[trf.GRAM_C]
+    B_S, g_S, coeffs = trf.subspace_model(eng, exchange, ga, gb, gc_, jg_sq, reg)
+    p_S, newton = trf.solve_trust_region_2d(B_S, g_S, Delta)
+    st["interior"] = st.get("interior", 0) + int(newton)
+    predicted = -(0.5 * p_S @ B_S @ p_S + g_S @ p_S)
+    eng.trial_gn(*coeffs(p_S))
+    h = exchange(hdr)
     cost_new = h[trf.COST_NEW]
     step_h_norm = np.linalg.norm(p_S)
     actual = cost - cost_new if np.isfinite(cost_new) else -1.0
@@ -202,7 +189,7 @@ def main():
                          "kernel": "k_linearize",
                          "algorithmic_bytes_per_launch": alg_bytes, "ms_per_launch": kern["linearize"]},
             "kernel_ms": kern,
-            "accepted_steps": st["accepted"], "final_cost": st["cost"], "scene_gen_s": t_gen,
+            "accepted_steps": st["accepted"], "interior_2d_steps": st.get("interior", 0), "final_cost": st["cost"], "scene_gen_s": t_gen,
         }
         if args.cpu_sample_pts > 0 and world == 1:
             out["cpu_baseline"] = cpu_baseline(scene, min(args.cpu_sample_pts, n_pts), corr)

@@ -52,6 +52,11 @@ enum {
 
 /* exchange-buffer header: SATBA_HDR_FIXED scalars + one slot per rank, rounded up to an even count */
 #define SATBA_HDR_FIXED 16
+/* after satba_solve, header slots SATBA_HDR_KEEP .. +SATBA_KEEP_LEN-1 repeat the scalars of the earlier phases of the
+ * same iteration: cost, |g|_inf, |g_h|^2, |J_h g_h|^2, |x_h|^2, damping used, trust radius used (0 unless
+ * satba_schur_auto computed them) */
+#define SATBA_HDR_KEEP 8
+#define SATBA_KEEP_LEN 7
 
 typedef struct satba_problem satba_problem;
 
@@ -119,6 +124,12 @@ int satba_prepare(satba_problem *p, int32_t first);
 /* local part of the reduced camera system  S = U + lam Dc^2 - sum_p W (V + lam Dp^2)^-1 W^T  and its
  * right-hand side; replaces LSMR (trf.py:479-480).  Exchange payload: S (n_c x n_c, column-major lower) | rhs. */
 int satba_schur(satba_problem *p, double lam);
+/* The same with the damping computed on the device from the (all-reduced) header of satba_prepare, exactly as the
+ * host does it for satba_schur: scipy's Cauchy-step regulariser (scipy:optimize/_lsq/trf.py:473-477,
+ * common.py:302-322) for the trust radius Delta, floored at lam_floor.  Delta <= 0 selects scipy's initial radius
+ * |x_h| (trf.py:440-442).  linearize -> prepare -> schur_auto -> solve can then be queued without a host
+ * round trip; satba_solve repeats the scalars the host would have read in between in header slots SATBA_HDR_KEEP.. */
+int satba_schur_auto(satba_problem *p, double Delta, double lam_floor);
 /* after the all-reduce: dense Cholesky solve, point back-substitution, Gram matrix of (g_h, gn_h).        */
 int satba_solve(satba_problem *p);
 /* basis of span{g_h, gn_h} (trf.py:481-482): q1 = inv_norm_g * g_h, w = gn_h - alpha * g_h, and their dots.
@@ -130,6 +141,8 @@ int satba_subspace(satba_problem *p, double alpha, double inv_norm_g);
 int satba_subspace_products(satba_problem *p);
 /* x_new = x + scale * (p0 q1 + p1 w); cost at x_new (trf.py:497-512).                                     */
 int satba_trial(satba_problem *p, double p0, double p1);
+/* the same step written on (g_h, gn_h): x_new = x + scale * (ca g_h + cb gn_h); needs no satba_subspace.           */
+int satba_trial_gn(satba_problem *p, double ca, double cb);
 int satba_accept(satba_problem *p);
 /* synchronise the stream and copy the exchange header to the host. */
 int satba_read_header(satba_problem *p, double *host_hdr);

@@ -304,6 +304,9 @@ class OracleEngine:
 
     def prepare(self, first):
         b = self._xb
+        self._keep = np.zeros(7)
+        self._keep[0] = b[0]
+        self._keep[1] = np.max(b[self.HDR_FIXED: self.HDR_FIXED + self.world])
         nU = self.n_cam * self.n_p ** 2
         self.U = b[self.hdr: self.hdr + nU].reshape(self.n_cam, self.n_p, self.n_p).copy()
         self.gc = b[self.hdr + nU: self.hdr + nU + self.n_c].copy()
@@ -338,6 +341,26 @@ class OracleEngine:
         b[self.hdr: self.hdr + self.n_c ** 2] = S.ravel()
         b[self.hdr + self.n_c ** 2: self.len_schur] = rhs
 
+    def schur_auto(self, Delta, lam_floor=0.0):
+        """Damping from the (all-reduced) prepare header, as satba/trf.py computes it on the host for schur()."""
+        b, k = self._xb, self._keep
+        gh_sq, jg_sq, xs_sq = b[1], b[2], b[3]
+        k[1] = max(k[1], b[4])
+        k[2:5] = gh_sq, jg_sq, xs_sq
+        if not Delta > 0:
+            Delta = np.sqrt(xs_sq) or 1.0
+        a, bb, ub = 0.5 * jg_sq, -gh_sq, Delta / np.sqrt(gh_sq)
+        best = min(0.0, a * ub * ub + bb * ub)
+        if a != 0:
+            ext = -0.5 * bb / a
+            if 0 < ext < ub:
+                best = min(best, a * ext * ext + bb * ext)
+        lam = -best / Delta ** 2
+        if not lam >= lam_floor:
+            lam = lam_floor
+        k[5], k[6] = lam, Delta
+        self.schur(lam)
+
     def solve(self):
         b = self._xb
         S = b[self.hdr: self.hdr + self.n_c ** 2].reshape(self.n_c, self.n_c)
@@ -358,6 +381,7 @@ class OracleEngine:
         b[2] = self._dot(self.g_h, self.gn_h)
         b[3] = self._dot(self.gn_h, self.gn_h)
         b[4] = self.lead * fail
+        b[8:15] = self.lead * getattr(self, "_keep", np.zeros(7))
 
     def subspace(self, alpha, inv_norm_g):
         self.q1 = self.g_h * inv_norm_g
@@ -377,6 +401,16 @@ class OracleEngine:
 
     def trial(self, p0, p1):
         step = self.scale * (p0 * self.q1 + p1 * self.w)
+        self.x_new = self.x + step
+        f_new = O.fun(self.x_new, self.p, np.float32 if self.rpc_f32 else np.float64)
+        b = self._xb
+        b[: self.hdr] = 0
+        b[1] = robust_cost(f_new, self.loss, self.f_scale)
+        b[2] = self._dot(step, step)
+        b[3] = self._dot(self.x, self.x)
+
+    def trial_gn(self, ca, cb):
+        step = self.scale * (ca * self.g_h + cb * self.gn_h)
         self.x_new = self.x + step
         f_new = O.fun(self.x_new, self.p, np.float32 if self.rpc_f32 else np.float64)
         b = self._xb

@@ -91,6 +91,8 @@ struct satba_problem {
     int* d_fail = nullptr;
     bool chol_two_launch = false;
     double* d_scal = nullptr;  // 8 private scalars (costs of satba_residuals, timing sinks)
+    double* d_keep = nullptr;  // SATBA_KEEP_LEN scalars of the running iteration that outlive the per-phase headers
+    bool prepared = false;
     double *d_xb_own = nullptr, *d_xb = nullptr;
     long long xb_len = 0;
     double* h_pin = nullptr;  // pinned staging for header reads
@@ -342,8 +344,44 @@ static int launch_jvp(satba_problem* p, int nv, const double* q1, const double* 
     return 0;
 }
 
-__global__ void k_flag_to_header(const int* __restrict__ flag, double lead, double* __restrict__ slot) {
-    *slot = (*flag != 0) ? lead : 0.0;
+// end of the solve phase: Cholesky status into header slot 4 and the scalars kept from the earlier phases of this
+// iteration into slots SATBA_HDR_KEEP.. (rank 0 only: the header is summed over ranks afterwards)
+__global__ void k_flag_to_header(const int* __restrict__ flag, double lead, double* __restrict__ hdr, const double* __restrict__ keep) {
+    const int t = threadIdx.x;
+    if (t == 0) hdr[4] = (*flag != 0) ? lead : 0.0;
+    if (t < SATBA_KEEP_LEN) hdr[SATBA_HDR_KEEP + t] = lead * keep[t];
+}
+
+// start of the prepare phase: the (already all-reduced) linearize header -> keep[0] = cost, keep[1] = max_rank |g_p|_inf
+__global__ void k_keep_linearize(const double* __restrict__ hdr, int world, double* __restrict__ keep) {
+    double m = 0.0;
+    for (int r = 0; r < world; ++r) m = fmax(m, hdr[SATBA_HDR_FIXED + r]);
+    keep[0] = hdr[0];
+    keep[1] = m;
+}
+
+// start of satba_schur_auto: the (already all-reduced) prepare header -> keep[1] = |g|_inf, keep[2..4] = |g_h|^2,
+// |J_h g_h|^2, |x_h|^2; trust radius (scipy trf.py:440-442 when Delta <= 0: first iteration) -> keep[6]; damping of the
+// Gauss-Newton system from the Cauchy step (scipy trf.py:473-477, common.py:302-322) -> keep[5]
+__global__ void k_lambda(const double* __restrict__ hdr, double Delta, double lam_floor, double* __restrict__ keep) {
+    const double gh_sq = hdr[1], jg_sq = hdr[2], xs_sq = hdr[3];
+    keep[1] = fmax(keep[1], hdr[4]);
+    keep[2] = gh_sq; keep[3] = jg_sq; keep[4] = xs_sq;
+    if (!(Delta > 0.0)) {
+        Delta = sqrt(xs_sq);
+        if (Delta == 0.0) Delta = 1.0;
+    }
+    // minimum of a t^2 + b t on [0, ub]
+    const double a = 0.5 * jg_sq, b = -gh_sq, ub = Delta / sqrt(gh_sq);
+    double best = fmin(0.0, a * ub * ub + b * ub);
+    if (a != 0.0) {
+        const double ext = -0.5 * b / a;
+        if (0.0 < ext && ext < ub) best = fmin(best, a * ext * ext + b * ext);
+    }
+    double lam = -best / (Delta * Delta);
+    if (!(lam >= lam_floor)) lam = lam_floor;  // also catches NaN (zero gradient)
+    keep[5] = lam;
+    keep[6] = Delta;
 }
 
 template <class K>
@@ -505,6 +543,8 @@ int satba_problem_create(const satba_problem_desc* d, satba_problem** out) {
             if (getenv("SATBA_DAG_TIMES")) TRY(dev_alloc(p, &p->dag.d_times, 4 * tasks.size()));
         }
         TRY(dev_alloc(p, &p->d_scal, 8));
+        TRY(dev_alloc(p, &p->d_keep, SATBA_KEEP_LEN));
+        HIP_TRY(hipMemset(p->d_keep, 0, sizeof(double) * SATBA_KEEP_LEN));
         p->lin_grid = grid_for(p->n_tiles, 16, lin1_lds(p, false) <= 78 * 1024 ? 512 : 256);
         TRY(dev_alloc(p, &p->d_part, (size_t)p->lin_grid * p->M * cam_acc_len(p->NP)));
         {   // camera-major copy of the observation data (Schur v3, linearize v3) and chunking of the camera passes
@@ -747,11 +787,30 @@ int satba_prepare(satba_problem* p, int32_t first) {
     const size_t nU = (size_t)p->M * p->NP * p->NP;
     HIP_TRY(hipMemcpyAsync(p->d_U, p->payload(), sizeof(double) * nU, hipMemcpyDeviceToDevice, p->stream));
     HIP_TRY(hipMemcpyAsync(p->d_gc, p->payload() + nU, sizeof(double) * p->n_c, hipMemcpyDeviceToDevice, p->stream));
+    hipLaunchKernelGGL(k_keep_linearize, dim3(1), dim3(1), 0, p->stream, p->d_xb, p->world, p->d_keep);
+    HIP_TRY(hipGetLastError());
     TRY(zero_header(p));
     hipLaunchKernelGGL(k_prepare_vec, dim3(grid_for(p->n, 256, 512)), dim3(256), 0, p->stream, p->n, p->n_c, p->NP, first,
                        p->lead, p->d_U, p->d_gc, p->d_V, p->d_x, p->d_g, p->d_scale_inv, p->d_gh, p->d_xb);
     HIP_TRY(hipGetLastError());
     TRY(launch_jvp(p, 1, p->d_gh, p->d_gh, p->d_xb + 2));
+    p->prepared = true;
+    return 0;
+}
+
+static int schur_impl(satba_problem* p, double lam, const double* lam_dev) {
+    const size_t nS = (size_t)p->n_c * p->n_c + p->n_c;
+    HIP_TRY(hipMemsetAsync(p->d_xb, 0, sizeof(double) * (p->hdr + nS), p->stream));
+    if (p->N > 0) {
+        hipLaunchKernelGGL(k_vinv, dim3((p->N + 255) / 256), dim3(256), 0, p->stream, p->N, lam, lam_dev, p->d_V,
+                           p->d_scale_inv + p->n_c, p->d_Vinv, p->d_x + p->n_c, p->d_g + p->n_c, p->d_PV);
+        HIP_TRY(hipGetLastError());
+    }
+    double* S = p->payload();
+    hipLaunchKernelGGL(k_schur_init, dim3((p->M * p->NP * p->NP + 255) / 256), dim3(256), 0, p->stream, p->M, p->NP, lam, lam_dev,
+                       p->lead, p->u_full, p->d_U, p->d_gc, p->d_scale_inv, S, S + (size_t)p->n_c * p->n_c);
+    HIP_TRY(hipGetLastError());
+    if (p->K > 0) TRY(launch_schur_kernel(p));
     return 0;
 }
 
@@ -759,19 +818,17 @@ int satba_schur(satba_problem* p, double lam) {
     if (!p) return fail(SATBA_E_ARG, "null handle");
     if (!p->linearized) return fail(SATBA_E_STATE, "schur before linearize");
     HIP_TRY(hipSetDevice(p->device));
-    const size_t nS = (size_t)p->n_c * p->n_c + p->n_c;
-    HIP_TRY(hipMemsetAsync(p->d_xb, 0, sizeof(double) * (p->hdr + nS), p->stream));
-    if (p->N > 0) {
-        hipLaunchKernelGGL(k_vinv, dim3((p->N + 255) / 256), dim3(256), 0, p->stream, p->N, lam, p->d_V,
-                           p->d_scale_inv + p->n_c, p->d_Vinv, p->d_x + p->n_c, p->d_g + p->n_c, p->d_PV);
-        HIP_TRY(hipGetLastError());
-    }
-    double* S = p->payload();
-    hipLaunchKernelGGL(k_schur_init, dim3((p->M * p->NP * p->NP + 255) / 256), dim3(256), 0, p->stream, p->M, p->NP, lam, p->lead,
-                       p->u_full, p->d_U, p->d_gc, p->d_scale_inv, S, S + (size_t)p->n_c * p->n_c);
+    return schur_impl(p, lam, nullptr);
+}
+
+int satba_schur_auto(satba_problem* p, double Delta, double lam_floor) {
+    if (!p) return fail(SATBA_E_ARG, "null handle");
+    if (!p->linearized || !p->prepared) return fail(SATBA_E_STATE, "schur_auto before prepare");
+    HIP_TRY(hipSetDevice(p->device));
+    hipLaunchKernelGGL(k_lambda, dim3(1), dim3(1), 0, p->stream, p->d_xb, Delta, lam_floor, p->d_keep);
     HIP_TRY(hipGetLastError());
-    if (p->K > 0) TRY(launch_schur_kernel(p));
-    return 0;
+    p->prepared = false;  // the prepare header is gone after this call
+    return schur_impl(p, 0.0, p->d_keep + 5);
 }
 
 int satba_solve(satba_problem* p) {
@@ -793,7 +850,7 @@ int satba_solve(satba_problem* p) {
     hipLaunchKernelGGL(k_backsub_finish, dim3(grid_for(p->n_c + p->N, 256, 512)), dim3(256), 0, p->stream, p->n_c, p->N, p->lead,
                        p->d_dch, p->d_Vinv, p->d_g, p->d_tbuf, p->d_scale_inv, p->d_gh, p->d_gn, p->d_xb);
     HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(k_flag_to_header, dim3(1), dim3(1), 0, p->stream, p->d_fail, p->lead, p->d_xb + 4);
+    hipLaunchKernelGGL(k_flag_to_header, dim3(1), dim3(64), 0, p->stream, p->d_fail, p->lead, p->d_xb, p->d_keep);
     HIP_TRY(hipGetLastError());
     p->have_step = true;
     return 0;
@@ -832,11 +889,24 @@ int satba_trial(satba_problem* p, double p0, double p1) {
     return 0;
 }
 
+int satba_trial_gn(satba_problem* p, double ca, double cb) {
+    if (!p) return fail(SATBA_E_ARG, "null handle");
+    if (!p->have_step) return fail(SATBA_E_STATE, "trial before solve");
+    HIP_TRY(hipSetDevice(p->device));
+    TRY(zero_header(p));
+    hipLaunchKernelGGL(k_trial_vec, dim3(grid_for(p->n, 256, 512)), dim3(256), 0, p->stream, p->n, p->n_c, p->lead, ca, cb,
+                       p->d_x, p->d_gh, p->d_gn, p->d_scale_inv, p->d_xnew, p->d_xb);
+    HIP_TRY(hipGetLastError());
+    TRY(launch_cam_consts(p, true));
+    TRY(launch_residual(p, true, nullptr, p->d_xb + 1));
+    return 0;
+}
+
 int satba_accept(satba_problem* p) {
     if (!p) return fail(SATBA_E_ARG, "null handle");
     std::swap(p->d_x, p->d_xnew);
     std::swap(p->d_camc, p->d_camc_new);
-    p->linearized = false; p->have_step = false;
+    p->linearized = false; p->have_step = false; p->prepared = false;
     return 0;
 }
 

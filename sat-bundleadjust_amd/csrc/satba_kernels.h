@@ -434,11 +434,13 @@ __global__ __launch_bounds__(512) void k_jvp(ObsArgs a, const double* __restrict
 // ------------------------------------------------------------------------------------------------ K3 Schur complement
 // (V_p + lam Dp^2)^-1 per point, symmetric 3x3 stored as xx xy xz yy yz zz
 // PV (optional): packed per-point record X(3) | Vinv(6) | g_p(3) for the gather-heavy Schur v3 kernels
-__global__ void k_vinv(int N, double lam, const double* __restrict__ V, const double* __restrict__ scale_inv_p,
-                       double* __restrict__ Vinv, const double* __restrict__ xp, const double* __restrict__ gp,
-                       double* __restrict__ PV) {
+// lam_dev (optional): the damping is read from device memory (satba_schur_auto) instead of the argument
+__global__ void k_vinv(int N, double lam, const double* __restrict__ lam_dev, const double* __restrict__ V,
+                       const double* __restrict__ scale_inv_p, double* __restrict__ Vinv, const double* __restrict__ xp,
+                       const double* __restrict__ gp, double* __restrict__ PV) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= N) return;
+    if (lam_dev) lam = *lam_dev;
     const double* v = V + 6 * (size_t)p;
     const double* s = scale_inv_p + 3 * (size_t)p;
     const double a = v[0] + lam * s[0] * s[0], b = v[1], c = v[2];
@@ -463,9 +465,10 @@ __global__ void k_vinv(int N, double lam, const double* __restrict__ V, const do
 
 // S <- (lead) * blockdiag(U_c + lam Dc^2), rhs <- (lead) * g_c ; S column-major n_c x n_c (already zeroed)
 // use_U = 0: the J_c^T J_c blocks are added by k_schur_diag instead (only the damping goes on the diagonal here)
-__global__ void k_schur_init(int M, int NP, double lam, double lead, int use_U, const double* __restrict__ U,
-                             const double* __restrict__ gc, const double* __restrict__ scale_inv,
+__global__ void k_schur_init(int M, int NP, double lam, const double* __restrict__ lam_dev, double lead, int use_U,
+                             const double* __restrict__ U, const double* __restrict__ gc, const double* __restrict__ scale_inv,
                              double* __restrict__ S, double* __restrict__ rhs) {
+    if (lam_dev) lam = *lam_dev;
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     const int n_c = M * NP;
     if (idx < M * NP * NP) {

@@ -26,7 +26,7 @@ HDR_FIXED = 16
 SYMBOLS = [
     "satba_last_error", "satba_version", "satba_problem_create", "satba_problem_destroy", "satba_set_stream",
     "satba_exchange_len", "satba_header_len", "satba_bind_exchange", "satba_configure", "satba_set_x", "satba_get_x",
-    "satba_residuals", "satba_linearize", "satba_prepare", "satba_schur", "satba_solve", "satba_subspace", "satba_subspace_products", "satba_trial",
+    "satba_residuals", "satba_linearize", "satba_prepare", "satba_schur", "satba_schur_auto", "satba_solve", "satba_subspace", "satba_subspace_products", "satba_trial", "satba_trial_gn",
     "satba_accept", "satba_read_header", "satba_get_blocks", "satba_get_jacobian", "satba_get_exchange",
     "satba_set_exchange", "satba_get_vector", "satba_time_kernel",
 ]
@@ -82,8 +82,10 @@ def load_library(path=None):
         getattr(lib, name).argtypes = [h]
     lib.satba_prepare.argtypes = [h, C.c_int32]
     lib.satba_schur.argtypes = [h, C.c_double]
+    lib.satba_schur_auto.argtypes = [h, C.c_double, C.c_double]
     lib.satba_subspace.argtypes = [h, C.c_double, C.c_double]
     lib.satba_trial.argtypes = [h, C.c_double, C.c_double]
+    lib.satba_trial_gn.argtypes = [h, C.c_double, C.c_double]
     lib.satba_read_header.argtypes = [h, _dp]
     lib.satba_get_blocks.argtypes = [h, _dp, _dp, _dp, _dp]
     lib.satba_get_jacobian.argtypes = [h, _dp, _dp]
@@ -229,6 +231,9 @@ class HipEngine:
     def schur(self, lam):
         _check(self.lib, self.lib.satba_schur(self._h, float(lam)))
 
+    def schur_auto(self, Delta, lam_floor=0.0):
+        _check(self.lib, self.lib.satba_schur_auto(self._h, float(Delta), float(lam_floor)))
+
     def solve(self):
         _check(self.lib, self.lib.satba_solve(self._h))
 
@@ -240,6 +245,9 @@ class HipEngine:
 
     def trial(self, p0, p1):
         _check(self.lib, self.lib.satba_trial(self._h, float(p0), float(p1)))
+
+    def trial_gn(self, ca, cb):
+        _check(self.lib, self.lib.satba_trial_gn(self._h, float(ca), float(cb)))
 
     def accept(self):
         _check(self.lib, self.lib.satba_accept(self._h))

@@ -26,10 +26,14 @@ Engine contract (implemented by engine_hip.HipEngine; tests use a CPU stand-in b
     linearize()         normal blocks at x          -> header[COST], slot[rank] = |g_p|_inf, payload U | g_c
     prepare(first)      scaling, g_h, |J_h g_h|^2   -> header[GH_SQ, JG_SQ, XS_SQ, GC_INF]
     schur(lam)          local reduced system        -> payload S | rhs
-    solve()             Cholesky + back-substitute  -> header[A, B, C, FAIL]   (Gram matrix of g_h, gn_h)
+    schur_auto(Delta, floor)  the same, lam = scipy's Cauchy-step regulariser computed by the engine from the
+                        prepare header (Delta <= 0: scipy's initial radius); no host round trip before it
+    solve()             Cholesky + back-substitute  -> header[A, B, C, FAIL]   (Gram matrix of g_h, gn_h) and
+                        header[K_COST .. K_DELTA]: what the earlier phases of this iteration reported
     subspace(alpha, s)  q1 = s g_h, w = gn_h - alpha g_h            -> header[WW, WQ1, GHW]
     subspace_products() |J_h q1|^2, (J_h q1).(J_h w), |J_h w|^2      -> header[B11, B12, B22]  (fallback / tests)
     trial(p0, p1)       x_new = x + scale (p0 q1 + p1 w); cost there -> header[COST_NEW, STEP_SQ, X_SQ]
+    trial_gn(ca, cb)    x_new = x + scale (ca g_h + cb gn_h): the same step without the subspace phase
     accept()            x <- x_new
 """
 import numpy as np
@@ -40,6 +44,8 @@ GH_SQ, JG_SQ, XS_SQ, GC_INF = 1, 2, 3, 4
 GRAM_A, GRAM_B, GRAM_C, CHOL_FAIL = 1, 2, 3, 4
 WW, WQ1, B11, B12, B22, GHW = 1, 2, 3, 4, 5, 6
 COST_NEW, STEP_SQ, X_SQ = 1, 2, 3
+# after solve(): scalars kept from the linearize / prepare / schur_auto phases of the same iteration
+K_COST, K_GINF, K_GH_SQ, K_JG_SQ, K_XS_SQ, K_LAM, K_DELTA = 8, 9, 10, 11, 12, 13, 14
 
 TERMINATION_MESSAGES = {
     -1: "Improper input parameters status returned from `leastsq`",
@@ -167,31 +173,40 @@ def _print_iteration(iteration, nfev, cost, cost_reduction, step_norm, optimalit
     print(f"{iteration:^15}{nfev:^15}{cost:^15.4e}{cr}{sn}{optimality:^15.2e}")
 
 
-def subspace_model(engine, exchange, h, ga, gb, gc, jg_sq, reg):
+def subspace_model(engine, exchange, ga, gb, gc, jg_sq, reg):
     """
-    Quadratic model on the orthonormal basis {q1, w / |w|} of span{g_h, gn_h}: B_S (2 x 2), g_S, |w|.
-    h is the header of the subspace phase (WW, GHW).  Because gn_h solves the damped normal equations exactly,
+    Quadratic model on the orthonormal basis {q1, q2} = {g_h / |g_h|, w / |w|}, w = gn_h - (b / a) g_h, of
+    span{g_h, gn_h} (scipy trf.py:481-485): returns B_S (2 x 2), g_S and (ca, cb) -> coefficients, i.e. a function
+    mapping a step p_S on that basis to its coefficients on (g_h, gn_h).
+    a, b, c = Gram matrix of (g_h, gn_h).  Because gn_h solves the damped normal equations exactly,
     J_h^T J_h gn_h = g_h - reg gn_h, the Gram matrix of (J_h g_h, J_h gn_h) is known without touching the
     observations again:  |J_h g_h|^2 = jg_sq (from the prepare phase), (J_h g_h).(J_h gn_h) = a - reg b,
-    |J_h gn_h|^2 = b - reg c, with a, b, c the Gram matrix of (g_h, gn_h).  Only when w is a tiny remainder of
-    gn_h (the two directions nearly parallel: cancellation) are the products computed explicitly on the device.
+    |J_h gn_h|^2 = b - reg c; and |w|^2 = c - b^2 / a, g_h.w = 0.  Only when w is a tiny remainder of gn_h (the two
+    directions nearly parallel: cancellation in these formulas) are w and the products formed explicitly on the
+    device (subspace, subspace_products: two more passes and round trips).
     """
-    ww = h[WW]
-    if not (ww > 1e-24 * gc and ww > 0):  # gn_h parallel to g_h: one-dimensional subspace
-        return np.array([[jg_sq / ga, 0.0], [0.0, 1.0]]), np.array([np.sqrt(ga), 0.0]), np.inf
-    nw = np.sqrt(ww)
+    sa = np.sqrt(ga)
     alpha = gb / ga
+    ww = gc - gb * alpha
     if ww > 1e-6 * gc:
+        nw = np.sqrt(ww)
         m11, m12, m22 = jg_sq, ga - reg * gb, gb - reg * gc
         b11 = m11 / ga
-        b12 = (m12 - alpha * m11) / np.sqrt(ga)
+        b12 = (m12 - alpha * m11) / sa
         b22 = m22 - 2.0 * alpha * m12 + alpha * alpha * m11
+        ghw = 0.0
     else:
+        engine.subspace(alpha, 1.0 / sa)
+        h = exchange(engine.hdr)
+        ww, ghw = h[WW], h[GHW]
+        if not (ww > 1e-24 * gc and ww > 0):  # gn_h parallel to g_h: one-dimensional subspace
+            return np.array([[jg_sq / ga, 0.0], [0.0, 1.0]]), np.array([sa, 0.0]), lambda p_S: (p_S[0] / sa, 0.0)
+        nw = np.sqrt(ww)
         engine.subspace_products()
         hp = exchange(engine.hdr)
         b11, b12, b22 = hp[B11], hp[B12], hp[B22]
     B_S = np.array([[b11, b12 / nw], [b12 / nw, b22 / ww]])
-    return B_S, np.array([np.sqrt(ga), h[GHW] / nw]), nw
+    return B_S, np.array([sa, ghw / nw]), lambda p_S: (p_S[0] / sa - p_S[1] * alpha / nw, p_S[1] / nw)
 
 
 # ----------------------------------------------------------------------------- the loop
@@ -212,23 +227,29 @@ def trf_solve(engine, comm=None, ftol=1e-8, xtol=1e-8, gtol=1e-8, max_nfev=None,
         comm.allreduce(engine, n)
         return engine.read_header()
 
-    def linearize(first):
+    def front(Delta):
+        """
+        linearize -> prepare -> damped Gauss-Newton step at the current x, queued without a host round trip: the
+        engine derives the damping from the trust radius itself (Delta None: first call, scipy's initial radius).
+        One header read returns what scipy computes at the top of an iteration (cost, |g|_inf, ...) together with
+        the Gram matrix of the step; scipy's gtol / max_nfev tests are taken right after it.
+        """
         engine.linearize()
-        h = exchange(engine.len_lin)
-        cost, gp_inf = h[COST], np.max(h[slots])
-        engine.prepare(first)
-        h = exchange(hdr)
-        return cost, max(gp_inf, h[GC_INF]), h[GH_SQ], h[JG_SQ], h[XS_SQ]
+        comm.allreduce(engine, engine.len_lin)
+        engine.prepare(Delta is None)
+        comm.allreduce(engine, hdr)
+        engine.schur_auto(-1.0 if Delta is None else Delta, 0.0)
+        comm.allreduce(engine, engine.len_schur)
+        engine.solve()
+        return exchange(hdr)
 
     engine.configure(loss, f_scale)
-    cost, g_norm, gh_sq, jg_sq, xs_sq = linearize(True)
+    h = front(None)
+    cost, g_norm, Delta = h[K_COST], h[K_GINF], h[K_DELTA]
     if not np.isfinite(cost):
         raise ValueError("Residuals are not finite in the initial point.")
     nfev = njev = 1
     initial_cost = cost
-    Delta = np.sqrt(xs_sq)
-    if Delta == 0:
-        Delta = 1.0
 
     status, iteration, step_norm, actual_reduction = None, 0, None, None
     lm_iterations = 0
@@ -243,38 +264,34 @@ def trf_solve(engine, comm=None, ftol=1e-8, xtol=1e-8, gtol=1e-8, max_nfev=None,
         if status is not None or nfev == max_nfev:
             break
 
-        # Cauchy-step regulariser of the Gauss-Newton system (scipy trf.py:473-477)
-        gh_norm = np.sqrt(gh_sq)
-        _, ag_value = minimize_quadratic_1d(0.5 * jg_sq, -gh_sq, 0.0, Delta / gh_norm)
-        reg = -ag_value / Delta ** 2
-
-        # In scaled variables the system matrix has a unit diagonal, so reg is relative to 1.  Where scipy's LSMR
-        # copes with a numerically singular system (gauge freedom, flat valleys), a Cholesky needs a floor:
-        # escalate the damping until the factorisation goes through.
+        # h: header of the solve phase for the current x and Delta.  reg = Cauchy-step regulariser of the
+        # Gauss-Newton system (scipy trf.py:473-477), computed by the engine.  In scaled variables the system matrix
+        # has a unit diagonal, so reg is relative to 1.  Where scipy's LSMR copes with a numerically singular system
+        # (gauge freedom, flat valleys), a Cholesky needs a floor: escalate the damping until the factorisation
+        # goes through.
+        reg, jg_sq = h[K_LAM], h[K_JG_SQ]
         for attempt in range(10):
+            if h[CHOL_FAIL] == 0 and np.isfinite(h[GRAM_C]):
+                break
+            reg = max(reg, 1e-16) * 100.0
             engine.schur(reg)
             comm.allreduce(engine, engine.len_schur)
             engine.solve()
             h = exchange(hdr)
-            if h[CHOL_FAIL] == 0 and np.isfinite(h[GRAM_C]):
-                break
-            reg = max(reg, 1e-16) * 100.0
         else:
             raise RuntimeError("reduced camera system could not be factorised")
         ga, gb, gc = h[GRAM_A], h[GRAM_B], h[GRAM_C]
 
-        # orthonormal basis of span{g_h, gn_h} and the model restricted to it (scipy trf.py:481-485)
-        engine.subspace(gb / ga, 1.0 / np.sqrt(ga))
-        h = exchange(hdr)
-        B_S, g_S, nw = subspace_model(engine, exchange, h, ga, gb, gc, jg_sq, reg)
+        # the model restricted to span{g_h, gn_h} (scipy trf.py:481-485)
+        B_S, g_S, coeffs = subspace_model(engine, exchange, ga, gb, gc, jg_sq, reg)
 
         actual_reduction = -1
         while actual_reduction <= 0 and nfev < max_nfev:
             p_S, _ = solve_trust_region_2d(B_S, g_S, Delta)
             predicted_reduction = -(0.5 * p_S @ B_S @ p_S + g_S @ p_S)
-            engine.trial(p_S[0], p_S[1] / nw)
-            h = exchange(hdr)
-            cost_new = h[COST_NEW]
+            engine.trial_gn(*coeffs(p_S))
+            ht = exchange(hdr)
+            cost_new = ht[COST_NEW]
             nfev += 1
             step_h_norm = np.linalg.norm(p_S)
             if not np.isfinite(cost_new):
@@ -283,19 +300,23 @@ def trf_solve(engine, comm=None, ftol=1e-8, xtol=1e-8, gtol=1e-8, max_nfev=None,
             actual_reduction = cost - cost_new
             Delta_new, ratio = update_tr_radius(Delta, actual_reduction, predicted_reduction, step_h_norm,
                                                 step_h_norm > 0.95 * Delta)
-            step_norm = np.sqrt(h[STEP_SQ])
-            status = check_termination(actual_reduction, cost, step_norm, np.sqrt(h[X_SQ]), ratio, ftol, xtol)
+            step_norm = np.sqrt(ht[STEP_SQ])
+            status = check_termination(actual_reduction, cost, step_norm, np.sqrt(ht[X_SQ]), ratio, ftol, xtol)
             if status is not None:
                 break
             Delta = Delta_new
 
         if actual_reduction > 0:
             engine.accept()
-            cost, g_norm, gh_sq, jg_sq, xs_sq = linearize(False)
+            h = front(Delta)
+            cost, g_norm = h[K_COST], h[K_GINF]
             njev += 1
         else:
             step_norm = 0
             actual_reduction = 0
+            # same x, smaller radius: a new damped step for it (scipy recomputes it at the top of the next iteration)
+            if status is None and nfev < max_nfev:
+                h = front(Delta)
         iteration += 1
         lm_iterations += 1
 

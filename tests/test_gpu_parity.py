@@ -464,6 +464,70 @@ def test_rccl_plumbing_single_rank(gpu):
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("name", ["affine_RT", "persp_RT", "rpc_R"])
+@pytest.mark.parametrize("Delta", [-1.0, 3e-3])
+def test_queued_front_matches_host_driven_phases(gpu, name, Delta):
+    """
+    schur_auto derives the damping on the device from the prepare header; solve repeats the scalars of the earlier
+    phases; trial_gn takes the step on (g_h, gn_h).  All of it must agree with the host-driven sequence
+    prepare -> read -> schur(lam) -> solve -> subspace -> trial, and with the oracle engine doing the same.
+    """
+    _, p, g = cases.fun_case(name)
+    v = ba_core._frozen_vars(g["v"][1].copy(), p)
+    a, b, ora = HipEngine(p, rpc_f32=False), HipEngine(p, rpc_f32=False), L.OracleEngine(p, rpc_f32=False)
+    for e in (a, b, ora):
+        e.configure("linear", 1.0)
+        e.set_x(v)
+    # host-driven
+    a.linearize()
+    hl = a.read_header()
+    a.prepare(True)
+    hp = a.read_header()
+    D = np.sqrt(hp[trf.XS_SQ]) if Delta <= 0 else Delta
+    _, ag = trf.minimize_quadratic_1d(0.5 * hp[trf.JG_SQ], -hp[trf.GH_SQ], 0.0, D / np.sqrt(hp[trf.GH_SQ]))
+    lam = -ag / D ** 2
+    a.schur(lam)
+    a.solve()
+    ha = a.read_header()
+    # queued
+    for e in (b, ora):
+        e.linearize(); e.prepare(True); e.schur_auto(Delta, 0.0); e.solve()
+    hb, ho = b.read_header(), ora.read_header()
+    assert abs(hb[trf.K_LAM] - lam) <= 1e-9 * lam and abs(hb[trf.K_DELTA] - D) <= 1e-12 * D
+    assert abs(ho[trf.K_LAM] - lam) <= 1e-6 * lam
+    # two engines: the atomics of the linearize kernel make the last bits of the sums run-dependent
+    for got, want in ((hb[trf.K_COST], hl[trf.COST]), (hb[trf.K_GINF], max(hl[a.HDR_FIXED], hp[trf.GC_INF])),
+                      (hb[trf.K_GH_SQ], hp[trf.GH_SQ]), (hb[trf.K_JG_SQ], hp[trf.JG_SQ]), (hb[trf.K_XS_SQ], hp[trf.XS_SQ])):
+        assert abs(got - want) <= 1e-10 * abs(want)
+    if Delta > 0:  # at scipy's initial radius the damping is ~0 and the system too ill-conditioned to compare steps
+        for k in (trf.GRAM_A, trf.GRAM_B, trf.GRAM_C):
+            assert abs(hb[k] - ha[k]) <= 1e-6 * abs(ha[k])
+            assert abs(ho[k] - ha[k]) <= 1e-4 * abs(ha[k])
+    assert hb[trf.CHOL_FAIL] == 0
+    # lam_floor
+    b.linearize(); b.prepare(False); b.schur_auto(Delta, 10.0 * lam); b.solve()
+    assert b.read_header()[trf.K_LAM] == 10.0 * lam
+    b.linearize(); b.prepare(False); b.schur_auto(Delta, 0.0); b.solve()
+    # the same step through both trial entry points
+    ga, gb = ha[trf.GRAM_A], ha[trf.GRAM_B]
+    alpha, s = gb / ga, 1.0 / np.sqrt(ga)
+    a.subspace(alpha, s)
+    a.read_header()
+    p0, p1 = -0.3 * np.sqrt(ga), 0.2
+    a.trial(p0, p1)
+    b.trial_gn(p0 * s - p1 * alpha, p1)
+    ora.trial_gn(p0 * s - p1 * alpha, p1)
+    ta, tb, to = a.read_header(), b.read_header(), ora.read_header()
+    if Delta > 0:
+        for k in (trf.COST_NEW, trf.STEP_SQ, trf.X_SQ):
+            assert abs(ta[k] - tb[k]) <= 1e-7 * abs(ta[k])
+            assert abs(to[k] - tb[k]) <= 1e-5 * abs(tb[k])
+    with pytest.raises(RuntimeError):
+        b.schur_auto(Delta, 0.0)  # the prepare header is consumed: calling it twice is a state error
+    for e in (a, b):
+        e.close()
+
+
 # ----------------------------------------------------------------------------- alternative kernel paths
 
 ALT_PATHS = [
@@ -527,9 +591,11 @@ def test_subspace_model_from_normal_equations(gpu, name, lam):
         def subspace_products(self):
             calls.append(1)
 
-    B_S, g_S, nw = trf.subspace_model(Spy(), None, out["sub"], ga, gb, gc, jg_sq, lam)
+    B_S, g_S, coeffs = trf.subspace_model(Spy(), None, ga, gb, gc, jg_sq, lam)
     assert not calls
-    ww = out["sub"][trf.WW]
+    ww = out["sub"][trf.WW]  # |w|^2 of the explicit vector against c - b^2 / a
+    assert abs(ww - (gc - gb * gb / ga)) < 1e-9 * ww
+    nw = np.sqrt(ww)
     hp = out["prod"]
     B_dev = np.array([[hp[trf.B11], hp[trf.B12] / nw], [hp[trf.B12] / nw, hp[trf.B22] / ww]])
     assert np.abs(B_S - B_dev).max() < 1e-6 * np.abs(B_dev).max()
