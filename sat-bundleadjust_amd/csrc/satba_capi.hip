@@ -218,7 +218,7 @@ static int launch_lin3(satba_problem* p, const ObsArgs& a) {
 
 static size_t lin1_lds(const satba_problem* p, bool robust) {
     const int waves = robust ? 8 : 16;
-    return sizeof(double) * ((size_t)p->M * cam_acc_len(p->NP) + (size_t)waves * 9 * 64) + p->camc_bytes;
+    return sizeof(double) * ((size_t)p->M * cam_acc_stride(p->NP) + (size_t)waves * 9 * LIN_STAGE) + p->camc_bytes;
 }
 
 template <int MODEL, int NP, bool CL, bool FULLU>

@@ -21,6 +21,9 @@ namespace satba {
 
 
 __host__ __device__ constexpr int cam_acc_len(int np) { return np * (np + 1) / 2 + np; }
+// row stride of the LDS camera table: odd, so that (stride * cam + k) visits all 32 bank pairs (an even stride such
+// as 20 folds the cameras onto 8 of them: 8-way conflicts of the ds_add_f64)
+__host__ __device__ constexpr int cam_acc_stride(int np) { return cam_acc_len(np) | 1; }
 
 struct ObsArgs {
     const double2* __restrict__ obs;   // K observed (col, row)
@@ -186,6 +189,10 @@ __global__ __launch_bounds__(512) void k_residual(ObsArgs a, double2* __restrict
 //                   ds_add_f64 in an LDS table (measured ~3 lanes/clk/CU, tools/ubench/lds_atomics.hip)
 //   hdr[0] += cost;  hdr[slot] = max |g_p|
 // Camera constants come from an LDS copy of the table (CL); linear loss is specialised at compile time (ROBUST).
+// row stride of the per-wave staging area: 65, so that the nine value rows of one observation sit in nine different
+// bank pairs when the run sums read them (a stride of 64 puts them all in the same one)
+constexpr int LIN_STAGE = 65;
+
 template <bool ROBUST>
 struct LinCfg {
     static constexpr int THREADS = ROBUST ? 512 : 1024;  // the robust variants need > 128 VGPRs
@@ -200,21 +207,21 @@ template <int MODEL, int NP, bool ROBUST, bool CL, bool FULLU>
 __global__ __launch_bounds__(LinCfg<ROBUST>::THREADS) void k_linearize(ObsArgs a, double2* __restrict__ f, double* __restrict__ V,
                                                                       double* __restrict__ gp, double* __restrict__ part,
                                                                       double* __restrict__ hdr_cost, double* __restrict__ hdr_gpmax) {
-    constexpr int CU = cam_acc_len(NP);
+    constexpr int CU = cam_acc_len(NP), CUS = cam_acc_stride(NP);
     constexpr int THREADS = LinCfg<ROBUST>::THREADS, WAVES = LinCfg<ROBUST>::WAVES;
     extern __shared__ double s_lin[];
-    double* s_acc = s_lin;                                          // M * CU
-    double* s_camc = s_acc + (size_t)a.M * CU;                      // M * CAMC
-    double* s_stage = s_camc + (CL ? (size_t)a.M * CAMC : 0);       // WAVES * 9 * 64
+    double* s_acc = s_lin;                                          // M * CUS
+    double* s_camc = s_acc + (size_t)a.M * CUS;                     // M * CAMC
+    double* s_stage = s_camc + (CL ? (size_t)a.M * CAMC : 0);       // WAVES * 9 * LIN_STAGE
     __shared__ unsigned char s_seg[WAVES][66];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int i = threadIdx.x; i < a.M * CU; i += THREADS) s_acc[i] = 0.0;
+    for (int i = threadIdx.x; i < a.M * CUS; i += THREADS) s_acc[i] = 0.0;
     if constexpr (CL)
         for (int i = threadIdx.x; i < a.M * CAMC; i += THREADS) s_camc[i] = a.camc[i];
     __syncthreads();
     const double* cbase;
     if constexpr (CL) cbase = s_camc; else cbase = a.camc;
-    double* stage = s_stage + (size_t)wave * 9 * 64;
+    double* stage = s_stage + (size_t)wave * 9 * LIN_STAGE;
 
     double cost = 0.0, gmax = 0.0;
     for (int tile = blockIdx.x * WAVES + wave; tile < a.n_tiles; tile += gridDim.x * WAVES) {
@@ -230,17 +237,17 @@ __global__ __launch_bounds__(LinCfg<ROBUST>::THREADS) void k_linearize(ObsArgs a
             f[o] = make_double2(e.ftrue[0], e.ftrue[1]);
             cost += e.rho;
             // per-point products into the wave's staging rows (conflict-free 8-byte stores)
-            stage[0 * 64 + lane] = e.Jp[0][0] * e.Jp[0][0] + e.Jp[1][0] * e.Jp[1][0];
-            stage[1 * 64 + lane] = e.Jp[0][0] * e.Jp[0][1] + e.Jp[1][0] * e.Jp[1][1];
-            stage[2 * 64 + lane] = e.Jp[0][0] * e.Jp[0][2] + e.Jp[1][0] * e.Jp[1][2];
-            stage[3 * 64 + lane] = e.Jp[0][1] * e.Jp[0][1] + e.Jp[1][1] * e.Jp[1][1];
-            stage[4 * 64 + lane] = e.Jp[0][1] * e.Jp[0][2] + e.Jp[1][1] * e.Jp[1][2];
-            stage[5 * 64 + lane] = e.Jp[0][2] * e.Jp[0][2] + e.Jp[1][2] * e.Jp[1][2];
-            stage[6 * 64 + lane] = e.Jp[0][0] * e.fs[0] + e.Jp[1][0] * e.fs[1];
-            stage[7 * 64 + lane] = e.Jp[0][1] * e.fs[0] + e.Jp[1][1] * e.fs[1];
-            stage[8 * 64 + lane] = e.Jp[0][2] * e.fs[0] + e.Jp[1][2] * e.fs[1];
+            stage[0 * LIN_STAGE + lane] = e.Jp[0][0] * e.Jp[0][0] + e.Jp[1][0] * e.Jp[1][0];
+            stage[1 * LIN_STAGE + lane] = e.Jp[0][0] * e.Jp[0][1] + e.Jp[1][0] * e.Jp[1][1];
+            stage[2 * LIN_STAGE + lane] = e.Jp[0][0] * e.Jp[0][2] + e.Jp[1][0] * e.Jp[1][2];
+            stage[3 * LIN_STAGE + lane] = e.Jp[0][1] * e.Jp[0][1] + e.Jp[1][1] * e.Jp[1][1];
+            stage[4 * LIN_STAGE + lane] = e.Jp[0][1] * e.Jp[0][2] + e.Jp[1][1] * e.Jp[1][2];
+            stage[5 * LIN_STAGE + lane] = e.Jp[0][2] * e.Jp[0][2] + e.Jp[1][2] * e.Jp[1][2];
+            stage[6 * LIN_STAGE + lane] = e.Jp[0][0] * e.fs[0] + e.Jp[1][0] * e.fs[1];
+            stage[7 * LIN_STAGE + lane] = e.Jp[0][1] * e.fs[0] + e.Jp[1][1] * e.fs[1];
+            stage[8 * LIN_STAGE + lane] = e.Jp[0][2] * e.fs[0] + e.Jp[1][2] * e.fs[1];
             // camera block: LDS atomics (ds_add_f64) into this workgroup's table
-            double* acc = s_acc + (size_t)cam * CU;
+            double* acc = s_acc + (size_t)cam * CUS;
             int k = 0;
 #ifndef SATBA_ABLATE_CAM_ATOMICS
 #pragma unroll
@@ -275,7 +282,7 @@ __global__ __launch_bounds__(LinCfg<ROBUST>::THREADS) void k_linearize(ObsArgs a
             const int q = q0 + lane / 9, v = lane % 9;
             if (lane < 63 && q < n_runs) {
                 const int b = s_seg[wave][q], en = s_seg[wave][q + 1];
-                const double* col = stage + v * 64;
+                const double* col = stage + v * LIN_STAGE;
                 double sum = 0.0;
                 for (int l = b; l < en; ++l) sum += col[l];
                 const int ptq = a.pt[o0 + b];
@@ -300,7 +307,7 @@ __global__ __launch_bounds__(LinCfg<ROBUST>::THREADS) void k_linearize(ObsArgs a
         atomic_max_pos(hdr_gpmax, g);
     }
     double* out = part + (size_t)blockIdx.x * a.M * CU;
-    for (int i = threadIdx.x; i < a.M * CU; i += THREADS) out[i] = s_acc[i];
+    for (int i = threadIdx.x; i < a.M * CU; i += THREADS) out[i] = s_acc[(i / CU) * CUS + i % CU];
 }
 
 // sum the per-workgroup camera partials and expand to the exchange payload: U (M x NP x NP, full), g_c (M x NP).

@@ -22,7 +22,7 @@ enum { AFFINE = 0, PERSPECTIVE = 1, RPC = 2 };
 //   [0..5]   cos a, sin a, cos b, sin b, cos g, sin g
 //   [6..14]  R row-major
 //   [15..]   affine: t0 t1 fx fy skew | perspective: t0 t1 t2 fx fy skew cx cy | rpc: T(3) C(3)
-constexpr int CAMC = 24;
+constexpr int CAMC = 25;  // odd: camera rows start in all 32 LDS bank pairs (24 folds them onto 4: 16-way conflicts of every gather)
 
 constexpr double WGS84_A = 6378137.0;
 constexpr double WGS84_E = 8.1819190842622e-2;  // as hard-coded at ref:bundle_adjust/geo_utils.py:241
