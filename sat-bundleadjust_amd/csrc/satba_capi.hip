@@ -330,10 +330,14 @@ static int launch_backsub_kernel(satba_problem* p) {
     return 0;
 }
 
-static int launch_jvp(satba_problem* p, int nv, const double* q1, const double* q2, double* out) {
+// pre: q1 is already in unscaled variables (nv == 1 only)
+static int launch_jvp(satba_problem* p, int nv, const double* q1, const double* q2, double* out, bool pre = false) {
     ObsArgs a = obs_args(p, false);
     const int grid = grid_for(p->K, 512, 512);
-    if (nv == 1) {
+    if (nv == 1 && pre) {
+        SATBA_DISPATCH(p, hipLaunchKernelGGL((k_jvp<MODEL, NP, 1, CL, true>), dim3(grid), dim3(512), p->camc_bytes + sizeof(double) * p->n_c,
+                                              p->stream, a, q1, q2, p->d_scale_inv, out));
+    } else if (nv == 1) {
         SATBA_DISPATCH(p, hipLaunchKernelGGL((k_jvp<MODEL, NP, 1, CL>), dim3(grid), dim3(512), p->camc_bytes, p->stream, a, q1, q2,
                                               p->d_scale_inv, out));
     } else {
@@ -791,9 +795,9 @@ int satba_prepare(satba_problem* p, int32_t first) {
     HIP_TRY(hipGetLastError());
     TRY(zero_header(p));
     hipLaunchKernelGGL(k_prepare_vec, dim3(grid_for(p->n, 256, 512)), dim3(256), 0, p->stream, p->n, p->n_c, p->NP, first,
-                       p->lead, p->d_U, p->d_gc, p->d_V, p->d_x, p->d_g, p->d_scale_inv, p->d_gh, p->d_xb);
+                       p->lead, p->d_U, p->d_gc, p->d_V, p->d_x, p->d_g, p->d_scale_inv, p->d_gh, p->d_q1, p->d_xb);
     HIP_TRY(hipGetLastError());
-    TRY(launch_jvp(p, 1, p->d_gh, p->d_gh, p->d_xb + 2));
+    TRY(launch_jvp(p, 1, p->d_q1, p->d_q1, p->d_xb + 2, true));  // d_q1 is free until the subspace phase
     p->prepared = true;
     return 0;
 }
@@ -1044,7 +1048,7 @@ int satba_time_kernel(satba_problem* p, int32_t phase, int32_t reps, float* ms_a
                 return dense_solve(p, p->payload(), p->d_dch);
             }
             case 4: return launch_backsub_kernel(p);
-            default: return launch_jvp(p, 2, p->d_gh, p->d_gn, p->d_scal);
+            default: return launch_jvp(p, 1, p->d_q1, p->d_q1, p->d_scal, true);  // the pass of the prepare phase
         }
     };
     rc = once();  // warm-up

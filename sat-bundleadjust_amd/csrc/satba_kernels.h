@@ -358,7 +358,8 @@ __global__ __launch_bounds__(256) void k_prepare_vec(int n, int n_c, int NP, int
                                                      const double* __restrict__ U, const double* __restrict__ gc_red,
                                                      const double* __restrict__ V, const double* __restrict__ x,
                                                      double* __restrict__ g, double* __restrict__ scale_inv,
-                                                     double* __restrict__ gh, double* __restrict__ hdr) {
+                                                     double* __restrict__ gh, double* __restrict__ ghs, double* __restrict__ hdr) {
+    // ghs = g_h / scale_inv: the unscaled direction of g_h, input of the Jacobian-vector product that follows
     double s_gh = 0.0, s_xs = 0.0, m_gc = 0.0;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         double diag, gi, wgt;
@@ -381,6 +382,7 @@ __global__ __launch_bounds__(256) void k_prepare_vec(int n, int n_c, int NP, int
         scale_inv[i] = si;
         const double h = gi / si;
         gh[i] = h;
+        ghs[i] = h / si;
         s_gh += wgt * h * h;
         const double xs = x[i] * si;
         s_xs += wgt * xs * xs;
@@ -395,11 +397,18 @@ __global__ __launch_bounds__(256) void k_prepare_vec(int n, int n_c, int NP, int
 // ------------------------------------------------------------------------------------------------ Jacobian-vector products
 // For NV vectors given in scaled variables (v = q / scale_inv): sums of (J v_a) . (J v_b) over the observations.
 // NV = 1: out[0] += |J v1|^2.   NV = 2: out[0] += |J v1|^2, out[1] += (J v1).(J v2), out[2] += |J v2|^2.
-template <int MODEL, int NP, int NV, bool CL>
+template <int MODEL, int NP, int NV, bool CL, bool PRE = false>
 __global__ __launch_bounds__(512) void k_jvp(ObsArgs a, const double* __restrict__ q1, const double* __restrict__ q2,
                                              const double* __restrict__ scale_inv, double* __restrict__ out) {
     extern __shared__ double s_camc_jvp[];
     const double* cbase = cam_table<CL>(a, s_camc_jvp, 512);
+    // PRE (NV = 1): q1 is already divided by scale_inv (k_prepare_vec); its camera part is staged in LDS behind the
+    // camera constants -- no divisions and no global gathers per observation
+    double* s_v = s_camc_jvp + (CL ? (size_t)a.M * CAMC : 0);
+    if constexpr (PRE) {
+        for (int i = threadIdx.x; i < a.n_c; i += 512) s_v[i] = q1[i];
+        __syncthreads();
+    }
     double s11 = 0.0, s12 = 0.0, s22 = 0.0;
     for (long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x; o < a.K; o += (long long)gridDim.x * blockDim.x) {
         const int cam = a.cam[o], pt = a.pt[o];
@@ -409,17 +418,25 @@ __global__ __launch_bounds__(512) void k_jvp(ObsArgs a, const double* __restrict
         double j1[2] = {0, 0}, j2[2] = {0, 0};
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
-            const double si = 1.0 / scale_inv[ic + i];
-            const double v1 = q1[ic + i] * si;
+            double v1;
+            if constexpr (PRE) v1 = s_v[cam * NP + i];
+            else {
+                const double si = 1.0 / scale_inv[ic + i];
+                v1 = q1[ic + i] * si;
+                if (NV == 2) { const double v2 = q2[ic + i] * si; j2[0] += e.Jc[0][i] * v2; j2[1] += e.Jc[1][i] * v2; }
+            }
             j1[0] += e.Jc[0][i] * v1; j1[1] += e.Jc[1][i] * v1;
-            if (NV == 2) { const double v2 = q2[ic + i] * si; j2[0] += e.Jc[0][i] * v2; j2[1] += e.Jc[1][i] * v2; }
         }
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-            const double si = 1.0 / scale_inv[ip + j];
-            const double v1 = q1[ip + j] * si;
+            double v1;
+            if constexpr (PRE) v1 = q1[ip + j];
+            else {
+                const double si = 1.0 / scale_inv[ip + j];
+                v1 = q1[ip + j] * si;
+                if (NV == 2) { const double v2 = q2[ip + j] * si; j2[0] += e.Jp[0][j] * v2; j2[1] += e.Jp[1][j] * v2; }
+            }
             j1[0] += e.Jp[0][j] * v1; j1[1] += e.Jp[1][j] * v1;
-            if (NV == 2) { const double v2 = q2[ip + j] * si; j2[0] += e.Jp[0][j] * v2; j2[1] += e.Jp[1][j] * v2; }
         }
         s11 += j1[0] * j1[0] + j1[1] * j1[1];
         if (NV == 2) {
@@ -795,7 +812,7 @@ __global__ __launch_bounds__(256) void k_backsub(ObsArgs a, const double* __rest
             double u0 = 0.0, u1 = 0.0;
 #pragma unroll
             for (int i = 0; i < NP; ++i) {
-                const double d = dc[cam * NP + i];
+                const double d = dc[cam * NP + i];  // global gather (L1 hits); an LDS copy of dc measured slower twice
                 u0 += e.Jc[0][i] * d;
                 u1 += e.Jc[1][i] * d;
             }
