@@ -80,6 +80,8 @@ struct satba_problem {
     double* d_part3 = nullptr;
     // Schur v3 (camera-pair intersection): sch3_chunks == 0: not used
     int sch3_chunks = 0, NW = 0;
+    int sch3_groups = 0;    // > 0: lane-group list kernel, number of pair groups
+    int* d_groups = nullptr;
     unsigned long long* d_bits = nullptr;
     int* d_rank = nullptr;
     double* d_PV = nullptr;    // packed per-point records (N x 12)
@@ -261,23 +263,35 @@ static int launch_schur3(satba_problem* p, const ObsArgs& a, double* S, double* 
     s.bits = p->d_bits; s.rank = p->d_rank; s.Vinv = p->d_Vinv; s.gp = p->d_g + p->n_c; s.NW = p->NW; s.n_chunks = p->sch3_chunks;
     s.PV = reinterpret_cast<const double2*>(p->d_PV);
     s.pair_ofs = p->d_pair_ofs; s.pair_pts = p->d_pair_pts; s.pair_part = p->d_pair_part;
-    const long long items = (long long)p->M * (p->M - 1) / 2 * p->sch3_chunks;
+    const long long n_pairs = (long long)p->M * (p->M - 1) / 2;
+    const long long items = n_pairs * p->sch3_chunks;
     const int diag_chunks = p->lin3_chunks;
+    const bool grp = p->sch3_groups > 0;
+    const unsigned ggrid = grp ? (unsigned)((p->sch3_groups + S3_GW - 1) / S3_GW) : 0;
+    const unsigned igrid = (unsigned)((items + 3) / 4);
     if (p->loss == 0 && p->unit_weights) {
-        if (items > 0) hipLaunchKernelGGL((k_schur_pairs<MODEL, NP, false, true>), dim3((unsigned)((items + 3) / 4)), dim3(256), 0, p->stream, a, cm, s, S);
+        if (items > 0 && grp) {
+            if constexpr (MODEL == AFFINE)
+                hipLaunchKernelGGL((k_schur_pairs_groups_occ3<MODEL, NP, false, true>), dim3(ggrid), dim3(64 * S3_GW), 0, p->stream, a, cm, s, p->d_groups, p->sch3_groups, S);
+            else
+                hipLaunchKernelGGL((k_schur_pairs_groups<MODEL, NP, false, true>), dim3(ggrid), dim3(64 * S3_GW), 0, p->stream, a, cm, s, p->d_groups, p->sch3_groups, S);
+        }
+        else if (items > 0) hipLaunchKernelGGL((k_schur_pairs<MODEL, NP, false, true>), dim3(igrid), dim3(256), 0, p->stream, a, cm, s, S);
         hipLaunchKernelGGL((k_schur_diag<MODEL, NP, false, ADDU>), dim3(diag_chunks, p->M), dim3(LINC_THREADS), 0, p->stream, a, cm, s, p->d_part3);
     } else if (p->loss == 0) {
-        if (items > 0) hipLaunchKernelGGL((k_schur_pairs<MODEL, NP, false, false>), dim3((unsigned)((items + 3) / 4)), dim3(256), 0, p->stream, a, cm, s, S);
+        if (items > 0 && grp) hipLaunchKernelGGL((k_schur_pairs_groups<MODEL, NP, false, false>), dim3(ggrid), dim3(64 * S3_GW), 0, p->stream, a, cm, s, p->d_groups, p->sch3_groups, S);
+        else if (items > 0) hipLaunchKernelGGL((k_schur_pairs<MODEL, NP, false, false>), dim3(igrid), dim3(256), 0, p->stream, a, cm, s, S);
         hipLaunchKernelGGL((k_schur_diag<MODEL, NP, false, ADDU>), dim3(diag_chunks, p->M), dim3(LINC_THREADS), 0, p->stream, a, cm, s, p->d_part3);
     } else {
-        if (items > 0) hipLaunchKernelGGL((k_schur_pairs<MODEL, NP, true, false>), dim3((unsigned)((items + 3) / 4)), dim3(256), 0, p->stream, a, cm, s, S);
+        if (items > 0 && grp) hipLaunchKernelGGL((k_schur_pairs_groups<MODEL, NP, true, false>), dim3(ggrid), dim3(64 * S3_GW), 0, p->stream, a, cm, s, p->d_groups, p->sch3_groups, S);
+        else if (items > 0) hipLaunchKernelGGL((k_schur_pairs<MODEL, NP, true, false>), dim3(igrid), dim3(256), 0, p->stream, a, cm, s, S);
         hipLaunchKernelGGL((k_schur_diag<MODEL, NP, true, ADDU>), dim3(diag_chunks, p->M), dim3(LINC_THREADS), 0, p->stream, a, cm, s, p->d_part3);
     }
     HIP_TRY(hipGetLastError());
-    if (items > 0 && p->d_pair_ofs && p->sch3_chunks > 1) {
-        const long long outs = (long long)p->M * (p->M - 1) / 2 * p->NP * p->NP;
+    if (items > 0 && p->d_pair_ofs && p->sch3_chunks > 1 && !grp) {
+        const long long outs = n_pairs * p->NP * p->NP;
         hipLaunchKernelGGL(k_schur_pairs_reduce, dim3((unsigned)((outs + 255) / 256)), dim3(256), 0, p->stream, p->M, p->NP, p->n_c,
-                           p->sch3_chunks, p->d_pair_part, S);
+                           p->sch3_chunks, p->d_pair_part, p->d_pair_ofs, 0, S);
         HIP_TRY(hipGetLastError());
     }
     const int total = p->M * cam_acc_len(p->NP);
@@ -605,9 +619,16 @@ int satba_problem_create(const satba_problem_desc* d, satba_problem** out) {
                     // the fixed cost per (pair, chunk) work item; fewer chunks when the lists are short
                     long long n_hits = 0;
                     for (int q = 0; q < p->N; ++q) { const long long dq = pt_ofs[q + 1] - pt_ofs[q]; n_hits += dq * (dq - 1) / 2; }
-                    int C = (int)std::max<long long>(1, ((long long)p->N * 96 + (12 << 20) - 1) / (12 << 20));
-                    C = (int)std::max<long long>(1, std::min<long long>(C, n_hits / n_pairs / 256));
+                    // one wave per (pair, chunk) item (default): 12 MB windows and >= 256 hits per item are the
+                    // measured optimum between gather locality and the fixed cost per item.  Lane-group kernel
+                    // (SATBA_SCHUR_STREAM=1, experiment): 3 MB windows stay in the 4 MB L2 of every XCD
+                    const char* st = getenv("SATBA_SCHUR_STREAM");
+                    const bool stream = st && atoi(st) == 1;
+                    const long long win = stream ? (3ll << 20) : (12ll << 20);
+                    int C = (int)std::max<long long>(1, ((long long)p->N * 96 + win - 1) / win);
+                    C = (int)std::max<long long>(1, std::min<long long>(C, n_hits / n_pairs / (stream ? 32 : 256)));
                     if (const char* cs = getenv("SATBA_SCHUR_CHUNKS")) C = std::max(1, atoi(cs));
+                    if (stream) C = std::min(C, S3_MAXC);
                     while (C > 1 && n_pairs * (long long)(C + 1) > (1ll << 27)) --C;
                     const long long M_ = p->M;
                     auto pair_index = [M_](long long a, long long b) { return a * M_ - a * (a + 1) / 2 + (b - a - 1); };
@@ -638,7 +659,16 @@ int satba_problem_create(const satba_problem_desc* d, satba_problem** out) {
                         HIP_TRY(hipMemcpy(p->d_pair_ofs, ofs.data(), sizeof(long long) * ofs.size(), hipMemcpyHostToDevice));
                         HIP_TRY(hipMemcpy(p->d_pair_pts, pts.data(), sizeof(int) * pts.size(), hipMemcpyHostToDevice));
                         p->sch3_chunks = C;
-                        if (C > 1) TRY(dev_alloc(p, &p->d_pair_part, (size_t)C * n_pairs * p->NP * p->NP));
+                        if (stream) {  // groups of up to 8 pairs (i, j0 ..) of one camera i
+                            std::vector<int> groups;
+                            for (int ci = 0; ci + 1 < p->M; ++ci)
+                                for (int cj = ci + 1; cj < p->M; cj += 8) {
+                                    groups.push_back(ci); groups.push_back(cj); groups.push_back(std::min(8, p->M - cj));
+                                }
+                            p->sch3_groups = (int)(groups.size() / 3);
+                            TRY(dev_alloc(p, &p->d_groups, groups.size()));
+                            HIP_TRY(hipMemcpy(p->d_groups, groups.data(), sizeof(int) * groups.size(), hipMemcpyHostToDevice));
+                        } else if (C > 1) TRY(dev_alloc(p, &p->d_pair_part, (size_t)C * n_pairs * p->NP * p->NP));
                     }
                 }
             }

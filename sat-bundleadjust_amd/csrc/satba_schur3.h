@@ -248,8 +248,147 @@ __global__ __launch_bounds__(256) void k_schur_pairs(ObsArgs a, CamMajor c, Schu
     }
 }
 
+// ---- list path, lane-group form (experiment, SATBA_SCHUR_STREAM=1).  A wave owns up to 8 camera pairs
+// (i, j0 .. j0+7) of ONE camera i and gives each pair 8 of its lanes for the whole launch: lane (g, r) walks hits
+// r, r+8, ... of pair g.  Every wave of the grid is resident and all of them go through the point-range chunks in the
+// same order and at the same pace, so the waves running at any time gather point records from one L2-sized window
+// (PMC: L2 misses 37 M -> 10 M per launch with 3 MB windows), and because a lane never changes its pair, its 25
+// accumulators survive from chunk to chunk: one 8-lane reduction per pair at the very end, no per-(pair, chunk)
+// work items, no partial blocks, no reduce kernel.  Measured at 200 x 1M x 10M: 1.02 ms against 0.71 ms for the
+// one-wave-per-item kernel above -- the memory side is solved, but the 8-lane lists leave 10-15 % of the lanes idle
+// at every chunk end, the j constants come from LDS instead of SGPRs, and 2590 long-running waves do not pack the
+// 2048 / 3072 wave slots (1.26 rounds at two waves per SIMD; at three the kernel got slower, not faster).  Kept
+// as the starting point for the next attempt.
+// grid: one wave per group; groups[g] = {i, j0, count}; S3_GW waves per workgroup.
+constexpr int S3_MAXC = 64;  // chunks (upper bound)
+constexpr int S3_GW = 4;     // waves per workgroup
+
+template <int MODEL, int NP, bool ROBUST, bool UNITW>
+__device__ __forceinline__ void schur_pairs_groups_body(const ObsArgs& a, const CamMajor& c, const Schur3Args& s, const int* __restrict__ groups,
+                                                         int n_groups, double* __restrict__ S) {
+    __shared__ long long s_ofs[S3_GW][8][S3_MAXC + 1];
+    __shared__ double s_cj[S3_GW][8][CAMC];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int gidx = blockIdx.x * S3_GW + __builtin_amdgcn_readfirstlane(wave);
+    if (gidx >= n_groups) return;
+    const int i = groups[3 * gidx], j0 = groups[3 * gidx + 1], cnt = groups[3 * gidx + 2];  // wave-uniform (scalar loads)
+    const int C = s.n_chunks, C1 = C + 1;
+    const long long pair0 = (long long)i * a.M - (long long)i * (i + 1) / 2 + (j0 - i - 1);
+    for (int k = lane; k < cnt * C1; k += 64) s_ofs[wave][k / C1][k % C1] = s.pair_ofs[pair0 * C1 + k];
+    for (int k = lane; k < cnt * CAMC; k += 64) s_cj[wave][k / CAMC][k % CAMC] = a.camc[(size_t)(j0 + k / CAMC) * CAMC + k % CAMC];
+    __builtin_amdgcn_wave_barrier();  // single wave: its LDS operations execute in order
+    const int g = lane >> 3, r8 = lane & 7;
+    const bool member = g < cnt;
+    const int gq = member ? g : 0;
+    const int j = j0 + gq;
+    const double* cci = a.camc + (size_t)i * CAMC;
+    const double* ccj = &s_cj[wave][gq][0];
+    const double* tabi = (MODEL == RPC) ? a.rpc + (size_t)i * 90 : nullptr;
+    const double* tabj = (MODEL == RPC) ? a.rpc + (size_t)j * 90 : nullptr;
+    const unsigned long long* bi = s.bits + (size_t)i * s.NW;
+    const unsigned long long* bj = s.bits + (size_t)j * s.NW;
+    const int* ri = s.rank + (size_t)i * s.NW;
+    const int* rj = s.rank + (size_t)j * s.NW;
+    int base_i = 0, base_j = 0;
+    if constexpr (!UNITW) { base_i = c.cam_ofs[i]; base_j = c.cam_ofs[j]; }
+
+    double acc[NP][NP];
+#pragma unroll
+    for (int r = 0; r < NP; ++r)
+#pragma unroll
+        for (int q = 0; q < NP; ++q) acc[r][q] = 0.0;
+
+    struct Rec { double2 r0, r1, r2, r3, r4; };  // packed point record: X0 X1 | X2 v00 | v01 v02 | v11 v12 | v22 g0
+    auto load_rec = [&](int p) {
+        const double2* pv = s.PV + 6 * (size_t)p;
+        Rec r;
+        r.r0 = pv[0]; r.r1 = pv[1]; r.r2 = pv[2]; r.r3 = pv[3]; r.r4 = pv[4];
+        return r;
+    };
+    auto compute = [&](int p, const Rec& rc) {
+        int pi = 0, pj = 0;
+        if constexpr (!UNITW) {
+            const int w = p >> 6;
+            const unsigned long long below = (1ull << (p & 63)) - 1ull;
+            pi = base_i + ri[w] + __popcll(bi[w] & below);
+            pj = base_j + rj[w] + __popcll(bj[w] & below);
+        }
+        const double X = rc.r0.x, Y = rc.r0.y, Z = rc.r1.x;
+        const double v00 = rc.r1.y, v01 = rc.r2.x, v02 = rc.r2.y, v11 = rc.r3.x, v12 = rc.r3.y, v22 = rc.r4.x;
+        double Jci[2][NP], Jpi[2][3], Jcj[2][NP], Jpj[2][3];
+        cm_jacobian<MODEL, NP, ROBUST, UNITW>(a, c, cci, tabi, i, pi, p, X, Y, Z, Jci, Jpi);
+        cm_jacobian<MODEL, NP, ROBUST, UNITW>(a, c, ccj, tabj, j, pj, p, X, Y, Z, Jcj, Jpj);
+        double A[2][3];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            A[r][0] = Jpi[r][0] * v00 + Jpi[r][1] * v01 + Jpi[r][2] * v02;
+            A[r][1] = Jpi[r][0] * v01 + Jpi[r][1] * v11 + Jpi[r][2] * v12;
+            A[r][2] = Jpi[r][0] * v02 + Jpi[r][1] * v12 + Jpi[r][2] * v22;
+        }
+        const double m00 = A[0][0] * Jpj[0][0] + A[0][1] * Jpj[0][1] + A[0][2] * Jpj[0][2];
+        const double m01 = A[0][0] * Jpj[1][0] + A[0][1] * Jpj[1][1] + A[0][2] * Jpj[1][2];
+        const double m10 = A[1][0] * Jpj[0][0] + A[1][1] * Jpj[0][1] + A[1][2] * Jpj[0][2];
+        const double m11 = A[1][0] * Jpj[1][0] + A[1][1] * Jpj[1][1] + A[1][2] * Jpj[1][2];
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            const double y0 = m00 * Jcj[0][q] + m01 * Jcj[1][q];
+            const double y1 = m10 * Jcj[0][q] + m11 * Jcj[1][q];
+#pragma unroll
+            for (int r = 0; r < NP; ++r) acc[r][q] = fma(-Jci[0][r], y0, fma(-Jci[1][r], y1, acc[r][q]));
+        }
+    };
+
+    for (int ch = 0; ch < C; ++ch) {
+        // this lane's hits of the chunk: pos, pos + 8, ... < hi; indices two steps ahead, records one step ahead
+        long long pos = s_ofs[wave][gq][ch] + r8;
+        const long long hi = member ? s_ofs[wave][gq][ch + 1] : 0;
+        int p_cur = (pos < hi) ? s.pair_pts[pos] : 0;
+        int p_nxt = (pos + 8 < hi) ? s.pair_pts[pos + 8] : 0;
+        Rec r_cur = load_rec(p_cur);
+        while (__any(pos < hi)) {
+            const int p_nn = (pos + 16 < hi) ? s.pair_pts[pos + 16] : 0;
+            const Rec r_nxt = load_rec(p_nxt);
+            // keep the gathers above the arithmetic: without the barrier the scheduler sinks them below compute()
+            // to save registers and every step pays the full memory latency
+            __builtin_amdgcn_sched_barrier(0);
+            {   // lanes past the end of their list evaluate point 0 with Vinv = 0: a zero contribution without a
+                // divergent branch around the accumulators (the branch costs 50 register copies per step)
+                Rec rc = r_cur;
+                if (!(pos < hi)) { rc.r1.y = 0.0; rc.r2 = make_double2(0.0, 0.0); rc.r3 = make_double2(0.0, 0.0); rc.r4.x = 0.0; }
+                compute(p_cur, rc);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            p_cur = p_nxt; p_nxt = p_nn; r_cur = r_nxt;
+            pos += 8;
+        }
+    }
+    // 8-lane reduction per pair; block (row j, col i) of the column-major lower triangle
+#pragma unroll
+    for (int r = 0; r < NP; ++r)
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            double t = acc[r][q];
+            t += __shfl_xor(t, 1); t += __shfl_xor(t, 2); t += __shfl_xor(t, 4);
+            if (member && r8 == 0) S[(size_t)(j * NP + q) + (size_t)(i * NP + r) * a.n_c] = t;  // S[(j,q), (i,r)] = (W_i Vinv W_j^T)[r][q]
+        }
+}
+
+template <int MODEL, int NP, bool ROBUST, bool UNITW>
+__global__ __launch_bounds__(64 * S3_GW) void k_schur_pairs_groups(ObsArgs a, CamMajor c, Schur3Args s, const int* __restrict__ groups,
+                                                                   int n_groups, double* __restrict__ S) {
+    schur_pairs_groups_body<MODEL, NP, ROBUST, UNITW>(a, c, s, groups, n_groups, S);
+}
+// the same held to three waves per SIMD (<= 168 VGPRs; the affine unit-weight body needs 170): all M(M-1)/16 waves of
+// the headline shape are then resident at once -- one round instead of 1.26
+template <int MODEL, int NP, bool ROBUST, bool UNITW>
+__global__ __launch_bounds__(64 * S3_GW) __attribute__((amdgpu_waves_per_eu(3, 8))) void k_schur_pairs_groups_occ3(
+    ObsArgs a, CamMajor c, Schur3Args s, const int* __restrict__ groups, int n_groups, double* __restrict__ S) {
+    schur_pairs_groups_body<MODEL, NP, ROBUST, UNITW>(a, c, s, groups, n_groups, S);
+}
+
 // list path with several point-range chunks: S block of each pair = sum of its chunk partials
 __global__ __launch_bounds__(256) void k_schur_pairs_reduce(int M, int NP, int n_c, int n_chunks, const double* __restrict__ part,
+                                                            const long long* __restrict__ pair_ofs, int skip_empty,
                                                             double* __restrict__ S) {
     const long long n_pairs = (long long)M * (M - 1) / 2;
     const int NB2 = NP * NP;
@@ -257,8 +396,10 @@ __global__ __launch_bounds__(256) void k_schur_pairs_reduce(int M, int NP, int n
     if (idx >= n_pairs * NB2) return;
     const long long pair = idx / NB2;
     const int e = (int)(idx % NB2);
+    const long long* po = pair_ofs + pair * (n_chunks + 1);
     double t = 0.0;
-    for (int ch = 0; ch < n_chunks; ++ch) t += part[((size_t)ch * n_pairs + pair) * NB2 + e];
+    for (int ch = 0; ch < n_chunks; ++ch)  // the streaming kernel writes nothing for an item without shared points
+        if (!skip_empty || po[ch + 1] > po[ch]) t += part[((size_t)ch * n_pairs + pair) * NB2 + e];
     int i = (int)((2.0 * M - 1.0 - sqrt((2.0 * M - 1.0) * (2.0 * M - 1.0) - 8.0 * (double)pair)) * 0.5);
     while ((long long)i * M - (long long)i * (i + 1) / 2 > pair) --i;
     while ((long long)(i + 1) * M - (long long)(i + 1) * (i + 2) / 2 <= pair) ++i;

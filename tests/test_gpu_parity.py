@@ -540,6 +540,7 @@ ALT_PATHS = [
     {"SATBA_CHOL": "1"},             # two-launch-per-panel Cholesky (k_potrf_trsm + k_syrk)
     {"SATBA_SCHUR_CHUNKS": "3"},     # Schur v3 pair lists cut into point-range chunks + partial reduce
     {"SATBA_SCHUR_CHUNKS": "1"},     # ... and as one chunk (direct store)
+    {"SATBA_SCHUR_STREAM": "1", "SATBA_SCHUR_CHUNKS": "3"},  # lane-group Schur kernel (experiment)
 ]
 
 
