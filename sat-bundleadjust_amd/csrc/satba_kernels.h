@@ -280,12 +280,22 @@ __global__ __launch_bounds__(LinCfg<ROBUST>::THREADS) void k_linearize(ObsArgs a
         if (lane == 0) s_seg[wave][n_runs] = (unsigned char)(o1 - o0);
         for (int q0 = 0; q0 < n_runs; q0 += 7) {
             const int q = q0 + lane / 9, v = lane % 9;
-            if (lane < 63 && q < n_runs) {
-                const int b = s_seg[wave][q], en = s_seg[wave][q + 1];
+            const bool owner = lane < 63 && q < n_runs;
+            const int b = owner ? s_seg[wave][q] : 0, en = owner ? s_seg[wave][q + 1] : 0;
+            const int ptq = __shfl(pt, b);  // the run's point index sits in the register of the run's first lane
+            if (owner) {
                 const double* col = stage + v * LIN_STAGE;
-                double sum = 0.0;
-                for (int l = b; l < en; ++l) sum += col[l];
-                const int ptq = a.pt[o0 + b];
+                // four independent partial sums: the reads of a run are in flight together instead of one LDS
+                // latency per element
+                double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+                for (int l = b; l < en; l += 4) {
+                    const double a0 = col[l];
+                    const double a1 = (l + 1 < en) ? col[l + 1] : 0.0;
+                    const double a2 = (l + 2 < en) ? col[l + 2] : 0.0;
+                    const double a3 = (l + 3 < en) ? col[l + 3] : 0.0;
+                    s0 += a0; s1 += a1; s2 += a2; s3 += a3;
+                }
+                const double sum = (s0 + s1) + (s2 + s3);
                 double* dst = (v < 6) ? V + 6 * (size_t)ptq + v : gp + 3 * (size_t)ptq + (v - 6);
                 if (a.tile_split[tile]) atomicAdd(dst, sum);
                 else *dst = sum;
