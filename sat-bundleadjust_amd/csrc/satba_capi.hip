@@ -81,6 +81,13 @@ struct satba_problem {
     // Schur v3 (camera-pair intersection): sch3_chunks == 0: not used
     int sch3_chunks = 0, NW = 0;
     int sch3_groups = 0;    // > 0: lane-group list kernel, number of pair groups
+    int sch3_group_pairs = 8;
+    int sch3_chunk_mul = 1;   // fine chunks per coarse chunk of the pair lists
+    int sch3_groups_m = 0;      // groups of the moments kernel
+    bool sch3_moments = false;  // affine + unit weights: pair blocks through point moments (linear loss only)
+    double* d_Tbuf = nullptr;
+    double c0[3] = {0, 0, 0};   // expansion point of the moments
+    bool c0_set = false;
     int* d_groups = nullptr;
     unsigned long long* d_bits = nullptr;
     int* d_rank = nullptr;
@@ -262,16 +269,30 @@ static int launch_schur3(satba_problem* p, const ObsArgs& a, double* S, double* 
     Schur3Args s;
     s.bits = p->d_bits; s.rank = p->d_rank; s.Vinv = p->d_Vinv; s.gp = p->d_g + p->n_c; s.NW = p->NW; s.n_chunks = p->sch3_chunks;
     s.PV = reinterpret_cast<const double2*>(p->d_PV);
-    s.pair_ofs = p->d_pair_ofs; s.pair_pts = p->d_pair_pts; s.pair_part = p->d_pair_part;
+    s.pair_ofs = p->d_pair_ofs; s.pair_pts = p->d_pair_pts; s.pair_part = p->d_pair_part; s.chunk_mul = p->sch3_chunk_mul;
     const long long n_pairs = (long long)p->M * (p->M - 1) / 2;
     const long long items = n_pairs * p->sch3_chunks;
     const int diag_chunks = p->lin3_chunks;
     const bool grp = p->sch3_groups > 0;
     const unsigned ggrid = grp ? (unsigned)((p->sch3_groups + S3_GW - 1) / S3_GW) : 0;
     const unsigned igrid = (unsigned)((items + 3) / 4);
-    if (p->loss == 0 && p->unit_weights) {
+    const bool moments = p->sch3_moments && p->loss == 0 && items > 0;
+    if constexpr (MODEL == AFFINE) {
+        if (moments) {
+            hipLaunchKernelGGL((k_schur_pairs_moments<6>), dim3((unsigned)((p->sch3_groups_m + S3_GW - 1) / S3_GW)), dim3(64 * S3_GW), 0, p->stream,
+                               p->M, p->n_pts_fix, s, p->d_groups, p->sch3_groups_m, p->c0[0], p->c0[1], p->c0[2], p->d_Tbuf);
+            const long long outs = n_pairs * NP * NP;
+            hipLaunchKernelGGL((k_schur_contract<NP>), dim3((unsigned)((outs + 255) / 256)), dim3(256), 0, p->stream, a, p->d_Tbuf,
+                               p->c0[0], p->c0[1], p->c0[2], S);
+            hipLaunchKernelGGL((k_schur_diag<MODEL, NP, false, ADDU>), dim3(diag_chunks, p->M), dim3(LINC_THREADS), 0, p->stream, a, cm, s, p->d_part3);
+        }
+    }
+    if (MODEL == AFFINE && moments) {
+    } else if (p->loss == 0 && p->unit_weights) {
         if (items > 0 && grp) {
-            if constexpr (MODEL == AFFINE)
+            if (p->sch3_group_pairs == 10)
+                hipLaunchKernelGGL((k_schur_pairs_groups6<MODEL, NP, false, true>), dim3(ggrid), dim3(64 * S3_GW), 0, p->stream, a, cm, s, p->d_groups, p->sch3_groups, S);
+            else if constexpr (MODEL == AFFINE)
                 hipLaunchKernelGGL((k_schur_pairs_groups_occ3<MODEL, NP, false, true>), dim3(ggrid), dim3(64 * S3_GW), 0, p->stream, a, cm, s, p->d_groups, p->sch3_groups, S);
             else
                 hipLaunchKernelGGL((k_schur_pairs_groups<MODEL, NP, false, true>), dim3(ggrid), dim3(64 * S3_GW), 0, p->stream, a, cm, s, p->d_groups, p->sch3_groups, S);
@@ -288,10 +309,10 @@ static int launch_schur3(satba_problem* p, const ObsArgs& a, double* S, double* 
         hipLaunchKernelGGL((k_schur_diag<MODEL, NP, true, ADDU>), dim3(diag_chunks, p->M), dim3(LINC_THREADS), 0, p->stream, a, cm, s, p->d_part3);
     }
     HIP_TRY(hipGetLastError());
-    if (items > 0 && p->d_pair_ofs && p->sch3_chunks > 1 && !grp) {
+    if (items > 0 && p->d_pair_ofs && p->sch3_chunks > 1 && !grp && !(MODEL == AFFINE && moments)) {
         const long long outs = n_pairs * p->NP * p->NP;
         hipLaunchKernelGGL(k_schur_pairs_reduce, dim3((unsigned)((outs + 255) / 256)), dim3(256), 0, p->stream, p->M, p->NP, p->n_c,
-                           p->sch3_chunks, p->d_pair_part, p->d_pair_ofs, 0, S);
+                           p->sch3_chunks, p->d_pair_part, S);
         HIP_TRY(hipGetLastError());
     }
     const int total = p->M * cam_acc_len(p->NP);
@@ -619,17 +640,29 @@ int satba_problem_create(const satba_problem_desc* d, satba_problem** out) {
                     // the fixed cost per (pair, chunk) work item; fewer chunks when the lists are short
                     long long n_hits = 0;
                     for (int q = 0; q < p->N; ++q) { const long long dq = pt_ofs[q + 1] - pt_ofs[q]; n_hits += dq * (dq - 1) / 2; }
-                    // one wave per (pair, chunk) item (default): 12 MB windows and >= 256 hits per item are the
-                    // measured optimum between gather locality and the fixed cost per item.  Lane-group kernel
-                    // (SATBA_SCHUR_STREAM=1, experiment): 3 MB windows stay in the 4 MB L2 of every XCD
+                    // Coarse chunks (one wave per (pair, chunk) item kernel): 12 MB windows and >= 256 hits per item are
+                    // the measured optimum between gather locality and the fixed cost per item.  Fine chunks (lane-group
+                    // kernels, which walk all chunks inside one wave): 3 MB windows stay in the 4 MB L2 of every XCD.
+                    // The lists are cut into the fine chunks; the item kernel takes them chunk_mul at a time.
                     const char* st = getenv("SATBA_SCHUR_STREAM");
                     const bool stream = st && atoi(st) == 1;
-                    const long long win = stream ? (3ll << 20) : (12ll << 20);
-                    int C = (int)std::max<long long>(1, ((long long)p->N * 96 + win - 1) / win);
-                    C = (int)std::max<long long>(1, std::min<long long>(C, n_hits / n_pairs / (stream ? 32 : 256)));
-                    if (const char* cs = getenv("SATBA_SCHUR_CHUNKS")) C = std::max(1, atoi(cs));
-                    if (stream) C = std::min(C, S3_MAXC);
-                    while (C > 1 && n_pairs * (long long)(C + 1) > (1ll << 27)) --C;
+                    int Cc = (int)std::max<long long>(1, ((long long)p->N * 96 + (12ll << 20) - 1) / (12ll << 20));
+                    Cc = (int)std::max<long long>(1, std::min<long long>(Cc, n_hits / n_pairs / 256));
+                    if (const char* cs = getenv("SATBA_SCHUR_CHUNKS")) Cc = std::max(1, atoi(cs));
+                    Cc = std::min(Cc, S3_MAXC);
+                    while (Cc > 1 && n_pairs * (long long)(Cc + 1) > (1ll << 27)) --Cc;
+                    const char* mo = getenv("SATBA_SCHUR_MOMENTS");
+                    const bool moments = p->model == AFFINE && p->unit_weights && mo && atoi(mo) == 1;  // experiment
+                    int mul = 1;
+                    if (stream || moments) {
+                        long long Cf = std::max<long long>(1, ((long long)p->N * 96 + (3ll << 20) - 1) / (3ll << 20));
+                        Cf = std::max<long long>(1, std::min<long long>(Cf, n_hits / n_pairs / 24));
+                        if (const char* cs = getenv("SATBA_SCHUR_FINE")) Cf = std::max(1, atoi(cs));
+                        mul = (int)std::max<long long>(1, std::min<long long>(Cf, S3_MAXC) / Cc);
+                        while (mul > 1 && n_pairs * (long long)(Cc * mul + 1) > (1ll << 27)) --mul;
+                    }
+                    p->sch3_chunk_mul = mul;
+                    const int C = Cc * mul;  // chunks the lists are cut into
                     const long long M_ = p->M;
                     auto pair_index = [M_](long long a, long long b) { return a * M_ - a * (a + 1) / 2 + (b - a - 1); };
                     auto chunk_of = [&](int q) { return (int)((long long)q * C / std::max(p->N, 1)); };
@@ -658,17 +691,26 @@ int satba_problem_create(const satba_problem_desc* d, satba_problem** out) {
                         TRY(dev_alloc(p, &p->d_pair_ofs, ofs.size())); TRY(dev_alloc(p, &p->d_pair_pts, pts.size()));
                         HIP_TRY(hipMemcpy(p->d_pair_ofs, ofs.data(), sizeof(long long) * ofs.size(), hipMemcpyHostToDevice));
                         HIP_TRY(hipMemcpy(p->d_pair_pts, pts.data(), sizeof(int) * pts.size(), hipMemcpyHostToDevice));
-                        p->sch3_chunks = C;
-                        if (stream) {  // groups of up to 8 pairs (i, j0 ..) of one camera i
+                        p->sch3_chunks = Cc;
+                        if (stream || moments) {  // groups of pairs (i, j0 ..) of one camera i: 8 (10 with six lanes per pair)
                             std::vector<int> groups;
+                            const char* gp = getenv("SATBA_SCHUR_GROUP");
+                            const int PW = (moments && !stream) || (gp && atoi(gp) == 10 && p->unit_weights) ? 10 : 8;
+                            p->sch3_group_pairs = PW;
                             for (int ci = 0; ci + 1 < p->M; ++ci)
-                                for (int cj = ci + 1; cj < p->M; cj += 8) {
-                                    groups.push_back(ci); groups.push_back(cj); groups.push_back(std::min(8, p->M - cj));
+                                for (int cj = ci + 1; cj < p->M; cj += PW) {
+                                    groups.push_back(ci); groups.push_back(cj); groups.push_back(std::min(PW, p->M - cj));
                                 }
-                            p->sch3_groups = (int)(groups.size() / 3);
                             TRY(dev_alloc(p, &p->d_groups, groups.size()));
                             HIP_TRY(hipMemcpy(p->d_groups, groups.data(), sizeof(int) * groups.size(), hipMemcpyHostToDevice));
-                        } else if (C > 1) TRY(dev_alloc(p, &p->d_pair_part, (size_t)C * n_pairs * p->NP * p->NP));
+                            if (stream) p->sch3_groups = (int)(groups.size() / 3);
+                            if (moments && !stream) {
+                                p->sch3_moments = true;
+                                p->sch3_groups_m = (int)(groups.size() / 3);
+                                TRY(dev_alloc(p, &p->d_Tbuf, (size_t)n_pairs * S3_NT));
+                            }
+                        }
+                        if (Cc > 1 && !stream) TRY(dev_alloc(p, &p->d_pair_part, (size_t)Cc * n_pairs * p->NP * p->NP));
                     }
                 }
             }
@@ -758,6 +800,11 @@ int satba_set_x(satba_problem* p, const double* host_x) {
     HIP_TRY(hipSetDevice(p->device));
     HIP_TRY(hipMemcpyAsync(p->d_x, host_x, sizeof(double) * p->n, hipMemcpyHostToDevice, p->stream));
     HIP_TRY(hipStreamSynchronize(p->stream));
+    if (p->N > 0 && !p->c0_set) {  // expansion point of the Schur moments: any point of the scene (conditioning only)
+        const double* q = host_x + p->n_c + 3 * (size_t)(p->N / 2);
+        p->c0[0] = q[0]; p->c0[1] = q[1]; p->c0[2] = q[2];
+        p->c0_set = true;
+    }
     TRY(launch_cam_consts(p, false));
     p->linearized = false; p->have_step = false;
     return 0;

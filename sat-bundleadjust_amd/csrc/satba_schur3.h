@@ -31,6 +31,7 @@ struct Schur3Args {
     const long long* __restrict__ pair_ofs;       // n_pairs + 1 (or null): offsets into pair_pts
     const int* __restrict__ pair_pts;             // points shared by each camera pair, ascending (static per problem)
     double* __restrict__ pair_part;               // n_chunks x n_pairs x NP*NP partial blocks (list path, n_chunks > 1)
+    int chunk_mul;                                // the lists are cut into n_chunks * chunk_mul fine chunks (pair_ofs stride + 1)
     int NW;                                       // words per camera
     int n_chunks;                                 // word-range chunks per pair (1: plain stores, >1: atomics)
 };
@@ -180,7 +181,8 @@ __global__ __launch_bounds__(256) void k_schur_pairs(ObsArgs a, CamMajor c, Schu
         // precomputed list of the points this camera pair shares (the structure is static across iterations): a
         // coalesced 4-byte stream replaces the bitmap scan (5 GB of bitmap traffic per launch at 200 x 1M)
         // pair_ofs[pair * (n_chunks + 1) + chunk]: start of the pair's points that fall into point-range chunk
-        const long long lo = s.pair_ofs[pair * (s.n_chunks + 1) + chunk], hi = s.pair_ofs[pair * (s.n_chunks + 1) + chunk + 1];
+        const int CF1 = s.n_chunks * s.chunk_mul + 1;  // this kernel works on groups of chunk_mul fine chunks
+        const long long lo = s.pair_ofs[pair * CF1 + chunk * s.chunk_mul], hi = s.pair_ofs[pair * CF1 + (chunk + 1) * s.chunk_mul];
         // software pipeline: the next point's index and record are in flight while the current one is evaluated
         long long idx = lo + lane;
         int p_cur = (idx < hi) ? s.pair_pts[idx] : 0;
@@ -263,21 +265,23 @@ __global__ __launch_bounds__(256) void k_schur_pairs(ObsArgs a, CamMajor c, Schu
 constexpr int S3_MAXC = 64;  // chunks (upper bound)
 constexpr int S3_GW = 4;     // waves per workgroup
 
-template <int MODEL, int NP, bool ROBUST, bool UNITW>
+// LP lanes per pair, PW = 64 / LP pairs per wave (LP = 6: 10 pairs on 60 lanes)
+template <int MODEL, int NP, bool ROBUST, bool UNITW, int LP>
 __device__ __forceinline__ void schur_pairs_groups_body(const ObsArgs& a, const CamMajor& c, const Schur3Args& s, const int* __restrict__ groups,
                                                          int n_groups, double* __restrict__ S) {
-    __shared__ long long s_ofs[S3_GW][8][S3_MAXC + 1];
-    __shared__ double s_cj[S3_GW][8][CAMC];
+    constexpr int PW = 64 / LP;
+    __shared__ long long s_ofs[S3_GW][PW][S3_MAXC + 1];
+    __shared__ double s_cj[S3_GW][PW][CAMC];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int gidx = blockIdx.x * S3_GW + __builtin_amdgcn_readfirstlane(wave);
     if (gidx >= n_groups) return;
     const int i = groups[3 * gidx], j0 = groups[3 * gidx + 1], cnt = groups[3 * gidx + 2];  // wave-uniform (scalar loads)
-    const int C = s.n_chunks, C1 = C + 1;
+    const int C = s.n_chunks * s.chunk_mul, C1 = C + 1;
     const long long pair0 = (long long)i * a.M - (long long)i * (i + 1) / 2 + (j0 - i - 1);
     for (int k = lane; k < cnt * C1; k += 64) s_ofs[wave][k / C1][k % C1] = s.pair_ofs[pair0 * C1 + k];
     for (int k = lane; k < cnt * CAMC; k += 64) s_cj[wave][k / CAMC][k % CAMC] = a.camc[(size_t)(j0 + k / CAMC) * CAMC + k % CAMC];
     __builtin_amdgcn_wave_barrier();  // single wave: its LDS operations execute in order
-    const int g = lane >> 3, r8 = lane & 7;
+    const int g = lane / LP, r8 = lane % LP;
     const bool member = g < cnt;
     const int gq = member ? g : 0;
     const int j = j0 + gq;
@@ -343,10 +347,10 @@ __device__ __forceinline__ void schur_pairs_groups_body(const ObsArgs& a, const 
         long long pos = s_ofs[wave][gq][ch] + r8;
         const long long hi = member ? s_ofs[wave][gq][ch + 1] : 0;
         int p_cur = (pos < hi) ? s.pair_pts[pos] : 0;
-        int p_nxt = (pos + 8 < hi) ? s.pair_pts[pos + 8] : 0;
+        int p_nxt = (pos + LP < hi) ? s.pair_pts[pos + LP] : 0;
         Rec r_cur = load_rec(p_cur);
         while (__any(pos < hi)) {
-            const int p_nn = (pos + 16 < hi) ? s.pair_pts[pos + 16] : 0;
+            const int p_nn = (pos + 2 * LP < hi) ? s.pair_pts[pos + 2 * LP] : 0;
             const Rec r_nxt = load_rec(p_nxt);
             // keep the gathers above the arithmetic: without the barrier the scheduler sinks them below compute()
             // to save registers and every step pays the full memory latency
@@ -359,16 +363,17 @@ __device__ __forceinline__ void schur_pairs_groups_body(const ObsArgs& a, const 
             }
             __builtin_amdgcn_sched_barrier(0);
             p_cur = p_nxt; p_nxt = p_nn; r_cur = r_nxt;
-            pos += 8;
+            pos += LP;
         }
     }
-    // 8-lane reduction per pair; block (row j, col i) of the column-major lower triangle
+    // LP-lane reduction per pair; block (row j, col i) of the column-major lower triangle
 #pragma unroll
     for (int r = 0; r < NP; ++r)
 #pragma unroll
         for (int q = 0; q < NP; ++q) {
             double t = acc[r][q];
-            t += __shfl_xor(t, 1); t += __shfl_xor(t, 2); t += __shfl_xor(t, 4);
+#pragma unroll
+            for (int d = 1; d < LP; ++d) t += __shfl(acc[r][q], min(lane + d, 63));  // only the sums of the lanes r8 == 0 are used
             if (member && r8 == 0) S[(size_t)(j * NP + q) + (size_t)(i * NP + r) * a.n_c] = t;  // S[(j,q), (i,r)] = (W_i Vinv W_j^T)[r][q]
         }
 }
@@ -376,19 +381,174 @@ __device__ __forceinline__ void schur_pairs_groups_body(const ObsArgs& a, const 
 template <int MODEL, int NP, bool ROBUST, bool UNITW>
 __global__ __launch_bounds__(64 * S3_GW) void k_schur_pairs_groups(ObsArgs a, CamMajor c, Schur3Args s, const int* __restrict__ groups,
                                                                    int n_groups, double* __restrict__ S) {
-    schur_pairs_groups_body<MODEL, NP, ROBUST, UNITW>(a, c, s, groups, n_groups, S);
+    schur_pairs_groups_body<MODEL, NP, ROBUST, UNITW, 8>(a, c, s, groups, n_groups, S);
 }
 // the same held to three waves per SIMD (<= 168 VGPRs; the affine unit-weight body needs 170): all M(M-1)/16 waves of
 // the headline shape are then resident at once -- one round instead of 1.26
 template <int MODEL, int NP, bool ROBUST, bool UNITW>
 __global__ __launch_bounds__(64 * S3_GW) __attribute__((amdgpu_waves_per_eu(3, 8))) void k_schur_pairs_groups_occ3(
     ObsArgs a, CamMajor c, Schur3Args s, const int* __restrict__ groups, int n_groups, double* __restrict__ S) {
-    schur_pairs_groups_body<MODEL, NP, ROBUST, UNITW>(a, c, s, groups, n_groups, S);
+    schur_pairs_groups_body<MODEL, NP, ROBUST, UNITW, 8>(a, c, s, groups, n_groups, S);
+}
+// six lanes per pair, ten pairs per wave: M(M-1)/20 waves fit the 2048 slots of two waves per SIMD in one round
+template <int MODEL, int NP, bool ROBUST, bool UNITW>
+__global__ __launch_bounds__(64 * S3_GW) void k_schur_pairs_groups6(ObsArgs a, CamMajor c, Schur3Args s, const int* __restrict__ groups,
+                                                                    int n_groups, double* __restrict__ S) {
+    schur_pairs_groups_body<MODEL, NP, ROBUST, UNITW, 6>(a, c, s, groups, n_groups, S);
+}
+
+// ---- affine cameras, unit weights, linear loss: the pair blocks through MOMENTS of the shared points
+// (experiment, SATBA_SCHUR_MOMENTS=1).
+// For an affine camera the point Jacobian A_i = dq/dX is a constant 2 x 3 matrix and every column of the camera
+// Jacobian is affine-linear in the point, Jc_i(X)[:, c] = E_ic x~ with x~ = (X - c0, 1) and E_ic a constant 2 x 4
+// matrix.  Therefore
+//   block_ij[r][q] = - sum_p Jc_i[:, r]^T (A_i Vinv_p A_j^T) Jc_j[:, q]
+//                  = - sum_{a,b,m,n} (E_ir^T A_i)[a][m]  T_ij[a][b][m][n]  (A_j^T E_jq)[n][b],
+//   T_ij[a][b][m][n] = sum_{p in i and j} x~_a x~_b Vinv_p[m][n]   (10 x 6 independent entries),
+// and the per-hit work drops from ~200 fp64 operations (two Jacobians, a 2 x 2 product, a 5 x 5 rank-2 update) to
+// 6 multiplications and 60 multiply-adds on data that needs no camera at all; the contraction with the cameras
+// happens once per pair (k_schur_contract).  Same lane-group layout as above (LP lanes per pair, accumulators live for
+// the whole launch).  Measured at 200 x 1M x 10M: exact (same solver trajectory), VALU instructions 277 M -> 98 M per
+// launch, but 1.0 ms against 0.71 ms: the waves do not stay in lockstep over the chunks (L2 misses 32 M per launch,
+// not the 10 M of a 3 MB window) and with two waves per SIMD nothing hides the gather latency.  The arithmetic is the
+// right one; the traversal needs a (soft) chunk barrier or the item kernel's dynamic scheduling -- next round.
+constexpr int S3_NT = 60;
+
+template <int LP>
+__global__ __launch_bounds__(64 * S3_GW) void k_schur_pairs_moments(int M, int n_pts_fix, Schur3Args s, const int* __restrict__ groups,
+                                                                    int n_groups, double c0x, double c0y, double c0z,
+                                                                    double* __restrict__ Tbuf) {
+    constexpr int PW = 64 / LP;
+    __shared__ long long s_ofs[S3_GW][PW][S3_MAXC + 1];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int gidx = blockIdx.x * S3_GW + __builtin_amdgcn_readfirstlane(wave);
+    if (gidx >= n_groups) return;
+    const int i = groups[3 * gidx], j0 = groups[3 * gidx + 1], cnt = groups[3 * gidx + 2];
+    const int C = s.n_chunks * s.chunk_mul, C1 = C + 1;
+    const long long pair0 = (long long)i * M - (long long)i * (i + 1) / 2 + (j0 - i - 1);
+    for (int k = lane; k < cnt * C1; k += 64) s_ofs[wave][k / C1][k % C1] = s.pair_ofs[pair0 * C1 + k];
+    __builtin_amdgcn_wave_barrier();  // single wave: its LDS operations execute in order
+    const int g = lane / LP, r8 = lane % LP;
+    const bool member = g < cnt;
+    const int gq = member ? g : 0;
+
+    double t[S3_NT];
+#pragma unroll
+    for (int k = 0; k < S3_NT; ++k) t[k] = 0.0;
+
+    struct Rec { double2 r0, r1, r2, r3, r4; };  // packed point record: X0 X1 | X2 v00 | v01 v02 | v11 v12 | v22 g0
+    auto load_rec = [&](int p) {
+        const double2* pv = s.PV + 6 * (size_t)p;
+        Rec r;
+        r.r0 = pv[0]; r.r1 = pv[1]; r.r2 = pv[2]; r.r3 = pv[3]; r.r4 = pv[4];
+        return r;
+    };
+    // One loop level carries the accumulators; moving on to the next chunk with work is a small loop of its own at
+    // the end of a step (a while loop per chunk makes the compiler keep two copies of the 60 accumulators).
+    int ch = -1;
+    long long pos = 0, hi = 0;
+    int p_cur = 0, p_nxt = 0;
+    Rec r_cur = load_rec(0);
+    auto next_chunk = [&]() {  // false: no chunk left
+        do {
+            if (++ch >= C) return false;
+            pos = s_ofs[wave][gq][ch] + r8;
+            hi = member ? s_ofs[wave][gq][ch + 1] : 0;
+        } while (!__any(pos < hi));
+        p_cur = (pos < hi) ? s.pair_pts[pos] : 0;
+        p_nxt = (pos + LP < hi) ? s.pair_pts[pos + LP] : 0;
+        r_cur = load_rec(p_cur);
+        return true;
+    };
+    bool more = next_chunk();
+    while (more) {
+        const int p_nn = (pos + 2 * LP < hi) ? s.pair_pts[pos + 2 * LP] : 0;
+        const Rec r_nxt = load_rec(p_nxt);
+        __builtin_amdgcn_sched_barrier(0);  // the gathers stay above the arithmetic
+        {
+            // lanes past the end of their list, and fixed points (their Jacobian is masked), contribute zero
+            const double on = (pos < hi && p_cur >= n_pts_fix) ? 1.0 : 0.0;
+            const double x0 = r_cur.r0.x - c0x, x1 = r_cur.r0.y - c0y, x2 = r_cur.r1.x - c0z;
+            const double v[6] = {on * r_cur.r1.y, on * r_cur.r2.x, on * r_cur.r2.y, on * r_cur.r3.x, on * r_cur.r3.y, on * r_cur.r4.x};
+            const double xx[10] = {x0 * x0, x0 * x1, x0 * x2, x0, x1 * x1, x1 * x2, x1, x2 * x2, x2, 1.0};
+#pragma unroll
+            for (int k = 0; k < 10; ++k)
+#pragma unroll
+                for (int m = 0; m < 6; ++m) t[k * 6 + m] = (k == 9) ? t[k * 6 + m] + v[m] : fma(xx[k], v[m], t[k * 6 + m]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        p_cur = p_nxt; p_nxt = p_nn; r_cur = r_nxt;
+        pos += LP;
+        if (!__any(pos < hi)) more = next_chunk();
+    }
+    // LP-lane reduction per pair
+#pragma unroll
+    for (int k = 0; k < S3_NT; ++k) {
+        double sum = t[k];
+#pragma unroll
+        for (int d = 1; d < LP; ++d) sum += __shfl(t[k], min(lane + d, 63));  // only the sums of the lanes r8 == 0 are used
+        if (member && r8 == 0) Tbuf[(size_t)(pair0 + g) * S3_NT + k] = sum;
+        __builtin_amdgcn_sched_barrier(0);  // one value at a time: 300 shuffles in flight would cost the main loop its registers
+    }
+}
+
+// contraction of the pair moments with the two cameras: one thread per (pair, r, q); the constant matrices of a camera
+// come out of the projector itself (it is exactly affine in the point): columns at the origin and at h e_a give the
+// linear part, the column at c0 the constant part.
+template <int NP>
+__global__ __launch_bounds__(256) void k_schur_contract(ObsArgs a, const double* __restrict__ Tbuf, double c0x, double c0y, double c0z,
+                                                        double* __restrict__ S) {
+    const long long n_pairs = (long long)a.M * (a.M - 1) / 2;
+    constexpr int NB2 = NP * NP;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_pairs * NB2) return;
+    const long long pair = idx / NB2;
+    const int e = (int)(idx % NB2), r = e / NP, q = e % NP;
+    int i = (int)((2.0 * a.M - 1.0 - sqrt((2.0 * a.M - 1.0) * (2.0 * a.M - 1.0) - 8.0 * (double)pair)) * 0.5);
+    while ((long long)i * a.M - (long long)i * (i + 1) / 2 > pair) --i;
+    while ((long long)(i + 1) * a.M - (long long)(i + 1) * (i + 2) / 2 <= pair) ++i;
+    const int j = i + 1 + (int)(pair - ((long long)i * a.M - (long long)i * (i + 1) / 2));
+    // B[al][m] = sum_k E[k][al] A[k][m] for parameter `col` of camera `cam`
+    auto cam_matrix = [&](int cam, int col, double B[4][3]) {
+        const double* cc = a.camc + (size_t)cam * CAMC;
+        const double h = 1048576.0;  // 2^20 m: exact scaling, keeps the difference quotient free of cancellation
+        double u, v, Jc0[2][NP], Jc1[2][NP], Jp[2][3], E[2][4];
+        project<AFFINE, NP, true>(cc, nullptr, 0.0, 0.0, 0.0, false, u, v, Jc0, Jp);
+#pragma unroll
+        for (int al = 0; al < 3; ++al) {
+            project<AFFINE, NP, true>(cc, nullptr, al == 0 ? h : 0.0, al == 1 ? h : 0.0, al == 2 ? h : 0.0, false, u, v, Jc1, Jp);
+            E[0][al] = (Jc1[0][col] - Jc0[0][col]) / h;
+            E[1][al] = (Jc1[1][col] - Jc0[1][col]) / h;
+        }
+        project<AFFINE, NP, true>(cc, nullptr, c0x, c0y, c0z, false, u, v, Jc1, Jp);
+        E[0][3] = Jc1[0][col];
+        E[1][3] = Jc1[1][col];
+        const double mc = (cam >= a.n_cam_fix) ? 1.0 : 0.0;
+#pragma unroll
+        for (int al = 0; al < 4; ++al)
+#pragma unroll
+            for (int m = 0; m < 3; ++m) B[al][m] = mc * (E[0][al] * Jp[0][m] + E[1][al] * Jp[1][m]);
+    };
+    double Bi[4][3], Bj[4][3];
+    cam_matrix(i, r, Bi);
+    cam_matrix(j, q, Bj);
+    const double* T = Tbuf + (size_t)pair * S3_NT;
+    const int XI[4][4] = {{0, 1, 2, 3}, {1, 4, 5, 6}, {2, 5, 7, 8}, {3, 6, 8, 9}};
+    const int VI[3][3] = {{0, 1, 2}, {1, 3, 4}, {2, 4, 5}};
+    double sum = 0.0;
+#pragma unroll
+    for (int al = 0; al < 4; ++al)
+#pragma unroll
+        for (int be = 0; be < 4; ++be)
+#pragma unroll
+            for (int m = 0; m < 3; ++m)
+#pragma unroll
+                for (int n = 0; n < 3; ++n) sum += Bi[al][m] * T[XI[al][be] * 6 + VI[m][n]] * Bj[be][n];
+    S[(size_t)(j * NP + q) + (size_t)(i * NP + r) * a.n_c] = -sum;
 }
 
 // list path with several point-range chunks: S block of each pair = sum of its chunk partials
 __global__ __launch_bounds__(256) void k_schur_pairs_reduce(int M, int NP, int n_c, int n_chunks, const double* __restrict__ part,
-                                                            const long long* __restrict__ pair_ofs, int skip_empty,
                                                             double* __restrict__ S) {
     const long long n_pairs = (long long)M * (M - 1) / 2;
     const int NB2 = NP * NP;
@@ -396,10 +556,8 @@ __global__ __launch_bounds__(256) void k_schur_pairs_reduce(int M, int NP, int n
     if (idx >= n_pairs * NB2) return;
     const long long pair = idx / NB2;
     const int e = (int)(idx % NB2);
-    const long long* po = pair_ofs + pair * (n_chunks + 1);
     double t = 0.0;
-    for (int ch = 0; ch < n_chunks; ++ch)  // the streaming kernel writes nothing for an item without shared points
-        if (!skip_empty || po[ch + 1] > po[ch]) t += part[((size_t)ch * n_pairs + pair) * NB2 + e];
+    for (int ch = 0; ch < n_chunks; ++ch) t += part[((size_t)ch * n_pairs + pair) * NB2 + e];
     int i = (int)((2.0 * M - 1.0 - sqrt((2.0 * M - 1.0) * (2.0 * M - 1.0) - 8.0 * (double)pair)) * 0.5);
     while ((long long)i * M - (long long)i * (i + 1) / 2 > pair) --i;
     while ((long long)(i + 1) * M - (long long)(i + 1) * (i + 2) / 2 <= pair) ++i;

@@ -541,6 +541,7 @@ ALT_PATHS = [
     {"SATBA_SCHUR_CHUNKS": "3"},     # Schur v3 pair lists cut into point-range chunks + partial reduce
     {"SATBA_SCHUR_CHUNKS": "1"},     # ... and as one chunk (direct store)
     {"SATBA_SCHUR_STREAM": "1", "SATBA_SCHUR_CHUNKS": "3"},  # lane-group Schur kernel (experiment)
+    {"SATBA_SCHUR_MOMENTS": "1", "SATBA_SCHUR_FINE": "6"},   # affine pair blocks through point moments (experiment)
 ]
 
 
@@ -566,6 +567,37 @@ def test_alternative_kernel_paths(gpu, monkeypatch, env, name, loss):
                          ("trial", [trf.COST_NEW, trf.STEP_SQ, trf.X_SQ])):
         for s in slots:
             assert abs(a[phase][s] - b[phase][s]) <= 1e-7 * abs(b[phase][s]) + 1e-300, (phase, s, a[phase][s], b[phase][s])
+    assert rel(dev.get_vector("gn_h"), ora.gn_h) < 1e-7
+    dev.close()
+
+
+@pytest.mark.parametrize("name", ["affine_RT", "affine_R_fix"])
+@pytest.mark.parametrize("env", [{"SATBA_SCHUR_MOMENTS": "1", "SATBA_SCHUR_FINE": "6"},
+                                 {"SATBA_SCHUR_STREAM": "1", "SATBA_SCHUR_CHUNKS": "2", "SATBA_SCHUR_GROUP": "10"},
+                                 {"SATBA_SCHUR_STREAM": "1", "SATBA_SCHUR_CHUNKS": "2"}])
+def test_unit_weight_schur_experiments(gpu, monkeypatch, env, name):
+    """
+    The unit-weight, linear-loss Schur variants (pair blocks through point moments; lane groups of 8 and 6 lanes)
+    against the oracle engine.  affine_R_fix has a fixed camera and fixed points (masked Jacobians) -- its reference
+    camera weight is reset to 1, these kernels are only selected when every weight is 1.
+    """
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    _, p, g = cases.fun_case(name)
+    p.pts2d_w = np.ones_like(p.pts2d_w)
+    v = ba_core._frozen_vars(g["v"][1].copy(), p)
+    dev, ora = HipEngine(p, rpc_f32=False), L.OracleEngine(p, rpc_f32=False)
+    for e in (dev, ora):
+        e.configure("linear", 1.0)
+        e.set_x(v)
+        e.linearize(); e.prepare(True); e.schur(1e-3)
+    n = dev.n_c
+    S = dev.get_exchange(dev.hdr, n * n).reshape(n, n).T  # column-major lower
+    So = ora._xb[ora.hdr: ora.hdr + n * n].reshape(n, n)
+    low = np.tril_indices(n)
+    assert np.abs(S[low] - So[low]).max() < 1e-9 * np.abs(So).max()
+    for e in (dev, ora):
+        e.solve()
     assert rel(dev.get_vector("gn_h"), ora.gn_h) < 1e-7
     dev.close()
 
