@@ -16,6 +16,9 @@ Tolerances (floating point, float64 arithmetic):
   solved camera params   1e-6 relative (north star; measured <= 2e-9); residual vector 5e-6 relative in norm
                          (measured 2e-7 .. 1.8e-6, the reference's finite-difference noise floor)
 """
+import os
+import socket
+
 import numpy as np
 import pytest
 
@@ -526,6 +529,62 @@ def test_queued_front_matches_host_driven_phases(gpu, name, Delta):
         b.schur_auto(Delta, 0.0)  # the prepare header is consumed: calling it twice is a state error
     for e in (a, b):
         e.close()
+
+
+def _two_rank_worker(rank, world, port, name, loss, out_dir):
+    import sys
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    root = os.path.dirname(here)
+    sys.path[:0] = [os.path.join(root, "sat-bundleadjust_amd"), root, here]
+    import torch
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import cases as cs
+    from satba import sharding as sh, trf as tr
+    from satba.engine_hip import HipEngine as Eng
+
+    _, make_p, _, _ = cs.solve_case(name)
+    p = make_p()
+    comm = tr.TorchComm()
+    shard = sh.make_shard(p, comm.rank, comm.world)
+    eng = Eng(p, shard)
+    res = tr.trf_solve(eng, comm, ftol=1e-15, xtol=1e-15, gtol=1e-15, max_nfev=300, loss=loss)
+    x = sh.assemble_x(p, shard, eng.get_x(), comm)
+    r = sh.assemble_residuals(p, shard, eng.residuals(), comm)
+    np.savez(os.path.join(out_dir, "rank{}.npz".format(rank)), x=x, r=r, cost=res.cost, nfev=res.nfev, status=res.status)
+    eng.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name,loss", [("affine_small_RT", "linear"), ("affine_small_R", "soft_l1")])
+def test_two_ranks_on_one_gpu(gpu, tmp_path, name, loss):
+    """
+    The N > 1 product path with the HIP engine: two processes share this GPU, each holds one shard of the points,
+    the exchange buffers (device tensors) are all-reduced over gloo.  RCCL itself is covered by the single-rank
+    plumbing test; here the sharded device arithmetic, the rank-0-only terms and the queued front are under test.
+    """
+    import torch.multiprocessing as mp
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_two_rank_worker, args=(2, port, name, loss, str(tmp_path)), nprocs=2, join=True)
+    outs = [np.load(os.path.join(str(tmp_path), "rank{}.npz".format(r))) for r in range(2)]
+    assert np.array_equal(outs[0]["x"], outs[1]["x"]) and int(outs[0]["nfev"]) == int(outs[1]["nfev"])
+    _, make_p, g, _ = cases.solve_case(name)
+    p = make_p()
+    n_c = p.n_cam * p.n_params
+    xt = g["tight_x_" + loss]
+    if name != "affine_small_RT":  # R+T on affine cameras with one frozen camera is a flat valley (SURVEY 7.3)
+        assert np.abs(outs[0]["x"][:n_c] - xt[:n_c]).max() < 1e-6 * np.abs(xt[:n_c]).max()
+    assert np.linalg.norm(outs[0]["r"] - g["tight_fun_" + loss]) < 5e-6 * np.linalg.norm(g["tight_fun_" + loss])
+    st = g["tight_stats_" + loss]
+    assert abs(float(outs[0]["cost"]) - st[0]) < 1e-9 * st[0]
 
 
 # ----------------------------------------------------------------------------- alternative kernel paths
