@@ -178,13 +178,14 @@ static int launch_cam_consts(satba_problem* p, bool at_new) {
 // S z = rhs for the reduced system (S column-major lower, destroyed; b in place)
 static int dense_solve(satba_problem* p, double* S, double* b) {
     if (p->dag.n_tasks > 0) {
+        HIP_TRY(hipMemsetAsync(p->d_fail, 0, sizeof(int), p->stream));
         HIP_TRY(hipMemsetAsync(p->dag.d_flags, 0, sizeof(int) * p->dag.flag_ints, p->stream));
         DagFlags fl = dag_flags(p->dag);
         hipLaunchKernelGGL(k_chol_dag, dim3(DG_GRID), dim3(DG_THREADS), 0, p->stream, S, p->n_c, b, p->dag.d_tasks, p->dag.n_tasks, fl);
         hipLaunchKernelGGL(k_dag_status, dim3(1), dim3(1), 0, p->stream, fl.ctr, p->d_fail);
         hipLaunchKernelGGL(k_trsv_back, dim3(1), dim3(1024), sizeof(double) * p->n_c, p->stream, S, p->n_c, b);
     } else {
-        cholesky_solve(S, p->n_c, b, p->d_fail, p->d_fail + 1, p->chol_two_launch, p->stream);
+        cholesky_solve(S, p->n_c, b, p->d_fail, p->d_fail + 1, p->chol_two_launch, p->stream);  // clears d_fail and the step flags
     }
     HIP_TRY(hipGetLastError());
     return 0;
@@ -381,22 +382,6 @@ static int launch_jvp(satba_problem* p, int nv, const double* q1, const double* 
     }
     HIP_TRY(hipGetLastError());
     return 0;
-}
-
-// end of the solve phase: Cholesky status into header slot 4 and the scalars kept from the earlier phases of this
-// iteration into slots SATBA_HDR_KEEP.. (rank 0 only: the header is summed over ranks afterwards)
-__global__ void k_flag_to_header(const int* __restrict__ flag, double lead, double* __restrict__ hdr, const double* __restrict__ keep) {
-    const int t = threadIdx.x;
-    if (t == 0) hdr[4] = (*flag != 0) ? lead : 0.0;
-    if (t < SATBA_KEEP_LEN) hdr[SATBA_HDR_KEEP + t] = lead * keep[t];
-}
-
-// start of the prepare phase: the (already all-reduced) linearize header -> keep[0] = cost, keep[1] = max_rank |g_p|_inf
-__global__ void k_keep_linearize(const double* __restrict__ hdr, int world, double* __restrict__ keep) {
-    double m = 0.0;
-    for (int r = 0; r < world; ++r) m = fmax(m, hdr[SATBA_HDR_FIXED + r]);
-    keep[0] = hdr[0];
-    keep[1] = m;
 }
 
 // start of satba_schur_auto: the (already all-reduced) prepare header -> keep[1] = |g|_inf, keep[2..4] = |g_h|^2,
@@ -866,11 +851,10 @@ int satba_prepare(satba_problem* p, int32_t first) {
     if (!p->linearized) return fail(SATBA_E_STATE, "prepare before linearize");
     HIP_TRY(hipSetDevice(p->device));
     const size_t nU = (size_t)p->M * p->NP * p->NP;
-    HIP_TRY(hipMemcpyAsync(p->d_U, p->payload(), sizeof(double) * nU, hipMemcpyDeviceToDevice, p->stream));
-    HIP_TRY(hipMemcpyAsync(p->d_gc, p->payload() + nU, sizeof(double) * p->n_c, hipMemcpyDeviceToDevice, p->stream));
-    hipLaunchKernelGGL(k_keep_linearize, dim3(1), dim3(1), 0, p->stream, p->d_xb, p->world, p->d_keep);
+    if (p->hdr > 1024) return fail(SATBA_E_ARG, "header too long");
+    hipLaunchKernelGGL(k_prepare_stash, dim3(1), dim3(1024), 0, p->stream, (int)nU, p->n_c, p->world, (int)p->hdr, p->d_xb, p->d_U, p->d_gc,
+                       p->d_keep);
     HIP_TRY(hipGetLastError());
-    TRY(zero_header(p));
     hipLaunchKernelGGL(k_prepare_vec, dim3(grid_for(p->n, 256, 512)), dim3(256), 0, p->stream, p->n, p->n_c, p->NP, first,
                        p->lead, p->d_U, p->d_gc, p->d_V, p->d_x, p->d_g, p->d_scale_inv, p->d_gh, p->d_q1, p->d_xb);
     HIP_TRY(hipGetLastError());
@@ -917,21 +901,18 @@ int satba_solve(satba_problem* p) {
     HIP_TRY(hipSetDevice(p->device));
     double* S = p->payload();
     double* rhs = S + (size_t)p->n_c * p->n_c;
-    HIP_TRY(hipMemsetAsync(p->d_fail, 0, sizeof(int), p->stream));
     hipLaunchKernelGGL(k_scale_system, dim3(grid_for((long long)p->n_c * p->n_c, 256, 2048)), dim3(256), 0, p->stream, p->n_c,
-                       p->d_scale_inv, S, rhs);
+                       p->d_scale_inv, S, rhs, p->d_dch);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(p->d_dch, rhs, sizeof(double) * p->n_c, hipMemcpyDeviceToDevice, p->stream));
-    TRY(dense_solve(p, S, p->d_dch));
-    hipLaunchKernelGGL(k_unscale, dim3((p->n_c + 255) / 256), dim3(256), 0, p->stream, p->n_c, p->d_scale_inv, p->d_dch, p->d_dc);
+    TRY(dense_solve(p, S, p->d_dch));  // also clears the not-SPD flag first
+    const int nu = std::max(p->n_c, (int)p->hdr);
+    hipLaunchKernelGGL(k_unscale, dim3((nu + 255) / 256), dim3(256), 0, p->stream, p->n_c, p->d_scale_inv, p->d_dch, p->d_dc, (int)p->hdr,
+                       p->d_xb, p->d_fail, p->lead, p->d_keep);
     HIP_TRY(hipGetLastError());
     if (p->n_split > 0) HIP_TRY(hipMemsetAsync(p->d_tbuf, 0, sizeof(double) * 3 * p->N, p->stream));
     if (p->K > 0) TRY(launch_backsub_kernel(p));
-    TRY(zero_header(p));
     hipLaunchKernelGGL(k_backsub_finish, dim3(grid_for(p->n_c + p->N, 256, 512)), dim3(256), 0, p->stream, p->n_c, p->N, p->lead,
                        p->d_dch, p->d_Vinv, p->d_g, p->d_tbuf, p->d_scale_inv, p->d_gh, p->d_gn, p->d_xb);
-    HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(k_flag_to_header, dim3(1), dim3(64), 0, p->stream, p->d_fail, p->lead, p->d_xb, p->d_keep);
     HIP_TRY(hipGetLastError());
     p->have_step = true;
     return 0;

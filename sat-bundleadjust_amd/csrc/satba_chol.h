@@ -523,10 +523,11 @@ __global__ __launch_bounds__(1024) void k_trsv_back_rl(const double* __restrict_
 constexpr int CH_MAX_STEPS = 256;  // flags: one per panel step (n <= 8192)
 
 // Factorise A (n x n, column-major lower, in place) and solve A z = b in place.  *fail != 0 if A was not SPD.
-// flags: CH_MAX_STEPS ints of scratch.  two_launch: the previous k_potrf_trsm + k_syrk pipeline.
+// flags: CH_MAX_STEPS ints of scratch directly behind *fail (flags == fail + 1); both are cleared here.  two_launch: the previous k_potrf_trsm + k_syrk pipeline.
 inline void cholesky_solve(double* A, int n, double* b, int* fail, int* flags, bool two_launch, hipStream_t stream,
                            long long* ts = nullptr) {
     if (two_launch) {
+        (void)hipMemsetAsync(fail, 0, sizeof(int), stream);
         for (int k0 = 0; k0 < n; k0 += CH_NB) {
             const int nb = n - k0 < CH_NB ? n - k0 : CH_NB;
             const int rest = n - k0 - nb;
@@ -538,7 +539,7 @@ inline void cholesky_solve(double* A, int n, double* b, int* fail, int* flags, b
             }
         }
     } else {
-        (void)hipMemsetAsync(flags, 0, sizeof(int) * CH_MAX_STEPS, stream);
+        (void)hipMemsetAsync(fail, 0, sizeof(int) * (1 + CH_MAX_STEPS), stream);  // flags == fail + 1: one fill for both
         int step = 0;
         for (int k0 = 0; k0 < n; k0 += CH_NB, ++step) {
             const int T = (n - k0 + 63) / 64;

@@ -782,22 +782,51 @@ __global__ __launch_bounds__(256) void k_schur_reduce(int n_c, int n_chunks, con
 // x_scale="jac" makes the scaled matrix unit-diagonal up to the damping, which keeps the dense factorisation
 // well conditioned although the raw camera blocks span ~12 orders of magnitude (angles vs translations).
 __global__ __launch_bounds__(256) void k_scale_system(int n_c, const double* __restrict__ scale_inv, double* __restrict__ S,
-                                                      double* __restrict__ rhs) {
+                                                      const double* __restrict__ rhs, double* __restrict__ rhs_scaled) {
     const size_t nn = (size_t)n_c * n_c;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nn + n_c; i += (size_t)gridDim.x * blockDim.x) {
         if (i < nn) {
             const int r = (int)(i % n_c), c = (int)(i / n_c);
             if (r >= c) S[i] /= scale_inv[r] * scale_inv[c];
         } else {
-            rhs[i - nn] /= scale_inv[i - nn];
+            rhs_scaled[i - nn] = rhs[i - nn] / scale_inv[i - nn];  // the solve works on a copy: the payload is all-reduced data
         }
     }
 }
 
-// dc = dc_h / scale_inv (unscaled camera step for the back-substitution)
-__global__ void k_unscale(int n_c, const double* __restrict__ scale_inv, const double* __restrict__ dch, double* __restrict__ dc) {
+// dc = dc_h / scale_inv (unscaled camera step for the back-substitution).  The same launch prepares the header of the
+// solve phase (nothing touches it between here and k_backsub_finish): zero, Cholesky status in slot 4, the scalars
+// kept from the earlier phases of this iteration in slots SATBA_HDR_KEEP.. (rank 0 only: headers are summed over ranks)
+__global__ void k_unscale(int n_c, const double* __restrict__ scale_inv, const double* __restrict__ dch, double* __restrict__ dc,
+                          int hdr_len, double* __restrict__ hdr, const int* __restrict__ fail_flag, double lead,
+                          const double* __restrict__ keep) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n_c) dc[i] = dch[i] / scale_inv[i];
+    if (i < hdr_len) {
+        double v = 0.0;
+        if (i == 4) v = (*fail_flag != 0) ? lead : 0.0;
+        if (i >= SATBA_HDR_KEEP && i < SATBA_HDR_KEEP + SATBA_KEEP_LEN) v = lead * keep[i - SATBA_HDR_KEEP];
+        hdr[i] = v;
+    }
+}
+
+// start of the prepare phase, one launch: the (already all-reduced) linearize payload U | g_c is copied out of the
+// exchange buffer, keep[0] = cost and keep[1] = max_rank |g_p|_inf are taken from its header, the header is zeroed
+__global__ __launch_bounds__(1024) void k_prepare_stash(int nU, int n_c, int world, int hdr_len, double* __restrict__ xb,
+                                                        double* __restrict__ U, double* __restrict__ gc, double* __restrict__ keep) {
+    const double* payload = xb + hdr_len;
+    for (int i = threadIdx.x; i < nU + n_c; i += blockDim.x) {
+        if (i < nU) U[i] = payload[i];
+        else gc[i - nU] = payload[i];
+    }
+    if (threadIdx.x == 0) {
+        double m = 0.0;
+        for (int r = 0; r < world; ++r) m = fmax(m, xb[SATBA_HDR_FIXED + r]);
+        keep[0] = xb[0];
+        keep[1] = m;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < hdr_len) xb[threadIdx.x] = 0.0;
 }
 
 // ------------------------------------------------------------------------------------------------ K5 back-substitution
