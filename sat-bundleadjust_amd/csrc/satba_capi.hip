@@ -86,6 +86,8 @@ struct satba_problem {
     int sch3_groups_m = 0;      // groups of the moments kernel
     bool sch3_moments = false;  // affine + unit weights: pair blocks through point moments (linear loss only)
     double* d_Tbuf = nullptr;
+    double* d_Jobs = nullptr;   // RPC: stored Jacobian blocks per observation (camera-major)
+    double* d_Jpm = nullptr;    // RPC: the same in observation order (written by the linearize kernels)
     double c0[3] = {0, 0, 0};   // expansion point of the moments
     bool c0_set = false;
     int* d_groups = nullptr;
@@ -155,6 +157,7 @@ static ObsArgs obs_args(const satba_problem* p, bool at_new) {
     a.x = at_new ? p->d_xnew : p->d_x;
     a.camc = at_new ? p->d_camc_new : p->d_camc;
     a.rpc = p->d_rpc;
+    a.Jpm = at_new ? nullptr : p->d_Jpm;  // stored Jacobian blocks belong to the linearisation at x
     a.K = p->K; a.n_tiles = p->n_tiles; a.M = p->M; a.N = p->N; a.n_c = p->n_c;
     a.n_cam_fix = p->n_cam_fix; a.n_pts_fix = p->n_pts_fix; a.loss = p->loss; a.f32 = p->f32;
     a.f_scale = p->f_scale;
@@ -213,7 +216,7 @@ static int launch_lin3(satba_problem* p, const ObsArgs& a) {
     s.pt_ofs = p->d_pt_ofs; s.f = p->d_f; s.V = p->d_V; s.gp = p->d_g + p->n_c;
     s.hdr_cost = p->d_xb + 0; s.hdr_gpmax = p->d_xb + SATBA_HDR_FIXED + p->rank;
     CamMajor cm;
-    cm.cam_ofs = p->d_cam_ofs; cm.obs = p->d_cm_obs; cm.w = p->d_cm_w; cm.pt = p->d_cm_pt;
+    cm.cam_ofs = p->d_cam_ofs; cm.obs = p->d_cm_obs; cm.w = p->d_cm_w; cm.pt = p->d_cm_pt; cm.oidx = p->d_cam_obs;
     const size_t lds = p->camc_bytes;
     if (p->loss == 0) {
         hipLaunchKernelGGL((k_lin_points<MODEL, NP, false, CL>), dim3(p->lin3_grid), dim3(256), lds, p->stream, a, s);
@@ -266,11 +269,11 @@ static size_t schur_lds(const satba_problem* p) { return sizeof(double) * ((size
 template <int MODEL, int NP, bool ADDU>
 static int launch_schur3(satba_problem* p, const ObsArgs& a, double* S, double* rhs) {
     CamMajor cm;
-    cm.cam_ofs = p->d_cam_ofs; cm.obs = p->d_cm_obs; cm.w = p->d_cm_w; cm.pt = p->d_cm_pt;
+    cm.cam_ofs = p->d_cam_ofs; cm.obs = p->d_cm_obs; cm.w = p->d_cm_w; cm.pt = p->d_cm_pt; cm.oidx = p->d_cam_obs;
     Schur3Args s;
     s.bits = p->d_bits; s.rank = p->d_rank; s.Vinv = p->d_Vinv; s.gp = p->d_g + p->n_c; s.NW = p->NW; s.n_chunks = p->sch3_chunks;
     s.PV = reinterpret_cast<const double2*>(p->d_PV);
-    s.pair_ofs = p->d_pair_ofs; s.pair_pts = p->d_pair_pts; s.pair_part = p->d_pair_part; s.chunk_mul = p->sch3_chunk_mul;
+    s.pair_ofs = p->d_pair_ofs; s.pair_pts = p->d_pair_pts; s.pair_part = p->d_pair_part; s.chunk_mul = p->sch3_chunk_mul; s.Jobs = p->d_Jobs;
     const long long n_pairs = (long long)p->M * (p->M - 1) / 2;
     const long long items = n_pairs * p->sch3_chunks;
     const int diag_chunks = p->lin3_chunks;
@@ -278,6 +281,10 @@ static int launch_schur3(satba_problem* p, const ObsArgs& a, double* S, double* 
     const unsigned ggrid = grp ? (unsigned)((p->sch3_groups + S3_GW - 1) / S3_GW) : 0;
     const unsigned igrid = (unsigned)((items + 3) / 4);
     const bool moments = p->sch3_moments && p->loss == 0 && items > 0;
+    // diagonal blocks first: for RPC cameras this pass also stores the Jacobian blocks the pair kernel gathers
+    if (p->loss == 0) hipLaunchKernelGGL((k_schur_diag<MODEL, NP, false, ADDU>), dim3(diag_chunks, p->M), dim3(LINC_THREADS), 0, p->stream, a, cm, s, p->d_part3);
+    else hipLaunchKernelGGL((k_schur_diag<MODEL, NP, true, ADDU>), dim3(diag_chunks, p->M), dim3(LINC_THREADS), 0, p->stream, a, cm, s, p->d_part3);
+    bool done = false;
     if constexpr (MODEL == AFFINE) {
         if (moments) {
             hipLaunchKernelGGL((k_schur_pairs_moments<6>), dim3((unsigned)((p->sch3_groups_m + S3_GW - 1) / S3_GW)), dim3(64 * S3_GW), 0, p->stream,
@@ -285,29 +292,27 @@ static int launch_schur3(satba_problem* p, const ObsArgs& a, double* S, double* 
             const long long outs = n_pairs * NP * NP;
             hipLaunchKernelGGL((k_schur_contract<NP>), dim3((unsigned)((outs + 255) / 256)), dim3(256), 0, p->stream, a, p->d_Tbuf,
                                p->c0[0], p->c0[1], p->c0[2], S);
-            hipLaunchKernelGGL((k_schur_diag<MODEL, NP, false, ADDU>), dim3(diag_chunks, p->M), dim3(LINC_THREADS), 0, p->stream, a, cm, s, p->d_part3);
+            done = true;
         }
     }
-    if (MODEL == AFFINE && moments) {
+    if (done || items == 0) {
     } else if (p->loss == 0 && p->unit_weights) {
-        if (items > 0 && grp) {
+        if (grp) {
             if (p->sch3_group_pairs == 10)
                 hipLaunchKernelGGL((k_schur_pairs_groups6<MODEL, NP, false, true>), dim3(ggrid), dim3(64 * S3_GW), 0, p->stream, a, cm, s, p->d_groups, p->sch3_groups, S);
             else if constexpr (MODEL == AFFINE)
                 hipLaunchKernelGGL((k_schur_pairs_groups_occ3<MODEL, NP, false, true>), dim3(ggrid), dim3(64 * S3_GW), 0, p->stream, a, cm, s, p->d_groups, p->sch3_groups, S);
             else
                 hipLaunchKernelGGL((k_schur_pairs_groups<MODEL, NP, false, true>), dim3(ggrid), dim3(64 * S3_GW), 0, p->stream, a, cm, s, p->d_groups, p->sch3_groups, S);
+        } else {
+            hipLaunchKernelGGL((k_schur_pairs<MODEL, NP, false, true>), dim3(igrid), dim3(256), 0, p->stream, a, cm, s, S);
         }
-        else if (items > 0) hipLaunchKernelGGL((k_schur_pairs<MODEL, NP, false, true>), dim3(igrid), dim3(256), 0, p->stream, a, cm, s, S);
-        hipLaunchKernelGGL((k_schur_diag<MODEL, NP, false, ADDU>), dim3(diag_chunks, p->M), dim3(LINC_THREADS), 0, p->stream, a, cm, s, p->d_part3);
     } else if (p->loss == 0) {
-        if (items > 0 && grp) hipLaunchKernelGGL((k_schur_pairs_groups<MODEL, NP, false, false>), dim3(ggrid), dim3(64 * S3_GW), 0, p->stream, a, cm, s, p->d_groups, p->sch3_groups, S);
-        else if (items > 0) hipLaunchKernelGGL((k_schur_pairs<MODEL, NP, false, false>), dim3(igrid), dim3(256), 0, p->stream, a, cm, s, S);
-        hipLaunchKernelGGL((k_schur_diag<MODEL, NP, false, ADDU>), dim3(diag_chunks, p->M), dim3(LINC_THREADS), 0, p->stream, a, cm, s, p->d_part3);
+        if (grp) hipLaunchKernelGGL((k_schur_pairs_groups<MODEL, NP, false, false>), dim3(ggrid), dim3(64 * S3_GW), 0, p->stream, a, cm, s, p->d_groups, p->sch3_groups, S);
+        else hipLaunchKernelGGL((k_schur_pairs<MODEL, NP, false, false>), dim3(igrid), dim3(256), 0, p->stream, a, cm, s, S);
     } else {
-        if (items > 0 && grp) hipLaunchKernelGGL((k_schur_pairs_groups<MODEL, NP, true, false>), dim3(ggrid), dim3(64 * S3_GW), 0, p->stream, a, cm, s, p->d_groups, p->sch3_groups, S);
-        else if (items > 0) hipLaunchKernelGGL((k_schur_pairs<MODEL, NP, true, false>), dim3(igrid), dim3(256), 0, p->stream, a, cm, s, S);
-        hipLaunchKernelGGL((k_schur_diag<MODEL, NP, true, ADDU>), dim3(diag_chunks, p->M), dim3(LINC_THREADS), 0, p->stream, a, cm, s, p->d_part3);
+        if (grp) hipLaunchKernelGGL((k_schur_pairs_groups<MODEL, NP, true, false>), dim3(ggrid), dim3(64 * S3_GW), 0, p->stream, a, cm, s, p->d_groups, p->sch3_groups, S);
+        else hipLaunchKernelGGL((k_schur_pairs<MODEL, NP, true, false>), dim3(igrid), dim3(256), 0, p->stream, a, cm, s, S);
     }
     HIP_TRY(hipGetLastError());
     if (items > 0 && p->d_pair_ofs && p->sch3_chunks > 1 && !grp && !(MODEL == AFFINE && moments)) {
@@ -566,6 +571,7 @@ int satba_problem_create(const satba_problem_desc* d, satba_problem** out) {
             HIP_TRY(hipMemcpy(p->dag.d_tasks, tasks.data(), sizeof(DagTask) * tasks.size(), hipMemcpyHostToDevice));
             if (getenv("SATBA_DAG_TIMES")) TRY(dev_alloc(p, &p->dag.d_times, 4 * tasks.size()));
         }
+        if (p->model == RPC && !getenv("SATBA_RPC_RECOMPUTE")) TRY(dev_alloc(p, &p->d_Jpm, (size_t)std::max<long long>(K, 1) * (2 * p->NP + 6)));
         TRY(dev_alloc(p, &p->d_scal, 8));
         TRY(dev_alloc(p, &p->d_keep, SATBA_KEEP_LEN));
         HIP_TRY(hipMemset(p->d_keep, 0, sizeof(double) * SATBA_KEEP_LEN));
@@ -607,6 +613,7 @@ int satba_problem_create(const satba_problem_desc* d, satba_problem** out) {
                 }
                 TRY(dev_alloc(p, &p->d_bits, bits.size())); TRY(dev_alloc(p, &p->d_rank, rank.size()));
                 TRY(dev_alloc(p, &p->d_PV, (size_t)12 * p->N));
+                if (p->model == RPC) TRY(dev_alloc(p, &p->d_Jobs, (size_t)K * (2 * p->NP + 6)));
                 p->unit_weights = 1;
                 for (long long o = 0; o < K; ++o) if (d->weights[o] != 1.0) { p->unit_weights = 0; break; }
                 HIP_TRY(hipMemcpy(p->d_bits, bits.data(), sizeof(unsigned long long) * bits.size(), hipMemcpyHostToDevice));
@@ -633,6 +640,8 @@ int satba_problem_create(const satba_problem_desc* d, satba_problem** out) {
                     const bool stream = st && atoi(st) == 1;
                     int Cc = (int)std::max<long long>(1, ((long long)p->N * 96 + (12ll << 20) - 1) / (12ll << 20));
                     Cc = (int)std::max<long long>(1, std::min<long long>(Cc, n_hits / n_pairs / 256));
+                    // few cameras: enough (pair, chunk) items to fill the chip (>= 8192 waves), at least 64 hits each
+                    Cc = (int)std::max<long long>(Cc, std::min<long long>((8192 + n_pairs - 1) / n_pairs, std::max<long long>(1, n_hits / n_pairs / 64)));
                     if (const char* cs = getenv("SATBA_SCHUR_CHUNKS")) Cc = std::max(1, atoi(cs));
                     Cc = std::min(Cc, S3_MAXC);
                     while (Cc > 1 && n_pairs * (long long)(Cc + 1) > (1ll << 27)) --Cc;
@@ -992,7 +1001,7 @@ int satba_get_blocks(satba_problem* p, double* U, double* gc, double* V, double*
         HIP_TRY(hipMalloc((void**)&dg, sizeof(double) * p->n_c));
         ObsArgs a = obs_args(p, false);
         CamMajor cm;
-        cm.cam_ofs = p->d_cam_ofs; cm.obs = p->d_cm_obs; cm.w = p->d_cm_w; cm.pt = p->d_cm_pt;
+        cm.cam_ofs = p->d_cam_ofs; cm.obs = p->d_cm_obs; cm.w = p->d_cm_w; cm.pt = p->d_cm_pt; cm.oidx = p->d_cam_obs;
         int rc = [&]() -> int {
             SATBA_DISPATCH(p, hipLaunchKernelGGL((k_lin_cameras<MODEL, NP, true>), dim3(p->lin3_chunks, p->M), dim3(LINC_THREADS), 0,
                                                  p->stream, a, cm, p->d_part3));

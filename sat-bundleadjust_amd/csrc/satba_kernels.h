@@ -35,6 +35,9 @@ struct ObsArgs {
     const double* __restrict__ x;      // variable vector whose POINT part is used
     const double* __restrict__ camc;   // M x CAMC camera constants built from the same vector
     const double* __restrict__ rpc;    // M x 90 or null
+    double* __restrict__ Jpm;          // RPC only (else null): K x (2 NP + 6) Jacobian blocks Jc | Jp of the current
+                                       // linearisation, observation order; written by the linearize kernels and read by
+                                       // every later pass (the RPC chain costs 2-3 kflop per evaluation)
     long long K;
     int n_tiles, M, N, n_c, n_cam_fix, n_pts_fix, loss, f32;
     double f_scale;
@@ -82,6 +85,35 @@ struct ObsEval {
 #pragma unroll
             for (int j = 0; j < 3; ++j) { Jp[0][j] *= s0 * mp; Jp[1][j] *= s1 * mp; }
         }
+    }
+
+    // the blocks of the current linearisation, stored / reloaded (RPC): 2 NP + 6 doubles = NP + 3 16-byte words
+    __device__ inline void store_jac(const ObsArgs& a, long long o) const {
+        double t[2 * NP + 6];
+#pragma unroll
+        for (int k = 0; k < NP; ++k) { t[k] = Jc[0][k]; t[NP + k] = Jc[1][k]; }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { t[2 * NP + k] = Jp[0][k]; t[2 * NP + 3 + k] = Jp[1][k]; }
+        double2* q = reinterpret_cast<double2*>(a.Jpm + (size_t)o * (2 * NP + 6));
+#pragma unroll
+        for (int k = 0; k < NP + 3; ++k) q[k] = make_double2(t[2 * k], t[2 * k + 1]);
+    }
+    __device__ inline void load_jac(const ObsArgs& a, long long o) {
+        const double2* q = reinterpret_cast<const double2*>(a.Jpm + (size_t)o * (2 * NP + 6));
+        double t[2 * NP + 6];
+#pragma unroll
+        for (int k = 0; k < NP + 3; ++k) { const double2 v = q[k]; t[2 * k] = v.x; t[2 * k + 1] = v.y; }
+#pragma unroll
+        for (int k = 0; k < NP; ++k) { Jc[0][k] = t[k]; Jc[1][k] = t[NP + k]; }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { Jp[0][k] = t[2 * NP + k]; Jp[1][k] = t[2 * NP + 3 + k]; }
+    }
+    // Jacobian blocks only: from the store when there is one
+    __device__ inline void jac(const ObsArgs& a, long long o, int cam, int pt, const double* cc) {
+        if constexpr (MODEL == RPC) {
+            if (a.Jpm) { load_jac(a, o); return; }
+        }
+        eval(a, o, cam, pt, cc);
     }
 };
 
@@ -234,6 +266,7 @@ __global__ __launch_bounds__(LinCfg<ROBUST>::THREADS) void k_linearize(ObsArgs a
             pt = a.pt[o];
             ObsEval<MODEL, NP, true, ROBUST> e;
             e.eval(a, o, cam, pt, cbase + (size_t)cam * CAMC);
+            if constexpr (MODEL == RPC) { if (a.Jpm) e.store_jac(a, o); }
             f[o] = make_double2(e.ftrue[0], e.ftrue[1]);
             cost += e.rho;
             // per-point products into the wave's staging rows (conflict-free 8-byte stores)
@@ -423,7 +456,7 @@ __global__ __launch_bounds__(512) void k_jvp(ObsArgs a, const double* __restrict
     for (long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x; o < a.K; o += (long long)gridDim.x * blockDim.x) {
         const int cam = a.cam[o], pt = a.pt[o];
         ObsEval<MODEL, NP, true> e;
-        e.eval(a, o, cam, pt, cbase + (size_t)cam * CAMC);
+        e.jac(a, o, cam, pt, cbase + (size_t)cam * CAMC);
         const size_t ic = (size_t)cam * NP, ip = (size_t)a.n_c + 3 * (size_t)pt;
         double j1[2] = {0, 0}, j2[2] = {0, 0};
 #pragma unroll
@@ -847,7 +880,7 @@ __global__ __launch_bounds__(256) void k_backsub(ObsArgs a, const double* __rest
             const int cam = a.cam[o];
             pt = a.pt[o];
             ObsEval<MODEL, NP, true> e;
-            e.eval(a, o, cam, pt, cbase + (size_t)cam * CAMC);
+            e.jac(a, o, cam, pt, cbase + (size_t)cam * CAMC);
             double u0 = 0.0, u1 = 0.0;
 #pragma unroll
             for (int i = 0; i < NP; ++i) {

@@ -44,6 +44,7 @@ __global__ __launch_bounds__(256) void k_lin_points(ObsArgs a, Lin3Args s) {
             const int cam = a.cam[o];
             ObsEval<MODEL, NP, true, ROBUST> e;
             e.eval(a, o, cam, p, cbase + (size_t)cam * CAMC);
+            if constexpr (MODEL == RPC) { if (a.Jpm) e.store_jac(a, o); }
             s.f[o] = make_double2(e.ftrue[0], e.ftrue[1]);
             cost += e.rho;
             v[0] += e.Jp[0][0] * e.Jp[0][0] + e.Jp[1][0] * e.Jp[1][0];
@@ -82,6 +83,7 @@ struct CamMajor {
     const double2* __restrict__ obs;     // K, camera-major
     const double* __restrict__ w;        // K
     const int* __restrict__ pt;          // K
+    const int* __restrict__ oidx;        // K: observation index of each camera-major position
 };
 
 constexpr int LINC_THREADS = 256;

@@ -32,6 +32,8 @@ struct Schur3Args {
     const int* __restrict__ pair_pts;             // points shared by each camera pair, ascending (static per problem)
     double* __restrict__ pair_part;               // n_chunks x n_pairs x NP*NP partial blocks (list path, n_chunks > 1)
     int chunk_mul;                                // the lists are cut into n_chunks * chunk_mul fine chunks (pair_ofs stride + 1)
+    double* __restrict__ Jobs;                    // RPC: K x (2 NP + 6) Jacobian blocks Jc | Jp per observation, camera-major,
+                                                  // written by k_schur_diag, read by k_schur_pairs (null otherwise)
     int NW;                                       // words per camera
     int n_chunks;                                 // word-range chunks per pair (1: plain stores, >1: atomics)
 };
@@ -148,8 +150,34 @@ __global__ __launch_bounds__(256) void k_schur_pairs(ObsArgs a, CamMajor c, Schu
         const double X = rc.r0.x, Y = rc.r0.y, Z = rc.r1.x;
         const double v00 = rc.r1.y, v01 = rc.r2.x, v02 = rc.r2.y, v11 = rc.r3.x, v12 = rc.r3.y, v22 = rc.r4.x;
         double Jci[2][NP], Jpi[2][3], Jcj[2][NP], Jpj[2][3];
-        cm_jacobian<MODEL, NP, ROBUST, UNITW>(a, c, cci, tabi, i, pi, p, X, Y, Z, Jci, Jpi);
-        cm_jacobian<MODEL, NP, ROBUST, UNITW>(a, c, ccj, tabj, j, pj, p, X, Y, Z, Jcj, Jpj);
+        if constexpr (MODEL == RPC) {
+            // the RPC chain costs 2-3 kflop per Jacobian and every observation sits in (track length - 1) pairs:
+            // the blocks k_schur_diag stored for this linearisation are gathered instead of being recomputed
+            if constexpr (UNITW) {
+                const int w = p >> 6;
+                const unsigned long long below = (1ull << (p & 63)) - 1ull;
+                pi = base_i + ri[w] + __popcll(bi[w] & below);
+                pj = base_j + rj[w] + __popcll(bj[w] & below);
+            }
+            const double2* qi = reinterpret_cast<const double2*>(s.Jobs + (size_t)pi * (2 * NP + 6));
+            const double2* qj = reinterpret_cast<const double2*>(s.Jobs + (size_t)pj * (2 * NP + 6));
+            double ti[2 * NP + 6], tj[2 * NP + 6];
+#pragma unroll
+            for (int k = 0; k < NP + 3; ++k) {
+                const double2 vi = qi[k], vj = qj[k];
+                ti[2 * k] = vi.x; ti[2 * k + 1] = vi.y; tj[2 * k] = vj.x; tj[2 * k + 1] = vj.y;
+            }
+#pragma unroll
+            for (int k = 0; k < NP; ++k) { Jci[0][k] = ti[k]; Jci[1][k] = ti[NP + k]; Jcj[0][k] = tj[k]; Jcj[1][k] = tj[NP + k]; }
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                Jpi[0][k] = ti[2 * NP + k]; Jpi[1][k] = ti[2 * NP + 3 + k];
+                Jpj[0][k] = tj[2 * NP + k]; Jpj[1][k] = tj[2 * NP + 3 + k];
+            }
+        } else {
+            cm_jacobian<MODEL, NP, ROBUST, UNITW>(a, c, cci, tabi, i, pi, p, X, Y, Z, Jci, Jpi);
+            cm_jacobian<MODEL, NP, ROBUST, UNITW>(a, c, ccj, tabj, j, pj, p, X, Y, Z, Jcj, Jpj);
+        }
         // Mm = Jp_i Vinv Jp_j^T (2 x 2)
         double A[2][3];
 #pragma unroll
@@ -586,7 +614,33 @@ __global__ __launch_bounds__(LINC_THREADS) void k_schur_diag(ObsArgs a, CamMajor
         const double2* pv = s.PV + 6 * (size_t)p;
         const double2 r0 = pv[0], r1 = pv[1], r2 = pv[2], r3 = pv[3], r4 = pv[4], r5 = pv[5];
         double Jc[2][NP], Jp[2][3];
-        cm_jacobian<MODEL, NP, ROBUST>(a, c, cc, tab, cam, pos, p, r0.x, r0.y, r1.x, Jc, Jp);
+        bool have = false;
+        if constexpr (MODEL == RPC) {
+            if (a.Jpm) {  // the blocks the linearize kernel stored, through the camera-major permutation
+                const double2* q = reinterpret_cast<const double2*>(a.Jpm + (size_t)c.oidx[pos] * (2 * NP + 6));
+                double t[2 * NP + 6];
+#pragma unroll
+                for (int k = 0; k < NP + 3; ++k) { const double2 v = q[k]; t[2 * k] = v.x; t[2 * k + 1] = v.y; }
+#pragma unroll
+                for (int k = 0; k < NP; ++k) { Jc[0][k] = t[k]; Jc[1][k] = t[NP + k]; }
+#pragma unroll
+                for (int k = 0; k < 3; ++k) { Jp[0][k] = t[2 * NP + k]; Jp[1][k] = t[2 * NP + 3 + k]; }
+                have = true;
+            }
+        }
+        if (!have) cm_jacobian<MODEL, NP, ROBUST>(a, c, cc, tab, cam, pos, p, r0.x, r0.y, r1.x, Jc, Jp);
+        if constexpr (MODEL == RPC) {
+            if (s.Jobs) {
+                double t[2 * NP + 6];
+#pragma unroll
+                for (int k = 0; k < NP; ++k) { t[k] = Jc[0][k]; t[NP + k] = Jc[1][k]; }
+#pragma unroll
+                for (int k = 0; k < 3; ++k) { t[2 * NP + k] = Jp[0][k]; t[2 * NP + 3 + k] = Jp[1][k]; }
+                double2* q = reinterpret_cast<double2*>(s.Jobs + (size_t)pos * (2 * NP + 6));
+#pragma unroll
+                for (int k = 0; k < NP + 3; ++k) q[k] = make_double2(t[2 * k], t[2 * k + 1]);
+            }
+        }
         const double v00 = r1.y, v01 = r2.x, v02 = r2.y, v11 = r3.x, v12 = r3.y, v22 = r4.x;
         double A[2][3];
 #pragma unroll
