@@ -36,6 +36,8 @@ Engine contract (implemented by engine_hip.HipEngine; tests use a CPU stand-in b
     trial_gn(ca, cb)    x_new = x + scale (ca g_h + cb gn_h): the same step without the subspace phase
     accept()            x <- x_new
 """
+import math
+
 import numpy as np
 
 # header slots, per phase (the header is zeroed by each phase before it writes)
@@ -104,21 +106,77 @@ class Result(dict):
 # ----------------------------------------------------------------------------- scalar helpers (scipy semantics)
 
 def solve_trust_region_2d(B, g, Delta):
-    """min 0.5 p^T B p + g^T p  s.t. |p| <= Delta in two dimensions (scipy:optimize/_lsq/common.py:171-219)."""
-    a, b, c = B[0, 0], B[0, 1], B[1, 1]
+    """
+    min 0.5 p^T B p + g^T p  s.t. |p| <= Delta in two dimensions (scipy:optimize/_lsq/common.py:171-219): the Newton
+    step when B is positive definite and the step fits, otherwise the minimiser on the boundary.  scipy finds the
+    latter among the real roots of a quartic (numpy.roots, ~60 us per call, with the device idle); the same point is
+    the solution of the secular equation |(B + mu I)^-1 g| = Delta, mu >= max(0, -lambda_min(B)), solved here in the
+    eigenbasis of B with Newton's method on 1/|p(mu)| - 1/Delta (monotone and concave on that interval), plain
+    Python floats.
+    """
+    a, b, c = float(B[0, 0]), float(B[0, 1]), float(B[1, 1])
+    g0, g1 = float(g[0]), float(g[1])
     det = a * c - b * b
     if a > 0 and det > 0:  # positive definite: try the Newton step
-        p = -np.array([c * g[0] - b * g[1], a * g[1] - b * g[0]]) / det
-        if p @ p <= Delta ** 2:
-            return p, True
-    # boundary solution: p = Delta (2t, 1 - t^2) / (1 + t^2); stationarity is a quartic in t
-    a, b, c = a * Delta ** 2, b * Delta ** 2, c * Delta ** 2
-    d, f = g[0] * Delta, g[1] * Delta
-    t = np.roots(np.array([-b + d, 2 * (a - c + f), 6 * b, 2 * (-a + c + f), -b - d]))
-    t = np.real(t[np.isreal(t)])
-    p = Delta * np.vstack((2 * t / (1 + t ** 2), (1 - t ** 2) / (1 + t ** 2)))
-    value = 0.5 * np.sum(p * B.dot(p), axis=0) + np.dot(g, p)
-    return p[:, np.argmin(value)], False
+        p0, p1 = -(c * g0 - b * g1) / det, -(a * g1 - b * g0) / det
+        if p0 * p0 + p1 * p1 <= Delta * Delta:
+            return np.array([p0, p1]), True
+    # eigen-decomposition B = l1 v1 v1^T + l2 v2 v2^T, l1 <= l2
+    h, d = 0.5 * (a + c), 0.5 * (a - c)
+    r = math.hypot(d, b)
+    l1, l2 = h - r, h + r
+    if r == 0.0:
+        v1x, v1y = 1.0, 0.0
+    elif d > 0:  # v2 = (d + r, b) is well conditioned, v1 is its rotation
+        n = math.hypot(d + r, b)
+        v1x, v1y = -b / n, (d + r) / n
+    else:
+        n = math.hypot(d - r, b)
+        v1x, v1y = (d - r) / n, b / n
+    v2x, v2y = -v1y, v1x
+    c1, c2 = g0 * v1x + g1 * v1y, g0 * v2x + g1 * v2y  # g in the eigenbasis
+    gn = math.hypot(c1, c2)
+    if gn == 0.0:  # no gradient: along the eigenvector of the smallest eigenvalue
+        return np.array([Delta * v1x, Delta * v1y]), False
+    lo = max(0.0, -l1)
+    # hard case: no component along v1 and the interior solution of the remaining direction is short
+    tiny = 1e-14 * gn
+    if abs(c1) <= tiny and l2 + lo > 0 and abs(c2) / (l2 + lo) < Delta:
+        q2 = -c2 / (l2 + lo)
+        q1 = math.sqrt(max(Delta * Delta - q2 * q2, 0.0))
+        return np.array([q1 * v1x + q2 * v2x, q1 * v1y + q2 * v2y]), False
+    # |p(mu)| <= |g| / (l1 + mu): the root lies in [lo, |g| / Delta - l1].  Newton on phi = 1/|p| - 1/Delta from the
+    # upper end, safeguarded by the bracket
+    mu_lo, mu_hi = lo, max(lo, gn / Delta - l1)
+    mu = mu_hi
+    for _ in range(100):
+        d1, d2 = l1 + mu, l2 + mu
+        if d1 <= 0.0:
+            mu = 0.5 * (mu_lo + mu_hi)
+            continue
+        q1, q2 = c1 / d1, c2 / d2
+        n2 = q1 * q1 + q2 * q2
+        nrm = math.sqrt(n2)
+        if nrm > Delta:
+            mu_lo = mu
+        else:
+            mu_hi = mu
+        if abs(nrm - Delta) <= 4e-16 * Delta:
+            break
+        # phi(mu) = 1/nrm - 1/Delta, phi' = (q1^2/d1 + q2^2/d2) / nrm^3
+        dphi = (q1 * q1 / d1 + q2 * q2 / d2) / (n2 * nrm)
+        step = (1.0 / nrm - 1.0 / Delta) / dphi
+        new = mu - step
+        if not (mu_lo <= new <= mu_hi) or new == mu:
+            new = 0.5 * (mu_lo + mu_hi)
+            if new == mu_lo or new == mu_hi:
+                break
+        mu = new
+    d1, d2 = l1 + mu, l2 + mu
+    q1, q2 = -c1 / d1, -c2 / d2
+    s = Delta / math.hypot(q1, q2)  # exactly on the boundary
+    q1, q2 = q1 * s, q2 * s
+    return np.array([q1 * v1x + q2 * v2x, q1 * v1y + q2 * v2y]), False
 
 
 def update_tr_radius(Delta, actual_reduction, predicted_reduction, step_norm, bound_hit):
