@@ -1,5 +1,5 @@
 // Latency of dependent operations in a single wave on gfx950 (ns per operation, wall clock 100 MHz):
-// what bounds the serial chain of the diagonal-block Cholesky.  Build: hipcc --offload-arch=gfx950 -O3 latency.hip -o latency
+// what bounds the serial chain of the diagonal-block Cholesky.  Build: hipcc --offload-arch=gfx950 -O3 latency.hip -o latency.bin
 #include <hip/hip_runtime.h>
 #include <cstdio>
 
