@@ -113,6 +113,7 @@ def main():
     ap.add_argument("--cpu-sample-pts", type=int, default=20000,
                     help="points of the CPU-baseline sub-problem (0 = skip); 20000 points = 200 k observations, ~20 s")
     ap.add_argument("--kernel-reps", type=int, default=20)
+    ap.add_argument("--loss", default="linear", help="linear (headline) | soft_l1 | huber | cauchy | arctan")
     args = ap.parse_args()
 
     import torch
@@ -136,7 +137,7 @@ def main():
     t_gen = time.perf_counter() - t_gen
     comm = trf.TorchComm() if world > 1 else trf.SingleComm()
     eng = HipEngine(p, sharding.make_shard(p, rank, world))
-    eng.configure("linear", 1.0)
+    eng.configure(args.loss, 1.0)
 
     def sync():
         torch.cuda.synchronize()
@@ -178,7 +179,7 @@ def main():
                       "LM iters/sec, config {}".format(args.shape),
             "value": args.steps / dt, "unit": "LM iters/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
+            "dtype": "f64", "data": "synthetic", "loss": args.loss,
             "config": {"workload": "{}: {} cams x {} pts x {} obs, {}, correction {}, 1 fixed camera, seed 1"
                        .format(args.shape, n_cam, n_pts, p.n_obs, model, "+".join(corr)),
                        "sharding": "points over {} rank(s)".format(world),

@@ -86,8 +86,9 @@ struct satba_problem {
     int sch3_groups_m = 0;      // groups of the moments kernel
     bool sch3_moments = false;  // affine + unit weights: pair blocks through point moments (linear loss only)
     double* d_Tbuf = nullptr;
-    double* d_Jobs = nullptr;   // RPC: stored Jacobian blocks per observation (camera-major)
-    double* d_Jpm = nullptr;    // RPC: the same in observation order (written by the linearize kernels)
+    double* d_Jpm = nullptr;    // RPC: Jacobian blocks of the current linearisation per observation (written by the linearize kernels)
+    int *d_pair_pi = nullptr, *d_pair_pj = nullptr;  // observation indices of the two observations of every pair-list entry
+    double2* d_sc = nullptr;    // Jacobian row scales of the current linearisation per observation (weighted / robust runs)
     double c0[3] = {0, 0, 0};   // expansion point of the moments
     bool c0_set = false;
     int* d_groups = nullptr;
@@ -158,6 +159,7 @@ static ObsArgs obs_args(const satba_problem* p, bool at_new) {
     a.camc = at_new ? p->d_camc_new : p->d_camc;
     a.rpc = p->d_rpc;
     a.Jpm = at_new ? nullptr : p->d_Jpm;  // stored Jacobian blocks belong to the linearisation at x
+    a.sc = (at_new || (p->loss == 0 && p->unit_weights)) ? nullptr : p->d_sc;
     a.K = p->K; a.n_tiles = p->n_tiles; a.M = p->M; a.N = p->N; a.n_c = p->n_c;
     a.n_cam_fix = p->n_cam_fix; a.n_pts_fix = p->n_pts_fix; a.loss = p->loss; a.f32 = p->f32;
     a.f_scale = p->f_scale;
@@ -273,7 +275,8 @@ static int launch_schur3(satba_problem* p, const ObsArgs& a, double* S, double* 
     Schur3Args s;
     s.bits = p->d_bits; s.rank = p->d_rank; s.Vinv = p->d_Vinv; s.gp = p->d_g + p->n_c; s.NW = p->NW; s.n_chunks = p->sch3_chunks;
     s.PV = reinterpret_cast<const double2*>(p->d_PV);
-    s.pair_ofs = p->d_pair_ofs; s.pair_pts = p->d_pair_pts; s.pair_part = p->d_pair_part; s.chunk_mul = p->sch3_chunk_mul; s.Jobs = p->d_Jobs;
+    s.pair_ofs = p->d_pair_ofs; s.pair_pts = p->d_pair_pts; s.pair_part = p->d_pair_part; s.chunk_mul = p->sch3_chunk_mul;
+    s.pair_pi = p->d_pair_pi; s.pair_pj = p->d_pair_pj;
     const long long n_pairs = (long long)p->M * (p->M - 1) / 2;
     const long long items = n_pairs * p->sch3_chunks;
     const int diag_chunks = p->lin3_chunks;
@@ -307,6 +310,9 @@ static int launch_schur3(satba_problem* p, const ObsArgs& a, double* S, double* 
         } else {
             hipLaunchKernelGGL((k_schur_pairs<MODEL, NP, false, true>), dim3(igrid), dim3(256), 0, p->stream, a, cm, s, S);
         }
+    } else if (!grp && p->d_pair_ofs && p->d_pair_pi && a.sc) {
+        // weighted / robust with pair lists that carry the observation indices: unit Jacobians times the stored scales
+        hipLaunchKernelGGL((k_schur_pairs<MODEL, NP, false, false, true>), dim3(igrid), dim3(256), 0, p->stream, a, cm, s, S);
     } else if (p->loss == 0) {
         if (grp) hipLaunchKernelGGL((k_schur_pairs_groups<MODEL, NP, false, false>), dim3(ggrid), dim3(64 * S3_GW), 0, p->stream, a, cm, s, p->d_groups, p->sch3_groups, S);
         else hipLaunchKernelGGL((k_schur_pairs<MODEL, NP, false, false>), dim3(igrid), dim3(256), 0, p->stream, a, cm, s, S);
@@ -613,7 +619,6 @@ int satba_problem_create(const satba_problem_desc* d, satba_problem** out) {
                 }
                 TRY(dev_alloc(p, &p->d_bits, bits.size())); TRY(dev_alloc(p, &p->d_rank, rank.size()));
                 TRY(dev_alloc(p, &p->d_PV, (size_t)12 * p->N));
-                if (p->model == RPC) TRY(dev_alloc(p, &p->d_Jobs, (size_t)K * (2 * p->NP + 6)));
                 p->unit_weights = 1;
                 for (long long o = 0; o < K; ++o) if (d->weights[o] != 1.0) { p->unit_weights = 0; break; }
                 HIP_TRY(hipMemcpy(p->d_bits, bits.data(), sizeof(unsigned long long) * bits.size(), hipMemcpyHostToDevice));
@@ -676,15 +681,28 @@ int satba_problem_create(const satba_problem_desc* d, satba_problem** out) {
                     }
                     const long long E = run;
                     if (E > 0 && E < (1ll << 31) && E * 4 < (8ll << 30)) {
-                        std::vector<int> pts(E);
+                        // per entry: the point and the indices of its two observations (the weighted / robust and the RPC pair
+                        // kernels fetch per-observation data there; 12 B per entry, 540 MB at 200 x 1M x 10M)
+                        const bool with_pos = !getenv("SATBA_SCHUR_NO_POS") && E * 12 < (24ll << 30);
+                        std::vector<int> pts(E), ppi(with_pos ? E : 0), ppj(with_pos ? E : 0);
                         std::vector<long long> fill((size_t)n_pairs);
                         for (long long pr = 0; pr < n_pairs; ++pr) fill[pr] = ofs[pr * (C + 1)];
                         for (int q = 0; q < p->N; ++q)  // ascending q: each pair's list comes out sorted, chunks contiguous
                             for (int x0 = pt_ofs[q]; x0 < pt_ofs[q + 1]; ++x0)
-                                for (int x1 = x0 + 1; x1 < pt_ofs[q + 1]; ++x1) pts[fill[pair_index(d->cam_ind[x0], d->cam_ind[x1])]++] = q;
+                                for (int x1 = x0 + 1; x1 < pt_ofs[q + 1]; ++x1) {
+                                    const long long at = fill[pair_index(d->cam_ind[x0], d->cam_ind[x1])]++;
+                                    pts[at] = q;
+                                    if (with_pos) { ppi[at] = x0; ppj[at] = x1; }
+                                }
                         TRY(dev_alloc(p, &p->d_pair_ofs, ofs.size())); TRY(dev_alloc(p, &p->d_pair_pts, pts.size()));
                         HIP_TRY(hipMemcpy(p->d_pair_ofs, ofs.data(), sizeof(long long) * ofs.size(), hipMemcpyHostToDevice));
                         HIP_TRY(hipMemcpy(p->d_pair_pts, pts.data(), sizeof(int) * pts.size(), hipMemcpyHostToDevice));
+                        if (with_pos) {
+                            TRY(dev_alloc(p, &p->d_pair_pi, ppi.size())); TRY(dev_alloc(p, &p->d_pair_pj, ppj.size()));
+                            HIP_TRY(hipMemcpy(p->d_pair_pi, ppi.data(), sizeof(int) * ppi.size(), hipMemcpyHostToDevice));
+                            HIP_TRY(hipMemcpy(p->d_pair_pj, ppj.data(), sizeof(int) * ppj.size(), hipMemcpyHostToDevice));
+                            TRY(dev_alloc(p, &p->d_sc, (size_t)K));
+                        }
                         p->sch3_chunks = Cc;
                         if (stream || moments) {  // groups of pairs (i, j0 ..) of one camera i: 8 (10 with six lanes per pair)
                             std::vector<int> groups;

@@ -38,6 +38,9 @@ struct ObsArgs {
     double* __restrict__ Jpm;          // RPC only (else null): K x (2 NP + 6) Jacobian blocks Jc | Jp of the current
                                        // linearisation, observation order; written by the linearize kernels and read by
                                        // every later pass (the RPC chain costs 2-3 kflop per evaluation)
+    double2* __restrict__ sc;          // weighted / robust runs (else null): K Jacobian row scales (w js0, w js1) of the current
+                                       // linearisation, observation order; written by the linearize kernels, read by the
+                                       // Schur pair kernel
     long long K;
     int n_tiles, M, N, n_c, n_cam_fix, n_pts_fix, loss, f32;
     double f_scale;
@@ -51,6 +54,7 @@ struct ObsEval {
     double rho;       // contribution to 2 * cost
     double Jc[2][NP];
     double Jp[2][3];
+    double sw[2];     // Jacobian row scales w * js (before the fixed-camera / fixed-point masks)
 
     __device__ inline void eval(const ObsArgs& a, long long o, int cam, int pt) {
         eval(a, o, cam, pt, a.camc + (size_t)cam * CAMC);
@@ -80,6 +84,7 @@ struct ObsEval {
             const double mc = (cam >= a.n_cam_fix) ? 1.0 : 0.0;
             const double mp = (pt >= a.n_pts_fix) ? 1.0 : 0.0;
             const double s0 = w * js0, s1 = w * js1;
+            sw[0] = s0; sw[1] = s1;
 #pragma unroll
             for (int i = 0; i < NP; ++i) { Jc[0][i] *= s0 * mc; Jc[1][i] *= s1 * mc; }
 #pragma unroll
@@ -267,6 +272,7 @@ __global__ __launch_bounds__(LinCfg<ROBUST>::THREADS) void k_linearize(ObsArgs a
             ObsEval<MODEL, NP, true, ROBUST> e;
             e.eval(a, o, cam, pt, cbase + (size_t)cam * CAMC);
             if constexpr (MODEL == RPC) { if (a.Jpm) e.store_jac(a, o); }
+            if (a.sc) a.sc[o] = make_double2(e.sw[0], e.sw[1]);
             f[o] = make_double2(e.ftrue[0], e.ftrue[1]);
             cost += e.rho;
             // per-point products into the wave's staging rows (conflict-free 8-byte stores)

@@ -45,6 +45,7 @@ __global__ __launch_bounds__(256) void k_lin_points(ObsArgs a, Lin3Args s) {
             ObsEval<MODEL, NP, true, ROBUST> e;
             e.eval(a, o, cam, p, cbase + (size_t)cam * CAMC);
             if constexpr (MODEL == RPC) { if (a.Jpm) e.store_jac(a, o); }
+            if (a.sc) a.sc[o] = make_double2(e.sw[0], e.sw[1]);
             s.f[o] = make_double2(e.ftrue[0], e.ftrue[1]);
             cost += e.rho;
             v[0] += e.Jp[0][0] * e.Jp[0][0] + e.Jp[1][0] * e.Jp[1][0];

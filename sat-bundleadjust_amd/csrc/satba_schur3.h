@@ -32,8 +32,9 @@ struct Schur3Args {
     const int* __restrict__ pair_pts;             // points shared by each camera pair, ascending (static per problem)
     double* __restrict__ pair_part;               // n_chunks x n_pairs x NP*NP partial blocks (list path, n_chunks > 1)
     int chunk_mul;                                // the lists are cut into n_chunks * chunk_mul fine chunks (pair_ofs stride + 1)
-    double* __restrict__ Jobs;                    // RPC: K x (2 NP + 6) Jacobian blocks Jc | Jp per observation, camera-major,
-                                                  // written by k_schur_diag, read by k_schur_pairs (null otherwise)
+    const int* __restrict__ pair_pi;              // per list entry: observation index (point-major order) of the point's observation
+    const int* __restrict__ pair_pj;              //   in camera i / j (null: not built); per-observation data of the two lies within
+                                                  //   the point's contiguous run of observations
     int NW;                                       // words per camera
     int n_chunks;                                 // word-range chunks per pair (1: plain stores, >1: atomics)
 };
@@ -44,7 +45,8 @@ constexpr int S3_QUEUE = 128;  // per-wave hit queue (entries): < 64 pending + a
 // UNITW: every observation weight is 1 and the loss is linear -> nothing has to be fetched per observation
 template <int MODEL, int NP, bool ROBUST, bool UNITW = false>
 __device__ inline void cm_jacobian(const ObsArgs& a, const CamMajor& c, const double* cc, const double* tab, int cam,
-                                   int pos, int pt, double X, double Y, double Z, double Jc[2][NP], double Jp[2][3]) {
+                                   int pos, int pt, double X, double Y, double Z, double Jc[2][NP], double Jp[2][3],
+                                   double2* scales = nullptr) {
     double w = 1.0;
     if constexpr (!UNITW) w = c.w[pos];
     double u, v;
@@ -62,6 +64,7 @@ __device__ inline void cm_jacobian(const ObsArgs& a, const CamMajor& c, const do
     for (int k = 0; k < NP; ++k) { Jc[0][k] *= s0 * mc; Jc[1][k] *= s1 * mc; }
 #pragma unroll
     for (int k = 0; k < 3; ++k) { Jp[0][k] *= s0 * mp; Jp[1][k] *= s1 * mp; }
+    if (scales) *scales = make_double2(s0, s1);
 }
 
 // Wave "reduce-scatter": N (power of two) values per lane are summed over the 64 lanes with N - 1 + (6 - log2 N)
@@ -96,7 +99,9 @@ __device__ inline int rs_index(int lane) {
 }
 
 // grid: one wave per (pair, chunk); 4 waves per workgroup.  pair index -> (i, j), i < j.
-template <int MODEL, int NP, bool ROBUST, bool UNITW>
+// SCL (weighted / robust runs with pair lists that carry observation indices): unit-weight Jacobians times the stored
+// row scales -- a separate instantiation, so that it does not carry the registers of the robust evaluation
+template <int MODEL, int NP, bool ROBUST, bool UNITW, bool SCL = false>
 __global__ __launch_bounds__(256) void k_schur_pairs(ObsArgs a, CamMajor c, Schur3Args s, double* __restrict__ S) {
     __shared__ int s_q[4][S3_QUEUE];  // shared points of the two cameras waiting to be evaluated
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -138,29 +143,28 @@ __global__ __launch_bounds__(256) void k_schur_pairs(ObsArgs a, CamMajor c, Schu
         r.r0 = pv[0]; r.r1 = pv[1]; r.r2 = pv[2]; r.r3 = pv[3]; r.r4 = pv[4];
         return r;
     };
-    auto compute = [&](int p, const Rec& rc) {
-        int pi = 0, pj = 0;
-        if constexpr (!UNITW) {
-            // position of (camera, point) in the camera-major arrays: rank of the word + bits below the point's bit
-            const int w = p >> 6;
-            const unsigned long long below = (1ull << (p & 63)) - 1ull;
-            pi = base_i + ri[w] + __popcll(bi[w] & below);
-            pj = base_j + rj[w] + __popcll(bj[w] & below);
+    // listpos: pi, pj = observation indices of (camera i, point) and (camera j, point) from the pair list, scl = the
+    // Jacobian row scales of the two observations (weighted / robust runs) -- the Jacobians are then evaluated for unit weight and linear loss and scaled, which is what
+    // the weighted / robust evaluation does, without fetching the observation or running the loss function
+    auto compute = [&](int p, const Rec& rc, int pi, int pj, const double2& scl_i, const double2& scl_j, bool listpos) {
+        if (!listpos) {
+            pi = pj = 0;
+            if constexpr ((!UNITW && !SCL) || MODEL == RPC) {
+                const int w = p >> 6;
+                const unsigned long long below = (1ull << (p & 63)) - 1ull;
+                pi = base_i + ri[w] + __popcll(bi[w] & below);
+                pj = base_j + rj[w] + __popcll(bj[w] & below);
+                if constexpr (MODEL == RPC) { pi = c.oidx[pi]; pj = c.oidx[pj]; }  // the stored blocks are in observation order
+            }
         }
         const double X = rc.r0.x, Y = rc.r0.y, Z = rc.r1.x;
         const double v00 = rc.r1.y, v01 = rc.r2.x, v02 = rc.r2.y, v11 = rc.r3.x, v12 = rc.r3.y, v22 = rc.r4.x;
         double Jci[2][NP], Jpi[2][3], Jcj[2][NP], Jpj[2][3];
         if constexpr (MODEL == RPC) {
             // the RPC chain costs 2-3 kflop per Jacobian and every observation sits in (track length - 1) pairs:
-            // the blocks k_schur_diag stored for this linearisation are gathered instead of being recomputed
-            if constexpr (UNITW) {
-                const int w = p >> 6;
-                const unsigned long long below = (1ull << (p & 63)) - 1ull;
-                pi = base_i + ri[w] + __popcll(bi[w] & below);
-                pj = base_j + rj[w] + __popcll(bj[w] & below);
-            }
-            const double2* qi = reinterpret_cast<const double2*>(s.Jobs + (size_t)pi * (2 * NP + 6));
-            const double2* qj = reinterpret_cast<const double2*>(s.Jobs + (size_t)pj * (2 * NP + 6));
+            // the blocks the linearize kernel stored are gathered instead of being recomputed
+            const double2* qi = reinterpret_cast<const double2*>(a.Jpm + (size_t)pi * (2 * NP + 6));
+            const double2* qj = reinterpret_cast<const double2*>(a.Jpm + (size_t)pj * (2 * NP + 6));
             double ti[2 * NP + 6], tj[2 * NP + 6];
 #pragma unroll
             for (int k = 0; k < NP + 3; ++k) {
@@ -174,6 +178,13 @@ __global__ __launch_bounds__(256) void k_schur_pairs(ObsArgs a, CamMajor c, Schu
                 Jpi[0][k] = ti[2 * NP + k]; Jpi[1][k] = ti[2 * NP + 3 + k];
                 Jpj[0][k] = tj[2 * NP + k]; Jpj[1][k] = tj[2 * NP + 3 + k];
             }
+        } else if constexpr (SCL) {
+            cm_jacobian<MODEL, NP, false, true>(a, c, cci, tabi, i, 0, p, X, Y, Z, Jci, Jpi);
+            cm_jacobian<MODEL, NP, false, true>(a, c, ccj, tabj, j, 0, p, X, Y, Z, Jcj, Jpj);
+#pragma unroll
+            for (int k = 0; k < NP; ++k) { Jci[0][k] *= scl_i.x; Jci[1][k] *= scl_i.y; Jcj[0][k] *= scl_j.x; Jcj[1][k] *= scl_j.y; }
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { Jpi[0][k] *= scl_i.x; Jpi[1][k] *= scl_i.y; Jpj[0][k] *= scl_j.x; Jpj[1][k] *= scl_j.y; }
         } else {
             cm_jacobian<MODEL, NP, ROBUST, UNITW>(a, c, cci, tabi, i, pi, p, X, Y, Z, Jci, Jpi);
             cm_jacobian<MODEL, NP, ROBUST, UNITW>(a, c, ccj, tabj, j, pj, p, X, Y, Z, Jcj, Jpj);
@@ -201,7 +212,7 @@ __global__ __launch_bounds__(256) void k_schur_pairs(ObsArgs a, CamMajor c, Schu
     auto process_point = [&](int p, bool valid) {
         if (!valid) return;
         const Rec rc = load_rec(p);
-        compute(p, rc);
+        compute(p, rc, -1, -1, make_double2(1.0, 1.0), make_double2(1.0, 1.0), false);
     };
     auto process = [&](int slot, bool valid) { process_point(valid ? s_q[wave][slot] : 0, valid); };
 
@@ -212,22 +223,37 @@ __global__ __launch_bounds__(256) void k_schur_pairs(ObsArgs a, CamMajor c, Schu
         const int CF1 = s.n_chunks * s.chunk_mul + 1;  // this kernel works on groups of chunk_mul fine chunks
         const long long lo = s.pair_ofs[pair * CF1 + chunk * s.chunk_mul], hi = s.pair_ofs[pair * CF1 + (chunk + 1) * s.chunk_mul];
         // software pipeline: the next point's index and record are in flight while the current one is evaluated
+        constexpr bool POS = !UNITW || MODEL == RPC;  // positions (and, weighted / robust, scales) ride along
+        const bool listpos = POS && s.pair_pi != nullptr;
         long long idx = lo + lane;
-        int p_cur = (idx < hi) ? s.pair_pts[idx] : 0;
-        int p_nxt = (idx + 64 < hi) ? s.pair_pts[idx + 64] : 0;
+        auto ld = [&](const int* arr, long long k) { return (k < hi) ? arr[k] : 0; };
+        int p_cur = ld(s.pair_pts, idx), p_nxt = ld(s.pair_pts, idx + 64);
+        int pi_cur = 0, pj_cur = 0, pi_nxt = 0, pj_nxt = 0;
+        double2 si_cur = make_double2(1.0, 1.0), sj_cur = si_cur;
+        if (listpos) {
+            pi_cur = ld(s.pair_pi, idx); pj_cur = ld(s.pair_pj, idx);
+            pi_nxt = ld(s.pair_pi, idx + 64); pj_nxt = ld(s.pair_pj, idx + 64);
+            if constexpr (!UNITW) { si_cur = a.sc[pi_cur]; sj_cur = a.sc[pj_cur]; }
+        }
         Rec r_cur = load_rec(p_cur);
         while (idx < hi) {
             // indices run two iterations ahead, records one: neither latency is on the critical path
-            const int p_nn = (idx + 128 < hi) ? s.pair_pts[idx + 128] : 0;
+            const int p_nn = ld(s.pair_pts, idx + 128);
+            int pi_nn = 0, pj_nn = 0;
+            double2 si_nxt = make_double2(1.0, 1.0), sj_nxt = si_nxt;
+            if (listpos) {
+                pi_nn = ld(s.pair_pi, idx + 128); pj_nn = ld(s.pair_pj, idx + 128);
+                if constexpr (!UNITW) { si_nxt = a.sc[pi_nxt]; sj_nxt = a.sc[pj_nxt]; }
+            }
             const Rec r_nxt = load_rec(p_nxt);
             // keep the gathers above the arithmetic: without the barrier the scheduler sinks them below compute() to
             // save registers and every iteration pays the full memory latency
             __builtin_amdgcn_sched_barrier(0);
-            compute(p_cur, r_cur);
+            compute(p_cur, r_cur, pi_cur, pj_cur, si_cur, sj_cur, listpos);
             __builtin_amdgcn_sched_barrier(0);
-            p_cur = p_nxt;
-            p_nxt = p_nn;
-            r_cur = r_nxt;
+            p_cur = p_nxt; p_nxt = p_nn; r_cur = r_nxt;
+            pi_cur = pi_nxt; pj_cur = pj_nxt; pi_nxt = pi_nn; pj_nxt = pj_nn;
+            si_cur = si_nxt; sj_cur = sj_nxt;
             idx += 64;
         }
     } else {
@@ -629,18 +655,6 @@ __global__ __launch_bounds__(LINC_THREADS) void k_schur_diag(ObsArgs a, CamMajor
             }
         }
         if (!have) cm_jacobian<MODEL, NP, ROBUST>(a, c, cc, tab, cam, pos, p, r0.x, r0.y, r1.x, Jc, Jp);
-        if constexpr (MODEL == RPC) {
-            if (s.Jobs) {
-                double t[2 * NP + 6];
-#pragma unroll
-                for (int k = 0; k < NP; ++k) { t[k] = Jc[0][k]; t[NP + k] = Jc[1][k]; }
-#pragma unroll
-                for (int k = 0; k < 3; ++k) { t[2 * NP + k] = Jp[0][k]; t[2 * NP + 3 + k] = Jp[1][k]; }
-                double2* q = reinterpret_cast<double2*>(s.Jobs + (size_t)pos * (2 * NP + 6));
-#pragma unroll
-                for (int k = 0; k < NP + 3; ++k) q[k] = make_double2(t[2 * k], t[2 * k + 1]);
-            }
-        }
         const double v00 = r1.y, v01 = r2.x, v02 = r2.y, v11 = r3.x, v12 = r3.y, v22 = r4.x;
         double A[2][3];
 #pragma unroll
