@@ -577,6 +577,7 @@ int satba_problem_create(const satba_problem_desc* d, satba_problem** out) {
             HIP_TRY(hipMemcpy(p->dag.d_tasks, tasks.data(), sizeof(DagTask) * tasks.size(), hipMemcpyHostToDevice));
             if (getenv("SATBA_DAG_TIMES")) TRY(dev_alloc(p, &p->dag.d_times, 4 * tasks.size()));
         }
+        TRY(dev_alloc(p, &p->d_sc, (size_t)std::max<long long>(K, 1)));  // row scales of weighted / robust runs
         if (p->model == RPC && !getenv("SATBA_RPC_RECOMPUTE")) TRY(dev_alloc(p, &p->d_Jpm, (size_t)std::max<long long>(K, 1) * (2 * p->NP + 6)));
         TRY(dev_alloc(p, &p->d_scal, 8));
         TRY(dev_alloc(p, &p->d_keep, SATBA_KEEP_LEN));
@@ -701,7 +702,6 @@ int satba_problem_create(const satba_problem_desc* d, satba_problem** out) {
                             TRY(dev_alloc(p, &p->d_pair_pi, ppi.size())); TRY(dev_alloc(p, &p->d_pair_pj, ppj.size()));
                             HIP_TRY(hipMemcpy(p->d_pair_pi, ppi.data(), sizeof(int) * ppi.size(), hipMemcpyHostToDevice));
                             HIP_TRY(hipMemcpy(p->d_pair_pj, ppj.data(), sizeof(int) * ppj.size(), hipMemcpyHostToDevice));
-                            TRY(dev_alloc(p, &p->d_sc, (size_t)K));
                         }
                         p->sch3_chunks = Cc;
                         if (stream || moments) {  // groups of pairs (i, j0 ..) of one camera i: 8 (10 with six lanes per pair)
