@@ -244,6 +244,9 @@ static int launch_lin1u(satba_problem* p, const ObsArgs& a) {
     if (p->loss == 0)
         hipLaunchKernelGGL((k_linearize<MODEL, NP, false, CL, FULLU>), dim3(p->lin_grid), dim3(LinCfg<false>::THREADS),
                            lin1_lds(p, false), p->stream, a, p->d_f, p->d_V, gpv, p->d_part, cost, gmax);
+    else if (p->loss == SATBA_LOSS_SOFT_L1 && MODEL != RPC)  // the pipeline's robust loss, specialised (RPC needs the registers)
+        hipLaunchKernelGGL((k_linearize<MODEL, NP, true, CL, FULLU, MODEL != RPC>), dim3(p->lin_grid), dim3(LinCfg<MODEL == RPC>::THREADS),
+                           lin1_lds(p, MODEL == RPC), p->stream, a, p->d_f, p->d_V, gpv, p->d_part, cost, gmax);
     else
         hipLaunchKernelGGL((k_linearize<MODEL, NP, true, CL, FULLU>), dim3(p->lin_grid), dim3(LinCfg<true>::THREADS),
                            lin1_lds(p, true), p->stream, a, p->d_f, p->d_V, gpv, p->d_part, cost, gmax);

@@ -47,7 +47,8 @@ struct ObsArgs {
 };
 
 // weighted, robust-scaled residual and (optionally) Jacobian blocks of observation o
-template <int MODEL, int NP, bool JAC, bool ROBUST = true>
+// ROBUST: the loss is not linear; SOFT: it is soft_l1 (folds the runtime loss switch away: registers, no log / atan code)
+template <int MODEL, int NP, bool JAC, bool ROBUST = true, bool SOFT = false>
 struct ObsEval {
     double ftrue[2];  // w * (proj - obs)
     double fs[2];     // robust-scaled residual
@@ -73,8 +74,9 @@ struct ObsEval {
         ftrue[1] = w * (v - ob.y);
         double r0, r1, js0 = 1.0, js1 = 1.0;
         if constexpr (ROBUST) {
-            robust(a.loss, a.f_scale, ftrue[0], r0, fs[0], js0);
-            robust(a.loss, a.f_scale, ftrue[1], r1, fs[1], js1);
+            const int loss = SOFT ? 1 : a.loss;
+            robust(loss, a.f_scale, ftrue[0], r0, fs[0], js0);
+            robust(loss, a.f_scale, ftrue[1], r1, fs[1], js1);
         } else {  // linear loss, specialised at compile time (no transcendental code, far fewer registers)
             fs[0] = ftrue[0]; fs[1] = ftrue[1];
             r0 = ftrue[0] * ftrue[0]; r1 = ftrue[1] * ftrue[1];
@@ -246,7 +248,7 @@ constexpr int LIN_STAGE = 65;
 
 template <bool ROBUST>
 struct LinCfg {
-    static constexpr int THREADS = ROBUST ? 512 : 1024;  // the robust variants need > 128 VGPRs
+    static constexpr int THREADS = ROBUST ? 512 : 1024;  // the generic robust variants need > 128 VGPRs
     static constexpr int WAVES = THREADS / 64;
 };
 
@@ -254,12 +256,13 @@ struct LinCfg {
 // FULLU = false: only diag(U_c) and g_c are accumulated (2 NP atomics per observation instead of NP(NP+3)/2): that
 // is all the solver needs before the Schur phase, whose camera-major pass (k_schur_diag) forms the full J_c^T J_c
 // blocks in registers anyway.
-template <int MODEL, int NP, bool ROBUST, bool CL, bool FULLU>
-__global__ __launch_bounds__(LinCfg<ROBUST>::THREADS) void k_linearize(ObsArgs a, double2* __restrict__ f, double* __restrict__ V,
+// SOFT (with ROBUST): soft_l1 specialised at compile time; it fits the 1024-thread configuration of the linear loss
+template <int MODEL, int NP, bool ROBUST, bool CL, bool FULLU, bool SOFT = false>
+__global__ __launch_bounds__(LinCfg<ROBUST && !SOFT>::THREADS) void k_linearize(ObsArgs a, double2* __restrict__ f, double* __restrict__ V,
                                                                       double* __restrict__ gp, double* __restrict__ part,
                                                                       double* __restrict__ hdr_cost, double* __restrict__ hdr_gpmax) {
     constexpr int CU = cam_acc_len(NP), CUS = cam_acc_stride(NP);
-    constexpr int THREADS = LinCfg<ROBUST>::THREADS, WAVES = LinCfg<ROBUST>::WAVES;
+    constexpr int THREADS = LinCfg<ROBUST && !SOFT>::THREADS, WAVES = LinCfg<ROBUST && !SOFT>::WAVES;
     extern __shared__ double s_lin[];
     double* s_acc = s_lin;                                          // M * CUS
     double* s_camc = s_acc + (size_t)a.M * CUS;                     // M * CAMC
@@ -283,7 +286,7 @@ __global__ __launch_bounds__(LinCfg<ROBUST>::THREADS) void k_linearize(ObsArgs a
         if (active) {
             cam = a.cam[o];
             pt = a.pt[o];
-            ObsEval<MODEL, NP, true, ROBUST> e;
+            ObsEval<MODEL, NP, true, ROBUST, SOFT> e;
             e.eval(a, o, cam, pt, cbase + (size_t)cam * CAMC);
             if constexpr (MODEL == RPC) { if (a.Jpm) e.store_jac(a, o); }
             if (a.sc) a.sc[o] = make_double2(e.sw[0], e.sw[1]);
