@@ -163,6 +163,7 @@ static ObsArgs obs_args(const satba_problem* p, bool at_new) {
     a.K = p->K; a.n_tiles = p->n_tiles; a.M = p->M; a.N = p->N; a.n_c = p->n_c;
     a.n_cam_fix = p->n_cam_fix; a.n_pts_fix = p->n_pts_fix; a.loss = p->loss; a.f32 = p->f32;
     a.f_scale = p->f_scale;
+    a.unit = (p->loss == 0 && p->unit_weights) ? 1 : 0;
     return a;
 }
 
@@ -869,8 +870,11 @@ int satba_linearize(satba_problem* p) {
         p->linearized = true; p->have_step = false;
         return 0;
     }
+    // unit weights + linear loss + affine R+T: the translation entries of diag(U_c) are (observation count) x constants
+    // and were not accumulated by the kernel (lin_const_t in satba_kernels.h)
+    const bool const_t = !p->u_full && lin_const_t(p->model, p->NP, p->loss != 0, p->loss == 0 && p->unit_weights);
     hipLaunchKernelGGL(k_lin_finish, dim3((total + 63) / 64), dim3(1024), 0, p->stream, p->M, p->NP, lin_partials(p), p->d_part,
-                       nullptr, U, gc);
+                       nullptr, U, gc, const_t ? p->d_cam_ofs : nullptr, p->d_camc, p->n_cam_fix);
     HIP_TRY(hipGetLastError());
     p->linearized = true; p->have_step = false;
     return 0;

@@ -43,6 +43,7 @@ struct ObsArgs {
                                        // Schur pair kernel
     long long K;
     int n_tiles, M, N, n_c, n_cam_fix, n_pts_fix, loss, f32;
+    int unit;                          // every weight is 1 and the loss is linear
     double f_scale;
 };
 
@@ -66,7 +67,12 @@ struct ObsEval {
         const double2 ob = a.obs[o];
         const double w = a.w[o];
         const double* px = a.x + a.n_c + 3 * (size_t)pt;
-        const double X = px[0], Y = px[1], Z = px[2];
+        eval_loaded(a, cam, pt, cc, ob, w, px[0], px[1], px[2]);
+    }
+
+    // the same with the observation, its weight and the point already in registers (software-pipelined callers)
+    __device__ inline void eval_loaded(const ObsArgs& a, int cam, int pt, const double* cc, const double2 ob, const double w,
+                                       const double X, const double Y, const double Z) {
         const double* tab = (MODEL == RPC) ? a.rpc + (size_t)cam * 90 : nullptr;
         double u, v;
         project<MODEL, NP, JAC>(cc, tab, X, Y, Z, a.f32 != 0, u, v, Jc, Jp);
@@ -246,6 +252,13 @@ __global__ __launch_bounds__(512) void k_residual(ObsArgs a, double2* __restrict
 // bank pairs when the run sums read them (a stride of 64 puts them all in the same one)
 constexpr int LIN_STAGE = 65;
 
+// Affine cameras with R+T corrected, unit weights, linear loss: d(col,row)/dT = [[fx, skew], [0, fy]] for every
+// observation, so the two translation entries of diag(U_c) are n_obs(c) * fx^2 and n_obs(c) * (skew^2 + fy^2).  The
+// kernel skips those two LDS atomics (8 instead of 10 per observation) and k_lin_finish fills the entries in.
+__host__ __device__ constexpr bool lin_const_t(int model, int np, bool robust, bool unit) {
+    return model == AFFINE && np == 5 && !robust && unit;
+}
+
 template <bool ROBUST>
 struct LinCfg {
     static constexpr int THREADS = ROBUST ? 512 : 1024;  // the generic robust variants need > 128 VGPRs
@@ -278,16 +291,59 @@ __global__ __launch_bounds__(LinCfg<ROBUST && !SOFT>::THREADS) void k_linearize(
     double* stage = s_stage + (size_t)wave * 9 * LIN_STAGE;
 
     double cost = 0.0, gmax = 0.0;
-    for (int tile = blockIdx.x * WAVES + wave; tile < a.n_tiles; tile += gridDim.x * WAVES) {
-        const int o0 = a.tile_start[tile], o1 = a.tile_start[tile + 1];
+    // Software pipeline (PIPE): a tile costs three dependent global loads (tile range -> observation record -> point)
+    // before the first flop and ~300 clocks of LDS traffic after it; with 4 waves per SIMD those latencies were
+    // exposed.  The record of the NEXT tile is requested before the arithmetic of the current one, its point
+    // gather before the run sums, the range of the tile after next before that.  RPC keeps the plain loop
+    // (register budget).
+    constexpr bool PIPE = MODEL != RPC;
+    const bool const_t = !FULLU && lin_const_t(MODEL, NP, ROBUST, a.unit != 0);
+    const int stride = gridDim.x * WAVES;
+    int tile = blockIdx.x * WAVES + wave;
+    // ranges: wave-uniform -> scalar loads
+    auto range = [&](int t, int& r0, int& r1, int& rs) {
+        const int tu = __builtin_amdgcn_readfirstlane(t);
+        if (tu < a.n_tiles) { r0 = a.tile_start[tu]; r1 = a.tile_start[tu + 1]; rs = a.tile_split[tu]; } else { r0 = 0; r1 = 0; rs = 0; }
+    };
+    int o0, o1, osplit, n0 = 0, n1 = 0, nsplit = 0;
+    range(tile, o0, o1, osplit);
+    int cam = 0, pt = -1 - lane, ncam = 0, npt = -1 - lane;
+    double2 ob = make_double2(0.0, 0.0), nob = make_double2(0.0, 0.0);
+    double w = 0.0, nw = 0.0, X = 0.0, Y = 0.0, Z = 0.0, nX = 0.0, nY = 0.0, nZ = 0.0;
+    if constexpr (PIPE) {
+        if (o0 + lane < o1) {
+            const long long o = (long long)o0 + lane;
+            pt = a.pt[o]; cam = a.cam[o]; ob = a.obs[o]; w = a.w[o];
+            const double* px = a.x + a.n_c + 3 * (size_t)pt;
+            X = px[0]; Y = px[1]; Z = px[2];
+        }
+        range(tile + stride, n0, n1, nsplit);
+    }
+    for (; tile < a.n_tiles; tile += stride) {
         const long long o = (long long)o0 + lane;
         const bool active = o < o1;
-        int pt = -1 - lane, cam = 0;
+        int nn0 = 0, nn1 = 0, nnsplit = 0;
+        if constexpr (PIPE) {
+            // request the next tile's record and the range after it
+            npt = -1 - lane; ncam = 0;
+            if (n0 + lane < n1) {
+                const long long on = (long long)n0 + lane;
+                npt = a.pt[on]; ncam = a.cam[on]; nob = a.obs[on]; nw = a.w[on];
+            }
+            range(tile + 2 * stride, nn0, nn1, nnsplit);
+            __builtin_amdgcn_sched_barrier(0);
+        } else {
+            pt = -1 - lane; cam = 0;
+        }
         if (active) {
-            cam = a.cam[o];
-            pt = a.pt[o];
             ObsEval<MODEL, NP, true, ROBUST, SOFT> e;
-            e.eval(a, o, cam, pt, cbase + (size_t)cam * CAMC);
+            if constexpr (PIPE) {
+                e.eval_loaded(a, cam, pt, cbase + (size_t)cam * CAMC, ob, w, X, Y, Z);
+            } else {
+                cam = a.cam[o];
+                pt = a.pt[o];
+                e.eval(a, o, cam, pt, cbase + (size_t)cam * CAMC);
+            }
             if constexpr (MODEL == RPC) { if (a.Jpm) e.store_jac(a, o); }
             if (a.sc) a.sc[o] = make_double2(e.sw[0], e.sw[1]);
             f[o] = make_double2(e.ftrue[0], e.ftrue[1]);
@@ -310,7 +366,8 @@ __global__ __launch_bounds__(LinCfg<ROBUST && !SOFT>::THREADS) void k_linearize(
             for (int i = 0; i < NP; ++i)
 #pragma unroll
                 for (int j = i; j < NP; ++j) {
-                    if (FULLU || i == j) atomicAdd(acc + k, e.Jc[0][i] * e.Jc[0][j] + e.Jc[1][i] * e.Jc[1][j]);
+                    if (FULLU || (i == j && !(const_t && i >= 3)))
+                        atomicAdd(acc + k, e.Jc[0][i] * e.Jc[0][j] + e.Jc[1][i] * e.Jc[1][j]);
                     ++k;
                 }
 #pragma unroll
@@ -325,6 +382,15 @@ __global__ __launch_bounds__(LinCfg<ROBUST && !SOFT>::THREADS) void k_linearize(
             for (int i = 0; i < NP; ++i) t += e.Jc[0][i] * e.fs[0] + e.Jc[1][i] * e.fs[1];
             atomicAdd(acc + k, t);
 #endif
+        }
+        if constexpr (PIPE) {
+            // the next tile's points: in flight during the run sums
+            __builtin_amdgcn_sched_barrier(0);
+            if (npt >= 0) {
+                const double* px = a.x + a.n_c + 3 * (size_t)npt;
+                nX = px[0]; nY = px[1]; nZ = px[2];
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
 #ifndef SATBA_ABLATE_POINT_SUMS
         // runs of equal point index -> lane (q, v) sums value v over run q (7 runs per pass); no shuffles
@@ -353,12 +419,18 @@ __global__ __launch_bounds__(LinCfg<ROBUST && !SOFT>::THREADS) void k_linearize(
                 }
                 const double sum = (s0 + s1) + (s2 + s3);
                 double* dst = (v < 6) ? V + 6 * (size_t)ptq + v : gp + 3 * (size_t)ptq + (v - 6);
-                if (a.tile_split[tile]) atomicAdd(dst, sum);
+                if (osplit) atomicAdd(dst, sum);
                 else *dst = sum;
                 if (v >= 6) gmax = fmax(gmax, fabs(sum));
             }
         }
 #endif
+        if constexpr (PIPE) {
+            o0 = n0; o1 = n1; osplit = nsplit; n0 = nn0; n1 = nn1; nsplit = nnsplit;
+            cam = ncam; pt = npt; ob = nob; w = nw; X = nX; Y = nY; Z = nZ;
+        } else {
+            range(tile + stride, o0, o1, osplit);
+        }
     }
     // per-workgroup epilogue
     __shared__ double s_red[2][WAVES];
@@ -380,7 +452,8 @@ __global__ __launch_bounds__(LinCfg<ROBUST && !SOFT>::THREADS) void k_linearize(
 // 64 outputs per workgroup, 16 waves each summing a strided subset of the workgroups, combined through LDS.
 __global__ __launch_bounds__(1024) void k_lin_finish(int M, int NP, int nblocks, const double* __restrict__ part,
                                                      const double* __restrict__ overflow, double* __restrict__ U,
-                                                     double* __restrict__ gc) {
+                                                     double* __restrict__ gc, const int* __restrict__ cam_ofs,
+                                                     const double* __restrict__ camc, int n_cam_fix) {
     const int CU = cam_acc_len(NP);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int idx = blockIdx.x * 64 + lane;
@@ -404,6 +477,12 @@ __global__ __launch_bounds__(1024) void k_lin_finish(int M, int NP, int nblocks,
     int i = 0, rem = k;
     while (rem >= NP - i) { rem -= NP - i; ++i; }
     const int j = i + rem;
+    if (cam_ofs && i == j && i >= 3) {  // lin_const_t: translation entries of diag(U_c) in closed form
+        const double* cc = camc + (size_t)cam * CAMC;
+        const double fx = cc[17], fy = cc[18], sk = cc[19];
+        const double cnt = cam >= n_cam_fix ? (double)(cam_ofs[cam + 1] - cam_ofs[cam]) : 0.0;
+        s = cnt * (i == 3 ? fx * fx : sk * sk + fy * fy);
+    }
     U[(size_t)cam * NP * NP + i * NP + j] = s;
     U[(size_t)cam * NP * NP + j * NP + i] = s;
 }

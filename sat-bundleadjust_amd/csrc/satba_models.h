@@ -200,10 +200,15 @@ __device__ inline void project(const double* __restrict__ cc, const double* __re
                 Jc[0][3] = fx; Jc[0][4] = sk;
                 Jc[1][3] = 0.0; Jc[1][4] = fy;
             }
+            // rows 0 and 1 of R from the six trig values already in registers (same expressions as cam_constants):
+            // six fewer gathers from the LDS camera table per observation; the kernels are bound by the LDS pipe
+            const double ca = cc[0], sa = cc[1], cb = cc[2], sb = cc[3], cg = cc[4], sg = cc[5];
+            const double R0[3] = {cg * cb, cg * sb * sa - sg * ca, cg * sb * ca + sg * sa};
+            const double R1[3] = {sg * cb, sg * sb * sa + cg * ca, sg * sb * ca - cg * sa};
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
-                Jp[0][j] = fx * cc[6 + j] + sk * cc[9 + j];
-                Jp[1][j] = fy * cc[9 + j];
+                Jp[0][j] = fx * R0[j] + sk * R1[j];
+                Jp[1][j] = fy * R1[j];
             }
         }
     } else if constexpr (MODEL == PERSPECTIVE) {
