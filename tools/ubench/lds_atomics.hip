@@ -25,6 +25,9 @@ __global__ __launch_bounds__(1024) void k(double* out, int spread) {
         else if (MODE == 4) acc += tab[idx];                                                // ds_read_b64
         else if (MODE == 5) tab[idx] = (double)it;                                          // ds_write_b64
         else if (MODE == 6) acc += (double)atomicAdd((unsigned*)&tab[idx], 1u);             // ds_add_rtn_u32
+        else if (MODE == 7) { const double2 t = *reinterpret_cast<const double2*>(&tab[idx & ~1]); acc += t.x + t.y; }  // ds_read_b128
+        else if (MODE == 8) *reinterpret_cast<double2*>(&tab[idx & ~1]) = make_double2((double)it, 1.0);           // ds_write_b128
+        else if (MODE == 9) { acc += tab[idx] + tab[(idx + 33 * 8) & (TABLE - 1)]; }                               // two b64 reads (ds_read2_b64 when the offsets allow)
     }
     __syncthreads();
     if (threadIdx.x == 0) out[blockIdx.x] = acc + tab[5];
@@ -68,6 +71,9 @@ int main() {
         run<6>("ds_add_rtn_u32", spread);
         run<4>("ds_read_b64", spread);
         run<5>("ds_write_b64", spread);
+        run<7>("ds_read_b128", spread);
+        run<8>("ds_write_b128", spread);
+        run<9>("ds_read2_b64", spread);
     }
     for (int n : {1000000, 15000, 1000}) {
         double* g;
