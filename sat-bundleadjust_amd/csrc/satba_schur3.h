@@ -185,6 +185,13 @@ __global__ __launch_bounds__(256) void k_schur_pairs(ObsArgs a, CamMajor c, Schu
             for (int k = 0; k < NP; ++k) { Jci[0][k] *= scl_i.x; Jci[1][k] *= scl_i.y; Jcj[0][k] *= scl_j.x; Jcj[1][k] *= scl_j.y; }
 #pragma unroll
             for (int k = 0; k < 3; ++k) { Jpi[0][k] *= scl_i.x; Jpi[1][k] *= scl_i.y; Jpj[0][k] *= scl_j.x; Jpj[1][k] *= scl_j.y; }
+        } else if constexpr (UNITW && !ROBUST) {
+            // unit weights, linear loss: the raw Jacobians.  The fixed-point mask multiplies the 2 x 2 middle matrix
+            // (4 products instead of 12 + 20 on the blocks), the fixed-camera masks are wave-uniform and multiply the
+            // reduced block once (cam_mask below)
+            double u, v;
+            project<MODEL, NP, true>(cci, tabi, X, Y, Z, a.f32 != 0, u, v, Jci, Jpi);
+            project<MODEL, NP, true>(ccj, tabj, X, Y, Z, a.f32 != 0, u, v, Jcj, Jpj);
         } else {
             cm_jacobian<MODEL, NP, ROBUST, UNITW>(a, c, cci, tabi, i, pi, p, X, Y, Z, Jci, Jpi);
             cm_jacobian<MODEL, NP, ROBUST, UNITW>(a, c, ccj, tabj, j, pj, p, X, Y, Z, Jcj, Jpj);
@@ -197,10 +204,14 @@ __global__ __launch_bounds__(256) void k_schur_pairs(ObsArgs a, CamMajor c, Schu
             A[r][1] = Jpi[r][0] * v01 + Jpi[r][1] * v11 + Jpi[r][2] * v12;
             A[r][2] = Jpi[r][0] * v02 + Jpi[r][1] * v12 + Jpi[r][2] * v22;
         }
-        const double m00 = A[0][0] * Jpj[0][0] + A[0][1] * Jpj[0][1] + A[0][2] * Jpj[0][2];
-        const double m01 = A[0][0] * Jpj[1][0] + A[0][1] * Jpj[1][1] + A[0][2] * Jpj[1][2];
-        const double m10 = A[1][0] * Jpj[0][0] + A[1][1] * Jpj[0][1] + A[1][2] * Jpj[0][2];
-        const double m11 = A[1][0] * Jpj[1][0] + A[1][1] * Jpj[1][1] + A[1][2] * Jpj[1][2];
+        double m00 = A[0][0] * Jpj[0][0] + A[0][1] * Jpj[0][1] + A[0][2] * Jpj[0][2];
+        double m01 = A[0][0] * Jpj[1][0] + A[0][1] * Jpj[1][1] + A[0][2] * Jpj[1][2];
+        double m10 = A[1][0] * Jpj[0][0] + A[1][1] * Jpj[0][1] + A[1][2] * Jpj[0][2];
+        double m11 = A[1][0] * Jpj[1][0] + A[1][1] * Jpj[1][1] + A[1][2] * Jpj[1][2];
+        if constexpr (UNITW && !ROBUST && MODEL != RPC) {
+            const double mp = (p >= a.n_pts_fix) ? 1.0 : 0.0;
+            m00 *= mp; m01 *= mp; m10 *= mp; m11 *= mp;
+        }
 #pragma unroll
         for (int q = 0; q < NP; ++q) {
             const double y0 = m00 * Jcj[0][q] + m01 * Jcj[1][q];
@@ -289,7 +300,9 @@ __global__ __launch_bounds__(256) void k_schur_pairs(ObsArgs a, CamMajor c, Schu
     double flat[NPAD];
 #pragma unroll
     for (int e = 0; e < NPAD; ++e) flat[e] = (e < NB2) ? acc[e / NP][e % NP] : 0.0;
-    const double total = wave_reduce_scatter<NPAD>(flat, lane, 32);
+    // camera masks of the unit-weight path (applied to every Jacobian by cm_jacobian on the other paths)
+    const double cam_mask = (UNITW && !ROBUST && MODEL != RPC && (i < a.n_cam_fix || j < a.n_cam_fix)) ? 0.0 : 1.0;
+    const double total = cam_mask * wave_reduce_scatter<NPAD>(flat, lane, 32);
     const int e = rs_index<NPAD>(lane);
     const bool writer = (lane & (64 / NPAD - 1)) == 0 && e < NB2;  // one lane per total (NPAD = 64: every lane)
     if (writer) {
@@ -635,12 +648,32 @@ __global__ __launch_bounds__(LINC_THREADS) void k_schur_diag(ObsArgs a, CamMajor
     double acc[CU];
 #pragma unroll
     for (int k = 0; k < CU; ++k) acc[k] = 0.0;
-    for (int pos = lo + threadIdx.x; pos < hi; pos += LINC_THREADS) {
-        const int p = c.pt[pos];
+    // Software pipeline: point indices run two iterations ahead, the 96-byte point records one (the loop was a chain
+    // of two dependent gathers per iteration, ~18 iterations per thread).  unit: every weight is 1 and the loss is
+    // linear -- nothing is fetched per observation, the fixed-point mask multiplies the 2 x 2 middle matrix and the
+    // (block-uniform) fixed-camera mask the accumulators at the end.
+    struct Rec { double2 r0, r1, r2, r3, r4, r5; };
+    auto load_rec = [&](int p) {
         const double2* pv = s.PV + 6 * (size_t)p;
-        const double2 r0 = pv[0], r1 = pv[1], r2 = pv[2], r3 = pv[3], r4 = pv[4], r5 = pv[5];
+        Rec r;
+        r.r0 = pv[0]; r.r1 = pv[1]; r.r2 = pv[2]; r.r3 = pv[3]; r.r4 = pv[4]; r.r5 = pv[5];
+        return r;
+    };
+    const bool unit = !ROBUST && MODEL != RPC && a.unit != 0;
+    auto ldp = [&](int q) { return q < hi ? c.pt[q] : 0; };
+    int pos = lo + threadIdx.x;
+    int p_cur = ldp(pos), p_nxt = ldp(pos + LINC_THREADS);
+    Rec rc = load_rec(p_cur);
+    for (; pos < hi; pos += LINC_THREADS) {
+        const int p_nn = ldp(pos + 2 * LINC_THREADS);
+        const Rec rn = load_rec(p_nxt);
+        __builtin_amdgcn_sched_barrier(0);
+        const int p = p_cur;
+        const double2 r0 = rc.r0, r1 = rc.r1, r2 = rc.r2, r3 = rc.r3, r4 = rc.r4, r5 = rc.r5;
+        p_cur = p_nxt; p_nxt = p_nn; rc = rn;
         double Jc[2][NP], Jp[2][3];
         bool have = false;
+        double mp = 1.0;
         if constexpr (MODEL == RPC) {
             if (a.Jpm) {  // the blocks the linearize kernel stored, through the camera-major permutation
                 const double2* q = reinterpret_cast<const double2*>(a.Jpm + (size_t)c.oidx[pos] * (2 * NP + 6));
@@ -654,7 +687,15 @@ __global__ __launch_bounds__(LINC_THREADS) void k_schur_diag(ObsArgs a, CamMajor
                 have = true;
             }
         }
-        if (!have) cm_jacobian<MODEL, NP, ROBUST>(a, c, cc, tab, cam, pos, p, r0.x, r0.y, r1.x, Jc, Jp);
+        if (!have) {
+            if (unit) {
+                double u, v;
+                project<MODEL, NP, true>(cc, tab, r0.x, r0.y, r1.x, a.f32 != 0, u, v, Jc, Jp);
+                mp = (p >= a.n_pts_fix) ? 1.0 : 0.0;
+            } else {
+                cm_jacobian<MODEL, NP, ROBUST>(a, c, cc, tab, cam, pos, p, r0.x, r0.y, r1.x, Jc, Jp);
+            }
+        }
         const double v00 = r1.y, v01 = r2.x, v02 = r2.y, v11 = r3.x, v12 = r3.y, v22 = r4.x;
         double A[2][3];
 #pragma unroll
@@ -663,11 +704,11 @@ __global__ __launch_bounds__(LINC_THREADS) void k_schur_diag(ObsArgs a, CamMajor
             A[r][1] = Jp[r][0] * v01 + Jp[r][1] * v11 + Jp[r][2] * v12;
             A[r][2] = Jp[r][0] * v02 + Jp[r][1] * v12 + Jp[r][2] * v22;
         }
-        const double m00 = A[0][0] * Jp[0][0] + A[0][1] * Jp[0][1] + A[0][2] * Jp[0][2];
-        const double m01 = A[0][0] * Jp[1][0] + A[0][1] * Jp[1][1] + A[0][2] * Jp[1][2];
-        const double m11 = A[1][0] * Jp[1][0] + A[1][1] * Jp[1][1] + A[1][2] * Jp[1][2];
-        const double ag0 = A[0][0] * r4.y + A[0][1] * r5.x + A[0][2] * r5.y;
-        const double ag1 = A[1][0] * r4.y + A[1][1] * r5.x + A[1][2] * r5.y;
+        const double m00 = mp * (A[0][0] * Jp[0][0] + A[0][1] * Jp[0][1] + A[0][2] * Jp[0][2]);
+        const double m01 = mp * (A[0][0] * Jp[1][0] + A[0][1] * Jp[1][1] + A[0][2] * Jp[1][2]);
+        const double m11 = mp * (A[1][0] * Jp[1][0] + A[1][1] * Jp[1][1] + A[1][2] * Jp[1][2]);
+        const double ag0 = mp * (A[0][0] * r4.y + A[0][1] * r5.x + A[0][2] * r5.y);
+        const double ag1 = mp * (A[1][0] * r4.y + A[1][1] * r5.x + A[1][2] * r5.y);
         int k = 0;
 #pragma unroll
         for (int r = 0; r < NP; ++r) {
@@ -682,6 +723,11 @@ __global__ __launch_bounds__(LINC_THREADS) void k_schur_diag(ObsArgs a, CamMajor
         }
 #pragma unroll
         for (int r = 0; r < NP; ++r) acc[k++] -= Jc[0][r] * ag0 + Jc[1][r] * ag1;
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (unit && cam < a.n_cam_fix) {
+#pragma unroll
+        for (int k = 0; k < CU; ++k) acc[k] = 0.0;
     }
     __shared__ double s_red[LINC_THREADS / 64][CU];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
