@@ -623,7 +623,7 @@ int satba_problem_create(const satba_problem_desc* d, satba_problem** out) {
                     for (int w = 0; w < NW; ++w) { rank[(size_t)cc * NW + w] = run; run += __builtin_popcountll(bits[(size_t)cc * NW + w]); }
                 }
                 TRY(dev_alloc(p, &p->d_bits, bits.size())); TRY(dev_alloc(p, &p->d_rank, rank.size()));
-                TRY(dev_alloc(p, &p->d_PV, (size_t)12 * p->N));
+                TRY(dev_alloc(p, &p->d_PV, (size_t)PV_STRIDE * p->N));
                 p->unit_weights = 1;
                 for (long long o = 0; o < K; ++o) if (d->weights[o] != 1.0) { p->unit_weights = 0; break; }
                 HIP_TRY(hipMemcpy(p->d_bits, bits.data(), sizeof(unsigned long long) * bits.size(), hipMemcpyHostToDevice));

@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256) void k_schur_pairs(ObsArgs a, CamMajor c, Schu
 
     struct Rec { double2 r0, r1, r2, r3, r4; };  // packed point record: X0 X1 | X2 v00 | v01 v02 | v11 v12 | v22 g0
     auto load_rec = [&](int p) {
-        const double2* pv = s.PV + 6 * (size_t)p;  // five 16-byte gathers instead of nine 8-byte ones
+        const double2* pv = s.PV + (PV_STRIDE / 2) * (size_t)p;  // five 16-byte gathers instead of nine 8-byte ones
         Rec r;
         r.r0 = pv[0]; r.r1 = pv[1]; r.r2 = pv[2]; r.r3 = pv[3]; r.r4 = pv[4];
         return r;
@@ -371,7 +371,7 @@ __device__ __forceinline__ void schur_pairs_groups_body(const ObsArgs& a, const 
 
     struct Rec { double2 r0, r1, r2, r3, r4; };  // packed point record: X0 X1 | X2 v00 | v01 v02 | v11 v12 | v22 g0
     auto load_rec = [&](int p) {
-        const double2* pv = s.PV + 6 * (size_t)p;
+        const double2* pv = s.PV + (PV_STRIDE / 2) * (size_t)p;
         Rec r;
         r.r0 = pv[0]; r.r1 = pv[1]; r.r2 = pv[2]; r.r3 = pv[3]; r.r4 = pv[4];
         return r;
@@ -505,7 +505,7 @@ __global__ __launch_bounds__(64 * S3_GW) void k_schur_pairs_moments(int M, int n
 
     struct Rec { double2 r0, r1, r2, r3, r4; };  // packed point record: X0 X1 | X2 v00 | v01 v02 | v11 v12 | v22 g0
     auto load_rec = [&](int p) {
-        const double2* pv = s.PV + 6 * (size_t)p;
+        const double2* pv = s.PV + (PV_STRIDE / 2) * (size_t)p;
         Rec r;
         r.r0 = pv[0]; r.r1 = pv[1]; r.r2 = pv[2]; r.r3 = pv[3]; r.r4 = pv[4];
         return r;
@@ -654,7 +654,7 @@ __global__ __launch_bounds__(LINC_THREADS) void k_schur_diag(ObsArgs a, CamMajor
     // (block-uniform) fixed-camera mask the accumulators at the end.
     struct Rec { double2 r0, r1, r2, r3, r4, r5; };
     auto load_rec = [&](int p) {
-        const double2* pv = s.PV + 6 * (size_t)p;
+        const double2* pv = s.PV + (PV_STRIDE / 2) * (size_t)p;
         Rec r;
         r.r0 = pv[0]; r.r1 = pv[1]; r.r2 = pv[2]; r.r3 = pv[3]; r.r4 = pv[4]; r.r5 = pv[5];
         return r;
