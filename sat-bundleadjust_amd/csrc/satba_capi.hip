@@ -96,6 +96,7 @@ struct satba_problem {
     int* d_rank = nullptr;
     double* d_PV = nullptr;    // packed per-point records (N x 12)
     long long* d_pair_ofs = nullptr;  // per camera pair: list of shared points (null: bitmap scan)
+    int2* d_pair_ij = nullptr;        // pair index -> (i, j)
     int* d_pair_pts = nullptr;
     double* d_pair_part = nullptr;  // chunk partials of the pair blocks
     int unit_weights = 0;
@@ -286,7 +287,10 @@ static int launch_schur3(satba_problem* p, const ObsArgs& a, double* S, double* 
     const int diag_chunks = p->lin3_chunks;
     const bool grp = p->sch3_groups > 0;
     const unsigned ggrid = grp ? (unsigned)((p->sch3_groups + S3_GW - 1) / S3_GW) : 0;
-    const unsigned igrid = (unsigned)((items + 3) / 4);
+    // list path: 2-D grid (pairs / 4, chunks); bitmap path: 1-D over the (pair, chunk) items
+    if (items >= (1ll << 31)) return fail(SATBA_E_ARG, "too many (camera pair, chunk) work items");
+    const dim3 igrid = p->d_pair_ofs ? dim3((unsigned)((n_pairs + 3) / 4), (unsigned)p->sch3_chunks) : dim3((unsigned)((items + 3) / 4));
+    s.pair_ij = p->d_pair_ij;
     const bool moments = p->sch3_moments && p->loss == 0 && items > 0;
     // diagonal blocks first: for RPC cameras this pass also stores the Jacobian blocks the pair kernel gathers
     if (p->loss == 0) hipLaunchKernelGGL((k_schur_diag<MODEL, NP, false, ADDU>), dim3(diag_chunks, p->M), dim3(LINC_THREADS), 0, p->stream, a, cm, s, p->d_part3);
@@ -312,17 +316,17 @@ static int launch_schur3(satba_problem* p, const ObsArgs& a, double* S, double* 
             else
                 hipLaunchKernelGGL((k_schur_pairs_groups<MODEL, NP, false, true>), dim3(ggrid), dim3(64 * S3_GW), 0, p->stream, a, cm, s, p->d_groups, p->sch3_groups, S);
         } else {
-            hipLaunchKernelGGL((k_schur_pairs<MODEL, NP, false, true>), dim3(igrid), dim3(256), 0, p->stream, a, cm, s, S);
+            hipLaunchKernelGGL((k_schur_pairs<MODEL, NP, false, true>), igrid, dim3(256), 0, p->stream, a, cm, s, S);
         }
     } else if (!grp && p->d_pair_ofs && p->d_pair_pi && a.sc) {
         // weighted / robust with pair lists that carry the observation indices: unit Jacobians times the stored scales
-        hipLaunchKernelGGL((k_schur_pairs<MODEL, NP, false, false, true>), dim3(igrid), dim3(256), 0, p->stream, a, cm, s, S);
+        hipLaunchKernelGGL((k_schur_pairs<MODEL, NP, false, false, true>), igrid, dim3(256), 0, p->stream, a, cm, s, S);
     } else if (p->loss == 0) {
         if (grp) hipLaunchKernelGGL((k_schur_pairs_groups<MODEL, NP, false, false>), dim3(ggrid), dim3(64 * S3_GW), 0, p->stream, a, cm, s, p->d_groups, p->sch3_groups, S);
-        else hipLaunchKernelGGL((k_schur_pairs<MODEL, NP, false, false>), dim3(igrid), dim3(256), 0, p->stream, a, cm, s, S);
+        else hipLaunchKernelGGL((k_schur_pairs<MODEL, NP, false, false>), igrid, dim3(256), 0, p->stream, a, cm, s, S);
     } else {
         if (grp) hipLaunchKernelGGL((k_schur_pairs_groups<MODEL, NP, true, false>), dim3(ggrid), dim3(64 * S3_GW), 0, p->stream, a, cm, s, p->d_groups, p->sch3_groups, S);
-        else hipLaunchKernelGGL((k_schur_pairs<MODEL, NP, true, false>), dim3(igrid), dim3(256), 0, p->stream, a, cm, s, S);
+        else hipLaunchKernelGGL((k_schur_pairs<MODEL, NP, true, false>), igrid, dim3(256), 0, p->stream, a, cm, s, S);
     }
     HIP_TRY(hipGetLastError());
     if (items > 0 && p->d_pair_ofs && p->sch3_chunks > 1 && !grp && !(MODEL == AFFINE && moments)) {
@@ -699,6 +703,14 @@ int satba_problem_create(const satba_problem_desc* d, satba_problem** out) {
                                     pts[at] = q;
                                     if (with_pos) { ppi[at] = x0; ppj[at] = x1; }
                                 }
+                        {   // pair index -> (i, j) table (the kernels used to unrank it with a square root and two loops)
+                            std::vector<int2> ij((size_t)n_pairs);
+                            size_t at = 0;
+                            for (int ci = 0; ci < p->M; ++ci)
+                                for (int cj = ci + 1; cj < p->M; ++cj) ij[at++] = make_int2(ci, cj);
+                            TRY(dev_alloc(p, &p->d_pair_ij, ij.size()));
+                            HIP_TRY(hipMemcpy(p->d_pair_ij, ij.data(), sizeof(int2) * ij.size(), hipMemcpyHostToDevice));
+                        }
                         TRY(dev_alloc(p, &p->d_pair_ofs, ofs.size())); TRY(dev_alloc(p, &p->d_pair_pts, pts.size()));
                         HIP_TRY(hipMemcpy(p->d_pair_ofs, ofs.data(), sizeof(long long) * ofs.size(), hipMemcpyHostToDevice));
                         HIP_TRY(hipMemcpy(p->d_pair_pts, pts.data(), sizeof(int) * pts.size(), hipMemcpyHostToDevice));

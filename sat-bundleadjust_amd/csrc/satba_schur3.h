@@ -35,6 +35,7 @@ struct Schur3Args {
     const int* __restrict__ pair_pi;              // per list entry: observation index (point-major order) of the point's observation
     const int* __restrict__ pair_pj;              //   in camera i / j (null: not built); per-observation data of the two lies within
                                                   //   the point's contiguous run of observations
+    const int2* __restrict__ pair_ij;             // pair index -> (i, j), i < j (null: unranked with a square root)
     int NW;                                       // words per camera
     int n_chunks;                                 // word-range chunks per pair (1: plain stores, >1: atomics)
 };
@@ -106,17 +107,34 @@ __global__ __launch_bounds__(256) void k_schur_pairs(ObsArgs a, CamMajor c, Schu
     __shared__ int s_q[4][S3_QUEUE];  // shared points of the two cameras waiting to be evaluated
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long long n_pairs = (long long)a.M * (a.M - 1) / 2;
-    const long long item = (long long)blockIdx.x * 4 + wave;
-    if (item >= n_pairs * s.n_chunks) return;
-    // list path: chunk-major order, so that the workgroups running at the same time gather point records from
-    // the same slice of the point array (an L2-sized window) instead of the whole 96 MB
-    const long long pair = s.pair_ofs ? item % n_pairs : item / s.n_chunks;
-    const int chunk = s.pair_ofs ? (int)(item / n_pairs) : (int)(item % s.n_chunks);
-    // unrank pair -> (i, j): pairs of row i start at i*M - i*(i+1)/2
-    int i = (int)((2.0 * a.M - 1.0 - sqrt((2.0 * a.M - 1.0) * (2.0 * a.M - 1.0) - 8.0 * (double)pair)) * 0.5);
-    while ((long long)i * a.M - (long long)i * (i + 1) / 2 > pair) --i;
-    while ((long long)(i + 1) * a.M - (long long)(i + 1) * (i + 2) / 2 <= pair) ++i;
-    int j = i + 1 + (int)(pair - ((long long)i * a.M - (long long)i * (i + 1) / 2));
+    // list path: grid (pairs / 4, chunks) -- chunk-major dispatch order, so that the workgroups running at the same time
+    // gather point records from the same slice of the point array (an L2-sized window) instead of the whole array.
+    // bitmap path: 1-D grid over (pair, chunk), chunk fastest.  32-bit arithmetic only: the four 64-bit divisions this
+    // used to take were ~500 of the ~2000 VALU instructions of a work item.
+    unsigned pair_u, chunk_u;
+    if (s.pair_ofs) {
+        pair_u = blockIdx.x * 4u + (unsigned)wave;
+        chunk_u = blockIdx.y;
+        if ((long long)pair_u >= n_pairs) return;
+    } else {
+        const unsigned item = blockIdx.x * 4u + (unsigned)wave;
+        if ((long long)item >= n_pairs * s.n_chunks) return;
+        pair_u = item / (unsigned)s.n_chunks;
+        chunk_u = item % (unsigned)s.n_chunks;
+    }
+    const long long pair = pair_u;
+    const int chunk = (int)chunk_u;
+    int i, j;
+    if (s.pair_ij) {
+        const int2 ij = s.pair_ij[pair_u];
+        i = ij.x; j = ij.y;
+    } else {
+        // unrank pair -> (i, j): pairs of row i start at i*M - i*(i+1)/2
+        i = (int)((2.0 * a.M - 1.0 - sqrt((2.0 * a.M - 1.0) * (2.0 * a.M - 1.0) - 8.0 * (double)pair)) * 0.5);
+        while ((long long)i * a.M - (long long)i * (i + 1) / 2 > pair) --i;
+        while ((long long)(i + 1) * a.M - (long long)(i + 1) * (i + 2) / 2 <= pair) ++i;
+        j = i + 1 + (int)(pair - ((long long)i * a.M - (long long)i * (i + 1) / 2));
+    }
     i = __builtin_amdgcn_readfirstlane(i);  // wave-uniform by construction: lets the camera constants use scalar loads
     j = __builtin_amdgcn_readfirstlane(j);
 
