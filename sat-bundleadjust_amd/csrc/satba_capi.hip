@@ -380,7 +380,10 @@ static int launch_schur_kernel(satba_problem* p) {
 static int launch_backsub_kernel(satba_problem* p) {
     ObsArgs a = obs_args(p, false);
     const int grid = grid_for(p->n_tiles, 4, 2048);
-    SATBA_DISPATCH(p, hipLaunchKernelGGL((k_backsub<MODEL, NP, CL>), dim3(grid), dim3(256), p->camc_bytes, p->stream, a, p->d_dc, p->d_tbuf));
+    // affine: the kernel builds its own 15-double-per-camera table in LDS (k_backsub); otherwise the camera-constant table
+    const size_t lds = p->model == AFFINE ? sizeof(double) * (size_t)p->M * BS_ROW : p->camc_bytes;
+    if (lds > 158 * 1024) return fail(SATBA_E_ARG, "n_cam = %d exceeds the LDS budget of the back-substitution kernel", p->M);
+    SATBA_DISPATCH(p, hipLaunchKernelGGL((k_backsub<MODEL, NP, CL>), dim3(grid), dim3(256), lds, p->stream, a, p->d_dc, p->d_tbuf));
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -527,6 +530,7 @@ int satba_problem_create(const satba_problem_desc* d, satba_problem** out) {
             SATBA_DISPATCH(p, TRY(raise_lds_limit(k_linearize<MODEL, NP, true, CL, false>, lin1_lds(p, true))));
         }
         SATBA_DISPATCH(p, TRY(raise_lds_limit(k_schur<MODEL, NP>, schur_lds(p))));
+        if (p->model == AFFINE) SATBA_DISPATCH(p, TRY(raise_lds_limit(k_backsub<MODEL, NP, CL>, sizeof(double) * (size_t)p->M * BS_ROW)));
         {   // Schur panel configuration: T cameras per panel so that panel (+ camera table) fit the 160 KB LDS
             const size_t budget = 160 * 1024 - 1024;  // static LDS of the kernel and alignment slack
             const size_t col_bytes = sizeof(double) * ((size_t)p->NP * p->n_c + p->NP);  // per camera of the tile

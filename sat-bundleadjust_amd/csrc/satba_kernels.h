@@ -972,11 +972,117 @@ __global__ __launch_bounds__(1024) void k_prepare_stash(int nU, int n_c, int wor
 // ------------------------------------------------------------------------------------------------ K5 back-substitution
 // t_p = sum_obs Jp^T (Jc dc[cam])  per point (segmented wave reduction; for three values the shuffle form beats the
 // LDS-staged form of k_linearize: 0.25 vs 0.28 ms at C4)
+// Affine cameras: the projection is exactly affine in the point, so J_c dc = B_c X + b_c with per-camera constants
+// B_c = sum_i dc_i D_ci (2 x 3), b_c = K-columns . dc_T, and J_p = A_c.  Every workgroup derives the 14 constants of each
+// camera once (three evaluations of the projector's Jacobian at the unit vectors) into an LDS table with an odd row
+// stride; an observation then costs 14 LDS reads and 14 multiply-adds instead of 11 + 5 gathers (the dc gathers went
+// through the texture path) and the full Jacobian evaluation.
+constexpr int BS_ROW = 15;
 template <int MODEL, int NP, bool CL>
 __global__ __launch_bounds__(256) void k_backsub(ObsArgs a, const double* __restrict__ dc, double* __restrict__ tbuf) {
     extern __shared__ double s_camc_bs[];
-    const double* cbase = cam_table<CL>(a, s_camc_bs, 256);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if constexpr (MODEL == AFFINE) {
+        double* tab = s_camc_bs;  // M x BS_ROW: B (6) | b (2) | A (6)
+        __shared__ double s_stage[4][3 * LIN_STAGE];
+        __shared__ unsigned char s_seg[4][66];
+        double* stage = s_stage[wave];
+        for (int c = threadIdx.x; c < a.M; c += 256) {
+            const double* cc = a.camc + (size_t)c * CAMC;
+            double u, v, Jc[2][NP], Jp[2][3], B[2][3], b[2] = {0.0, 0.0};
+            const double mc = (c >= a.n_cam_fix) ? 1.0 : 0.0;
+#pragma unroll
+            for (int m = 0; m < 3; ++m) {
+                project<AFFINE, NP, true>(cc, nullptr, m == 0 ? 1.0 : 0.0, m == 1 ? 1.0 : 0.0, m == 2 ? 1.0 : 0.0, false, u, v, Jc, Jp);
+                B[0][m] = 0.0; B[1][m] = 0.0;
+#pragma unroll
+                for (int i = 0; i < 3; ++i) { B[0][m] += Jc[0][i] * dc[c * NP + i]; B[1][m] += Jc[1][i] * dc[c * NP + i]; }
+            }
+#pragma unroll
+            for (int i = 3; i < NP; ++i) { b[0] += Jc[0][i] * dc[c * NP + i]; b[1] += Jc[1][i] * dc[c * NP + i]; }
+            double* row = tab + (size_t)c * BS_ROW;
+#pragma unroll
+            for (int m = 0; m < 3; ++m) { row[m] = mc * B[0][m]; row[3 + m] = mc * B[1][m]; row[8 + m] = Jp[0][m]; row[11 + m] = Jp[1][m]; }
+            row[6] = mc * b[0]; row[7] = mc * b[1];
+        }
+        __syncthreads();
+        // software pipeline as in k_linearize: a wave walks ~20 tiles and each one was a chain of three dependent
+        // loads (range -> record -> point); ranges run three tiles ahead, records two, point gathers one
+        const int stride = gridDim.x * 4;
+        int tile = blockIdx.x * 4 + wave;
+        auto range = [&](int t, int& r0, int& r1, int& rs) {
+            const int tu = __builtin_amdgcn_readfirstlane(t);
+            if (tu < a.n_tiles) { r0 = a.tile_start[tu]; r1 = a.tile_start[tu + 1]; rs = a.tile_split[tu]; } else { r0 = 0; r1 = 0; rs = 0; }
+        };
+        int o0, o1, osplit, n0, n1, nsplit, m0, m1, msplit;
+        range(tile, o0, o1, osplit);
+        range(tile + stride, n0, n1, nsplit);
+        range(tile + 2 * stride, m0, m1, msplit);
+        int cam = 0, pt = -1 - lane, ncam = 0, npt = -1 - lane, mcam = 0, mpt = -1 - lane;
+        double X = 0.0, Y = 0.0, Z = 0.0, nX = 0.0, nY = 0.0, nZ = 0.0;
+        if (o0 + lane < o1) { pt = a.pt[o0 + lane]; cam = a.cam[o0 + lane]; }
+        if (n0 + lane < n1) { npt = a.pt[n0 + lane]; ncam = a.cam[n0 + lane]; }
+        if (pt >= 0) { const double* px = a.x + a.n_c + 3 * (size_t)pt; X = px[0]; Y = px[1]; Z = px[2]; }
+        for (; tile < a.n_tiles; tile += stride) {
+            const long long o = (long long)o0 + lane;
+            const bool active = o < o1;
+            int q0, q1, qsplit;
+            if (npt >= 0) { const double* px = a.x + a.n_c + 3 * (size_t)npt; nX = px[0]; nY = px[1]; nZ = px[2]; }
+            mpt = -1 - lane; mcam = 0;
+            if (m0 + lane < m1) { mpt = a.pt[m0 + lane]; mcam = a.cam[m0 + lane]; }
+            range(tile + 3 * stride, q0, q1, qsplit);
+            __builtin_amdgcn_sched_barrier(0);
+            double v[3] = {0, 0, 0};
+            if (active) {
+                const double* row = tab + (size_t)cam * BS_ROW;
+                double u0 = row[0] * X + row[1] * Y + row[2] * Z + row[6];
+                double u1 = row[3] * X + row[4] * Y + row[5] * Z + row[7];
+                if (a.sc) { const double2 t = a.sc[o]; u0 *= t.x * t.x; u1 *= t.y * t.y; }  // both blocks carry the row scale
+                const double mp = (pt >= a.n_pts_fix) ? 1.0 : 0.0;
+                u0 *= mp; u1 *= mp;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) v[j] = row[8 + j] * u0 + row[11 + j] * u1;
+            }
+            // per-point sums through the wave's staging rows, as in k_linearize: 3 ds_write + ~12 ds_read per tile; the
+            // shuffle form (seg_reduce) issues 43 ds_bpermute per tile and kept this kernel bound by the LDS pipe
+            if (active) {
+                stage[0 * LIN_STAGE + lane] = v[0];
+                stage[1 * LIN_STAGE + lane] = v[1];
+                stage[2 * LIN_STAGE + lane] = v[2];
+            }
+            const int prev = __shfl_up(pt, 1);
+            const bool head = active && (lane == 0 || prev != pt);
+            const unsigned long long heads = __ballot(head);
+            const int n_runs = __popcll(heads);
+            if (head) s_seg[wave][__popcll(heads & ((1ull << lane) - 1ull))] = (unsigned char)lane;
+            if (lane == 0) s_seg[wave][n_runs] = (unsigned char)(o1 - o0);
+            for (int r0 = 0; r0 < n_runs; r0 += 21) {
+                const int q = r0 + lane / 3, vi = lane % 3;
+                const bool owner = lane < 63 && q < n_runs;
+                const int rb = owner ? s_seg[wave][q] : 0, re = owner ? s_seg[wave][q + 1] : 0;
+                const int ptq = __shfl(pt, rb);
+                if (owner) {
+                    const double* col = stage + vi * LIN_STAGE;
+                    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+                    for (int l = rb; l < re; l += 4) {
+                        const double a0 = col[l];
+                        const double a1 = (l + 1 < re) ? col[l + 1] : 0.0;
+                        const double a2 = (l + 2 < re) ? col[l + 2] : 0.0;
+                        const double a3 = (l + 3 < re) ? col[l + 3] : 0.0;
+                        s0 += a0; s1 += a1; s2 += a2; s3 += a3;
+                    }
+                    const double sum = (s0 + s1) + (s2 + s3);
+                    double* t = tbuf + 3 * (size_t)ptq + vi;
+                    if (osplit) atomicAdd(t, sum);
+                    else *t = sum;
+                }
+            }
+            o0 = n0; o1 = n1; osplit = nsplit; n0 = m0; n1 = m1; nsplit = msplit; m0 = q0; m1 = q1; msplit = qsplit;
+            cam = ncam; pt = npt; X = nX; Y = nY; Z = nZ; ncam = mcam; npt = mpt;
+        }
+        return;
+    }
+    const double* cbase = cam_table<CL>(a, s_camc_bs, 256);
     for (int tile = blockIdx.x * 4 + wave; tile < a.n_tiles; tile += gridDim.x * 4) {
         const int o0 = a.tile_start[tile], o1 = a.tile_start[tile + 1];
         const long long o = (long long)o0 + lane;
