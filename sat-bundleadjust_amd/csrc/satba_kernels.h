@@ -972,6 +972,46 @@ __global__ __launch_bounds__(1024) void k_prepare_stash(int nU, int n_c, int wor
 // ------------------------------------------------------------------------------------------------ K5 back-substitution
 // t_p = sum_obs Jp^T (Jc dc[cam])  per point (segmented wave reduction; for three values the shuffle form beats the
 // LDS-staged form of k_linearize: 0.25 vs 0.28 ms at C4)
+// Per-point sums of three values per observation over a wave tile (runs of equal point index), through the wave's LDS
+// staging rows as in k_linearize: 3 ds_write + ~12 ds_read per tile.  The shuffle form (seg_reduce<3>) issues 43
+// ds_bpermute per tile and kept the back-substitution bound by the LDS pipe (0.132 -> 0.083 ms at the headline shape).
+// stage: 3 * LIN_STAGE doubles, seg: 66 bytes, both private to the wave; n_obs = observations of the tile.
+__device__ inline void point_sums3(double* stage, unsigned char* seg, const double (&v)[3], int pt, bool active, int lane,
+                                   int n_obs, bool split, double* __restrict__ tbuf) {
+    if (active) {
+        stage[0 * LIN_STAGE + lane] = v[0];
+        stage[1 * LIN_STAGE + lane] = v[1];
+        stage[2 * LIN_STAGE + lane] = v[2];
+    }
+    const int prev = __shfl_up(pt, 1);
+    const bool head = active && (lane == 0 || prev != pt);
+    const unsigned long long heads = __ballot(head);
+    const int n_runs = __popcll(heads);
+    if (head) seg[__popcll(heads & ((1ull << lane) - 1ull))] = (unsigned char)lane;
+    if (lane == 0) seg[n_runs] = (unsigned char)n_obs;
+    for (int r0 = 0; r0 < n_runs; r0 += 21) {
+        const int q = r0 + lane / 3, vi = lane % 3;
+        const bool owner = lane < 63 && q < n_runs;
+        const int rb = owner ? seg[q] : 0, re = owner ? seg[q + 1] : 0;
+        const int ptq = __shfl(pt, rb);
+        if (owner) {
+            const double* col = stage + vi * LIN_STAGE;
+            double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+            for (int l = rb; l < re; l += 4) {
+                const double a0 = col[l];
+                const double a1 = (l + 1 < re) ? col[l + 1] : 0.0;
+                const double a2 = (l + 2 < re) ? col[l + 2] : 0.0;
+                const double a3 = (l + 3 < re) ? col[l + 3] : 0.0;
+                s0 += a0; s1 += a1; s2 += a2; s3 += a3;
+            }
+            const double sum = (s0 + s1) + (s2 + s3);
+            double* t = tbuf + 3 * (size_t)ptq + vi;
+            if (split) atomicAdd(t, sum);
+            else *t = sum;
+        }
+    }
+}
+
 // Affine cameras: the projection is exactly affine in the point, so J_c dc = B_c X + b_c with per-camera constants
 // B_c = sum_i dc_i D_ci (2 x 3), b_c = K-columns . dc_T, and J_p = A_c.  Every workgroup derives the 14 constants of each
 // camera once (three evaluations of the projector's Jacobian at the unit vectors) into an LDS table with an odd row
@@ -982,11 +1022,11 @@ template <int MODEL, int NP, bool CL>
 __global__ __launch_bounds__(256) void k_backsub(ObsArgs a, const double* __restrict__ dc, double* __restrict__ tbuf) {
     extern __shared__ double s_camc_bs[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __shared__ double s_stage[4][3 * LIN_STAGE];
+    __shared__ unsigned char s_seg[4][66];
+    double* stage = s_stage[wave];
     if constexpr (MODEL == AFFINE) {
         double* tab = s_camc_bs;  // M x BS_ROW: B (6) | b (2) | A (6)
-        __shared__ double s_stage[4][3 * LIN_STAGE];
-        __shared__ unsigned char s_seg[4][66];
-        double* stage = s_stage[wave];
         for (int c = threadIdx.x; c < a.M; c += 256) {
             const double* cc = a.camc + (size_t)c * CAMC;
             double u, v, Jc[2][NP], Jp[2][3], B[2][3], b[2] = {0.0, 0.0};
@@ -1043,40 +1083,7 @@ __global__ __launch_bounds__(256) void k_backsub(ObsArgs a, const double* __rest
 #pragma unroll
                 for (int j = 0; j < 3; ++j) v[j] = row[8 + j] * u0 + row[11 + j] * u1;
             }
-            // per-point sums through the wave's staging rows, as in k_linearize: 3 ds_write + ~12 ds_read per tile; the
-            // shuffle form (seg_reduce) issues 43 ds_bpermute per tile and kept this kernel bound by the LDS pipe
-            if (active) {
-                stage[0 * LIN_STAGE + lane] = v[0];
-                stage[1 * LIN_STAGE + lane] = v[1];
-                stage[2 * LIN_STAGE + lane] = v[2];
-            }
-            const int prev = __shfl_up(pt, 1);
-            const bool head = active && (lane == 0 || prev != pt);
-            const unsigned long long heads = __ballot(head);
-            const int n_runs = __popcll(heads);
-            if (head) s_seg[wave][__popcll(heads & ((1ull << lane) - 1ull))] = (unsigned char)lane;
-            if (lane == 0) s_seg[wave][n_runs] = (unsigned char)(o1 - o0);
-            for (int r0 = 0; r0 < n_runs; r0 += 21) {
-                const int q = r0 + lane / 3, vi = lane % 3;
-                const bool owner = lane < 63 && q < n_runs;
-                const int rb = owner ? s_seg[wave][q] : 0, re = owner ? s_seg[wave][q + 1] : 0;
-                const int ptq = __shfl(pt, rb);
-                if (owner) {
-                    const double* col = stage + vi * LIN_STAGE;
-                    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-                    for (int l = rb; l < re; l += 4) {
-                        const double a0 = col[l];
-                        const double a1 = (l + 1 < re) ? col[l + 1] : 0.0;
-                        const double a2 = (l + 2 < re) ? col[l + 2] : 0.0;
-                        const double a3 = (l + 3 < re) ? col[l + 3] : 0.0;
-                        s0 += a0; s1 += a1; s2 += a2; s3 += a3;
-                    }
-                    const double sum = (s0 + s1) + (s2 + s3);
-                    double* t = tbuf + 3 * (size_t)ptq + vi;
-                    if (osplit) atomicAdd(t, sum);
-                    else *t = sum;
-                }
-            }
+            point_sums3(stage, s_seg[wave], v, pt, active, lane, o1 - o0, osplit != 0, tbuf);
             o0 = n0; o1 = n1; osplit = nsplit; n0 = m0; n1 = m1; nsplit = msplit; m0 = q0; m1 = q1; msplit = qsplit;
             cam = ncam; pt = npt; X = nX; Y = nY; Z = nZ; ncam = mcam; npt = mpt;
         }
@@ -1104,16 +1111,7 @@ __global__ __launch_bounds__(256) void k_backsub(ObsArgs a, const double* __rest
 #pragma unroll
             for (int j = 0; j < 3; ++j) v[j] = e.Jp[0][j] * u0 + e.Jp[1][j] * u1;
         }
-        seg_reduce<3>(v, pt, lane);
-        const int prev = __shfl_up(pt, 1);
-        if (active && (lane == 0 || prev != pt)) {
-            double* t = tbuf + 3 * (size_t)pt;
-            if (a.tile_split[tile]) {
-                atomicAdd(t, v[0]); atomicAdd(t + 1, v[1]); atomicAdd(t + 2, v[2]);
-            } else {
-                t[0] = v[0]; t[1] = v[1]; t[2] = v[2];
-            }
-        }
+        point_sums3(stage, s_seg[wave], v, pt, active, lane, o1 - o0, a.tile_split[tile] != 0, tbuf);
     }
 }
 
