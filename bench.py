@@ -32,11 +32,11 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 
-# HBM bytes per k_linearize launch from rocprofv3 PMC passes of this same command (profiles/r1_final_pmc_hbm_traffic.txt):
+# HBM bytes per k_linearize launch from rocprofv3 PMC passes of this same command (profiles/r1_s4_pmc_hbm_traffic.txt):
 # 2 x FETCH_SIZE (gfx950 counts 128-B requests as 64 B, MI355X_MICROARCH.md section HBM) + WRITE_SIZE, both in KiB.
 # PMC counters cannot be read from inside an unprofiled run, so the committed measurement is quoted for the shape
 # it was taken on (one GPU) and the field is null otherwise.
-PROFILED_TRAFFIC_BYTES = {("C4", 1): (2 * 176764.2 + 241805.2) * 1024.0}
+PROFILED_TRAFFIC_BYTES = {("C4", 1): (2 * 182180.3 + 240836.7) * 1024.0}
 
 
 def lm_step(eng, comm, st, trf):
