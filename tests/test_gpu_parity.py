@@ -183,6 +183,50 @@ def test_phases_match_oracle_engine(gpu, name, loss):
     dev.close()
 
 
+@pytest.mark.parametrize("model,corr", [("affine", ["R", "T"]), ("affine", ["R"]), ("perspective", ["R", "T"])])
+@pytest.mark.parametrize("ref_w", [1.0, 3.0])
+@pytest.mark.parametrize("loss", ["linear", "soft_l1"])
+def test_fixed_cameras_points_and_weights(gpu, model, corr, ref_w, loss):
+    """
+    Frozen cameras AND frozen points with unit / non-unit weights: the unit-weight affine kernels apply the masks in
+    other places than the generic ones (closed-form translation entries of diag U_c, the mask on the 2 x 2 middle matrix
+    of the pair blocks, the camera mask on the reduced block, the constant table of the back-substitution).
+    """
+    scene = synth.make_scene(model, 7, 160, 4, seed=11)
+    p = synth.make_params(scene, {"correction_params": corr, "n_cam_fix": 2, "n_pts_fix": 9, "ref_cam_weight": ref_w,
+                                  "reduce": False})
+    rng = np.random.default_rng(5)
+    v = ba_core._frozen_vars(p.params_opt + 1e-6 * rng.standard_normal(p.params_opt.size) * np.abs(p.params_opt).clip(1.0), p)
+    dev, ora = HipEngine(p), L.OracleEngine(p)
+    for e in (dev, ora):
+        e.configure(loss, 1.0)
+        e.set_x(v)
+    a, b = _run_phases(dev, 1e-3), _run_phases(ora, 1e-3)
+    for phase, slots in (("lin", [trf.COST, dev.HDR_FIXED]), ("prep", [trf.GH_SQ, trf.JG_SQ, trf.XS_SQ, trf.GC_INF]),
+                         ("solve", [trf.GRAM_A, trf.GRAM_B, trf.GRAM_C, trf.CHOL_FAIL]),
+                         ("trial", [trf.COST_NEW, trf.STEP_SQ, trf.X_SQ])):
+        for s in slots:
+            assert abs(a[phase][s] - b[phase][s]) <= 1e-7 * abs(b[phase][s]) + 1e-300, (phase, s, a[phase][s], b[phase][s])
+    assert rel(dev.get_vector("scale_inv"), ora.scale_inv) < 1e-9
+    assert rel(dev.get_vector("g_h"), ora.g_h) < 1e-8
+    assert rel(dev.get_vector("gn_h"), ora.gn_h) < 1e-7
+    gn = dev.get_vector("gn_h")
+    n_p = dev.n_c // p.n_cam
+    assert np.all(gn[: 2 * n_p] == 0.0) and np.all(gn[dev.n_c: dev.n_c + 27] == 0.0)  # frozen cameras / points do not move
+    # Schur matrix and right-hand side
+    for e in (dev, ora):
+        e.linearize(); e.prepare(True); e.schur(0.37)
+    n_c = dev.n_c
+    S = dev.get_exchange(dev.hdr, n_c * n_c).reshape(n_c, n_c).T
+    rhs = dev.get_exchange(dev.hdr + n_c * n_c, n_c)
+    S_o = ora._xb[ora.hdr: ora.hdr + n_c * n_c].reshape(n_c, n_c)
+    rhs_o = ora._xb[ora.hdr + n_c * n_c: ora.len_schur]
+    low = np.tril_indices(n_c)
+    assert rel(S[low], S_o[low]) < 1e-10
+    assert rel(rhs, rhs_o) < 1e-10
+    dev.close()
+
+
 def test_schur_matrix_and_rhs(gpu):
     _, p, g = cases.fun_case("affine_RT")
     v = g["v"][1]
