@@ -615,25 +615,25 @@ __global__ void k_vinv(int N, double lam, const double* __restrict__ lam_dev, co
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= N) return;
     if (lam_dev) lam = *lam_dev;
-    const double* v = V + 6 * (size_t)p;
+    // 16-byte accesses: V and Vinv rows are 48 bytes apart, records 128 (hipMalloc aligns the arrays to 256 bytes)
+    const double2* v2 = reinterpret_cast<const double2*>(V + 6 * (size_t)p);
+    const double2 va = v2[0], vb = v2[1], vc = v2[2];
     const double* s = scale_inv_p + 3 * (size_t)p;
-    const double a = v[0] + lam * s[0] * s[0], b = v[1], c = v[2];
-    const double d = v[3] + lam * s[1] * s[1], e = v[4], f = v[5] + lam * s[2] * s[2];
+    const double a = va.x + lam * s[0] * s[0], b = va.y, c = vb.x;
+    const double d = vb.y + lam * s[1] * s[1], e = vc.x, f = vc.y + lam * s[2] * s[2];
     const double c00 = d * f - e * e, c01 = c * e - b * f, c02 = b * e - c * d;
     const double idet = 1.0 / (a * c00 + b * c01 + c * c02);
-    double* o = Vinv + 6 * (size_t)p;
-    o[0] = c00 * idet;
-    o[1] = c01 * idet;
-    o[2] = c02 * idet;
-    o[3] = (a * f - c * c) * idet;
-    o[4] = (b * c - a * e) * idet;
-    o[5] = (a * d - b * b) * idet;
+    const double o0 = c00 * idet, o1 = c01 * idet, o2 = c02 * idet;
+    const double o3 = (a * f - c * c) * idet, o4 = (b * c - a * e) * idet, o5 = (a * d - b * b) * idet;
+    double2* o = reinterpret_cast<double2*>(Vinv + 6 * (size_t)p);
+    o[0] = make_double2(o0, o1); o[1] = make_double2(o2, o3); o[2] = make_double2(o4, o5);
     if (PV) {
-        double* q = PV + PV_STRIDE * (size_t)p;
-        q[0] = xp[3 * (size_t)p]; q[1] = xp[3 * (size_t)p + 1]; q[2] = xp[3 * (size_t)p + 2];
-#pragma unroll
-        for (int k = 0; k < 6; ++k) q[3 + k] = o[k];
-        q[9] = gp[3 * (size_t)p]; q[10] = gp[3 * (size_t)p + 1]; q[11] = gp[3 * (size_t)p + 2];
+        static_assert(PV_STRIDE % 2 == 0, "records are written as 16-byte words");
+        double2* q = reinterpret_cast<double2*>(PV + PV_STRIDE * (size_t)p);
+        const double x0 = xp[3 * (size_t)p], x1 = xp[3 * (size_t)p + 1], x2 = xp[3 * (size_t)p + 2];
+        const double g0 = gp[3 * (size_t)p], g1 = gp[3 * (size_t)p + 1], g2 = gp[3 * (size_t)p + 2];
+        q[0] = make_double2(x0, x1); q[1] = make_double2(x2, o0); q[2] = make_double2(o1, o2);
+        q[3] = make_double2(o3, o4); q[4] = make_double2(o5, g0); q[5] = make_double2(g1, g2);
     }
 }
 
