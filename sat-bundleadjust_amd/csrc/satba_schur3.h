@@ -103,7 +103,7 @@ __device__ inline int rs_index(int lane) {
 // SCL (weighted / robust runs with pair lists that carry observation indices): unit-weight Jacobians times the stored
 // row scales -- a separate instantiation, so that it does not carry the registers of the robust evaluation
 template <int MODEL, int NP, bool ROBUST, bool UNITW, bool SCL = false>
-__global__ __launch_bounds__(256) void k_schur_pairs(ObsArgs a, CamMajor c, Schur3Args s, double* __restrict__ S) {
+__device__ __forceinline__ void schur_pairs_body(const ObsArgs& a, const CamMajor& c, const Schur3Args& s, double* __restrict__ S) {
     __shared__ int s_q[4][S3_QUEUE];  // shared points of the two cameras waiting to be evaluated
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long long n_pairs = (long long)a.M * (a.M - 1) / 2;
@@ -154,11 +154,11 @@ __global__ __launch_bounds__(256) void k_schur_pairs(ObsArgs a, CamMajor c, Schu
 #pragma unroll
         for (int q = 0; q < NP; ++q) acc[r][q] = 0.0;
 
-    struct Rec { double2 r0, r1, r2, r3, r4; };  // packed point record: X0 X1 | X2 v00 | v01 v02 | v11 v12 | v22 g0
+    struct Rec { double2 r0, r1, r2, r3; double r4; };  // packed point record: X0 X1 | X2 v00 | v01 v02 | v11 v12 | v22
     auto load_rec = [&](int p) {
-        const double2* pv = s.PV + (PV_STRIDE / 2) * (size_t)p;  // five 16-byte gathers instead of nine 8-byte ones
+        const double2* pv = s.PV + (PV_STRIDE / 2) * (size_t)p;  // four 16-byte gathers and one of 8 instead of nine 8-byte ones
         Rec r;
-        r.r0 = pv[0]; r.r1 = pv[1]; r.r2 = pv[2]; r.r3 = pv[3]; r.r4 = pv[4];
+        r.r0 = pv[0]; r.r1 = pv[1]; r.r2 = pv[2]; r.r3 = pv[3]; r.r4 = reinterpret_cast<const double*>(pv + 4)[0];
         return r;
     };
     // listpos: pi, pj = observation indices of (camera i, point) and (camera j, point) from the pair list, scl = the
@@ -176,7 +176,7 @@ __global__ __launch_bounds__(256) void k_schur_pairs(ObsArgs a, CamMajor c, Schu
             }
         }
         const double X = rc.r0.x, Y = rc.r0.y, Z = rc.r1.x;
-        const double v00 = rc.r1.y, v01 = rc.r2.x, v02 = rc.r2.y, v11 = rc.r3.x, v12 = rc.r3.y, v22 = rc.r4.x;
+        const double v00 = rc.r1.y, v01 = rc.r2.x, v02 = rc.r2.y, v11 = rc.r3.x, v12 = rc.r3.y, v22 = rc.r4;
         double Jci[2][NP], Jpi[2][3], Jcj[2][NP], Jpj[2][3];
         if constexpr (MODEL == RPC) {
             // the RPC chain costs 2-3 kflop per Jacobian and every observation sits in (track length - 1) pairs:
@@ -196,17 +196,10 @@ __global__ __launch_bounds__(256) void k_schur_pairs(ObsArgs a, CamMajor c, Schu
                 Jpi[0][k] = ti[2 * NP + k]; Jpi[1][k] = ti[2 * NP + 3 + k];
                 Jpj[0][k] = tj[2 * NP + k]; Jpj[1][k] = tj[2 * NP + 3 + k];
             }
-        } else if constexpr (SCL) {
-            cm_jacobian<MODEL, NP, false, true>(a, c, cci, tabi, i, 0, p, X, Y, Z, Jci, Jpi);
-            cm_jacobian<MODEL, NP, false, true>(a, c, ccj, tabj, j, 0, p, X, Y, Z, Jcj, Jpj);
-#pragma unroll
-            for (int k = 0; k < NP; ++k) { Jci[0][k] *= scl_i.x; Jci[1][k] *= scl_i.y; Jcj[0][k] *= scl_j.x; Jcj[1][k] *= scl_j.y; }
-#pragma unroll
-            for (int k = 0; k < 3; ++k) { Jpi[0][k] *= scl_i.x; Jpi[1][k] *= scl_i.y; Jpj[0][k] *= scl_j.x; Jpj[1][k] *= scl_j.y; }
-        } else if constexpr (UNITW && !ROBUST) {
-            // unit weights, linear loss: the raw Jacobians.  The fixed-point mask multiplies the 2 x 2 middle matrix
-            // (4 products instead of 12 + 20 on the blocks), the fixed-camera masks are wave-uniform and multiply the
-            // reduced block once (cam_mask below)
+        } else if constexpr (SCL || (UNITW && !ROBUST)) {
+            // unit weights with the linear loss, or stored row scales (SCL): the raw Jacobians.  The fixed-point mask and
+            // the row scales multiply the 2 x 2 middle matrix (4 products instead of 12 + 20 on the blocks), the
+            // fixed-camera masks are wave-uniform and multiply the reduced block once (cam_mask below)
             double u, v;
             project<MODEL, NP, true>(cci, tabi, X, Y, Z, a.f32 != 0, u, v, Jci, Jpi);
             project<MODEL, NP, true>(ccj, tabj, X, Y, Z, a.f32 != 0, u, v, Jcj, Jpj);
@@ -226,9 +219,18 @@ __global__ __launch_bounds__(256) void k_schur_pairs(ObsArgs a, CamMajor c, Schu
         double m01 = A[0][0] * Jpj[1][0] + A[0][1] * Jpj[1][1] + A[0][2] * Jpj[1][2];
         double m10 = A[1][0] * Jpj[0][0] + A[1][1] * Jpj[0][1] + A[1][2] * Jpj[0][2];
         double m11 = A[1][0] * Jpj[1][0] + A[1][1] * Jpj[1][1] + A[1][2] * Jpj[1][2];
-        if constexpr (UNITW && !ROBUST && MODEL != RPC) {
+        if constexpr ((SCL || (UNITW && !ROBUST)) && MODEL != RPC) {
             const double mp = (p >= a.n_pts_fix) ? 1.0 : 0.0;
-            m00 *= mp; m01 *= mp; m10 *= mp; m11 *= mp;
+            if constexpr (SCL) {
+                // row scales s of the two observations (weights, robust loss): both blocks of an observation carry them, so the
+                // pair block is Jc_i^T [diag(s_i^2) (Jp_i Vinv Jp_j^T) diag(s_j^2)] Jc_j -- four products on the 2 x 2
+                // middle matrix instead of 32 on the Jacobian entries (and fewer live registers)
+                const double ax = scl_i.x * scl_i.x * mp, ay = scl_i.y * scl_i.y * mp;
+                const double bx = scl_j.x * scl_j.x, by = scl_j.y * scl_j.y;
+                m00 *= ax * bx; m01 *= ax * by; m10 *= ay * bx; m11 *= ay * by;
+            } else {
+                m00 *= mp; m01 *= mp; m10 *= mp; m11 *= mp;
+            }
         }
 #pragma unroll
         for (int q = 0; q < NP; ++q) {
@@ -319,7 +321,7 @@ __global__ __launch_bounds__(256) void k_schur_pairs(ObsArgs a, CamMajor c, Schu
 #pragma unroll
     for (int e = 0; e < NPAD; ++e) flat[e] = (e < NB2) ? acc[e / NP][e % NP] : 0.0;
     // camera masks of the unit-weight path (applied to every Jacobian by cm_jacobian on the other paths)
-    const double cam_mask = (UNITW && !ROBUST && MODEL != RPC && (i < a.n_cam_fix || j < a.n_cam_fix)) ? 0.0 : 1.0;
+    const double cam_mask = ((SCL || (UNITW && !ROBUST)) && MODEL != RPC && (i < a.n_cam_fix || j < a.n_cam_fix)) ? 0.0 : 1.0;
     const double total = cam_mask * wave_reduce_scatter<NPAD>(flat, lane, 32);
     const int e = rs_index<NPAD>(lane);
     const bool writer = (lane & (64 / NPAD - 1)) == 0 && e < NB2;  // one lane per total (NPAD = 64: every lane)
@@ -335,6 +337,10 @@ __global__ __launch_bounds__(256) void k_schur_pairs(ObsArgs a, CamMajor c, Schu
     }
 }
 
+template <int MODEL, int NP, bool ROBUST, bool UNITW, bool SCL = false>
+__global__ __launch_bounds__(256) void k_schur_pairs(ObsArgs a, CamMajor c, Schur3Args s, double* __restrict__ S) {
+    schur_pairs_body<MODEL, NP, ROBUST, UNITW, SCL>(a, c, s, S);
+}
 // ---- list path, lane-group form (experiment, SATBA_SCHUR_STREAM=1).  A wave owns up to 8 camera pairs
 // (i, j0 .. j0+7) of ONE camera i and gives each pair 8 of its lanes for the whole launch: lane (g, r) walks hits
 // r, r+8, ... of pair g.  Every wave of the grid is resident and all of them go through the point-range chunks in the
