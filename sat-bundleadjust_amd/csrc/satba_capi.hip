@@ -102,7 +102,7 @@ struct satba_problem {
     int unit_weights = 0;
     int u_full = 1;            // linearize accumulates the full U_c blocks (0: diagonal only, Schur v3 adds the rest)
     int* d_fail = nullptr;
-    bool chol_two_launch = false;
+    int chol_mode = 0;  // SATBA_CHOL: 0 double steps (default), 1 two launches per panel, 2 single steps
     double* d_scal = nullptr;  // 8 private scalars (costs of satba_residuals, timing sinks)
     double* d_keep = nullptr;  // SATBA_KEEP_LEN scalars of the running iteration that outlive the per-phase headers
     bool prepared = false;
@@ -192,7 +192,7 @@ static int dense_solve(satba_problem* p, double* S, double* b) {
         hipLaunchKernelGGL(k_dag_status, dim3(1), dim3(1), 0, p->stream, fl.ctr, p->d_fail);
         hipLaunchKernelGGL(k_trsv_back, dim3(1), dim3(1024), sizeof(double) * p->n_c, p->stream, S, p->n_c, b);
     } else {
-        cholesky_solve(S, p->n_c, b, p->d_fail, p->d_fail + 1, p->chol_two_launch, p->stream);  // clears d_fail and the step flags
+        cholesky_solve(S, p->n_c, b, p->d_fail, p->d_fail + 1, p->chol_mode, p->stream);  // clears d_fail and the step flags
     }
     HIP_TRY(hipGetLastError());
     return 0;
@@ -576,7 +576,7 @@ int satba_problem_create(const satba_problem_desc* d, satba_problem** out) {
         TRY(dev_alloc(p, &p->d_tbuf, (size_t)3 * p->N)); TRY(dev_alloc(p, &p->d_dc, p->n_c));
         TRY(dev_alloc(p, &p->d_fail, 1 + CH_MAX_STEPS));  // [0] not-SPD flag, then the panel-step flags
         if (p->n_c > CH_NB * CH_MAX_STEPS) return fail(SATBA_E_ARG, "reduced camera system too large for the dense solver");
-        { const char* cs = getenv("SATBA_CHOL"); p->chol_two_launch = cs && atoi(cs) == 1; }
+        { const char* cs = getenv("SATBA_CHOL"); p->chol_mode = cs ? atoi(cs) : 0; }
         TRY(dev_alloc(p, &p->d_dch, p->n_c));
         if (getenv("SATBA_CHOL_DAG")) {  // experimental dataflow Cholesky (satba_chol_dag.h): correct, but slower
                                          // than the blocked multi-launch version on MI355X
@@ -1121,7 +1121,7 @@ int satba_debug_chol_times(satba_problem* p, long long* host_out, int32_t* n_ste
     long long* d_ts = nullptr;
     HIP_TRY(hipMalloc((void**)&d_ts, sizeof(long long) * 8 * CH_MAX_STEPS));
     HIP_TRY(hipMemset(d_ts, 0, sizeof(long long) * 8 * CH_MAX_STEPS));
-    cholesky_solve(p->payload(), p->n_c, p->d_dch, p->d_fail, p->d_fail + 1, false, p->stream, d_ts);
+    cholesky_solve(p->payload(), p->n_c, p->d_dch, p->d_fail, p->d_fail + 1, 2, p->stream, d_ts);
     HIP_TRY(hipStreamSynchronize(p->stream));
     HIP_TRY(hipMemcpy(host_out, d_ts, sizeof(long long) * 8 * CH_MAX_STEPS, hipMemcpyDeviceToHost));
     HIP_TRY(hipFree(d_ts));

@@ -165,8 +165,10 @@ __device__ inline double half_rsqrt(double d) {
 // tools/chol_times.py).
 // FULL: the panel has all CH_NB columns (every step but possibly the last).
 template <bool FULL>
-__global__ __launch_bounds__(256) void k_chol_step(double* __restrict__ A, int n, int kp, int k0, int* __restrict__ fail,
+__global__ __launch_bounds__(256) void k_chol_step(double* __restrict__ A, int n, int kp2, int kp, int k0, int* __restrict__ fail,
                                                    int* __restrict__ flag, double* __restrict__ b, long long* __restrict__ ts) {
+    // kp2 (>= 0 only for the first single step after double steps, k_chol_dstep): one more previous panel whose trailing
+    // update is still pending; it is applied before panel kp in the same pass over the tile
     // ts (tools only, normally null): 8 wall-clock stamps of this step -- 0 start of tile (0,0), 1 its update done,
     // 2 diagonal block factorised (flag raised), 3 its wave done; 4..7 the same for tile (1, 0): start, update done, flag seen, end
     __shared__ double Pi[CH_NB][64], Pj[CH_NB][64];  // Pj doubles as the stash X[c][r] of the tile's first 32 columns
@@ -198,33 +200,36 @@ __global__ __launch_bounds__(256) void k_chol_step(double* __restrict__ A, int n
                 const int r = r0 + tr + i, c = c0 + tc + j;
                 old[j][i] = (r < n && c < n && r >= c) ? A[(size_t)r + (size_t)c * n] : 0.0;
             }
-        for (int idx = tid; idx < CH_NB * 64; idx += 256) {
-            const int r = idx & 63, k = idx >> 6;
-            Pi[k][r] = (r0 + r < n) ? A[(size_t)(r0 + r) + (size_t)(kp + k) * n] : 0.0;
-            Pj[k][r] = (c0 + r < n) ? A[(size_t)(c0 + r) + (size_t)(kp + k) * n] : 0.0;
-        }
         if (bj == 0 && tid < 64) brow[tid] = (r0 + tid < n) ? b[r0 + tid] : 0.0;
-        if (bj == 0 && tid >= 64 && tid < 64 + CH_NB) lcol[0][tid - 64] = b[kp + tid - 64];  // y of the previous panel
-        __syncthreads();
-        if (bj == 0 && tid < 64) {
-            double s = 0.0;
-#pragma unroll 8
-            for (int k = 0; k < CH_NB; ++k) s += Pi[k][tid] * lcol[0][k];
-            const double v = brow[tid] - s;
-            brow[tid] = v;  // only this thread touches brow[tid] until the barrier below
-            if (bi > 0 && r0 + tid < n) b[r0 + tid] = v;  // tile (0, 0): solved and stored below
-        }
         double acc[4][4] = {};
+        for (int pass = (kp2 >= 0) ? 0 : 1; pass < 2; ++pass) {
+            const int kq = pass == 0 ? kp2 : kp;
+            if (pass == 1 && kp2 >= 0) __syncthreads();  // the first pass is done with Pi, Pj, lcol
+            for (int idx = tid; idx < CH_NB * 64; idx += 256) {
+                const int r = idx & 63, k = idx >> 6;
+                Pi[k][r] = (r0 + r < n) ? A[(size_t)(r0 + r) + (size_t)(kq + k) * n] : 0.0;
+                Pj[k][r] = (c0 + r < n) ? A[(size_t)(c0 + r) + (size_t)(kq + k) * n] : 0.0;
+            }
+            if (bj == 0 && tid >= 64 && tid < 64 + CH_NB) lcol[0][tid - 64] = b[kq + tid - 64];  // y of that panel
+            __syncthreads();
+            if (bj == 0 && tid < 64) {
+                double s = 0.0;
 #pragma unroll 8
-        for (int k = 0; k < CH_NB; ++k) {
-            double a[4], c[4];
+                for (int k = 0; k < CH_NB; ++k) s += Pi[k][tid] * lcol[0][k];
+                brow[tid] -= s;  // only this thread touches brow[tid] until the barrier below
+            }
+#pragma unroll 8
+            for (int k = 0; k < CH_NB; ++k) {
+                double a[4], c[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { a[i] = Pi[k][tr + i]; c[i] = Pj[k][tc + i]; }
+                for (int i = 0; i < 4; ++i) { a[i] = Pi[k][tr + i]; c[i] = Pj[k][tc + i]; }
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) acc[j][i] += a[i] * c[j];
+                    for (int i = 0; i < 4; ++i) acc[j][i] += a[i] * c[j];
+            }
         }
+        if (bj == 0 && tid < 64 && bi > 0 && r0 + tid < n) b[r0 + tid] = brow[tid];  // tile (0, 0): solved and stored below
         if (bj == 0) __syncthreads();  // everyone is done reading Pj before it becomes the stash
 #pragma unroll
         for (int j = 0; j < 4; ++j)
@@ -520,12 +525,19 @@ __global__ __launch_bounds__(1024) void k_trsv_back_rl(const double* __restrict_
     if (c < n) b[c] = yb[c];
 }
 
+}  // namespace satba
+#include "satba_chol2.h"
+namespace satba {
+
 constexpr int CH_MAX_STEPS = 256;  // flags: one per panel step (n <= 8192)
 
 // Factorise A (n x n, column-major lower, in place) and solve A z = b in place.  *fail != 0 if A was not SPD.
 // flags: CH_MAX_STEPS ints of scratch directly behind *fail (flags == fail + 1); both are cleared here.  two_launch: the previous k_potrf_trsm + k_syrk pipeline.
-inline void cholesky_solve(double* A, int n, double* b, int* fail, int* flags, bool two_launch, hipStream_t stream,
+// mode 0: double steps (k_chol_dstep, satba_chol2.h) while at least 64 columns remain, then single steps; 1: the first
+// pipeline (k_potrf_trsm + k_syrk, two launches per panel); 2: single steps only (k_chol_step)
+inline void cholesky_solve(double* A, int n, double* b, int* fail, int* flags, int mode, hipStream_t stream,
                            long long* ts = nullptr) {
+    const bool two_launch = mode == 1;
     if (two_launch) {
         (void)hipMemsetAsync(fail, 0, sizeof(int), stream);
         for (int k0 = 0; k0 < n; k0 += CH_NB) {
@@ -540,14 +552,22 @@ inline void cholesky_solve(double* A, int n, double* b, int* fail, int* flags, b
         }
     } else {
         (void)hipMemsetAsync(fail, 0, sizeof(int) * (1 + CH_MAX_STEPS), stream);  // flags == fail + 1: one fill for both
-        int step = 0;
-        for (int k0 = 0; k0 < n; k0 += CH_NB, ++step) {
+        int step = 0, k0 = 0, kp2 = -1, kp = -1;
+        if (mode == 0 && !ts) {
+            for (; n - k0 >= 2 * CH_NB; k0 += 2 * CH_NB, step += 2) {
+                const int T = (n - k0 + 63) / 64;
+                hipLaunchKernelGGL(k_chol_dstep, dim3(T * (T + 1) / 2), dim3(256), 0, stream, A, n, kp2, kp, k0, fail, flags + step, b);
+                kp2 = k0; kp = k0 + CH_NB;
+            }
+        }
+        for (; k0 < n; k0 += CH_NB, ++step) {
             const int T = (n - k0 + 63) / 64;
             long long* tsk = ts ? ts + 8 * step : nullptr;
             if (n - k0 >= CH_NB)
-                hipLaunchKernelGGL(k_chol_step<true>, dim3(T * (T + 1) / 2), dim3(256), 0, stream, A, n, k0 - CH_NB, k0, fail, flags + step, b, tsk);
+                hipLaunchKernelGGL(k_chol_step<true>, dim3(T * (T + 1) / 2), dim3(256), 0, stream, A, n, kp2, kp, k0, fail, flags + step, b, tsk);
             else
-                hipLaunchKernelGGL(k_chol_step<false>, dim3(T * (T + 1) / 2), dim3(256), 0, stream, A, n, k0 - CH_NB, k0, fail, flags + step, b, tsk);
+                hipLaunchKernelGGL(k_chol_step<false>, dim3(T * (T + 1) / 2), dim3(256), 0, stream, A, n, kp2, kp, k0, fail, flags + step, b, tsk);
+            kp2 = -1; kp = k0;
         }
     }
     if (n <= 1024 && !two_launch) {
