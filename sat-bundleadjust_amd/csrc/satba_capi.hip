@@ -243,7 +243,10 @@ static int launch_lin1u(satba_problem* p, const ObsArgs& a) {
     double* gpv = p->d_g + p->n_c;
     double* cost = p->d_xb + 0;
     double* gmax = p->d_xb + SATBA_HDR_FIXED + p->rank;
-    if (p->loss == 0)
+    if (p->loss == 0 && p->unit_weights && MODEL != RPC)  // RPC keeps the generic form (its Jacobian store carries the masks)
+        hipLaunchKernelGGL((k_linearize<MODEL, NP, false, CL, FULLU, false, MODEL != RPC>), dim3(p->lin_grid), dim3(LinCfg<false>::THREADS),
+                           lin1_lds(p, false), p->stream, a, p->d_f, p->d_V, gpv, p->d_part, cost, gmax);
+    else if (p->loss == 0)
         hipLaunchKernelGGL((k_linearize<MODEL, NP, false, CL, FULLU>), dim3(p->lin_grid), dim3(LinCfg<false>::THREADS),
                            lin1_lds(p, false), p->stream, a, p->d_f, p->d_V, gpv, p->d_part, cost, gmax);
     else if (p->loss == SATBA_LOSS_SOFT_L1 && MODEL != RPC)  // the pipeline's robust loss, specialised (RPC needs the registers)
@@ -525,6 +528,8 @@ int satba_problem_create(const satba_problem_desc* d, satba_problem** out) {
             return fail(SATBA_E_ARG, "n_cam = %d exceeds the LDS budget of the Schur kernels of this build", p->M);
         if (lin1_fits) {
             SATBA_DISPATCH(p, TRY(raise_lds_limit(k_linearize<MODEL, NP, false, CL, true>, lin1_lds(p, false))));
+            SATBA_DISPATCH(p, TRY(raise_lds_limit(k_linearize<MODEL, NP, false, CL, true, false, MODEL != RPC>, lin1_lds(p, false))));
+            SATBA_DISPATCH(p, TRY(raise_lds_limit(k_linearize<MODEL, NP, false, CL, false, false, MODEL != RPC>, lin1_lds(p, false))));
             SATBA_DISPATCH(p, TRY(raise_lds_limit(k_linearize<MODEL, NP, true, CL, true>, lin1_lds(p, true))));
             SATBA_DISPATCH(p, TRY(raise_lds_limit(k_linearize<MODEL, NP, false, CL, false>, lin1_lds(p, false))));
             SATBA_DISPATCH(p, TRY(raise_lds_limit(k_linearize<MODEL, NP, true, CL, false>, lin1_lds(p, true))));

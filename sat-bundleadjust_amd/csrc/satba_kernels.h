@@ -49,7 +49,10 @@ struct ObsArgs {
 
 // weighted, robust-scaled residual and (optionally) Jacobian blocks of observation o
 // ROBUST: the loss is not linear; SOFT: it is soft_l1 (folds the runtime loss switch away: registers, no log / atan code)
-template <int MODEL, int NP, bool JAC, bool ROBUST = true, bool SOFT = false>
+// UNITW (with !ROBUST): every weight is 1 and the loss is linear -- the weight is not applied and the Jacobian blocks
+// are returned WITHOUT the fixed-camera / fixed-point masks (the caller masks its sums instead: ~20 multiplications
+// per observation fewer)
+template <int MODEL, int NP, bool JAC, bool ROBUST = true, bool SOFT = false, bool UNITW = false>
 struct ObsEval {
     double ftrue[2];  // w * (proj - obs)
     double fs[2];     // robust-scaled residual
@@ -76,6 +79,13 @@ struct ObsEval {
         const double* tab = (MODEL == RPC) ? a.rpc + (size_t)cam * 90 : nullptr;
         double u, v;
         project<MODEL, NP, JAC>(cc, tab, X, Y, Z, a.f32 != 0, u, v, Jc, Jp);
+        if constexpr (UNITW && !ROBUST) {
+            ftrue[0] = u - ob.x; ftrue[1] = v - ob.y;
+            fs[0] = ftrue[0]; fs[1] = ftrue[1];
+            rho = ftrue[0] * ftrue[0] + ftrue[1] * ftrue[1];
+            sw[0] = 1.0; sw[1] = 1.0;
+            return;
+        }
         ftrue[0] = w * (u - ob.x);
         ftrue[1] = w * (v - ob.y);
         double r0, r1, js0 = 1.0, js1 = 1.0;
@@ -270,7 +280,9 @@ struct LinCfg {
 // is all the solver needs before the Schur phase, whose camera-major pass (k_schur_diag) forms the full J_c^T J_c
 // blocks in registers anyway.
 // SOFT (with ROBUST): soft_l1 specialised at compile time; it fits the 1024-thread configuration of the linear loss
-template <int MODEL, int NP, bool ROBUST, bool CL, bool FULLU, bool SOFT = false>
+// UNITW (linear loss, every weight 1): the weight array is not read, the Jacobians carry no masks -- the fixed-camera mask
+// is applied when the workgroup's camera table is flushed, the fixed-point mask when a point's sums are stored
+template <int MODEL, int NP, bool ROBUST, bool CL, bool FULLU, bool SOFT = false, bool UNITW = false>
 __global__ __launch_bounds__(LinCfg<ROBUST && !SOFT>::THREADS) void k_linearize(ObsArgs a, double2* __restrict__ f, double* __restrict__ V,
                                                                       double* __restrict__ gp, double* __restrict__ part,
                                                                       double* __restrict__ hdr_cost, double* __restrict__ hdr_gpmax) {
@@ -313,7 +325,8 @@ __global__ __launch_bounds__(LinCfg<ROBUST && !SOFT>::THREADS) void k_linearize(
     if constexpr (PIPE) {
         if (o0 + lane < o1) {
             const long long o = (long long)o0 + lane;
-            pt = a.pt[o]; cam = a.cam[o]; ob = a.obs[o]; w = a.w[o];
+            pt = a.pt[o]; cam = a.cam[o]; ob = a.obs[o];
+            if constexpr (!UNITW) w = a.w[o];
             const double* px = a.x + a.n_c + 3 * (size_t)pt;
             X = px[0]; Y = px[1]; Z = px[2];
         }
@@ -328,7 +341,8 @@ __global__ __launch_bounds__(LinCfg<ROBUST && !SOFT>::THREADS) void k_linearize(
             npt = -1 - lane; ncam = 0;
             if (n0 + lane < n1) {
                 const long long on = (long long)n0 + lane;
-                npt = a.pt[on]; ncam = a.cam[on]; nob = a.obs[on]; nw = a.w[on];
+                npt = a.pt[on]; ncam = a.cam[on]; nob = a.obs[on];
+                if constexpr (!UNITW) nw = a.w[on];
             }
             range(tile + 2 * stride, nn0, nn1, nnsplit);
             __builtin_amdgcn_sched_barrier(0);
@@ -336,7 +350,7 @@ __global__ __launch_bounds__(LinCfg<ROBUST && !SOFT>::THREADS) void k_linearize(
             pt = -1 - lane; cam = 0;
         }
         if (active) {
-            ObsEval<MODEL, NP, true, ROBUST, SOFT> e;
+            ObsEval<MODEL, NP, true, ROBUST, SOFT, UNITW> e;
             if constexpr (PIPE) {
                 e.eval_loaded(a, cam, pt, cbase + (size_t)cam * CAMC, ob, w, X, Y, Z);
             } else {
@@ -417,7 +431,8 @@ __global__ __launch_bounds__(LinCfg<ROBUST && !SOFT>::THREADS) void k_linearize(
                     const double a3 = (l + 3 < en) ? col[l + 3] : 0.0;
                     s0 += a0; s1 += a1; s2 += a2; s3 += a3;
                 }
-                const double sum = (s0 + s1) + (s2 + s3);
+                double sum = (s0 + s1) + (s2 + s3);
+                if constexpr (UNITW) sum = (ptq >= a.n_pts_fix) ? sum : 0.0;  // fixed points: their blocks are masked here
                 double* dst = (v < 6) ? V + 6 * (size_t)ptq + v : gp + 3 * (size_t)ptq + (v - 6);
                 if (osplit) atomicAdd(dst, sum);
                 else *dst = sum;
@@ -445,7 +460,10 @@ __global__ __launch_bounds__(LinCfg<ROBUST && !SOFT>::THREADS) void k_linearize(
         atomic_max_pos(hdr_gpmax, g);
     }
     double* out = part + (size_t)blockIdx.x * a.M * CU;
-    for (int i = threadIdx.x; i < a.M * CU; i += THREADS) out[i] = s_acc[(i / CU) * CUS + i % CU];
+    for (int i = threadIdx.x; i < a.M * CU; i += THREADS) {
+        const double t = s_acc[(i / CU) * CUS + i % CU];
+        out[i] = (UNITW && i / CU < a.n_cam_fix) ? 0.0 : t;  // fixed cameras: masked here on the unit-weight path
+    }
 }
 
 // sum the per-workgroup camera partials and expand to the exchange payload: U (M x NP x NP, full), g_c (M x NP).
