@@ -53,7 +53,7 @@ def lm_step(eng, comm, st, trf):
     eng.prepare(st["first"])
     comm.allreduce(eng, hdr)
     eng.schur_auto(-1.0 if st["first"] else st["Delta"], 1e-14)
-    comm.allreduce(eng, eng.len_schur)
+    comm.allreduce_schur(eng)
     eng.solve()
     h = exchange(hdr)
     st["first"] = False

@@ -100,6 +100,15 @@ int64_t satba_header_len(const satba_problem *p);
  * exchange buffer; NULL restores the internally allocated one. */
 int satba_bind_exchange(satba_problem *p, double *device_ptr, int64_t len);
 
+/* The reduced camera system S is symmetric and only its lower triangle is formed and used: for the all-reduce between
+ * ranks (no counterpart in the reference) the Schur payload [header | S (n_c^2) | rhs (n_c)] of the
+ * exchange buffer is packed to [header | lower triangle, column-major, n_c (n_c + 1) / 2 | rhs] in caller-provided device
+ * memory (again typically a torch tensor), all-reduced there, and unpacked -- half the bytes over xGMI.
+ * satba_packed_schur_len: length of that packed buffer in doubles. */
+int64_t satba_packed_schur_len(const satba_problem *p);
+int satba_pack_schur(satba_problem *p, double *packed_device_ptr);
+int satba_unpack_schur(satba_problem *p, const double *packed_device_ptr);
+
 /* loss and f_scale of least_squares (ba_core.py:292-293). */
 int satba_configure(satba_problem *p, int32_t loss, double f_scale);
 

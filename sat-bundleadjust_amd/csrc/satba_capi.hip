@@ -826,6 +826,39 @@ int satba_bind_exchange(satba_problem* p, double* device_ptr, int64_t len) {
     return 0;
 }
 
+// lower triangle of S (column-major, n x n) <-> packed columns; block j = column j, block n = header and rhs
+__global__ __launch_bounds__(256) void k_pack_lower(int n, int hdr, double* __restrict__ xb, double* __restrict__ packed, int unpack) {
+    const int j = blockIdx.x;
+    const long long tri = (long long)n * (n + 1) / 2;
+    if (j == n) {
+        for (int i = threadIdx.x; i < hdr + n; i += 256) {
+            double* a = i < hdr ? xb + i : xb + hdr + (size_t)n * n + (i - hdr);
+            double* b = i < hdr ? packed + i : packed + hdr + tri + (i - hdr);
+            if (unpack) *a = *b; else *b = *a;
+        }
+        return;
+    }
+    double* col = xb + hdr + (size_t)j * n;
+    double* pk = packed + hdr + ((long long)j * n - (long long)j * (j - 1) / 2) - j;  // pk[r] for r >= j
+    for (int r = j + threadIdx.x; r < n; r += 256) {
+        if (unpack) col[r] = pk[r]; else pk[r] = col[r];
+    }
+}
+
+int64_t satba_packed_schur_len(const satba_problem* p) {
+    return p ? p->hdr + (long long)p->n_c * (p->n_c + 1) / 2 + p->n_c : 0;
+}
+
+static int pack_schur_impl(satba_problem* p, double* packed, int unpack) {
+    if (!p || !packed) return fail(SATBA_E_ARG, "null argument");
+    HIP_TRY(hipSetDevice(p->device));
+    hipLaunchKernelGGL(k_pack_lower, dim3(p->n_c + 1), dim3(256), 0, p->stream, p->n_c, (int)p->hdr, p->d_xb, packed, unpack);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+int satba_pack_schur(satba_problem* p, double* packed) { return pack_schur_impl(p, packed, 0); }
+int satba_unpack_schur(satba_problem* p, const double* packed) { return pack_schur_impl(p, const_cast<double*>(packed), 1); }
+
 int satba_configure(satba_problem* p, int32_t loss, double f_scale) {
     if (!p) return fail(SATBA_E_ARG, "null handle");
     if (loss < 0 || loss > 4) return fail(SATBA_E_ARG, "unknown loss %d", loss);

@@ -29,6 +29,7 @@ SYMBOLS = [
     "satba_residuals", "satba_linearize", "satba_prepare", "satba_schur", "satba_schur_auto", "satba_solve", "satba_subspace", "satba_subspace_products", "satba_trial", "satba_trial_gn",
     "satba_accept", "satba_read_header", "satba_get_blocks", "satba_get_jacobian", "satba_get_exchange",
     "satba_set_exchange", "satba_get_vector", "satba_time_kernel",
+    "satba_packed_schur_len", "satba_pack_schur", "satba_unpack_schur",
 ]
 
 _dp = C.POINTER(C.c_double)
@@ -91,6 +92,10 @@ def load_library(path=None):
     lib.satba_get_jacobian.argtypes = [h, _dp, _dp]
     lib.satba_get_exchange.argtypes = [h, C.c_int64, C.c_int64, _dp]
     lib.satba_set_exchange.argtypes = [h, C.c_int64, C.c_int64, _dp]
+    lib.satba_packed_schur_len.argtypes = [h]
+    lib.satba_packed_schur_len.restype = C.c_int64
+    lib.satba_pack_schur.argtypes = [h, C.c_void_p]
+    lib.satba_unpack_schur.argtypes = [h, C.c_void_p]
     lib.satba_get_vector.argtypes = [h, C.c_int32, _dp]
     lib.satba_time_kernel.argtypes = [h, C.c_int32, C.c_int32, C.POINTER(C.c_float)]
     if path == LIB_PATH:
@@ -175,6 +180,8 @@ class HipEngine:
             _check(self.lib, self.lib.satba_bind_exchange(self._h, C.c_void_p(self.xb.data_ptr()), self.xb_len))
             self.use_stream(torch.cuda.current_stream(self.device))
         self._hdr_host = np.zeros(self.hdr)
+        self.xp = None  # packed Schur payload (header | lower triangle of S | rhs), allocated on first use
+        self.len_schur_packed = int(self.lib.satba_packed_schur_len(self._h))
         self.set_x(sh.local_x(p, np.asarray(p.params_opt, dtype=np.float64)))
 
     # -- lifetime
@@ -188,6 +195,20 @@ class HipEngine:
             self.close()
         except Exception:
             pass
+
+    # -- packed exchange of the Schur payload (multi-rank runs): S is symmetric, only its lower triangle is formed
+    def pack_schur(self):
+        """Copy [header | lower triangle of S | rhs] of the exchange buffer into the tensor `xp` and return it."""
+        if self._torch is None:
+            raise SatbaError("the packed exchange needs the torch exchange buffer")
+        if self.xp is None:
+            self.xp = self._torch.zeros(self.len_schur_packed, dtype=self._torch.float64, device="cuda:{}".format(self.device))
+        _check(self.lib, self.lib.satba_pack_schur(self._h, C.c_void_p(self.xp.data_ptr())))
+        return self.xp
+
+    def unpack_schur(self):
+        """Copy the (all-reduced) packed payload back into the exchange buffer."""
+        _check(self.lib, self.lib.satba_unpack_schur(self._h, C.c_void_p(self.xp.data_ptr())))
 
     def use_stream(self, stream):
         """Launch on a torch.cuda.Stream (or None for the default stream)."""

@@ -37,6 +37,7 @@ Engine contract (implemented by engine_hip.HipEngine; tests use a CPU stand-in b
     accept()            x <- x_new
 """
 import math
+import os
 
 import numpy as np
 
@@ -66,6 +67,9 @@ class SingleComm:
     def allreduce(self, engine, n):
         pass
 
+    def allreduce_schur(self, engine):
+        pass
+
     def sum_array(self, a):
         return a
 
@@ -79,11 +83,27 @@ class TorchComm:
         self.dist, self.group = dist, group
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
         self.always = always  # issue the collectives even for a single rank (plumbing tests)
+        self.pack = not os.environ.get("SATBA_NO_PACK")  # packed lower triangle for the Schur all-reduce
 
     def allreduce(self, engine, n):
         """Sum the first n doubles of the engine's exchange buffer over all ranks, in place."""
         if self.world > 1 or self.always:
             self.dist.all_reduce(engine.xb[:n], op=self.dist.ReduceOp.SUM, group=self.group)
+
+    def allreduce_schur(self, engine):
+        """
+        Sum the Schur payload (header, reduced camera system, right-hand side) over all ranks.  Engines that can pack the
+        lower triangle of the symmetric system (HipEngine) send n_c (n_c + 1) / 2 instead of n_c^2 doubles: the 8 MB
+        all-reduce of the headline shape is the largest message of an iteration.
+        """
+        if not (self.world > 1 or self.always):
+            return
+        if getattr(engine, "pack_schur", None) is not None and getattr(engine, "xb", None) is not None and self.pack:
+            xp = engine.pack_schur()
+            self.dist.all_reduce(xp, op=self.dist.ReduceOp.SUM, group=self.group)
+            engine.unpack_schur()
+        else:
+            self.allreduce(engine, engine.len_schur)
 
     def sum_array(self, a):
         """Element-wise sum of a host float64 array over all ranks (used to assemble sharded results)."""
@@ -297,7 +317,7 @@ def trf_solve(engine, comm=None, ftol=1e-8, xtol=1e-8, gtol=1e-8, max_nfev=None,
         engine.prepare(Delta is None)
         comm.allreduce(engine, hdr)
         engine.schur_auto(-1.0 if Delta is None else Delta, 0.0)
-        comm.allreduce(engine, engine.len_schur)
+        comm.allreduce_schur(engine)
         engine.solve()
         return exchange(hdr)
 
@@ -333,7 +353,7 @@ def trf_solve(engine, comm=None, ftol=1e-8, xtol=1e-8, gtol=1e-8, max_nfev=None,
                 break
             reg = max(reg, 1e-16) * 100.0
             engine.schur(reg)
-            comm.allreduce(engine, engine.len_schur)
+            comm.allreduce_schur(engine)
             engine.solve()
             h = exchange(hdr)
         else:

@@ -227,6 +227,30 @@ def test_fixed_cameras_points_and_weights(gpu, model, corr, ref_w, loss):
     dev.close()
 
 
+def test_packed_schur_exchange(gpu):
+    """The packed form of the Schur payload (what multi-rank runs all-reduce): header | lower triangle | rhs, and back."""
+    _, p, g = cases.fun_case("affine_RT")
+    dev = HipEngine(p)
+    dev.configure("linear", 1.0)
+    dev.set_x(g["v"][1])
+    dev.linearize(); dev.prepare(True); dev.schur(0.37)
+    n_c, hdr = dev.n_c, dev.hdr
+    full = dev.get_exchange(0, dev.len_schur).copy()
+    S = full[hdr: hdr + n_c * n_c].reshape(n_c, n_c)  # S[j, r]: column j of the column-major matrix
+    xp = dev.pack_schur().cpu().numpy()
+    assert xp.size == hdr + n_c * (n_c + 1) // 2 + n_c == dev.len_schur_packed
+    expect = np.concatenate([full[:hdr]] + [S[j, j:] for j in range(n_c)] + [full[hdr + n_c * n_c:]])
+    assert np.array_equal(xp, expect)
+    dev.xp.mul_(2.0)  # what a two-rank all-reduce of identical shards would leave
+    dev.unpack_schur()
+    back = dev.get_exchange(0, dev.len_schur)
+    S2 = back[hdr: hdr + n_c * n_c].reshape(n_c, n_c)
+    for j in range(n_c):
+        assert np.array_equal(S2[j, j:], 2.0 * S[j, j:]) and np.array_equal(S2[j, :j], S[j, :j])  # upper part untouched
+    assert np.array_equal(back[:hdr], 2.0 * full[:hdr]) and np.array_equal(back[hdr + n_c * n_c:], 2.0 * full[hdr + n_c * n_c:])
+    dev.close()
+
+
 def test_schur_matrix_and_rhs(gpu):
     _, p, g = cases.fun_case("affine_RT")
     v = g["v"][1]
