@@ -120,18 +120,41 @@ __global__ __launch_bounds__(256) void k_chol_dstep(double* __restrict__ A, int 
             }
         if (bj == 0 && tid < 64) brow[tid] = (r0 + tid < n) ? b[r0 + tid] : 0.0;
         double acc[4][4] = {};
-        bool loaded = false;
-        for (int pass = 0; pass < 2; ++pass) {
-            const int kq = pass == 0 ? kpA : kpB;
-            if (kq < 0) continue;
-            if (loaded) __syncthreads();  // the previous pass is done with Pi, Pj, lcol
-            loaded = true;
-            for (int idx = tid; idx < CH_NB * 64; idx += 256) {
-                const int r = idx & 63, k = idx >> 6;
-                Pi[k][r] = (r0 + r < n) ? A[(size_t)(r0 + r) + (size_t)(kq + k) * n] : 0.0;
-                Pj[k][r] = (c0 + r < n) ? A[(size_t)(c0 + r) + (size_t)(kq + k) * n] : 0.0;
+        // the loads of the second panel are issued before the arithmetic of the first (registers, then LDS): one exposed
+        // round of loads per launch instead of two
+        constexpr int PF = CH_NB * 64 / 256;  // panel elements per thread and operand
+        double pfi[PF], pfj[PF], pfy = 0.0;
+        const int kq1 = kpA >= 0 ? kpA : kpB, kq2 = kpA >= 0 ? kpB : -1;  // first / second panel to apply (-1: none)
+        if (kq1 >= 0) {
+#pragma unroll
+            for (int t = 0; t < PF; ++t) {
+                const int idx = tid + t * 256, r = idx & 63, k = idx >> 6;
+                Pi[k][r] = (r0 + r < n) ? A[(size_t)(r0 + r) + (size_t)(kq1 + k) * n] : 0.0;
+                Pj[k][r] = (c0 + r < n) ? A[(size_t)(c0 + r) + (size_t)(kq1 + k) * n] : 0.0;
             }
-            if (bj == 0 && tid >= 64 && tid < 64 + CH_NB) lcol[0][tid - 64] = b[kq + tid - 64];  // y of that panel
+            if (bj == 0 && tid >= 64 && tid < 64 + CH_NB) lcol[0][tid - 64] = b[kq1 + tid - 64];  // y of that panel
+        }
+        if (kq2 >= 0) {
+#pragma unroll
+            for (int t = 0; t < PF; ++t) {
+                const int idx = tid + t * 256, r = idx & 63, k = idx >> 6;
+                pfi[t] = (r0 + r < n) ? A[(size_t)(r0 + r) + (size_t)(kq2 + k) * n] : 0.0;
+                pfj[t] = (c0 + r < n) ? A[(size_t)(c0 + r) + (size_t)(kq2 + k) * n] : 0.0;
+            }
+            if (bj == 0 && tid >= 64 && tid < 64 + CH_NB) pfy = b[kq2 + tid - 64];
+        }
+        for (int pass = 0; pass < 2; ++pass) {
+            if ((pass == 0 ? kq1 : kq2) < 0) continue;
+            if (pass == 1) {
+                __syncthreads();  // the first pass is done with Pi, Pj, lcol
+#pragma unroll
+                for (int t = 0; t < PF; ++t) {
+                    const int idx = tid + t * 256, r = idx & 63, k = idx >> 6;
+                    Pi[k][r] = pfi[t];
+                    Pj[k][r] = pfj[t];
+                }
+                if (bj == 0 && tid >= 64 && tid < 64 + CH_NB) lcol[0][tid - 64] = pfy;
+            }
             __syncthreads();
             if (bj == 0 && tid < 64) {
                 double s = 0.0;
