@@ -206,7 +206,10 @@ static int zero_header(satba_problem* p) {
 static int launch_residual(satba_problem* p, bool at_new, double2* f, double* hdr_slot) {
     ObsArgs a = obs_args(p, at_new);
     const int grid = grid_for(p->K, 512, 512);
-    SATBA_DISPATCH(p, hipLaunchKernelGGL((k_residual<MODEL, NP, CL>), dim3(grid), dim3(512), p->camc_bytes, p->stream, a, f, hdr_slot));
+    if (p->loss == 0 && p->unit_weights)
+        SATBA_DISPATCH(p, hipLaunchKernelGGL((k_residual<MODEL, NP, CL, true>), dim3(grid), dim3(512), p->camc_bytes, p->stream, a, f, hdr_slot));
+    else
+        SATBA_DISPATCH(p, hipLaunchKernelGGL((k_residual<MODEL, NP, CL>), dim3(grid), dim3(512), p->camc_bytes, p->stream, a, f, hdr_slot));
     HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -231,17 +231,26 @@ __global__ void k_cam_consts(int model, int M, int n_p, int c_p, const double* _
 // ------------------------------------------------------------------------------------------------ K1 residuals
 // ba_core.fun (ref:bundle_adjust/ba_core.py:157-183): one thread per observation, grid-stride.
 // hdr_cost += 0.5 * sum rho.  f may be null (cost only).
-template <int MODEL, int NP, bool CL>
+// UNITW: every weight is 1 and the loss is linear (the weight array is not read: 8 of 32 streamed bytes per observation)
+template <int MODEL, int NP, bool CL, bool UNITW = false>
 __global__ __launch_bounds__(512) void k_residual(ObsArgs a, double2* __restrict__ f, double* __restrict__ hdr_cost) {
     extern __shared__ double s_camc_res[];
     const double* cbase = cam_table<CL>(a, s_camc_res, 512);
     double acc = 0.0;
     for (long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x; o < a.K; o += (long long)gridDim.x * blockDim.x) {
-        ObsEval<MODEL, NP, false> e;
         const int cam = a.cam[o];
-        e.eval(a, o, cam, a.pt[o], cbase + (size_t)cam * CAMC);
-        if (f) f[o] = make_double2(e.ftrue[0], e.ftrue[1]);
-        acc += e.rho;
+        if constexpr (UNITW) {
+            ObsEval<MODEL, NP, false, false, false, true> e;
+            const double* px = a.x + a.n_c + 3 * (size_t)a.pt[o];
+            e.eval_loaded(a, cam, 0, cbase + (size_t)cam * CAMC, a.obs[o], 1.0, px[0], px[1], px[2]);
+            if (f) f[o] = make_double2(e.ftrue[0], e.ftrue[1]);
+            acc += e.rho;
+        } else {
+            ObsEval<MODEL, NP, false> e;
+            e.eval(a, o, cam, a.pt[o], cbase + (size_t)cam * CAMC);
+            if (f) f[o] = make_double2(e.ftrue[0], e.ftrue[1]);
+            acc += e.rho;
+        }
     }
     double v[1] = {0.5 * acc};
     double* const dst[1] = {hdr_cost};
