@@ -567,6 +567,7 @@ __global__ __launch_bounds__(256) void k_prepare_vec(int n, int n_c, int NP, int
 }
 
 // ------------------------------------------------------------------------------------------------ Jacobian-vector products
+constexpr int JVP_ROW = 15;  // per-camera constants of the affine form of k_jvp: B (6) | b (2) | A (6), odd stride
 // For NV vectors given in scaled variables (v = q / scale_inv): sums of (J v_a) . (J v_b) over the observations.
 // NV = 1: out[0] += |J v1|^2.   NV = 2: out[0] += |J v1|^2, out[1] += (J v1).(J v2), out[2] += |J v2|^2.
 template <int MODEL, int NP, int NV, bool CL, bool PRE = false>
@@ -582,6 +583,76 @@ __global__ __launch_bounds__(512) void k_jvp(ObsArgs a, const double* __restrict
         __syncthreads();
     }
     double s11 = 0.0, s12 = 0.0, s22 = 0.0;
+    if constexpr (MODEL == AFFINE && PRE && NV == 1 && CL) {
+        // affine cameras: J_c v_c = B_c X + b_c with B_c = sum_i v_ci D_ci, b_c = K-columns . v_cT, and J_p = A_c -- the
+        // per-camera constants of k_backsub (JVP_ROW doubles per camera, odd stride), built here from the staged vector;
+        // an observation costs 14 LDS reads and 18 multiply-adds instead of the Jacobian evaluation and 16 reads
+        __syncthreads();  // every thread is done with the staging loops above
+        double* tab = s_camc_jvp;  // overwrites the camera constants: M x JVP_ROW <= M x CAMC
+        double row_[JVP_ROW];
+        for (int c0 = 0; c0 < a.M; c0 += 512) {
+            const int c = c0 + threadIdx.x;
+            if (c < a.M) {
+                const double* cc = a.camc + (size_t)c * CAMC;
+                double u, v, Jc[2][NP], Jp[2][3], b[2] = {0.0, 0.0};
+                const double mc = (c >= a.n_cam_fix) ? 1.0 : 0.0;
+#pragma unroll
+                for (int m = 0; m < 3; ++m) {
+                    project<AFFINE, NP, true>(cc, nullptr, m == 0 ? 1.0 : 0.0, m == 1 ? 1.0 : 0.0, m == 2 ? 1.0 : 0.0, false, u, v, Jc, Jp);
+                    double b0 = 0.0, b1 = 0.0;
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) { b0 += Jc[0][i] * s_v[c * NP + i]; b1 += Jc[1][i] * s_v[c * NP + i]; }
+                    row_[m] = mc * b0; row_[3 + m] = mc * b1;
+                }
+#pragma unroll
+                for (int i = 3; i < NP; ++i) { b[0] += Jc[0][i] * s_v[c * NP + i]; b[1] += Jc[1][i] * s_v[c * NP + i]; }
+                row_[6] = mc * b[0]; row_[7] = mc * b[1];
+#pragma unroll
+                for (int m = 0; m < 3; ++m) { row_[8 + m] = Jp[0][m]; row_[11 + m] = Jp[1][m]; }
+            }
+            __syncthreads();  // (first trip) all reads of the camera constants through a.camc are global: nothing to wait for
+            if (c < a.M) {
+#pragma unroll
+                for (int k = 0; k < 14; ++k) tab[(size_t)c * JVP_ROW + k] = row_[k];
+            }
+        }
+        __syncthreads();
+        // four observations per thread and trip: the loop is a chain of two dependent loads (index -> point), so the
+        // number of independent chains in flight is what sets its speed
+        constexpr int UN = 4;
+        const long long stride = (long long)gridDim.x * blockDim.x;
+        for (long long o0 = (long long)blockIdx.x * blockDim.x + threadIdx.x; o0 < a.K; o0 += UN * stride) {
+            int cam[UN], pt[UN];
+            double2 sc[UN];
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const long long o = o0 + u * stride;
+                const bool ok = o < a.K;
+                cam[u] = ok ? a.cam[o] : 0;
+                pt[u] = ok ? a.pt[o] : -1;
+                sc[u] = (ok && a.sc) ? a.sc[o] : make_double2(ok ? 1.0 : 0.0, ok ? 1.0 : 0.0);
+            }
+            double X[UN], Y[UN], Z[UN], v0[UN], v1[UN], v2[UN];
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const size_t q = (size_t)a.n_c + 3 * (size_t)(pt[u] < 0 ? 0 : pt[u]);
+                X[u] = a.x[q]; Y[u] = a.x[q + 1]; Z[u] = a.x[q + 2];
+                const double mp = (pt[u] >= a.n_pts_fix) ? 1.0 : 0.0;
+                v0[u] = mp * q1[q]; v1[u] = mp * q1[q + 1]; v2[u] = mp * q1[q + 2];
+            }
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const double* row = tab + (size_t)cam[u] * JVP_ROW;
+                const double j0 = sc[u].x * (row[0] * X[u] + row[1] * Y[u] + row[2] * Z[u] + row[6] + row[8] * v0[u] + row[9] * v1[u] + row[10] * v2[u]);
+                const double j1 = sc[u].y * (row[3] * X[u] + row[4] * Y[u] + row[5] * Z[u] + row[7] + row[11] * v0[u] + row[12] * v1[u] + row[13] * v2[u]);
+                s11 += j0 * j0 + j1 * j1;
+            }
+        }
+        double v[1] = {s11};
+        double* const dst[1] = {out};
+        block_sum_atomic<1>(v, dst);
+        return;
+    }
     for (long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x; o < a.K; o += (long long)gridDim.x * blockDim.x) {
         const int cam = a.cam[o], pt = a.pt[o];
         ObsEval<MODEL, NP, true> e;
