@@ -272,7 +272,9 @@ def test_schur_matrix_and_rhs(gpu):
     dev.close()
 
 
-@pytest.mark.parametrize("n_cam,n_p", [(3, 3), (13, 5), (60, 5), (200, 5), (150, 6)])
+# n_c = 9, 65, 300, 1000, 900; 192 (double steps only), 96 (one double step + one full single step with two pending
+# panels), 129 (double steps + a one-column partial step), 66 (one double step + a two-column partial step)
+@pytest.mark.parametrize("n_cam,n_p", [(3, 3), (13, 5), (60, 5), (200, 5), (150, 6), (64, 3), (32, 3), (43, 3), (11, 6)])
 def test_dense_cholesky_solve(gpu, n_cam, n_p):
     """The reduced-system solver alone: plant a random SPD system in the exchange payload and solve it."""
     rng = np.random.default_rng(n_cam)
@@ -665,6 +667,7 @@ ALT_PATHS = [
     {"SATBA_CAMC_GLOBAL": "1"},      # camera constants gathered from global memory (more than ~210 cameras)
     {"SATBA_CHOL_DAG": "1"},         # experimental dataflow Cholesky
     {"SATBA_CHOL": "1"},             # two-launch-per-panel Cholesky (k_potrf_trsm + k_syrk)
+    {"SATBA_CHOL": "2"},             # single panel steps only (k_chol_step; default: double steps, k_chol_dstep)
     {"SATBA_SCHUR_CHUNKS": "3"},     # Schur v3 pair lists cut into point-range chunks + partial reduce
     {"SATBA_SCHUR_CHUNKS": "1"},     # ... and as one chunk (direct store)
     {"SATBA_SCHUR_STREAM": "1", "SATBA_SCHUR_CHUNKS": "3"},  # lane-group Schur kernel (experiment)
