@@ -299,8 +299,8 @@ static int launch_schur3(satba_problem* p, const ObsArgs& a, double* S, double* 
     s.pair_ij = p->d_pair_ij;
     const bool moments = p->sch3_moments && p->loss == 0 && items > 0;
     // diagonal blocks first: for RPC cameras this pass also stores the Jacobian blocks the pair kernel gathers
-    if (p->loss == 0) hipLaunchKernelGGL((k_schur_diag<MODEL, NP, false, ADDU>), dim3(diag_chunks, p->M), dim3(LINC_THREADS), 0, p->stream, a, cm, s, p->d_part3);
-    else hipLaunchKernelGGL((k_schur_diag<MODEL, NP, true, ADDU>), dim3(diag_chunks, p->M), dim3(LINC_THREADS), 0, p->stream, a, cm, s, p->d_part3);
+    if (p->loss == 0) hipLaunchKernelGGL((k_schur_diag<MODEL, NP, false, ADDU>), dim3(p->M, diag_chunks), dim3(LINC_THREADS), 0, p->stream, a, cm, s, p->d_part3);
+    else hipLaunchKernelGGL((k_schur_diag<MODEL, NP, true, ADDU>), dim3(p->M, diag_chunks), dim3(LINC_THREADS), 0, p->stream, a, cm, s, p->d_part3);
     bool done = false;
     if constexpr (MODEL == AFFINE) {
         if (moments) {
@@ -610,6 +610,7 @@ int satba_problem_create(const satba_problem_desc* d, satba_problem** out) {
             int chunks = (2048 + p->M - 1) / p->M;
             if (chunks > 64) chunks = 64;
             while (chunks > 1 && K / ((long long)p->M * chunks) < 512) --chunks;  // keep >= ~2 obs per thread
+            if (const char* dc = getenv("SATBA_CM_CHUNKS")) chunks = std::max(1, std::min(256, atoi(dc)));  // experiments
             TRY(dev_alloc(p, &p->d_cm_obs, K)); TRY(dev_alloc(p, &p->d_cm_w, K)); TRY(dev_alloc(p, &p->d_cm_pt, K));
             TRY(dev_alloc(p, &p->d_part3, (size_t)p->M * chunks * cam_acc_len(p->NP)));
             std::vector<double> tmp(2 * (size_t)K + 1);

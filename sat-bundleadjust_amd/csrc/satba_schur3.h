@@ -663,7 +663,9 @@ __global__ __launch_bounds__(256) void k_schur_pairs_reduce(int M, int NP, int n
 template <int MODEL, int NP, bool ROBUST, bool ADDU>
 __global__ __launch_bounds__(LINC_THREADS) void k_schur_diag(ObsArgs a, CamMajor c, Schur3Args s, double* __restrict__ part) {
     constexpr int CU = cam_acc_len(NP);
-    const int cam = blockIdx.y, chunk = blockIdx.x, n_chunks = gridDim.x;
+    // grid (M, chunks): the workgroups of one chunk (the same slice of every camera's point-sorted list, i.e. about the same
+    // point range) are dispatched together and share their point records in L2
+    const int cam = blockIdx.x, chunk = blockIdx.y, n_chunks = gridDim.y;
     const int b = c.cam_ofs[cam], e = c.cam_ofs[cam + 1];
     const long long len = e - b;
     const int lo = b + (int)(len * chunk / n_chunks), hi = b + (int)(len * (chunk + 1) / n_chunks);
