@@ -36,7 +36,7 @@ HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is
 # 2 x FETCH_SIZE (gfx950 counts 128-B requests as 64 B, MI355X_MICROARCH.md section HBM) + WRITE_SIZE, both in KiB.
 # PMC counters cannot be read from inside an unprofiled run, so the committed measurement is quoted for the shape
 # it was taken on (one GPU) and the field is null otherwise.
-PROFILED_TRAFFIC_BYTES = {("C4", 1): (2 * 140246.6 + 240491.9) * 1024.0}
+PROFILED_TRAFFIC_BYTES = {("C4", 1): (2 * 140079.6 + 240552.2) * 1024.0}
 
 
 def lm_step(eng, comm, st, trf):
