@@ -17,7 +17,10 @@ Differences from the reference, all deliberate:
     -- without changing any default of ref:bundle_adjust/ba_core.py:233-234;
   * when torch.distributed is initialised with world_size > 1, `run_ba_optimization` shards the points over
     the ranks (satba/sharding.py) and every rank returns the full vectors;
-  * the figure helpers of ref:bundle_adjust/ba_core.py:373-567 are not provided (plotting only).
+  * the figure helpers (`save_histogram_of_errors`, `save_heatmap_of_reprojection_error`, `idw_interpolation`,
+    ref:bundle_adjust/ba_core.py:373-567) keep their signatures but are self-contained: UTM coordinates come from
+    satba/geo_utils.py and footprint masks from matplotlib paths instead of pyproj / utm / shapely; `plots=True` of
+    `run_ba_optimization` is accepted and ignored (the reference opens an interactive window there).
 """
 import time
 
@@ -234,3 +237,158 @@ def compute_mean_reprojection_error_per_track(err, pts_ind, cam_ind):
     total = np.bincount(pts_ind, weights=err, minlength=n_pts)
     with np.errstate(invalid="ignore", divide="ignore"):
         return (total / count).astype(np.float32)
+
+
+# ----------------------------------------------------------------------------- figures (host only; never on the solver path)
+
+def _pyplot():
+    import matplotlib
+
+    if not matplotlib.get_backend():  # pragma: no cover
+        matplotlib.use("Agg")
+    import matplotlib.pyplot as plt
+
+    return plt
+
+
+def save_histogram_of_errors(img_path, err_init, err_ba, plot=False):
+    """
+    Histograms of the reprojection error of every observation before and after the adjustment, on a common range
+    (ref:bundle_adjust/ba_core.py:376-401).  Writes img_path unless plot is set.
+    """
+    import os
+
+    plt = _pyplot()
+    err_init, err_ba = np.asarray(err_init, dtype=np.float64), np.asarray(err_ba, dtype=np.float64)
+    lim = (float(err_init.min()), float(err_init.max())) if err_init.size else (0.0, 1.0)
+    fig, axes = plt.subplots(1, 2, figsize=(12, 3))
+    for ax, e, title, rng in ((axes[0], err_init, "Before BA", None), (axes[1], err_ba, "After BA", lim)):
+        ax.hist(e, bins=40, range=rng)
+        ax.set_title(title)
+        ax.set_xlabel("Reprojection error (pixel units)")
+        ax.set_ylabel("Number of tie point observations")
+    if plot:
+        plt.show()
+    else:
+        if os.path.dirname(img_path):
+            os.makedirs(os.path.dirname(img_path), exist_ok=True)
+        fig.savefig(img_path, bbox_inches="tight")
+    plt.close(fig)
+
+
+def idw_interpolation(pts2d, z, pts2d_query, N=8):
+    """
+    Inverse-distance-weighted average of the N nearest known points for every query point
+    (ref:bundle_adjust/ba_core.py:525-567): z(q) = sum(z_i / d_i) / sum(1 / d_i); a query that coincides with a known
+    point (d < 1e-10) takes that point's value; N = 1 is nearest-neighbour interpolation.
+    """
+    from scipy.spatial import cKDTree
+
+    pts2d, z = np.asarray(pts2d, dtype=np.float64), np.asarray(z)
+    N = int(min(N, pts2d.shape[0]))
+    dist, idx = cKDTree(pts2d).query(np.asarray(pts2d_query, dtype=np.float64), k=N)
+    if N == 1:
+        return z[idx]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        w = 1.0 / dist
+        out = np.sum(w * z[idx], axis=1) / np.sum(w, axis=1)
+    hit = dist[:, 0] < 1e-10
+    out[hit] = z[idx[hit, 0]]
+    return out
+
+
+def _ring(geojson):
+    """Outer ring (n, 2) of a geojson polygon."""
+    return np.asarray(geojson["coordinates"][0], dtype=np.float64)
+
+
+def save_heatmap_of_reprojection_error(img_path, p, err, input_ims_footprints_lonlat, aoi_lonlat_roi=None, plot=False,
+                                       smooth=20, global_transform=None):
+    """
+    Mean reprojection error per track, interpolated (IDW, then a Gaussian of sigma `smooth` pixels) over the union of the
+    image footprints on a UTM grid of at most 1000 pixels per side, with the tie points drawn on top
+    (ref:bundle_adjust/ba_core.py:404-522).  `p` needs pts_ind, cam_ind and pts3d_ba (set by reconstruct_vars; pts3d is
+    used before that).  A .png path gets the figure; a .tif path gets the georeferenced raster (needs rasterio).
+    """
+    import os
+
+    from scipy.ndimage import gaussian_filter
+
+    from . import geo_utils
+
+    max_size = 1000
+    rings = [_ring(g) for g in input_ims_footprints_lonlat]
+    all_ll = np.vstack(rings)
+    zone = geo_utils.utm_zone_from_lonlat(all_ll[0, 0], all_ll[0, 1])
+    south = all_ll[:, 1].mean() < 0
+
+    def to_utm(ll):
+        e, n = geo_utils.utm_from_lonlat(ll[:, 0], ll[:, 1], zone)
+        return np.column_stack((e, np.where(n < 0, n + 10e6, n)))  # as ref:bundle_adjust/geo_utils.py:72
+
+    rings_utm = [to_utm(r) for r in rings]
+    allu = np.vstack(rings_utm)
+    xmin, xmax, ymin, ymax = allu[:, 0].min(), allu[:, 0].max(), allu[:, 1].min(), allu[:, 1].max()
+    resolution = max(float(max(ymax - ymin, xmax - xmin)) / max_size, 1e-9)
+    height, width = int(np.floor((ymax - ymin) / resolution) + 1), int(np.floor((xmax - xmin) / resolution) + 1)
+
+    def to_grid(u):  # column to the east, row to the south
+        return np.column_stack(((u[:, 0] - xmin) / resolution, (ymax - u[:, 1]) / resolution))
+
+    track_err = compute_mean_reprojection_error_per_track(err, p.pts_ind, p.cam_ind)
+    pts3d = np.array(getattr(p, "pts3d_ba", p.pts3d), dtype=np.float64)[: track_err.size]
+    if global_transform is not None:
+        pts3d = pts3d - np.asarray(global_transform)
+    lat, lon, _ = geo_utils.ecef_to_latlon_custom(pts3d[:, 0], pts3d[:, 1], pts3d[:, 2])
+    g = to_grid(to_utm(np.column_stack((lon, lat))))
+    ok = (g[:, 0] >= 0) & (g[:, 0] < width) & (g[:, 1] >= 0) & (g[:, 1] < height) & np.isfinite(track_err)
+    g, te = g[ok], track_err[ok]
+
+    cols, rows = np.meshgrid(np.arange(width), np.arange(height))
+    query = np.column_stack((cols.ravel(), rows.ravel()))
+    if te.size:
+        raster = idw_interpolation(g, te, query).reshape(height, width)
+        if smooth:
+            raster = gaussian_filter(raster, sigma=smooth)
+    else:
+        raster = np.full((height, width), np.nan)
+    from matplotlib.path import Path
+
+    inside = np.zeros(height * width, dtype=bool)
+    for r in rings_utm:
+        inside |= Path(to_grid(r)).contains_points(query)
+    raster[~inside.reshape(height, width)] = np.nan
+
+    if os.path.dirname(img_path):
+        os.makedirs(os.path.dirname(img_path), exist_ok=True)
+    if not plot and os.path.splitext(img_path)[1].lower() == ".tif":
+        import rasterio  # not a dependency of the solver: only for this output format
+        from rasterio.transform import from_origin
+
+        epsg = geo_utils.epsg_code_from_utm_zone(zone, north=not south)
+        with rasterio.open(img_path, "w", driver="GTiff", height=height, width=width, count=1, dtype="float32",
+                           crs="EPSG:{}".format(epsg), transform=from_origin(xmin, ymax, resolution, resolution)) as dst:
+            dst.write(raster.astype(np.float32), 1)
+        return
+
+    plt = _pyplot()
+    vmin, vmax = 0.0, 2.0
+    fig, ax = plt.subplots(figsize=(10, 10))
+    im = ax.imshow(raster, vmin=vmin, vmax=vmax)
+    for r in rings_utm:
+        ax.plot(*to_grid(r).T, color="black")
+    ax.scatter(g[:, 0], g[:, 1], 30, te, edgecolors="k", vmin=vmin, vmax=vmax)
+    if aoi_lonlat_roi is not None:
+        ax.plot(*to_grid(to_utm(_ring(aoi_lonlat_roi))).T, color="red", linewidth=3.0)
+    ax.axis("equal")
+    ax.axis("off")
+    cbar = fig.colorbar(im, ax=ax, fraction=0.046, pad=0.04)
+    ticks = np.linspace(vmin, vmax, 9)
+    cbar.set_ticks(ticks)
+    cbar.set_ticklabels(["{:.2f}".format(t) for t in ticks[:-1]] + [">={:.2f}".format(vmax)])
+    cbar.set_label("Reprojection error across AOI (pixel units)", rotation=270, labelpad=25)
+    if plot:
+        plt.show()
+    else:
+        fig.savefig(img_path, bbox_inches="tight")
+    plt.close(fig)

@@ -21,7 +21,12 @@ SOLVE_CASES = {
     "affine_small_RT": ("affine", 6, 400, 4, 2, {"correction_params": ["R", "T"], "n_cam_fix": 1}, ["linear"]),
     "persp_small_R": ("perspective", 5, 300, 4, 4, {"correction_params": ["R"], "n_cam_fix": 1}, ["linear"]),
     "affine_C2_R": ("affine", 10, 5000, 6, 1, {"correction_params": ["R"], "n_cam_fix": 1}, ["linear", "soft_l1"]),
+    # tight-protocol vectors only (tools/gen_golden.py tight2); rpc: the reference chain in float64 (no float32 store),
+    # every camera sees every point (the two shipped RPCs alternate: same-parity-only points have no parallax)
+    "rpc_small_R": ("rpc", 4, 300, 4, 5, {"correction_params": ["R"], "n_cam_fix": 1}, ["linear", "soft_l1"]),
+    "persp_small_RT": ("perspective", 5, 300, 4, 4, {"correction_params": ["R", "T"], "n_cam_fix": 1}, ["linear"]),
 }
+SCENE_KW = {"rpc_small_R": {"sigma_theta": 5e-6}}
 
 
 def golden(name):
@@ -36,5 +41,5 @@ def fun_case(name, dense=False):
 
 def solve_case(name):
     model, M, N, opp, seed, d, losses = SOLVE_CASES[name]
-    scene = synth.make_scene(model, M, N, opp, seed=seed)
+    scene = synth.make_scene(model, M, N, opp, seed=seed, **SCENE_KW.get(name, {}))
     return scene, (lambda: synth.make_params(scene, dict(d, reduce=False))), golden("solve_" + name), losses

@@ -311,14 +311,21 @@ def test_dense_cholesky_solve(gpu, n_cam, n_p):
 
 @pytest.mark.parametrize("name", list(cases.SOLVE_CASES))
 def test_tight_solve_matches_tight_scipy_reference(gpu, name):
-    """SURVEY.md section 8c protocol: reference run with ftol=xtol=gtol=1e-15, LSMR atol=btol=1e-12, gauge fixed."""
+    """
+    SURVEY.md section 8c protocol: reference run with ftol=xtol=gtol=1e-15, LSMR atol=btol=1e-12, gauge fixed.
+    rpc: the reference chain in float64 (rpc_store_f32=False here) and scipy's 3-point differences -- its forward
+    differences bias the stationary point of the cubic RPC chain by 1e-3 relative in the angles (tools/gen_golden.py);
+    the forward-difference run is compared too, at what it can resolve.
+    """
     _, make_p, g, losses = cases.solve_case(name)
     for loss in losses:
         p = make_p()
+        rpc = p.cam_model == "rpc"
         out = ba_core.run_ba_optimization(p, {"loss": loss, "ftol": 1e-15, "xtol": 1e-15, "gtol": 1e-15, "max_iter": 300,
-                                              "verbose": 0, "return_result": True}, False, False)
+                                              "verbose": 0, "return_result": True, "rpc_store_f32": not rpc}, False, False)
         vars_ba, err_ba, res = out[1], out[3], out[5]
-        xt, ft, st = g["tight_x_" + loss], g["tight_fun_" + loss], g["tight_stats_" + loss]
+        key = "tight3_" if rpc else "tight_"
+        xt, ft, st = g[key + "x_" + loss], g[key + "fun_" + loss], g[key + "stats_" + loss]
         n_c = p.n_cam * p.n_params
         assert res.status in (2, 3, 4)
         assert abs(res.cost - st[0]) < 1e-9 * st[0]
@@ -328,9 +335,18 @@ def test_tight_solve_matches_tight_scipy_reference(gpu, name):
         # DESIGN.md section 'parity'): per-observation errors are compared at 5e-5 of their mean, the mean at 1e-7 px
         assert np.abs(err_ba - err_t).max() < 5e-5 * err_t.mean()
         assert abs(err_ba.mean() - err_t.mean()) < 1e-7
-        assert np.linalg.norm(res.fun - ft) < 5e-6 * np.linalg.norm(ft)
+        # north star: residual vector to 1e-6 relative.  Met wherever the reference's finite differences resolve it
+        # (measured: C2 1.7e-7 / 8.4e-7, perspective 6e-7 .. 1e-6, rpc vs 3-point 1e-7); the two 6 x 400 affine toys sit
+        # on their own finite-difference floor (1.5e-6 / 5e-7 measured) and keep 5e-6
+        r_tol = 5e-6 if name in ("affine_small_R", "affine_small_RT", "persp_small_R") else 1e-6
+        assert np.linalg.norm(res.fun - ft) < r_tol * np.linalg.norm(ft), np.linalg.norm(res.fun - ft) / np.linalg.norm(ft)
         if name != "affine_small_RT":  # R+T on affine cameras with one frozen camera is a flat valley
-            assert rel(vars_ba[:n_c], xt[:n_c]) < 1e-6
+            # rpc: the angles are ~1e-5 rad and scipy's xtol test (|dx| < xtol |x|, |x| ~ 1e8 m) stops at steps of 1e-7:
+            # 1e-5 relative = 1e-10 rad is what the reference run itself resolves (measured 2.7e-6)
+            assert rel(vars_ba[:n_c], xt[:n_c]) < (1e-5 if rpc else 1e-6)
+        if rpc:  # the forward-difference reference run: same cost, angles within its own bias
+            assert abs(res.cost - g["tight_stats_" + loss][0]) < 1e-8 * res.cost
+            assert rel(vars_ba[:n_c], g["tight_x_" + loss][:n_c]) < 5e-3
 
 
 @pytest.mark.parametrize("name", ["affine_small_R", "persp_small_R", "affine_C2_R"])
@@ -449,27 +465,49 @@ def _lm_iterations(eng, n):
     return costs, st
 
 
-@pytest.mark.parametrize("shape", ["C3", "C4"])
-def test_full_size_properties(gpu, shape):
+_SCENES = {}
+
+
+def _full_size_scene(shape, sigma_theta):
+    """One BASELINE-shape scene at a time (C4 is ~1 GB of host arrays and takes a while to draw)."""
+    key = (shape, sigma_theta)
+    if key not in _SCENES:
+        _SCENES.clear()
+        model, corr, n_cam, n_pts, opp = synth.CONFIGS[shape]
+        _SCENES[key] = synth.make_scene(model, n_cam, n_pts, opp, seed=1, sigma_theta=sigma_theta)
+    return _SCENES[key]
+
+
+# (shape, loss, sigma_theta): C3 / C4 affine R+T, C5 = full RPC chain 50 x 100 k (BASELINE config 5); soft_l1 is the loss of
+# the pipeline's FIRST solve (ref:bundle_adjust/ba_pipeline.py:330), started like real data from ~15 px (SURVEY 8d)
+FULL_SIZE = [("C3", "linear", 2e-5), ("C3", "soft_l1", 2e-6), ("C4", "linear", 2e-5), ("C4", "soft_l1", 2e-6),
+             ("C5", "linear", 1e-6), ("C5", "soft_l1", 1e-6)]
+
+
+@pytest.mark.parametrize("shape,loss,sigma_theta", FULL_SIZE, ids=["-".join(map(str, c[:2])) for c in FULL_SIZE])
+def test_full_size_properties(gpu, shape, loss, sigma_theta):
     """
     At BASELINE.json's sizes the oracle is too slow to be the checker; check size-independent properties instead:
-    cost == 0.5 |fun|^2, a random sample of residuals against the oracle, monotone decrease over LM iterations down
+    cost == 0.5 sum rho(fun^2), a random sample of residuals against the oracle, monotone decrease over LM iterations down
     to the noise floor of the generator, and two half-shards reproducing the camera blocks of the whole problem.
     """
-    n_cam, n_pts, opp = synth.SHAPES[shape]
-    scene = synth.make_affine_scene(n_cam, n_pts, opp, seed=1, sigma_theta=2e-5)
-    p = synth.make_params(scene, {"correction_params": ["R", "T"], "n_cam_fix": 1})
+    model, corr, n_cam, n_pts, opp = synth.CONFIGS[shape]
+    scene = _full_size_scene(shape, sigma_theta)
+    p = synth.make_params(scene, {"correction_params": corr, "n_cam_fix": 1})
+    rpc = model == "rpc"
+    noise = 0.2 if rpc else 0.3  # generator noise per coordinate [px] (synth.make_*_scene defaults)
     eng = HipEngine(p)
-    eng.configure("linear", 1.0)
+    eng.configure(loss, 1.0)
     r0, cost0 = eng.residuals(with_cost=True)
-    assert abs(cost0 - 0.5 * r0 @ r0) < 1e-9 * cost0
+    assert abs(cost0 - L.robust_cost(r0, loss, 1.0)) < 1e-9 * cost0
     # a random sample of observations against the CPU oracle (the whole vector would take minutes at 10 M)
     rng = np.random.default_rng(0)
     sel = np.sort(rng.choice(p.n_obs, 5000, replace=False))
     q = type("P", (), {})()
     q.__dict__.update(p.__dict__)
     q.pts_ind, q.cam_ind, q.pts2d, q.pts2d_w = p.pts_ind[sel], p.cam_ind[sel], p.pts2d[sel], p.pts2d_w[sel]
-    assert np.abs(O.fun(p.params_opt, q) - r0.reshape(-1, 2)[sel].ravel()).max() < 1e-8
+    # rpc: one float32 ulp of a pixel coordinate (the reference stores projections in float32, ba_core.py:150)
+    assert np.abs(O.fun(p.params_opt, q) - r0.reshape(-1, 2)[sel].ravel()).max() < (2.5e-4 if rpc else 1e-8)
 
     # two half-shards of the same problem produce the same camera blocks as the whole
     eng.linearize()
@@ -479,7 +517,7 @@ def test_full_size_properties(gpu, shape):
     Us, gcs = np.zeros_like(U), np.zeros_like(gc)
     for rank in range(2):
         e2 = HipEngine(p, sharding.make_shard(p, rank, 2))
-        e2.configure("linear", 1.0)
+        e2.configure(loss, 1.0)
         e2.linearize()
         U2, gc2, V2, gp2 = e2.get_blocks()
         Us += U2
@@ -489,15 +527,39 @@ def test_full_size_properties(gpu, shape):
         e2.close()
     assert rel(Us, U) < 1e-9 and rel(gcs, gc) < 1e-7
 
-    costs, st = _lm_iterations(eng, 6)
-    assert all(b <= a * (1 + 1e-12) for a, b in zip(costs, costs[1:])) and st["accepted"] >= 2  # then at the floor
-    # noise floor: 0.3 px per coordinate -> cost ~ 0.5 * 2K * 0.09 minus the fitted degrees of freedom
-    expected = 0.5 * 0.09 * (2 * p.n_obs - (p.n_cam * p.n_params + 3 * p.n_pts))
-    assert abs(costs[-1] - expected) < 0.02 * expected
-    # reprojection errors are Rayleigh(0.3 px) shrunk by the fitted degrees of freedom
-    err = O.reprojection_error(eng.residuals(), p.pts2d_w)
     dof = 1.0 - (p.n_cam * p.n_params + 3 * p.n_pts) / (2.0 * p.n_obs)
-    assert abs(err.mean() - 0.3 * np.sqrt(np.pi / 2) * np.sqrt(dof)) < 0.01
+    floor = noise * np.sqrt(np.pi / 2) * np.sqrt(dof)  # reprojection errors are Rayleigh(noise) shrunk by the fitted dof
+    if loss == "linear":
+        costs, st = _lm_iterations(eng, 6)
+        assert all(b <= a * (1 + 1e-12) for a, b in zip(costs, costs[1:])) and st["accepted"] >= 2  # then at the floor
+        r1, cost1 = eng.residuals(with_cost=True)
+        assert abs(cost1 - costs[-1]) < 1e-9 * cost1 and abs(cost1 - 0.5 * r1 @ r1) < 1e-9 * cost1
+        err = O.reprojection_error(r1, p.pts2d_w)
+        print("full-size", shape, loss, "cost", cost0, "->", costs, "accepted", st["accepted"], "mean err", err.mean(), "floor", floor)
+        # noise floor: cost ~ 0.5 * 2K * noise^2 minus the fitted degrees of freedom
+        expected = 0.5 * noise ** 2 * (2 * p.n_obs - (p.n_cam * p.n_params + 3 * p.n_pts))
+        assert abs(costs[-1] - expected) < 0.02 * expected
+        assert abs(err.mean() - floor) < 0.01
+    else:
+        # the pipeline's sequence at full size (ref:bundle_adjust/ba_pipeline.py:706-712): soft-L1 solve with the shipped
+        # tolerances, then the L2 solve from its solution.  scipy's radius starts at |x0 / scale| and the robust cost is flat
+        # far from the solution, so the loop spends its first evaluations shrinking the radius: that is the reference's
+        # behaviour (158 evaluations at C2, tests/golden/solve_affine_C2_R.npz), not a fixed-work property -- the real loop runs
+        res = trf.trf_solve(eng, ftol=1e-4, xtol=1e-10, gtol=1e-8, max_nfev=300, loss="soft_l1", f_scale=1.0)
+        r1, cost1 = eng.residuals(with_cost=True)
+        assert res.status > 0 and res.cost < cost0 and abs(cost1 - res.cost) < 1e-9 * cost1
+        assert abs(cost1 - L.robust_cost(r1, loss, 1.0)) < 1e-9 * cost1
+        err1 = O.reprojection_error(r1, p.pts2d_w)
+        res2 = trf.trf_solve(eng, ftol=1e-4, xtol=1e-10, gtol=1e-8, max_nfev=300, loss="linear")
+        eng.configure("linear", 1.0)
+        r2 = eng.residuals()
+        err = O.reprojection_error(r2, p.pts2d_w)
+        print("full-size", shape, loss, "cost", cost0, "->", res.cost, "nfev", res.nfev, "status", res.status, "mean err",
+              err1.mean(), "then L2: nfev", res2.nfev, "status", res2.status, "mean err", err.mean(), "floor", floor)
+        # soft_l1 down-weights the tails of the same Gaussian noise: the same scene, the mean error within a few percent of
+        # the least-squares floor after the robust solve, at the floor after the L2 solve
+        assert abs(err1.mean() - floor) < 0.05 * floor + 0.01
+        assert res2.status > 0 and abs(err.mean() - floor) < 0.01
     eng.close()
 
 

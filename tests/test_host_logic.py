@@ -118,3 +118,61 @@ def test_product_path_fails_loudly_without_device_or_library(tmp_path):
         ba_core.fun(p.params_opt.copy(), p)
     with pytest.raises((engine_hip.SatbaError, RuntimeError)):
         ba_core.run_ba_optimization(p, {"verbose": 0}, False, False)
+
+
+# ----------------------------------------------------------------------------- figure helpers of the drop-in surface
+
+def test_utm_series_against_published_coordinates():
+    """Krueger-series UTM (satba/geo_utils.py) against coordinates any converter prints (metre level)."""
+    from satba import geo_utils as G
+
+    e, n = G.utm_from_lonlat([2.3522], [48.8566])  # Paris, zone 31
+    assert G.utm_zone_from_lonlat(2.3522, 48.8566) == 31 and abs(e[0] - 452482.5) < 1.0 and abs(n[0] - 5411717.2) < 1.0
+    e, n = G.utm_from_lonlat([-58.3816], [-34.6037])  # Buenos Aires, zone 21 south
+    assert G.utm_zone_from_lonlat(-58.3816, -34.6037) == 21 and abs(e[0] - 373317.5) < 1.0 and abs(n[0] + 10e6 - 6170036.2) < 1.0
+    assert G.epsg_code_from_utm_zone(31) == 32631 and G.epsg_code_from_utm_zone(21, north=False) == 32721
+    # central meridian: easting 500 km exactly, scale factor 0.9996 on the meridian arc
+    e, n = G.utm_from_lonlat([3.0, 3.0], [0.0, 1.0])
+    assert abs(e[0] - 500000.0) < 1e-6 and abs(n[0]) < 1e-6 and abs(n[1] - 0.9996 * 110574.3886) < 0.01
+
+
+def test_idw_interpolation_semantics():
+    """ref:bundle_adjust/ba_core.py:525-567: 1/d weights over the N nearest, exact hits, N = 1."""
+    from satba import ba_core
+
+    rng = np.random.default_rng(0)
+    pts, z = rng.uniform(0, 10, (40, 2)), rng.normal(size=40)
+    q = rng.uniform(0, 10, (25, 2))
+    got = ba_core.idw_interpolation(pts, z, q, N=5)
+    d = np.linalg.norm(q[:, None] - pts[None], axis=2)
+    idx = np.argsort(d, axis=1)[:, :5]
+    w = 1.0 / np.take_along_axis(d, idx, 1)
+    assert np.allclose(got, (w * z[idx]).sum(1) / w.sum(1), rtol=1e-12)
+    assert np.array_equal(ba_core.idw_interpolation(pts, z, pts[:7], N=5), z[:7])  # a query on a known point
+    assert np.array_equal(ba_core.idw_interpolation(pts, z, q, N=1), z[np.argmin(d, axis=1)])
+
+
+def test_figure_helpers_write_files(tmp_path):
+    """The three figure entry points a default ba_pipeline.run() calls (ref:bundle_adjust/ba_pipeline.py:654-663)."""
+    import matplotlib
+
+    matplotlib.use("Agg")
+    from satba import ba_core, geo_utils, synth
+
+    rng = np.random.default_rng(1)
+    e0, e1 = rng.rayleigh(3.0, 500), rng.rayleigh(0.3, 500)
+    path = tmp_path / "ba_figures" / "error_histograms.png"
+    ba_core.save_histogram_of_errors(str(path), e0, e1)
+    assert path.stat().st_size > 1000
+
+    scene = synth.make_rpc_scene(3, 200, 3, seed=2)
+    p = synth.make_params(scene, {"correction_params": ["R"], "reduce": False})
+    lat, lon, _ = geo_utils.ecef_to_latlon_custom(*scene.pts3d.T)
+    box = [[lon.min(), lat.min()], [lon.max(), lat.min()], [lon.max(), lat.max()], [lon.min(), lat.max()], [lon.min(), lat.min()]]
+    half = [[lon.min(), lat.min()], [lon.mean(), lat.min()], [lon.mean(), lat.max()], [lon.min(), lat.max()], [lon.min(), lat.min()]]
+    footprints = [{"type": "Polygon", "coordinates": [box]}, {"type": "Polygon", "coordinates": [half]}]
+    err = rng.rayleigh(0.5, p.n_obs)
+    out = tmp_path / "ba_figures" / "error_after.png"
+    ba_core.save_heatmap_of_reprojection_error(str(out), p, err, footprints, aoi_lonlat_roi=footprints[1], smooth=2,
+                                               global_transform=np.zeros(3))
+    assert out.stat().st_size > 1000

@@ -222,12 +222,70 @@ def golden_solves():
     save("solve_rpc_config1", x_softl1=v1, x_l2=v2, err_init=e0, err_softl1=e1, err_l2=e2, iters=np.array([it1, it2]))
 
 
+def rpc_fun_f64(p):
+    """The reference's rpc residual chain with the float32 store of ba_core.py:150 left out."""
+    def f64(v):
+        pts3d, cam_params = p.get_vars_ready_for_fun(v.copy())
+        X = ref.ba_core.adjust_pts3d(pts3d[p.pts_ind], cam_params[p.cam_ind])
+        proj = np.zeros((p.pts_ind.size, 2))
+        for c in np.unique(p.cam_ind).tolist():
+            sel = p.cam_ind == c
+            proj[sel] = ref.cam_utils.apply_rpc_projection(p.cameras[c], X[sel])
+        return np.repeat(p.pts2d_w, 2) * (proj - p.pts2d).ravel()
+    return f64
+
+
+def golden_tight_rpc_persp():
+    """
+    G6 for the two models round 1 left without a tight-protocol vector: rpc (["R"], one frozen camera; the reference's
+    functions evaluated in float64, i.e. without the float32 store of ba_core.py:150, which a finite-difference Jacobian
+    cannot see through) and perspective R+T.
+    """
+    from scipy.optimize import least_squares
+
+    specs = [
+        # every camera sees every point: the two shipped RPCs alternate over the cameras, so a point seen only by cameras of
+        # the same parity has no parallax and the problem a flat valley (tight scipy and an exact LM then stop at different
+        # points of it)
+        ("rpc_small_R", "rpc", 4, 300, 4, 5, {"correction_params": ["R"], "n_cam_fix": 1}, ["linear", "soft_l1"]),
+        ("persp_small_RT", "perspective", 5, 300, 4, 4, {"correction_params": ["R", "T"], "n_cam_fix": 1}, ["linear"]),
+    ]
+    for name, model, M, N, opp, seed, d, losses in specs:
+        kw = {"sigma_theta": 5e-6} if model == "rpc" else {}
+        scene = synth.make_scene(model, M, N, opp, seed=seed, **kw)
+        out = dict(n_obs=scene.n_obs)
+        for loss in losses:
+            p = ref_params(scene, dict(d, reduce=False))
+            f = rpc_fun_f64(p) if model == "rpc" else (lambda v, p=p: ref.ba_core.fun(v.copy(), p))
+            A = ref.ba_core.build_jacobian_sparsity(p)
+            res = least_squares(f, p.params_opt.copy(), jac_sparsity=A, x_scale="jac", method="trf", loss=loss,
+                                f_scale=1.0, ftol=1e-15, xtol=1e-15, gtol=1e-15, max_nfev=300,
+                                tr_options={"atol": 1e-12, "btol": 1e-12})
+            print(name, loss, "tight: status", res.status, "nfev", res.nfev, "cost %.10f" % res.cost)
+            out.update({"tight_x_" + loss: res.x, "tight_fun_" + loss: res.fun,
+                        "tight_stats_" + loss: np.array([res.cost, res.nfev, res.status, res.optimality])})
+            if model == "rpc":
+                # scipy's forward differences (step 1.5e-8 x max(1, |x|): 9 cm on ECEF coordinates) are biased by the
+                # curvature of the cubic RPC chain: the stationary point of J_fd^T f = 0 sits 1e-3 (relative) away from the
+                # minimiser in the angles (measured here: exact-Jacobian LM vs this run).  The same solver with scipy's own
+                # jac="3-point" option removes the bias; both solutions are stored.
+                res3 = least_squares(f, p.params_opt.copy(), jac="3-point", jac_sparsity=A, x_scale="jac", method="trf",
+                                     loss=loss, f_scale=1.0, ftol=1e-15, xtol=1e-15, gtol=1e-15, max_nfev=300,
+                                     tr_options={"atol": 1e-12, "btol": 1e-12})
+                print(name, loss, "tight, 3-point FD: status", res3.status, "nfev", res3.nfev, "cost %.10f" % res3.cost)
+                out.update({"tight3_x_" + loss: res3.x, "tight3_fun_" + loss: res3.fun,
+                            "tight3_stats_" + loss: np.array([res3.cost, res3.nfev, res3.status, res3.optimality])})
+        save("solve_" + name, **out)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["fun", "params", "solves"]
+    which = sys.argv[1:] or ["fun", "params", "solves", "tight2"]
     if "fun" in which:
         golden_fun_and_jac()
     if "params" in which:
         golden_params()
     if "solves" in which:
         golden_solves()
+    if "tight2" in which:
+        golden_tight_rpc_persp()
