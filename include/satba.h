@@ -60,6 +60,12 @@ enum {
 
 typedef struct satba_problem satba_problem;
 
+/* satba_problem_desc.flags.  DETERMINISTIC: bitwise-repeatable runs -- the per-camera sums of the linearisation are formed by a
+ * camera-major pass with a fixed order instead of LDS float atomics (every other reduction of the library has a fixed order
+ * anyway); costs one extra pass over the observations per linearisation.  Also switched on by the environment variable
+ * SATBA_DETERMINISTIC. */
+#define SATBA_FLAG_DETERMINISTIC 1
+
 typedef struct satba_problem_desc {
     int32_t cam_model;      /* SATBA_AFFINE | SATBA_PERSPECTIVE | SATBA_RPC  (BundleAdjustmentParameters.cam_model) */
     int32_t n_cam;          /* M                                                                    */
@@ -71,7 +77,7 @@ typedef struct satba_problem_desc {
     int32_t rank, world;    /* position of this shard; 0, 1 for a single GPU                        */
     int32_t rpc_store_f32;  /* non-zero: round RPC projections to float32 like ba_core.py:150        */
     int32_t device;         /* HIP device ordinal                                                    */
-    int32_t reserved;
+    int32_t flags;          /* SATBA_FLAG_* bits                                                     */
     int64_t n_obs;          /* K: observations held by this handle                                   */
     int64_t n_total;        /* size of the global variable vector (only used for default max_nfev)   */
     const double *cam_params;  /* host, M x cam_param_len, row-major (BundleAdjustmentParameters.cam_params) */
@@ -86,7 +92,10 @@ typedef struct satba_problem_desc {
 const char *satba_last_error(void);
 int satba_version(void);
 
-/* Upload a problem (replaces the per-call numpy gathers of ba_core.py:72-81, 97-107, 147-153). */
+/* Upload a problem (replaces the per-call numpy gathers of ba_core.py:72-81, 97-107, 147-153) and build its index structures
+ * on the device: points sorted by track length into 64-point slices (sliced-ELL observation order), camera-major lists,
+ * per-camera-pair lists of shared points (csrc/satba_layout.h).  pts_ind must be non-decreasing and the cameras of a point
+ * strictly ascending -- the order ba_params.py:142-147 emits. */
 int satba_problem_create(const satba_problem_desc *desc, satba_problem **out);
 void satba_problem_destroy(satba_problem *p);
 
@@ -125,7 +134,7 @@ int satba_residuals(satba_problem *p, double *host_r, double *host_cost);
 /* residuals + analytic Jacobian -> normal-equation blocks at x.  Replaces scipy's finite-difference
  * Jacobian (scipy:optimize/_numdiff.py:628-705), compute_grad (common.py:590-595) and the robust
  * rescaling (common.py:720-731).  Exchange payload: U (M x n_p x n_p) | g_c (M x n_p); only diag(U_c) is
- * guaranteed (the off-diagonal entries are formed in the Schur phase when its camera-major pass is used).  */
+ * guaranteed (the off-diagonal entries are formed in the Schur phase by its camera-major pass).           */
 int satba_linearize(satba_problem *p);
 /* after the all-reduce: x_scale="jac" update (common.py:598-610), g_h, |J_h g_h|^2 for the Cauchy step
  * (trf.py:473-477).                                                                                       */
@@ -156,9 +165,46 @@ int satba_accept(satba_problem *p);
 /* synchronise the stream and copy the exchange header to the host. */
 int satba_read_header(satba_problem *p, double *host_hdr);
 
+/* ---- one-shot solve: the whole trust-region loop (scipy:optimize/_lsq/trf.py:401-560 as ba_core.py:284-297 configures it,
+ * with the exact damped step of this library) below the ABI, for callers that do not want to drive the phases themselves.
+ * Starts from the current x (satba_set_x), leaves the solution in the handle (satba_get_x, satba_residuals).  Single-rank
+ * handles only (world == 1): with several ranks the exchange buffer must be all-reduced between the phases by the caller.
+ * status, nfev: scipy's (0 max_nfev reached, 1 gtol, 2 ftol, 3 xtol, 4 ftol and xtol).  max_nfev <= 0: 100 * n_total. */
+typedef struct satba_lm_opts {
+    double ftol, xtol, gtol, f_scale;
+    int64_t max_nfev;
+    int32_t loss;     /* SATBA_LOSS_* */
+    int32_t verbose;  /* 0 silent, 1 final message, 2 scipy's iteration table */
+} satba_lm_opts;
+typedef struct satba_lm_stats {
+    double cost, initial_cost, optimality;
+    int64_t nfev, njev, iterations;
+    int32_t status, reserved;
+} satba_lm_stats;
+int satba_solve_lm(satba_problem *p, const satba_lm_opts *opts, satba_lm_stats *stats);
+
+/* ---- outlier rejection between the two solves of the pipeline (ba_outliers.py:14-58, 112-155): per-camera elbow threshold
+ * on the reprojection errors of the current x and the observations above it.
+ * err (host, K, caller's observation order, may be NULL: computed from the residuals at the current x as
+ * ba_core.compute_reprojection_error does); predef_thr < 0: automatic (elbow) thresholds; outputs: cam_thr (host, M),
+ * remove (host, K bytes: 1 = observation is an outlier), n_removed. */
+int satba_outliers(satba_problem *p, const double *err, double predef_thr, double min_thr, double *cam_thr, uint8_t *remove,
+                   int64_t *n_removed);
+
 /* ---- inspection entry points (parity tests; not used by the solver loop) */
+/* index structures built by satba_problem_create, as int32 arrays (SATBA_LAY_PAIR_OFS: int64): n must equal satba_layout_len */
+enum { SATBA_LAY_PERM = 0, SATBA_LAY_RANK, SATBA_LAY_PT_CNT, SATBA_LAY_SLICE_BASE, SATBA_LAY_E_CAM, SATBA_LAY_OBS_POS, SATBA_LAY_CAM_OFS,
+       SATBA_LAY_CM_PT, SATBA_LAY_CM_POS, SATBA_LAY_PAIR_OFS, SATBA_LAY_PAIR_PTS, SATBA_LAY_PAIR_PI, SATBA_LAY_PAIR_PJ, SATBA_LAY_PAIR_IJ };
+int64_t satba_layout_len(const satba_problem *p, int32_t which);
+int satba_get_layout(satba_problem *p, int32_t which, int64_t n, void *host_out);
+/* n >= 16 doubles: [0..4] milliseconds since the start of satba_problem_create when the uploads were queued, the layout sizes were
+ * known, the ELL + camera-major lists were queued, the pair lists were finished, the handle was complete; [5] padded ELL length,
+ * [6] pair-list entries, [7] pair-list chunks, [8] unit weights, [9] camera constants in LDS, [10] RPC tables in LDS,
+ * [11] camera sums by LDS atomics, [12] deterministic, [13] chunks of the camera-major passes, [14] workgroups of k_linearize */
+int satba_get_info(const satba_problem *p, double *out, int32_t n);
 /* normal-equation blocks of the last linearize: U (M n_p n_p), g_c (M n_p) as written to the exchange
- * payload, V (N x 6: xx xy xz yy yz zz), g_p (N x 3). Any pointer may be NULL.                          */
+ * payload, V (N x 6: xx xy xz yy yz zz), g_p (N x 3), points in the caller's order. Any pointer may be NULL.
+ * U is formed by a camera-major pass (the solver itself only needs diag U_c before the Schur phase).       */
 int satba_get_blocks(satba_problem *p, double *U, double *gc, double *V, double *gp);
 /* materialised, weighted, row-scaled Jacobian blocks at x: Jc (K x 2 x n_p), Jp (K x 2 x 3).            */
 int satba_get_jacobian(satba_problem *p, double *Jc, double *Jp);
@@ -170,8 +216,8 @@ int satba_get_vector(satba_problem *p, int32_t which, double *host_out);
 
 /* ---- measurement: average duration in milliseconds of `reps` back-to-back launches of one phase's
  * dominant kernel, bracketed by HIP events on the handle's stream.
- * phase: 0 residual kernel, 1 linearize kernel (residual + Jacobian -> normal blocks), 2 Schur kernel,
- *        3 dense Cholesky solve, 4 back-substitution, 5 Jacobian-vector products (subspace)            */
+ * phase: 0 residual kernel, 1 linearize kernel (residual + Jacobian -> normal blocks), 2 Schur kernels,
+ *        3 dense Cholesky solve, 4 back-substitution, 5 the Jacobian-vector product of the prepare phase */
 int satba_time_kernel(satba_problem *p, int32_t phase, int32_t reps, float *ms_avg);
 
 #ifdef __cplusplus

@@ -1,15 +1,17 @@
-// satba_capi.hip -- C ABI of libsatba_hip.so (declared in include/satba.h) over the kernels of satba_kernels.h.
+// satba_capi.hip -- C ABI of libsatba_hip.so (declared in include/satba.h) over the kernels of satba_kernels.h,
+// satba_schur.h, satba_chol.h and the device-side layout builder of satba_layout.h.
 //
 // The handle owns every device array of one shard (all cameras, a contiguous range of points, their
 // observations).  Phases are launched asynchronously on the handle's stream; the only synchronisation points
 // are the functions that return data to the host.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
-#include <algorithm>
 #include <cstring>
 #include <new>
 #include <string>
@@ -17,10 +19,11 @@
 
 #include "../../include/satba.h"
 #include "satba_chol.h"
-#include "satba_chol_dag.h"
 #include "satba_kernels.h"
-#include "satba_linearize3.h"
-#include "satba_schur3.h"
+#include "satba_layout.h"
+#include "satba_lm.h"
+#include "satba_outliers.h"
+#include "satba_schur.h"
 
 using namespace satba;
 
@@ -42,67 +45,35 @@ static int fail(int code, const char* fmt, ...) {
         if (e_ != hipSuccess) return fail(SATBA_E_HIP, "%s: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
     } while (0)
 
+constexpr int RED_SLOTS = 8, RED_MAX_GRID = 2048, RED_MAX_NV = 4;
+
 struct satba_problem {
     int model = 0, M = 0, N = 0, NP = 0, c_p = 0, n_cam_fix = 0, n_pts_fix = 0, rank = 0, world = 1, f32 = 0, device = 0;
     long long K = 0, n_total = 0;
     int n_c = 0, n = 0, hdr = 0;
     int loss = 0;
-    int camc_lds = 0;          // camera-constant table fits the per-workgroup LDS budget (40 KB)
-    size_t camc_bytes = 0;
+    int camc_lds = 0, rpc_lds = 0;  // per-camera tables staged in LDS by the observation kernels
+    int cam_sums_lds = 1;           // k_linearize accumulates diag U_c / g_c with LDS atomics (0: camera-major pass k_cam_sums)
+    int deterministic = 0;
     double f_scale = 1.0, lead = 1.0;
     hipStream_t stream = nullptr;
-    // observation data
-    double2* d_obs = nullptr;
-    double* d_w = nullptr;
-    int *d_cam = nullptr, *d_pt = nullptr, *d_tile_start = nullptr;
-    unsigned char* d_tile_split = nullptr;
-    int n_tiles = 0, n_split = 0;
-    int *d_split_pts = nullptr, *d_split_o0 = nullptr, *d_split_o1 = nullptr;
-    int *d_cam_ofs = nullptr, *d_cam_obs = nullptr, *d_pt_ofs = nullptr;  // camera-major lists, point CSR
-    int sch_T = 0, sch_ctiles = 0, sch_chunks = 0, sch_camc_lds = 0;       // Schur panel configuration (T == 0: v1 kernel)
-    size_t sch_lds = 0;
-    double *d_S_part = nullptr, *d_rhs_part = nullptr;
-    double* d_dch = nullptr;   // camera step in scaled variables
-    DagWorkspace dag;          // dataflow Cholesky (dag.n_tasks == 0: blocked multi-launch version)
+    Layout L;
+    int unit_weights = 0;
     double *d_cam_static = nullptr, *d_rpc = nullptr;
-    // solver state
+    // solver state (point parts in internal point order)
     double *d_x = nullptr, *d_xnew = nullptr, *d_camc = nullptr, *d_camc_new = nullptr;
     double *d_scale_inv = nullptr, *d_g = nullptr, *d_gh = nullptr, *d_gn = nullptr, *d_q1 = nullptr, *d_wv = nullptr;
-    double *d_U = nullptr, *d_gc = nullptr, *d_V = nullptr, *d_Vinv = nullptr, *d_tbuf = nullptr, *d_dc = nullptr;
-    double2* d_f = nullptr;
-    double* d_part = nullptr;
-    int lin_grid = 0;
-    // linearize v3 (two register-accumulating passes); lin3_chunks == 0: not used
-    int lin3_chunks = 0, lin3_grid = 0;
-    double2* d_cm_obs = nullptr;
-    double* d_cm_w = nullptr;
-    int* d_cm_pt = nullptr;
-    double* d_part3 = nullptr;
-    // Schur v3 (camera-pair intersection): sch3_chunks == 0: not used
-    int sch3_chunks = 0, NW = 0;
-    int sch3_groups = 0;    // > 0: lane-group list kernel, number of pair groups
-    int sch3_group_pairs = 8;
-    int sch3_chunk_mul = 1;   // fine chunks per coarse chunk of the pair lists
-    int sch3_groups_m = 0;      // groups of the moments kernel
-    bool sch3_moments = false;  // affine + unit weights: pair blocks through point moments (linear loss only)
-    double* d_Tbuf = nullptr;
-    double* d_Jpm = nullptr;    // RPC: Jacobian blocks of the current linearisation per observation (written by the linearize kernels)
-    int *d_pair_pi = nullptr, *d_pair_pj = nullptr;  // observation indices of the two observations of every pair-list entry
-    double2* d_sc = nullptr;    // Jacobian row scales of the current linearisation per observation (weighted / robust runs)
-    double c0[3] = {0, 0, 0};   // expansion point of the moments
-    bool c0_set = false;
-    int* d_groups = nullptr;
-    unsigned long long* d_bits = nullptr;
-    int* d_rank = nullptr;
-    double* d_PV = nullptr;    // packed per-point records (N x 12)
-    long long* d_pair_ofs = nullptr;  // per camera pair: list of shared points (null: bitmap scan)
-    int2* d_pair_ij = nullptr;        // pair index -> (i, j)
-    int* d_pair_pts = nullptr;
-    double* d_pair_part = nullptr;  // chunk partials of the pair blocks
-    int unit_weights = 0;
-    int u_full = 1;            // linearize accumulates the full U_c blocks (0: diagonal only, Schur v3 adds the rest)
+    double *d_U = nullptr, *d_gc = nullptr, *d_V = nullptr, *d_Vinv = nullptr, *d_PV = nullptr, *d_dc = nullptr, *d_dch = nullptr;
+    double2 *d_f = nullptr, *d_sc = nullptr;  // residual pairs / Jacobian row scales, ELL order
+    double* d_Jpm = nullptr;                  // RPC: Jacobian blocks of the current linearisation, ELL order
+    double *d_part = nullptr, *d_part3 = nullptr, *d_pair_part = nullptr;
+    int lin_grid = 0, cm_chunks = 1;
+    double* d_red = nullptr;  // RED_SLOTS x (RED_MAX_NV x RED_MAX_GRID doubles) partials of the deterministic grid sums
+    unsigned* d_red_cnt = nullptr;
+    double* d_stage = nullptr;  // staging for host transfers in the caller's order
+    size_t stage_len = 0;
     int* d_fail = nullptr;
-    int chol_mode = 0;  // SATBA_CHOL: 0 double steps (default), 1 two launches per panel, 2 single steps
+    int chol_mode = 0;  // SATBA_CHOL: 0 double steps (default), 2 single steps
     double* d_scal = nullptr;  // 8 private scalars (costs of satba_residuals, timing sinks)
     double* d_keep = nullptr;  // SATBA_KEEP_LEN scalars of the running iteration that outlive the per-phase headers
     bool prepared = false;
@@ -110,10 +81,14 @@ struct satba_problem {
     long long xb_len = 0;
     double* h_pin = nullptr;  // pinned staging for header reads
     bool linearized = false, have_step = false;
+    double create_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     std::vector<void*> allocs;
 
     double* payload() const { return d_xb + hdr; }
+    RedBuf red(int slot) const { return RedBuf{d_red + (size_t)slot * RED_MAX_NV * RED_MAX_GRID, d_red_cnt + slot}; }
 };
+// RedBuf slots
+enum { RB_RES = 0, RB_LIN = 1, RB_PREP = 2, RB_JVP = 3, RB_BS = 4, RB_SUB = 5, RB_TRIAL = 6, RB_MISC = 7 };
 
 template <class T>
 static int dev_alloc(satba_problem* p, T** out, size_t count) {
@@ -130,49 +105,70 @@ static int dev_alloc(satba_problem* p, T** out, size_t count) {
         if (rc_) return rc_; \
     } while (0)
 
-// dispatch on (camera model, parameters per camera, camera table in LDS); valid pairs: affine {3,5},
+// dispatch on (camera model, parameters per camera, camera table in LDS, RPC table in LDS); valid pairs: affine {3,5},
 // perspective / rpc {3,6}
+#define SATBA_CASE(key, M_, NP_, CL_, RL_, ...)                                                                    \
+    case key: { constexpr int MODEL = M_, NP = NP_; constexpr bool CL = CL_, RL = RL_; (void)CL; (void)RL; __VA_ARGS__; } break;
 #define SATBA_DISPATCH(p, ...)                                                                                    \
     do {                                                                                                          \
-        const int key_ = (p)->model * 10 + (p)->NP + ((p)->camc_lds ? 100 : 0);                                   \
+        const int key_ = (p)->model * 10 + (p)->NP + ((p)->camc_lds ? 100 : 0) + (((p)->model == RPC && (p)->rpc_lds) ? 1000 : 0); \
         switch (key_) {                                                                                           \
-            case 3:   { constexpr int MODEL = AFFINE, NP = 3; constexpr bool CL = false; (void)CL; __VA_ARGS__; } break;      \
-            case 5:   { constexpr int MODEL = AFFINE, NP = 5; constexpr bool CL = false; (void)CL; __VA_ARGS__; } break;      \
-            case 13:  { constexpr int MODEL = PERSPECTIVE, NP = 3; constexpr bool CL = false; (void)CL; __VA_ARGS__; } break; \
-            case 16:  { constexpr int MODEL = PERSPECTIVE, NP = 6; constexpr bool CL = false; (void)CL; __VA_ARGS__; } break; \
-            case 23:  { constexpr int MODEL = RPC, NP = 3; constexpr bool CL = false; (void)CL; __VA_ARGS__; } break;         \
-            case 26:  { constexpr int MODEL = RPC, NP = 6; constexpr bool CL = false; (void)CL; __VA_ARGS__; } break;         \
-            case 103: { constexpr int MODEL = AFFINE, NP = 3; constexpr bool CL = true; (void)CL; __VA_ARGS__; } break;       \
-            case 105: { constexpr int MODEL = AFFINE, NP = 5; constexpr bool CL = true; (void)CL; __VA_ARGS__; } break;       \
-            case 113: { constexpr int MODEL = PERSPECTIVE, NP = 3; constexpr bool CL = true; (void)CL; __VA_ARGS__; } break;  \
-            case 116: { constexpr int MODEL = PERSPECTIVE, NP = 6; constexpr bool CL = true; (void)CL; __VA_ARGS__; } break;  \
-            case 123: { constexpr int MODEL = RPC, NP = 3; constexpr bool CL = true; (void)CL; __VA_ARGS__; } break;          \
-            case 126: { constexpr int MODEL = RPC, NP = 6; constexpr bool CL = true; (void)CL; __VA_ARGS__; } break;          \
+            SATBA_CASE(3, AFFINE, 3, false, false, __VA_ARGS__)                                                   \
+            SATBA_CASE(5, AFFINE, 5, false, false, __VA_ARGS__)                                                   \
+            SATBA_CASE(13, PERSPECTIVE, 3, false, false, __VA_ARGS__)                                             \
+            SATBA_CASE(16, PERSPECTIVE, 6, false, false, __VA_ARGS__)                                             \
+            SATBA_CASE(23, RPC, 3, false, false, __VA_ARGS__)                                                     \
+            SATBA_CASE(26, RPC, 6, false, false, __VA_ARGS__)                                                     \
+            SATBA_CASE(103, AFFINE, 3, true, false, __VA_ARGS__)                                                  \
+            SATBA_CASE(105, AFFINE, 5, true, false, __VA_ARGS__)                                                  \
+            SATBA_CASE(113, PERSPECTIVE, 3, true, false, __VA_ARGS__)                                             \
+            SATBA_CASE(116, PERSPECTIVE, 6, true, false, __VA_ARGS__)                                             \
+            SATBA_CASE(123, RPC, 3, true, false, __VA_ARGS__)                                                     \
+            SATBA_CASE(126, RPC, 6, true, false, __VA_ARGS__)                                                     \
+            SATBA_CASE(1123, RPC, 3, true, true, __VA_ARGS__)                                                     \
+            SATBA_CASE(1126, RPC, 6, true, true, __VA_ARGS__)                                                     \
+            SATBA_CASE(1023, RPC, 3, false, true, __VA_ARGS__)                                                    \
+            SATBA_CASE(1026, RPC, 6, false, true, __VA_ARGS__)                                                    \
             default: return fail(SATBA_E_ARG, "unsupported (cam_model, n_params) = (%d, %d)", (p)->model, (p)->NP);           \
         }                                                                                                         \
     } while (0)
 
 static ObsArgs obs_args(const satba_problem* p, bool at_new) {
     ObsArgs a;
-    a.obs = p->d_obs; a.w = p->d_w; a.cam = p->d_cam; a.pt = p->d_pt;
-    a.tile_start = p->d_tile_start; a.tile_split = p->d_tile_split;
+    const Layout& L = p->L;
+    a.e_cam = L.e_cam; a.e_obs = L.e_obs; a.e_w = L.e_w; a.slice_base = L.slice_base; a.pt_cnt = L.pt_cnt; a.perm = L.perm;
     a.x = at_new ? p->d_xnew : p->d_x;
     a.camc = at_new ? p->d_camc_new : p->d_camc;
     a.rpc = p->d_rpc;
     a.Jpm = at_new ? nullptr : p->d_Jpm;  // stored Jacobian blocks belong to the linearisation at x
     a.sc = (at_new || (p->loss == 0 && p->unit_weights)) ? nullptr : p->d_sc;
-    a.K = p->K; a.n_tiles = p->n_tiles; a.M = p->M; a.N = p->N; a.n_c = p->n_c;
+    a.K = p->K; a.P = L.P; a.n_slices = L.n_slices; a.M = p->M; a.N = p->N; a.n_c = p->n_c;
     a.n_cam_fix = p->n_cam_fix; a.n_pts_fix = p->n_pts_fix; a.loss = p->loss; a.f32 = p->f32;
     a.f_scale = p->f_scale;
     a.unit = (p->loss == 0 && p->unit_weights) ? 1 : 0;
     return a;
 }
+static CamMajor cam_major(const satba_problem* p) { return CamMajor{p->L.cam_ofs, p->L.cm_pt, p->L.cm_pos}; }
 
 static int grid_for(long long work, int block, int cap) {
     long long g = (work + block - 1) / block;
     if (g < 1) g = 1;
     if (g > cap) g = cap;
     return (int)g;
+}
+
+static size_t table_bytes(const satba_problem* p) {
+    return sizeof(double) * ((p->camc_lds ? (size_t)p->M * CAMC : 0) + ((p->model == RPC && p->rpc_lds) ? (size_t)p->M * RPCS : 0));
+}
+static size_t lin_lds(const satba_problem* p) {
+    return table_bytes(p) + (p->cam_sums_lds ? sizeof(double) * (size_t)p->M * cam_sum_stride(p->NP) : 0);
+}
+static size_t dir_table_bytes(const satba_problem* p) { return sizeof(double) * (size_t)p->M * JVP_ROW; }
+
+template <class K>
+static int raise_lds_limit(K kernel, size_t bytes) {
+    if (bytes > 64 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return 0;
 }
 
 static int launch_cam_consts(satba_problem* p, bool at_new) {
@@ -182,168 +178,130 @@ static int launch_cam_consts(satba_problem* p, bool at_new) {
     return 0;
 }
 
-// S z = rhs for the reduced system (S column-major lower, destroyed; b in place)
-static int dense_solve(satba_problem* p, double* S, double* b) {
-    if (p->dag.n_tasks > 0) {
-        HIP_TRY(hipMemsetAsync(p->d_fail, 0, sizeof(int), p->stream));
-        HIP_TRY(hipMemsetAsync(p->dag.d_flags, 0, sizeof(int) * p->dag.flag_ints, p->stream));
-        DagFlags fl = dag_flags(p->dag);
-        hipLaunchKernelGGL(k_chol_dag, dim3(DG_GRID), dim3(DG_THREADS), 0, p->stream, S, p->n_c, b, p->dag.d_tasks, p->dag.n_tasks, fl);
-        hipLaunchKernelGGL(k_dag_status, dim3(1), dim3(1), 0, p->stream, fl.ctr, p->d_fail);
-        hipLaunchKernelGGL(k_trsv_back, dim3(1), dim3(1024), sizeof(double) * p->n_c, p->stream, S, p->n_c, b);
-    } else {
-        cholesky_solve(S, p->n_c, b, p->d_fail, p->d_fail + 1, p->chol_mode, p->stream);  // clears d_fail and the step flags
-    }
-    HIP_TRY(hipGetLastError());
-    return 0;
-}
-
 static int zero_header(satba_problem* p) {
     HIP_TRY(hipMemsetAsync(p->d_xb, 0, sizeof(double) * p->hdr, p->stream));
     return 0;
 }
 
-static int launch_residual(satba_problem* p, bool at_new, double2* f, double* hdr_slot) {
+// slices are sorted by track length: a grid-stride walk hands every wave short and long slices alike
+static int slice_grid(const satba_problem* p, int waves_per_block, int cap) { return grid_for(p->L.n_slices, waves_per_block, cap); }
+
+static int launch_residual(satba_problem* p, bool at_new, double2* f, double* cost) {
     ObsArgs a = obs_args(p, at_new);
-    const int grid = grid_for(p->K, 512, 512);
+    const int grid = slice_grid(p, RES_THREADS / 64, 1024);
+    const size_t lds = table_bytes(p);
     if (p->loss == 0 && p->unit_weights)
-        SATBA_DISPATCH(p, hipLaunchKernelGGL((k_residual<MODEL, NP, CL, true>), dim3(grid), dim3(512), p->camc_bytes, p->stream, a, f, hdr_slot));
+        SATBA_DISPATCH(p, hipLaunchKernelGGL((k_residual<MODEL, NP, CL, RL, true>), dim3(grid), dim3(RES_THREADS), lds, p->stream, a, f, p->red(RB_RES), cost));
     else
-        SATBA_DISPATCH(p, hipLaunchKernelGGL((k_residual<MODEL, NP, CL>), dim3(grid), dim3(512), p->camc_bytes, p->stream, a, f, hdr_slot));
+        SATBA_DISPATCH(p, hipLaunchKernelGGL((k_residual<MODEL, NP, CL, RL, false>), dim3(grid), dim3(RES_THREADS), lds, p->stream, a, f, p->red(RB_RES), cost));
     HIP_TRY(hipGetLastError());
     return 0;
 }
 
-// number of workgroup partials the last linearize launch produced
-static int lin_partials(const satba_problem* p) { return p->lin_grid; }
-
-template <int MODEL, int NP, bool CL>
-static int launch_lin3(satba_problem* p, const ObsArgs& a) {
-    Lin3Args s;
-    s.pt_ofs = p->d_pt_ofs; s.f = p->d_f; s.V = p->d_V; s.gp = p->d_g + p->n_c;
-    s.hdr_cost = p->d_xb + 0; s.hdr_gpmax = p->d_xb + SATBA_HDR_FIXED + p->rank;
-    CamMajor cm;
-    cm.cam_ofs = p->d_cam_ofs; cm.obs = p->d_cm_obs; cm.w = p->d_cm_w; cm.pt = p->d_cm_pt; cm.oidx = p->d_cam_obs;
-    const size_t lds = p->camc_bytes;
-    if (p->loss == 0) {
-        hipLaunchKernelGGL((k_lin_points<MODEL, NP, false, CL>), dim3(p->lin3_grid), dim3(256), lds, p->stream, a, s);
-        hipLaunchKernelGGL((k_lin_cameras<MODEL, NP, false>), dim3(p->lin3_chunks, p->M), dim3(LINC_THREADS), 0, p->stream, a, cm, p->d_part3);
-    } else {
-        hipLaunchKernelGGL((k_lin_points<MODEL, NP, true, CL>), dim3(p->lin3_grid), dim3(256), lds, p->stream, a, s);
-        hipLaunchKernelGGL((k_lin_cameras<MODEL, NP, true>), dim3(p->lin3_chunks, p->M), dim3(LINC_THREADS), 0, p->stream, a, cm, p->d_part3);
-    }
-    HIP_TRY(hipGetLastError());
-    return 0;
+// which instantiation of k_linearize a run takes: 0 unit weights + linear loss (not RPC: its Jacobian store carries the
+// masks), 1 linear loss, 2 soft_l1 specialised (not RPC: registers), 3 generic robust
+static int lin_variant(const satba_problem* p) {
+    if (p->loss == 0) return (p->unit_weights && p->model != RPC) ? 0 : 1;
+    return (p->loss == SATBA_LOSS_SOFT_L1 && p->model != RPC) ? 2 : 3;
 }
 
-static size_t lin1_lds(const satba_problem* p, bool robust) {
-    const int waves = robust ? 8 : 16;
-    return sizeof(double) * ((size_t)p->M * cam_acc_stride(p->NP) + (size_t)waves * 9 * LIN_STAGE) + p->camc_bytes;
-}
-
-template <int MODEL, int NP, bool CL, bool FULLU>
-static int launch_lin1u(satba_problem* p, const ObsArgs& a) {
+template <int MODEL, int NP, bool CL, bool RL>
+static int launch_lin(satba_problem* p, const ObsArgs& a) {
     double* gpv = p->d_g + p->n_c;
     double* cost = p->d_xb + 0;
     double* gmax = p->d_xb + SATBA_HDR_FIXED + p->rank;
-    if (p->loss == 0 && p->unit_weights && MODEL != RPC)  // RPC keeps the generic form (its Jacobian store carries the masks)
-        hipLaunchKernelGGL((k_linearize<MODEL, NP, false, CL, FULLU, false, MODEL != RPC>), dim3(p->lin_grid), dim3(LinCfg<false>::THREADS),
-                           lin1_lds(p, false), p->stream, a, p->d_f, p->d_V, gpv, p->d_part, cost, gmax);
-    else if (p->loss == 0)
-        hipLaunchKernelGGL((k_linearize<MODEL, NP, false, CL, FULLU>), dim3(p->lin_grid), dim3(LinCfg<false>::THREADS),
-                           lin1_lds(p, false), p->stream, a, p->d_f, p->d_V, gpv, p->d_part, cost, gmax);
-    else if (p->loss == SATBA_LOSS_SOFT_L1 && MODEL != RPC)  // the pipeline's robust loss, specialised (RPC needs the registers)
-        hipLaunchKernelGGL((k_linearize<MODEL, NP, true, CL, FULLU, MODEL != RPC>), dim3(p->lin_grid), dim3(LinCfg<MODEL == RPC>::THREADS),
-                           lin1_lds(p, MODEL == RPC), p->stream, a, p->d_f, p->d_V, gpv, p->d_part, cost, gmax);
-    else
-        hipLaunchKernelGGL((k_linearize<MODEL, NP, true, CL, FULLU>), dim3(p->lin_grid), dim3(LinCfg<true>::THREADS),
-                           lin1_lds(p, true), p->stream, a, p->d_f, p->d_V, gpv, p->d_part, cost, gmax);
+    const size_t lds = lin_lds(p);
+    const RedBuf rb = p->red(RB_LIN);
+    constexpr bool BIGL = MODEL == RPC;  // LinCfg of the linear-loss variants
+#define SATBA_LIN_LAUNCH(ROB, SOFT_, UNIT_, CS_, BIG_)                                                                                   \
+    hipLaunchKernelGGL((k_linearize<MODEL, NP, ROB, CL, RL, SOFT_, UNIT_, CS_>), dim3(p->lin_grid), dim3(LinCfg<BIG_>::THREADS), lds, p->stream, \
+                       a, p->d_f, p->d_V, gpv, p->d_part, rb, cost, gmax)
+    const int v = lin_variant(p);
+    if (p->cam_sums_lds) {
+        if (v == 0) { if constexpr (MODEL != RPC) SATBA_LIN_LAUNCH(false, false, true, true, false); }
+        else if (v == 1) SATBA_LIN_LAUNCH(false, false, false, true, BIGL);
+        else if (v == 2) { if constexpr (MODEL != RPC) SATBA_LIN_LAUNCH(true, true, false, true, false); }
+        else SATBA_LIN_LAUNCH(true, false, false, true, true);
+    } else {
+        if (v == 0) { if constexpr (MODEL != RPC) SATBA_LIN_LAUNCH(false, false, true, false, false); }
+        else if (v == 1) SATBA_LIN_LAUNCH(false, false, false, false, BIGL);
+        else if (v == 2) { if constexpr (MODEL != RPC) SATBA_LIN_LAUNCH(true, true, false, false, false); }
+        else SATBA_LIN_LAUNCH(true, false, false, false, true);
+    }
+#undef SATBA_LIN_LAUNCH
     HIP_TRY(hipGetLastError());
     return 0;
 }
 
-template <int MODEL, int NP, bool CL>
-static int launch_lin1(satba_problem* p, const ObsArgs& a) {
-    return p->u_full ? launch_lin1u<MODEL, NP, CL, true>(p, a) : launch_lin1u<MODEL, NP, CL, false>(p, a);
+template <int MODEL, int NP, bool CL, bool RL>
+static int raise_lin_limits(satba_problem* p) {
+    const size_t lds = lin_lds(p);
+    TRY(raise_lds_limit(k_linearize<MODEL, NP, false, CL, RL, false, false, true>, lds));
+    TRY(raise_lds_limit(k_linearize<MODEL, NP, false, CL, RL, false, false, false>, lds));
+    TRY(raise_lds_limit(k_linearize<MODEL, NP, true, CL, RL, false, false, true>, lds));
+    TRY(raise_lds_limit(k_linearize<MODEL, NP, true, CL, RL, false, false, false>, lds));
+    if constexpr (MODEL != RPC) {
+        TRY(raise_lds_limit(k_linearize<MODEL, NP, false, CL, RL, false, true, true>, lds));
+        TRY(raise_lds_limit(k_linearize<MODEL, NP, false, CL, RL, false, true, false>, lds));
+        TRY(raise_lds_limit(k_linearize<MODEL, NP, true, CL, RL, true, false, true>, lds));
+        TRY(raise_lds_limit(k_linearize<MODEL, NP, true, CL, RL, true, false, false>, lds));
+    }
+    TRY(raise_lds_limit(k_residual<MODEL, NP, CL, RL, true>, table_bytes(p)));
+    TRY(raise_lds_limit(k_residual<MODEL, NP, CL, RL, false>, table_bytes(p)));
+    const size_t t = std::max(table_bytes(p), dir_table_bytes(p));
+    TRY(raise_lds_limit(k_jvp<MODEL, NP, 1, CL, RL, true>, t));
+    TRY(raise_lds_limit(k_jvp<MODEL, NP, 1, CL, RL, false>, t));
+    TRY(raise_lds_limit(k_jvp<MODEL, NP, 2, CL, RL, false>, t));
+    TRY(raise_lds_limit(k_backsub<MODEL, NP, CL, RL>, t));
+    return 0;
 }
 
 static int launch_linearize_kernel(satba_problem* p) {
     ObsArgs a = obs_args(p, false);
-    if (p->lin3_grid > 0) {
-        SATBA_DISPATCH(p, TRY((launch_lin3<MODEL, NP, CL>(p, a))));
-        return 0;
-    }
-    SATBA_DISPATCH(p, TRY((launch_lin1<MODEL, NP, CL>(p, a))));
+    SATBA_DISPATCH(p, TRY((launch_lin<MODEL, NP, CL, RL>(p, a))));
     return 0;
 }
 
-static size_t schur_lds(const satba_problem* p) { return sizeof(double) * ((size_t)4 * 64 * p->NP * 3 + p->n_c); }
-
-template <int MODEL, int NP, bool ADDU>
-static int launch_schur3(satba_problem* p, const ObsArgs& a, double* S, double* rhs) {
-    CamMajor cm;
-    cm.cam_ofs = p->d_cam_ofs; cm.obs = p->d_cm_obs; cm.w = p->d_cm_w; cm.pt = p->d_cm_pt; cm.oidx = p->d_cam_obs;
-    Schur3Args s;
-    s.bits = p->d_bits; s.rank = p->d_rank; s.Vinv = p->d_Vinv; s.gp = p->d_g + p->n_c; s.NW = p->NW; s.n_chunks = p->sch3_chunks;
-    s.PV = reinterpret_cast<const double2*>(p->d_PV);
-    s.pair_ofs = p->d_pair_ofs; s.pair_pts = p->d_pair_pts; s.pair_part = p->d_pair_part; s.chunk_mul = p->sch3_chunk_mul;
-    s.pair_pi = p->d_pair_pi; s.pair_pj = p->d_pair_pj;
-    const long long n_pairs = (long long)p->M * (p->M - 1) / 2;
-    const long long items = n_pairs * p->sch3_chunks;
-    const int diag_chunks = p->lin3_chunks;
-    const bool grp = p->sch3_groups > 0;
-    const unsigned ggrid = grp ? (unsigned)((p->sch3_groups + S3_GW - 1) / S3_GW) : 0;
-    // list path: 2-D grid (pairs / 4, chunks); bitmap path: 1-D over the (pair, chunk) items
-    if (items >= (1ll << 31)) return fail(SATBA_E_ARG, "too many (camera pair, chunk) work items");
-    const dim3 igrid = p->d_pair_ofs ? dim3((unsigned)((n_pairs + 3) / 4), (unsigned)p->sch3_chunks) : dim3((unsigned)((items + 3) / 4));
-    s.pair_ij = p->d_pair_ij;
-    const bool moments = p->sch3_moments && p->loss == 0 && items > 0;
-    // diagonal blocks first: for RPC cameras this pass also stores the Jacobian blocks the pair kernel gathers
-    if (p->loss == 0) hipLaunchKernelGGL((k_schur_diag<MODEL, NP, false, ADDU>), dim3(p->M, diag_chunks), dim3(LINC_THREADS), 0, p->stream, a, cm, s, p->d_part3);
-    else hipLaunchKernelGGL((k_schur_diag<MODEL, NP, true, ADDU>), dim3(p->M, diag_chunks), dim3(LINC_THREADS), 0, p->stream, a, cm, s, p->d_part3);
-    bool done = false;
-    if constexpr (MODEL == AFFINE) {
-        if (moments) {
-            hipLaunchKernelGGL((k_schur_pairs_moments<6>), dim3((unsigned)((p->sch3_groups_m + S3_GW - 1) / S3_GW)), dim3(64 * S3_GW), 0, p->stream,
-                               p->M, p->n_pts_fix, s, p->d_groups, p->sch3_groups_m, p->c0[0], p->c0[1], p->c0[2], p->d_Tbuf);
-            const long long outs = n_pairs * NP * NP;
-            hipLaunchKernelGGL((k_schur_contract<NP>), dim3((unsigned)((outs + 255) / 256)), dim3(256), 0, p->stream, a, p->d_Tbuf,
-                               p->c0[0], p->c0[1], p->c0[2], S);
-            done = true;
-        }
-    }
-    if (done || items == 0) {
-    } else if (p->loss == 0 && p->unit_weights) {
-        if (grp) {
-            if (p->sch3_group_pairs == 10)
-                hipLaunchKernelGGL((k_schur_pairs_groups6<MODEL, NP, false, true>), dim3(ggrid), dim3(64 * S3_GW), 0, p->stream, a, cm, s, p->d_groups, p->sch3_groups, S);
-            else if constexpr (MODEL == AFFINE)
-                hipLaunchKernelGGL((k_schur_pairs_groups_occ3<MODEL, NP, false, true>), dim3(ggrid), dim3(64 * S3_GW), 0, p->stream, a, cm, s, p->d_groups, p->sch3_groups, S);
-            else
-                hipLaunchKernelGGL((k_schur_pairs_groups<MODEL, NP, false, true>), dim3(ggrid), dim3(64 * S3_GW), 0, p->stream, a, cm, s, p->d_groups, p->sch3_groups, S);
-        } else {
-            hipLaunchKernelGGL((k_schur_pairs<MODEL, NP, false, true>), igrid, dim3(256), 0, p->stream, a, cm, s, S);
-        }
-    } else if (!grp && p->d_pair_ofs && p->d_pair_pi && a.sc) {
-        // weighted / robust with pair lists that carry the observation indices: unit Jacobians times the stored scales
-        hipLaunchKernelGGL((k_schur_pairs<MODEL, NP, false, false, true>), igrid, dim3(256), 0, p->stream, a, cm, s, S);
-    } else if (p->loss == 0) {
-        if (grp) hipLaunchKernelGGL((k_schur_pairs_groups<MODEL, NP, false, false>), dim3(ggrid), dim3(64 * S3_GW), 0, p->stream, a, cm, s, p->d_groups, p->sch3_groups, S);
-        else hipLaunchKernelGGL((k_schur_pairs<MODEL, NP, false, false>), igrid, dim3(256), 0, p->stream, a, cm, s, S);
-    } else {
-        if (grp) hipLaunchKernelGGL((k_schur_pairs_groups<MODEL, NP, true, false>), dim3(ggrid), dim3(64 * S3_GW), 0, p->stream, a, cm, s, p->d_groups, p->sch3_groups, S);
-        else hipLaunchKernelGGL((k_schur_pairs<MODEL, NP, true, false>), igrid, dim3(256), 0, p->stream, a, cm, s, S);
-    }
+// camera-major camera sums of the stored linearisation -> U (full blocks), g_c
+static int launch_cam_sums(satba_problem* p, double* U, double* gc) {
+    ObsArgs a = obs_args(p, false);
+    CamMajor cm = cam_major(p);
+    SATBA_DISPATCH(p, hipLaunchKernelGGL((k_cam_sums<MODEL, NP>), dim3(p->M, p->cm_chunks), dim3(LINC_THREADS), 0, p->stream, a, cm, p->d_f, p->d_part3));
     HIP_TRY(hipGetLastError());
-    if (items > 0 && p->d_pair_ofs && p->sch3_chunks > 1 && !grp && !(MODEL == AFFINE && moments)) {
-        const long long outs = n_pairs * p->NP * p->NP;
-        hipLaunchKernelGGL(k_schur_pairs_reduce, dim3((unsigned)((outs + 255) / 256)), dim3(256), 0, p->stream, p->M, p->NP, p->n_c,
-                           p->sch3_chunks, p->d_pair_part, S);
-        HIP_TRY(hipGetLastError());
-    }
     const int total = p->M * cam_acc_len(p->NP);
-    hipLaunchKernelGGL(k_schur_diag_finish, dim3((total + 255) / 256), dim3(256), 0, p->stream, p->M, p->NP, p->n_c, diag_chunks,
-                       p->d_part3, S, rhs);
+    hipLaunchKernelGGL(k_cam_sums_finish, dim3((total + 255) / 256), dim3(256), 0, p->stream, p->M, p->NP, p->cm_chunks, p->d_part3, U, gc);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+static SchurArgs schur_args(const satba_problem* p) {
+    SchurArgs s;
+    s.PV = reinterpret_cast<const double2*>(p->d_PV);
+    s.pair_ofs = p->L.pair_ofs; s.pair_pts = p->L.pair_pts; s.pair_pi = p->L.pair_pi; s.pair_pj = p->L.pair_pj;
+    s.pair_ij = p->L.pair_ij; s.pair_part = p->d_pair_part; s.n_chunks = p->L.C;
+    return s;
+}
+
+template <int MODEL, int NP>
+static int launch_schur(satba_problem* p, const ObsArgs& a, double* S, double* rhs) {
+    CamMajor cm = cam_major(p);
+    SchurArgs s = schur_args(p);
+    const long long n_pairs = p->L.n_pairs;
+    // diagonal blocks (with J_c^T J_c) and right-hand side
+    hipLaunchKernelGGL((k_schur_diag<MODEL, NP>), dim3(p->M, p->cm_chunks), dim3(LINC_THREADS), 0, p->stream, a, cm, s, p->d_part3);
+    if (n_pairs > 0 && p->L.E > 0) {
+        const dim3 igrid((unsigned)((n_pairs + 3) / 4), (unsigned)p->L.C);
+        if (a.unit) hipLaunchKernelGGL((k_schur_pairs<MODEL, NP, true>), igrid, dim3(256), 0, p->stream, a, s, S);
+        else hipLaunchKernelGGL((k_schur_pairs<MODEL, NP, false>), igrid, dim3(256), 0, p->stream, a, s, S);
+        HIP_TRY(hipGetLastError());
+        if (p->L.C > 1) {
+            const long long outs = n_pairs * NP * NP;
+            hipLaunchKernelGGL(k_schur_pairs_reduce, dim3((unsigned)((outs + 255) / 256)), dim3(256), 0, p->stream, p->M, NP, p->n_c, p->L.C,
+                               p->L.pair_ij, p->d_pair_part, S);
+        }
+    }
+    const int total = p->M * cam_acc_len(NP);
+    hipLaunchKernelGGL(k_schur_diag_finish, dim3((total + 255) / 256), dim3(256), 0, p->stream, p->M, NP, p->n_c, p->cm_chunks, p->d_part3, S, rhs);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -352,44 +310,16 @@ static int launch_schur_kernel(satba_problem* p) {
     ObsArgs a = obs_args(p, false);
     double* S = p->payload();
     double* rhs = S + (size_t)p->n_c * p->n_c;
-    if (p->sch3_chunks > 0) {  // v3: camera-pair intersection, register accumulation
-        if (p->u_full) SATBA_DISPATCH(p, TRY((launch_schur3<MODEL, NP, false>(p, a, S, rhs))));
-        else SATBA_DISPATCH(p, TRY((launch_schur3<MODEL, NP, true>(p, a, S, rhs))));
-        return 0;
-    }
-    if (p->sch_T > 0) {  // v2: LDS column panels, no global atomics
-        SchurArgs s;
-        s.cam_ofs = p->d_cam_ofs; s.cam_obs = p->d_cam_obs; s.pt_ofs = p->d_pt_ofs;
-        s.Vinv = p->d_Vinv; s.gp = p->d_g + p->n_c; s.S_part = p->d_S_part; s.rhs_part = p->d_rhs_part;
-        s.T = p->sch_T; s.n_ctiles = p->sch_ctiles; s.n_chunks = p->sch_chunks; s.camc_in_lds = p->sch_camc_lds;
-        SATBA_DISPATCH(p, hipLaunchKernelGGL((k_schur_panel<MODEL, NP, CL>), dim3(p->sch_ctiles * p->sch_chunks),
-                                             dim3(SCHUR_THREADS), p->sch_lds, p->stream, a, s));
-        HIP_TRY(hipGetLastError());
-        hipLaunchKernelGGL(k_schur_reduce, dim3(grid_for((long long)p->n_c * p->n_c, 256, 2048)), dim3(256), 0, p->stream,
-                           p->n_c, p->sch_chunks, p->d_S_part, p->d_rhs_part, S, rhs);
-        HIP_TRY(hipGetLastError());
-        return 0;
-    }
-    const int grid = grid_for(p->n_tiles, 4, 2048);
-    SATBA_DISPATCH(p, hipLaunchKernelGGL((k_schur<MODEL, NP>), dim3(grid), dim3(256), schur_lds(p), p->stream, a, p->d_Vinv,
-                                          p->d_g + p->n_c, S, rhs));
-    HIP_TRY(hipGetLastError());
-    if (p->n_split > 0) {
-        SATBA_DISPATCH(p, hipLaunchKernelGGL((k_schur_split<MODEL, NP>), dim3(grid_for(p->n_split, 1, 1024)), dim3(64), 0,
-                                              p->stream, a, p->n_split, p->d_split_pts, p->d_split_o0, p->d_split_o1,
-                                              p->d_Vinv, p->d_g + p->n_c, S, rhs));
-        HIP_TRY(hipGetLastError());
-    }
+    SATBA_DISPATCH(p, TRY((launch_schur<MODEL, NP>(p, a, S, rhs))));
     return 0;
 }
 
 static int launch_backsub_kernel(satba_problem* p) {
     ObsArgs a = obs_args(p, false);
-    const int grid = grid_for(p->n_tiles, 4, 2048);
-    // affine: the kernel builds its own 15-double-per-camera table in LDS (k_backsub); otherwise the camera-constant table
-    const size_t lds = p->model == AFFINE ? sizeof(double) * (size_t)p->M * BS_ROW : p->camc_bytes;
-    if (lds > 158 * 1024) return fail(SATBA_E_ARG, "n_cam = %d exceeds the LDS budget of the back-substitution kernel", p->M);
-    SATBA_DISPATCH(p, hipLaunchKernelGGL((k_backsub<MODEL, NP, CL>), dim3(grid), dim3(256), lds, p->stream, a, p->d_dc, p->d_tbuf));
+    const int grid = slice_grid(p, BS_THREADS / 64, 1024);
+    const size_t lds = p->model == AFFINE ? dir_table_bytes(p) : table_bytes(p);
+    SATBA_DISPATCH(p, hipLaunchKernelGGL((k_backsub<MODEL, NP, CL, RL>), dim3(grid), dim3(BS_THREADS), lds, p->stream, a, p->d_dc, p->d_dch, p->lead,
+                                         p->d_Vinv, p->d_g, p->d_scale_inv, p->d_gh, p->d_gn, p->red(RB_BS), p->d_xb));
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -397,17 +327,25 @@ static int launch_backsub_kernel(satba_problem* p) {
 // pre: q1 is already in unscaled variables (nv == 1 only)
 static int launch_jvp(satba_problem* p, int nv, const double* q1, const double* q2, double* out, bool pre = false) {
     ObsArgs a = obs_args(p, false);
-    const int grid = grid_for(p->K, 512, 512);
+    const int grid = slice_grid(p, JVP_THREADS / 64, 1024);
+    const RedBuf rb = p->red(RB_JVP);
     if (nv == 1 && pre) {
-        SATBA_DISPATCH(p, hipLaunchKernelGGL((k_jvp<MODEL, NP, 1, CL, true>), dim3(grid), dim3(512), p->camc_bytes + sizeof(double) * p->n_c,
-                                              p->stream, a, q1, q2, p->d_scale_inv, out));
+        const size_t lds = p->model == AFFINE ? dir_table_bytes(p) : table_bytes(p);
+        SATBA_DISPATCH(p, hipLaunchKernelGGL((k_jvp<MODEL, NP, 1, CL, RL, true>), dim3(grid), dim3(JVP_THREADS), lds, p->stream, a, q1, q2, p->d_scale_inv, rb, out));
     } else if (nv == 1) {
-        SATBA_DISPATCH(p, hipLaunchKernelGGL((k_jvp<MODEL, NP, 1, CL>), dim3(grid), dim3(512), p->camc_bytes, p->stream, a, q1, q2,
-                                              p->d_scale_inv, out));
+        SATBA_DISPATCH(p, hipLaunchKernelGGL((k_jvp<MODEL, NP, 1, CL, RL, false>), dim3(grid), dim3(JVP_THREADS), table_bytes(p), p->stream, a, q1, q2,
+                                             p->d_scale_inv, rb, out));
     } else {
-        SATBA_DISPATCH(p, hipLaunchKernelGGL((k_jvp<MODEL, NP, 2, CL>), dim3(grid), dim3(512), p->camc_bytes, p->stream, a, q1, q2,
-                                              p->d_scale_inv, out));
+        SATBA_DISPATCH(p, hipLaunchKernelGGL((k_jvp<MODEL, NP, 2, CL, RL, false>), dim3(grid), dim3(JVP_THREADS), table_bytes(p), p->stream, a, q1, q2,
+                                             p->d_scale_inv, rb, out));
     }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// S z = rhs for the reduced system (S column-major lower, destroyed; b in place)
+static int dense_solve(satba_problem* p, double* S, double* b) {
+    cholesky_solve(S, p->n_c, b, p->d_fail, p->d_fail + 1, p->chol_mode, p->stream);  // clears d_fail and the step flags
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -436,16 +374,182 @@ __global__ void k_lambda(const double* __restrict__ hdr, double Delta, double la
     keep[6] = Delta;
 }
 
-template <class K>
-static int raise_lds_limit(K kernel, size_t bytes) {
-    if (bytes > 64 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-    return 0;
+static double ms_since(std::chrono::steady_clock::time_point t0) {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+}
+
+// ---------------------------------------------------------------------------------------------------- layout builder
+// All index structures are derived on the device (satba_layout.h); the host sizes allocations from three scalars it reads
+// back (padded ELL length, pair-list length, status flags).
+static int build_layout(satba_problem* p, const satba_problem_desc* d) {
+    Layout& L = p->L;
+    const long long K = p->K;
+    const int M = p->M, N = p->N;
+    hipStream_t st = p->stream;
+    L.M = M; L.N = N; L.K = K;
+    L.n_slices = (N + 63) / 64;
+    L.n_pairs = (long long)M * (M - 1) / 2;
+    if (L.n_pairs >= (1ll << 31)) return fail(SATBA_E_ARG, "too many camera pairs");
+    auto t0 = std::chrono::steady_clock::now();
+
+    // temporaries of the build (freed at the end)
+    std::vector<void*> tmp;
+    auto tmp_alloc = [&](void** out, size_t bytes) -> int {
+        HIP_TRY(hipMalloc(out, bytes ? bytes : 1));
+        tmp.push_back(*out);
+        return 0;
+    };
+    auto free_tmp = [&]() { for (void* q : tmp) (void)hipFree(q); tmp.clear(); };
+#define TMP(ptr, count) TRY(tmp_alloc((void**)&(ptr), sizeof(*(ptr)) * (size_t)(count)))
+    int rc = [&]() -> int {
+        int *o_cam = nullptr, *flags = nullptr, *o_ofs = nullptr, *cnt_o = nullptr, *iota = nullptr, *slots = nullptr, *ipt_ofs = nullptr;
+        double2* o_obs = nullptr;
+        double* o_w = nullptr;
+        long long* hits = nullptr;
+        const size_t Kz = (size_t)std::max<long long>(K, 1), Nz = (size_t)std::max(N, 1);
+        TMP(o_cam, Kz); TMP(o_obs, Kz); TMP(o_w, Kz); TMP(flags, 4); TMP(o_ofs, Nz + 1); TMP(cnt_o, Nz); TMP(iota, Nz);
+        TMP(slots, L.n_slices + 1); TMP(ipt_ofs, Nz + 1); TMP(hits, Nz + 1);
+        TRY(dev_alloc(p, &L.pts_ind, Kz)); TRY(dev_alloc(p, &L.obs_pos, Kz));
+        TRY(dev_alloc(p, &L.perm, Nz)); TRY(dev_alloc(p, &L.rank, Nz)); TRY(dev_alloc(p, &L.pt_cnt, Nz));
+        TRY(dev_alloc(p, &L.slice_base, L.n_slices + 1)); TRY(dev_alloc(p, &L.hit_ofs, Nz + 1));
+        TRY(dev_alloc(p, &L.cam_ofs, M + 1)); TRY(dev_alloc(p, &L.cm_pt, Kz)); TRY(dev_alloc(p, &L.cm_pos, Kz));
+        HIP_TRY(hipMemsetAsync(flags, 0, sizeof(int) * 4, st));
+        if (K) {
+            HIP_TRY(hipMemcpyAsync(o_cam, d->cam_ind, sizeof(int) * K, hipMemcpyHostToDevice, st));
+            HIP_TRY(hipMemcpyAsync(L.pts_ind, d->pts_ind, sizeof(int) * K, hipMemcpyHostToDevice, st));
+            HIP_TRY(hipMemcpyAsync(o_obs, d->pts2d, sizeof(double) * 2 * K, hipMemcpyHostToDevice, st));
+            HIP_TRY(hipMemcpyAsync(o_w, d->weights, sizeof(double) * K, hipMemcpyHostToDevice, st));
+            hipLaunchKernelGGL(k_lay_validate, dim3(grid_for(K, 256, 4096)), dim3(256), 0, st, K, M, N, o_cam, L.pts_ind, o_w, flags);
+        }
+        p->create_ms[0] = ms_since(t0);  // uploads queued (pageable host memory: the copies are synchronous in effect)
+        // point CSR of the caller's order, track lengths, stable sort by length
+        hipLaunchKernelGGL((k_lay_offsets<int>), dim3(grid_for(K + 1, 256, 4096)), dim3(256), 0, st, K, N, L.pts_ind, o_ofs);
+        if (N) hipLaunchKernelGGL(k_lay_counts, dim3((N + 255) / 256), dim3(256), 0, st, N, o_ofs, cnt_o, iota);
+        size_t cub_bytes = 0, need = 0;
+        int bits_n = 1;
+        while ((1ll << bits_n) <= M) ++bits_n;  // track lengths are <= M
+        HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, need, cnt_o, L.pt_cnt, iota, L.perm, N, 0, bits_n, st));
+        cub_bytes = std::max(cub_bytes, need);
+        HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, need, slots, L.slice_base, L.n_slices + 1, st));
+        cub_bytes = std::max(cub_bytes, need);
+        HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, need, hits, L.hit_ofs, N + 1, st));
+        cub_bytes = std::max(cub_bytes, need);
+        int *io_cam = nullptr, *io_pos = nullptr, *io_pt = nullptr, *io_iota = nullptr, *cm_key = nullptr, *cm_io = nullptr;
+        TMP(io_cam, Kz); TMP(io_pos, Kz); TMP(io_pt, Kz); TMP(io_iota, Kz); TMP(cm_key, Kz); TMP(cm_io, Kz);
+        int bits_m = 1;
+        while ((1ll << bits_m) < M) ++bits_m;
+        HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, need, io_cam, cm_key, io_iota, cm_io, (int)K, 0, bits_m, st));
+        cub_bytes = std::max(cub_bytes, need);
+        char* cub = nullptr;
+        TMP(cub, cub_bytes + 16);
+        need = cub_bytes;
+        if (N) HIP_TRY(hipcub::DeviceRadixSort::SortPairs(cub, need, cnt_o, L.pt_cnt, iota, L.perm, N, 0, bits_n, st));
+        HIP_TRY(hipMemsetAsync(slots, 0, sizeof(int) * (L.n_slices + 1), st));
+        HIP_TRY(hipMemsetAsync(hits, 0, sizeof(long long) * (Nz + 1), st));
+        if (N) hipLaunchKernelGGL(k_lay_rank, dim3((N + 255) / 256), dim3(256), 0, st, N, L.perm, L.pt_cnt, L.rank, slots, hits);
+        need = cub_bytes;
+        HIP_TRY(hipcub::DeviceScan::ExclusiveSum(cub, need, slots, L.slice_base, L.n_slices + 1, st));
+        need = cub_bytes;
+        HIP_TRY(hipcub::DeviceScan::ExclusiveSum(cub, need, hits, L.hit_ofs, N + 1, st));
+        // internal point-major CSR: exclusive sum of the sorted lengths (pt_cnt has N entries; one spare slot is read)
+        {
+            int* cnt_pad = nullptr;
+            TMP(cnt_pad, Nz + 1);
+            HIP_TRY(hipMemsetAsync(cnt_pad, 0, sizeof(int) * (Nz + 1), st));
+            if (N) HIP_TRY(hipMemcpyAsync(cnt_pad, L.pt_cnt, sizeof(int) * N, hipMemcpyDeviceToDevice, st));
+            need = cub_bytes;
+            HIP_TRY(hipcub::DeviceScan::ExclusiveSum(cub, need, cnt_pad, ipt_ofs, N + 1, st));
+        }
+        // sizes the host needs: padded ELL length, pair-list length, status
+        int h_flags[4] = {0, 0, 0, 0}, h_P = 0;
+        long long h_E = 0;
+        HIP_TRY(hipMemcpyAsync(h_flags, flags, sizeof(int) * 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(&h_P, L.slice_base + L.n_slices, sizeof(int), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(&h_E, L.hit_ofs + N, sizeof(long long), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        switch (h_flags[0]) {
+            case LAY_OK: break;
+            case LAY_E_CAM: return fail(SATBA_E_ARG, "cam_ind out of range [0, %d)", M);
+            case LAY_E_PT: return fail(SATBA_E_ARG, "pts_ind out of range [0, %d)", N);
+            case LAY_E_ORDER: return fail(SATBA_E_ARG, "pts_ind must be non-decreasing (point-major order)");
+            default: return fail(SATBA_E_ARG, "cameras must ascend strictly inside a point (ba_params.py:142-147 order)");
+        }
+        p->unit_weights = h_flags[1] ? 0 : 1;
+        L.P = h_P; L.E = h_E;
+        if ((long long)L.P >= (1ll << 31) - 128 || L.E >= (1ll << 31)) return fail(SATBA_E_ARG, "observation or pair lists exceed 2^31 entries per shard");
+        p->create_ms[1] = ms_since(t0);
+        // sliced ELL
+        const size_t Pz = (size_t)std::max(L.P, 1);
+        TRY(dev_alloc(p, &L.e_cam, Pz + 64)); TRY(dev_alloc(p, &L.e_obs, Pz + 64)); TRY(dev_alloc(p, &L.e_w, Pz + 64));
+        HIP_TRY(hipMemsetAsync(L.e_cam, 0xFF, sizeof(int) * (Pz + 64), st));
+        HIP_TRY(hipMemsetAsync(L.e_obs, 0, sizeof(double2) * (Pz + 64), st));
+        HIP_TRY(hipMemsetAsync(L.e_w, 0, sizeof(double) * (Pz + 64), st));
+        if (K) {
+            hipLaunchKernelGGL(k_lay_fill_ell, dim3(grid_for(K, 256, 8192)), dim3(256), 0, st, K, o_cam, L.pts_ind, o_obs, o_w, o_ofs, L.rank,
+                               L.slice_base, ipt_ofs, L.e_cam, L.e_obs, L.e_w, L.obs_pos, io_cam, io_pos, io_pt);
+            // camera-major lists: stable sort of the internal point-major list by camera
+            hipLaunchKernelGGL(k_lay_iota, dim3(grid_for(K, 256, 4096)), dim3(256), 0, st, K, io_iota);
+            need = cub_bytes;
+            HIP_TRY(hipcub::DeviceRadixSort::SortPairs(cub, need, io_cam, cm_key, io_iota, cm_io, (int)K, 0, bits_m, st));
+            hipLaunchKernelGGL(k_lay_gather2, dim3(grid_for(K, 256, 8192)), dim3(256), 0, st, K, cm_io, io_pos, io_pt, L.cm_pos, L.cm_pt);
+        }
+        hipLaunchKernelGGL((k_lay_offsets<int>), dim3(grid_for(K + 1, 256, 4096)), dim3(256), 0, st, K, M, cm_key, L.cam_ofs);
+        HIP_TRY(hipGetLastError());
+        p->create_ms[2] = ms_since(t0);
+        // pair lists
+        {
+            // point-range chunks: 32 MB windows of the 128-byte point records and >= 256 entries per (pair, chunk) item on
+            // average are the measured optimum between gather locality and the fixed cost per item at 200 x 1M x 10M; few
+            // cameras: enough items to fill the chip (>= 8192 waves), at least 64 entries each
+            int C = 1;
+            if (L.n_pairs > 0 && L.E > 0) {
+                C = (int)std::max<long long>(1, ((long long)N * 8 * PV_STRIDE + (32ll << 20) - 1) / (32ll << 20));
+                C = (int)std::max<long long>(1, std::min<long long>(C, L.E / L.n_pairs / 256));
+                C = (int)std::max<long long>(C, std::min<long long>((8192 + L.n_pairs - 1) / L.n_pairs, std::max<long long>(1, L.E / L.n_pairs / 64)));
+                if (const char* cs = getenv("SATBA_SCHUR_CHUNKS")) C = std::max(1, atoi(cs));
+                C = std::min(C, 64);
+                C = std::min(C, std::max(N, 1));
+                while (C > 1 && L.n_pairs * (long long)(C + 1) > (1ll << 27)) --C;
+            }
+            L.C = C;
+            const size_t n_ofs = (size_t)std::max<long long>(L.n_pairs, 1) * (C + 1) + 1;
+            TRY(dev_alloc(p, &L.pair_ofs, n_ofs)); TRY(dev_alloc(p, &L.pair_ij, (size_t)std::max<long long>(L.n_pairs, 1)));
+            const size_t Ez = (size_t)std::max<long long>(L.E, 1);
+            TRY(dev_alloc(p, &L.pair_pts, Ez)); TRY(dev_alloc(p, &L.pair_pi, Ez)); TRY(dev_alloc(p, &L.pair_pj, Ez));
+            if (M > 1) hipLaunchKernelGGL(k_lay_pair_ij, dim3(M - 1), dim3(64), 0, st, M, L.pair_ij);
+            if (L.E > 0) {
+                int *hk = nullptr, *hq = nullptr, *hpi = nullptr, *hpj = nullptr, *hi = nullptr, *hk_s = nullptr, *hi_s = nullptr;
+                TMP(hk, Ez); TMP(hq, Ez); TMP(hpi, Ez); TMP(hpj, Ez); TMP(hi, Ez); TMP(hk_s, Ez); TMP(hi_s, Ez);
+                hipLaunchKernelGGL(k_lay_hits, dim3((N + 255) / 256), dim3(256), 0, st, N, M, L.pt_cnt, L.slice_base, L.e_cam, L.hit_ofs, hk, hq, hpi, hpj);
+                hipLaunchKernelGGL(k_lay_iota, dim3(grid_for(L.E, 256, 8192)), dim3(256), 0, st, L.E, hi);
+                int bits_p = 1;
+                while ((1ll << bits_p) < L.n_pairs) ++bits_p;
+                size_t need2 = 0;
+                HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, need2, hk, hk_s, hi, hi_s, (int)L.E, 0, bits_p, st));
+                char* cub2 = nullptr;
+                TMP(cub2, need2 + 16);
+                HIP_TRY(hipcub::DeviceRadixSort::SortPairs(cub2, need2, hk, hk_s, hi, hi_s, (int)L.E, 0, bits_p, st));  // stable: points stay ascending
+                hipLaunchKernelGGL(k_lay_gather3, dim3(grid_for(L.E, 256, 8192)), dim3(256), 0, st, L.E, hi_s, hq, hpi, hpj, L.pair_pts, L.pair_pi, L.pair_pj);
+                hipLaunchKernelGGL(k_lay_offsets_pair, dim3(grid_for(L.E + 1, 256, 8192)), dim3(256), 0, st, L.E, (long long)(n_ofs - 1), hk_s, L.pair_pts,
+                                   std::max(N, 1), C, L.pair_ofs);
+            } else {
+                HIP_TRY(hipMemsetAsync(L.pair_ofs, 0, sizeof(long long) * n_ofs, st));
+            }
+            HIP_TRY(hipGetLastError());
+        }
+        HIP_TRY(hipStreamSynchronize(st));
+        p->create_ms[3] = ms_since(t0);
+        return 0;
+    }();
+#undef TMP
+    free_tmp();
+    return rc;
 }
 
 extern "C" {
 
 const char* satba_last_error(void) { return g_err.c_str(); }
-int satba_version(void) { return 1; }
+int satba_version(void) { return 2; }
 
 int satba_problem_create(const satba_problem_desc* d, satba_problem** out) {
     if (!d || !out) return fail(SATBA_E_ARG, "null argument");
@@ -463,51 +567,8 @@ int satba_problem_create(const satba_problem_desc* d, satba_problem** out) {
     if (d->n_cam_fix < 0 || d->n_cam_fix > d->n_cam || d->n_pts_fix < 0 || d->n_pts_fix > d->n_pts)
         return fail(SATBA_E_ARG, "n_cam_fix / n_pts_fix out of range");
     if (d->world < 1 || d->rank < 0 || d->rank >= d->world) return fail(SATBA_E_ARG, "bad rank / world");
-    // validate indices, build wave tiles (whole points, <= 64 observations)
     const long long K = d->n_obs;
-    std::vector<int> tile_start;
-    std::vector<unsigned char> tile_split;
-    std::vector<int> split_pts, split_o0, split_o1;
-    tile_start.push_back(0);
-    {
-        long long o = 0;
-        int fill = 0;  // observations in the open tile
-        while (o < K) {
-            const int pt = d->pts_ind[o];
-            if (pt < 0 || pt >= d->n_pts) return fail(SATBA_E_ARG, "pts_ind[%lld] = %d out of range", o, pt);
-            long long e = o;
-            while (e < K && d->pts_ind[e] == pt) {
-                const int c = d->cam_ind[e];
-                if (c < 0 || c >= d->n_cam) return fail(SATBA_E_ARG, "cam_ind[%lld] = %d out of range", e, c);
-                ++e;
-            }
-            if (e < K && d->pts_ind[e] < pt) return fail(SATBA_E_ARG, "pts_ind must be non-decreasing (point-major order)");
-            const long long k = e - o;
-            if (k > 64) {
-                if (fill > 0) { tile_start.push_back((int)o); tile_split.push_back(0); fill = 0; }
-                for (long long s = o; s < e; s += 64) {
-                    tile_start.push_back((int)std::min(e, s + 64));
-                    tile_split.push_back(1);
-                }
-                split_pts.push_back(pt); split_o0.push_back((int)o); split_o1.push_back((int)e);
-            } else {
-                if (fill + k > 64) { tile_start.push_back((int)o); tile_split.push_back(0); fill = 0; }
-                fill += (int)k;
-            }
-            o = e;
-        }
-        if (fill > 0) { tile_start.push_back((int)K); tile_split.push_back(0); }
-    }
-
-    // camera-major observation lists and point CSR offsets (Schur panel kernel)
-    std::vector<int> cam_ofs(d->n_cam + 1, 0), cam_obs(K), pt_ofs(d->n_pts + 1, 0);
-    for (long long o = 0; o < K; ++o) { ++cam_ofs[d->cam_ind[o] + 1]; ++pt_ofs[d->pts_ind[o] + 1]; }
-    for (int c = 0; c < d->n_cam; ++c) cam_ofs[c + 1] += cam_ofs[c];
-    for (int q = 0; q < d->n_pts; ++q) pt_ofs[q + 1] += pt_ofs[q];
-    {
-        std::vector<int> fill(cam_ofs.begin(), cam_ofs.end() - 1);
-        for (long long o = 0; o < K; ++o) cam_obs[fill[d->cam_ind[o]]++] = (int)o;
-    }
+    auto t_create = std::chrono::steady_clock::now();
 
     satba_problem* p = new (std::nothrow) satba_problem();
     if (!p) return fail(SATBA_E_ARG, "out of host memory");
@@ -517,250 +578,59 @@ int satba_problem_create(const satba_problem_desc* d, satba_problem** out) {
     p->n_c = p->M * p->NP; p->n = p->n_c + 3 * p->N;
     p->hdr = SATBA_HDR_FIXED + p->world + (p->world & 1);
     p->lead = p->rank == 0 ? 1.0 : 0.0;
-    p->n_tiles = (int)tile_split.size();
-    p->n_split = (int)split_pts.size();
+    p->deterministic = ((d->flags & SATBA_FLAG_DETERMINISTIC) || getenv("SATBA_DETERMINISTIC")) ? 1 : 0;
 
     int rc = [&]() -> int {
         HIP_TRY(hipSetDevice(p->device));
-        p->camc_lds = (sizeof(double) * (size_t)p->M * CAMC <= 40 * 1024 && !getenv("SATBA_CAMC_GLOBAL")) ? 1 : 0;
-        p->camc_bytes = p->camc_lds ? sizeof(double) * (size_t)p->M * CAMC : 0;
-        // the fused linearize kernel keeps a per-workgroup camera table in LDS; beyond ~700 cameras the two-pass
-        // variant (satba_linearize3.h), which has no such table, takes over
-        const bool lin1_fits = lin1_lds(p, false) <= 158 * 1024;
-        if (schur_lds(p) > 160 * 1024)
-            return fail(SATBA_E_ARG, "n_cam = %d exceeds the LDS budget of the Schur kernels of this build", p->M);
-        if (lin1_fits) {
-            SATBA_DISPATCH(p, TRY(raise_lds_limit(k_linearize<MODEL, NP, false, CL, true>, lin1_lds(p, false))));
-            SATBA_DISPATCH(p, TRY(raise_lds_limit(k_linearize<MODEL, NP, false, CL, true, false, MODEL != RPC>, lin1_lds(p, false))));
-            SATBA_DISPATCH(p, TRY(raise_lds_limit(k_linearize<MODEL, NP, false, CL, false, false, MODEL != RPC>, lin1_lds(p, false))));
-            SATBA_DISPATCH(p, TRY(raise_lds_limit(k_linearize<MODEL, NP, true, CL, true>, lin1_lds(p, true))));
-            SATBA_DISPATCH(p, TRY(raise_lds_limit(k_linearize<MODEL, NP, false, CL, false>, lin1_lds(p, false))));
-            SATBA_DISPATCH(p, TRY(raise_lds_limit(k_linearize<MODEL, NP, true, CL, false>, lin1_lds(p, true))));
-        }
-        SATBA_DISPATCH(p, TRY(raise_lds_limit(k_schur<MODEL, NP>, schur_lds(p))));
-        if (p->model == AFFINE) SATBA_DISPATCH(p, TRY(raise_lds_limit(k_backsub<MODEL, NP, CL>, sizeof(double) * (size_t)p->M * BS_ROW)));
-        {   // Schur panel configuration: T cameras per panel so that panel (+ camera table) fit the 160 KB LDS
-            const size_t budget = 160 * 1024 - 1024;  // static LDS of the kernel and alignment slack
-            const size_t col_bytes = sizeof(double) * ((size_t)p->NP * p->n_c + p->NP);  // per camera of the tile
-            const size_t camc_bytes = sizeof(double) * (size_t)p->M * CAMC;
-            int T = 0;
-            const int camc_lds = p->camc_lds;
-            const size_t table = camc_lds ? camc_bytes : 0;
-            if (table + col_bytes <= budget) T = (int)((budget - table) / col_bytes);
-            if (T > SCHUR_MAX_T) T = SCHUR_MAX_T;
-            if (T > p->M) T = p->M;
-            if (getenv("SATBA_SCHUR_V1")) T = 0;
-            p->sch_T = T;
-            if (T > 0) {
-                p->sch_camc_lds = camc_lds;
-                p->sch_ctiles = (p->M + T - 1) / T;
-                int chunks = (512 + p->sch_ctiles - 1) / p->sch_ctiles;  // ~2 workgroups' worth of work per CU
-                if (chunks > 16) chunks = 16;
-                if (chunks < 1) chunks = 1;
-                while (chunks > 1 && (size_t)chunks * p->n_c * p->n_c * sizeof(double) > ((size_t)1 << 30)) --chunks;
-                p->sch_chunks = chunks;
-                p->sch_lds = col_bytes * T + (camc_lds ? camc_bytes : 0);
-                SATBA_DISPATCH(p, TRY(raise_lds_limit(k_schur_panel<MODEL, NP, CL>, p->sch_lds)));
-                TRY(dev_alloc(p, &p->d_S_part, (size_t)chunks * p->n_c * p->n_c));
-                TRY(dev_alloc(p, &p->d_rhs_part, (size_t)chunks * p->n_c));
-            }
-        }
-        TRY(dev_alloc(p, &p->d_cam_ofs, cam_ofs.size())); TRY(dev_alloc(p, &p->d_cam_obs, cam_obs.size()));
-        TRY(dev_alloc(p, &p->d_pt_ofs, pt_ofs.size()));
-        TRY(dev_alloc(p, &p->d_obs, K)); TRY(dev_alloc(p, &p->d_w, K)); TRY(dev_alloc(p, &p->d_cam, K)); TRY(dev_alloc(p, &p->d_pt, K));
-        TRY(dev_alloc(p, &p->d_f, K));
-        TRY(dev_alloc(p, &p->d_tile_start, tile_start.size())); TRY(dev_alloc(p, &p->d_tile_split, tile_split.size()));
-        TRY(dev_alloc(p, &p->d_split_pts, split_pts.size())); TRY(dev_alloc(p, &p->d_split_o0, split_pts.size()));
-        TRY(dev_alloc(p, &p->d_split_o1, split_pts.size()));
+        if (p->n_c > CH_NB * CH_MAX_STEPS) return fail(SATBA_E_ARG, "reduced camera system too large for the dense solver");
+        TRY(build_layout(p, d));
+        // LDS budget of the observation kernels: camera-sum table first, then the camera constants, then the RPC tables
+        const size_t budget = 150 * 1024;
+        const size_t acc_b = sizeof(double) * (size_t)p->M * cam_sum_stride(p->NP);
+        const size_t camc_b = sizeof(double) * (size_t)p->M * CAMC, rpc_b = sizeof(double) * (size_t)p->M * RPCS;
+        p->cam_sums_lds = (acc_b <= budget && !p->deterministic && !getenv("SATBA_CAM_SUMS")) ? 1 : 0;
+        size_t used = p->cam_sums_lds ? acc_b : 0;
+        p->camc_lds = (camc_b <= 48 * 1024 && used + camc_b <= budget && !getenv("SATBA_CAMC_GLOBAL")) ? 1 : 0;
+        used += p->camc_lds ? camc_b : 0;
+        p->rpc_lds = (p->model == RPC && rpc_b <= 64 * 1024 && used + rpc_b <= budget && !getenv("SATBA_RPC_GLOBAL")) ? 1 : 0;
+        if (dir_table_bytes(p) > budget) return fail(SATBA_E_ARG, "n_cam = %d exceeds the LDS budget of the per-camera tables", p->M);
+        SATBA_DISPATCH(p, TRY((raise_lin_limits<MODEL, NP, CL, RL>(p))));
+
+        const size_t n = p->n, Pz = (size_t)std::max(p->L.P, 1) + 64;
         TRY(dev_alloc(p, &p->d_cam_static, (size_t)p->M * p->c_p));
         if (p->model == RPC) TRY(dev_alloc(p, &p->d_rpc, (size_t)p->M * SATBA_RPC_TABLE_LEN));
-        const size_t n = p->n;
         TRY(dev_alloc(p, &p->d_x, n)); TRY(dev_alloc(p, &p->d_xnew, n)); TRY(dev_alloc(p, &p->d_scale_inv, n));
         TRY(dev_alloc(p, &p->d_g, n)); TRY(dev_alloc(p, &p->d_gh, n)); TRY(dev_alloc(p, &p->d_gn, n));
         TRY(dev_alloc(p, &p->d_q1, n)); TRY(dev_alloc(p, &p->d_wv, n));
         TRY(dev_alloc(p, &p->d_camc, (size_t)p->M * CAMC)); TRY(dev_alloc(p, &p->d_camc_new, (size_t)p->M * CAMC));
         TRY(dev_alloc(p, &p->d_U, (size_t)p->M * p->NP * p->NP)); TRY(dev_alloc(p, &p->d_gc, p->n_c));
         TRY(dev_alloc(p, &p->d_V, (size_t)6 * p->N)); TRY(dev_alloc(p, &p->d_Vinv, (size_t)6 * p->N));
-        TRY(dev_alloc(p, &p->d_tbuf, (size_t)3 * p->N)); TRY(dev_alloc(p, &p->d_dc, p->n_c));
+        TRY(dev_alloc(p, &p->d_PV, (size_t)PV_STRIDE * std::max(p->N, 1)));
+        TRY(dev_alloc(p, &p->d_dc, p->n_c)); TRY(dev_alloc(p, &p->d_dch, p->n_c));
+        TRY(dev_alloc(p, &p->d_f, Pz)); TRY(dev_alloc(p, &p->d_sc, Pz));
+        if (p->model == RPC) TRY(dev_alloc(p, &p->d_Jpm, Pz * (2 * p->NP + 6)));
         TRY(dev_alloc(p, &p->d_fail, 1 + CH_MAX_STEPS));  // [0] not-SPD flag, then the panel-step flags
-        if (p->n_c > CH_NB * CH_MAX_STEPS) return fail(SATBA_E_ARG, "reduced camera system too large for the dense solver");
         { const char* cs = getenv("SATBA_CHOL"); p->chol_mode = cs ? atoi(cs) : 0; }
-        TRY(dev_alloc(p, &p->d_dch, p->n_c));
-        if (getenv("SATBA_CHOL_DAG")) {  // experimental dataflow Cholesky (satba_chol_dag.h): correct, but slower
-                                         // than the blocked multi-launch version on MI355X
-            std::vector<DagTask> tasks = dag_task_list(p->n_c);
-            p->dag.NT = (p->n_c + DG_T - 1) / DG_T;
-            p->dag.n_tasks = (int)tasks.size();
-            p->dag.flag_ints = dag_flag_ints(p->dag.NT);
-            TRY(dev_alloc(p, &p->dag.d_tasks, tasks.size()));
-            TRY(dev_alloc(p, &p->dag.d_flags, p->dag.flag_ints));
-            HIP_TRY(hipMemcpy(p->dag.d_tasks, tasks.data(), sizeof(DagTask) * tasks.size(), hipMemcpyHostToDevice));
-            if (getenv("SATBA_DAG_TIMES")) TRY(dev_alloc(p, &p->dag.d_times, 4 * tasks.size()));
-        }
-        TRY(dev_alloc(p, &p->d_sc, (size_t)std::max<long long>(K, 1)));  // row scales of weighted / robust runs
-        if (p->model == RPC && !getenv("SATBA_RPC_RECOMPUTE")) TRY(dev_alloc(p, &p->d_Jpm, (size_t)std::max<long long>(K, 1) * (2 * p->NP + 6)));
         TRY(dev_alloc(p, &p->d_scal, 8));
         TRY(dev_alloc(p, &p->d_keep, SATBA_KEEP_LEN));
         HIP_TRY(hipMemset(p->d_keep, 0, sizeof(double) * SATBA_KEEP_LEN));
-        p->lin_grid = grid_for(p->n_tiles, 16, lin1_lds(p, false) <= 78 * 1024 ? 512 : 256);
-        TRY(dev_alloc(p, &p->d_part, (size_t)p->lin_grid * p->M * cam_acc_len(p->NP)));
-        {   // camera-major copy of the observation data (Schur v3, linearize v3) and chunking of the camera passes
-            const char* sel = getenv("SATBA_LIN");
-            const int which = (sel ? atoi(sel) : 1) + (lin1_fits ? 0 : 2);
+        TRY(dev_alloc(p, &p->d_red, (size_t)RED_SLOTS * RED_MAX_NV * RED_MAX_GRID));
+        TRY(dev_alloc(p, &p->d_red_cnt, RED_SLOTS));
+        HIP_TRY(hipMemset(p->d_red_cnt, 0, sizeof(unsigned) * RED_SLOTS));
+        // one workgroup per CU for the linearize kernel (its LDS table is flushed once per workgroup)
+        p->lin_grid = slice_grid(p, LinCfg<false>::WAVES, 256);
+        TRY(dev_alloc(p, &p->d_part, (size_t)512 * p->M * 2 * p->NP));
+        {   // chunking of the camera-major passes (k_schur_diag, k_cam_sums)
             int chunks = (2048 + p->M - 1) / p->M;
             if (chunks > 64) chunks = 64;
             while (chunks > 1 && K / ((long long)p->M * chunks) < 512) --chunks;  // keep >= ~2 obs per thread
             if (const char* dc = getenv("SATBA_CM_CHUNKS")) chunks = std::max(1, std::min(256, atoi(dc)));  // experiments
-            TRY(dev_alloc(p, &p->d_cm_obs, K)); TRY(dev_alloc(p, &p->d_cm_w, K)); TRY(dev_alloc(p, &p->d_cm_pt, K));
+            p->cm_chunks = chunks;
             TRY(dev_alloc(p, &p->d_part3, (size_t)p->M * chunks * cam_acc_len(p->NP)));
-            std::vector<double> tmp(2 * (size_t)K + 1);
-            for (long long i = 0; i < K; ++i) { tmp[2 * i] = d->pts2d[2 * (size_t)cam_obs[i]]; tmp[2 * i + 1] = d->pts2d[2 * (size_t)cam_obs[i] + 1]; }
-            HIP_TRY(hipMemcpy(p->d_cm_obs, tmp.data(), sizeof(double) * 2 * K, hipMemcpyHostToDevice));
-            for (long long i = 0; i < K; ++i) tmp[i] = d->weights[cam_obs[i]];
-            HIP_TRY(hipMemcpy(p->d_cm_w, tmp.data(), sizeof(double) * K, hipMemcpyHostToDevice));
-            std::vector<int> tmpi(K + 1);
-            for (long long i = 0; i < K; ++i) tmpi[i] = d->pts_ind[cam_obs[i]];
-            HIP_TRY(hipMemcpy(p->d_cm_pt, tmpi.data(), sizeof(int) * K, hipMemcpyHostToDevice));
-            p->lin3_chunks = chunks;  // chunk count of the camera-major passes (also used by k_schur_diag)
-            p->lin3_grid = (which >= 3 && K > 0) ? grid_for(p->N, 256, 256 * 4) : 0;
-
-            // Schur v3: visibility bitmaps and ranks.  Scan cost grows with M^2 N / 64: beyond 512 cameras the
-            // panel kernel (v2) is used instead.  SATBA_SCHUR=1|2 forces the older variants.
-            const char* ssel = getenv("SATBA_SCHUR");
-            const int swhich = ssel ? atoi(ssel) : 3;
-            if (swhich >= 3 && p->M <= 512 && K > 0) {
-                const int NW = (p->N + 63) / 64;
-                p->NW = NW;
-                std::vector<unsigned long long> bits((size_t)p->M * NW, 0ull);
-                for (long long o = 0; o < K; ++o)
-                    bits[(size_t)d->cam_ind[o] * NW + (d->pts_ind[o] >> 6)] |= 1ull << (d->pts_ind[o] & 63);
-                std::vector<int> rank((size_t)p->M * NW);
-                for (int cc = 0; cc < p->M; ++cc) {
-                    int run = 0;
-                    for (int w = 0; w < NW; ++w) { rank[(size_t)cc * NW + w] = run; run += __builtin_popcountll(bits[(size_t)cc * NW + w]); }
-                }
-                TRY(dev_alloc(p, &p->d_bits, bits.size())); TRY(dev_alloc(p, &p->d_rank, rank.size()));
-                TRY(dev_alloc(p, &p->d_PV, (size_t)PV_STRIDE * p->N));
-                p->unit_weights = 1;
-                for (long long o = 0; o < K; ++o) if (d->weights[o] != 1.0) { p->unit_weights = 0; break; }
-                HIP_TRY(hipMemcpy(p->d_bits, bits.data(), sizeof(unsigned long long) * bits.size(), hipMemcpyHostToDevice));
-                HIP_TRY(hipMemcpy(p->d_rank, rank.data(), sizeof(int) * rank.size(), hipMemcpyHostToDevice));
-                const long long n_pairs = (long long)p->M * (p->M - 1) / 2;
-                int sc = 1;
-                if (n_pairs > 0) {
-                    sc = (int)std::min<long long>((8192 + n_pairs - 1) / n_pairs, (NW + 63) / 64);
-                    if (sc < 1) sc = 1;
-                }
-                p->sch3_chunks = sc;
-                // shared-point lists per camera pair (static structure; 4 B per pair entry, e.g. 200 MB at 200 x 1M x 10M),
-                // cut into point-range chunks sized so that one chunk's packed point records (96 B each) stay in L2
-                if (n_pairs > 0 && !getenv("SATBA_SCHUR_BITMAP")) {
-                    // measured on 200 x 1M x 10M: 12 MB windows (8 chunks) are the optimum between gather locality and
-                    // the fixed cost per (pair, chunk) work item; fewer chunks when the lists are short
-                    long long n_hits = 0;
-                    for (int q = 0; q < p->N; ++q) { const long long dq = pt_ofs[q + 1] - pt_ofs[q]; n_hits += dq * (dq - 1) / 2; }
-                    // Coarse chunks (one wave per (pair, chunk) item kernel): 12 MB windows and >= 256 hits per item are
-                    // the measured optimum between gather locality and the fixed cost per item.  Fine chunks (lane-group
-                    // kernels, which walk all chunks inside one wave): 3 MB windows stay in the 4 MB L2 of every XCD.
-                    // The lists are cut into the fine chunks; the item kernel takes them chunk_mul at a time.
-                    const char* st = getenv("SATBA_SCHUR_STREAM");
-                    const bool stream = st && atoi(st) == 1;
-                    // 32 MB windows of the 128-byte point records (with line-aligned records the optimum moved from 8 chunks to
-                    // 3..5 at 200 x 1M: 0.835 -> 0.789 ms for the Schur phase)
-                    int Cc = (int)std::max<long long>(1, ((long long)p->N * 8 * PV_STRIDE + (32ll << 20) - 1) / (32ll << 20));
-                    Cc = (int)std::max<long long>(1, std::min<long long>(Cc, n_hits / n_pairs / 256));
-                    // few cameras: enough (pair, chunk) items to fill the chip (>= 8192 waves), at least 64 hits each
-                    Cc = (int)std::max<long long>(Cc, std::min<long long>((8192 + n_pairs - 1) / n_pairs, std::max<long long>(1, n_hits / n_pairs / 64)));
-                    if (const char* cs = getenv("SATBA_SCHUR_CHUNKS")) Cc = std::max(1, atoi(cs));
-                    Cc = std::min(Cc, S3_MAXC);
-                    while (Cc > 1 && n_pairs * (long long)(Cc + 1) > (1ll << 27)) --Cc;
-                    const char* mo = getenv("SATBA_SCHUR_MOMENTS");
-                    const bool moments = p->model == AFFINE && p->unit_weights && mo && atoi(mo) == 1;  // experiment
-                    int mul = 1;
-                    if (stream || moments) {
-                        long long Cf = std::max<long long>(1, ((long long)p->N * 96 + (3ll << 20) - 1) / (3ll << 20));
-                        Cf = std::max<long long>(1, std::min<long long>(Cf, n_hits / n_pairs / 24));
-                        if (const char* cs = getenv("SATBA_SCHUR_FINE")) Cf = std::max(1, atoi(cs));
-                        mul = (int)std::max<long long>(1, std::min<long long>(Cf, S3_MAXC) / Cc);
-                        while (mul > 1 && n_pairs * (long long)(Cc * mul + 1) > (1ll << 27)) --mul;
-                    }
-                    p->sch3_chunk_mul = mul;
-                    const int C = Cc * mul;  // chunks the lists are cut into
-                    const long long M_ = p->M;
-                    auto pair_index = [M_](long long a, long long b) { return a * M_ - a * (a + 1) / 2 + (b - a - 1); };
-                    auto chunk_of = [&](int q) { return (int)((long long)q * C / std::max(p->N, 1)); };
-                    // counts per (pair, chunk), then offsets in (pair-major, chunk) order == the order of the lists
-                    std::vector<long long> ofs((size_t)n_pairs * (C + 1) + 1, 0);
-                    for (int q = 0; q < p->N; ++q) {
-                        const int ch = chunk_of(q);
-                        for (int x0 = pt_ofs[q]; x0 < pt_ofs[q + 1]; ++x0)
-                            for (int x1 = x0 + 1; x1 < pt_ofs[q + 1]; ++x1)
-                                ++ofs[pair_index(d->cam_ind[x0], d->cam_ind[x1]) * (C + 1) + ch + 1];
-                    }
-                    // ofs[pair*(C+1) + ch + 1] holds count(pair, ch); turn into running offsets, entry [pair*(C+1)] = start
-                    long long run = 0;
-                    for (long long pr = 0; pr < n_pairs; ++pr) {
-                        ofs[pr * (C + 1)] = run;
-                        for (int ch = 0; ch < C; ++ch) { run += ofs[pr * (C + 1) + ch + 1]; ofs[pr * (C + 1) + ch + 1] = run; }
-                    }
-                    const long long E = run;
-                    if (E > 0 && E < (1ll << 31) && E * 4 < (8ll << 30)) {
-                        // per entry: the point and the indices of its two observations (the weighted / robust and the RPC pair
-                        // kernels fetch per-observation data there; 12 B per entry, 540 MB at 200 x 1M x 10M)
-                        const bool with_pos = !getenv("SATBA_SCHUR_NO_POS") && E * 12 < (24ll << 30);
-                        std::vector<int> pts(E), ppi(with_pos ? E : 0), ppj(with_pos ? E : 0);
-                        std::vector<long long> fill((size_t)n_pairs);
-                        for (long long pr = 0; pr < n_pairs; ++pr) fill[pr] = ofs[pr * (C + 1)];
-                        for (int q = 0; q < p->N; ++q)  // ascending q: each pair's list comes out sorted, chunks contiguous
-                            for (int x0 = pt_ofs[q]; x0 < pt_ofs[q + 1]; ++x0)
-                                for (int x1 = x0 + 1; x1 < pt_ofs[q + 1]; ++x1) {
-                                    const long long at = fill[pair_index(d->cam_ind[x0], d->cam_ind[x1])]++;
-                                    pts[at] = q;
-                                    if (with_pos) { ppi[at] = x0; ppj[at] = x1; }
-                                }
-                        {   // pair index -> (i, j) table (the kernels used to unrank it with a square root and two loops)
-                            std::vector<int2> ij((size_t)n_pairs);
-                            size_t at = 0;
-                            for (int ci = 0; ci < p->M; ++ci)
-                                for (int cj = ci + 1; cj < p->M; ++cj) ij[at++] = make_int2(ci, cj);
-                            TRY(dev_alloc(p, &p->d_pair_ij, ij.size()));
-                            HIP_TRY(hipMemcpy(p->d_pair_ij, ij.data(), sizeof(int2) * ij.size(), hipMemcpyHostToDevice));
-                        }
-                        TRY(dev_alloc(p, &p->d_pair_ofs, ofs.size())); TRY(dev_alloc(p, &p->d_pair_pts, pts.size()));
-                        HIP_TRY(hipMemcpy(p->d_pair_ofs, ofs.data(), sizeof(long long) * ofs.size(), hipMemcpyHostToDevice));
-                        HIP_TRY(hipMemcpy(p->d_pair_pts, pts.data(), sizeof(int) * pts.size(), hipMemcpyHostToDevice));
-                        if (with_pos) {
-                            TRY(dev_alloc(p, &p->d_pair_pi, ppi.size())); TRY(dev_alloc(p, &p->d_pair_pj, ppj.size()));
-                            HIP_TRY(hipMemcpy(p->d_pair_pi, ppi.data(), sizeof(int) * ppi.size(), hipMemcpyHostToDevice));
-                            HIP_TRY(hipMemcpy(p->d_pair_pj, ppj.data(), sizeof(int) * ppj.size(), hipMemcpyHostToDevice));
-                        }
-                        p->sch3_chunks = Cc;
-                        if (stream || moments) {  // groups of pairs (i, j0 ..) of one camera i: 8 (10 with six lanes per pair)
-                            std::vector<int> groups;
-                            const char* gp = getenv("SATBA_SCHUR_GROUP");
-                            const int PW = (moments && !stream) || (gp && atoi(gp) == 10 && p->unit_weights) ? 10 : 8;
-                            p->sch3_group_pairs = PW;
-                            for (int ci = 0; ci + 1 < p->M; ++ci)
-                                for (int cj = ci + 1; cj < p->M; cj += PW) {
-                                    groups.push_back(ci); groups.push_back(cj); groups.push_back(std::min(PW, p->M - cj));
-                                }
-                            TRY(dev_alloc(p, &p->d_groups, groups.size()));
-                            HIP_TRY(hipMemcpy(p->d_groups, groups.data(), sizeof(int) * groups.size(), hipMemcpyHostToDevice));
-                            if (stream) p->sch3_groups = (int)(groups.size() / 3);
-                            if (moments && !stream) {
-                                p->sch3_moments = true;
-                                p->sch3_groups_m = (int)(groups.size() / 3);
-                                TRY(dev_alloc(p, &p->d_Tbuf, (size_t)n_pairs * S3_NT));
-                            }
-                        }
-                        if (Cc > 1 && !stream) TRY(dev_alloc(p, &p->d_pair_part, (size_t)Cc * n_pairs * p->NP * p->NP));
-                    }
-                }
-            }
-            if (swhich == 1) p->sch_T = 0;
-            // with Schur v3 and the fused linearize kernel, U_c's off-diagonal entries are formed in k_schur_diag
-            p->u_full = (p->sch3_chunks > 0 && p->lin3_grid == 0 && !getenv("SATBA_FULL_U")) ? 0 : 1;
         }
+        if (p->L.C > 1) TRY(dev_alloc(p, &p->d_pair_part, (size_t)p->L.C * std::max<long long>(p->L.n_pairs, 1) * p->NP * p->NP));
+        p->stage_len = std::max<size_t>(std::max<size_t>(n, 2 * (size_t)K), (size_t)6 * p->N) + 16;
+        TRY(dev_alloc(p, &p->d_stage, p->stage_len));
         p->xb_len = satba_exchange_len(p);
         TRY(dev_alloc(p, &p->d_xb_own, p->xb_len));
         p->d_xb = p->d_xb_own;
@@ -769,22 +639,6 @@ int satba_problem_create(const satba_problem_desc* d, satba_problem** out) {
         HIP_TRY(hipMemset(p->d_scale_inv, 0, sizeof(double) * n));
         HIP_TRY(hipMemset(p->d_x, 0, sizeof(double) * n));
         HIP_TRY(hipMemset(p->d_xnew, 0, sizeof(double) * n));
-        // uploads (synchronous: the caller's arrays may go away after this call)
-        HIP_TRY(hipMemcpy(p->d_obs, d->pts2d, sizeof(double) * 2 * K, hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(p->d_w, d->weights, sizeof(double) * K, hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(p->d_cam, d->cam_ind, sizeof(int) * K, hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(p->d_pt, d->pts_ind, sizeof(int) * K, hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(p->d_cam_ofs, cam_ofs.data(), sizeof(int) * cam_ofs.size(), hipMemcpyHostToDevice));
-        if (K) HIP_TRY(hipMemcpy(p->d_cam_obs, cam_obs.data(), sizeof(int) * K, hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(p->d_pt_ofs, pt_ofs.data(), sizeof(int) * pt_ofs.size(), hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(p->d_tile_start, tile_start.data(), sizeof(int) * tile_start.size(), hipMemcpyHostToDevice));
-        if (!tile_split.empty())
-            HIP_TRY(hipMemcpy(p->d_tile_split, tile_split.data(), tile_split.size(), hipMemcpyHostToDevice));
-        if (p->n_split) {
-            HIP_TRY(hipMemcpy(p->d_split_pts, split_pts.data(), sizeof(int) * p->n_split, hipMemcpyHostToDevice));
-            HIP_TRY(hipMemcpy(p->d_split_o0, split_o0.data(), sizeof(int) * p->n_split, hipMemcpyHostToDevice));
-            HIP_TRY(hipMemcpy(p->d_split_o1, split_o1.data(), sizeof(int) * p->n_split, hipMemcpyHostToDevice));
-        }
         HIP_TRY(hipMemcpy(p->d_cam_static, d->cam_params, sizeof(double) * p->M * p->c_p, hipMemcpyHostToDevice));
         if (p->model == RPC)
             HIP_TRY(hipMemcpy(p->d_rpc, d->rpc_tables, sizeof(double) * p->M * SATBA_RPC_TABLE_LEN, hipMemcpyHostToDevice));
@@ -794,6 +648,7 @@ int satba_problem_create(const satba_problem_desc* d, satba_problem** out) {
         satba_problem_destroy(p);
         return rc;
     }
+    p->create_ms[4] = ms_since(t_create);
     *out = p;
     return 0;
 }
@@ -867,42 +722,72 @@ int satba_configure(satba_problem* p, int32_t loss, double f_scale) {
     if (!p) return fail(SATBA_E_ARG, "null handle");
     if (loss < 0 || loss > 4) return fail(SATBA_E_ARG, "unknown loss %d", loss);
     if (!(f_scale > 0.0)) return fail(SATBA_E_ARG, "f_scale must be positive");
+    if (loss != p->loss || f_scale != p->f_scale) { p->linearized = false; p->have_step = false; p->prepared = false; }
     p->loss = loss; p->f_scale = f_scale;
+    return 0;
+}
+
+// host vector in the caller's point order -> device vector in internal order (and back); dim doubles per point
+static int upload_permuted(satba_problem* p, const double* host, double* dev, int n_c, int dim) {
+    const size_t len = (size_t)n_c + (size_t)p->N * dim;
+    if (len > p->stage_len) return fail(SATBA_E_ARG, "staging buffer too small");
+    HIP_TRY(hipMemcpyAsync(p->d_stage, host, sizeof(double) * len, hipMemcpyHostToDevice, p->stream));
+    hipLaunchKernelGGL(k_permute_vec, dim3(grid_for((long long)len, 256, 2048)), dim3(256), 0, p->stream, n_c, p->N, dim, p->L.perm, p->d_stage, dev, 0);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    return 0;
+}
+static int download_permuted(satba_problem* p, const double* dev, double* host, int n_c, int dim) {
+    const size_t len = (size_t)n_c + (size_t)p->N * dim;
+    if (len > p->stage_len) return fail(SATBA_E_ARG, "staging buffer too small");
+    hipLaunchKernelGGL(k_permute_vec, dim3(grid_for((long long)len, 256, 2048)), dim3(256), 0, p->stream, n_c, p->N, dim, p->L.perm, dev, p->d_stage, 1);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(host, p->d_stage, sizeof(double) * len, hipMemcpyDeviceToHost, p->stream));
+    HIP_TRY(hipStreamSynchronize(p->stream));
     return 0;
 }
 
 int satba_set_x(satba_problem* p, const double* host_x) {
     if (!p || !host_x) return fail(SATBA_E_ARG, "null argument");
     HIP_TRY(hipSetDevice(p->device));
-    HIP_TRY(hipMemcpyAsync(p->d_x, host_x, sizeof(double) * p->n, hipMemcpyHostToDevice, p->stream));
-    HIP_TRY(hipStreamSynchronize(p->stream));
-    if (p->N > 0 && !p->c0_set) {  // expansion point of the Schur moments: any point of the scene (conditioning only)
-        const double* q = host_x + p->n_c + 3 * (size_t)(p->N / 2);
-        p->c0[0] = q[0]; p->c0[1] = q[1]; p->c0[2] = q[2];
-        p->c0_set = true;
-    }
+    TRY(upload_permuted(p, host_x, p->d_x, p->n_c, 3));
     TRY(launch_cam_consts(p, false));
-    p->linearized = false; p->have_step = false;
+    p->linearized = false; p->have_step = false; p->prepared = false;
     return 0;
 }
 
 int satba_get_x(satba_problem* p, double* host_x) {
     if (!p || !host_x) return fail(SATBA_E_ARG, "null argument");
-    HIP_TRY(hipMemcpyAsync(host_x, p->d_x, sizeof(double) * p->n, hipMemcpyDeviceToHost, p->stream));
-    HIP_TRY(hipStreamSynchronize(p->stream));
-    return 0;
+    HIP_TRY(hipSetDevice(p->device));
+    return download_permuted(p, p->d_x, host_x, p->n_c, 3);
 }
 
 int satba_residuals(satba_problem* p, double* host_r, double* host_cost) {
     if (!p) return fail(SATBA_E_ARG, "null handle");
     HIP_TRY(hipSetDevice(p->device));
-    // the cost goes through a private scalar so the exchange header of a running solve is left alone
+    // the cost goes through a private scalar so the exchange header of a running solve is left alone; the residual pairs
+    // go to the staging buffer (d_f holds the residuals of the current linearisation, which later phases read)
     double* slot = p->d_scal;
-    HIP_TRY(hipMemsetAsync(slot, 0, sizeof(double), p->stream));
-    TRY(launch_residual(p, false, p->d_f, slot));
-    HIP_TRY(hipMemcpyAsync(p->h_pin, slot, sizeof(double), hipMemcpyDeviceToHost, p->stream));
-    if (host_r) HIP_TRY(hipMemcpyAsync(host_r, p->d_f, sizeof(double) * 2 * p->K, hipMemcpyDeviceToHost, p->stream));
-    HIP_TRY(hipStreamSynchronize(p->stream));
+    double2* f_ell = reinterpret_cast<double2*>(p->d_stage);
+    const bool want = host_r != nullptr && p->K > 0;
+    // ELL-ordered scratch: behind the caller-ordered copy in the staging buffer would not fit; use d_sc when it is free
+    double2* scratch = nullptr;
+    if (want) {
+        HIP_TRY(hipMalloc((void**)&scratch, sizeof(double2) * ((size_t)p->L.P + 64)));
+    }
+    int rc = [&]() -> int {
+        TRY(launch_residual(p, false, want ? scratch : nullptr, slot));
+        HIP_TRY(hipMemcpyAsync(p->h_pin, slot, sizeof(double), hipMemcpyDeviceToHost, p->stream));
+        if (want) {
+            hipLaunchKernelGGL(k_gather_obs, dim3(grid_for(p->K, 256, 4096)), dim3(256), 0, p->stream, p->K, p->L.obs_pos, scratch, f_ell);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipMemcpyAsync(host_r, f_ell, sizeof(double) * 2 * p->K, hipMemcpyDeviceToHost, p->stream));
+        }
+        HIP_TRY(hipStreamSynchronize(p->stream));
+        return 0;
+    }();
+    if (scratch) (void)hipFree(scratch);
+    if (rc) return rc;
     if (host_cost) *host_cost = p->h_pin[0];
     return 0;
 }
@@ -910,32 +795,22 @@ int satba_residuals(satba_problem* p, double* host_r, double* host_cost) {
 int satba_linearize(satba_problem* p) {
     if (!p) return fail(SATBA_E_ARG, "null handle");
     HIP_TRY(hipSetDevice(p->device));
-    TRY(zero_header(p));
-    if (p->n_split) {
-        HIP_TRY(hipMemsetAsync(p->d_V, 0, sizeof(double) * 6 * p->N, p->stream));
-        HIP_TRY(hipMemsetAsync(p->d_g + p->n_c, 0, sizeof(double) * 3 * p->N, p->stream));
-    }
+    const size_t nU = (size_t)p->M * p->NP * p->NP;
+    HIP_TRY(hipMemsetAsync(p->d_xb, 0, sizeof(double) * (p->hdr + nU + p->n_c), p->stream));  // header, U (only its diagonal is written), g_c
     TRY(launch_linearize_kernel(p));
-    if (p->n_split) {
-        hipLaunchKernelGGL(k_gpmax, dim3(grid_for(3ll * p->N, 256, 1024)), dim3(256), 0, p->stream, p->N, p->d_g + p->n_c,
-                           p->d_xb + SATBA_HDR_FIXED + p->rank);
-        HIP_TRY(hipGetLastError());
-    }
     double* U = p->payload();
-    double* gc = U + (size_t)p->M * p->NP * p->NP;
-    const int total = p->M * cam_acc_len(p->NP);
-    if (p->lin3_grid > 0) {
-        hipLaunchKernelGGL(k_lin3_finish, dim3((total + 255) / 256), dim3(256), 0, p->stream, p->M, p->NP, p->lin3_chunks, p->d_part3, U, gc);
+    double* gc = U + nU;
+    if (p->cam_sums_lds) {
+        // unit weights + linear loss + affine R+T: the translation entries of diag(U_c) are (observation count) x constants
+        // and were not accumulated by the kernel (lin_const_t in satba_kernels.h)
+        const int const_t = lin_const_t(p->model, p->NP, p->loss != 0, p->loss == 0 && p->unit_weights) && lin_variant(p) == 0;
+        const int total = p->M * 2 * p->NP;
+        hipLaunchKernelGGL(k_lin_finish, dim3((total + 63) / 64), dim3(1024), 0, p->stream, p->M, p->NP, p->lin_grid, p->d_part, U, gc,
+                           p->L.cam_ofs, p->d_camc, p->n_cam_fix, const_t);
         HIP_TRY(hipGetLastError());
-        p->linearized = true; p->have_step = false;
-        return 0;
+    } else {
+        TRY(launch_cam_sums(p, U, gc));  // fixed summation order; fills the full blocks
     }
-    // unit weights + linear loss + affine R+T: the translation entries of diag(U_c) are (observation count) x constants
-    // and were not accumulated by the kernel (lin_const_t in satba_kernels.h)
-    const bool const_t = !p->u_full && lin_const_t(p->model, p->NP, p->loss != 0, p->loss == 0 && p->unit_weights);
-    hipLaunchKernelGGL(k_lin_finish, dim3((total + 63) / 64), dim3(1024), 0, p->stream, p->M, p->NP, lin_partials(p), p->d_part,
-                       nullptr, U, gc, const_t ? p->d_cam_ofs : nullptr, p->d_camc, p->n_cam_fix);
-    HIP_TRY(hipGetLastError());
     p->linearized = true; p->have_step = false;
     return 0;
 }
@@ -946,11 +821,11 @@ int satba_prepare(satba_problem* p, int32_t first) {
     HIP_TRY(hipSetDevice(p->device));
     const size_t nU = (size_t)p->M * p->NP * p->NP;
     if (p->hdr > 1024) return fail(SATBA_E_ARG, "header too long");
-    hipLaunchKernelGGL(k_prepare_stash, dim3(1), dim3(1024), 0, p->stream, (int)nU, p->n_c, p->world, (int)p->hdr, p->d_xb, p->d_U, p->d_gc,
-                       p->d_keep);
+    hipLaunchKernelGGL(k_prepare_stash, dim3(1), dim3(1024), 0, p->stream, (int)nU, p->n_c, p->world, SATBA_HDR_FIXED, (int)p->hdr, p->d_xb, p->d_U,
+                       p->d_gc, p->d_keep);
     HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(k_prepare_vec, dim3(grid_for(p->n, 256, 512)), dim3(256), 0, p->stream, p->n, p->n_c, p->NP, first,
-                       p->lead, p->d_U, p->d_gc, p->d_V, p->d_x, p->d_g, p->d_scale_inv, p->d_gh, p->d_q1, p->d_xb);
+                       p->lead, p->d_U, p->d_gc, p->d_V, p->d_x, p->d_g, p->d_scale_inv, p->d_gh, p->d_q1, p->red(RB_PREP), p->d_xb);
     HIP_TRY(hipGetLastError());
     TRY(launch_jvp(p, 1, p->d_q1, p->d_q1, p->d_xb + 2, true));  // d_q1 is free until the subspace phase
     p->prepared = true;
@@ -966,10 +841,10 @@ static int schur_impl(satba_problem* p, double lam, const double* lam_dev) {
         HIP_TRY(hipGetLastError());
     }
     double* S = p->payload();
-    hipLaunchKernelGGL(k_schur_init, dim3((p->M * p->NP * p->NP + 255) / 256), dim3(256), 0, p->stream, p->M, p->NP, lam, lam_dev,
-                       p->lead, p->u_full, p->d_U, p->d_gc, p->d_scale_inv, S, S + (size_t)p->n_c * p->n_c);
+    hipLaunchKernelGGL(k_schur_init, dim3((p->n_c + 255) / 256), dim3(256), 0, p->stream, p->M, p->NP, lam, lam_dev,
+                       p->lead, p->d_gc, p->d_scale_inv, S, S + (size_t)p->n_c * p->n_c);
     HIP_TRY(hipGetLastError());
-    if (p->K > 0) TRY(launch_schur_kernel(p));
+    TRY(launch_schur_kernel(p));
     return 0;
 }
 
@@ -1001,13 +876,9 @@ int satba_solve(satba_problem* p) {
     TRY(dense_solve(p, S, p->d_dch));  // also clears the not-SPD flag first
     const int nu = std::max(p->n_c, (int)p->hdr);
     hipLaunchKernelGGL(k_unscale, dim3((nu + 255) / 256), dim3(256), 0, p->stream, p->n_c, p->d_scale_inv, p->d_dch, p->d_dc, (int)p->hdr,
-                       p->d_xb, p->d_fail, p->lead, p->d_keep);
+                       p->d_xb, p->d_fail, p->lead, p->d_keep, SATBA_HDR_KEEP, SATBA_KEEP_LEN);
     HIP_TRY(hipGetLastError());
-    if (p->n_split > 0) HIP_TRY(hipMemsetAsync(p->d_tbuf, 0, sizeof(double) * 3 * p->N, p->stream));
-    if (p->K > 0) TRY(launch_backsub_kernel(p));
-    hipLaunchKernelGGL(k_backsub_finish, dim3(grid_for(p->n_c + p->N, 256, 512)), dim3(256), 0, p->stream, p->n_c, p->N, p->lead,
-                       p->d_dch, p->d_Vinv, p->d_g, p->d_tbuf, p->d_scale_inv, p->d_gh, p->d_gn, p->d_xb);
-    HIP_TRY(hipGetLastError());
+    TRY(launch_backsub_kernel(p));
     p->have_step = true;
     return 0;
 }
@@ -1018,7 +889,7 @@ int satba_subspace(satba_problem* p, double alpha, double inv_norm_g) {
     HIP_TRY(hipSetDevice(p->device));
     TRY(zero_header(p));
     hipLaunchKernelGGL(k_subspace_vec, dim3(grid_for(p->n, 256, 512)), dim3(256), 0, p->stream, p->n, p->n_c, p->lead, alpha,
-                       inv_norm_g, p->d_gh, p->d_gn, p->d_q1, p->d_wv, p->d_xb);
+                       inv_norm_g, p->d_gh, p->d_gn, p->d_q1, p->d_wv, p->red(RB_SUB), p->d_xb);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -1032,30 +903,28 @@ int satba_subspace_products(satba_problem* p) {
     return 0;
 }
 
-int satba_trial(satba_problem* p, double p0, double p1) {
-    if (!p) return fail(SATBA_E_ARG, "null handle");
-    if (!p->have_step) return fail(SATBA_E_STATE, "trial before solve");
-    HIP_TRY(hipSetDevice(p->device));
+static int trial_impl(satba_problem* p, double c0, double c1, const double* v0, const double* v1) {
     TRY(zero_header(p));
-    hipLaunchKernelGGL(k_trial_vec, dim3(grid_for(p->n, 256, 512)), dim3(256), 0, p->stream, p->n, p->n_c, p->lead, p0, p1,
-                       p->d_x, p->d_q1, p->d_wv, p->d_scale_inv, p->d_xnew, p->d_xb);
+    hipLaunchKernelGGL(k_trial_vec, dim3(grid_for(p->n, 256, 512)), dim3(256), 0, p->stream, p->n, p->n_c, p->lead, c0, c1,
+                       p->d_x, v0, v1, p->d_scale_inv, p->d_xnew, p->red(RB_TRIAL), p->d_xb);
     HIP_TRY(hipGetLastError());
     TRY(launch_cam_consts(p, true));
     TRY(launch_residual(p, true, nullptr, p->d_xb + 1));
     return 0;
 }
 
+int satba_trial(satba_problem* p, double p0, double p1) {
+    if (!p) return fail(SATBA_E_ARG, "null handle");
+    if (!p->have_step) return fail(SATBA_E_STATE, "trial before solve");
+    HIP_TRY(hipSetDevice(p->device));
+    return trial_impl(p, p0, p1, p->d_q1, p->d_wv);
+}
+
 int satba_trial_gn(satba_problem* p, double ca, double cb) {
     if (!p) return fail(SATBA_E_ARG, "null handle");
     if (!p->have_step) return fail(SATBA_E_STATE, "trial before solve");
     HIP_TRY(hipSetDevice(p->device));
-    TRY(zero_header(p));
-    hipLaunchKernelGGL(k_trial_vec, dim3(grid_for(p->n, 256, 512)), dim3(256), 0, p->stream, p->n, p->n_c, p->lead, ca, cb,
-                       p->d_x, p->d_gh, p->d_gn, p->d_scale_inv, p->d_xnew, p->d_xb);
-    HIP_TRY(hipGetLastError());
-    TRY(launch_cam_consts(p, true));
-    TRY(launch_residual(p, true, nullptr, p->d_xb + 1));
-    return 0;
+    return trial_impl(p, ca, cb, p->d_gh, p->d_gn);
 }
 
 int satba_accept(satba_problem* p) {
@@ -1074,25 +943,140 @@ int satba_read_header(satba_problem* p, double* host_hdr) {
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------------------- one-shot solve
+// The loop of satba/trf.py (scipy's trf_no_bounds with an exact damped step) below the ABI: single rank only -- with several
+// ranks the exchange buffer has to be all-reduced between the phases, which is the caller's side of the contract.
+int satba_solve_lm(satba_problem* p, const satba_lm_opts* o, satba_lm_stats* out) {
+    if (!p || !o || !out) return fail(SATBA_E_ARG, "null argument");
+    if (p->world != 1) return fail(SATBA_E_ARG, "satba_solve_lm drives a single-rank handle (world = %d): use the phase entry points", p->world);
+    memset(out, 0, sizeof *out);
+    TRY(satba_configure(p, o->loss, o->f_scale));
+    const int64_t max_nfev = o->max_nfev > 0 ? o->max_nfev : p->n_total * 100;
+    std::vector<double> hbuf((size_t)p->hdr), tbuf((size_t)p->hdr);
+    double* h = hbuf.data();
+    auto front = [&](double Delta, bool first) -> int {
+        TRY(satba_linearize(p));
+        TRY(satba_prepare(p, first ? 1 : 0));
+        TRY(satba_schur_auto(p, first ? -1.0 : Delta, 0.0));
+        TRY(satba_solve(p));
+        return satba_read_header(p, h);
+    };
+    enum { COST_NEW = 1, STEP_SQ = 2, X_SQ = 3, GRAM_A = 1, GRAM_B = 2, GRAM_C = 3, CHOL_FAIL = 4, WW = 1, B11 = 3, B12 = 4, B22 = 5, GHW = 6,
+           K_COST = SATBA_HDR_KEEP, K_GINF, K_GH_SQ, K_JG_SQ, K_XS_SQ, K_LAM, K_DELTA };
+    TRY(front(0.0, true));
+    double cost = h[K_COST], g_norm = h[K_GINF], Delta = h[K_DELTA];
+    if (!std::isfinite(cost)) return fail(SATBA_E_NONFINITE, "Residuals are not finite in the initial point.");
+    int64_t nfev = 1, njev = 1, iterations = 0;
+    const double initial_cost = cost;
+    int status = -1;
+    double step_norm = 0.0, actual = 0.0;
+    bool have_actual = false;
+    if (o->verbose >= 2) printf("%15s%15s%15s%15s%15s%15s\n", "Iteration  ", "Total nfev  ", "Cost     ", "Cost reduction ", "Step norm   ", "Optimality  ");
+    for (;;) {
+        if (g_norm < o->gtol) status = 1;
+        if (o->verbose >= 2) {
+            if (have_actual) printf("%10lld     %10lld     %15.4e%15.2e%15.2e%15.2e\n", (long long)iterations, (long long)nfev, cost, actual, step_norm, g_norm);
+            else printf("%10lld     %10lld     %15.4e%30s%15.2e\n", (long long)iterations, (long long)nfev, cost, "", g_norm);
+        }
+        if (status != -1 || nfev == max_nfev) break;
+        double reg = h[K_LAM];
+        const double jg_sq = h[K_JG_SQ];
+        int attempt = 0;
+        for (; attempt < 10; ++attempt) {  // a Cholesky needs a floor where LSMR copes with a numerically singular system
+            if (h[CHOL_FAIL] == 0 && std::isfinite(h[GRAM_C])) break;
+            reg = std::fmax(reg, 1e-16) * 100.0;
+            TRY(satba_schur(p, reg));
+            TRY(satba_solve(p));
+            TRY(satba_read_header(p, h));
+        }
+        if (attempt == 10) return fail(SATBA_E_STATE, "reduced camera system could not be factorised");
+        const double ga = h[GRAM_A], gb = h[GRAM_B], gc = h[GRAM_C];
+        // quadratic model on the orthonormal basis of span{g_h, gn_h} (satba/trf.py:subspace_model)
+        const double sa = std::sqrt(ga), alpha = gb / ga;
+        double ww = gc - gb * alpha, nw = 0.0, b11, b12, b22, ghw = 0.0;
+        bool one_dim = false;
+        if (ww > 1e-6 * gc) {
+            nw = std::sqrt(ww);
+            const double m11 = jg_sq, m12 = ga - reg * gb, m22 = gb - reg * gc;
+            b11 = m11 / ga;
+            b12 = (m12 - alpha * m11) / sa;
+            b22 = m22 - 2.0 * alpha * m12 + alpha * alpha * m11;
+        } else {
+            TRY(satba_subspace(p, alpha, 1.0 / sa));
+            TRY(satba_read_header(p, tbuf.data()));
+            ww = tbuf[WW]; ghw = tbuf[GHW];
+            if (!(ww > 1e-24 * gc && ww > 0)) {
+                one_dim = true;
+                b11 = jg_sq / ga; b12 = 0.0; b22 = 1.0; nw = 1.0; ww = 1.0; ghw = 0.0;
+            } else {
+                nw = std::sqrt(ww);
+                TRY(satba_subspace_products(p));
+                TRY(satba_read_header(p, tbuf.data()));
+                b11 = tbuf[B11]; b12 = tbuf[B12]; b22 = tbuf[B22];
+            }
+        }
+        const double Ba = b11, Bb = one_dim ? 0.0 : b12 / nw, Bc = one_dim ? 1.0 : b22 / ww;
+        const double gS0 = sa, gS1 = one_dim ? 0.0 : ghw / nw;
+
+        actual = -1.0;
+        while (actual <= 0 && nfev < max_nfev) {
+            double p0, p1;
+            satba_lm::solve_trust_region_2d(Ba, Bb, Bc, gS0, gS1, Delta, p0, p1);
+            const double predicted = -(0.5 * (p0 * (Ba * p0 + Bb * p1) + p1 * (Bb * p0 + Bc * p1)) + gS0 * p0 + gS1 * p1);
+            const double ca = one_dim ? p0 / sa : p0 / sa - p1 * alpha / nw, cb = one_dim ? 0.0 : p1 / nw;
+            TRY(satba_trial_gn(p, ca, cb));
+            TRY(satba_read_header(p, tbuf.data()));
+            const double cost_new = tbuf[COST_NEW];
+            ++nfev;
+            const double step_h_norm = std::hypot(p0, p1);
+            if (!std::isfinite(cost_new)) { Delta = 0.25 * step_h_norm; continue; }
+            actual = cost - cost_new;
+            double ratio;
+            const double Delta_new = satba_lm::update_tr_radius(Delta, actual, predicted, step_h_norm, step_h_norm > 0.95 * Delta, ratio);
+            step_norm = std::sqrt(tbuf[STEP_SQ]);
+            const int term = satba_lm::check_termination(actual, cost, step_norm, std::sqrt(tbuf[X_SQ]), ratio, o->ftol, o->xtol);
+            if (term) { status = term; break; }
+            Delta = Delta_new;
+        }
+        have_actual = true;
+        if (actual > 0) {
+            TRY(satba_accept(p));
+            TRY(front(Delta, false));
+            cost = h[K_COST]; g_norm = h[K_GINF];
+            ++njev;
+        } else {
+            step_norm = 0.0; actual = 0.0;
+            if (status == -1 && nfev < max_nfev) TRY(front(Delta, false));
+        }
+        ++iterations;
+    }
+    if (status == -1) status = 0;
+    out->cost = cost; out->initial_cost = initial_cost; out->optimality = g_norm;
+    out->nfev = nfev; out->njev = njev; out->iterations = iterations; out->status = status;
+    if (o->verbose >= 1) {
+        static const char* msg[] = {"The maximum number of function evaluations is exceeded.", "`gtol` termination condition is satisfied.",
+                                    "`ftol` termination condition is satisfied.", "`xtol` termination condition is satisfied.",
+                                    "Both `ftol` and `xtol` termination conditions are satisfied."};
+        printf("%s\nFunction evaluations %lld, initial cost %.4e, final cost %.4e, first-order optimality %.2e.\n", msg[status], (long long)nfev,
+               initial_cost, cost, g_norm);
+    }
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------- inspection
 int satba_get_blocks(satba_problem* p, double* U, double* gc, double* V, double* gp) {
     if (!p) return fail(SATBA_E_ARG, "null handle");
     if (!p->linearized) return fail(SATBA_E_STATE, "get_blocks before linearize");
+    HIP_TRY(hipSetDevice(p->device));
     HIP_TRY(hipStreamSynchronize(p->stream));
     const size_t nU = (size_t)p->M * p->NP * p->NP;
-    if (U && !p->u_full) {
-        // the linearize kernel only kept diag(U_c): form the full blocks with the camera-major pass (inspection only)
+    if (U) {
+        // the linearize kernel only keeps diag(U_c): form the full blocks with the camera-major pass (inspection only)
         double *dU = nullptr, *dg = nullptr;
         HIP_TRY(hipMalloc((void**)&dU, sizeof(double) * nU));
         HIP_TRY(hipMalloc((void**)&dg, sizeof(double) * p->n_c));
-        ObsArgs a = obs_args(p, false);
-        CamMajor cm;
-        cm.cam_ofs = p->d_cam_ofs; cm.obs = p->d_cm_obs; cm.w = p->d_cm_w; cm.pt = p->d_cm_pt; cm.oidx = p->d_cam_obs;
         int rc = [&]() -> int {
-            SATBA_DISPATCH(p, hipLaunchKernelGGL((k_lin_cameras<MODEL, NP, true>), dim3(p->lin3_chunks, p->M), dim3(LINC_THREADS), 0,
-                                                 p->stream, a, cm, p->d_part3));
-            const int total = p->M * cam_acc_len(p->NP);
-            hipLaunchKernelGGL(k_lin3_finish, dim3((total + 255) / 256), dim3(256), 0, p->stream, p->M, p->NP, p->lin3_chunks, p->d_part3, dU, dg);
-            HIP_TRY(hipGetLastError());
+            TRY(launch_cam_sums(p, dU, dg));
             HIP_TRY(hipStreamSynchronize(p->stream));
             HIP_TRY(hipMemcpy(U, dU, sizeof(double) * nU, hipMemcpyDeviceToHost));
             return 0;
@@ -1100,12 +1084,10 @@ int satba_get_blocks(satba_problem* p, double* U, double* gc, double* V, double*
         (void)hipFree(dU);
         (void)hipFree(dg);
         if (rc) return rc;
-    } else if (U) {
-        HIP_TRY(hipMemcpy(U, p->payload(), sizeof(double) * nU, hipMemcpyDeviceToHost));
     }
     if (gc) HIP_TRY(hipMemcpy(gc, p->payload() + nU, sizeof(double) * p->n_c, hipMemcpyDeviceToHost));
-    if (V) HIP_TRY(hipMemcpy(V, p->d_V, sizeof(double) * 6 * p->N, hipMemcpyDeviceToHost));
-    if (gp) HIP_TRY(hipMemcpy(gp, p->d_g + p->n_c, sizeof(double) * 3 * p->N, hipMemcpyDeviceToHost));
+    if (V) TRY(download_permuted(p, p->d_V, V, 0, 6));
+    if (gp) TRY(download_permuted(p, p->d_g + p->n_c, gp, 0, 3));
     return 0;
 }
 
@@ -1117,7 +1099,8 @@ int satba_get_jacobian(satba_problem* p, double* Jc, double* Jp) {
     HIP_TRY(hipMalloc((void**)&dJp, sizeof(double) * (6 * p->K + 1)));
     ObsArgs a = obs_args(p, false);
     int rc = [&]() -> int {
-        SATBA_DISPATCH(p, hipLaunchKernelGGL((k_jacobian<MODEL, NP>), dim3(grid_for(p->K, 256, 1024)), dim3(256), 0, p->stream, a, dJc, dJp));
+        SATBA_DISPATCH(p, hipLaunchKernelGGL((k_jacobian<MODEL, NP>), dim3(grid_for(p->K, 256, 1024)), dim3(256), 0, p->stream, a, p->L.pts_ind,
+                                             p->L.rank, p->L.obs_pos, dJc, dJp));
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(p->stream));
         HIP_TRY(hipMemcpy(Jc, dJc, sizeof(double) * 2 * p->K * p->NP, hipMemcpyDeviceToHost));
@@ -1145,17 +1128,6 @@ int satba_set_exchange(satba_problem* p, int64_t offset, int64_t n, const double
     return 0;
 }
 
-// tools only (not declared in satba.h): per-task timestamps of the last dataflow Cholesky
-int satba_debug_dag_times(satba_problem* p, long long* host_out, int32_t* n_tasks) {
-    if (!p || !n_tasks) return fail(SATBA_E_ARG, "null argument");
-    *n_tasks = p->dag.d_times ? p->dag.n_tasks : 0;
-    if (host_out && p->dag.d_times) {
-        HIP_TRY(hipStreamSynchronize(p->stream));
-        HIP_TRY(hipMemcpy(host_out, p->dag.d_times, sizeof(long long) * 4 * p->dag.n_tasks, hipMemcpyDeviceToHost));
-    }
-    return 0;
-}
-
 // tools only (tools/chol_times.py): wall-clock stamps (100 MHz) of every panel step of one factorisation of the
 // current reduced system; host_out holds 8 * CH_MAX_STEPS values.  Destroys S.
 int satba_debug_chol_times(satba_problem* p, long long* host_out, int32_t* n_steps) {
@@ -1175,8 +1147,62 @@ int satba_get_vector(satba_problem* p, int32_t which, double* host_out) {
     if (!p || !host_out) return fail(SATBA_E_ARG, "null argument");
     const double* src[] = {p->d_g, p->d_scale_inv, p->d_gn, p->d_q1, p->d_wv, p->d_xnew, p->d_gh};
     if (which < 0 || which > 6) return fail(SATBA_E_ARG, "unknown vector id %d", which);
+    HIP_TRY(hipSetDevice(p->device));
+    return download_permuted(p, src[which], host_out, p->n_c, 3);
+}
+
+int64_t satba_layout_len(const satba_problem* p, int32_t which) {
+    if (!p) return -1;
+    const Layout& L = p->L;
+    switch (which) {
+        case SATBA_LAY_PERM: case SATBA_LAY_RANK: case SATBA_LAY_PT_CNT: return L.N;
+        case SATBA_LAY_SLICE_BASE: return L.n_slices + 1;
+        case SATBA_LAY_E_CAM: return L.P;
+        case SATBA_LAY_OBS_POS: case SATBA_LAY_CM_PT: case SATBA_LAY_CM_POS: return L.K;
+        case SATBA_LAY_CAM_OFS: return L.M + 1;
+        case SATBA_LAY_PAIR_OFS: return L.n_pairs * (L.C + 1) + 1;
+        case SATBA_LAY_PAIR_PTS: case SATBA_LAY_PAIR_PI: case SATBA_LAY_PAIR_PJ: return L.E;
+        case SATBA_LAY_PAIR_IJ: return 2 * L.n_pairs;
+        default: return -1;
+    }
+}
+
+int satba_get_layout(satba_problem* p, int32_t which, int64_t n, void* host_out) {
+    if (!p || !host_out) return fail(SATBA_E_ARG, "null argument");
+    const int64_t len = satba_layout_len(p, which);
+    if (len < 0 || n != len) return fail(SATBA_E_ARG, "layout array %d has %lld entries, caller expects %lld", which, (long long)len, (long long)n);
+    const Layout& L = p->L;
+    const void* src = nullptr;
+    size_t esz = sizeof(int);
+    switch (which) {
+        case SATBA_LAY_PERM: src = L.perm; break;
+        case SATBA_LAY_RANK: src = L.rank; break;
+        case SATBA_LAY_PT_CNT: src = L.pt_cnt; break;
+        case SATBA_LAY_SLICE_BASE: src = L.slice_base; break;
+        case SATBA_LAY_E_CAM: src = L.e_cam; break;
+        case SATBA_LAY_OBS_POS: src = L.obs_pos; break;
+        case SATBA_LAY_CM_PT: src = L.cm_pt; break;
+        case SATBA_LAY_CM_POS: src = L.cm_pos; break;
+        case SATBA_LAY_CAM_OFS: src = L.cam_ofs; break;
+        case SATBA_LAY_PAIR_OFS: src = L.pair_ofs; esz = sizeof(long long); break;
+        case SATBA_LAY_PAIR_PTS: src = L.pair_pts; break;
+        case SATBA_LAY_PAIR_PI: src = L.pair_pi; break;
+        case SATBA_LAY_PAIR_PJ: src = L.pair_pj; break;
+        case SATBA_LAY_PAIR_IJ: src = L.pair_ij; break;
+        default: return fail(SATBA_E_ARG, "unknown layout array %d", which);
+    }
+    HIP_TRY(hipSetDevice(p->device));
     HIP_TRY(hipStreamSynchronize(p->stream));
-    HIP_TRY(hipMemcpy(host_out, src[which], sizeof(double) * p->n, hipMemcpyDeviceToHost));
+    if (len) HIP_TRY(hipMemcpy(host_out, src, esz * (size_t)len, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int satba_get_info(const satba_problem* p, double* out, int32_t n) {
+    if (!p || !out || n < 16) return fail(SATBA_E_ARG, "bad argument");
+    for (int i = 0; i < n; ++i) out[i] = 0.0;
+    for (int i = 0; i < 5; ++i) out[i] = p->create_ms[i];
+    out[5] = p->L.P; out[6] = (double)p->L.E; out[7] = p->L.C; out[8] = p->unit_weights; out[9] = p->camc_lds; out[10] = p->rpc_lds;
+    out[11] = p->cam_sums_lds; out[12] = p->deterministic; out[13] = p->cm_chunks; out[14] = p->lin_grid;
     return 0;
 }
 
@@ -1218,5 +1244,7 @@ int satba_time_kernel(satba_problem* p, int32_t phase, int32_t reps, float* ms_a
     p->linearized = false; p->have_step = false;  // blocks / exchange payload were overwritten
     return rc;
 }
+
+#include "satba_outliers_api.inc"
 
 }  // extern "C"

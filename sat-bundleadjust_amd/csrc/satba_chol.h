@@ -13,7 +13,6 @@
 // by readlane broadcasts.  Tile (0, 0) is workgroup 0 of a 1-D grid, so the flag setter is always resident before
 // any waiter.  The right-hand side is carried along (forward substitution folded in).  k_trsv_back finishes with
 // a left-looking backward substitution in one workgroup.
-// The previous version (k_potrf_trsm + k_syrk, two launches per panel, SATBA_CHOL=1) is kept for A/B runs.
 // fp64 MFMA runs at the vector rate on gfx950 and the matrix is tiny: the solve is bound by the latency of the
 // dependent panel chain, not by flops; see DESIGN.md.
 #pragma once
@@ -28,120 +27,6 @@ __device__ inline double readlane_f64(double v, int src_lane) {  // src_lane mus
     lo = __builtin_amdgcn_readlane(lo, src_lane);
     hi = __builtin_amdgcn_readlane(hi, src_lane);
     return __hiloint2double(hi, lo);
-}
-
-// Panel step, entirely in registers, no LDS and no barriers.  Every wave first factorises the 32 x 32 diagonal
-// block redundantly -- lane r (< 32) holds row r in 32 registers, column values are broadcast with v_readlane --
-// and then solves 64 panel rows (one per lane, also in registers) against it, again through v_readlane
-// broadcasts of L.  The right-hand side is treated as one more panel row (forward substitution folded in).
-// Wave 0 of workgroup 0 writes the factorised diagonal block back.
-// rows handled: base .. n-1 (base = k0 + nb) and the virtual row n = right-hand side b.
-__global__ __launch_bounds__(256) void k_potrf_trsm(double* __restrict__ A, int n, int k0, int* __restrict__ fail,
-                                                    double* __restrict__ b) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int nb = min(CH_NB, n - k0);
-    const int base = k0 + nb;
-    const int gw = blockIdx.x * 4 + wave;  // global wave index
-    if (gw * 64 > n - base) return;        // this wave's first row is beyond the virtual row n
-
-    // ---- diagonal block into registers (identity padding beyond nb)
-    double a[CH_NB];
-    const int dr = min(lane, CH_NB - 1);
-#pragma unroll
-    for (int c = 0; c < CH_NB; ++c) {
-        double v = (c == dr) ? 1.0 : 0.0;
-        if (lane < nb && c < nb && c <= lane) v = A[(size_t)(k0 + lane) + (size_t)(k0 + c) * n];
-        a[c] = v;
-    }
-    // ---- Cholesky of the block: after step j, a[j] of lane r >= j holds L[r][j]
-    double my_inv = 1.0;  // 1 / L[lane][lane]
-    bool bad = false;
-#pragma unroll
-    for (int j = 0; j < CH_NB; ++j) {
-        double d = readlane_f64(a[j], j);
-        if (!(d > 0.0)) { bad = true; d = 1.0; }
-        const double sq = sqrt(d), inv = 1.0 / sq;
-        const double l = (lane == j) ? sq : a[j] * inv;
-        a[j] = l;
-        if (lane == j) my_inv = inv;
-#pragma unroll
-        for (int c = j + 1; c < CH_NB; ++c) a[c] -= l * readlane_f64(l, c);
-    }
-    if (gw == 0) {
-        if (bad && lane == 0) atomicOr(fail, 1);
-        if (lane < nb) {
-#pragma unroll
-            for (int c = 0; c < CH_NB; ++c)
-                if (c <= lane && c < nb) A[(size_t)(k0 + lane) + (size_t)(k0 + c) * n] = a[c];
-        }
-    }
-    // ---- this lane's panel row (or the right-hand side): x L_kk^T = p
-    const int r = base + gw * 64 + lane;
-    const bool is_rhs = (r == n), valid = (r <= n);
-    double x[CH_NB];
-#pragma unroll
-    for (int c = 0; c < CH_NB; ++c) {
-        double v = 0.0;
-        if (c < nb && valid) v = is_rhs ? b[k0 + c] : A[(size_t)r + (size_t)(k0 + c) * n];
-        x[c] = v;
-    }
-#pragma unroll
-    for (int m = 0; m < CH_NB; ++m) {
-        const double xm = x[m] * readlane_f64(my_inv, m);
-        x[m] = xm;
-#pragma unroll
-        for (int c = m + 1; c < CH_NB; ++c) x[c] -= xm * readlane_f64(a[m], c);  // L[c][m]
-    }
-    if (valid) {
-#pragma unroll
-        for (int c = 0; c < CH_NB; ++c) {
-            if (c < nb) {
-                if (is_rhs) b[k0 + c] = x[c];
-                else A[(size_t)r + (size_t)(k0 + c) * n] = x[c];
-            }
-        }
-    }
-}
-
-// trailing update A[base:, base:] -= P P^T (lower tiles only), P = A[base:, k0:k0+nb], base = k0 + nb;
-// the first tile column also applies  b[base:] -= P y_k  with y_k = b[k0:k0+nb] (already final).
-__global__ __launch_bounds__(256) void k_syrk(double* __restrict__ A, int n, int k0, int nb, double* __restrict__ b) {
-    const int bi = blockIdx.y, bj = blockIdx.x;
-    if (bj > bi) return;
-    __shared__ double Pi[CH_NB][64], Pj[CH_NB][64];
-    const int base = k0 + nb;
-    const int r0 = base + bi * 64, c0 = base + bj * 64;
-    const int tid = threadIdx.y * 16 + threadIdx.x;
-    for (int idx = tid; idx < nb * 64; idx += 256) {
-        const int r = idx & 63, k = idx >> 6;
-        Pi[k][r] = (r0 + r < n) ? A[(size_t)(r0 + r) + (size_t)(k0 + k) * n] : 0.0;
-        Pj[k][r] = (c0 + r < n) ? A[(size_t)(c0 + r) + (size_t)(k0 + k) * n] : 0.0;
-    }
-    __syncthreads();
-    if (bj == 0 && tid < 64 && r0 + tid < n) {
-        double s = 0.0;
-        for (int k = 0; k < nb; ++k) s += Pi[k][tid] * b[k0 + k];
-        b[r0 + tid] -= s;
-    }
-    double acc[4][4] = {};
-    const int tr = threadIdx.x * 4, tc = threadIdx.y * 4;  // rows on the fast index: coalesced A accesses
-#pragma unroll 8
-    for (int k = 0; k < nb; ++k) {
-        double a[4], c[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { a[i] = Pi[k][tr + i]; c[i] = Pj[k][tc + i]; }
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) acc[j][i] += a[i] * c[j];
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int r = r0 + tr + i, c = c0 + tc + j;
-            if (r < n && c < n && r >= c) A[(size_t)r + (size_t)c * n] -= acc[j][i];
-        }
 }
 
 // h = 0.5 / sqrt(d): v_rsq_f64 seed + two coupled Goldschmidt steps (six dependent operations; the library sqrt
@@ -532,45 +417,30 @@ namespace satba {
 constexpr int CH_MAX_STEPS = 256;  // flags: one per panel step (n <= 8192)
 
 // Factorise A (n x n, column-major lower, in place) and solve A z = b in place.  *fail != 0 if A was not SPD.
-// flags: CH_MAX_STEPS ints of scratch directly behind *fail (flags == fail + 1); both are cleared here.  two_launch: the previous k_potrf_trsm + k_syrk pipeline.
-// mode 0: double steps (k_chol_dstep, satba_chol2.h) while at least 64 columns remain, then single steps; 1: the first
-// pipeline (k_potrf_trsm + k_syrk, two launches per panel); 2: single steps only (k_chol_step)
+// flags: CH_MAX_STEPS ints of scratch directly behind *fail (flags == fail + 1); both are cleared here.
+// mode 0: double steps (k_chol_dstep, satba_chol2.h) while at least 64 columns remain, then single steps; 2: single steps
+// only (k_chol_step)
 inline void cholesky_solve(double* A, int n, double* b, int* fail, int* flags, int mode, hipStream_t stream,
                            long long* ts = nullptr) {
-    const bool two_launch = mode == 1;
-    if (two_launch) {
-        (void)hipMemsetAsync(fail, 0, sizeof(int), stream);
-        for (int k0 = 0; k0 < n; k0 += CH_NB) {
-            const int nb = n - k0 < CH_NB ? n - k0 : CH_NB;
-            const int rest = n - k0 - nb;
-            const int waves = (rest + 1 + 63) / 64;  // panel rows + the right-hand side row
-            hipLaunchKernelGGL(k_potrf_trsm, dim3((waves + 3) / 4), dim3(256), 0, stream, A, n, k0, fail, b);
-            if (rest > 0) {
-                const int tiles = (rest + 63) / 64;
-                hipLaunchKernelGGL(k_syrk, dim3(tiles, tiles), dim3(16, 16), 0, stream, A, n, k0, nb, b);
-            }
-        }
-    } else {
-        (void)hipMemsetAsync(fail, 0, sizeof(int) * (1 + CH_MAX_STEPS), stream);  // flags == fail + 1: one fill for both
-        int step = 0, k0 = 0, kp2 = -1, kp = -1;
-        if (mode == 0 && !ts) {
-            for (; n - k0 >= 2 * CH_NB; k0 += 2 * CH_NB, step += 2) {
-                const int T = (n - k0 + 63) / 64;
-                hipLaunchKernelGGL(k_chol_dstep, dim3(T * (T + 1) / 2), dim3(256), 0, stream, A, n, kp2, kp, k0, fail, flags + step, b);
-                kp2 = k0; kp = k0 + CH_NB;
-            }
-        }
-        for (; k0 < n; k0 += CH_NB, ++step) {
+    (void)hipMemsetAsync(fail, 0, sizeof(int) * (1 + CH_MAX_STEPS), stream);  // flags == fail + 1: one fill for both
+    int step = 0, k0 = 0, kp2 = -1, kp = -1;
+    if (mode == 0 && !ts) {
+        for (; n - k0 >= 2 * CH_NB; k0 += 2 * CH_NB, step += 2) {
             const int T = (n - k0 + 63) / 64;
-            long long* tsk = ts ? ts + 8 * step : nullptr;
-            if (n - k0 >= CH_NB)
-                hipLaunchKernelGGL(k_chol_step<true>, dim3(T * (T + 1) / 2), dim3(256), 0, stream, A, n, kp2, kp, k0, fail, flags + step, b, tsk);
-            else
-                hipLaunchKernelGGL(k_chol_step<false>, dim3(T * (T + 1) / 2), dim3(256), 0, stream, A, n, kp2, kp, k0, fail, flags + step, b, tsk);
-            kp2 = -1; kp = k0;
+            hipLaunchKernelGGL(k_chol_dstep, dim3(T * (T + 1) / 2), dim3(256), 0, stream, A, n, kp2, kp, k0, fail, flags + step, b);
+            kp2 = k0; kp = k0 + CH_NB;
         }
     }
-    if (n <= 1024 && !two_launch) {
+    for (; k0 < n; k0 += CH_NB, ++step) {
+        const int T = (n - k0 + 63) / 64;
+        long long* tsk = ts ? ts + 8 * step : nullptr;
+        if (n - k0 >= CH_NB)
+            hipLaunchKernelGGL(k_chol_step<true>, dim3(T * (T + 1) / 2), dim3(256), 0, stream, A, n, kp2, kp, k0, fail, flags + step, b, tsk);
+        else
+            hipLaunchKernelGGL(k_chol_step<false>, dim3(T * (T + 1) / 2), dim3(256), 0, stream, A, n, kp2, kp, k0, fail, flags + step, b, tsk);
+        kp2 = -1; kp = k0;
+    }
+    if (n <= 1024) {
         const int T = (n + 31) / 32;
         hipLaunchKernelGGL(k_mirror_lower, dim3(T * (T + 1) / 2), dim3(256), 0, stream, A, n);
         hipLaunchKernelGGL(k_trsv_back_rl, dim3(1), dim3(1024), 0, stream, A, n, b);

@@ -1,0 +1,167 @@
+// satba_layout.h -- index structures of one shard, built ON THE DEVICE from the caller's (pts_ind, cam_ind) lists
+// (what ref:bundle_adjust/ba_params.py:139-148 produces: point-major observation lists, cameras ascending inside a point).
+//
+// Everything the kernels index with is derived here with sort / scan kernels (hipCUB radix sort and prefix sums plus a
+// few fill kernels); the host only sizes the allocations.  tests/test_gpu_layout.py checks every array bit for bit
+// against a numpy restatement.
+//
+//   points     internal order = stable sort by track length (number of observations), ascending.
+//              perm[q] = caller's local point index of internal point q, rank[] its inverse, pt_cnt[q] the length.
+//   sliced ELL 64 consecutive internal points form a slice (one wavefront, lane = point).  Slot k of all 64 points
+//              is stored contiguously, so "observation k of my point" is a coalesced access for the wave:
+//                  pos(q, k) = slice_base[q / 64] + 64 k + q % 64,       k < pt_cnt[q]
+//              A slice is as long as its longest track; because the points are sorted by length the padding is a few
+//              slots at the boundaries between length classes (e_cam = -1 there).  Every per-observation array of the
+//              solver (residuals, row scales, stored RPC Jacobian blocks) uses these positions.
+//   cameras    cam_ofs[M + 1], cm_pt[K], cm_pos[K]: the observations of every camera, internal point ascending
+//              (camera-major passes: diagonal Schur blocks, deterministic camera sums).
+//   pairs      for every camera pair (i < j) the points both see, ascending, cut into C point-range chunks:
+//              pair_ofs[pair (C + 1) + chunk], pair_pts[E], pair_pi[E], pair_pj[E] (ELL positions of the two
+//              observations), pair_ij[pair] = (i, j).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+#include <stdint.h>
+
+namespace satba {
+
+struct Layout {
+    int M = 0, N = 0, n_slices = 0, P = 0;  // P: padded ELL length
+    long long K = 0, E = 0;                 // observations, pair-list entries
+    long long n_pairs = 0;
+    int C = 1;                              // point-range chunks of the pair lists
+    int *perm = nullptr, *rank = nullptr, *pt_cnt = nullptr, *slice_base = nullptr;
+    int* e_cam = nullptr;
+    double2* e_obs = nullptr;
+    double* e_w = nullptr;
+    int *obs_pos = nullptr, *pts_ind = nullptr;
+    int *cam_ofs = nullptr, *cm_pt = nullptr, *cm_pos = nullptr;
+    long long* pair_ofs = nullptr;
+    int2* pair_ij = nullptr;
+    int *pair_pts = nullptr, *pair_pi = nullptr, *pair_pj = nullptr;
+    long long* hit_ofs = nullptr;  // N + 1: running count of the k (k - 1) / 2 pair entries of the points before q
+};
+
+// error word: 0 ok; otherwise (code << 32 | index of the first offender + 1 is not tracked: code only)
+enum { LAY_OK = 0, LAY_E_CAM = 1, LAY_E_PT = 2, LAY_E_ORDER = 3, LAY_E_CAM_ORDER = 4 };
+
+// indices in range, points non-decreasing, cameras strictly ascending inside a point; flags[0] = first error code,
+// flags[1] = 1 if some weight differs from 1
+__global__ void k_lay_validate(long long K, int M, int N, const int* __restrict__ cam, const int* __restrict__ pt,
+                               const double* __restrict__ w, int* __restrict__ flags) {
+    for (long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x; o < K; o += (long long)gridDim.x * blockDim.x) {
+        const int c = cam[o], p = pt[o];
+        int err = 0;
+        if (c < 0 || c >= M) err = LAY_E_CAM;
+        else if (p < 0 || p >= N) err = LAY_E_PT;
+        else if (o > 0) {
+            const int pp = pt[o - 1];
+            if (pp > p) err = LAY_E_ORDER;
+            else if (pp == p && cam[o - 1] >= c) err = LAY_E_CAM_ORDER;
+        }
+        if (err) atomicCAS(flags, 0, err);
+        if (w[o] != 1.0) flags[1] = 1;
+    }
+}
+
+// CSR offsets of a sorted key list: ofs[v] = first index whose key is >= v, for v = 0 .. n_keys (ofs[n_keys] = K)
+template <class T>
+__global__ void k_lay_offsets(long long K, int n_keys, const int* __restrict__ key, T* __restrict__ ofs) {
+    for (long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x; o <= K; o += (long long)gridDim.x * blockDim.x) {
+        const int lo = (o == 0) ? 0 : key[o - 1] + 1;
+        const int hi = (o == K) ? n_keys : key[o];
+        for (int v = lo; v <= hi; ++v) ofs[v] = (T)o;
+    }
+}
+// the same for 64-bit composite keys that are given by a functor of the index
+__global__ void k_lay_offsets_pair(long long E, long long n_keys, const int* __restrict__ pair_sorted, const int* __restrict__ pts,
+                                   int N, int C, long long* __restrict__ ofs) {
+    auto key = [&](long long r) { return (long long)pair_sorted[r] * (C + 1) + (int)((long long)pts[r] * C / N); };
+    for (long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x; r <= E; r += (long long)gridDim.x * blockDim.x) {
+        const long long lo = (r == 0) ? 0 : key(r - 1) + 1;
+        const long long hi = (r == E) ? n_keys : key(r);
+        for (long long v = lo; v <= hi; ++v) ofs[v] = r;
+    }
+}
+
+__global__ void k_lay_counts(int N, const int* __restrict__ ofs, int* __restrict__ cnt, int* __restrict__ iota) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < N) { cnt[p] = ofs[p + 1] - ofs[p]; iota[p] = p; }
+}
+
+__global__ void k_lay_iota(long long n, int* __restrict__ iota) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) iota[i] = (int)i;
+}
+
+// rank = perm^-1; slice lengths (the last point of a slice has its longest track); pair-entry counts per point
+__global__ void k_lay_rank(int N, const int* __restrict__ perm, const int* __restrict__ cnt_sorted, int* __restrict__ rank,
+                           int* __restrict__ slice_slots, long long* __restrict__ hits) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= N) return;
+    rank[perm[q]] = q;
+    const long long c = cnt_sorted[q];
+    hits[q] = c * (c - 1) / 2;
+    if ((q & 63) == 63 || q == N - 1) slice_slots[q >> 6] = 64 * (int)c;
+}
+
+// scatter the caller's observation arrays into ELL order; internal point-major list (cam, pos, point) for the camera sort
+__global__ void k_lay_fill_ell(long long K, const int* __restrict__ cam, const int* __restrict__ pt, const double2* __restrict__ obs,
+                               const double* __restrict__ w, const int* __restrict__ ofs, const int* __restrict__ rank,
+                               const int* __restrict__ slice_base, const int* __restrict__ ipt_ofs, int* __restrict__ e_cam,
+                               double2* __restrict__ e_obs, double* __restrict__ e_w, int* __restrict__ obs_pos,
+                               int* __restrict__ io_cam, int* __restrict__ io_pos, int* __restrict__ io_pt) {
+    for (long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x; o < K; o += (long long)gridDim.x * blockDim.x) {
+        const int p = pt[o], q = rank[p], k = (int)(o - ofs[p]);
+        const int pos = slice_base[q >> 6] + 64 * k + (q & 63);
+        const int c = cam[o];
+        e_cam[pos] = c;
+        e_obs[pos] = obs[o];
+        e_w[pos] = w[o];
+        obs_pos[o] = pos;
+        const int io = ipt_ofs[q] + k;
+        io_cam[io] = c; io_pos[io] = pos; io_pt[io] = q;
+    }
+}
+
+__global__ void k_lay_gather2(long long n, const int* __restrict__ idx, const int* __restrict__ a, const int* __restrict__ b,
+                              int* __restrict__ oa, int* __restrict__ ob) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int j = idx[i];
+        oa[i] = a[j]; ob[i] = b[j];
+    }
+}
+__global__ void k_lay_gather3(long long n, const int* __restrict__ idx, const int* __restrict__ a, const int* __restrict__ b,
+                              const int* __restrict__ c, int* __restrict__ oa, int* __restrict__ ob, int* __restrict__ oc) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int j = idx[i];
+        oa[i] = a[j]; ob[i] = b[j]; oc[i] = c[j];
+    }
+}
+
+__host__ __device__ inline long long pair_index(long long M, long long a, long long b) { return a * M - a * (a + 1) / 2 + (b - a - 1); }
+
+// all camera pairs of every point, in internal point order: key = pair index, values = point, the two ELL positions
+__global__ void k_lay_hits(int N, int M, const int* __restrict__ cnt, const int* __restrict__ slice_base, const int* __restrict__ e_cam,
+                           const long long* __restrict__ hit_ofs, int* __restrict__ key, int* __restrict__ hq, int* __restrict__ hpi,
+                           int* __restrict__ hpj) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= N) return;
+    const int n = cnt[q], base = slice_base[q >> 6] + (q & 63);
+    long long at = hit_ofs[q];
+    for (int a = 0; a < n; ++a) {
+        const int ca = e_cam[base + 64 * a];
+        for (int b = a + 1; b < n; ++b) {
+            const int cb = e_cam[base + 64 * b];
+            key[at] = (int)pair_index(M, ca, cb);
+            hq[at] = q; hpi[at] = base + 64 * a; hpj[at] = base + 64 * b;
+            ++at;
+        }
+    }
+}
+
+__global__ void k_lay_pair_ij(int M, int2* __restrict__ ij) {
+    const int i = blockIdx.x;
+    for (int j = i + 1 + threadIdx.x; j < M; j += blockDim.x) ij[pair_index(M, i, j)] = make_int2(i, j);
+}
+
+}  // namespace satba

@@ -157,13 +157,17 @@ __device__ inline void rpc_project(const double* __restrict__ tab, double x, dou
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
         double n, nL, nP, nH, d, dL, dP, dH;
-        // compiler barriers: only one polynomial's 20 coefficients are in flight at a time; without them all 80
-        // loads are hoisted to the top and the kernels spill
+#ifdef SATBA_RPC_FENCES
         asm volatile("" ::: "memory");
+#endif
         rpc_poly<JAC>(tab + 40 * k, L, P, H, LL, PP, HH, LP, LH, PH, n, nL, nP, nH);
+#ifdef SATBA_RPC_FENCES
         asm volatile("" ::: "memory");
+#endif
         rpc_poly<JAC>(tab + 40 * k + 20, L, P, H, LL, PP, HH, LP, LH, PH, d, dL, dP, dH);
+#ifdef SATBA_RPC_FENCES
         asm volatile("" ::: "memory");
+#endif
         const double id = 1.0 / d;
         const double q = n * id;
         const double scale = tab[87 + 2 * k], off = tab[86 + 2 * k];

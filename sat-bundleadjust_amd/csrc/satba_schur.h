@@ -1,0 +1,397 @@
+// satba_schur.h -- K3: Schur complement of the point blocks, by camera-pair intersection.  No atomics on the data path,
+// everything accumulates in registers.
+//
+//   S_ij -= sum over points p seen by BOTH cameras i and j of  W_ip Vinv_p W_jp^T,   W = Jc^T Jp  (NP x 3)
+//
+// One wavefront owns one (camera pair, point-range chunk) item: it streams the pair's static list of shared points
+// (satba_layout.h; a coalesced 12-byte stream: point, the ELL positions of its two observations), gathers the packed
+// 128-byte point record (X, Vinv) of every hit, evaluates both Jacobians -- both cameras are wave-uniform, their constants
+// sit in scalar registers -- and accumulates the NP x NP block in registers; one wave reduce-scatter per item, the chunk
+// partials are added by k_schur_pairs_reduce.  The diagonal blocks (including the full J_c^T J_c) and the right-hand side
+// come from a camera-major pass (k_schur_diag) that also accumulates in registers.
+// History (round 1): global float64 atomics 72.5 ms, LDS column panels 6.2 ms, visibility-bitmap intersection 1.8-3.0 ms,
+// static pair lists 0.90 ms, chunked dispatch + 128-byte records 0.59 ms at 200 x 1M x 10M.
+#pragma once
+#include "satba_kernels.h"
+
+namespace satba {
+
+// ------------------------------------------------------------------------------------------------ point blocks
+// (V_p + lam Dp^2)^-1 per point, symmetric 3x3 stored as xx xy xz yy yz zz
+constexpr int PV_STRIDE = 16;  // doubles per packed point record: 12 used, padded to 16 so that a record is exactly one
+                               // 128-byte line (96-byte records straddle lines: 1.5 lines per gather; Schur 0.945 -> 0.845 ms)
+// PV: packed per-point record X(3) | Vinv(6) | g_p(3) for the gather-heavy Schur kernels
+// lam_dev (optional): the damping is read from device memory (satba_schur_auto) instead of the argument
+__global__ void k_vinv(int N, double lam, const double* __restrict__ lam_dev, const double* __restrict__ V,
+                       const double* __restrict__ scale_inv_p, double* __restrict__ Vinv, const double* __restrict__ xp,
+                       const double* __restrict__ gp, double* __restrict__ PV) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= N) return;
+    if (lam_dev) lam = *lam_dev;
+    // 16-byte accesses: V and Vinv rows are 48 bytes apart, records 128 (hipMalloc aligns the arrays to 256 bytes)
+    const double2* v2 = reinterpret_cast<const double2*>(V + 6 * (size_t)p);
+    const double2 va = v2[0], vb = v2[1], vc = v2[2];
+    const double* s = scale_inv_p + 3 * (size_t)p;
+    const double a = va.x + lam * s[0] * s[0], b = va.y, c = vb.x;
+    const double d = vb.y + lam * s[1] * s[1], e = vc.x, f = vc.y + lam * s[2] * s[2];
+    const double c00 = d * f - e * e, c01 = c * e - b * f, c02 = b * e - c * d;
+    const double idet = 1.0 / (a * c00 + b * c01 + c * c02);
+    const double o0 = c00 * idet, o1 = c01 * idet, o2 = c02 * idet;
+    const double o3 = (a * f - c * c) * idet, o4 = (b * c - a * e) * idet, o5 = (a * d - b * b) * idet;
+    double2* o = reinterpret_cast<double2*>(Vinv + 6 * (size_t)p);
+    o[0] = make_double2(o0, o1); o[1] = make_double2(o2, o3); o[2] = make_double2(o4, o5);
+    static_assert(PV_STRIDE % 2 == 0, "records are written as 16-byte words");
+    double2* q = reinterpret_cast<double2*>(PV + PV_STRIDE * (size_t)p);
+    const double x0 = xp[3 * (size_t)p], x1 = xp[3 * (size_t)p + 1], x2 = xp[3 * (size_t)p + 2];
+    const double g0 = gp[3 * (size_t)p], g1 = gp[3 * (size_t)p + 1], g2 = gp[3 * (size_t)p + 2];
+    q[0] = make_double2(x0, x1); q[1] = make_double2(x2, o0); q[2] = make_double2(o1, o2);
+    q[3] = make_double2(o3, o4); q[4] = make_double2(o5, g0); q[5] = make_double2(g1, g2);
+}
+
+// S <- (lead) * lam Dc^2 on the diagonal, rhs <- (lead) * g_c ; S column-major n_c x n_c (already zeroed).  The J_c^T J_c
+// blocks are added by k_schur_diag.
+__global__ void k_schur_init(int M, int NP, double lam, const double* __restrict__ lam_dev, double lead,
+                             const double* __restrict__ gc, const double* __restrict__ scale_inv,
+                             double* __restrict__ S, double* __restrict__ rhs) {
+    if (lam_dev) lam = *lam_dev;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n_c = M * NP;
+    if (idx < n_c) {
+        const double s = scale_inv[idx];
+        S[(size_t)idx + (size_t)idx * n_c] = lead * lam * s * s;
+        rhs[idx] = lead * gc[idx];
+    }
+}
+
+struct SchurArgs {
+    const double2* __restrict__ PV;          // N x 8 double2: X0 X1 | X2 v00 | v01 v02 | v11 v12 | v22 g0 | g1 g2 | pad
+    const long long* __restrict__ pair_ofs;  // n_pairs x (n_chunks + 1): offsets into the lists
+    const int* __restrict__ pair_pts;        // points shared by each camera pair, ascending (static per problem)
+    const int* __restrict__ pair_pi;         // ELL positions of the point's observation in camera i / j
+    const int* __restrict__ pair_pj;
+    const int2* __restrict__ pair_ij;        // pair index -> (i, j), i < j
+    double* __restrict__ pair_part;          // n_chunks x n_pairs x NP*NP partial blocks (n_chunks > 1)
+    int n_chunks;
+};
+
+// Wave "reduce-scatter": N (power of two) values per lane are summed over the 64 lanes with N - 1 + (6 - log2 N)
+// shuffles instead of 6 N: at every step a lane keeps one half of its values and trades the other half with its
+// partner.  On return v[0] of the lanes with (lane & (64/N - 1)) == 0 ... holds total number rs_index<N>(lane).
+template <int N>
+__device__ inline double wave_reduce_scatter(const double (&v)[N], int lane, int mask) {
+    if constexpr (N == 1) {
+        double t = v[0];
+        for (int m = mask; m > 0; m >>= 1) t += __shfl_xor(t, m);
+        return t;
+    } else {
+        constexpr int H = N / 2;
+        const bool upper = (lane & mask) != 0;
+        double w[H];
+#pragma unroll
+        for (int k = 0; k < H; ++k) {
+            const double keep = upper ? v[k + H] : v[k];
+            const double send = upper ? v[k] : v[k + H];
+            w[k] = keep + __shfl_xor(send, mask);
+        }
+        return wave_reduce_scatter<H>(w, lane, mask >> 1);
+    }
+}
+// index (in 0 .. N-1) of the total a lane ends up with
+template <int N>
+__device__ inline int rs_index(int lane) {
+    int idx = 0, mask = 32;
+    for (int h = N / 2; h >= 1; h >>= 1, mask >>= 1)
+        if (lane & mask) idx += h;
+    return idx;
+}
+
+// grid (pairs / 4, chunks): chunk-major dispatch order, so that the workgroups running at the same time gather point
+// records from the same slice of the point array instead of the whole array; 4 waves per workgroup, one item each.
+// UNITW: every weight is 1 and the loss is linear -- raw Jacobians, nothing is fetched per observation.
+// Otherwise (weighted / robust): unit-weight Jacobians times the row scales k_linearize stored (a.sc) -- the scales multiply
+// the 2 x 2 middle matrix (4 products instead of 32 on the blocks).  RPC: the stored Jacobian blocks are gathered instead
+// of being recomputed (they carry scales and masks).
+template <int MODEL, int NP, bool UNITW>
+__global__ __launch_bounds__(256) void k_schur_pairs(ObsArgs a, SchurArgs s, double* __restrict__ S) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long n_pairs = (long long)a.M * (a.M - 1) / 2;
+    const unsigned pair_u = blockIdx.x * 4u + (unsigned)wave;
+    const int chunk = blockIdx.y;
+    if ((long long)pair_u >= n_pairs) return;
+    const long long pair = pair_u;
+    const int2 ij = s.pair_ij[pair_u];
+    const int i = __builtin_amdgcn_readfirstlane(ij.x);  // wave-uniform by construction: lets the camera constants use scalar loads
+    const int j = __builtin_amdgcn_readfirstlane(ij.y);
+    const double* cci = a.camc + (size_t)i * CAMC;
+    const double* ccj = a.camc + (size_t)j * CAMC;
+
+    double acc[NP][NP];
+#pragma unroll
+    for (int r = 0; r < NP; ++r)
+#pragma unroll
+        for (int q = 0; q < NP; ++q) acc[r][q] = 0.0;
+
+    struct Rec { double2 r0, r1, r2, r3; double r4; };  // packed point record: X0 X1 | X2 v00 | v01 v02 | v11 v12 | v22
+    auto load_rec = [&](int p) {
+        const double2* pv = s.PV + (PV_STRIDE / 2) * (size_t)p;  // four 16-byte gathers and one of 8 instead of nine 8-byte ones
+        Rec r;
+        r.r0 = pv[0]; r.r1 = pv[1]; r.r2 = pv[2]; r.r3 = pv[3]; r.r4 = reinterpret_cast<const double*>(pv + 4)[0];
+        return r;
+    };
+    auto compute = [&](int p, const Rec& rc, int pi, int pj, const double2& scl_i, const double2& scl_j) {
+        const double X = rc.r0.x, Y = rc.r0.y, Z = rc.r1.x;
+        const double v00 = rc.r1.y, v01 = rc.r2.x, v02 = rc.r2.y, v11 = rc.r3.x, v12 = rc.r3.y, v22 = rc.r4;
+        double Jci[2][NP], Jpi[2][3], Jcj[2][NP], Jpj[2][3];
+        if constexpr (MODEL == RPC) {
+            const double2* qi = reinterpret_cast<const double2*>(a.Jpm + (size_t)pi * (2 * NP + 6));
+            const double2* qj = reinterpret_cast<const double2*>(a.Jpm + (size_t)pj * (2 * NP + 6));
+            double ti[2 * NP + 6], tj[2 * NP + 6];
+#pragma unroll
+            for (int k = 0; k < NP + 3; ++k) {
+                const double2 vi = qi[k], vj = qj[k];
+                ti[2 * k] = vi.x; ti[2 * k + 1] = vi.y; tj[2 * k] = vj.x; tj[2 * k + 1] = vj.y;
+            }
+#pragma unroll
+            for (int k = 0; k < NP; ++k) { Jci[0][k] = ti[k]; Jci[1][k] = ti[NP + k]; Jcj[0][k] = tj[k]; Jcj[1][k] = tj[NP + k]; }
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                Jpi[0][k] = ti[2 * NP + k]; Jpi[1][k] = ti[2 * NP + 3 + k];
+                Jpj[0][k] = tj[2 * NP + k]; Jpj[1][k] = tj[2 * NP + 3 + k];
+            }
+        } else {
+            double u, v;
+            project<MODEL, NP, true>(cci, nullptr, X, Y, Z, false, u, v, Jci, Jpi);
+            project<MODEL, NP, true>(ccj, nullptr, X, Y, Z, false, u, v, Jcj, Jpj);
+        }
+        // Mm = Jp_i Vinv Jp_j^T (2 x 2)
+        double A[2][3];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            A[r][0] = Jpi[r][0] * v00 + Jpi[r][1] * v01 + Jpi[r][2] * v02;
+            A[r][1] = Jpi[r][0] * v01 + Jpi[r][1] * v11 + Jpi[r][2] * v12;
+            A[r][2] = Jpi[r][0] * v02 + Jpi[r][1] * v12 + Jpi[r][2] * v22;
+        }
+        double m00 = A[0][0] * Jpj[0][0] + A[0][1] * Jpj[0][1] + A[0][2] * Jpj[0][2];
+        double m01 = A[0][0] * Jpj[1][0] + A[0][1] * Jpj[1][1] + A[0][2] * Jpj[1][2];
+        double m10 = A[1][0] * Jpj[0][0] + A[1][1] * Jpj[0][1] + A[1][2] * Jpj[0][2];
+        double m11 = A[1][0] * Jpj[1][0] + A[1][1] * Jpj[1][1] + A[1][2] * Jpj[1][2];
+        if constexpr (MODEL != RPC) {
+            const double mp = (a.perm[p] >= a.n_pts_fix) ? 1.0 : 0.0;
+            if constexpr (!UNITW) {
+                // row scales s of the two observations (weights, robust loss): both blocks of an observation carry them, so the
+                // pair block is Jc_i^T [diag(s_i^2) (Jp_i Vinv Jp_j^T) diag(s_j^2)] Jc_j
+                const double ax = scl_i.x * scl_i.x * mp, ay = scl_i.y * scl_i.y * mp;
+                const double bx = scl_j.x * scl_j.x, by = scl_j.y * scl_j.y;
+                m00 *= ax * bx; m01 *= ax * by; m10 *= ay * bx; m11 *= ay * by;
+            } else {
+                m00 *= mp; m01 *= mp; m10 *= mp; m11 *= mp;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            const double y0 = m00 * Jcj[0][q] + m01 * Jcj[1][q];
+            const double y1 = m10 * Jcj[0][q] + m11 * Jcj[1][q];
+#pragma unroll
+            for (int r = 0; r < NP; ++r) acc[r][q] = fma(-Jci[0][r], y0, fma(-Jci[1][r], y1, acc[r][q]));
+        }
+    };
+
+    {
+        const int C1 = s.n_chunks + 1;
+        const long long lo = s.pair_ofs[pair * C1 + chunk], hi = s.pair_ofs[pair * C1 + chunk + 1];
+        // software pipeline: the next point's index and record are in flight while the current one is evaluated
+        constexpr bool POS = !UNITW || MODEL == RPC;  // positions (and, weighted / robust, scales) ride along
+        constexpr bool SCL = !UNITW && MODEL != RPC;
+        long long idx = lo + lane;
+        auto ld = [&](const int* arr, long long k) { return (k < hi) ? arr[k] : 0; };
+        int p_cur = ld(s.pair_pts, idx), p_nxt = ld(s.pair_pts, idx + 64);
+        int pi_cur = 0, pj_cur = 0, pi_nxt = 0, pj_nxt = 0;
+        double2 si_cur = make_double2(1.0, 1.0), sj_cur = si_cur;
+        if constexpr (POS) {
+            pi_cur = ld(s.pair_pi, idx); pj_cur = ld(s.pair_pj, idx);
+            pi_nxt = ld(s.pair_pi, idx + 64); pj_nxt = ld(s.pair_pj, idx + 64);
+            if constexpr (SCL) { si_cur = a.sc[pi_cur]; sj_cur = a.sc[pj_cur]; }
+        }
+        Rec r_cur = load_rec(p_cur);
+        while (idx < hi) {
+            // indices run two iterations ahead, records one: neither latency is on the critical path
+            const int p_nn = ld(s.pair_pts, idx + 128);
+            int pi_nn = 0, pj_nn = 0;
+            double2 si_nxt = make_double2(1.0, 1.0), sj_nxt = si_nxt;
+            if constexpr (POS) {
+                pi_nn = ld(s.pair_pi, idx + 128); pj_nn = ld(s.pair_pj, idx + 128);
+                if constexpr (SCL) { si_nxt = a.sc[pi_nxt]; sj_nxt = a.sc[pj_nxt]; }
+            }
+            const Rec r_nxt = load_rec(p_nxt);
+            // keep the gathers above the arithmetic: without the barrier the scheduler sinks them below compute() to
+            // save registers and every iteration pays the full memory latency
+            __builtin_amdgcn_sched_barrier(0);
+            compute(p_cur, r_cur, pi_cur, pj_cur, si_cur, sj_cur);
+            __builtin_amdgcn_sched_barrier(0);
+            p_cur = p_nxt; p_nxt = p_nn; r_cur = r_nxt;
+            pi_cur = pi_nxt; pj_cur = pj_nxt; pi_nxt = pi_nn; pj_nxt = pj_nn;
+            si_cur = si_nxt; sj_cur = sj_nxt;
+            idx += 64;
+        }
+    }
+
+    // wave reduction of the NP x NP block; block (row j, col i) of the column-major lower triangle
+    constexpr int NB2 = NP * NP;
+    constexpr int NPAD = NB2 <= 16 ? 16 : (NB2 <= 32 ? 32 : 64);
+    double flat[NPAD];
+#pragma unroll
+    for (int e = 0; e < NPAD; ++e) flat[e] = (e < NB2) ? acc[e / NP][e % NP] : 0.0;
+    // fixed-camera masks (RPC: the stored blocks carry them)
+    const double cam_mask = (MODEL != RPC && (i < a.n_cam_fix || j < a.n_cam_fix)) ? 0.0 : 1.0;
+    const double total = cam_mask * wave_reduce_scatter<NPAD>(flat, lane, 32);
+    const int e = rs_index<NPAD>(lane);
+    const bool writer = (lane & (64 / NPAD - 1)) == 0 && e < NB2;  // one lane per total (NPAD = 64: every lane)
+    if (writer) {
+        const int r = e / NP, q = e % NP;
+        if (s.n_chunks > 1) s.pair_part[((size_t)chunk * n_pairs + pair) * NB2 + e] = total;
+        else S[(size_t)(j * NP + q) + (size_t)(i * NP + r) * a.n_c] = total;  // S[(j,q), (i,r)] = (W_i Vinv W_j^T)[r][q]
+    }
+}
+
+// several point-range chunks: S block of each pair = sum of its chunk partials (chunk order: repeatable)
+__global__ __launch_bounds__(256) void k_schur_pairs_reduce(int M, int NP, int n_c, int n_chunks, const int2* __restrict__ pair_ij,
+                                                            const double* __restrict__ part, double* __restrict__ S) {
+    const long long n_pairs = (long long)M * (M - 1) / 2;
+    const int NB2 = NP * NP;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_pairs * NB2) return;
+    const long long pair = idx / NB2;
+    const int e = (int)(idx % NB2);
+    double t = 0.0;
+    for (int ch = 0; ch < n_chunks; ++ch) t += part[((size_t)ch * n_pairs + pair) * NB2 + e];
+    const int2 ij = pair_ij[pair];
+    const int r = e / NP, q = e % NP;
+    S[(size_t)(ij.y * NP + q) + (size_t)(ij.x * NP + r) * n_c] = t;
+}
+
+// Diagonal blocks and right-hand side: camera-major pass, registers only.
+//   S_ii += sum_p (Jc^T Jc - W_ip Vinv W_ip^T),   rhs_i -= sum_p W_ip Vinv g_p.   grid (M, chunks); part [M][chunks][CU]
+// The J_c^T J_c term is the U_c block, which the linearize kernel therefore does not have to accumulate.
+// grid (M, chunks): the workgroups of one chunk (the same slice of every camera's point-sorted list, i.e. about the same
+// point range) are dispatched together and share their point records in L2.
+template <int MODEL, int NP>
+__global__ __launch_bounds__(LINC_THREADS) void k_schur_diag(ObsArgs a, CamMajor c, SchurArgs s, double* __restrict__ part) {
+    constexpr int CU = cam_acc_len(NP);
+    const int cam = blockIdx.x, chunk = blockIdx.y, n_chunks = gridDim.y;
+    const int b = c.cam_ofs[cam], e = c.cam_ofs[cam + 1];
+    const long long len = e - b;
+    const int lo = b + (int)(len * chunk / n_chunks), hi = b + (int)(len * (chunk + 1) / n_chunks);
+    const double* cc = a.camc + (size_t)cam * CAMC;
+    double acc[CU];
+#pragma unroll
+    for (int k = 0; k < CU; ++k) acc[k] = 0.0;
+    // Software pipeline: point indices run two iterations ahead, the 128-byte point records one (the loop was a chain
+    // of two dependent gathers per iteration, ~18 iterations per thread).
+    struct Rec { double2 r0, r1, r2, r3, r4, r5; };
+    auto load_rec = [&](int p) {
+        const double2* pv = s.PV + (PV_STRIDE / 2) * (size_t)p;
+        Rec r;
+        r.r0 = pv[0]; r.r1 = pv[1]; r.r2 = pv[2]; r.r3 = pv[3]; r.r4 = pv[4]; r.r5 = pv[5];
+        return r;
+    };
+    auto ldp = [&](int q) { return q < hi ? c.pt[q] : 0; };
+    int pos = lo + threadIdx.x;
+    int p_cur = ldp(pos), p_nxt = ldp(pos + LINC_THREADS);
+    Rec rc = load_rec(p_cur);
+    for (; pos < hi; pos += LINC_THREADS) {
+        const int p_nn = ldp(pos + 2 * LINC_THREADS);
+        const Rec rn = load_rec(p_nxt);
+        __builtin_amdgcn_sched_barrier(0);
+        const int p = p_cur;
+        const double2 r0 = rc.r0, r1 = rc.r1, r2 = rc.r2, r3 = rc.r3, r4 = rc.r4, r5 = rc.r5;
+        p_cur = p_nxt; p_nxt = p_nn; rc = rn;
+        double Jc[2][NP], Jp[2][3];
+        double sx = 1.0, sy = 1.0;  // squared row scales times the fixed-point mask, applied to the 2 x 2 middle matrix
+        double ux = 1.0, uy = 1.0;  // squared row scales on the J_c^T J_c term (no point mask there)
+        if constexpr (MODEL == RPC) {  // the blocks the linearize kernel stored (scales and masks included)
+            ObsEval<MODEL, NP, true> e2;
+            e2.load_jac(a, c.pos[pos]);
+#pragma unroll
+            for (int k = 0; k < NP; ++k) { Jc[0][k] = e2.Jc[0][k]; Jc[1][k] = e2.Jc[1][k]; }
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { Jp[0][k] = e2.Jp[0][k]; Jp[1][k] = e2.Jp[1][k]; }
+        } else {
+            double u, v;
+            project<MODEL, NP, true>(cc, nullptr, r0.x, r0.y, r1.x, false, u, v, Jc, Jp);
+            const double mp = (a.perm[p] >= a.n_pts_fix) ? 1.0 : 0.0;
+            if (a.sc) { const double2 t = a.sc[c.pos[pos]]; ux = t.x * t.x; uy = t.y * t.y; }
+            sx = ux * mp; sy = uy * mp;
+        }
+        const double v00 = r1.y, v01 = r2.x, v02 = r2.y, v11 = r3.x, v12 = r3.y, v22 = r4.x;
+        double A[2][3];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            A[r][0] = Jp[r][0] * v00 + Jp[r][1] * v01 + Jp[r][2] * v02;
+            A[r][1] = Jp[r][0] * v01 + Jp[r][1] * v11 + Jp[r][2] * v12;
+            A[r][2] = Jp[r][0] * v02 + Jp[r][1] * v12 + Jp[r][2] * v22;
+        }
+        // W Vinv W^T = Jc^T [diag(s) Jp Vinv Jp^T diag(s)] Jc with s = row scale^2 (both blocks carry the row scale) -- one more
+        // factor s on each side comes from Jc: (s_r Jp_r) Vinv (s_q Jp_q)^T sandwiched by (s Jc)
+        const double m00 = sx * ux * (A[0][0] * Jp[0][0] + A[0][1] * Jp[0][1] + A[0][2] * Jp[0][2]);
+        const double m01 = sx * uy * (A[0][0] * Jp[1][0] + A[0][1] * Jp[1][1] + A[0][2] * Jp[1][2]);
+        const double m11 = sy * uy * (A[1][0] * Jp[1][0] + A[1][1] * Jp[1][1] + A[1][2] * Jp[1][2]);
+        // rhs: W Vinv g_p = Jc^T diag(s) Jp Vinv g_p
+        const double ag0 = sx * (A[0][0] * r4.y + A[0][1] * r5.x + A[0][2] * r5.y);
+        const double ag1 = sy * (A[1][0] * r4.y + A[1][1] * r5.x + A[1][2] * r5.y);
+        int k = 0;
+#pragma unroll
+        for (int r = 0; r < NP; ++r) {
+            const double y0 = m00 * Jc[0][r] + m01 * Jc[1][r];
+            const double y1 = m01 * Jc[0][r] + m11 * Jc[1][r];
+#pragma unroll
+            for (int q = r; q < NP; ++q) {
+                acc[k] -= Jc[0][q] * y0 + Jc[1][q] * y1;
+                acc[k] += ux * Jc[0][r] * Jc[0][q] + uy * Jc[1][r] * Jc[1][q];
+                ++k;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < NP; ++r) acc[k++] -= Jc[0][r] * ag0 + Jc[1][r] * ag1;
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (MODEL != RPC && cam < a.n_cam_fix) {  // fixed camera (block-uniform); RPC: the stored blocks carry the mask
+#pragma unroll
+        for (int k = 0; k < CU; ++k) acc[k] = 0.0;
+    }
+    __shared__ double s_red[LINC_THREADS / 64][CU];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < CU; ++k) {
+        const double t = wave_sum(acc[k]);
+        if (lane == 0) s_red[wave][k] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x < CU) {
+        double t = 0.0;
+        for (int wv = 0; wv < LINC_THREADS / 64; ++wv) t += s_red[wv][threadIdx.x];
+        part[((size_t)cam * n_chunks + chunk) * CU + threadIdx.x] = t;
+    }
+}
+
+// S_ii (lower incl. diagonal, both triangles of the block are written) and rhs_i += chunk partials
+__global__ void k_schur_diag_finish(int M, int NP, int n_c, int n_chunks, const double* __restrict__ part,
+                                    double* __restrict__ S, double* __restrict__ rhs) {
+    const int CU = cam_acc_len(NP);
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= M * CU) return;
+    const int cam = idx / CU, k = idx % CU;
+    double t = 0.0;
+    for (int ch = 0; ch < n_chunks; ++ch) t += part[((size_t)cam * n_chunks + ch) * CU + k];
+    const int ntri = NP * (NP + 1) / 2;
+    if (k >= ntri) {
+        rhs[cam * NP + (k - ntri)] += t;
+        return;
+    }
+    int r = 0, rem = k;
+    while (rem >= NP - r) { rem -= NP - r; ++r; }
+    const int q = r + rem;
+    S[(size_t)(cam * NP + q) + (size_t)(cam * NP + r) * n_c] += t;
+    if (q != r) S[(size_t)(cam * NP + r) + (size_t)(cam * NP + q) * n_c] += t;
+}
+
+}  // namespace satba

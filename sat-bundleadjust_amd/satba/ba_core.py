@@ -227,7 +227,7 @@ def compute_reprojection_error(residuals, pts2d_w=None):
     r = np.asarray(residuals).reshape(-1, 2)
     if pts2d_w is not None:
         r = r / np.asarray(pts2d_w)[:, None]
-    return np.hypot(r[:, 0], r[:, 1])
+    return np.sqrt(r[:, 0] * r[:, 0] + r[:, 1] * r[:, 1])  # the reference's operations, bit for bit (not np.hypot)
 
 
 def compute_mean_reprojection_error_per_track(err, pts_ind, cam_ind):

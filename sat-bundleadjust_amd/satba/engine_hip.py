@@ -30,7 +30,22 @@ SYMBOLS = [
     "satba_accept", "satba_read_header", "satba_get_blocks", "satba_get_jacobian", "satba_get_exchange",
     "satba_set_exchange", "satba_get_vector", "satba_time_kernel",
     "satba_packed_schur_len", "satba_pack_schur", "satba_unpack_schur",
+    "satba_solve_lm", "satba_outliers", "satba_layout_len", "satba_get_layout", "satba_get_info",
 ]
+
+FLAG_DETERMINISTIC = 1
+LAYOUT = {"perm": 0, "rank": 1, "pt_cnt": 2, "slice_base": 3, "e_cam": 4, "obs_pos": 5, "cam_ofs": 6, "cm_pt": 7, "cm_pos": 8,
+          "pair_ofs": 9, "pair_pts": 10, "pair_pi": 11, "pair_pj": 12, "pair_ij": 13}
+
+
+class LmOpts(C.Structure):
+    _fields_ = [("ftol", C.c_double), ("xtol", C.c_double), ("gtol", C.c_double), ("f_scale", C.c_double),
+                ("max_nfev", C.c_int64), ("loss", C.c_int32), ("verbose", C.c_int32)]
+
+
+class LmStats(C.Structure):
+    _fields_ = [("cost", C.c_double), ("initial_cost", C.c_double), ("optimality", C.c_double),
+                ("nfev", C.c_int64), ("njev", C.c_int64), ("iterations", C.c_int64), ("status", C.c_int32), ("reserved", C.c_int32)]
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int32)
@@ -40,7 +55,7 @@ class ProblemDesc(C.Structure):
     _fields_ = [
         ("cam_model", C.c_int32), ("n_cam", C.c_int32), ("n_pts", C.c_int32), ("n_params", C.c_int32),
         ("cam_param_len", C.c_int32), ("n_cam_fix", C.c_int32), ("n_pts_fix", C.c_int32), ("rank", C.c_int32),
-        ("world", C.c_int32), ("rpc_store_f32", C.c_int32), ("device", C.c_int32), ("reserved", C.c_int32),
+        ("world", C.c_int32), ("rpc_store_f32", C.c_int32), ("device", C.c_int32), ("flags", C.c_int32),
         ("n_obs", C.c_int64), ("n_total", C.c_int64),
         ("cam_params", _dp), ("rpc_tables", _dp), ("cam_ind", _ip), ("pts_ind", _ip), ("pts2d", _dp), ("weights", _dp),
     ]
@@ -98,6 +113,12 @@ def load_library(path=None):
     lib.satba_unpack_schur.argtypes = [h, C.c_void_p]
     lib.satba_get_vector.argtypes = [h, C.c_int32, _dp]
     lib.satba_time_kernel.argtypes = [h, C.c_int32, C.c_int32, C.POINTER(C.c_float)]
+    lib.satba_solve_lm.argtypes = [h, C.POINTER(LmOpts), C.POINTER(LmStats)]
+    lib.satba_outliers.argtypes = [h, _dp, C.c_double, C.c_double, _dp, C.POINTER(C.c_uint8), C.POINTER(C.c_int64)]
+    lib.satba_layout_len.argtypes = [h, C.c_int32]
+    lib.satba_layout_len.restype = C.c_int64
+    lib.satba_get_layout.argtypes = [h, C.c_int32, C.c_int64, C.c_void_p]
+    lib.satba_get_info.argtypes = [h, _dp, C.c_int32]
     if path == LIB_PATH:
         _LIB = lib
     return lib
@@ -125,7 +146,7 @@ class HipEngine:
 
     HDR_FIXED = HDR_FIXED
 
-    def __init__(self, p, shard=None, device=None, rpc_f32=True, use_torch=None):
+    def __init__(self, p, shard=None, device=None, rpc_f32=True, use_torch=None, deterministic=False):
         self.lib = load_library()
         self.p = p
         self.shard = shard or Shard(p)
@@ -163,7 +184,8 @@ class HipEngine:
         d = ProblemDesc(
             cam_model=CAM_MODELS[p.cam_model], n_cam=p.n_cam, n_pts=sh.n_pts, n_params=p.n_params,
             cam_param_len=cam_params.shape[1], n_cam_fix=int(p.n_cam_fix), n_pts_fix=sh.n_pts_fix, rank=sh.rank,
-            world=sh.world, rpc_store_f32=int(bool(rpc_f32)), device=self.device, reserved=0, n_obs=self.n_obs,
+            world=sh.world, rpc_store_f32=int(bool(rpc_f32)), device=self.device,
+            flags=FLAG_DETERMINISTIC if deterministic else 0, n_obs=self.n_obs,
             n_total=self.n_total, cam_params=_ptr(cam_params), rpc_tables=_ptr(rpc) if rpc is not None else None,
             cam_ind=_ptr(cam_ind, _ip), pts_ind=_ptr(pts_ind, _ip), pts2d=_ptr(pts2d), weights=_ptr(w))
         self._h = C.c_void_p()
@@ -273,7 +295,49 @@ class HipEngine:
     def accept(self):
         _check(self.lib, self.lib.satba_accept(self._h))
 
+    # -- whole solve below the ABI (single rank)
+    def solve_lm(self, ftol=1e-8, xtol=1e-8, gtol=1e-8, max_nfev=None, loss="linear", f_scale=1.0, verbose=0):
+        """satba_solve_lm: the loop of satba/trf.py in C++; returns the LmStats structure."""
+        if loss not in LOSSES:
+            raise ValueError("`loss` must be one of {}".format(list(LOSSES)))
+        o = LmOpts(ftol=ftol, xtol=xtol, gtol=gtol, f_scale=f_scale, max_nfev=-1 if max_nfev is None else int(max_nfev),
+                   loss=LOSSES[loss], verbose=int(verbose))
+        st = LmStats()
+        _check(self.lib, self.lib.satba_solve_lm(self._h, C.byref(o), C.byref(st)))
+        return st
+
+    def outliers(self, err=None, predef_thr=None, min_thr=1.0):
+        """
+        Per-camera elbow thresholds and the observations above them (ref:bundle_adjust/ba_outliers.py:112-155) for the errors
+        `err` (caller's observation order; None: the reprojection errors at the current x).  Returns (cam_thr (M,),
+        remove (K,) bool, n_removed).
+        """
+        thr = np.empty(self.n_cam)
+        rm = np.zeros(max(self.n_obs, 1), dtype=np.uint8)
+        n = C.c_int64()
+        e = None if err is None else np.ascontiguousarray(err, dtype=np.float64)
+        if e is not None and e.size != self.n_obs:
+            raise ValueError("err has {} entries, expected {}".format(e.size, self.n_obs))
+        _check(self.lib, self.lib.satba_outliers(self._h, _ptr(e) if e is not None else None, -1.0 if predef_thr is None else float(predef_thr),
+                                                 float(min_thr), _ptr(thr), rm.ctypes.data_as(C.POINTER(C.c_uint8)), C.byref(n)))
+        return thr, rm[: self.n_obs].astype(bool), int(n.value)
+
     # -- inspection (parity tests)
+    def get_layout(self, name):
+        """One of the index structures satba_problem_create built on the device (csrc/satba_layout.h), as a numpy array."""
+        which = LAYOUT[name]
+        n = int(self.lib.satba_layout_len(self._h, which))
+        out = np.empty(n, dtype=np.int64 if name == "pair_ofs" else np.int32)
+        _check(self.lib, self.lib.satba_get_layout(self._h, which, n, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def info(self):
+        v = np.zeros(16)
+        _check(self.lib, self.lib.satba_get_info(self._h, _ptr(v), 16))
+        keys = ["ms_uploads", "ms_sizes", "ms_ell", "ms_pairs", "ms_create", "ell_len", "pair_entries", "pair_chunks", "unit_weights",
+                "camc_lds", "rpc_lds", "cam_sums_lds", "deterministic", "cm_chunks", "lin_grid"]
+        return dict(zip(keys, v[: len(keys)]))
+
     def get_blocks(self):
         U = np.empty((self.n_cam, self.n_p, self.n_p))
         gc = np.empty((self.n_cam, self.n_p))

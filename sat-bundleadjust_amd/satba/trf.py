@@ -290,12 +290,28 @@ def subspace_model(engine, exchange, ga, gb, gc, jg_sq, reg):
 # ----------------------------------------------------------------------------- the loop
 
 def trf_solve(engine, comm=None, ftol=1e-8, xtol=1e-8, gtol=1e-8, max_nfev=None, loss="linear", f_scale=1.0,
-              verbose=0, timers=None):
+              verbose=0, timers=None, native=None):
     """
     Run the loop on `engine` from its current x.  Returns a Result; the solution stays in the engine
     (engine.get_x(), engine.residuals()).  `timers`, if a dict, accumulates per-phase call counts.
+
+    native: run the same loop below the C ABI (satba_solve_lm, csrc/satba_capi.hip) instead of in Python -- the default for a
+    single rank when the engine offers it and no iteration table is requested (verbose < 2); with several ranks the
+    all-reduces between the phases are issued from here.
     """
     comm = comm or SingleComm()
+    if native is None:
+        native = comm.world == 1 and not getattr(comm, "always", False) and verbose < 2 and hasattr(engine, "solve_lm")
+    if native:
+        st = engine.solve_lm(ftol=ftol, xtol=xtol, gtol=gtol, max_nfev=max_nfev, loss=loss, f_scale=f_scale, verbose=0)
+        res = Result(cost=st.cost, optimality=st.optimality, nfev=int(st.nfev), njev=int(st.njev), status=int(st.status),
+                     success=st.status > 0, message=TERMINATION_MESSAGES[int(st.status)], iterations=int(st.iterations),
+                     initial_cost=st.initial_cost)
+        if verbose >= 1:
+            print(res.message)
+            print("Function evaluations {}, initial cost {:.4e}, final cost {:.4e}, first-order optimality {:.2e}."
+                  .format(res.nfev, res.initial_cost, res.cost, res.optimality))
+        return res
     hdr = engine.hdr
     slots = slice(engine.HDR_FIXED, engine.HDR_FIXED + comm.world)
     if max_nfev is None:

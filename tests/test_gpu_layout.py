@@ -1,0 +1,211 @@
+"""
+Round-2 components, through the C ABI on the GPU:
+  * the index structures satba_problem_create builds ON THE DEVICE (csrc/satba_layout.h: track-length-sorted sliced ELL,
+    camera-major lists, per-camera-pair lists) against a numpy restatement -- integer work: bit-exact;
+  * satba_solve_lm (the trust-region loop in C++) against the Python loop of satba/trf.py: same nfev, status, x;
+  * satba_outliers against vectors captured from ref:bundle_adjust/ba_outliers.py (tests/golden/outliers.npz): thresholds
+    equal, removed set index-exact;
+  * SATBA_FLAG_DETERMINISTIC: bitwise-repeatable runs;
+  * a pipeline-shaped driver through the drop-in names only (ref:bundle_adjust/ba_pipeline.py:700-728).
+"""
+import numpy as np
+import pytest
+
+import cases
+from oracle import ba_oracle as O
+from satba import ba_core, ba_outliers, synth, trf
+from satba.engine_hip import HipEngine
+
+pytestmark = pytest.mark.gpu
+
+
+def numpy_layout(p, C):
+    """The structures of csrc/satba_layout.h restated with numpy (the 'host builder' the device is checked against)."""
+    N, M, K = p.n_pts, p.n_cam, p.n_obs
+    pts, cam = p.pts_ind.astype(np.int64), p.cam_ind.astype(np.int64)
+    cnt = np.bincount(pts, minlength=N)
+    perm = np.argsort(cnt, kind="stable")
+    rank = np.empty(N, dtype=np.int64)
+    rank[perm] = np.arange(N)
+    pt_cnt = cnt[perm]
+    n_slices = (N + 63) // 64
+    last = np.minimum(64 * np.arange(n_slices) + 63, N - 1)
+    slice_base = np.concatenate(([0], np.cumsum(64 * pt_cnt[last])))
+    ofs = np.searchsorted(pts, np.arange(N + 1))
+    k = np.arange(K) - ofs[pts]
+    q = rank[pts]
+    pos = slice_base[q >> 6] + 64 * k + (q & 63)
+    e_cam = np.full(slice_base[-1], -1, dtype=np.int64)
+    e_cam[pos] = cam
+    order = np.lexsort((q, cam))  # camera-major, internal point ascending
+    out = dict(perm=perm, rank=rank, pt_cnt=pt_cnt, slice_base=slice_base, e_cam=e_cam, obs_pos=pos, cm_pt=q[order], cm_pos=pos[order],
+               cam_ofs=np.searchsorted(cam[order], np.arange(M + 1)))
+    # pair lists: all camera pairs of every point in internal point order, stable sort by pair index
+    io = np.lexsort((k, q))  # internal point-major
+    keys, hq, hpi, hpj = [], [], [], []
+    b = 0
+    for n in pt_cnt[pt_cnt > 0]:
+        cs, ps, qq = cam[io[b: b + n]], pos[io[b: b + n]], q[io[b]]
+        for x in range(n):
+            for y in range(x + 1, n):
+                keys.append(cs[x] * M - cs[x] * (cs[x] + 1) // 2 + (cs[y] - cs[x] - 1))
+                hq.append(qq); hpi.append(ps[x]); hpj.append(ps[y])
+        b += n
+    keys, hq, hpi, hpj = (np.array(a, dtype=np.int64) for a in (keys, hq, hpi, hpj))
+    s = np.argsort(keys, kind="stable")
+    n_pairs = M * (M - 1) // 2
+    comp = keys[s] * (C + 1) + hq[s] * C // N
+    out.update(pair_pts=hq[s], pair_pi=hpi[s], pair_pj=hpj[s], pair_ofs=np.searchsorted(comp, np.arange(n_pairs * (C + 1) + 1)),
+               pair_ij=np.array([(i, j) for i in range(M) for j in range(i + 1, M)]).ravel())
+    return out
+
+
+@pytest.mark.parametrize("model,M,N,opp,seed", [("affine", 9, 3000, 4, 3), ("affine", 70, 200, 68, 5), ("rpc", 3, 100, 2, 7),
+                                                ("perspective", 5, 64, 3, 1), ("affine", 2, 1, 2, 2)])
+def test_device_layout_is_bit_exact(gpu, model, M, N, opp, seed):
+    scene = synth.make_scene(model, M, N, opp, seed=seed)
+    p = synth.make_params(scene, {"correction_params": ["R"], "n_cam_fix": 1})
+    eng = HipEngine(p)
+    info = eng.info()
+    want = numpy_layout(p, int(info["pair_chunks"]))
+    assert info["ell_len"] == want["slice_base"][-1] and info["pair_entries"] == want["pair_pts"].size
+    for name, ref in want.items():
+        got = eng.get_layout(name)
+        assert got.shape == ref.shape and np.array_equal(got, ref), name
+    # a point with more than 64 observations is nothing special in this layout (round 1 had a split-tile path)
+    assert model != "affine" or M < 70 or np.bincount(p.pts_ind).max() > 64
+    eng.close()
+
+
+def test_layout_rejects_unsorted_cameras(gpu):
+    scene = synth.make_affine_scene(4, 30, 3, seed=1)
+    p = synth.make_params(scene, {"correction_params": ["R"]})
+    p.cam_ind = p.cam_ind.copy()
+    first = np.nonzero(np.diff(p.pts_ind) == 0)[0][0]
+    p.cam_ind[[first, first + 1]] = p.cam_ind[[first + 1, first]]  # cameras of one point descending
+    with pytest.raises(ValueError):
+        HipEngine(p)
+    p.cam_ind[first] = 99
+    with pytest.raises(ValueError):
+        HipEngine(p)
+
+
+@pytest.mark.parametrize("name,loss", [("affine_small_R", "linear"), ("affine_small_R", "soft_l1"), ("persp_small_RT", "linear"),
+                                       ("affine_C2_R", "linear")])
+@pytest.mark.parametrize("tight", [True, False])
+def test_solve_lm_matches_python_loop(gpu, name, loss, tight):
+    """satba_solve_lm (C++) against satba/trf.py (Python): the same scalars drive the same decisions."""
+    _, make_p, g, _ = cases.solve_case(name)
+    tol = dict(ftol=1e-15, xtol=1e-15, gtol=1e-15) if tight else dict(ftol=1e-4, xtol=1e-10, gtol=1e-8)
+    outs = []
+    for native in (False, True):
+        p = make_p()
+        eng = HipEngine(p, deterministic=True)  # bitwise-repeatable sums: the two loops see identical scalars
+        res = trf.trf_solve(eng, max_nfev=300, loss=loss, native=native, **tol)
+        outs.append((res, eng.get_x()))
+        eng.close()
+    (ra, xa), (rb, xb) = outs
+    assert ra.nfev == rb.nfev and ra.status == rb.status and ra.njev == rb.njev and ra.iterations == rb.iterations
+    assert abs(ra.cost - rb.cost) <= 1e-14 * ra.cost
+    assert np.abs(xa - xb).max() <= 1e-12 * np.abs(xa).max()
+
+
+def test_solve_lm_rejects_multi_rank_handles_and_bad_loss(gpu):
+    from satba import sharding
+
+    _, make_p, _, _ = cases.solve_case("affine_small_R")
+    p = make_p()
+    eng = HipEngine(p, sharding.make_shard(p, 0, 2))
+    with pytest.raises(ValueError):
+        eng.solve_lm()
+    with pytest.raises(ValueError):
+        eng.solve_lm(loss="nope")
+    eng.close()
+
+
+@pytest.mark.parametrize("name,M,N,opp", [("a", 6, 600, 4), ("b", 12, 1500, 5), ("c", 3, 40, 2)])
+def test_outliers_match_reference(gpu, name, M, N, opp):
+    """Thresholds and removed set of ref:bundle_adjust/ba_outliers.py:112-155 -- index-exact (golden from the reference)."""
+    g = cases.golden("outliers")
+    scene = synth.make_affine_scene(M, N, opp, seed=13, sigma_theta=2e-6)
+    p = synth.make_params(scene, {"correction_params": ["R"], "n_cam_fix": 0, "reduce": False}, dense=True)
+    p.pts2d = g[name + "_pts2d"].copy()
+    # (1) errors handed in: the reference's own vector
+    remove, cam_thr, n = ba_outliers.compute_obs_mask(g[name + "_err"], p)
+    assert np.array_equal(np.array(cam_thr), g[name + "_cam_thr"])
+    assert n == int(g[name + "_n"]) and np.array_equal(remove, g[name + "_removed"])
+    C_new, thr2, n2 = ba_outliers.compute_obs_to_remove(g[name + "_err"], p)
+    assert n2 == n and np.array_equal(np.isnan(C_new[2 * p.cam_ind, p.pts_ind]), g[name + "_removed"])
+    # (2) errors computed on the device from the residuals at the current x
+    eng = ba_core.get_engine(p)
+    eng.configure("linear", 1.0)
+    eng.set_x(ba_core._frozen_vars(p.params_opt.copy(), p))
+    thr_d, rm_d, n_d = eng.outliers()
+    assert np.array_equal(thr_d, g[name + "_cam_thr"]) and n_d == n and np.array_equal(rm_d, g[name + "_removed"])
+    # (3) predefined threshold
+    rm3, thr3, _ = ba_outliers.compute_obs_mask(g[name + "_err"], p, predef_thr=3.14159)
+    assert np.array_equal(np.array(thr3), g[name + "_thr_predef"]) and np.array_equal(rm3, g[name + "_removed_predef"])
+
+
+@pytest.mark.parametrize("loss", ["linear", "soft_l1"])
+def test_deterministic_runs_repeat_bitwise(gpu, loss):
+    """SATBA_FLAG_DETERMINISTIC: every reduction has a fixed order -- two handles, two runs, identical bits."""
+    scene = synth.make_affine_scene(12, 4000, 5, seed=4, sigma_theta=2e-5)
+    xs, costs = [], []
+    for _ in range(2):
+        p = synth.make_params(scene, {"correction_params": ["R", "T"], "n_cam_fix": 1})
+        eng = HipEngine(p, deterministic=True)
+        assert eng.info()["deterministic"] == 1 and eng.info()["cam_sums_lds"] == 0
+        res = trf.trf_solve(eng, ftol=1e-10, xtol=1e-12, gtol=1e-12, max_nfev=40, loss=loss)
+        xs.append(eng.get_x())
+        costs.append((res.cost, res.nfev, res.optimality))
+        eng.close()
+    assert costs[0] == costs[1] and np.array_equal(xs[0], xs[1])
+    # and it is the same minimiser the default (LDS-atomic) path finds
+    p = synth.make_params(scene, {"correction_params": ["R", "T"], "n_cam_fix": 1})
+    eng = HipEngine(p)
+    res = trf.trf_solve(eng, ftol=1e-10, xtol=1e-12, gtol=1e-12, max_nfev=40, loss=loss)
+    assert abs(res.cost - costs[0][0]) < 1e-9 * res.cost
+    eng.close()
+
+
+def test_pipeline_shaped_driver_through_dropin_names(gpu, tmp_path):
+    """
+    ref:bundle_adjust/ba_pipeline.py:700-728 with the modules swapped for this package's: define_ba_parameters ->
+    run_ba_softL1 -> clean_outlier_observations -> run_ba_L2 -> reconstruct_vars -> save_debug_figures, default options
+    (save_figures=True, clean_outliers=True).
+    """
+    import matplotlib
+
+    matplotlib.use("Agg")
+    from satba import ba_params, geo_utils
+
+    scene = synth.make_affine_scene(8, 2500, 5, seed=6, sigma_theta=2e-6, pts_float32=True)
+    rng = np.random.default_rng(0)
+    bad = rng.random(scene.n_obs) < 0.02
+    scene.pts2d[bad] += rng.normal(0, 30.0, (int(bad.sum()), 2))
+    C = scene.to_dense_C()
+    scene.pairs_to_triangulate = [(i, j) for i in range(8) for j in range(i + 1, 8)]  # every pair has enough baseline
+    d = {"n_cam_fix": 0, "n_pts_fix": 0, "ref_cam_weight": 1.0, "correction_params": ["R"], "verbose": False}
+    p = ba_params.BundleAdjustmentParameters(C, scene.pts3d, scene.cameras, "affine", scene.pairs_to_triangulate, scene.camera_centers, d)
+    ba_iters = 0
+    _, ba_sol, init_e, ba_e, iters = ba_core.run_ba_optimization(p, {"loss": "soft_l1", "f_scale": 1.0, "max_iter": 300, "verbose": 0}, False, False)
+    ba_iters += iters
+    n_before = p.n_obs
+    pts3d_now, _ = p.reconstruct_vars(ba_sol, scene.pts3d, scene.cameras)
+    p = ba_outliers.rm_outliers(ba_e, p, verbose=False, pts3d=pts3d_now[p.pts_prev_indices] if len(pts3d_now) != p.n_pts else pts3d_now)
+    removed = n_before - p.n_obs
+    assert 0.5 * bad.sum() < removed < 3 * bad.sum() + 50  # the injected gross errors (and little else) are gone
+    _, ba_sol, init_e2, ba_e, iters = ba_core.run_ba_optimization(p, None, False, False)
+    ba_iters += iters
+    corrected_pts3d, corrected_cameras = p.reconstruct_vars(ba_sol, scene.pts3d, scene.cameras)
+    assert ba_e.mean() < 0.5 and len(corrected_cameras) == 8 and len(p.estimated_params) == 8
+    ba_core.save_histogram_of_errors(str(tmp_path / "ba_figures" / "error_histograms.png"), init_e, ba_e)
+    lat, lon, _ = geo_utils.ecef_to_latlon_custom(*np.asarray(scene.pts3d, dtype=np.float64).T)
+    box = [[lon.min(), lat.min()], [lon.max(), lat.min()], [lon.max(), lat.max()], [lon.min(), lat.max()], [lon.min(), lat.min()]]
+    fp = [{"type": "Polygon", "coordinates": [box]}]
+    for tag, e in (("before", init_e2), ("after", ba_e)):
+        path = tmp_path / "ba_figures" / "error_{}.png".format(tag)
+        ba_core.save_heatmap_of_reprojection_error(str(path), p, e, fp, None, smooth=2, global_transform=None)
+        assert path.stat().st_size > 1000
+    assert (tmp_path / "ba_figures" / "error_histograms.png").stat().st_size > 1000 and ba_iters > 2

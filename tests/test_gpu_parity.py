@@ -390,7 +390,7 @@ def test_rpc_pipeline_sequence_config1(gpu):
 # ----------------------------------------------------------------------------- edge cases
 
 def test_points_with_more_than_64_observations(gpu):
-    """Tracks longer than a wavefront take the split-tile path (global atomics + k_schur_split)."""
+    """Tracks longer than a wavefront: nothing special in the sliced-ELL layout (a lane walks its point's observations)."""
     scene = synth.make_affine_scene(90, 40, 80, seed=5)  # ~80 of 90 cameras see every point
     p = synth.make_params(scene, {"correction_params": ["R", "T"], "n_cam_fix": 1})
     assert np.bincount(p.pts_ind).max() > 64
@@ -725,25 +725,21 @@ def test_two_ranks_on_one_gpu(gpu, tmp_path, name, loss):
 # ----------------------------------------------------------------------------- alternative kernel paths
 
 ALT_PATHS = [
-    {"SATBA_SCHUR": "2"},            # Schur v2: LDS column panels (taken by default above 512 cameras)
-    {"SATBA_SCHUR": "1"},            # Schur v1: global atomics (panel does not fit LDS)
-    {"SATBA_SCHUR_BITMAP": "1"},     # Schur v3 with the bitmap scan instead of the per-pair lists (lists too large)
-    {"SATBA_LIN": "3"},              # two-pass linearize (camera table larger than the fused kernel's LDS budget)
-    {"SATBA_CAMC_GLOBAL": "1"},      # camera constants gathered from global memory (more than ~210 cameras)
-    {"SATBA_CHOL_DAG": "1"},         # experimental dataflow Cholesky
-    {"SATBA_CHOL": "1"},             # two-launch-per-panel Cholesky (k_potrf_trsm + k_syrk)
+    {"SATBA_CAMC_GLOBAL": "1"},      # camera constants gathered from global memory (more than ~245 cameras)
+    {"SATBA_RPC_GLOBAL": "1"},       # RPC tables gathered from global memory (more than ~90 RPC cameras)
+    {"SATBA_CAM_SUMS": "1"},         # camera sums by the camera-major pass (accumulator table larger than the LDS)
+    {"SATBA_DETERMINISTIC": "1"},    # the same pass, selected by the repeatability option
     {"SATBA_CHOL": "2"},             # single panel steps only (k_chol_step; default: double steps, k_chol_dstep)
-    {"SATBA_SCHUR_CHUNKS": "3"},     # Schur v3 pair lists cut into point-range chunks + partial reduce
+    {"SATBA_SCHUR_CHUNKS": "3"},     # pair lists cut into point-range chunks + partial reduce
     {"SATBA_SCHUR_CHUNKS": "1"},     # ... and as one chunk (direct store)
-    {"SATBA_SCHUR_STREAM": "1", "SATBA_SCHUR_CHUNKS": "3"},  # lane-group Schur kernel (experiment)
-    {"SATBA_SCHUR_MOMENTS": "1", "SATBA_SCHUR_FINE": "6"},   # affine pair blocks through point moments (experiment)
+    {"SATBA_CM_CHUNKS": "5"},        # chunking of the camera-major passes
 ]
 
 
 @pytest.mark.parametrize("env", ALT_PATHS, ids=lambda e: "-".join("{}={}".format(k, v) for k, v in e.items()))
 @pytest.mark.parametrize("name,loss", [("affine_RT", "linear"), ("persp_RT", "soft_l1"), ("rpc_R", "linear")])
 def test_alternative_kernel_paths(gpu, monkeypatch, env, name, loss):
-    """The fallback variants selected by problem size (or by these switches) must give the same phases."""
+    """The variants selected by problem size (or by these switches) must give the same phases."""
     for k, v in env.items():
         monkeypatch.setenv(k, v)  # read once, when the problem handle is created
     _, p, g = cases.fun_case(name)
@@ -762,37 +758,6 @@ def test_alternative_kernel_paths(gpu, monkeypatch, env, name, loss):
                          ("trial", [trf.COST_NEW, trf.STEP_SQ, trf.X_SQ])):
         for s in slots:
             assert abs(a[phase][s] - b[phase][s]) <= 1e-7 * abs(b[phase][s]) + 1e-300, (phase, s, a[phase][s], b[phase][s])
-    assert rel(dev.get_vector("gn_h"), ora.gn_h) < 1e-7
-    dev.close()
-
-
-@pytest.mark.parametrize("name", ["affine_RT", "affine_R_fix"])
-@pytest.mark.parametrize("env", [{"SATBA_SCHUR_MOMENTS": "1", "SATBA_SCHUR_FINE": "6"},
-                                 {"SATBA_SCHUR_STREAM": "1", "SATBA_SCHUR_CHUNKS": "2", "SATBA_SCHUR_GROUP": "10"},
-                                 {"SATBA_SCHUR_STREAM": "1", "SATBA_SCHUR_CHUNKS": "2"}])
-def test_unit_weight_schur_experiments(gpu, monkeypatch, env, name):
-    """
-    The unit-weight, linear-loss Schur variants (pair blocks through point moments; lane groups of 8 and 6 lanes)
-    against the oracle engine.  affine_R_fix has a fixed camera and fixed points (masked Jacobians) -- its reference
-    camera weight is reset to 1, these kernels are only selected when every weight is 1.
-    """
-    for k, v in env.items():
-        monkeypatch.setenv(k, v)
-    _, p, g = cases.fun_case(name)
-    p.pts2d_w = np.ones_like(p.pts2d_w)
-    v = ba_core._frozen_vars(g["v"][1].copy(), p)
-    dev, ora = HipEngine(p, rpc_f32=False), L.OracleEngine(p, rpc_f32=False)
-    for e in (dev, ora):
-        e.configure("linear", 1.0)
-        e.set_x(v)
-        e.linearize(); e.prepare(True); e.schur(1e-3)
-    n = dev.n_c
-    S = dev.get_exchange(dev.hdr, n * n).reshape(n, n).T  # column-major lower
-    So = ora._xb[ora.hdr: ora.hdr + n * n].reshape(n, n)
-    low = np.tril_indices(n)
-    assert np.abs(S[low] - So[low]).max() < 1e-9 * np.abs(So).max()
-    for e in (dev, ora):
-        e.solve()
     assert rel(dev.get_vector("gn_h"), ora.gn_h) < 1e-7
     dev.close()
 

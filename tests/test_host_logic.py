@@ -176,3 +176,17 @@ def test_figure_helpers_write_files(tmp_path):
     ba_core.save_heatmap_of_reprojection_error(str(out), p, err, footprints, aoi_lonlat_roi=footprints[1], smooth=2,
                                                global_transform=np.zeros(3))
     assert out.stat().st_size > 1000
+
+
+def test_host_elbow_matches_reference_vectors():
+    """satba.ba_outliers.get_elbow_value (host, one vector) on vectors run through ref:bundle_adjust/ba_outliers.py:14-58."""
+    import cases
+    from satba import ba_outliers
+
+    g = cases.golden("outliers")
+    for v, (elbow, ok, n) in zip(g["elbow_vecs"], g["elbow_out"]):
+        v = v[: int(n)]
+        if n < 2:
+            continue
+        e, s = ba_outliers.get_elbow_value(v)
+        assert e == elbow and bool(s) == bool(ok)

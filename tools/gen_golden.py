@@ -30,7 +30,7 @@ def import_reference():
     pkg.__path__ = ["/root/reference/bundle_adjust"]
     sys.modules["bundle_adjust"] = pkg
     mods = {}
-    for m in ["ba_core", "ba_params", "ba_rotate", "cam_utils", "geo_utils"]:
+    for m in ["ba_core", "ba_params", "ba_rotate", "cam_utils", "geo_utils", "ba_outliers"]:
         mods[m] = importlib.import_module("bundle_adjust." + m)
     return types.SimpleNamespace(**mods)
 
@@ -278,9 +278,43 @@ def golden_tight_rpc_persp():
         save("solve_" + name, **out)
 
 
+def golden_outliers():
+    """
+    ref:bundle_adjust/ba_outliers.py get_elbow_value / compute_obs_to_remove (pure numpy, importable) on the reprojection
+    errors of a scene with injected gross errors: thresholds per camera and the removed set, plus single-vector elbows.
+    """
+    rng = np.random.default_rng(21)
+    out = {}
+    for name, M, N, opp, frac in (("a", 6, 600, 4, 0.03), ("b", 12, 1500, 5, 0.10), ("c", 3, 40, 2, 0.0)):
+        scene = synth.make_affine_scene(M, N, opp, seed=13, sigma_theta=2e-6)
+        p = ref_params(scene, {"correction_params": ["R"], "n_cam_fix": 0, "reduce": False})
+        pts2d = p.pts2d.copy()
+        bad = rng.random(p.n_obs) < frac
+        p.pts2d[bad] += rng.normal(0, 25.0, (int(bad.sum()), 2))
+        r = ref.ba_core.fun(p.params_opt.copy(), p)
+        err = ref.ba_core.compute_reprojection_error(r, p.pts2d_w)
+        C_new, cam_thr, n = ref.ba_outliers.compute_obs_to_remove(err, p)
+        removed = np.isnan(C_new[2 * p.cam_ind, p.pts_ind]) & ~np.isnan(p.C[2 * p.cam_ind, p.pts_ind])
+        C2, thr2, n2 = ref.ba_outliers.compute_obs_to_remove(err, p, predef_thr=3.14159)
+        removed2 = np.isnan(C2[2 * p.cam_ind, p.pts_ind])
+        out.update({name + "_pts2d": p.pts2d, name + "_err": err, name + "_cam_thr": np.array(cam_thr), name + "_n": n,
+                    name + "_removed": removed, name + "_thr_predef": np.array(thr2), name + "_removed_predef": removed2,
+                    name + "_bad": bad})
+        print("outliers", name, "obs", p.n_obs, "injected", int(bad.sum()), "removed", n, "thr", cam_thr)
+    vecs, elbows = [], []
+    for k in range(6):
+        n = [5, 17, 200, 1, 2, 1000][k]
+        v = np.abs(rng.normal(0, 1, n)) + (rng.random(n) < 0.1) * rng.uniform(5, 50, n)
+        e, ok = ref.ba_outliers.get_elbow_value(v) if n > 1 else (v[0], True)
+        vecs.append(np.pad(v, (0, 1000 - n), constant_values=np.nan))
+        elbows.append([e, float(ok), n])
+    out.update(elbow_vecs=np.array(vecs), elbow_out=np.array(elbows))
+    save("outliers", **out)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["fun", "params", "solves", "tight2"]
+    which = sys.argv[1:] or ["fun", "params", "solves", "tight2", "outliers"]
     if "fun" in which:
         golden_fun_and_jac()
     if "params" in which:
@@ -289,3 +323,5 @@ if __name__ == "__main__":
         golden_solves()
     if "tight2" in which:
         golden_tight_rpc_persp()
+    if "outliers" in which:
+        golden_outliers()
