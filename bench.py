@@ -2,7 +2,8 @@
 bench.py -- Levenberg-Marquardt iterations per second of the device bundle-adjustment solver on synthetic
 tracks of BASELINE.json's headline shape (200 cameras x 1 M points x ~10 M observations, affine, R+T).
 
-    python bench.py --gpus 1 --steps 10 --warmup 2
+    python bench.py --gpus 1 --steps 200 --warmup 10
+    python bench.py --gpus N ...            (starts N rank processes itself, as fresh children, before anything touches the GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -14,8 +15,10 @@ readbacks.  Inputs are resident in HBM before the timed region.  With N > 1 the 
 points over the ranks (strong scaling); value = steps / max-over-ranks wall time.
 
 One JSON line is printed by rank 0; see DESIGN.md for `roofline` (fused residual+Jacobian kernel, algorithmic
-bytes 48 K + 96 N per launch) and `cpu_baseline` (the reference's scipy path restated in oracle/, timed on a
-bounded sub-problem on this host and scaled linearly in the number of observations).
+bytes 48 K + 96 N per launch) and `cpu_baseline` (the reference's scipy path restated in oracle/, timed on this host:
+the full solve at the C2 shape and one LM iteration on a bounded sub-problem of the benchmarked scene, scaled linearly in
+the number of observations -- a lower bound on the CPU time, LSMR needs more iterations on larger problems; the measured
+C3 run of BASELINE.md section 3 is quoted from profiles/ when it has been taken).
 """
 import argparse
 import json
@@ -32,11 +35,16 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 
-# HBM bytes per k_linearize launch from rocprofv3 PMC passes of this same command (profiles/r1_s4_pmc_hbm_traffic.txt):
-# 2 x FETCH_SIZE (gfx950 counts 128-B requests as 64 B, MI355X_MICROARCH.md section HBM) + WRITE_SIZE, both in KiB.
+# HBM bytes per k_linearize launch from rocprofv3 PMC passes of this same command (profiles/r2_pmc_hbm_traffic.txt):
+# 2 x FETCH_SIZE (gfx950 counts 128-B requests as 64 B, MI355X_MICROARCH.md section HBM) + WRITE_SIZE.
 # PMC counters cannot be read from inside an unprofiled run, so the committed measurement is quoted for the shape
 # it was taken on (one GPU) and the field is null otherwise.
-PROFILED_TRAFFIC_BYTES = {("C4", 1): (2 * 140079.6 + 240552.2) * 1024.0}
+def profiled_traffic(shape, world):
+    path = os.path.join(ROOT, "profiles", "r2_pmc_hbm_traffic.json")
+    if world != 1 or not os.path.exists(path):
+        return None
+    with open(path) as fh:
+        return json.load(fh).get(shape)
 
 
 def lm_step(eng, comm, st, trf):
@@ -75,17 +83,33 @@ def lm_step(eng, comm, st, trf):
     st["cost"] = cost_new if actual > 0 else cost
 
 
-def cpu_baseline(scene, n_pts_sample, corr):
+def cpu_baseline(scene, n_pts_sample, corr, full_c3=False):
     """
-    The reference's scipy path (oracle/ba_oracle.solve_scipy == ref ba_core.py:284-297 on the numpy restatement of
-    fun) on the first n_pts_sample points of the same scene: one LM iteration = max_nfev 2 (initial evaluation +
-    one trial), which includes one finite-difference Jacobian and one LSMR solve.  Scaled linearly in the number of
-    observations to the full workload (FD Jacobian and LSMR matvecs are both linear in nnz).
+    The reference's scipy path (oracle/ba_oracle.solve_scipy == ref ba_core.py:284-297 on the numpy restatement of fun),
+    BASELINE.md section 3:
+      * the FULL solve at the C2 shape (10 x 5 k x 30 k, shipped tolerances): LM it/s = (nfev - 1) / wall;
+      * one LM iteration (max_nfev 2: one finite-difference Jacobian, one LSMR solve, one trial) on the first n_pts_sample
+        points of the benchmarked scene, scaled linearly in the number of observations to the full workload -- both the FD
+        Jacobian and an LSMR iteration are linear in nnz, but LSMR needs MORE iterations on larger problems (290 per LM step at
+        C2, ~2500 at C3, BASELINE.md section 2), so this is a lower bound on the CPU time;
+      * --cpu-c3: the measured C3 run (50 x 100 k x 1 M, max_nfev 3, ~10 min) of BASELINE.md; its result is kept in
+        profiles/r2_cpu_baseline_C3.json and quoted by later runs, with the C4 figure extrapolated from it (x K ratio) and
+        labelled as such.
     """
     from oracle import ba_oracle as O
     from satba import synth
     from satba.ba_params import BundleAdjustmentParameters
 
+    out = {"unit": "LM iters/sec", "cores": 1, "kind": "port", "host_cores": os.cpu_count()}
+    # C2, full solve
+    model, c2corr, n_cam, n_pts, opp = synth.CONFIGS["C2"]
+    sc2 = synth.make_scene(model, n_cam, n_pts, opp, seed=1, sigma_theta=2e-6)
+    p2 = synth.make_params(sc2, {"correction_params": c2corr, "n_cam_fix": 1})
+    t0 = time.perf_counter()
+    r2 = O.solve_scipy(p2, {"verbose": 0})
+    t2 = time.perf_counter() - t0
+    out["C2_full_solve"] = {"seconds": t2, "nfev": int(r2.nfev), "lm_iters_per_sec": max(int(r2.nfev) - 1, 1) / t2, "n_obs": int(p2.n_obs)}
+    # bounded sample of the benchmarked scene
     keep = scene.pts_ind < n_pts_sample
     p = BundleAdjustmentParameters.from_observations(
         scene.pts_ind[keep], scene.cam_ind[keep], scene.pts2d[keep], scene.pts3d[:n_pts_sample], scene.cameras,
@@ -96,33 +120,75 @@ def cpu_baseline(scene, n_pts_sample, corr):
     dt = time.perf_counter() - t0
     full = scene.pts_ind.size
     t_full = dt * full / p.n_obs
-    return {"value": 1.0 / t_full, "unit": "LM iters/sec", "cores": 1, "kind": "port",
-            "sample": "scipy least_squares(trf, lsmr, 2-point FD Jacobian) max_nfev=2 (1 LM iteration) on the first "
-                      "{} points / {} obs of the same scene: {:.1f} s, scaled linearly to {} obs; host has {} cores, "
-                      "the scipy path uses one".format(n_pts_sample, p.n_obs, dt, full, os.cpu_count()),
-            "seconds_on_sample": dt, "nfev": int(res.nfev)}
+    out.update({"value": 1.0 / t_full, "seconds_on_sample": dt, "nfev": int(res.nfev),
+                "sample": "scipy least_squares(trf, lsmr, 2-point FD Jacobian) max_nfev=2 (1 LM iteration) on the first {} points / {} obs "
+                          "of the benchmarked scene: {:.1f} s, scaled linearly to {} obs (a lower bound on the CPU time: LSMR "
+                          "iterations grow with the problem); the scipy path uses one of the host's {} cores; full C2 solve "
+                          "{:.1f} s / nfev {}".format(n_pts_sample, p.n_obs, dt, full, os.cpu_count(), t2, int(r2.nfev))})
+    c3_path = os.path.join(ROOT, "profiles", "r2_cpu_baseline_C3.json")
+    if full_c3:
+        model, c3corr, n_cam, n_pts, opp = synth.CONFIGS["C3"]
+        sc3 = synth.make_scene(model, n_cam, n_pts, opp, seed=1, sigma_theta=1e-4)
+        p3 = synth.make_params(sc3, {"correction_params": c3corr, "n_cam_fix": 1})
+        t0 = time.perf_counter()
+        r3 = O.solve_scipy(p3, {"verbose": 0}, max_nfev=3)
+        t3 = time.perf_counter() - t0
+        c3 = {"seconds": t3, "nfev": int(r3.nfev), "lm_iters": int(r3.nfev) - 1, "lm_iters_per_sec": (int(r3.nfev) - 1) / t3,
+              "n_obs": int(p3.n_obs), "host_cores": os.cpu_count()}
+        out["C3_measured"] = c3
+        try:
+            os.makedirs(os.path.dirname(c3_path), exist_ok=True)
+            with open(os.path.join(ROOT, "gpurun_out", "r2_cpu_baseline_C3.json"), "w") as fh:
+                json.dump(c3, fh)
+        except OSError:
+            pass
+    elif os.path.exists(c3_path):
+        with open(c3_path) as fh:
+            out["C3_measured"] = dict(json.load(fh), quoted_from="profiles/r2_cpu_baseline_C3.json (taken with --cpu-c3 on an MI355X box's host)")
+    if "C3_measured" in out and full > 0:
+        c3 = out["C3_measured"]
+        out["C4_extrapolated_from_C3"] = {"lm_iters_per_sec": c3["lm_iters_per_sec"] * c3["n_obs"] / full,
+                                          "note": "measured C3 rate x (K_C3 / K): linear in observations, LSMR iteration count of C3"}
+    return out
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--shape", default="C4", help="C2 | C3 | C4 (affine R+T) | C5 (rpc R) | P3 (perspective R+T); SURVEY.md section 8d")
     ap.add_argument("--sigma-theta", type=float, default=1e-4, help="initial camera angle error [rad]")
     ap.add_argument("--cpu-sample-pts", type=int, default=20000,
                     help="points of the CPU-baseline sub-problem (0 = skip); 20000 points = 200 k observations, ~20 s")
     ap.add_argument("--kernel-reps", type=int, default=20)
     ap.add_argument("--loss", default="linear", help="linear (headline) | soft_l1 | huber | cauchy | arctan")
+    ap.add_argument("--cpu-c3", action="store_true", help="also run the measured C3 CPU baseline (max_nfev=3, ~10 min)")
     args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # plain `python bench.py --gpus N`: start the N ranks as fresh child processes.  Decided before torch is imported or
+        # anything touches HIP in this process (a process that has initialised the GPU must never be replaced or forked into
+        # the ranks); this parent only waits and passes the exit code on.
+        import socket
+        import subprocess
+
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        sys.exit(subprocess.run(cmd, env=env).returncode)
 
     import torch
     import torch.distributed as dist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, "--gpus must equal the number of launched ranks"
+    if world != args.gpus:
+        raise SystemExit("--gpus {} but {} rank(s) were launched".format(args.gpus, world))
     torch.cuda.set_device(local_rank)
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -174,6 +240,7 @@ def main():
         alg_bytes = 48.0 * K_loc + 96.0 * N_loc
         t_lin = kern["linearize"] * 1e-3
         achieved = alg_bytes / t_lin / 1e9
+        traffic = profiled_traffic(args.shape, world)
         out = {
             "metric": "LM iters/sec at 200 cams x 1M pts x 10M obs (affine, R+T)" if args.shape == "C4" else
                       "LM iters/sec, config {}".format(args.shape),
@@ -186,14 +253,15 @@ def main():
                        "obs_per_rank0": K_loc},
             "obs_per_sec_residual_jacobian": world * K_loc / t_lin,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": PROFILED_TRAFFIC_BYTES.get((args.shape, world)),
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "achieved_counter": (traffic / t_lin / 1e9) if traffic else None,  # counter bytes / time, GB/s
                          "kernel": "k_linearize",
                          "algorithmic_bytes_per_launch": alg_bytes, "ms_per_launch": kern["linearize"]},
             "kernel_ms": kern,
             "accepted_steps": st["accepted"], "interior_2d_steps": st.get("interior", 0), "final_cost": st["cost"], "scene_gen_s": t_gen,
         }
         if args.cpu_sample_pts > 0 and world == 1:
-            out["cpu_baseline"] = cpu_baseline(scene, min(args.cpu_sample_pts, n_pts), corr)
+            out["cpu_baseline"] = cpu_baseline(scene, min(args.cpu_sample_pts, n_pts), corr, full_c3=args.cpu_c3)
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out))
     if world > 1:

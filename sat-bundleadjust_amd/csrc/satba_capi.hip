@@ -183,12 +183,16 @@ static int zero_header(satba_problem* p) {
     return 0;
 }
 
-// slices are sorted by track length: a grid-stride walk hands every wave short and long slices alike
-static int slice_grid(const satba_problem* p, int waves_per_block, int cap) { return grid_for(p->L.n_slices, waves_per_block, cap); }
+// grid of the thread-per-point kernels: `per_cu` workgroups per CU, all resident from the start (a later round of workgroups
+// would run its slices alone at the end), every wave walking several slices (for_each_slice balances short and long tracks)
+static int slice_grid(const satba_problem* p, int waves_per_block, int per_cu) {
+    static const int env = getenv("SATBA_BPC") ? atoi(getenv("SATBA_BPC")) : 0;
+    return grid_for(p->L.n_slices, waves_per_block, 256 * (env > 0 ? env : per_cu));
+}
 
 static int launch_residual(satba_problem* p, bool at_new, double2* f, double* cost) {
     ObsArgs a = obs_args(p, at_new);
-    const int grid = slice_grid(p, RES_THREADS / 64, 1024);
+    const int grid = slice_grid(p, RES_THREADS / 64, 2);
     const size_t lds = table_bytes(p);
     if (p->loss == 0 && p->unit_weights)
         SATBA_DISPATCH(p, hipLaunchKernelGGL((k_residual<MODEL, NP, CL, RL, true>), dim3(grid), dim3(RES_THREADS), lds, p->stream, a, f, p->red(RB_RES), cost));
@@ -316,7 +320,7 @@ static int launch_schur_kernel(satba_problem* p) {
 
 static int launch_backsub_kernel(satba_problem* p) {
     ObsArgs a = obs_args(p, false);
-    const int grid = slice_grid(p, BS_THREADS / 64, 1024);
+    const int grid = slice_grid(p, BS_THREADS / 64, 2);
     const size_t lds = p->model == AFFINE ? dir_table_bytes(p) : table_bytes(p);
     SATBA_DISPATCH(p, hipLaunchKernelGGL((k_backsub<MODEL, NP, CL, RL>), dim3(grid), dim3(BS_THREADS), lds, p->stream, a, p->d_dc, p->d_dch, p->lead,
                                          p->d_Vinv, p->d_g, p->d_scale_inv, p->d_gh, p->d_gn, p->red(RB_BS), p->d_xb));
@@ -327,7 +331,7 @@ static int launch_backsub_kernel(satba_problem* p) {
 // pre: q1 is already in unscaled variables (nv == 1 only)
 static int launch_jvp(satba_problem* p, int nv, const double* q1, const double* q2, double* out, bool pre = false) {
     ObsArgs a = obs_args(p, false);
-    const int grid = slice_grid(p, JVP_THREADS / 64, 1024);
+    const int grid = slice_grid(p, JVP_THREADS / 64, 2);
     const RedBuf rb = p->red(RB_JVP);
     if (nv == 1 && pre) {
         const size_t lds = p->model == AFFINE ? dir_table_bytes(p) : table_bytes(p);
@@ -618,7 +622,7 @@ int satba_problem_create(const satba_problem_desc* d, satba_problem** out) {
         TRY(dev_alloc(p, &p->d_red_cnt, RED_SLOTS));
         HIP_TRY(hipMemset(p->d_red_cnt, 0, sizeof(unsigned) * RED_SLOTS));
         // one workgroup per CU for the linearize kernel (its LDS table is flushed once per workgroup)
-        p->lin_grid = slice_grid(p, LinCfg<false>::WAVES, 256);
+        p->lin_grid = grid_for(p->L.n_slices, LinCfg<false>::WAVES, 256 * (1024 / LinCfg<false>::THREADS));
         TRY(dev_alloc(p, &p->d_part, (size_t)512 * p->M * 2 * p->NP));
         {   // chunking of the camera-major passes (k_schur_diag, k_cam_sums)
             int chunks = (2048 + p->M - 1) / p->M;
@@ -837,7 +841,7 @@ static int schur_impl(satba_problem* p, double lam, const double* lam_dev) {
     HIP_TRY(hipMemsetAsync(p->d_xb, 0, sizeof(double) * (p->hdr + nS), p->stream));
     if (p->N > 0) {
         hipLaunchKernelGGL(k_vinv, dim3((p->N + 255) / 256), dim3(256), 0, p->stream, p->N, lam, lam_dev, p->d_V,
-                           p->d_scale_inv + p->n_c, p->d_Vinv, p->d_x + p->n_c, p->d_g + p->n_c, p->d_PV);
+                           p->d_scale_inv + p->n_c, p->d_Vinv, p->d_x + p->n_c, p->d_g + p->n_c, p->d_PV, p->L.perm, p->n_pts_fix);
         HIP_TRY(hipGetLastError());
     }
     double* S = p->payload();

@@ -149,6 +149,24 @@ struct ObsEval {
     }
 };
 
+// one observation record of the ELL stream (camera, observed pixel, weight); `on` false: nothing is fetched
+#ifndef SATBA_PF
+#define SATBA_PF 2  // slots of the ELL stream in flight ahead of the one being evaluated
+#endif
+struct ObsRec {
+    int cam = 0;
+    double2 ob = {0.0, 0.0};
+    double w = 1.0;
+    template <bool UNITW>
+    __device__ inline void load(const ObsArgs& a, int pos, bool on) {
+        if (on) {
+            cam = a.e_cam[pos];
+            ob = a.e_obs[pos];
+            if constexpr (!UNITW) w = a.e_w[pos];
+        }
+    }
+};
+
 // Per-camera tables in LDS.  CL / RL = true: the workgroup stages the whole camera-constant / RPC table in dynamic LDS once
 // and every lookup is a ds_read (the pointers never merge with global ones, so no FLAT instructions are generated; odd row
 // strides: no structural bank conflicts); false (table too large for LDS): gathers from global memory through L1.
@@ -213,7 +231,6 @@ __device__ inline void grid_sum(double (&v)[NV], double* const (&dst)[NV], const
         double t = 0.0;
         for (int w = 0; w < nw; ++w) t += s_part[threadIdx.x][w];
         __hip_atomic_store(rb.part + (size_t)threadIdx.x * gridDim.x + blockIdx.x, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __builtin_amdgcn_s_waitcnt(0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();
@@ -222,17 +239,46 @@ __device__ inline void grid_sum(double (&v)[NV], double* const (&dst)[NV], const
         s_last = (old == gridDim.x - 1) ? 1 : 0;
     }
     __syncthreads();
-    if (s_last && threadIdx.x < NV) {
+    if (!s_last) return;
+    // the last workgroup: thread t adds the partials t, t + T, t + 2 T, ... (a fixed assignment, whatever the arrival order was),
+    // then the same shuffle / LDS tree as above.  One thread adding all of them took ~0.12 us per workgroup of the grid.
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
         double t = 0.0;
-        for (unsigned b = 0; b < gridDim.x; ++b)
-            t += __hip_atomic_load(rb.part + (size_t)threadIdx.x * gridDim.x + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        *dst[threadIdx.x] = t;
-        if (threadIdx.x == 0) __hip_atomic_store(rb.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (unsigned b = threadIdx.x; b < gridDim.x; b += blockDim.x)
+            t += __hip_atomic_load(rb.part + (size_t)k * gridDim.x + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        t = wave_sum(t);
+        __syncthreads();  // s_part of the first stage has been consumed
+        if (lane == 0) s_part[k][wave] = t;
     }
+    __syncthreads();
+    if (threadIdx.x < NV) {
+        double t = 0.0;
+        for (int w = 0; w < nw; ++w) t += s_part[threadIdx.x][w];
+        *dst[threadIdx.x] = t;
+    }
+    if (threadIdx.x == 0) __hip_atomic_store(rb.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 __device__ inline void atomic_max_pos(double* addr, double v) {  // v >= 0; a maximum does not depend on the order
     atomicMax(reinterpret_cast<unsigned long long*>(addr), (unsigned long long)__double_as_longlong(v));
+}
+
+
+// Which slices a wave processes.  Slices are sorted by track length (short first), so a plain grid-stride walk gives the
+// waves with the highest indices the longest tracks in every round.  Here a wave alternates between the short end and
+// the long end of the list: slice fi from the front, then slice n - 1 - fi from the back, with fi = wave, wave + G,
+// wave + 2 G, ...  Every wave gets about the same number of observations, and neighbouring waves still read neighbouring
+// slices.  body(g) is called with a wave-uniform slice index.
+template <class F>
+__device__ inline void for_each_slice(int n_slices, int waves_per_block, F&& body) {
+    const int w = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * waves_per_block + (threadIdx.x >> 6)));
+    const int G = gridDim.x * waves_per_block;
+    const int half = (n_slices + 1) >> 1, rest = n_slices - half;
+    for (int fi = w; fi < half; fi += G) {
+        body(fi);
+        if (fi < rest) body(n_slices - 1 - fi);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ camera constants
@@ -274,11 +320,10 @@ __global__ __launch_bounds__(RES_THREADS) void k_residual(ObsArgs a, double2* __
     extern __shared__ double s_dyn_res[];
     CamTables<CL, RL> T;
     T.stage(a, s_dyn_res, RES_THREADS);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
     constexpr int WAVES = RES_THREADS / 64;
     double acc = 0.0;
-    for (int g = blockIdx.x * WAVES + wave; g < a.n_slices; g += gridDim.x * WAVES) {
-        const int gu = __builtin_amdgcn_readfirstlane(g);
+    for_each_slice(a.n_slices, WAVES, [&](const int gu) {
         const int base = a.slice_base[gu], len = (a.slice_base[gu + 1] - base) >> 6;
         const int q = gu * 64 + lane;
         const bool has = q < a.N;
@@ -286,25 +331,23 @@ __global__ __launch_bounds__(RES_THREADS) void k_residual(ObsArgs a, double2* __
         double X = 0.0, Y = 0.0, Z = 0.0;
         if (has) { const double* px = a.x + a.n_c + 3 * (size_t)q; X = px[0]; Y = px[1]; Z = px[2]; }
         int pos = base + lane;
-        // the next slot's record is requested before the arithmetic of the current one
-        int cam_n = 0;
-        double2 ob_n = make_double2(0.0, 0.0);
-        double w_n = 1.0;
-        if (0 < cnt) { cam_n = a.e_cam[pos]; ob_n = a.e_obs[pos]; if constexpr (!UNITW) w_n = a.e_w[pos]; }
+        // software pipeline: the records of the next two slots are in flight during the arithmetic of the current one
+        ObsRec r[SATBA_PF + 1];
+#pragma unroll
+        for (int j = 0; j < SATBA_PF; ++j) r[j].load<UNITW>(a, pos + 64 * j, j < cnt);
         for (int k = 0; k < len; ++k, pos += 64) {
-            const int cam = cam_n;
-            const double2 ob = ob_n;
-            const double w = w_n;
-            if (k + 1 < cnt) { cam_n = a.e_cam[pos + 64]; ob_n = a.e_obs[pos + 64]; if constexpr (!UNITW) w_n = a.e_w[pos + 64]; }
+            r[SATBA_PF].load<UNITW>(a, pos + 64 * SATBA_PF, k + SATBA_PF < cnt);
             __builtin_amdgcn_sched_barrier(0);
             if (k < cnt) {
                 ObsEval<MODEL, NP, false, !UNITW, false, UNITW> e;
-                e.eval(a, cam, 1.0, T.cc(cam), T.tab(cam), ob, w, X, Y, Z);
+                e.eval(a, r[0].cam, 1.0, T.cc(r[0].cam), T.tab(r[0].cam), r[0].ob, r[0].w, X, Y, Z);
                 if (f) f[pos] = make_double2(e.ftrue[0], e.ftrue[1]);
                 acc += e.rho;
             }
+#pragma unroll
+            for (int j = 0; j < SATBA_PF; ++j) r[j] = r[j + 1];
         }
-    }
+    });
     double v[1] = {0.5 * acc};
     double* const dst[1] = {cost};
     grid_sum<1>(v, dst, rb);
@@ -328,7 +371,10 @@ __host__ __device__ constexpr bool lin_const_t(int model, int np, bool robust, b
 
 template <bool BIG>
 struct LinCfg {
-    static constexpr int THREADS = BIG ? 512 : 1024;  // the generic robust variants and the RPC chain need > 128 VGPRs
+#ifndef SATBA_LIN_THREADS
+#define SATBA_LIN_THREADS 1024
+#endif
+    static constexpr int THREADS = BIG ? 512 : SATBA_LIN_THREADS;  // the generic robust variants and the RPC chain need > 128 VGPRs
     static constexpr int WAVES = THREADS / 64;
 };
 
@@ -351,12 +397,11 @@ __global__ __launch_bounds__(LinCfg<(ROBUST && !SOFT) || MODEL == RPC>::THREADS)
     CamTables<CL, RL> T;
     T.stage(a, s_lin + (CAMSUMS ? (size_t)a.M * CUS : 0), THREADS);
     if constexpr (CAMSUMS && !CL && !RL) __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
     const bool const_t = lin_const_t(MODEL, NP, ROBUST, a.unit != 0);
 
     double cost = 0.0, gmax = 0.0;
-    for (int g = blockIdx.x * WAVES + wave; g < a.n_slices; g += gridDim.x * WAVES) {
-        const int gu = __builtin_amdgcn_readfirstlane(g);
+    for_each_slice(a.n_slices, WAVES, [&](const int gu) {
         const int base = a.slice_base[gu], len = (a.slice_base[gu + 1] - base) >> 6;
         const int q = gu * 64 + lane;
         const bool has = q < a.N;
@@ -369,21 +414,18 @@ __global__ __launch_bounds__(LinCfg<(ROBUST && !SOFT) || MODEL == RPC>::THREADS)
         }
         double v[9] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
         int pos = base + lane;
-        int cam_n = 0;
-        double2 ob_n = make_double2(0.0, 0.0);
-        double w_n = 1.0;
-        if (0 < cnt) { cam_n = a.e_cam[pos]; ob_n = a.e_obs[pos]; if constexpr (!UNITW) w_n = a.e_w[pos]; }
+        // software pipeline: the records of the next two slots are in flight during the arithmetic and the LDS atomics of this one
+        ObsRec r[SATBA_PF + 1];
+#pragma unroll
+        for (int j = 0; j < SATBA_PF; ++j) r[j].load<UNITW>(a, pos + 64 * j, j < cnt);
         for (int k = 0; k < len; ++k, pos += 64) {
-            const int cam = cam_n;
-            const double2 ob = ob_n;
-            const double w = w_n;
-            // software pipeline: the record of the next slot is in flight during the arithmetic and the LDS atomics of this one
-            if (k + 1 < cnt) { cam_n = a.e_cam[pos + 64]; ob_n = a.e_obs[pos + 64]; if constexpr (!UNITW) w_n = a.e_w[pos + 64]; }
+            r[SATBA_PF].load<UNITW>(a, pos + 64 * SATBA_PF, k + SATBA_PF < cnt);
             __builtin_amdgcn_sched_barrier(0);
             if (k < cnt) {
+                const int cam = r[0].cam;
                 ObsEval<MODEL, NP, true, ROBUST, SOFT, UNITW> e;
-                e.eval(a, cam, mp, T.cc(cam), T.tab(cam), ob, w, X, Y, Z);
-                if constexpr (MODEL == RPC) { if (a.Jpm) e.store_jac(a, pos); }
+                e.eval(a, cam, mp, T.cc(cam), T.tab(cam), r[0].ob, r[0].w, X, Y, Z);
+                if constexpr (MODEL == RPC) e.store_jac(a, pos);
                 if (a.sc) a.sc[pos] = make_double2(e.sw[0], e.sw[1]);
                 f[pos] = make_double2(e.ftrue[0], e.ftrue[1]);
                 cost += e.rho;
@@ -406,6 +448,8 @@ __global__ __launch_bounds__(LinCfg<(ROBUST && !SOFT) || MODEL == RPC>::THREADS)
                     for (int i = 0; i < NP; ++i) atomicAdd(acc + NP + i, e.Jc[0][i] * e.fs[0] + e.Jc[1][i] * e.fs[1]);
                 }
             }
+#pragma unroll
+            for (int j = 0; j < SATBA_PF; ++j) r[j] = r[j + 1];
         }
         if (has) {
             if constexpr (UNITW) {  // fixed points: their blocks are masked here
@@ -418,7 +462,7 @@ __global__ __launch_bounds__(LinCfg<(ROBUST && !SOFT) || MODEL == RPC>::THREADS)
             go[0] = v[6]; go[1] = v[7]; go[2] = v[8];
             gmax = fmax(gmax, fmax(fabs(v[6]), fmax(fabs(v[7]), fabs(v[8]))));
         }
-    }
+    });
     // per-workgroup epilogue
     gmax = wave_max(gmax);
     if (lane == 0 && gmax > 0.0) atomic_max_pos(hdr_gpmax, gmax);
@@ -638,14 +682,13 @@ template <int MODEL, int NP, int NV, bool CL, bool RL, bool PRE>
 __global__ __launch_bounds__(JVP_THREADS) void k_jvp(ObsArgs a, const double* __restrict__ q1, const double* __restrict__ q2,
                                                      const double* __restrict__ scale_inv, RedBuf rb, double* __restrict__ out) {
     extern __shared__ double s_dyn_jvp[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
     constexpr int WAVES = JVP_THREADS / 64;
     double s11 = 0.0, s12 = 0.0, s22 = 0.0;
     if constexpr (MODEL == AFFINE && PRE && NV == 1) {
         double* tab = s_dyn_jvp;  // M x JVP_ROW
         affine_dir_table<NP>(a, q1, tab, JVP_THREADS);
-        for (int g = blockIdx.x * WAVES + wave; g < a.n_slices; g += gridDim.x * WAVES) {
-            const int gu = __builtin_amdgcn_readfirstlane(g);
+        for_each_slice(a.n_slices, WAVES, [&](const int gu) {
             const int base = a.slice_base[gu], len = (a.slice_base[gu + 1] - base) >> 6;
             const int q = gu * 64 + lane;
             const bool has = q < a.N;
@@ -658,25 +701,27 @@ __global__ __launch_bounds__(JVP_THREADS) void k_jvp(ObsArgs a, const double* __
                 v0 = mp * q1[ip]; v1 = mp * q1[ip + 1]; v2 = mp * q1[ip + 2];
             }
             int pos = base + lane;
-            int cam_n = (0 < cnt) ? a.e_cam[pos] : 0;
-            double2 sc_n = (0 < cnt && a.sc) ? a.sc[pos] : make_double2(1.0, 1.0);
+            // cameras (and row scales) of the next two slots in flight
+            int c0 = (0 < cnt) ? a.e_cam[pos] : 0, c1 = (1 < cnt) ? a.e_cam[pos + 64] : 0;
+            double2 s0 = (0 < cnt && a.sc) ? a.sc[pos] : make_double2(1.0, 1.0), s1 = (1 < cnt && a.sc) ? a.sc[pos + 64] : make_double2(1.0, 1.0);
             for (int k = 0; k < len; ++k, pos += 64) {
-                const int cam = cam_n;
-                const double2 sc = sc_n;
-                if (k + 1 < cnt) { cam_n = a.e_cam[pos + 64]; if (a.sc) sc_n = a.sc[pos + 64]; }
+                int c2 = 0;
+                double2 s2 = make_double2(1.0, 1.0);
+                if (k + 2 < cnt) { c2 = a.e_cam[pos + 128]; if (a.sc) s2 = a.sc[pos + 128]; }
+                __builtin_amdgcn_sched_barrier(0);
                 if (k < cnt) {
-                    const double* row = tab + (size_t)cam * JVP_ROW;
-                    const double j0 = sc.x * (row[0] * X + row[1] * Y + row[2] * Z + row[6] + row[8] * v0 + row[9] * v1 + row[10] * v2);
-                    const double j1 = sc.y * (row[3] * X + row[4] * Y + row[5] * Z + row[7] + row[11] * v0 + row[12] * v1 + row[13] * v2);
+                    const double* row = tab + (size_t)c0 * JVP_ROW;
+                    const double j0 = s0.x * (row[0] * X + row[1] * Y + row[2] * Z + row[6] + row[8] * v0 + row[9] * v1 + row[10] * v2);
+                    const double j1 = s0.y * (row[3] * X + row[4] * Y + row[5] * Z + row[7] + row[11] * v0 + row[12] * v1 + row[13] * v2);
                     s11 += j0 * j0 + j1 * j1;
                 }
+                c0 = c1; c1 = c2; s0 = s1; s1 = s2;
             }
-        }
+        });
     } else {
         CamTables<CL, RL> T;
         T.stage(a, s_dyn_jvp, JVP_THREADS);
-        for (int g = blockIdx.x * WAVES + wave; g < a.n_slices; g += gridDim.x * WAVES) {
-            const int gu = __builtin_amdgcn_readfirstlane(g);
+        for_each_slice(a.n_slices, WAVES, [&](const int gu) {
             const int base = a.slice_base[gu], len = (a.slice_base[gu + 1] - base) >> 6;
             const int q = gu * 64 + lane;
             const bool has = q < a.N;
@@ -727,7 +772,7 @@ __global__ __launch_bounds__(JVP_THREADS) void k_jvp(ObsArgs a, const double* __
                     }
                 }
             }
-        }
+        });
     }
     if constexpr (NV == 2) {
         double v[3] = {s11, s12, s22};
@@ -803,7 +848,7 @@ __global__ __launch_bounds__(BS_THREADS) void k_backsub(ObsArgs a, const double*
                                                         const double* __restrict__ scale_inv, const double* __restrict__ gh,
                                                         double* __restrict__ gn, RedBuf rb, double* __restrict__ hdr) {
     extern __shared__ double s_dyn_bs[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
     constexpr int WAVES = BS_THREADS / 64;
     double sa = 0.0, sb = 0.0, sc = 0.0;
     if (blockIdx.x == 0) {
@@ -817,8 +862,7 @@ __global__ __launch_bounds__(BS_THREADS) void k_backsub(ObsArgs a, const double*
     double* tab = s_dyn_bs;
     if constexpr (MODEL == AFFINE) affine_dir_table<NP>(a, dc, tab, BS_THREADS);
     else T.stage(a, s_dyn_bs, BS_THREADS);
-    for (int gI = blockIdx.x * WAVES + wave; gI < a.n_slices; gI += gridDim.x * WAVES) {
-        const int gu = __builtin_amdgcn_readfirstlane(gI);
+    for_each_slice(a.n_slices, WAVES, [&](const int gu) {
         const int base = a.slice_base[gu], len = (a.slice_base[gu + 1] - base) >> 6;
         const int q = gu * 64 + lane;
         const bool has = q < a.N;
@@ -832,12 +876,16 @@ __global__ __launch_bounds__(BS_THREADS) void k_backsub(ObsArgs a, const double*
         double t[3] = {0.0, 0.0, 0.0};
         int pos = base + lane;
         if constexpr (MODEL == AFFINE) {
-            int cam_n = (0 < cnt) ? a.e_cam[pos] : 0;
-            double2 sc_n = (0 < cnt && a.sc) ? a.sc[pos] : make_double2(1.0, 1.0);
+            int c0 = (0 < cnt) ? a.e_cam[pos] : 0, c1 = (1 < cnt) ? a.e_cam[pos + 64] : 0;
+            double2 w0 = (0 < cnt && a.sc) ? a.sc[pos] : make_double2(1.0, 1.0), w1 = (1 < cnt && a.sc) ? a.sc[pos + 64] : make_double2(1.0, 1.0);
             for (int k = 0; k < len; ++k, pos += 64) {
-                const int cam = cam_n;
-                const double2 s2 = sc_n;
-                if (k + 1 < cnt) { cam_n = a.e_cam[pos + 64]; if (a.sc) sc_n = a.sc[pos + 64]; }
+                int c2 = 0;
+                double2 w2 = make_double2(1.0, 1.0);
+                if (k + 2 < cnt) { c2 = a.e_cam[pos + 128]; if (a.sc) w2 = a.sc[pos + 128]; }
+                __builtin_amdgcn_sched_barrier(0);
+                const int cam = c0;
+                const double2 s2 = w0;
+                c0 = c1; c1 = c2; w0 = w1; w1 = w2;
                 if (k < cnt) {
                     const double* row = tab + (size_t)cam * JVP_ROW;
                     // both blocks of an observation carry its row scale
@@ -878,7 +926,7 @@ __global__ __launch_bounds__(BS_THREADS) void k_backsub(ObsArgs a, const double*
                 sa += h * h; sb += h * v; sc += v * v;
             }
         }
-    }
+    });
     double v[3] = {sa, sb, sc};
     double* const dst[3] = {hdr + 1, hdr + 2, hdr + 3};
     grid_sum<3>(v, dst, rb);

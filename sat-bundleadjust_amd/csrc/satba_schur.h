@@ -22,9 +22,11 @@ constexpr int PV_STRIDE = 16;  // doubles per packed point record: 12 used, padd
                                // 128-byte line (96-byte records straddle lines: 1.5 lines per gather; Schur 0.945 -> 0.845 ms)
 // PV: packed per-point record X(3) | Vinv(6) | g_p(3) for the gather-heavy Schur kernels
 // lam_dev (optional): the damping is read from device memory (satba_schur_auto) instead of the argument
+// The copy of Vinv inside PV is multiplied by the point's fixed mask (0 for a frozen point, 1 otherwise): every Schur term
+// contains Vinv_p exactly once, so the Schur kernels need no mask of their own (a gather of perm[] per hit otherwise).
 __global__ void k_vinv(int N, double lam, const double* __restrict__ lam_dev, const double* __restrict__ V,
                        const double* __restrict__ scale_inv_p, double* __restrict__ Vinv, const double* __restrict__ xp,
-                       const double* __restrict__ gp, double* __restrict__ PV) {
+                       const double* __restrict__ gp, double* __restrict__ PV, const int* __restrict__ perm, int n_pts_fix) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= N) return;
     if (lam_dev) lam = *lam_dev;
@@ -44,8 +46,9 @@ __global__ void k_vinv(int N, double lam, const double* __restrict__ lam_dev, co
     double2* q = reinterpret_cast<double2*>(PV + PV_STRIDE * (size_t)p);
     const double x0 = xp[3 * (size_t)p], x1 = xp[3 * (size_t)p + 1], x2 = xp[3 * (size_t)p + 2];
     const double g0 = gp[3 * (size_t)p], g1 = gp[3 * (size_t)p + 1], g2 = gp[3 * (size_t)p + 2];
-    q[0] = make_double2(x0, x1); q[1] = make_double2(x2, o0); q[2] = make_double2(o1, o2);
-    q[3] = make_double2(o3, o4); q[4] = make_double2(o5, g0); q[5] = make_double2(g1, g2);
+    const double mp = (perm[p] >= n_pts_fix) ? 1.0 : 0.0;
+    q[0] = make_double2(x0, x1); q[1] = make_double2(x2, mp * o0); q[2] = make_double2(mp * o1, mp * o2);
+    q[3] = make_double2(mp * o3, mp * o4); q[4] = make_double2(mp * o5, g0); q[5] = make_double2(g1, g2);
 }
 
 // S <- (lead) * lam Dc^2 on the diagonal, rhs <- (lead) * g_c ; S column-major n_c x n_c (already zeroed).  The J_c^T J_c
@@ -138,7 +141,7 @@ __global__ __launch_bounds__(256) void k_schur_pairs(ObsArgs a, SchurArgs s, dou
         r.r0 = pv[0]; r.r1 = pv[1]; r.r2 = pv[2]; r.r3 = pv[3]; r.r4 = reinterpret_cast<const double*>(pv + 4)[0];
         return r;
     };
-    auto compute = [&](int p, const Rec& rc, int pi, int pj, const double2& scl_i, const double2& scl_j) {
+    auto compute = [&](const Rec& rc, int pi, int pj, const double2& scl_i, const double2& scl_j) {
         const double X = rc.r0.x, Y = rc.r0.y, Z = rc.r1.x;
         const double v00 = rc.r1.y, v01 = rc.r2.x, v02 = rc.r2.y, v11 = rc.r3.x, v12 = rc.r3.y, v22 = rc.r4;
         double Jci[2][NP], Jpi[2][3], Jcj[2][NP], Jpj[2][3];
@@ -175,17 +178,12 @@ __global__ __launch_bounds__(256) void k_schur_pairs(ObsArgs a, SchurArgs s, dou
         double m01 = A[0][0] * Jpj[1][0] + A[0][1] * Jpj[1][1] + A[0][2] * Jpj[1][2];
         double m10 = A[1][0] * Jpj[0][0] + A[1][1] * Jpj[0][1] + A[1][2] * Jpj[0][2];
         double m11 = A[1][0] * Jpj[1][0] + A[1][1] * Jpj[1][1] + A[1][2] * Jpj[1][2];
-        if constexpr (MODEL != RPC) {
-            const double mp = (a.perm[p] >= a.n_pts_fix) ? 1.0 : 0.0;
-            if constexpr (!UNITW) {
-                // row scales s of the two observations (weights, robust loss): both blocks of an observation carry them, so the
-                // pair block is Jc_i^T [diag(s_i^2) (Jp_i Vinv Jp_j^T) diag(s_j^2)] Jc_j
-                const double ax = scl_i.x * scl_i.x * mp, ay = scl_i.y * scl_i.y * mp;
-                const double bx = scl_j.x * scl_j.x, by = scl_j.y * scl_j.y;
-                m00 *= ax * bx; m01 *= ax * by; m10 *= ay * bx; m11 *= ay * by;
-            } else {
-                m00 *= mp; m01 *= mp; m10 *= mp; m11 *= mp;
-            }
+        if constexpr (MODEL != RPC && !UNITW) {
+            // row scales s of the two observations (weights, robust loss): both blocks of an observation carry them, so the
+            // pair block is Jc_i^T [diag(s_i^2) (Jp_i Vinv Jp_j^T) diag(s_j^2)] Jc_j  (the fixed-point mask rides in Vinv)
+            const double ax = scl_i.x * scl_i.x, ay = scl_i.y * scl_i.y;
+            const double bx = scl_j.x * scl_j.x, by = scl_j.y * scl_j.y;
+            m00 *= ax * bx; m01 *= ax * by; m10 *= ay * bx; m11 *= ay * by;
         }
 #pragma unroll
         for (int q = 0; q < NP; ++q) {
@@ -226,7 +224,7 @@ __global__ __launch_bounds__(256) void k_schur_pairs(ObsArgs a, SchurArgs s, dou
             // keep the gathers above the arithmetic: without the barrier the scheduler sinks them below compute() to
             // save registers and every iteration pays the full memory latency
             __builtin_amdgcn_sched_barrier(0);
-            compute(p_cur, r_cur, pi_cur, pj_cur, si_cur, sj_cur);
+            compute(r_cur, pi_cur, pj_cur, si_cur, sj_cur);
             __builtin_amdgcn_sched_barrier(0);
             p_cur = p_nxt; p_nxt = p_nn; r_cur = r_nxt;
             pi_cur = pi_nxt; pj_cur = pj_nxt; pi_nxt = pi_nn; pj_nxt = pj_nn;
@@ -302,7 +300,6 @@ __global__ __launch_bounds__(LINC_THREADS) void k_schur_diag(ObsArgs a, CamMajor
         const int p_nn = ldp(pos + 2 * LINC_THREADS);
         const Rec rn = load_rec(p_nxt);
         __builtin_amdgcn_sched_barrier(0);
-        const int p = p_cur;
         const double2 r0 = rc.r0, r1 = rc.r1, r2 = rc.r2, r3 = rc.r3, r4 = rc.r4, r5 = rc.r5;
         p_cur = p_nxt; p_nxt = p_nn; rc = rn;
         double Jc[2][NP], Jp[2][3];
@@ -318,9 +315,8 @@ __global__ __launch_bounds__(LINC_THREADS) void k_schur_diag(ObsArgs a, CamMajor
         } else {
             double u, v;
             project<MODEL, NP, true>(cc, nullptr, r0.x, r0.y, r1.x, false, u, v, Jc, Jp);
-            const double mp = (a.perm[p] >= a.n_pts_fix) ? 1.0 : 0.0;
             if (a.sc) { const double2 t = a.sc[c.pos[pos]]; ux = t.x * t.x; uy = t.y * t.y; }
-            sx = ux * mp; sy = uy * mp;
+            sx = ux; sy = uy;  // the fixed-point mask rides in the record's Vinv
         }
         const double v00 = r1.y, v01 = r2.x, v02 = r2.y, v11 = r3.x, v12 = r3.y, v22 = r4.x;
         double A[2][3];
