@@ -194,7 +194,7 @@ int satba_outliers(satba_problem *p, const double *err, double predef_thr, doubl
 /* ---- inspection entry points (parity tests; not used by the solver loop) */
 /* index structures built by satba_problem_create, as int32 arrays (SATBA_LAY_PAIR_OFS: int64): n must equal satba_layout_len */
 enum { SATBA_LAY_PERM = 0, SATBA_LAY_RANK, SATBA_LAY_PT_CNT, SATBA_LAY_SLICE_BASE, SATBA_LAY_E_CAM, SATBA_LAY_OBS_POS, SATBA_LAY_CAM_OFS,
-       SATBA_LAY_CM_PT, SATBA_LAY_CM_POS, SATBA_LAY_PAIR_OFS, SATBA_LAY_PAIR_PTS, SATBA_LAY_PAIR_PI, SATBA_LAY_PAIR_PJ, SATBA_LAY_PAIR_IJ };
+       SATBA_LAY_CM_PT, SATBA_LAY_CM_POS, SATBA_LAY_PAIR_OFS, SATBA_LAY_PAIR_PTS, SATBA_LAY_PAIR_PI, SATBA_LAY_PAIR_PJ, SATBA_LAY_PAIR_IJ, SATBA_LAY_CM_IO, SATBA_LAY_IPT_OFS };
 int64_t satba_layout_len(const satba_problem *p, int32_t which);
 int satba_get_layout(satba_problem *p, int32_t which, int64_t n, void *host_out);
 /* n >= 16 doubles: [0..4] milliseconds since the start of satba_problem_create when the uploads were queued, the layout sizes were

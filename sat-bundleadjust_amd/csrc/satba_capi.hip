@@ -64,8 +64,9 @@ struct satba_problem {
     double *d_x = nullptr, *d_xnew = nullptr, *d_camc = nullptr, *d_camc_new = nullptr;
     double *d_scale_inv = nullptr, *d_g = nullptr, *d_gh = nullptr, *d_gn = nullptr, *d_q1 = nullptr, *d_wv = nullptr;
     double *d_U = nullptr, *d_gc = nullptr, *d_V = nullptr, *d_Vinv = nullptr, *d_PV = nullptr, *d_dc = nullptr, *d_dch = nullptr;
-    double2 *d_f = nullptr, *d_sc = nullptr;  // residual pairs / Jacobian row scales, ELL order
-    double* d_Jpm = nullptr;                  // RPC: Jacobian blocks of the current linearisation, ELL order
+    double2 *d_f = nullptr, *d_ftmp = nullptr;  // residual pairs of the current linearisation / of satba_residuals, ELL order
+    double2* d_sc = nullptr;                  // Jacobian row scales of the current linearisation, io order
+    double* d_Jpm = nullptr;                  // RPC: Jacobian blocks of the current linearisation, io order
     double *d_part = nullptr, *d_part3 = nullptr, *d_pair_part = nullptr;
     int lin_grid = 0, cm_chunks = 1;
     double* d_red = nullptr;  // RED_SLOTS x (RED_MAX_NV x RED_MAX_GRID doubles) partials of the deterministic grid sums
@@ -73,7 +74,8 @@ struct satba_problem {
     double* d_stage = nullptr;  // staging for host transfers in the caller's order
     size_t stage_len = 0;
     int* d_fail = nullptr;
-    int chol_mode = 0;  // SATBA_CHOL: 0 double steps (default), 2 single steps
+    int chol_mode = 0;  // SATBA_CHOL: 0 double steps (default), 2 single steps, 3 double steps + triangular backward substitution
+    double* d_dinv = nullptr;  // inverted diagonal blocks of the factor
     double* d_scal = nullptr;  // 8 private scalars (costs of satba_residuals, timing sinks)
     double* d_keep = nullptr;  // SATBA_KEEP_LEN scalars of the running iteration that outlive the per-phase headers
     bool prepared = false;
@@ -137,6 +139,7 @@ static ObsArgs obs_args(const satba_problem* p, bool at_new) {
     ObsArgs a;
     const Layout& L = p->L;
     a.e_cam = L.e_cam; a.e_obs = L.e_obs; a.e_w = L.e_w; a.slice_base = L.slice_base; a.pt_cnt = L.pt_cnt; a.perm = L.perm;
+    a.ipt_ofs = L.ipt_ofs;
     a.x = at_new ? p->d_xnew : p->d_x;
     a.camc = at_new ? p->d_camc_new : p->d_camc;
     a.rpc = p->d_rpc;
@@ -148,7 +151,7 @@ static ObsArgs obs_args(const satba_problem* p, bool at_new) {
     a.unit = (p->loss == 0 && p->unit_weights) ? 1 : 0;
     return a;
 }
-static CamMajor cam_major(const satba_problem* p) { return CamMajor{p->L.cam_ofs, p->L.cm_pt, p->L.cm_pos}; }
+static CamMajor cam_major(const satba_problem* p) { return CamMajor{p->L.cam_ofs, p->L.cm_pt, p->L.cm_pos, p->L.cm_io}; }
 
 static int grid_for(long long work, int block, int cap) {
     long long g = (work + block - 1) / block;
@@ -349,7 +352,8 @@ static int launch_jvp(satba_problem* p, int nv, const double* q1, const double* 
 
 // S z = rhs for the reduced system (S column-major lower, destroyed; b in place)
 static int dense_solve(satba_problem* p, double* S, double* b) {
-    cholesky_solve(S, p->n_c, b, p->d_fail, p->d_fail + 1, p->chol_mode, p->stream);  // clears d_fail and the step flags
+    cholesky_solve(S, p->n_c, b, p->d_fail, p->d_fail + 1, p->chol_mode == 3 ? 0 : p->chol_mode, p->stream, nullptr,
+                   p->chol_mode == 3 ? nullptr : p->d_dinv);  // clears d_fail and the step flags
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -406,13 +410,15 @@ static int build_layout(satba_problem* p, const satba_problem_desc* d) {
     auto free_tmp = [&]() { for (void* q : tmp) (void)hipFree(q); tmp.clear(); };
 #define TMP(ptr, count) TRY(tmp_alloc((void**)&(ptr), sizeof(*(ptr)) * (size_t)(count)))
     int rc = [&]() -> int {
-        int *o_cam = nullptr, *flags = nullptr, *o_ofs = nullptr, *cnt_o = nullptr, *iota = nullptr, *slots = nullptr, *ipt_ofs = nullptr;
+        int *o_cam = nullptr, *flags = nullptr, *o_ofs = nullptr, *cnt_o = nullptr, *iota = nullptr, *slots = nullptr;
         double2* o_obs = nullptr;
         double* o_w = nullptr;
         long long* hits = nullptr;
         const size_t Kz = (size_t)std::max<long long>(K, 1), Nz = (size_t)std::max(N, 1);
         TMP(o_cam, Kz); TMP(o_obs, Kz); TMP(o_w, Kz); TMP(flags, 4); TMP(o_ofs, Nz + 1); TMP(cnt_o, Nz); TMP(iota, Nz);
-        TMP(slots, L.n_slices + 1); TMP(ipt_ofs, Nz + 1); TMP(hits, Nz + 1);
+        TMP(slots, L.n_slices + 1); TMP(hits, Nz + 1);
+        TRY(dev_alloc(p, &L.ipt_ofs, Nz + 1)); TRY(dev_alloc(p, &L.cm_io, Kz));
+        int* ipt_ofs = L.ipt_ofs;
         TRY(dev_alloc(p, &L.pts_ind, Kz)); TRY(dev_alloc(p, &L.obs_pos, Kz));
         TRY(dev_alloc(p, &L.perm, Nz)); TRY(dev_alloc(p, &L.rank, Nz)); TRY(dev_alloc(p, &L.pt_cnt, Nz));
         TRY(dev_alloc(p, &L.slice_base, L.n_slices + 1)); TRY(dev_alloc(p, &L.hit_ofs, Nz + 1));
@@ -438,8 +444,8 @@ static int build_layout(satba_problem* p, const satba_problem_desc* d) {
         cub_bytes = std::max(cub_bytes, need);
         HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, need, hits, L.hit_ofs, N + 1, st));
         cub_bytes = std::max(cub_bytes, need);
-        int *io_cam = nullptr, *io_pos = nullptr, *io_pt = nullptr, *io_iota = nullptr, *cm_key = nullptr, *cm_io = nullptr;
-        TMP(io_cam, Kz); TMP(io_pos, Kz); TMP(io_pt, Kz); TMP(io_iota, Kz); TMP(cm_key, Kz); TMP(cm_io, Kz);
+        int *io_cam = nullptr, *io_pos = nullptr, *io_pt = nullptr, *io_iota = nullptr, *cm_key = nullptr, *cm_io = L.cm_io;
+        TMP(io_cam, Kz); TMP(io_pos, Kz); TMP(io_pt, Kz); TMP(io_iota, Kz); TMP(cm_key, Kz);
         int bits_m = 1;
         while ((1ll << bits_m) < M) ++bits_m;
         HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, need, io_cam, cm_key, io_iota, cm_io, (int)K, 0, bits_m, st));
@@ -524,7 +530,7 @@ static int build_layout(satba_problem* p, const satba_problem_desc* d) {
             if (L.E > 0) {
                 int *hk = nullptr, *hq = nullptr, *hpi = nullptr, *hpj = nullptr, *hi = nullptr, *hk_s = nullptr, *hi_s = nullptr;
                 TMP(hk, Ez); TMP(hq, Ez); TMP(hpi, Ez); TMP(hpj, Ez); TMP(hi, Ez); TMP(hk_s, Ez); TMP(hi_s, Ez);
-                hipLaunchKernelGGL(k_lay_hits, dim3((N + 255) / 256), dim3(256), 0, st, N, M, L.pt_cnt, L.slice_base, L.e_cam, L.hit_ofs, hk, hq, hpi, hpj);
+                hipLaunchKernelGGL(k_lay_hits, dim3((N + 255) / 256), dim3(256), 0, st, N, M, L.pt_cnt, L.slice_base, L.ipt_ofs, L.e_cam, L.hit_ofs, hk, hq, hpi, hpj);
                 hipLaunchKernelGGL(k_lay_iota, dim3(grid_for(L.E, 256, 8192)), dim3(256), 0, st, L.E, hi);
                 int bits_p = 1;
                 while ((1ll << bits_p) < L.n_pairs) ++bits_p;
@@ -611,10 +617,12 @@ int satba_problem_create(const satba_problem_desc* d, satba_problem** out) {
         TRY(dev_alloc(p, &p->d_V, (size_t)6 * p->N)); TRY(dev_alloc(p, &p->d_Vinv, (size_t)6 * p->N));
         TRY(dev_alloc(p, &p->d_PV, (size_t)PV_STRIDE * std::max(p->N, 1)));
         TRY(dev_alloc(p, &p->d_dc, p->n_c)); TRY(dev_alloc(p, &p->d_dch, p->n_c));
-        TRY(dev_alloc(p, &p->d_f, Pz)); TRY(dev_alloc(p, &p->d_sc, Pz));
-        if (p->model == RPC) TRY(dev_alloc(p, &p->d_Jpm, Pz * (2 * p->NP + 6)));
+        const size_t Kz = (size_t)std::max<long long>(K, 1) + 64;
+        TRY(dev_alloc(p, &p->d_f, Pz)); TRY(dev_alloc(p, &p->d_ftmp, Pz)); TRY(dev_alloc(p, &p->d_sc, Kz));
+        if (p->model == RPC) TRY(dev_alloc(p, &p->d_Jpm, Kz * (2 * p->NP + 6)));
         TRY(dev_alloc(p, &p->d_fail, 1 + CH_MAX_STEPS));  // [0] not-SPD flag, then the panel-step flags
         { const char* cs = getenv("SATBA_CHOL"); p->chol_mode = cs ? atoi(cs) : 0; }
+        TRY(dev_alloc(p, &p->d_dinv, (size_t)((p->n_c + CH_NB - 1) / CH_NB) * CH_NB * CH_NB));
         TRY(dev_alloc(p, &p->d_scal, 8));
         TRY(dev_alloc(p, &p->d_keep, SATBA_KEEP_LEN));
         HIP_TRY(hipMemset(p->d_keep, 0, sizeof(double) * SATBA_KEEP_LEN));
@@ -769,29 +777,20 @@ int satba_get_x(satba_problem* p, double* host_x) {
 int satba_residuals(satba_problem* p, double* host_r, double* host_cost) {
     if (!p) return fail(SATBA_E_ARG, "null handle");
     HIP_TRY(hipSetDevice(p->device));
-    // the cost goes through a private scalar so the exchange header of a running solve is left alone; the residual pairs
-    // go to the staging buffer (d_f holds the residuals of the current linearisation, which later phases read)
+    // the cost goes through a private scalar so the exchange header of a running solve is left alone; the residual pairs go
+    // to their own buffer (d_f holds the residuals of the current linearisation) and from there, in the caller's observation
+    // order, through the staging buffer
     double* slot = p->d_scal;
-    double2* f_ell = reinterpret_cast<double2*>(p->d_stage);
+    double2* f_obs = reinterpret_cast<double2*>(p->d_stage);
     const bool want = host_r != nullptr && p->K > 0;
-    // ELL-ordered scratch: behind the caller-ordered copy in the staging buffer would not fit; use d_sc when it is free
-    double2* scratch = nullptr;
+    TRY(launch_residual(p, false, want ? p->d_ftmp : nullptr, slot));
+    HIP_TRY(hipMemcpyAsync(p->h_pin, slot, sizeof(double), hipMemcpyDeviceToHost, p->stream));
     if (want) {
-        HIP_TRY(hipMalloc((void**)&scratch, sizeof(double2) * ((size_t)p->L.P + 64)));
+        hipLaunchKernelGGL(k_gather_obs, dim3(grid_for(p->K, 256, 4096)), dim3(256), 0, p->stream, p->K, p->L.obs_pos, p->d_ftmp, f_obs);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(host_r, f_obs, sizeof(double) * 2 * p->K, hipMemcpyDeviceToHost, p->stream));
     }
-    int rc = [&]() -> int {
-        TRY(launch_residual(p, false, want ? scratch : nullptr, slot));
-        HIP_TRY(hipMemcpyAsync(p->h_pin, slot, sizeof(double), hipMemcpyDeviceToHost, p->stream));
-        if (want) {
-            hipLaunchKernelGGL(k_gather_obs, dim3(grid_for(p->K, 256, 4096)), dim3(256), 0, p->stream, p->K, p->L.obs_pos, scratch, f_ell);
-            HIP_TRY(hipGetLastError());
-            HIP_TRY(hipMemcpyAsync(host_r, f_ell, sizeof(double) * 2 * p->K, hipMemcpyDeviceToHost, p->stream));
-        }
-        HIP_TRY(hipStreamSynchronize(p->stream));
-        return 0;
-    }();
-    if (scratch) (void)hipFree(scratch);
-    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(p->stream));
     if (host_cost) *host_cost = p->h_pin[0];
     return 0;
 }
@@ -1162,7 +1161,8 @@ int64_t satba_layout_len(const satba_problem* p, int32_t which) {
         case SATBA_LAY_PERM: case SATBA_LAY_RANK: case SATBA_LAY_PT_CNT: return L.N;
         case SATBA_LAY_SLICE_BASE: return L.n_slices + 1;
         case SATBA_LAY_E_CAM: return L.P;
-        case SATBA_LAY_OBS_POS: case SATBA_LAY_CM_PT: case SATBA_LAY_CM_POS: return L.K;
+        case SATBA_LAY_OBS_POS: case SATBA_LAY_CM_PT: case SATBA_LAY_CM_POS: case SATBA_LAY_CM_IO: return L.K;
+        case SATBA_LAY_IPT_OFS: return L.N + 1;
         case SATBA_LAY_CAM_OFS: return L.M + 1;
         case SATBA_LAY_PAIR_OFS: return L.n_pairs * (L.C + 1) + 1;
         case SATBA_LAY_PAIR_PTS: case SATBA_LAY_PAIR_PI: case SATBA_LAY_PAIR_PJ: return L.E;
@@ -1187,6 +1187,8 @@ int satba_get_layout(satba_problem* p, int32_t which, int64_t n, void* host_out)
         case SATBA_LAY_OBS_POS: src = L.obs_pos; break;
         case SATBA_LAY_CM_PT: src = L.cm_pt; break;
         case SATBA_LAY_CM_POS: src = L.cm_pos; break;
+        case SATBA_LAY_CM_IO: src = L.cm_io; break;
+        case SATBA_LAY_IPT_OFS: src = L.ipt_ofs; break;
         case SATBA_LAY_CAM_OFS: src = L.cam_ofs; break;
         case SATBA_LAY_PAIR_OFS: src = L.pair_ofs; esz = sizeof(long long); break;
         case SATBA_LAY_PAIR_PTS: src = L.pair_pts; break;

@@ -41,6 +41,71 @@ __device__ inline double half_rsqrt(double d) {
     return fma(h, r, h);
 }
 
+// Diagonal block in registers: lanes 0..31 hold the rows of the block (a[c], zero above the diagonal), lanes 32..63
+// ride along (rows below the block: they end up holding L21).  Returns true if a pivot was not positive and finite.
+//
+// Micro-panels of 8 columns.  Inside a micro-panel everything stays in registers: the serial chain per column is
+// l = a_j * rsqrt(d) -> pivot of column j + 1 from the lane's own value (a[j+1] - l * l) -> readlane -> rsqrt; the other
+// columns of the micro-panel get L[c][j] by v_readlane (an SGPR operand of the multiply-add).  After a micro-panel its
+// 8 values per row go to LDS once and the remaining columns receive a rank-8 update from LDS broadcasts.
+// Round 1 broadcast every column through LDS: the LDS write -> read round trip (~60 ns) sat on the chain of the next
+// pivot 32 times per block (6.5 us per block; tools/chol_times.py); here it is paid 3 times.
+// pan: 64 x 8 doubles of LDS private to the wave.
+constexpr int CH_MP = 8;
+__device__ __forceinline__ bool chol_diag_block(double (&a)[CH_NB], int lane, double (*pan)[CH_MP]) {
+    bool bad = false;
+    double d = readlane_f64(a[0], 0);
+    bad |= !(d > 1e-300) || !(d < 1e300);
+    double h = half_rsqrt(d);
+#pragma unroll
+    for (int p = 0; p < CH_NB / CH_MP; ++p) {
+#pragma unroll
+        for (int jj = 0; jj < CH_MP; ++jj) {
+            const int j = CH_MP * p + jj;
+            const double a2 = a[j] + a[j];
+            const double l = a2 * h;  // lane j: 2 d h = sqrt(d)
+            a[j] = l;
+            if (j + 1 < CH_NB) {
+                const double piv = fma(-l, l, a[j + 1]);  // lane j + 1: its own l is L[j+1][j]
+                if (jj + 1 < CH_MP) {  // next pivot inside the micro-panel: complete after this column
+                    d = readlane_f64(piv, j + 1);
+                    bad |= !(d > 1e-300) || !(d < 1e300);
+                    h = half_rsqrt(d);
+                }
+#pragma unroll
+                for (int c = j + 1; c < CH_MP * (p + 1); ++c) a[c] = fma(-l, readlane_f64(l, c), a[c]);
+            }
+        }
+        if (p + 1 < CH_NB / CH_MP) {
+            // rank-8 update of the columns behind the micro-panel
+            double2* row = reinterpret_cast<double2*>(&pan[lane][0]);
+#pragma unroll
+            for (int m = 0; m < CH_MP / 2; ++m) row[m] = make_double2(a[CH_MP * p + 2 * m], a[CH_MP * p + 2 * m + 1]);
+            __builtin_amdgcn_wave_barrier();  // single wave: its LDS operations execute in order
+#pragma unroll
+            for (int c = CH_MP * (p + 1); c < CH_NB; ++c) {
+                const double2* lc = reinterpret_cast<const double2*>(&pan[c][0]);  // row c of the panel: the same address for every lane
+                double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+                for (int m = 0; m < CH_MP / 2; ++m) {
+                    const double2 t = lc[m];
+                    s0 = fma(a[CH_MP * p + 2 * m], t.x, s0);
+                    s1 = fma(a[CH_MP * p + 2 * m + 1], t.y, s1);
+                }
+                a[c] -= s0 + s1;
+                if (c == CH_MP * (p + 1)) {  // the next pivot: start its chain as early as possible
+                    d = readlane_f64(a[c], c);
+                    bad |= !(d > 1e-300) || !(d < 1e300);
+                    h = half_rsqrt(d);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            asm volatile("" ::: "memory");
+        }
+    }
+    return bad;
+}
+
 // One panel step in one launch.  kp: first column of the previous panel (applied to the trailing matrix here; < 0:
 // none), k0: first column of the panel that is factorised (k0 = kp + CH_NB or 0).  1-D grid over the lower 64x64
 // tiles of A[k0:, k0:], tile column 0 first.  flag: one int per launch, zero on entry.
@@ -59,6 +124,7 @@ __global__ __launch_bounds__(256) void k_chol_step(double* __restrict__ A, int n
     __shared__ double Pi[CH_NB][64], Pj[CH_NB][64];  // Pj doubles as the stash X[c][r] of the tile's first 32 columns
     __shared__ double Lb[CH_NB][CH_NB];              // L_kk, Lb[c][r] = L[r][c] (column-major like A)
     __shared__ double lcol[2][64];
+    __shared__ double pan[64][CH_MP];
     __shared__ double brow[64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int T = (n - k0 + 63) / 64;
@@ -148,32 +214,7 @@ __global__ __launch_bounds__(256) void k_chol_step(double* __restrict__ A, int n
                 if (c >= nb && lane >= CH_NB) v = 0.0;
                 a[c] = v;
             }
-            // Serial chain per column: l = a_j * inv -> pivot of column j + 1 (own l: a[j+1] - l * l, no LDS round trip)
-            // -> readlane -> rsqrt.  Everything else (broadcast of l through LDS, the other columns) hangs off it.
-            // The positivity test only raises the flag: a failed factorisation is discarded by the caller.
-            bool bad = false;
-            double d = readlane_f64(a[0], 0);
-            bad |= !(d > 1e-300) || !(d < 1e300);
-            double h = half_rsqrt(d);
-#pragma unroll
-            for (int j = 0; j < CH_NB; ++j) {
-                const double a2 = a[j] + a[j];
-                const double l = a2 * h;  // lane j: 2 d h = sqrt(d)
-                a[j] = l;
-                if (j + 1 < CH_NB) {
-                    const double piv = fma(-l, l, a[j + 1]);
-                    d = readlane_f64(piv, j + 1);
-                    bad |= !(d > 1e-300) || !(d < 1e300);
-                    h = half_rsqrt(d);
-                    lcol[j & 1][lane] = l;  // single wave: its LDS operations execute in order
-                    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                    for (int c = j + 1; c < CH_NB; ++c) a[c] -= l * lcol[j & 1][c];
-                    __builtin_amdgcn_wave_barrier();
-                    asm volatile("" ::: "memory");
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
+            const bool bad = chol_diag_block(a, lane, pan);  // a failed factorisation only raises the flag: the caller discards it
             // publish L_kk first: agent-scope stores (write through to the coherence point) + flag, no release fence --
             // a fence writes back the whole L2 of this XCD (~2.5 us measured) while the other tiles are still storing
             if (lane < nb) {
@@ -410,6 +451,85 @@ __global__ __launch_bounds__(1024) void k_trsv_back_rl(const double* __restrict_
     if (c < n) b[c] = yb[c];
 }
 
+
+// Inverse of every 32 x 32 diagonal block of the factor (lower triangular), one wave per block: lane c solves D x = e_c by
+// forward substitution in registers, the entries of D come as LDS broadcasts (every lane reads the same address).
+// dinv: n_blocks x 32 x 32, [r][c] row-major, identity padded.  All blocks at once, off the factorisation's chain (~2 us).
+__global__ __launch_bounds__(64) void k_chol_dinv(const double* __restrict__ L, int n, double* __restrict__ dinv) {
+    __shared__ double D[CH_NB][CH_NB + 1];
+    const int kb = blockIdx.x, k0 = kb * CH_NB, nb = min(CH_NB, n - k0), lane = threadIdx.x;
+    for (int idx = lane; idx < CH_NB * CH_NB; idx += 64) {
+        const int r = idx % CH_NB, c = idx / CH_NB;
+        D[r][c] = (r < nb && c <= r) ? L[(size_t)(k0 + r) + (size_t)(k0 + c) * n] : ((r == c) ? 1.0 : 0.0);
+    }
+    __builtin_amdgcn_wave_barrier();
+    const int c = min(lane, CH_NB - 1);
+    double x[CH_NB];
+#pragma unroll
+    for (int r = 0; r < CH_NB; ++r) {
+        double s = (r == c) ? 1.0 : 0.0;
+#pragma unroll
+        for (int m = 0; m < r; ++m) s = fma(-D[r][m], x[m], s);
+        x[r] = s / D[r][r];
+    }
+    if (lane < CH_NB) {
+#pragma unroll
+        for (int r = 0; r < CH_NB; ++r) dinv[((size_t)kb * CH_NB + r) * CH_NB + c] = x[r];
+    }
+}
+
+// L^T z = y for n <= 1024 with the inverted diagonal blocks: right-looking, one workgroup, thread = column.  Per 32-row block
+// (bottom up): z_k = D_k^-T y_k is a 32 x 32 matrix-vector product in one wave (no dependent chain: the triangular solve of
+// k_trsv_back_rl took 2 us per block), then every thread c < k0 subtracts its 32-term dot product L[k0:k0+32, c] . z_k, reading
+// L^T from the mirrored upper triangle (coalesced).  The operands of a step and the next inverse block are requested before
+// the product of that step and arrive behind it.
+__global__ __launch_bounds__(1024) void k_trsv_back_dinv(const double* __restrict__ L, const double* __restrict__ dinv, int n,
+                                                         double* __restrict__ b) {
+    __shared__ double yb[1024 + CH_NB];
+    __shared__ double zs[CH_NB];
+    __shared__ double Dk[2][CH_NB][CH_NB + 1];  // Dk[.][r][c] = (D_k^-1)[r][c]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = tid;
+    const int nblk = (n + CH_NB - 1) / CH_NB;
+    auto load_dinv = [&](int kb) {
+        const int r = tid / CH_NB, cc = tid % CH_NB;
+        Dk[kb & 1][r][cc] = dinv[((size_t)kb * CH_NB + r) * CH_NB + cc];
+    };
+    double yc = (c < n) ? b[c] : 0.0;
+    yb[c] = yc;
+    if (tid < CH_NB) yb[1024 + tid] = 0.0;
+    load_dinv(nblk - 1);
+    __syncthreads();
+    for (int kb = nblk - 1; kb >= 0; --kb) {
+        const int k0 = kb * CH_NB, nb = min(CH_NB, n - k0);
+        double lv[CH_NB];
+        if (c < k0) {
+            const double* src = L + (size_t)c + (size_t)k0 * n;  // (row c, column k0 + r) of the upper triangle = L[k0 + r][c]
+#pragma unroll
+            for (int r = 0; r < CH_NB; ++r) lv[r] = (r < nb) ? src[(size_t)r * n] : 0.0;
+        }
+        if (kb > 0) load_dinv(kb - 1);
+        if (wave == 0) {  // z_j = sum_r Dinv[r][j] y[k0 + r]; lanes 32..63 take the second half of the sum
+            const int j = lane & (CH_NB - 1), h = lane >> 5;
+            double v = 0.0;
+#pragma unroll
+            for (int r = 0; r < CH_NB / 2; ++r) v = fma(Dk[kb & 1][h * (CH_NB / 2) + r][j], yb[k0 + h * (CH_NB / 2) + r], v);
+            v += __shfl_xor(v, 32);
+            __builtin_amdgcn_wave_barrier();  // every lane has read y_k
+            if (lane < CH_NB) { zs[lane] = v; yb[k0 + lane] = v; }
+        }
+        __syncthreads();
+        if (c < k0) {
+            double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+            for (int r = 0; r < CH_NB; r += 2) { s0 = fma(lv[r], zs[r], s0); s1 = fma(lv[r + 1], zs[r + 1], s1); }
+            yc -= s0 + s1;
+            yb[c] = yc;
+        }
+        __syncthreads();
+    }
+    if (c < n) b[c] = yb[c];
+}
+
 }  // namespace satba
 #include "satba_chol2.h"
 namespace satba {
@@ -420,8 +540,9 @@ constexpr int CH_MAX_STEPS = 256;  // flags: one per panel step (n <= 8192)
 // flags: CH_MAX_STEPS ints of scratch directly behind *fail (flags == fail + 1); both are cleared here.
 // mode 0: double steps (k_chol_dstep, satba_chol2.h) while at least 64 columns remain, then single steps; 2: single steps
 // only (k_chol_step)
+// dinv: (n / 32 rounded up) x 1024 doubles of scratch for the inverted diagonal blocks (n <= 1024), or null
 inline void cholesky_solve(double* A, int n, double* b, int* fail, int* flags, int mode, hipStream_t stream,
-                           long long* ts = nullptr) {
+                           long long* ts = nullptr, double* dinv = nullptr) {
     (void)hipMemsetAsync(fail, 0, sizeof(int) * (1 + CH_MAX_STEPS), stream);  // flags == fail + 1: one fill for both
     int step = 0, k0 = 0, kp2 = -1, kp = -1;
     if (mode == 0 && !ts) {
@@ -443,7 +564,12 @@ inline void cholesky_solve(double* A, int n, double* b, int* fail, int* flags, i
     if (n <= 1024) {
         const int T = (n + 31) / 32;
         hipLaunchKernelGGL(k_mirror_lower, dim3(T * (T + 1) / 2), dim3(256), 0, stream, A, n);
-        hipLaunchKernelGGL(k_trsv_back_rl, dim3(1), dim3(1024), 0, stream, A, n, b);
+        if (dinv) {
+            hipLaunchKernelGGL(k_chol_dinv, dim3(T), dim3(64), 0, stream, A, n, dinv);
+            hipLaunchKernelGGL(k_trsv_back_dinv, dim3(1), dim3(1024), 0, stream, A, dinv, n, b);
+        } else {
+            hipLaunchKernelGGL(k_trsv_back_rl, dim3(1), dim3(1024), 0, stream, A, n, b);
+        }
     }
     else hipLaunchKernelGGL(k_trsv_back, dim3(1), dim3(1024), sizeof(double) * n, stream, A, n, b);
 }

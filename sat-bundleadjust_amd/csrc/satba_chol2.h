@@ -18,37 +18,6 @@
 
 namespace satba {
 
-// Diagonal block in registers: lanes 0..31 hold the rows of the block (a[c], zero above the diagonal), lanes 32..63
-// ride along (rows below the block: they end up holding L21).  Serial chain per column: l = a_j * inv -> pivot of
-// column j + 1 (own l: a[j+1] - l * l, no LDS round trip) -> readlane -> rsqrt; the broadcast of l through LDS and the
-// other columns hang off it.  Returns true if a pivot was not positive and finite.
-__device__ __forceinline__ bool chol_diag_block(double (&a)[CH_NB], int lane, double (*lcol)[64]) {
-    bool bad = false;
-    double d = readlane_f64(a[0], 0);
-    bad |= !(d > 1e-300) || !(d < 1e300);
-    double h = half_rsqrt(d);
-#pragma unroll
-    for (int j = 0; j < CH_NB; ++j) {
-        const double a2 = a[j] + a[j];
-        const double l = a2 * h;  // lane j: 2 d h = sqrt(d)
-        a[j] = l;
-        if (j + 1 < CH_NB) {
-            const double piv = fma(-l, l, a[j + 1]);
-            d = readlane_f64(piv, j + 1);
-            bad |= !(d > 1e-300) || !(d < 1e300);
-            h = half_rsqrt(d);
-            lcol[j & 1][lane] = l;  // single wave: its LDS operations execute in order
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int c = j + 1; c < CH_NB; ++c) a[c] -= l * lcol[j & 1][c];
-            __builtin_amdgcn_wave_barrier();
-            asm volatile("" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-    return bad;
-}
-
 // x L^T = p for one row per lane, in registers; Lb[c][r] = L[r][c] in LDS, inv[m] = 1 / L[m][m] in LDS.
 // Row m + 1 of L^T is read from LDS while step m is computed.
 __device__ __forceinline__ void chol_panel_rows(double (&x)[CH_NB], const double (*Lb)[CH_NB], const double* inv) {
@@ -92,6 +61,7 @@ __global__ __launch_bounds__(256) void k_chol_dstep(double* __restrict__ A, int 
     __shared__ double Pi[CH_NB][64], Pj[CH_NB][64];  // after the update: the tile's columns 0..31 (Pj) and 32..63 (Pi), [c][r]
     __shared__ double Lb[CH_NB][CH_NB], Lb2[CH_NB][CH_NB], L21s[CH_NB][CH_NB];  // [c][r] = L[r][c]
     __shared__ double lcol[2][64];
+    __shared__ double pan[64][CH_MP];
     __shared__ double brow[64];
     __shared__ double ys[CH_NB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -200,7 +170,7 @@ __global__ __launch_bounds__(256) void k_chol_dstep(double* __restrict__ A, int 
                 if (lane < CH_NB && c > lane) v = 0.0;  // above the diagonal
                 a[c] = v;
             }
-            const bool bad = chol_diag_block(a, lane, lcol);
+            const bool bad = chol_diag_block(a, lane, pan);
             // publish L11 and L21: agent-scope stores (write through to the coherence point) + flag, no release fence
 #pragma unroll
             for (int c = 0; c < CH_NB; ++c)
@@ -250,7 +220,7 @@ __global__ __launch_bounds__(256) void k_chol_dstep(double* __restrict__ A, int 
             double a[CH_NB];
 #pragma unroll
             for (int c = 0; c < CH_NB; ++c) a[c] = (lane < CH_NB && c <= lane) ? Pi[c][CH_NB + lane] : 0.0;  // no riders
-            const bool bad = chol_diag_block(a, lane, lcol);
+            const bool bad = chol_diag_block(a, lane, pan);
             if (lane < CH_NB) {
 #pragma unroll
                 for (int c = 0; c < CH_NB; ++c)

@@ -37,14 +37,17 @@ struct ObsArgs {
     const int* __restrict__ slice_base;  // n_slices + 1: first ELL position of every slice
     const int* __restrict__ pt_cnt;      // N: track length of internal point q
     const int* __restrict__ perm;        // N: caller's local index of internal point q (fixed points: perm < n_pts_fix)
+    const int* __restrict__ ipt_ofs;     // N + 1: io index (internal point-major) of every point's first observation
     const double* __restrict__ x;        // variable vector [cameras | internal points] whose POINT part is used
     const double* __restrict__ camc;     // M x CAMC camera constants built from the same vector
     const double* __restrict__ rpc;      // M x 90 or null
-    double* __restrict__ Jpm;            // RPC only (else null): P x (2 NP + 6) Jacobian blocks Jc | Jp of the current
-                                         // linearisation; written by the linearize kernel and read by every later pass
-                                         // (the RPC chain costs 2-3 kflop per evaluation)
-    double2* __restrict__ sc;            // weighted / robust runs (else null): P Jacobian row scales (w js0, w js1) of the
-                                         // current linearisation; written by the linearize kernel
+    double* __restrict__ Jpm;            // RPC only (else null): K x (2 NP + 6) Jacobian blocks Jc | Jp of the current
+                                         // linearisation, io order; written by the linearize kernel and read by every later
+                                         // pass (the RPC chain costs 2-3 kflop per evaluation)
+    double2* __restrict__ sc;            // weighted / robust runs (else null): K Jacobian row scales (w js0, w js1) of the
+                                         // current linearisation, io order; written by the linearize kernel.  io order: a
+                                         // lane streams through its point's entries, and the Schur pair kernel finds the two
+                                         // scales of a hit in neighbouring lines (in ELL order they are 1 KB apart)
     long long K;
     int P, n_slices, M, N, n_c, n_cam_fix, n_pts_fix, loss, f32;
     int unit;                            // every weight is 1 and the loss is linear
@@ -107,18 +110,18 @@ struct ObsEval {
     }
 
     // the blocks of the current linearisation, stored / reloaded (RPC): 2 NP + 6 doubles = NP + 3 16-byte words
-    __device__ inline void store_jac(const ObsArgs& a, int pos) const {
+    __device__ inline void store_jac(const ObsArgs& a, int io) const {
         double t[2 * NP + 6];
 #pragma unroll
         for (int k = 0; k < NP; ++k) { t[k] = Jc[0][k]; t[NP + k] = Jc[1][k]; }
 #pragma unroll
         for (int k = 0; k < 3; ++k) { t[2 * NP + k] = Jp[0][k]; t[2 * NP + 3 + k] = Jp[1][k]; }
-        double2* q = reinterpret_cast<double2*>(a.Jpm + (size_t)pos * (2 * NP + 6));
+        double2* q = reinterpret_cast<double2*>(a.Jpm + (size_t)io * (2 * NP + 6));
 #pragma unroll
         for (int k = 0; k < NP + 3; ++k) q[k] = make_double2(t[2 * k], t[2 * k + 1]);
     }
-    __device__ inline void load_jac(const ObsArgs& a, int pos) {
-        const double2* q = reinterpret_cast<const double2*>(a.Jpm + (size_t)pos * (2 * NP + 6));
+    __device__ inline void load_jac(const ObsArgs& a, int io) {
+        const double2* q = reinterpret_cast<const double2*>(a.Jpm + (size_t)io * (2 * NP + 6));
         double t[2 * NP + 6];
 #pragma unroll
         for (int k = 0; k < NP + 3; ++k) { const double2 v = q[k]; t[2 * k] = v.x; t[2 * k + 1] = v.y; }
@@ -131,16 +134,16 @@ struct ObsEval {
     // (RPC); otherwise the unit-weight, linear-loss Jacobian times the row scales the linearize kernel stored (a.sc;
     // null when every weight is 1 and the loss is linear).  Neither the observation nor its weight is read and the
     // loss function is not evaluated.
-    __device__ inline void jac(const ObsArgs& a, int pos, int cam, double mp, const double* cc, const double* tab,
+    __device__ inline void jac(const ObsArgs& a, int io, int cam, double mp, const double* cc, const double* tab,
                                const double X, const double Y, const double Z) {
         if constexpr (MODEL == RPC) {  // always stored for RPC cameras
-            load_jac(a, pos);
+            load_jac(a, io);
             return;
         }
         double u, v;
         project<MODEL, NP, true>(cc, tab, X, Y, Z, false, u, v, Jc, Jp);
         double s0 = 1.0, s1 = 1.0;
-        if (a.sc) { const double2 t = a.sc[pos]; s0 = t.x; s1 = t.y; }
+        if (a.sc) { const double2 t = a.sc[io]; s0 = t.x; s1 = t.y; }
         const double mc = (cam >= a.n_cam_fix) ? 1.0 : 0.0;
 #pragma unroll
         for (int i = 0; i < NP; ++i) { Jc[0][i] *= s0 * mc; Jc[1][i] *= s1 * mc; }
@@ -414,6 +417,7 @@ __global__ __launch_bounds__(LinCfg<(ROBUST && !SOFT) || MODEL == RPC>::THREADS)
         }
         double v[9] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
         int pos = base + lane;
+        const int io0 = has ? a.ipt_ofs[q] : 0;
         // software pipeline: the records of the next two slots are in flight during the arithmetic and the LDS atomics of this one
         ObsRec r[SATBA_PF + 1];
 #pragma unroll
@@ -425,8 +429,8 @@ __global__ __launch_bounds__(LinCfg<(ROBUST && !SOFT) || MODEL == RPC>::THREADS)
                 const int cam = r[0].cam;
                 ObsEval<MODEL, NP, true, ROBUST, SOFT, UNITW> e;
                 e.eval(a, cam, mp, T.cc(cam), T.tab(cam), r[0].ob, r[0].w, X, Y, Z);
-                if constexpr (MODEL == RPC) e.store_jac(a, pos);
-                if (a.sc) a.sc[pos] = make_double2(e.sw[0], e.sw[1]);
+                if constexpr (MODEL == RPC) e.store_jac(a, io0 + k);
+                if (a.sc) a.sc[io0 + k] = make_double2(e.sw[0], e.sw[1]);
                 f[pos] = make_double2(e.ftrue[0], e.ftrue[1]);
                 cost += e.rho;
                 v[0] += e.Jp[0][0] * e.Jp[0][0] + e.Jp[1][0] * e.Jp[1][0];
@@ -516,7 +520,8 @@ __global__ __launch_bounds__(1024) void k_lin_finish(int M, int NP, int nblocks,
 struct CamMajor {
     const int* __restrict__ cam_ofs;  // M + 1
     const int* __restrict__ pt;       // K: internal point of every entry
-    const int* __restrict__ pos;      // K: its ELL position
+    const int* __restrict__ pos;      // K: its ELL position (residuals)
+    const int* __restrict__ io;       // K: its io index (row scales, stored RPC blocks)
 };
 constexpr int LINC_THREADS = 256;
 
@@ -537,12 +542,12 @@ __global__ __launch_bounds__(LINC_THREADS) void k_cam_sums(ObsArgs a, CamMajor c
 #pragma unroll
     for (int k = 0; k < CU; ++k) acc[k] = 0.0;
     for (int i = lo + threadIdx.x; i < hi; i += LINC_THREADS) {
-        const int pos = c.pos[i], q = c.pt[i];
+        const int pos = c.pos[i], q = c.pt[i], io = c.io[i];
         const double2 ff = f[pos];
         double Jc[2][NP], Jp[2][3];
         if constexpr (MODEL == RPC) {  // the blocks k_linearize stored (scales and masks included)
             ObsEval<MODEL, NP, true> e2;
-            e2.load_jac(a, pos);
+            e2.load_jac(a, io);
 #pragma unroll
             for (int k = 0; k < NP; ++k) { Jc[0][k] = e2.Jc[0][k]; Jc[1][k] = e2.Jc[1][k]; }
         } else {
@@ -550,7 +555,7 @@ __global__ __launch_bounds__(LINC_THREADS) void k_cam_sums(ObsArgs a, CamMajor c
             double u, v;
             project<MODEL, NP, true>(cc, nullptr, px[0], px[1], px[2], false, u, v, Jc, Jp);
             double s0 = mc, s1 = mc;
-            if (a.sc) { const double2 t = a.sc[pos]; s0 *= t.x; s1 *= t.y; }
+            if (a.sc) { const double2 t = a.sc[io]; s0 *= t.x; s1 *= t.y; }
 #pragma unroll
             for (int k = 0; k < NP; ++k) { Jc[0][k] *= s0; Jc[1][k] *= s1; }
         }
@@ -701,13 +706,14 @@ __global__ __launch_bounds__(JVP_THREADS) void k_jvp(ObsArgs a, const double* __
                 v0 = mp * q1[ip]; v1 = mp * q1[ip + 1]; v2 = mp * q1[ip + 2];
             }
             int pos = base + lane;
+            const int io0 = has ? a.ipt_ofs[q] : 0;
             // cameras (and row scales) of the next two slots in flight
             int c0 = (0 < cnt) ? a.e_cam[pos] : 0, c1 = (1 < cnt) ? a.e_cam[pos + 64] : 0;
-            double2 s0 = (0 < cnt && a.sc) ? a.sc[pos] : make_double2(1.0, 1.0), s1 = (1 < cnt && a.sc) ? a.sc[pos + 64] : make_double2(1.0, 1.0);
+            double2 s0 = (0 < cnt && a.sc) ? a.sc[io0] : make_double2(1.0, 1.0), s1 = (1 < cnt && a.sc) ? a.sc[io0 + 1] : make_double2(1.0, 1.0);
             for (int k = 0; k < len; ++k, pos += 64) {
                 int c2 = 0;
                 double2 s2 = make_double2(1.0, 1.0);
-                if (k + 2 < cnt) { c2 = a.e_cam[pos + 128]; if (a.sc) s2 = a.sc[pos + 128]; }
+                if (k + 2 < cnt) { c2 = a.e_cam[pos + 128]; if (a.sc) s2 = a.sc[io0 + k + 2]; }
                 __builtin_amdgcn_sched_barrier(0);
                 if (k < cnt) {
                     const double* row = tab + (size_t)c0 * JVP_ROW;
@@ -742,11 +748,12 @@ __global__ __launch_bounds__(JVP_THREADS) void k_jvp(ObsArgs a, const double* __
                 }
             }
             int pos = base + lane;
+            const int io0 = has ? a.ipt_ofs[q] : 0;
             for (int k = 0; k < len; ++k, pos += 64) {
                 if (k < cnt) {
                     const int cam = a.e_cam[pos];
                     ObsEval<MODEL, NP, true> e;
-                    e.jac(a, pos, cam, mp, T.cc(cam), T.tab(cam), X, Y, Z);
+                    e.jac(a, io0 + k, cam, mp, T.cc(cam), T.tab(cam), X, Y, Z);
                     const size_t ic = (size_t)cam * NP;
                     double j1[2] = {0, 0}, j2[2] = {0, 0};
 #pragma unroll
@@ -875,13 +882,14 @@ __global__ __launch_bounds__(BS_THREADS) void k_backsub(ObsArgs a, const double*
         }
         double t[3] = {0.0, 0.0, 0.0};
         int pos = base + lane;
+        const int io0 = has ? a.ipt_ofs[q] : 0;
         if constexpr (MODEL == AFFINE) {
             int c0 = (0 < cnt) ? a.e_cam[pos] : 0, c1 = (1 < cnt) ? a.e_cam[pos + 64] : 0;
-            double2 w0 = (0 < cnt && a.sc) ? a.sc[pos] : make_double2(1.0, 1.0), w1 = (1 < cnt && a.sc) ? a.sc[pos + 64] : make_double2(1.0, 1.0);
+            double2 w0 = (0 < cnt && a.sc) ? a.sc[io0] : make_double2(1.0, 1.0), w1 = (1 < cnt && a.sc) ? a.sc[io0 + 1] : make_double2(1.0, 1.0);
             for (int k = 0; k < len; ++k, pos += 64) {
                 int c2 = 0;
                 double2 w2 = make_double2(1.0, 1.0);
-                if (k + 2 < cnt) { c2 = a.e_cam[pos + 128]; if (a.sc) w2 = a.sc[pos + 128]; }
+                if (k + 2 < cnt) { c2 = a.e_cam[pos + 128]; if (a.sc) w2 = a.sc[io0 + k + 2]; }
                 __builtin_amdgcn_sched_barrier(0);
                 const int cam = c0;
                 const double2 s2 = w0;
@@ -900,7 +908,7 @@ __global__ __launch_bounds__(BS_THREADS) void k_backsub(ObsArgs a, const double*
                 if (k < cnt) {
                     const int cam = a.e_cam[pos];
                     ObsEval<MODEL, NP, true> e;
-                    e.jac(a, pos, cam, mp, T.cc(cam), T.tab(cam), X, Y, Z);
+                    e.jac(a, io0 + k, cam, mp, T.cc(cam), T.tab(cam), X, Y, Z);
                     double u0 = 0.0, u1 = 0.0;
 #pragma unroll
                     for (int i = 0; i < NP; ++i) {

@@ -13,10 +13,13 @@
 //              A slice is as long as its longest track; because the points are sorted by length the padding is a few
 //              slots at the boundaries between length classes (e_cam = -1 there).  Every per-observation array of the
 //              solver (residuals, row scales, stored RPC Jacobian blocks) uses these positions.
-//   cameras    cam_ofs[M + 1], cm_pt[K], cm_pos[K]: the observations of every camera, internal point ascending
+//   io         internal point-major observation index io(q, k) = ipt_ofs[q] + k: the observations of a point are neighbours.
+//              Per-observation data that the Schur kernels GATHER (Jacobian row scales, stored RPC blocks) is kept in this
+//              order, so that the two observations of a (camera pair, point) hit share cache lines.
+//   cameras    cam_ofs[M + 1], cm_pt[K], cm_pos[K], cm_io[K]: the observations of every camera, internal point ascending
 //              (camera-major passes: diagonal Schur blocks, deterministic camera sums).
 //   pairs      for every camera pair (i < j) the points both see, ascending, cut into C point-range chunks:
-//              pair_ofs[pair (C + 1) + chunk], pair_pts[E], pair_pi[E], pair_pj[E] (ELL positions of the two
+//              pair_ofs[pair (C + 1) + chunk], pair_pts[E], pair_pi[E], pair_pj[E] (io indices of the two
 //              observations), pair_ij[pair] = (i, j).
 #pragma once
 #include <hip/hip_runtime.h>
@@ -35,7 +38,8 @@ struct Layout {
     double2* e_obs = nullptr;
     double* e_w = nullptr;
     int *obs_pos = nullptr, *pts_ind = nullptr;
-    int *cam_ofs = nullptr, *cm_pt = nullptr, *cm_pos = nullptr;
+    int* ipt_ofs = nullptr;  // N + 1: internal point-major observation index ("io") of every point's first observation
+    int *cam_ofs = nullptr, *cm_pt = nullptr, *cm_pos = nullptr, *cm_io = nullptr;
     long long* pair_ofs = nullptr;
     int2* pair_ij = nullptr;
     int *pair_pts = nullptr, *pair_pi = nullptr, *pair_pj = nullptr;
@@ -140,20 +144,20 @@ __global__ void k_lay_gather3(long long n, const int* __restrict__ idx, const in
 
 __host__ __device__ inline long long pair_index(long long M, long long a, long long b) { return a * M - a * (a + 1) / 2 + (b - a - 1); }
 
-// all camera pairs of every point, in internal point order: key = pair index, values = point, the two ELL positions
-__global__ void k_lay_hits(int N, int M, const int* __restrict__ cnt, const int* __restrict__ slice_base, const int* __restrict__ e_cam,
-                           const long long* __restrict__ hit_ofs, int* __restrict__ key, int* __restrict__ hq, int* __restrict__ hpi,
-                           int* __restrict__ hpj) {
+// all camera pairs of every point, in internal point order: key = pair index, values = point, the io indices of its two observations
+__global__ void k_lay_hits(int N, int M, const int* __restrict__ cnt, const int* __restrict__ slice_base, const int* __restrict__ ipt_ofs,
+                           const int* __restrict__ e_cam, const long long* __restrict__ hit_ofs, int* __restrict__ key, int* __restrict__ hq,
+                           int* __restrict__ hpi, int* __restrict__ hpj) {
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= N) return;
-    const int n = cnt[q], base = slice_base[q >> 6] + (q & 63);
+    const int n = cnt[q], base = slice_base[q >> 6] + (q & 63), io0 = ipt_ofs[q];
     long long at = hit_ofs[q];
     for (int a = 0; a < n; ++a) {
         const int ca = e_cam[base + 64 * a];
         for (int b = a + 1; b < n; ++b) {
             const int cb = e_cam[base + 64 * b];
             key[at] = (int)pair_index(M, ca, cb);
-            hq[at] = q; hpi[at] = base + 64 * a; hpj[at] = base + 64 * b;
+            hq[at] = q; hpi[at] = io0 + a; hpj[at] = io0 + b;
             ++at;
         }
     }

@@ -70,7 +70,7 @@ struct SchurArgs {
     const double2* __restrict__ PV;          // N x 8 double2: X0 X1 | X2 v00 | v01 v02 | v11 v12 | v22 g0 | g1 g2 | pad
     const long long* __restrict__ pair_ofs;  // n_pairs x (n_chunks + 1): offsets into the lists
     const int* __restrict__ pair_pts;        // points shared by each camera pair, ascending (static per problem)
-    const int* __restrict__ pair_pi;         // ELL positions of the point's observation in camera i / j
+    const int* __restrict__ pair_pi;         // io indices of the point's observation in camera i / j
     const int* __restrict__ pair_pj;
     const int2* __restrict__ pair_ij;        // pair index -> (i, j), i < j
     double* __restrict__ pair_part;          // n_chunks x n_pairs x NP*NP partial blocks (n_chunks > 1)
@@ -307,7 +307,7 @@ __global__ __launch_bounds__(LINC_THREADS) void k_schur_diag(ObsArgs a, CamMajor
         double ux = 1.0, uy = 1.0;  // squared row scales on the J_c^T J_c term (no point mask there)
         if constexpr (MODEL == RPC) {  // the blocks the linearize kernel stored (scales and masks included)
             ObsEval<MODEL, NP, true> e2;
-            e2.load_jac(a, c.pos[pos]);
+            e2.load_jac(a, c.io[pos]);
 #pragma unroll
             for (int k = 0; k < NP; ++k) { Jc[0][k] = e2.Jc[0][k]; Jc[1][k] = e2.Jc[1][k]; }
 #pragma unroll
@@ -315,7 +315,7 @@ __global__ __launch_bounds__(LINC_THREADS) void k_schur_diag(ObsArgs a, CamMajor
         } else {
             double u, v;
             project<MODEL, NP, true>(cc, nullptr, r0.x, r0.y, r1.x, false, u, v, Jc, Jp);
-            if (a.sc) { const double2 t = a.sc[c.pos[pos]]; ux = t.x * t.x; uy = t.y * t.y; }
+            if (a.sc) { const double2 t = a.sc[c.io[pos]]; ux = t.x * t.x; uy = t.y * t.y; }
             sx = ux; sy = uy;  // the fixed-point mask rides in the record's Vinv
         }
         const double v00 = r1.y, v01 = r2.x, v02 = r2.y, v11 = r3.x, v12 = r3.y, v22 = r4.x;

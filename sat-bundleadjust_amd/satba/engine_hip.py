@@ -35,7 +35,7 @@ SYMBOLS = [
 
 FLAG_DETERMINISTIC = 1
 LAYOUT = {"perm": 0, "rank": 1, "pt_cnt": 2, "slice_base": 3, "e_cam": 4, "obs_pos": 5, "cam_ofs": 6, "cm_pt": 7, "cm_pos": 8,
-          "pair_ofs": 9, "pair_pts": 10, "pair_pi": 11, "pair_pj": 12, "pair_ij": 13}
+          "pair_ofs": 9, "pair_pts": 10, "pair_pi": 11, "pair_pj": 12, "pair_ij": 13, "cm_io": 14, "ipt_ofs": 15}
 
 
 class LmOpts(C.Structure):

@@ -38,14 +38,16 @@ def numpy_layout(p, C):
     e_cam = np.full(slice_base[-1], -1, dtype=np.int64)
     e_cam[pos] = cam
     order = np.lexsort((q, cam))  # camera-major, internal point ascending
+    ipt_ofs = np.concatenate(([0], np.cumsum(pt_cnt)))
+    io_idx = ipt_ofs[q] + k  # internal point-major index of every observation
     out = dict(perm=perm, rank=rank, pt_cnt=pt_cnt, slice_base=slice_base, e_cam=e_cam, obs_pos=pos, cm_pt=q[order], cm_pos=pos[order],
-               cam_ofs=np.searchsorted(cam[order], np.arange(M + 1)))
+               cm_io=io_idx[order], ipt_ofs=ipt_ofs, cam_ofs=np.searchsorted(cam[order], np.arange(M + 1)))
     # pair lists: all camera pairs of every point in internal point order, stable sort by pair index
     io = np.lexsort((k, q))  # internal point-major
     keys, hq, hpi, hpj = [], [], [], []
     b = 0
     for n in pt_cnt[pt_cnt > 0]:
-        cs, ps, qq = cam[io[b: b + n]], pos[io[b: b + n]], q[io[b]]
+        cs, ps, qq = cam[io[b: b + n]], io_idx[io[b: b + n]], q[io[b]]
         for x in range(n):
             for y in range(x + 1, n):
                 keys.append(cs[x] * M - cs[x] * (cs[x] + 1) // 2 + (cs[y] - cs[x] - 1))

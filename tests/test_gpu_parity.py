@@ -310,7 +310,7 @@ def test_dense_cholesky_solve(gpu, n_cam, n_p):
 # ----------------------------------------------------------------------------- full solves
 
 @pytest.mark.parametrize("name", list(cases.SOLVE_CASES))
-def test_tight_solve_matches_tight_scipy_reference(gpu, name):
+def test_tight_solve_matches_tight_scipy_reference(gpu, monkeypatch, name):
     """
     SURVEY.md section 8c protocol: reference run with ftol=xtol=gtol=1e-15, LSMR atol=btol=1e-12, gauge fixed.
     rpc: the reference chain in float64 (rpc_store_f32=False here) and scipy's 3-point differences -- its forward
@@ -318,6 +318,11 @@ def test_tight_solve_matches_tight_scipy_reference(gpu, name):
     the forward-difference run is compared too, at what it can resolve.
     """
     _, make_p, g, losses = cases.solve_case(name)
+    if name == "rpc_small_R":
+        # the last iterations of this case crawl along a flat direction and the 1e-15 tolerances stop on rounding noise: with
+        # the run-dependent summation order of the LDS atomics one run in six stopped a step early (residuals 1e-5 off);
+        # the fixed-order option makes the run, and the test, repeatable
+        monkeypatch.setenv("SATBA_DETERMINISTIC", "1")
     for loss in losses:
         p = make_p()
         rpc = p.cam_model == "rpc"
@@ -666,7 +671,7 @@ def test_queued_front_matches_host_driven_phases(gpu, name, Delta):
         e.close()
 
 
-def _two_rank_worker(rank, world, port, name, loss, out_dir):
+def _two_rank_worker(rank, world, port, name, loss, out_dir, backend="gloo"):
     import sys
 
     here = os.path.dirname(os.path.abspath(__file__))
@@ -675,9 +680,13 @@ def _two_rank_worker(rank, world, port, name, loss, out_dir):
     import torch
     import torch.distributed as dist
 
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if backend == "nccl":  # one GPU per rank, RCCL over xGMI
+        torch.cuda.set_device(rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    else:
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     import cases as cs
     from satba import sharding as sh, trf as tr
     from satba.engine_hip import HipEngine as Eng
@@ -718,6 +727,33 @@ def test_two_ranks_on_one_gpu(gpu, tmp_path, name, loss):
     if name != "affine_small_RT":  # R+T on affine cameras with one frozen camera is a flat valley
         assert np.abs(outs[0]["x"][:n_c] - xt[:n_c]).max() < 1e-6 * np.abs(xt[:n_c]).max()
     assert np.linalg.norm(outs[0]["r"] - g["tight_fun_" + loss]) < 5e-6 * np.linalg.norm(g["tight_fun_" + loss])
+    st = g["tight_stats_" + loss]
+    assert abs(float(outs[0]["cost"]) - st[0]) < 1e-9 * st[0]
+
+
+def test_two_ranks_over_rccl(gpu, tmp_path):
+    """
+    The N > 1 product path as the driver's scaling runs launch it: one process and one GPU per rank, the exchange buffers
+    all-reduced by RCCL (backend "nccl").  Needs two devices: skipped on the single-GPU boxes of the test pool.
+    """
+    import torch
+    import torch.multiprocessing as mp
+
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs (RCCL with real ranks); one rank is covered by test_rccl_plumbing_single_rank")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    name, loss = "affine_small_R", "soft_l1"
+    mp.spawn(_two_rank_worker, args=(2, port, name, loss, str(tmp_path), "nccl"), nprocs=2, join=True)
+    outs = [np.load(os.path.join(str(tmp_path), "rank{}.npz".format(r))) for r in range(2)]
+    assert np.array_equal(outs[0]["x"], outs[1]["x"]) and int(outs[0]["nfev"]) == int(outs[1]["nfev"])
+    _, make_p, g, _ = cases.solve_case(name)
+    p = make_p()
+    n_c = p.n_cam * p.n_params
+    xt = g["tight_x_" + loss]
+    assert np.abs(outs[0]["x"][:n_c] - xt[:n_c]).max() < 1e-6 * np.abs(xt[:n_c]).max()
     st = g["tight_stats_" + loss]
     assert abs(float(outs[0]["cost"]) - st[0]) < 1e-9 * st[0]
 
