@@ -68,6 +68,8 @@ struct satba_problem {
     double2* d_sc = nullptr;                  // Jacobian row scales of the current linearisation, io order
     double* d_Jpm = nullptr;                  // RPC: Jacobian blocks of the current linearisation, io order
     double *d_part = nullptr, *d_part3 = nullptr, *d_pair_part = nullptr;
+    int2* d_items = nullptr;  // (pair, chunk) work items of the Schur pair kernel in dispatch order
+    int n_item_blocks = 0;
     int lin_grid = 0, cm_chunks = 1;
     double* d_red = nullptr;  // RED_SLOTS x (RED_MAX_NV x RED_MAX_GRID doubles) partials of the deterministic grid sums
     unsigned* d_red_cnt = nullptr;
@@ -285,7 +287,7 @@ static SchurArgs schur_args(const satba_problem* p) {
     SchurArgs s;
     s.PV = reinterpret_cast<const double2*>(p->d_PV);
     s.pair_ofs = p->L.pair_ofs; s.pair_pts = p->L.pair_pts; s.pair_pi = p->L.pair_pi; s.pair_pj = p->L.pair_pj;
-    s.pair_ij = p->L.pair_ij; s.pair_part = p->d_pair_part; s.n_chunks = p->L.C;
+    s.pair_ij = p->L.pair_ij; s.pair_part = p->d_pair_part; s.n_chunks = p->L.C; s.items = p->d_items;
     return s;
 }
 
@@ -297,7 +299,7 @@ static int launch_schur(satba_problem* p, const ObsArgs& a, double* S, double* r
     // diagonal blocks (with J_c^T J_c) and right-hand side
     hipLaunchKernelGGL((k_schur_diag<MODEL, NP>), dim3(p->M, p->cm_chunks), dim3(LINC_THREADS), 0, p->stream, a, cm, s, p->d_part3);
     if (n_pairs > 0 && p->L.E > 0) {
-        const dim3 igrid((unsigned)((n_pairs + 3) / 4), (unsigned)p->L.C);
+        const dim3 igrid((unsigned)p->n_item_blocks);
         if (a.unit) hipLaunchKernelGGL((k_schur_pairs<MODEL, NP, true>), igrid, dim3(256), 0, p->stream, a, s, S);
         else hipLaunchKernelGGL((k_schur_pairs<MODEL, NP, false>), igrid, dim3(256), 0, p->stream, a, s, S);
         HIP_TRY(hipGetLastError());
@@ -384,6 +386,47 @@ __global__ void k_lambda(const double* __restrict__ hdr, double Delta, double la
 
 static double ms_since(std::chrono::steady_clock::time_point t0) {
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+}
+
+// ---------------------------------------------------------------------------------------------------- Schur work items
+// Dispatch order of the (pair, chunk) items of k_schur_pairs (see the kernel's comment).  The rows of the pair triangle
+// (all pairs (i, j > i) of one camera i) are dealt to the 8 XCDs longest-first onto the least loaded one; an XCD's items
+// are ordered row by row, chunk by chunk; workgroup b = 8 s + x takes the s-th group of 4 items of XCD x.
+// SATBA_SCHUR_ORDER=chunk restores round 1's chunk-major order (A/B runs).
+static int schur_item_table(satba_problem* p) {
+    const int M = p->M, C = p->L.C, X = 8;
+    const long long n_pairs = p->L.n_pairs;
+    std::vector<int2> table;
+    const char* ord = getenv("SATBA_SCHUR_ORDER");
+    if (ord && !strcmp(ord, "chunk")) {
+        for (int ch = 0; ch < C; ++ch) {
+            for (long long pr = 0; pr < n_pairs; ++pr) table.push_back(make_int2((int)pr, ch));
+            while (table.size() % 4) table.push_back(make_int2(-1, 0));
+        }
+    } else {
+        std::vector<std::vector<int2>> per(X);
+        std::vector<long long> load(X, 0);
+        for (int i = 0; i + 1 < M; ++i) {  // rows by decreasing length: i ascending
+            int x = 0;
+            for (int k = 1; k < X; ++k) if (load[k] < load[x]) x = k;
+            load[x] += M - 1 - i;
+            for (int ch = 0; ch < C; ++ch) {
+                for (int j = i + 1; j < M; ++j) per[x].push_back(make_int2((int)pair_index(M, i, j), ch));
+                while (per[x].size() % 4) per[x].push_back(make_int2(-1, 0));  // a workgroup stays inside one (row, chunk) group
+            }
+        }
+        size_t slots = 0;
+        for (int x = 0; x < X; ++x) slots = std::max(slots, per[x].size() / 4);
+        table.assign(slots * X * 4, make_int2(-1, 0));
+        for (int x = 0; x < X; ++x)
+            for (size_t s = 0; s < per[x].size() / 4; ++s)
+                for (int w = 0; w < 4; ++w) table[(s * X + x) * 4 + w] = per[x][s * 4 + w];
+    }
+    if (table.empty()) table.push_back(make_int2(-1, 0)), table.resize(4, make_int2(-1, 0));
+    p->n_item_blocks = (int)(table.size() / 4);
+    TRY(dev_alloc(p, &p->d_items, table.size()));
+    HIP_TRY(hipMemcpy(p->d_items, table.data(), sizeof(int2) * table.size(), hipMemcpyHostToDevice));
+    return 0;
 }
 
 // ---------------------------------------------------------------------------------------------------- layout builder
@@ -641,6 +684,7 @@ int satba_problem_create(const satba_problem_desc* d, satba_problem** out) {
             TRY(dev_alloc(p, &p->d_part3, (size_t)p->M * chunks * cam_acc_len(p->NP)));
         }
         if (p->L.C > 1) TRY(dev_alloc(p, &p->d_pair_part, (size_t)p->L.C * std::max<long long>(p->L.n_pairs, 1) * p->NP * p->NP));
+        TRY(schur_item_table(p));
         p->stage_len = std::max<size_t>(std::max<size_t>(n, 2 * (size_t)K), (size_t)6 * p->N) + 16;
         TRY(dev_alloc(p, &p->d_stage, p->stage_len));
         p->xb_len = satba_exchange_len(p);
