@@ -70,6 +70,7 @@ struct satba_problem {
     double *d_part = nullptr, *d_part3 = nullptr, *d_pair_part = nullptr;
     int2* d_items = nullptr;  // (pair, chunk) work items of the Schur pair kernel in dispatch order
     int n_item_blocks = 0;
+
     int lin_grid = 0, cm_chunks = 1;
     double* d_red = nullptr;  // RED_SLOTS x (RED_MAX_NV x RED_MAX_GRID doubles) partials of the deterministic grid sums
     unsigned* d_red_cnt = nullptr;

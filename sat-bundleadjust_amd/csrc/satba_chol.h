@@ -41,6 +41,27 @@ __device__ inline double half_rsqrt(double d) {
     return fma(h, r, h);
 }
 
+constexpr int CH_LD = 80;  // row stride (doubles) of the LDS panel copies: 160 dwords = 32 mod 64 banks, so the four k-rows an
+                           // MFMA operand load touches (16 consecutive doubles each) fall into disjoint bank ranges
+typedef double chol_d4 __attribute__((ext_vector_type(4)));
+// acc[rb] += sum_k Pc[k][16 w + i] Pr[k][16 rb + j] for the 64 x 16 strip of a 64 x 64 tile that wave w owns, K = CH_NB, with
+// v_mfma_f64_16x16x4 (A[i][k]: lane i + 16 k, B[k][j]: lane j + 16 k, D[i][j]: lane j + 16 (i & 3), register i >> 2):
+// on return acc[rb][reg] of a lane is the update of tile row 16 rb + (lane & 15), tile column 16 w + (lane >> 4) + 4 reg.
+// fp64 MFMA runs at the vector rate: what it saves is LDS operand traffic (40 instead of 256 reads per wave and panel) -- with
+// one wave per SIMD the register-tiled form was bound by LDS latency (4.3 us per panel against ~1 us of arithmetic).
+__device__ __forceinline__ void chol_mfma_update(const double (*Pr)[CH_LD], const double (*Pc)[CH_LD], int wave, int lane, chol_d4 (&acc)[4]) {
+    const int kq = lane >> 4, e = lane & 15;
+#pragma unroll
+    for (int ks = 0; ks < CH_NB / 4; ++ks) {
+        const double a = Pc[4 * ks + kq][16 * wave + e];
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) {
+            const double bb = Pr[4 * ks + kq][16 * rb + e];
+            acc[rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bb, acc[rb], 0, 0, 0);
+        }
+    }
+}
+
 // Diagonal block in registers: lanes 0..31 hold the rows of the block (a[c], zero above the diagonal), lanes 32..63
 // ride along (rows below the block: they end up holding L21).  Returns true if a pivot was not positive and finite.
 //
@@ -52,7 +73,11 @@ __device__ inline double half_rsqrt(double d) {
 // pivot 32 times per block (6.5 us per block; tools/chol_times.py); here it is paid 3 times.
 // pan: 64 x 8 doubles of LDS private to the wave.
 constexpr int CH_MP = 8;
-__device__ __forceinline__ bool chol_diag_block(double (&a)[CH_NB], int lane, double (*pan)[CH_MP]) {
+// pub(c, v): called for every column c of a finished micro-panel with the lane's final value -- the callers publish the block
+// with write-through stores there, so that all but the last micro-panel's stores are acknowledged while the factorisation is
+// still running (they used to be issued at the end: ~1.5 us of store latency on the chain of every panel).
+template <class PUB>
+__device__ __forceinline__ bool chol_diag_block(double (&a)[CH_NB], int lane, double (*pan)[CH_MP], PUB&& pub) {
     bool bad = false;
     double d = readlane_f64(a[0], 0);
     bad |= !(d > 1e-300) || !(d < 1e300);
@@ -76,6 +101,8 @@ __device__ __forceinline__ bool chol_diag_block(double (&a)[CH_NB], int lane, do
                 for (int c = j + 1; c < CH_MP * (p + 1); ++c) a[c] = fma(-l, readlane_f64(l, c), a[c]);
             }
         }
+#pragma unroll
+        for (int jj = 0; jj < CH_MP; ++jj) pub(CH_MP * p + jj, a[CH_MP * p + jj]);
         if (p + 1 < CH_NB / CH_MP) {
             // rank-8 update of the columns behind the micro-panel
             double2* row = reinterpret_cast<double2*>(&pan[lane][0]);
@@ -121,7 +148,7 @@ __global__ __launch_bounds__(256) void k_chol_step(double* __restrict__ A, int n
     // update is still pending; it is applied before panel kp in the same pass over the tile
     // ts (tools only, normally null): 8 wall-clock stamps of this step -- 0 start of tile (0,0), 1 its update done,
     // 2 diagonal block factorised (flag raised), 3 its wave done; 4..7 the same for tile (1, 0): start, update done, flag seen, end
-    __shared__ double Pi[CH_NB][64], Pj[CH_NB][64];  // Pj doubles as the stash X[c][r] of the tile's first 32 columns
+    __shared__ double Pi[CH_NB][CH_LD], Pj[CH_NB][CH_LD];  // Pj doubles as the stash X[c][r] of the tile's first 32 columns
     __shared__ double Lb[CH_NB][CH_NB];              // L_kk, Lb[c][r] = L[r][c] (column-major like A)
     __shared__ double lcol[2][64];
     __shared__ double pan[64][CH_MP];
@@ -137,22 +164,26 @@ __global__ __launch_bounds__(256) void k_chol_step(double* __restrict__ A, int n
         bj = idx + 1;
     }
     const int r0 = k0 + bi * 64, c0 = k0 + bj * 64;
-    const int tr = (tid & 15) * 4, tc = (tid >> 4) * 4;  // rows on the fast index: coalesced A accesses
     const bool stamp = ts && bj == 0 && bi < 2 && tid == 0;
     if (stamp) ts[bi * 4 + 0] = wall_clock64();
 
     if (kp >= 0) {
         // ---- trailing update with the previous panel: A[r0.., c0..] -= P_i P_j^T, b[r0..] -= P_i y_prev
-        double old[4][4];  // the tile itself: in flight together with the panel loads
+        // v_mfma_f64_16x16x4 (chol_mfma_update): wave w owns tile columns 16 w .. 16 w + 15; a lane holds rows 16 rb + (lane & 15),
+        // columns 16 w + (lane >> 4) + 4 reg
+        const int e16 = lane & 15, g4 = lane >> 4;
+        chol_d4 old[4];  // the tile itself: in flight together with the panel loads
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int rb = 0; rb < 4; ++rb)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int r = r0 + tr + i, c = c0 + tc + j;
-                old[j][i] = (r < n && c < n && r >= c) ? A[(size_t)r + (size_t)c * n] : 0.0;
+            for (int reg = 0; reg < 4; ++reg) {
+                const int r = r0 + 16 * rb + e16, cc = c0 + 16 * wave + g4 + 4 * reg;
+                old[rb][reg] = (r < n && cc < n && r >= cc) ? A[(size_t)r + (size_t)cc * n] : 0.0;
             }
         if (bj == 0 && tid < 64) brow[tid] = (r0 + tid < n) ? b[r0 + tid] : 0.0;
-        double acc[4][4] = {};
+        chol_d4 acc[4];
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) acc[rb] = chol_d4{0.0, 0.0, 0.0, 0.0};
         for (int pass = (kp2 >= 0) ? 0 : 1; pass < 2; ++pass) {
             const int kq = pass == 0 ? kp2 : kp;
             if (pass == 1 && kp2 >= 0) __syncthreads();  // the first pass is done with Pi, Pj, lcol
@@ -169,27 +200,19 @@ __global__ __launch_bounds__(256) void k_chol_step(double* __restrict__ A, int n
                 for (int k = 0; k < CH_NB; ++k) s += Pi[k][tid] * lcol[0][k];
                 brow[tid] -= s;  // only this thread touches brow[tid] until the barrier below
             }
-#pragma unroll 8
-            for (int k = 0; k < CH_NB; ++k) {
-                double a[4], c[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) { a[i] = Pi[k][tr + i]; c[i] = Pj[k][tc + i]; }
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) acc[j][i] += a[i] * c[j];
-            }
+            chol_mfma_update(Pi, Pj, wave, lane, acc);
         }
         if (bj == 0 && tid < 64 && bi > 0 && r0 + tid < n) b[r0 + tid] = brow[tid];  // tile (0, 0): solved and stored below
         if (bj == 0) __syncthreads();  // everyone is done reading Pj before it becomes the stash
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int rb = 0; rb < 4; ++rb)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int r = r0 + tr + i, c = c0 + tc + j;
-                const double v = old[j][i] - acc[j][i];
-                if (bj == 0 && tc + j < CH_NB) Pj[tc + j][tr + i] = v;  // panel columns are stored after the solve
-                else if (r < n && c < n && r >= c) A[(size_t)r + (size_t)c * n] = v;
+            for (int reg = 0; reg < 4; ++reg) {
+                const int row = 16 * rb + e16, col = 16 * wave + g4 + 4 * reg;
+                const int r = r0 + row, cc = c0 + col;
+                const double v = old[rb][reg] - acc[rb][reg];
+                if (bj == 0 && col < CH_NB) Pj[col][row] = v;  // panel columns are stored after the solve
+                else if (r < n && cc < n && r >= cc) A[(size_t)r + (size_t)cc * n] = v;
             }
     } else {
         for (int idx = tid; idx < CH_NB * 64; idx += 256) {
@@ -214,14 +237,12 @@ __global__ __launch_bounds__(256) void k_chol_step(double* __restrict__ A, int n
                 if (c >= nb && lane >= CH_NB) v = 0.0;
                 a[c] = v;
             }
-            const bool bad = chol_diag_block(a, lane, pan);  // a failed factorisation only raises the flag: the caller discards it
-            // publish L_kk first: agent-scope stores (write through to the coherence point) + flag, no release fence --
-            // a fence writes back the whole L2 of this XCD (~2.5 us measured) while the other tiles are still storing
-            if (lane < nb) {
-#pragma unroll
-                for (int c = 0; c < CH_NB; ++c)
-                    if (c <= lane) __hip_atomic_store(A + (size_t)(k0 + lane) + (size_t)(k0 + c) * n, a[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
+            // publish L_kk as it is formed: agent-scope stores (write through to the coherence point) + flag, no release fence --
+            // a fence writes back the whole L2 of this XCD (~2.5 us measured) while the other tiles are still storing.
+            // A failed factorisation only raises the flag: the caller discards it.
+            const bool bad = chol_diag_block(a, lane, pan, [&](int c, double v) {
+                if (lane < nb && c <= lane) __hip_atomic_store(A + (size_t)(k0 + lane) + (size_t)(k0 + c) * n, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            });
             __builtin_amdgcn_s_waitcnt(0);  // the stores above are acknowledged
             if (lane == 0) __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (stamp) ts[2] = wall_clock64();

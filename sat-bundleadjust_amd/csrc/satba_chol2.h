@@ -58,7 +58,7 @@ __device__ __forceinline__ void chol_fetch_block(const double* A, int n, int rb,
 
 __global__ __launch_bounds__(256) void k_chol_dstep(double* __restrict__ A, int n, int kpA, int kpB, int k0, int* __restrict__ fail,
                                                     int* __restrict__ flag, double* __restrict__ b) {
-    __shared__ double Pi[CH_NB][64], Pj[CH_NB][64];  // after the update: the tile's columns 0..31 (Pj) and 32..63 (Pi), [c][r]
+    __shared__ double Pi[CH_NB][CH_LD], Pj[CH_NB][CH_LD];  // after the update: the tile's columns 0..31 (Pj) and 32..63 (Pi), [c][r]
     __shared__ double Lb[CH_NB][CH_NB], Lb2[CH_NB][CH_NB], L21s[CH_NB][CH_NB];  // [c][r] = L[r][c]
     __shared__ double lcol[2][64];
     __shared__ double pan[64][CH_MP];
@@ -76,20 +76,24 @@ __global__ __launch_bounds__(256) void k_chol_dstep(double* __restrict__ A, int 
     }
     if (bj != 0 && kpA < 0 && kpB < 0) return;  // first launch: nothing to apply to the trailing tiles
     const int r0 = k0 + bi * 64, c0 = k0 + bj * 64;
-    const int tr = (tid & 15) * 4, tc = (tid >> 4) * 4;  // rows on the fast index: coalesced A accesses
 
     // ---- trailing update with the previous two panels: A[r0.., c0..] -= P_i P_j^T, b[r0..] -= P_i y_prev
+    // v_mfma_f64_16x16x4: wave w owns the 16 tile columns 16 w .. 16 w + 15 and all 64 rows (four 16 x 16 outputs); a lane holds
+    // rows 16 rb + (lane & 15), columns 16 w + (lane >> 4) + 4 reg  (chol_mfma_update)
     {
-        double old[4][4];
+        const int e16 = lane & 15, g4 = lane >> 4;
+        chol_d4 old[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int rb = 0; rb < 4; ++rb)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int r = r0 + tr + i, c = c0 + tc + j;
-                old[j][i] = (r < n && c < n && r >= c) ? A[(size_t)r + (size_t)c * n] : 0.0;
+            for (int reg = 0; reg < 4; ++reg) {
+                const int r = r0 + 16 * rb + e16, c = c0 + 16 * wave + g4 + 4 * reg;
+                old[rb][reg] = (r < n && c < n && r >= c) ? A[(size_t)r + (size_t)c * n] : 0.0;
             }
         if (bj == 0 && tid < 64) brow[tid] = (r0 + tid < n) ? b[r0 + tid] : 0.0;
-        double acc[4][4] = {};
+        chol_d4 acc[4];
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) acc[rb] = chol_d4{0.0, 0.0, 0.0, 0.0};
         // the loads of the second panel are issued before the arithmetic of the first (registers, then LDS): one exposed
         // round of loads per launch instead of two
         constexpr int PF = CH_NB * 64 / 256;  // panel elements per thread and operand
@@ -132,28 +136,20 @@ __global__ __launch_bounds__(256) void k_chol_dstep(double* __restrict__ A, int 
                 for (int k = 0; k < CH_NB; ++k) s += Pi[k][tid] * lcol[0][k];
                 brow[tid] -= s;  // only this thread touches brow[tid] until the next barrier
             }
-#pragma unroll 8
-            for (int k = 0; k < CH_NB; ++k) {
-                double a[4], c[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) { a[i] = Pi[k][tr + i]; c[i] = Pj[k][tc + i]; }
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) acc[j][i] += a[i] * c[j];
-            }
+            chol_mfma_update(Pi, Pj, wave, lane, acc);
         }
         if (bj == 0 && tid < 64 && bi > 0 && r0 + tid < n) b[r0 + tid] = brow[tid];  // tile (0, 0): solved below
         if (bj == 0) __syncthreads();  // everyone is done reading Pi / Pj before they become the stash
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int rb = 0; rb < 4; ++rb)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int r = r0 + tr + i, c = c0 + tc + j;
-                const double v = old[j][i] - acc[j][i];
+            for (int reg = 0; reg < 4; ++reg) {
+                const int row = 16 * rb + e16, col = 16 * wave + g4 + 4 * reg;
+                const int r = r0 + row, c = c0 + col;
+                const double v = old[rb][reg] - acc[rb][reg];
                 if (bj == 0) {
-                    if (tc + j < CH_NB) Pj[tc + j][tr + i] = v;
-                    else Pi[tc + j - CH_NB][tr + i] = v;
+                    if (col < CH_NB) Pj[col][row] = v;
+                    else Pi[col - CH_NB][row] = v;
                 } else if (r < n && c < n && r >= c) A[(size_t)r + (size_t)c * n] = v;
             }
     }
@@ -170,12 +166,11 @@ __global__ __launch_bounds__(256) void k_chol_dstep(double* __restrict__ A, int 
                 if (lane < CH_NB && c > lane) v = 0.0;  // above the diagonal
                 a[c] = v;
             }
-            const bool bad = chol_diag_block(a, lane, pan);
-            // publish L11 and L21: agent-scope stores (write through to the coherence point) + flag, no release fence
-#pragma unroll
-            for (int c = 0; c < CH_NB; ++c)
+            // publish L11 and L21 as they are formed: agent-scope stores (write through to the coherence point) + flag, no release fence
+            const bool bad = chol_diag_block(a, lane, pan, [&](int c, double v) {
                 if (lane >= CH_NB || c <= lane)
-                    __hip_atomic_store(A + (size_t)(k0 + lane) + (size_t)(k0 + c) * n, a[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(A + (size_t)(k0 + lane) + (size_t)(k0 + c) * n, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            });
             __builtin_amdgcn_s_waitcnt(0);  // the stores above are acknowledged
             if (lane == 0) __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (bad && lane == 0) atomicOr(fail, 1);
@@ -220,14 +215,10 @@ __global__ __launch_bounds__(256) void k_chol_dstep(double* __restrict__ A, int 
             double a[CH_NB];
 #pragma unroll
             for (int c = 0; c < CH_NB; ++c) a[c] = (lane < CH_NB && c <= lane) ? Pi[c][CH_NB + lane] : 0.0;  // no riders
-            const bool bad = chol_diag_block(a, lane, pan);
-            if (lane < CH_NB) {
-#pragma unroll
-                for (int c = 0; c < CH_NB; ++c)
-                    if (c <= lane)
-                        __hip_atomic_store(A + (size_t)(k0 + CH_NB + lane) + (size_t)(k0 + CH_NB + c) * n, a[c], __ATOMIC_RELAXED,
-                                           __HIP_MEMORY_SCOPE_AGENT);
-            }
+            const bool bad = chol_diag_block(a, lane, pan, [&](int c, double v) {
+                if (lane < CH_NB && c <= lane)
+                    __hip_atomic_store(A + (size_t)(k0 + CH_NB + lane) + (size_t)(k0 + CH_NB + c) * n, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            });
             __builtin_amdgcn_s_waitcnt(0);
             if (lane == 0) __hip_atomic_store(flag + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (bad && lane == 0) atomicOr(fail, 1);

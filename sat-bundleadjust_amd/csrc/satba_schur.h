@@ -257,6 +257,7 @@ __global__ __launch_bounds__(256) void k_schur_pairs(ObsArgs a, SchurArgs s, dou
     }
 }
 
+
 // several point-range chunks: S block of each pair = sum of its chunk partials (chunk order: repeatable)
 __global__ __launch_bounds__(256) void k_schur_pairs_reduce(int M, int NP, int n_c, int n_chunks, const int2* __restrict__ pair_ij,
                                                             const double* __restrict__ part, double* __restrict__ S) {

@@ -769,6 +769,7 @@ ALT_PATHS = [
     {"SATBA_SCHUR_CHUNKS": "3"},     # pair lists cut into point-range chunks + partial reduce
     {"SATBA_SCHUR_CHUNKS": "1"},     # ... and as one chunk (direct store)
     {"SATBA_CM_CHUNKS": "5"},        # chunking of the camera-major passes
+    {"SATBA_SCHUR_ORDER": "chunk"},  # chunk-major item order of round 1
 ]
 
 
