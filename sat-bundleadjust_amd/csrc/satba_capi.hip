@@ -54,6 +54,7 @@ struct satba_problem {
     int loss = 0;
     int camc_lds = 0, rpc_lds = 0;  // per-camera tables staged in LDS by the observation kernels
     int cam_sums_lds = 1;           // k_linearize accumulates diag U_c / g_c with LDS atomics (0: camera-major pass k_cam_sums)
+    int lin_rep_shift = 0;          // log2 of the replicas of that LDS table (few cameras: same-address atomics serialise)
     int deterministic = 0;
     double f_scale = 1.0, lead = 1.0;
     hipStream_t stream = nullptr;
@@ -152,6 +153,7 @@ static ObsArgs obs_args(const satba_problem* p, bool at_new) {
     a.n_cam_fix = p->n_cam_fix; a.n_pts_fix = p->n_pts_fix; a.loss = p->loss; a.f32 = p->f32;
     a.f_scale = p->f_scale;
     a.unit = (p->loss == 0 && p->unit_weights) ? 1 : 0;
+    a.rep_shift = p->lin_rep_shift;
     return a;
 }
 static CamMajor cam_major(const satba_problem* p) { return CamMajor{p->L.cam_ofs, p->L.cm_pt, p->L.cm_pos, p->L.cm_io}; }
@@ -167,7 +169,7 @@ static size_t table_bytes(const satba_problem* p) {
     return sizeof(double) * ((p->camc_lds ? (size_t)p->M * CAMC : 0) + ((p->model == RPC && p->rpc_lds) ? (size_t)p->M * RPCS : 0));
 }
 static size_t lin_lds(const satba_problem* p) {
-    return table_bytes(p) + (p->cam_sums_lds ? sizeof(double) * (size_t)p->M * cam_sum_stride(p->NP) : 0);
+    return table_bytes(p) + (p->cam_sums_lds ? sizeof(double) * (size_t)(p->M << p->lin_rep_shift) * cam_sum_stride(p->NP) : 0);
 }
 static size_t dir_table_bytes(const satba_problem* p) { return sizeof(double) * (size_t)p->M * JVP_ROW; }
 
@@ -640,7 +642,8 @@ int satba_problem_create(const satba_problem_desc* d, satba_problem** out) {
         TRY(build_layout(p, d));
         // LDS budget of the observation kernels: camera-sum table first, then the camera constants, then the RPC tables
         const size_t budget = 150 * 1024;
-        const size_t acc_b = sizeof(double) * (size_t)p->M * cam_sum_stride(p->NP);
+        while (p->lin_rep_shift < 4 && (p->M << (p->lin_rep_shift + 1)) <= 256) ++p->lin_rep_shift;  // >= ~128 rows
+        const size_t acc_b = sizeof(double) * (size_t)(p->M << p->lin_rep_shift) * cam_sum_stride(p->NP);
         const size_t camc_b = sizeof(double) * (size_t)p->M * CAMC, rpc_b = sizeof(double) * (size_t)p->M * RPCS;
         p->cam_sums_lds = (acc_b <= budget && !p->deterministic && !getenv("SATBA_CAM_SUMS")) ? 1 : 0;
         size_t used = p->cam_sums_lds ? acc_b : 0;

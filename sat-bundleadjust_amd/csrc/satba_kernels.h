@@ -51,6 +51,7 @@ struct ObsArgs {
     long long K;
     int P, n_slices, M, N, n_c, n_cam_fix, n_pts_fix, loss, f32;
     int unit;                            // every weight is 1 and the loss is linear
+    int rep_shift;                       // log2 of the number of replicas of k_linearize's LDS camera table (few cameras)
     double f_scale;
 };
 
@@ -395,10 +396,14 @@ __global__ __launch_bounds__(LinCfg<(ROBUST && !SOFT) || MODEL == RPC>::THREADS)
     constexpr int THREADS = Cfg::THREADS, WAVES = Cfg::WAVES;
     extern __shared__ double s_lin[];
     double* s_acc = s_lin;
+    // With few cameras the 64 lanes of an atomic hit the same few addresses and serialise (10 cameras: 58 of the kernel's 75 us
+    // at 10 x 5 k x 30 k): the table is replicated 2^rep_shift times, a lane adds to replica (lane mod replicas), the flush
+    // adds the replicas up in order.
+    const int n_rows = a.M << a.rep_shift;
     if constexpr (CAMSUMS)
-        for (int i = threadIdx.x; i < a.M * CUS; i += THREADS) s_acc[i] = 0.0;
+        for (int i = threadIdx.x; i < n_rows * CUS; i += THREADS) s_acc[i] = 0.0;
     CamTables<CL, RL> T;
-    T.stage(a, s_lin + (CAMSUMS ? (size_t)a.M * CUS : 0), THREADS);
+    T.stage(a, s_lin + (CAMSUMS ? (size_t)n_rows * CUS : 0), THREADS);
     if constexpr (CAMSUMS && !CL && !RL) __syncthreads();
     const int lane = threadIdx.x & 63;
     const bool const_t = lin_const_t(MODEL, NP, ROBUST, a.unit != 0);
@@ -431,7 +436,12 @@ __global__ __launch_bounds__(LinCfg<(ROBUST && !SOFT) || MODEL == RPC>::THREADS)
                 e.eval(a, cam, mp, T.cc(cam), T.tab(cam), r[0].ob, r[0].w, X, Y, Z);
                 if constexpr (MODEL == RPC) e.store_jac(a, io0 + k);
                 if (a.sc) a.sc[io0 + k] = make_double2(e.sw[0], e.sw[1]);
+#ifdef SATBA_NT_F
+                __builtin_nontemporal_store(e.ftrue[0], &f[pos].x);
+                __builtin_nontemporal_store(e.ftrue[1], &f[pos].y);
+#else
                 f[pos] = make_double2(e.ftrue[0], e.ftrue[1]);
+#endif
                 cost += e.rho;
                 v[0] += e.Jp[0][0] * e.Jp[0][0] + e.Jp[1][0] * e.Jp[1][0];
                 v[1] += e.Jp[0][0] * e.Jp[0][1] + e.Jp[1][0] * e.Jp[1][1];
@@ -444,7 +454,7 @@ __global__ __launch_bounds__(LinCfg<(ROBUST && !SOFT) || MODEL == RPC>::THREADS)
                 v[8] += e.Jp[0][2] * e.fs[0] + e.Jp[1][2] * e.fs[1];
                 if constexpr (CAMSUMS) {
                     // camera block: LDS atomics (ds_add_f64) into this workgroup's table
-                    double* acc = s_acc + (size_t)cam * CUS;
+                    double* acc = s_acc + (size_t)((cam << a.rep_shift) | (lane & ((1 << a.rep_shift) - 1))) * CUS;
 #pragma unroll
                     for (int i = 0; i < NP; ++i)
                         if (!(const_t && i >= 3)) atomicAdd(acc + i, e.Jc[0][i] * e.Jc[0][i] + e.Jc[1][i] * e.Jc[1][i]);
@@ -474,8 +484,10 @@ __global__ __launch_bounds__(LinCfg<(ROBUST && !SOFT) || MODEL == RPC>::THREADS)
         __syncthreads();
         double* out = part + (size_t)blockIdx.x * a.M * 2 * NP;
         for (int i = threadIdx.x; i < a.M * 2 * NP; i += THREADS) {
-            const double t = s_acc[(i / (2 * NP)) * CUS + i % (2 * NP)];
-            out[i] = (UNITW && i / (2 * NP) < a.n_cam_fix) ? 0.0 : t;  // fixed cameras: masked here on the unit-weight path
+            const int cam = i / (2 * NP), k = i % (2 * NP);
+            double t = 0.0;
+            for (int r = 0; r < (1 << a.rep_shift); ++r) t += s_acc[(size_t)((cam << a.rep_shift) | r) * CUS + k];
+            out[i] = (UNITW && cam < a.n_cam_fix) ? 0.0 : t;  // fixed cameras: masked here on the unit-weight path
         }
     }
     double cv[1] = {0.5 * cost};
