@@ -1179,16 +1179,16 @@ int satba_set_exchange(satba_problem* p, int64_t offset, int64_t n, const double
     return 0;
 }
 
-// tools only (tools/chol_times.py): wall-clock stamps (100 MHz) of every panel step of one factorisation of the
-// current reduced system; host_out holds 8 * CH_MAX_STEPS values.  Destroys S.
+// tools only (tools/chol_times.py): wall-clock stamps (100 MHz) of every launch of one factorisation of the current reduced
+// system in the configured mode (SATBA_CHOL); host_out holds CH_TS * CH_MAX_STEPS values, CH_TS per launch.  Destroys S.
 int satba_debug_chol_times(satba_problem* p, long long* host_out, int32_t* n_steps) {
     if (!p || !host_out || !n_steps) return fail(SATBA_E_ARG, "null argument");
     long long* d_ts = nullptr;
-    HIP_TRY(hipMalloc((void**)&d_ts, sizeof(long long) * 8 * CH_MAX_STEPS));
-    HIP_TRY(hipMemset(d_ts, 0, sizeof(long long) * 8 * CH_MAX_STEPS));
-    cholesky_solve(p->payload(), p->n_c, p->d_dch, p->d_fail, p->d_fail + 1, 2, p->stream, d_ts);
+    HIP_TRY(hipMalloc((void**)&d_ts, sizeof(long long) * CH_TS * CH_MAX_STEPS));
+    HIP_TRY(hipMemset(d_ts, 0, sizeof(long long) * CH_TS * CH_MAX_STEPS));
+    cholesky_solve(p->payload(), p->n_c, p->d_dch, p->d_fail, p->d_fail + 1, p->chol_mode == 3 ? 0 : p->chol_mode, p->stream, d_ts);
     HIP_TRY(hipStreamSynchronize(p->stream));
-    HIP_TRY(hipMemcpy(host_out, d_ts, sizeof(long long) * 8 * CH_MAX_STEPS, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(host_out, d_ts, sizeof(long long) * CH_TS * CH_MAX_STEPS, hipMemcpyDeviceToHost));
     HIP_TRY(hipFree(d_ts));
     *n_steps = (p->n_c + CH_NB - 1) / CH_NB;
     return 0;

@@ -142,10 +142,10 @@ __device__ __forceinline__ bool chol_diag_block(double (&a)[CH_NB], int lane, do
 // tools/chol_times.py).
 // FULL: the panel has all CH_NB columns (every step but possibly the last).
 template <bool FULL>
-__global__ __launch_bounds__(256) void k_chol_step(double* __restrict__ A, int n, int kp2, int kp, int k0, int* __restrict__ fail,
+__global__ __launch_bounds__(256) void k_chol_step(double* __restrict__ A, int n, int npend, int k0, int* __restrict__ fail,
                                                    int* __restrict__ flag, double* __restrict__ b, long long* __restrict__ ts) {
-    // kp2 (>= 0 only for the first single step after double steps, k_chol_dstep): one more previous panel whose trailing
-    // update is still pending; it is applied before panel kp in the same pass over the tile
+    // npend: number of 32-column panels directly before k0 whose trailing update is still pending (1 after a single step, 2
+    // after a double step, k_chol_dstep); they are applied one after the other in the same pass over the tile
     // ts (tools only, normally null): 8 wall-clock stamps of this step -- 0 start of tile (0,0), 1 its update done,
     // 2 diagonal block factorised (flag raised), 3 its wave done; 4..7 the same for tile (1, 0): start, update done, flag seen, end
     __shared__ double Pi[CH_NB][CH_LD], Pj[CH_NB][CH_LD];  // Pj doubles as the stash X[c][r] of the tile's first 32 columns
@@ -167,8 +167,8 @@ __global__ __launch_bounds__(256) void k_chol_step(double* __restrict__ A, int n
     const bool stamp = ts && bj == 0 && bi < 2 && tid == 0;
     if (stamp) ts[bi * 4 + 0] = wall_clock64();
 
-    if (kp >= 0) {
-        // ---- trailing update with the previous panel: A[r0.., c0..] -= P_i P_j^T, b[r0..] -= P_i y_prev
+    if (npend > 0) {
+        // ---- trailing update with the previous panel(s): A[r0.., c0..] -= P_i P_j^T, b[r0..] -= P_i y_prev
         // v_mfma_f64_16x16x4 (chol_mfma_update): wave w owns tile columns 16 w .. 16 w + 15; a lane holds rows 16 rb + (lane & 15),
         // columns 16 w + (lane >> 4) + 4 reg
         const int e16 = lane & 15, g4 = lane >> 4;
@@ -184,9 +184,9 @@ __global__ __launch_bounds__(256) void k_chol_step(double* __restrict__ A, int n
         chol_d4 acc[4];
 #pragma unroll
         for (int rb = 0; rb < 4; ++rb) acc[rb] = chol_d4{0.0, 0.0, 0.0, 0.0};
-        for (int pass = (kp2 >= 0) ? 0 : 1; pass < 2; ++pass) {
-            const int kq = pass == 0 ? kp2 : kp;
-            if (pass == 1 && kp2 >= 0) __syncthreads();  // the first pass is done with Pi, Pj, lcol
+        for (int pass = 0; pass < npend; ++pass) {
+            const int kq = k0 - CH_NB * (npend - pass);
+            if (pass > 0) __syncthreads();  // the previous pass is done with Pi, Pj, lcol
             for (int idx = tid; idx < CH_NB * 64; idx += 256) {
                 const int r = idx & 63, k = idx >> 6;
                 Pi[k][r] = (r0 + r < n) ? A[(size_t)(r0 + r) + (size_t)(kq + k) * n] : 0.0;
@@ -555,32 +555,37 @@ __global__ __launch_bounds__(1024) void k_trsv_back_dinv(const double* __restric
 #include "satba_chol2.h"
 namespace satba {
 
-constexpr int CH_MAX_STEPS = 256;  // flags: one per panel step (n <= 8192)
+constexpr int CH_MAX_STEPS = 256;  // panels (n <= 8192); one flag word per panel
 
 // Factorise A (n x n, column-major lower, in place) and solve A z = b in place.  *fail != 0 if A was not SPD.
 // flags: CH_MAX_STEPS ints of scratch directly behind *fail (flags == fail + 1); both are cleared here.
 // mode 0: double steps (k_chol_dstep, satba_chol2.h) while at least 64 columns remain, then single steps; 2: single steps
 // only (k_chol_step)
 // dinv: (n / 32 rounded up) x 1024 doubles of scratch for the inverted diagonal blocks (n <= 1024), or null
+// ts (tools): CH_TS time stamps per launch
 inline void cholesky_solve(double* A, int n, double* b, int* fail, int* flags, int mode, hipStream_t stream,
                            long long* ts = nullptr, double* dinv = nullptr) {
+    static const bool once = [] {  // k_chol_dstep's tile column + scratch exceed the 64 KB a kernel gets without asking
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chol_dstep), hipFuncAttributeMaxDynamicSharedMemorySize, (int)chol_dstep_lds());
+        return true;
+    }();
+    (void)once;
     (void)hipMemsetAsync(fail, 0, sizeof(int) * (1 + CH_MAX_STEPS), stream);  // flags == fail + 1: one fill for both
-    int step = 0, k0 = 0, kp2 = -1, kp = -1;
-    if (mode == 0 && !ts) {
-        for (; n - k0 >= 2 * CH_NB; k0 += 2 * CH_NB, step += 2) {
+    int k0 = 0, npend = 0, step = 0;  // step: launches so far
+    int* fl = flags;
+    auto tsk = [&] { return ts ? ts + CH_TS * step : nullptr; };
+    if (mode == 0) {
+        for (; n - k0 >= 2 * CH_NB; k0 += 2 * CH_NB, fl += 2, npend = 2, ++step) {
             const int T = (n - k0 + 63) / 64;
-            hipLaunchKernelGGL(k_chol_dstep, dim3(T * (T + 1) / 2), dim3(256), 0, stream, A, n, kp2, kp, k0, fail, flags + step, b);
-            kp2 = k0; kp = k0 + CH_NB;
+            hipLaunchKernelGGL(k_chol_dstep, dim3(T * (T + 1) / 2), dim3(256), chol_dstep_lds(), stream, A, n, npend, k0, fail, fl, b, tsk());
         }
     }
-    for (; k0 < n; k0 += CH_NB, ++step) {
+    for (; k0 < n; k0 += CH_NB, ++fl, ++step, npend = 1) {
         const int T = (n - k0 + 63) / 64;
-        long long* tsk = ts ? ts + 8 * step : nullptr;
         if (n - k0 >= CH_NB)
-            hipLaunchKernelGGL(k_chol_step<true>, dim3(T * (T + 1) / 2), dim3(256), 0, stream, A, n, kp2, kp, k0, fail, flags + step, b, tsk);
+            hipLaunchKernelGGL(k_chol_step<true>, dim3(T * (T + 1) / 2), dim3(256), 0, stream, A, n, npend, k0, fail, fl, b, tsk());
         else
-            hipLaunchKernelGGL(k_chol_step<false>, dim3(T * (T + 1) / 2), dim3(256), 0, stream, A, n, kp2, kp, k0, fail, flags + step, b, tsk);
-        kp2 = -1; kp = k0;
+            hipLaunchKernelGGL(k_chol_step<false>, dim3(T * (T + 1) / 2), dim3(256), 0, stream, A, n, npend, k0, fail, fl, b, tsk());
     }
     if (n <= 1024) {
         const int T = (n + 31) / 32;

@@ -1,22 +1,29 @@
-// satba_chol2.h -- double panel step of the dense Cholesky (included by satba_chol.h).
+// satba_chol2.h -- double panel step of the dense Cholesky (included by satba_chol.h): two panels of 32 columns per launch.
 //
-// k_chol_step spends ~20 us per 32-column panel on a chain that cannot be shortened by more parallelism: launch gap
-// (3 us), trailing update of the tile column that holds the panel (7 us, 3 of them the first loads after the launch),
-// diagonal block (6.5 us), panel solve behind a flag (3.4 us).  k_chol_dstep factorises TWO panels (k0 and k0 + 32)
-// per launch: one launch gap and one cold start per 64 columns, the panel solve of the first panel and the update of
-// the second half of the tile column overlap with the second diagonal block.
+// A single panel step costs ~20 us of chain that no amount of parallelism shortens: launch gap (3 us), trailing update of the
+// tile that holds the diagonal block (2.3 us per pending panel: 64 x 64 x 32 fp64 multiply-adds on one CU, plus the cold
+// loads), diagonal block (~6 us), panel solve behind a flag (4 us).  k_chol_dstep factorises TWO panels (k0 and k0 + 32) per
+// launch: one gap and one cold start per 64 columns, and the panel solve of the first panel overlaps the second diagonal block.
 //
-//   all tiles        A_tile -= P_i P_j^T for the (up to) two previous panels kpA, kpB (their trailing updates were
-//                    deferred to this launch), tile column 0 keeps all 64 columns of its tiles in LDS
-//   tile (0, 0)      wave 0 factorises L11 (lanes 32..63 carry the rows of L21 along) and publishes both behind flag[0];
-//                    all four waves form A22 - L21 L21^T; wave 0 factorises L22 and publishes it behind flag[1];
-//                    wave 1 carries the right-hand side (forward substitution folded in)
-//   tiles (i > 0, 0) wave 0 solves its 64 rows against L11 as soon as flag[0] is up, all four waves subtract
-//                    x1 L21^T from the second half, wave 0 solves against L22 behind flag[1]
+// Tile column 0 of a launch = the 64-row tiles of columns k0 .. k0 + 63, one workgroup each, the tile resident in LDS
+// (W[p] = its 32 columns of panel p, [c][r]).
+//   all tiles        first apply the `npend` panels of the previous launch(es) (trailing update, v_mfma_f64_16x16x4; the operands
+//                    of two panels are in flight in registers)
+//   tile (0, 0)      wave 0 factorises D0 (lanes 32..63 carry the rows of L21 along) and publishes both behind flag[0]; three waves
+//                    form A22 - L21 L21^T (MFMA); wave 0 factorises D1 and publishes it behind flag[1].  Wave 1 carries the
+//                    right-hand side (forward substitution folded in) beside the second diagonal block -- off the chain.
+//   tiles (i > 0, 0) wave 0 solves its 64 rows against D0 as soon as flag[0] is up while waves 1..3 fetch L21; all four waves
+//                    subtract X0 L21^T from the second half; wave 0 solves against D1 behind flag[1].
 // Tile (0, 0) is workgroup 0 of the 1-D grid and therefore resident before any waiter.  Requires n - k0 >= 64.
+//
+// Round 2 tried four panels per launch (row tile 1 takes the chain over after two diagonal blocks): 57 us per 128 columns
+// against 2 x 27.5 here -- the trailing update of four pending panels on one CU costs what the saved launch gap gains.
 #pragma once
 
 namespace satba {
+
+constexpr int CH_LS = 48;  // row stride of a fetched 32 x 32 factor block used as MFMA operand (96 dwords = 32 mod 64 banks)
+constexpr int CH_TS = 24;  // time stamps per launch (tools/chol_times.py)
 
 // x L^T = p for one row per lane, in registers; Lb[c][r] = L[r][c] in LDS, inv[m] = 1 / L[m][m] in LDS.
 // Row m + 1 of L^T is read from LDS while step m is computed.
@@ -56,243 +63,297 @@ __device__ __forceinline__ void chol_fetch_block(const double* A, int n, int rb,
     for (int t = 0; t < CH_NB * CH_NB / 64; ++t) (&dst[0][0])[t * 64 + lane] = v[t];  // dst[c][r]
 }
 
-__global__ __launch_bounds__(256) void k_chol_dstep(double* __restrict__ A, int n, int kpA, int kpB, int k0, int* __restrict__ fail,
-                                                    int* __restrict__ flag, double* __restrict__ b) {
-    __shared__ double Pi[CH_NB][CH_LD], Pj[CH_NB][CH_LD];  // after the update: the tile's columns 0..31 (Pj) and 32..63 (Pi), [c][r]
-    __shared__ double Lb[CH_NB][CH_NB], Lb2[CH_NB][CH_NB], L21s[CH_NB][CH_NB];  // [c][r] = L[r][c]
-    __shared__ double lcol[2][64];
-    __shared__ double pan[64][CH_MP];
-    __shared__ double brow[64];
-    __shared__ double ys[CH_NB];
+// acc[i] += sum_k Pc[k][16 c16 + u] Pr[k][16 (rb0 + i) + v]  for i < NRB, K = CH_NB  (lane mapping of chol_mfma_update: on
+// return acc[i][reg] of a lane belongs to row 16 (rb0 + i) + (lane & 15), column 16 c16 + (lane >> 4) + 4 reg)
+template <int NRB>
+__device__ __forceinline__ void chol_mfma_acc(const double* Pr, int ldr, const double* Pc, int ldc, int c16, int rb0, int lane, chol_d4 (&acc)[NRB]) {
+    const int kq = lane >> 4, e = lane & 15;
+#pragma unroll
+    for (int ks = 0; ks < CH_NB / 4; ++ks) {
+        const double a = Pc[(4 * ks + kq) * ldc + 16 * c16 + e];
+#pragma unroll
+        for (int i = 0; i < NRB; ++i) {
+            const double bb = Pr[(4 * ks + kq) * ldr + 16 * (rb0 + i) + e];
+            acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bb, acc[i], 0, 0, 0);
+        }
+    }
+}
+
+__device__ __forceinline__ void chol_spin(const int* f) {
+    while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(1);
+}
+__device__ __forceinline__ void chol_spin_lds(const volatile int* f) {  // hand-over between two waves of a workgroup
+    while (*f == 0) __builtin_amdgcn_s_sleep(1);
+    asm volatile("" ::: "memory");
+}
+
+// y = D^-1 v for a 32 x 32 lower triangular D (Lb[c][r] = D[r][c] in LDS), lane = entry (lanes >= 32 idle)
+__device__ __forceinline__ double chol_fwd32(double v, const double (*Lb)[CH_NB], int lane) {
+    const int cl = min(lane, CH_NB - 1);
+    for (int m = 0; m < CH_NB; ++m) {
+        const double ym = __shfl(v, m) / Lb[m][m];
+        if (lane == m) v = ym;
+        else if (lane > m && lane < CH_NB) v -= Lb[m][cl] * ym;
+    }
+    return v;
+}
+
+// dynamic LDS of k_chol_dstep (more than the 64 KB a kernel may declare statically)
+constexpr size_t chol_dstep_lds() {
+    return sizeof(double) * (2 * CH_NB * CH_LD + CH_NB * CH_LS + 2 * CH_NB * CH_NB + 64 * CH_MP + 64 + 64 + 2 * CH_NB + 8);
+}
+
+__global__ __launch_bounds__(256) void k_chol_dstep(double* __restrict__ A, int n, int npend, int k0, int* __restrict__ fail,
+                                                    int* __restrict__ flag, double* __restrict__ b, long long* __restrict__ ts) {
+    // npend: number of 32-column panels directly before k0 whose trailing update is still pending (0, 1 or 2)
+    // flag: two ints per launch, zero on entry: [p] diagonal block p (and, p = 0, L21) is visible
+    // ts (tools only, normally null): CH_TS wall-clock stamps of this launch, 8 per row tile 0..2 of tile column 0:
+    //   0 start, 1 trailing update done, 2 + p: panel p done (tile 0: diagonal block published; others: rows solved)
+    extern __shared__ double s_ds[];
+    // W[2][32][CH_LD] (during the trailing update: its operands) | Lr[32][CH_LS] | Lb[2][32][32] | pan[64][CH_MP] | brow[64] | lcol[64]
+    // | yv[2][32] | lf (int)           (chol_dstep_lds)
+    double (*W)[CH_NB][CH_LD] = reinterpret_cast<double (*)[CH_NB][CH_LD]>(s_ds);
+    double* Pi = &W[0][0][0];
+    double* Pj = &W[1][0][0];
+    double (*Lr)[CH_LS] = reinterpret_cast<double (*)[CH_LS]>(s_ds + 2 * CH_NB * CH_LD);
+    double (*Lb)[CH_NB][CH_NB] = reinterpret_cast<double (*)[CH_NB][CH_NB]>(s_ds + 2 * CH_NB * CH_LD + CH_NB * CH_LS);
+    double (*pan)[CH_MP] = reinterpret_cast<double (*)[CH_MP]>(&Lb[0][0][0] + 2 * CH_NB * CH_NB);
+    double* brow = &pan[0][0] + 64 * CH_MP;
+    double* lcol = brow + 64;
+    double (*yv)[CH_NB] = reinterpret_cast<double (*)[CH_NB]>(lcol + 64);
+    int* lf = reinterpret_cast<int*>(&yv[0][0] + 2 * CH_NB);
+
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int T = (n - k0 + 63) / 64;
     int bi, bj;
     if ((int)blockIdx.x < T) { bi = blockIdx.x; bj = 0; }
-    else {  // tiles (bi >= bj >= 1), row by row
+    else {  // trailing tiles (bi >= bj >= 1), row by row
         int idx = blockIdx.x - T;
         bi = 1;
         while (idx >= bi) { idx -= bi; ++bi; }
         bj = idx + 1;
     }
-    if (bj != 0 && kpA < 0 && kpB < 0) return;  // first launch: nothing to apply to the trailing tiles
+    const bool col0 = bj == 0;
+    if (!col0 && npend == 0) return;  // first launch: nothing to apply to the trailing tiles
     const int r0 = k0 + bi * 64, c0 = k0 + bj * 64;
+    const int e16 = lane & 15, g4 = lane >> 4;
+    const bool stamp = ts && col0 && bi < 3 && tid == 0;
+    if (stamp) ts[bi * 8 + 0] = wall_clock64();
+    if (col0 && tid == 0) lf[0] = 0;
 
-    // ---- trailing update with the previous two panels: A[r0.., c0..] -= P_i P_j^T, b[r0..] -= P_i y_prev
-    // v_mfma_f64_16x16x4: wave w owns the 16 tile columns 16 w .. 16 w + 15 and all 64 rows (four 16 x 16 outputs); a lane holds
-    // rows 16 rb + (lane & 15), columns 16 w + (lane >> 4) + 4 reg  (chol_mfma_update)
+    // ------------------------------------------------------------------ trailing update with the pending panels
+    // A[r0.., c0..] -= P_i P_j^T, b[r0..] -= P_i y_prev.  Wave w owns the 16 tile columns 16 w .. 16 w + 15 and all 64 rows (four
+    // 16 x 16 outputs); a lane holds rows 16 rb + (lane & 15), columns 16 w + (lane >> 4) + 4 reg  (chol_mfma_update)
     {
-        const int e16 = lane & 15, g4 = lane >> 4;
-        chol_d4 old[4];
+        chol_d4 old[4], acc[4];
 #pragma unroll
-        for (int rb = 0; rb < 4; ++rb)
+        for (int rb = 0; rb < 4; ++rb) {
+            acc[rb] = chol_d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
                 const int r = r0 + 16 * rb + e16, c = c0 + 16 * wave + g4 + 4 * reg;
                 old[rb][reg] = (r < n && c < n && r >= c) ? A[(size_t)r + (size_t)c * n] : 0.0;
             }
-        if (bj == 0 && tid < 64) brow[tid] = (r0 + tid < n) ? b[r0 + tid] : 0.0;
-        chol_d4 acc[4];
-#pragma unroll
-        for (int rb = 0; rb < 4; ++rb) acc[rb] = chol_d4{0.0, 0.0, 0.0, 0.0};
-        // the loads of the second panel are issued before the arithmetic of the first (registers, then LDS): one exposed
-        // round of loads per launch instead of two
-        constexpr int PF = CH_NB * 64 / 256;  // panel elements per thread and operand
-        double pfi[PF], pfj[PF], pfy = 0.0;
-        const int kq1 = kpA >= 0 ? kpA : kpB, kq2 = kpA >= 0 ? kpB : -1;  // first / second panel to apply (-1: none)
-        if (kq1 >= 0) {
+        }
+        if (col0 && tid < 64) brow[tid] = (r0 + tid < n) ? b[r0 + tid] : 0.0;
+        // operands of one pending panel: my rows (Pi) and the rows of the tile's column range (Pj); both panels in flight in registers
+        constexpr int PF = CH_NB * 64 / 256;
+        struct Operands { double i[PF], j[PF], y; };
+        auto fetch = [&](Operands& o, int kq) {
 #pragma unroll
             for (int t = 0; t < PF; ++t) {
                 const int idx = tid + t * 256, r = idx & 63, k = idx >> 6;
-                Pi[k][r] = (r0 + r < n) ? A[(size_t)(r0 + r) + (size_t)(kq1 + k) * n] : 0.0;
-                Pj[k][r] = (c0 + r < n) ? A[(size_t)(c0 + r) + (size_t)(kq1 + k) * n] : 0.0;
+                const size_t col = (size_t)(kq + k) * n;
+                o.i[t] = (r0 + r < n) ? A[(size_t)(r0 + r) + col] : 0.0;
+                o.j[t] = (c0 + r < n) ? A[(size_t)(c0 + r) + col] : 0.0;
             }
-            if (bj == 0 && tid >= 64 && tid < 64 + CH_NB) lcol[0][tid - 64] = b[kq1 + tid - 64];  // y of that panel
-        }
-        if (kq2 >= 0) {
+            o.y = (col0 && tid >= 64 && tid < 64 + CH_NB) ? b[kq + tid - 64] : 0.0;  // y of that panel
+        };
+        auto apply = [&](Operands& o, int pass) {
+            if (pass > 0) __syncthreads();  // the previous pass is done with the operand arrays
 #pragma unroll
             for (int t = 0; t < PF; ++t) {
                 const int idx = tid + t * 256, r = idx & 63, k = idx >> 6;
-                pfi[t] = (r0 + r < n) ? A[(size_t)(r0 + r) + (size_t)(kq2 + k) * n] : 0.0;
-                pfj[t] = (c0 + r < n) ? A[(size_t)(c0 + r) + (size_t)(kq2 + k) * n] : 0.0;
+                Pi[k * CH_LD + r] = o.i[t]; Pj[k * CH_LD + r] = o.j[t];
             }
-            if (bj == 0 && tid >= 64 && tid < 64 + CH_NB) pfy = b[kq2 + tid - 64];
-        }
-        for (int pass = 0; pass < 2; ++pass) {
-            if ((pass == 0 ? kq1 : kq2) < 0) continue;
-            if (pass == 1) {
-                __syncthreads();  // the first pass is done with Pi, Pj, lcol
-#pragma unroll
-                for (int t = 0; t < PF; ++t) {
-                    const int idx = tid + t * 256, r = idx & 63, k = idx >> 6;
-                    Pi[k][r] = pfi[t];
-                    Pj[k][r] = pfj[t];
-                }
-                if (bj == 0 && tid >= 64 && tid < 64 + CH_NB) lcol[0][tid - 64] = pfy;
-            }
+            if (col0 && tid >= 64 && tid < 64 + CH_NB) lcol[tid - 64] = o.y;
             __syncthreads();
-            if (bj == 0 && tid < 64) {
+            if (col0 && tid < 64) {
                 double s = 0.0;
 #pragma unroll 8
-                for (int k = 0; k < CH_NB; ++k) s += Pi[k][tid] * lcol[0][k];
+                for (int k = 0; k < CH_NB; ++k) s += Pi[k * CH_LD + tid] * lcol[k];
                 brow[tid] -= s;  // only this thread touches brow[tid] until the next barrier
             }
-            chol_mfma_update(Pi, Pj, wave, lane, acc);
-        }
-        if (bj == 0 && tid < 64 && bi > 0 && r0 + tid < n) b[r0 + tid] = brow[tid];  // tile (0, 0): solved below
-        if (bj == 0) __syncthreads();  // everyone is done reading Pi / Pj before they become the stash
+            chol_mfma_acc<4>(Pi, CH_LD, Pj, CH_LD, wave, 0, lane, acc);
+        };
+        Operands oa, ob;
+        if (npend > 0) fetch(oa, k0 - CH_NB * npend);
+        if (npend > 1) fetch(ob, k0 - CH_NB);
+        if (npend > 0) apply(oa, 0);
+        if (npend > 1) apply(ob, 1);
+        // rows below tile 0: their right-hand side is final for this launch (the panels of this launch are applied to it by the next
+        // one); the rows of tile 0 stay in brow
+        if (col0 && tid < 64 && bi > 0 && r0 + tid < n) b[r0 + tid] = brow[tid];
+        if (col0) __syncthreads();  // everyone is done with the operand arrays before they become the tile
 #pragma unroll
         for (int rb = 0; rb < 4; ++rb)
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
                 const int row = 16 * rb + e16, col = 16 * wave + g4 + 4 * reg;
-                const int r = r0 + row, c = c0 + col;
                 const double v = old[rb][reg] - acc[rb][reg];
-                if (bj == 0) {
-                    if (col < CH_NB) Pj[col][row] = v;
-                    else Pi[col - CH_NB][row] = v;
-                } else if (r < n && c < n && r >= c) A[(size_t)r + (size_t)c * n] = v;
+                if (col0) {
+                    W[col >> 5][col & 31][row] = v;  // the tile stays in LDS
+                } else {
+                    const int r = r0 + row, c = c0 + col;
+                    if (r < n && c < n && r >= c) A[(size_t)r + (size_t)c * n] = v;
+                }
             }
     }
-    if (bj != 0) return;
+    if (!col0) return;
     __syncthreads();
+    if (stamp) ts[bi * 8 + 1] = wall_clock64();
 
     if (bi == 0) {
-        // ---------------------------------------------------------------- tile (0, 0): L11, L21, then L22
+        // ---------------------------------------------------------------- tile (0, 0): D0 + L21, A22 -= L21 L21^T, D1
+        double a[CH_NB];
+        bool bad = false;
         if (wave == 0) {
-            double a[CH_NB];
 #pragma unroll
             for (int c = 0; c < CH_NB; ++c) {
-                double v = Pj[c][lane];
+                double v = W[0][c][lane];
                 if (lane < CH_NB && c > lane) v = 0.0;  // above the diagonal
                 a[c] = v;
             }
-            // publish L11 and L21 as they are formed: agent-scope stores (write through to the coherence point) + flag, no release fence
-            const bool bad = chol_diag_block(a, lane, pan, [&](int c, double v) {
+            // published as it is formed: agent-scope stores (write through to the coherence point), then the flag -- no release
+            // fence (a fence writes back the whole L2 of this XCD, ~2.5 us, while the other tiles are still storing)
+            bad = chol_diag_block(a, lane, pan, [&](int c, double v) {
                 if (lane >= CH_NB || c <= lane)
                     __hip_atomic_store(A + (size_t)(k0 + lane) + (size_t)(k0 + c) * n, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             });
             __builtin_amdgcn_s_waitcnt(0);  // the stores above are acknowledged
             if (lane == 0) __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (bad && lane == 0) atomicOr(fail, 1);
+            if (stamp) ts[2] = wall_clock64();
 #pragma unroll
             for (int c = 0; c < CH_NB; ++c) {
-                if (lane < CH_NB) Lb[c][lane] = a[c];
-                else L21s[c][lane - CH_NB] = a[c];
+                if (lane >= CH_NB) W[0][c][lane] = a[c];  // L21: operand of the update below and of the right-hand side
+                else Lb[0][c][lane] = a[c];
             }
         }
         __syncthreads();
-        {   // A22 <- A22 - L21 L21^T (rows / columns 32..63 of the tile: Pi[c][32 + r]); 4 columns per thread
-            const int r = tid & 31, cg = tid >> 5;
-            double s[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll 8
-            for (int k = 0; k < CH_NB; ++k) {
-                const double lr = L21s[k][r];
+        if (wave != 1) {
+            // A22 (rows / columns 32..63 of the tile: W[1][c][32 + r]) -= L21 L21^T: the three 16 x 16 blocks of its lower part, one
+            // per wave (a v_mfma_f64_16x16x4 takes 64 cycles: one wave doing all three was slower than this with its two barriers)
+            const int rb = wave == 0 ? 0 : 1, cb = wave == 3 ? 1 : 0;
+            chol_d4 u[1] = {chol_d4{0.0, 0.0, 0.0, 0.0}};
+            chol_mfma_acc<1>(&W[0][0][32], CH_LD, &W[0][0][32], CH_LD, cb, rb, lane, u);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) s[j] += lr * L21s[k][cg * 4 + j];
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) Pi[cg * 4 + j][CH_NB + r] -= s[j];
-        }
-        if (wave == 1) {  // y1 = L11^-1 b1, then b2 -= L21 y1
-            double v = (lane < CH_NB) ? brow[lane] : 0.0;
-            const int cl = min(lane, CH_NB - 1);
-            for (int m = 0; m < CH_NB; ++m) {
-                const double ym = __shfl(v, m) / Lb[m][m];
-                if (lane == m) v = ym;
-                else if (lane > m && lane < CH_NB) v -= Lb[m][cl] * ym;
-            }
-            if (lane < CH_NB) { b[k0 + lane] = v; ys[lane] = v; }
-            __builtin_amdgcn_wave_barrier();
-            if (lane >= CH_NB) {
-                double s = 0.0;
-#pragma unroll 8
-                for (int k = 0; k < CH_NB; ++k) s += L21s[k][lane - CH_NB] * ys[k];
-                brow[lane] -= s;
-            }
+            for (int reg = 0; reg < 4; ++reg) W[1][16 * cb + g4 + 4 * reg][32 + 16 * rb + e16] -= u[0][reg];
         }
         __syncthreads();
         if (wave == 0) {
-            double a[CH_NB];
 #pragma unroll
-            for (int c = 0; c < CH_NB; ++c) a[c] = (lane < CH_NB && c <= lane) ? Pi[c][CH_NB + lane] : 0.0;  // no riders
-            const bool bad = chol_diag_block(a, lane, pan, [&](int c, double v) {
+            for (int c = 0; c < CH_NB; ++c) a[c] = (lane < CH_NB && c <= lane) ? W[1][c][CH_NB + lane] : 0.0;  // no riders
+            bad |= chol_diag_block(a, lane, pan, [&](int c, double v) {
                 if (lane < CH_NB && c <= lane)
                     __hip_atomic_store(A + (size_t)(k0 + CH_NB + lane) + (size_t)(k0 + CH_NB + c) * n, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             });
             __builtin_amdgcn_s_waitcnt(0);
             if (lane == 0) __hip_atomic_store(flag + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (stamp) ts[3] = wall_clock64();
             if (bad && lane == 0) atomicOr(fail, 1);
             if (lane < CH_NB) {
 #pragma unroll
-                for (int c = 0; c < CH_NB; ++c) Lb2[c][lane] = a[c];
+                for (int c = 0; c < CH_NB; ++c) Lb[1][c][lane] = a[c];
             }
-        }
-        __syncthreads();
-        if (wave == 1) {  // y2 = L22^-1 b2
-            double v = (lane < CH_NB) ? brow[CH_NB + lane] : 0.0;
-            const int cl = min(lane, CH_NB - 1);
-            for (int m = 0; m < CH_NB; ++m) {
-                const double ym = __shfl(v, m) / Lb2[m][m];
-                if (lane == m) v = ym;
-                else if (lane > m && lane < CH_NB) v -= Lb2[m][cl] * ym;
+            __builtin_amdgcn_s_waitcnt(0);  // ... and written, before the hand-over to wave 1
+            if (lane == 0) *(volatile int*)&lf[0] = 1;
+        } else if (wave == 1) {
+            // the right-hand side, beside the second diagonal block: y0 = D0^-1 b (rows 0..31), b (rows 32..63) -= L21 y0, then
+            // y1 = D1^-1 b (rows 32..63) once wave 0 has handed D1 over
+            double v = chol_fwd32((lane < CH_NB) ? brow[lane] : 0.0, Lb[0], lane);
+            if (lane < CH_NB) { yv[0][lane] = v; b[k0 + lane] = v; }
+            __builtin_amdgcn_wave_barrier();
+            asm volatile("" ::: "memory");
+            double bv = 0.0;
+            if (lane >= CH_NB) {
+                double s = 0.0;
+#pragma unroll 8
+                for (int k = 0; k < CH_NB; ++k) s += W[0][k][lane] * yv[0][k];
+                bv = brow[lane] - s;
             }
+            bv = __shfl(bv, CH_NB + (lane & (CH_NB - 1)));  // row 32 + l to lane l
+            chol_spin_lds(&lf[0]);
+            v = chol_fwd32((lane < CH_NB) ? bv : 0.0, Lb[1], lane);
             if (lane < CH_NB) b[k0 + CH_NB + lane] = v;
         }
         return;
     }
 
     // -------------------------------------------------------------------- tiles (i > 0, 0): 64 panel rows, 64 columns
-    // lanes past the last row of the matrix (last tile row only) duplicate the last valid row: the same arithmetic, the
-    // same stores to the same addresses -- no store sits under a condition (a conditional store lets the compiler sink the
-    // whole solve below its LDS reads: kilobytes of spills)
+    // lanes past the last row of the matrix (last row tile only) duplicate the last valid row: the same arithmetic, the same
+    // stores to the same addresses -- no store sits under a condition (a conditional store lets the compiler sink the whole solve
+    // below its LDS reads: kilobytes of spills)
     const int lane_c = min(lane, n - 1 - r0);
-    const int row = r0 + lane_c;
+    const size_t row = (size_t)(r0 + lane_c);
     if (wave == 0) {
         double x[CH_NB];
 #pragma unroll
-        for (int c = 0; c < CH_NB; ++c) x[c] = Pj[c][lane_c];
-        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(1);
-        chol_fetch_block(A, n, k0, k0, true, Lb, lane);
+        for (int c = 0; c < CH_NB; ++c) x[c] = W[0][c][lane_c];
+        chol_spin(flag);
+        chol_fetch_block(A, n, k0, k0, true, Lb[0], lane);
         __builtin_amdgcn_wave_barrier();
-        if (lane < CH_NB) lcol[0][lane] = 1.0 / Lb[lane][lane];
+        if (lane < CH_NB) lcol[lane] = 1.0 / Lb[0][lane][lane];
         __builtin_amdgcn_wave_barrier();
-        chol_panel_rows(x, Lb, lcol[0]);
+        chol_panel_rows(x, Lb[0], lcol);
 #pragma unroll
         for (int c = 0; c < CH_NB; ++c) {
-            Pj[c][lane] = x[c];  // x1, operand of the update of the second half
-            A[(size_t)row + (size_t)(k0 + c) * n] = x[c];
+            W[0][c][lane] = x[c];  // X0, operand of the update of the second half
+            A[row + (size_t)(k0 + c) * n] = x[c];
         }
-    } else if (wave == 1) {
-        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(1);
-        chol_fetch_block(A, n, k0 + CH_NB, k0, false, L21s, lane);
+        if (stamp) ts[bi * 8 + 2] = wall_clock64();
+    } else {
+        // waves 1..3, while wave 0 solves: L21 (rows k0 + 32.., columns k0..) -> Lr[k][i]
+        chol_spin(flag);
+        constexpr int PER = (CH_NB * CH_NB + 191) / 192;
+        double v[PER];
+#pragma unroll
+        for (int t = 0; t < PER; ++t) {
+            const int idx = (tid - 64) + t * 192, i = idx % CH_NB, k = idx / CH_NB;
+            v[t] = (idx < CH_NB * CH_NB)
+                       ? __hip_atomic_load(A + (size_t)(k0 + CH_NB + i) + (size_t)(k0 + k) * n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                       : 0.0;
+        }
+#pragma unroll
+        for (int t = 0; t < PER; ++t) {
+            const int idx = (tid - 64) + t * 192, i = idx % CH_NB, k = idx / CH_NB;
+            if (idx < CH_NB * CH_NB) Lr[k][i] = v[t];
+        }
     }
     __syncthreads();
-    {   // second half of the tile column: X2 <- X2 - x1 L21^T; thread = (row, 8 columns)
-        const int r = tid & 63, cg = tid >> 6;
-        double s[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-#pragma unroll 4
-        for (int k = 0; k < CH_NB; ++k) {
-            const double xr = Pj[k][r];
+    {   // second half of the tile column: W[1] -= X0 L21^T; wave -> 16 columns x 32 rows
+        chol_d4 u[2] = {chol_d4{0.0, 0.0, 0.0, 0.0}, chol_d4{0.0, 0.0, 0.0, 0.0}};
+        const int c16 = wave & 1, rb0 = 2 * (wave >> 1);
+        chol_mfma_acc<2>(&W[0][0][0], CH_LD, &Lr[0][0], CH_LS, c16, rb0, lane, u);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) s[j] += xr * L21s[k][cg * 8 + j];
-        }
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) Pi[cg * 8 + j][r] -= s[j];
+            for (int reg = 0; reg < 4; ++reg) W[1][16 * c16 + g4 + 4 * reg][16 * (rb0 + i) + e16] -= u[i][reg];
     }
     __syncthreads();
     if (wave != 0) return;
     {
         double x[CH_NB];
 #pragma unroll
-        for (int c = 0; c < CH_NB; ++c) x[c] = Pi[c][lane_c];
-        while (__hip_atomic_load(flag + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(1);
-        chol_fetch_block(A, n, k0 + CH_NB, k0 + CH_NB, true, Lb, lane);
+        for (int c = 0; c < CH_NB; ++c) x[c] = W[1][c][lane_c];
+        chol_spin(flag + 1);
+        chol_fetch_block(A, n, k0 + CH_NB, k0 + CH_NB, true, Lb[0], lane);
         __builtin_amdgcn_wave_barrier();
-        if (lane < CH_NB) lcol[0][lane] = 1.0 / Lb[lane][lane];
+        if (lane < CH_NB) lcol[lane] = 1.0 / Lb[0][lane][lane];
         __builtin_amdgcn_wave_barrier();
-        chol_panel_rows(x, Lb, lcol[0]);
+        chol_panel_rows(x, Lb[0], lcol);
 #pragma unroll
-        for (int c = 0; c < CH_NB; ++c) A[(size_t)row + (size_t)(k0 + CH_NB + c) * n] = x[c];
+        for (int c = 0; c < CH_NB; ++c) A[row + (size_t)(k0 + CH_NB + c) * n] = x[c];
+        if (stamp) ts[bi * 8 + 3] = wall_clock64();
     }
 }
 
