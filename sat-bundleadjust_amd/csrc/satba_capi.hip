@@ -662,7 +662,8 @@ int satba_problem_create(const satba_problem_desc* d, satba_problem** out) {
         TRY(dev_alloc(p, &p->d_camc, (size_t)p->M * CAMC)); TRY(dev_alloc(p, &p->d_camc_new, (size_t)p->M * CAMC));
         TRY(dev_alloc(p, &p->d_U, (size_t)p->M * p->NP * p->NP)); TRY(dev_alloc(p, &p->d_gc, p->n_c));
         TRY(dev_alloc(p, &p->d_V, (size_t)6 * p->N)); TRY(dev_alloc(p, &p->d_Vinv, (size_t)6 * p->N));
-        TRY(dev_alloc(p, &p->d_PV, (size_t)PV_STRIDE * std::max(p->N, 1)));
+        TRY(dev_alloc(p, &p->d_PV, (size_t)PV_STRIDE * (p->N + 1)));  // record N: all zeros, the target of lanes past the end of a pair list
+        HIP_TRY(hipMemset(p->d_PV + (size_t)PV_STRIDE * p->N, 0, sizeof(double) * PV_STRIDE));
         TRY(dev_alloc(p, &p->d_dc, p->n_c)); TRY(dev_alloc(p, &p->d_dch, p->n_c));
         const size_t Kz = (size_t)std::max<long long>(K, 1) + 64;
         TRY(dev_alloc(p, &p->d_f, Pz)); TRY(dev_alloc(p, &p->d_ftmp, Pz)); TRY(dev_alloc(p, &p->d_sc, Kz));

@@ -120,7 +120,8 @@ __device__ inline int rs_index(int lane) {
 // the 2 x 2 middle matrix (4 products instead of 32 on the blocks).  RPC: the stored Jacobian blocks are gathered instead
 // of being recomputed (they carry scales and masks).
 template <int MODEL, int NP, bool UNITW>
-__global__ __launch_bounds__(256) void k_schur_pairs(ObsArgs a, SchurArgs s, double* __restrict__ S) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 3))) void k_schur_pairs(ObsArgs a, SchurArgs s, double* __restrict__ S) {
+    __shared__ double2 s_coop[4 * 64 * 5];  // per wave: 64 records x 80 bytes (the quad-cooperative gathers are transposed here)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long long n_pairs = (long long)a.M * (a.M - 1) / 2;
     const int2 item = s.items[blockIdx.x * 4u + (unsigned)wave];
@@ -140,15 +141,88 @@ __global__ __launch_bounds__(256) void k_schur_pairs(ObsArgs a, SchurArgs s, dou
         for (int q = 0; q < NP; ++q) acc[r][q] = 0.0;
 
     struct Rec { double2 r0, r1, r2, r3; double r4; };  // packed point record: X0 X1 | X2 v00 | v01 v02 | v11 v12 | v22
-    auto load_rec = [&](int p) {
-        const double2* pv = s.PV + (PV_STRIDE / 2) * (size_t)p;  // four 16-byte gathers and one of 8 instead of nine 8-byte ones
-        Rec r;
-        r.r0 = pv[0]; r.r1 = pv[1]; r.r2 = pv[2]; r.r3 = pv[3]; r.r4 = reinterpret_cast<const double*>(pv + 4)[0];
-        return r;
+    // Affine cameras: J_c = A [D(X) | I] with A = (fx sk; 0 fy) and D(X) = rows 0, 1 of (dR/da X, dR/db X, dR/dg X), and
+    // J_p = A R(rows 0, 1) does not depend on the point.  With m' = A_i^T [J_pi Vinv J_pj^T] A_j (2 x 2) the pair block is
+    //     [D_i | I]^T m' [D_j | I]
+    // -- 120 multiply-adds per hit instead of 198 for the generic form below (two full Jacobian evaluations, 2 x 5 blocks).
+    // P_i, P_j: unit weights: A^T A R (so that m' = P_i Vinv P_j^T directly); otherwise A R, and A_i^T . A_j is applied after
+    // the row scales.  Wave-uniform, computed once per item.
+    double Pi_[2][3], Pj_[2][3], Ai_[3] = {0.0, 0.0, 0.0}, Aj_[3] = {0.0, 0.0, 0.0};
+    double tri[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, trj[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};  // cos, sin of the three angles
+    if constexpr (MODEL == AFFINE) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) { tri[k] = cci[k]; trj[k] = ccj[k]; }
+        auto cam_p = [&](const double* cc, double (&P)[2][3], double (&Au)[3]) {
+            const double fx = cc[17], fy = cc[18], sk = cc[19];
+            Au[0] = fx; Au[1] = sk; Au[2] = fy;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const double p0 = fx * cc[6 + k] + sk * cc[9 + k], p1 = fy * cc[9 + k];  // A R
+                if constexpr (UNITW) { P[0][k] = fx * p0; P[1][k] = sk * p0 + fy * p1; }  // A^T (A R)
+                else { P[0][k] = p0; P[1][k] = p1; }
+            }
+        };
+        cam_p(cci, Pi_, Ai_);
+        cam_p(ccj, Pj_, Aj_);
+    }
+    // rows 0, 1 of the three angle derivatives of R X (satba_models.h: rotate), d[c][k]
+    auto affine_d = [&](const double (&cc)[6], double X, double Y, double Z, double (&d)[2][3]) {
+        const double ca = cc[0], sa = cc[1], cb = cc[2], sb = cc[3], cg = cc[4], sg = cc[5];
+        const double y1y = ca * Y - sa * Z, y1z = sa * Y + ca * Z;
+        const double y2x = cb * X + sb * y1z, y2z = -sb * X + cb * y1z;
+        const double ax = sb * y1y;
+        d[0][0] = cg * ax + sg * y1z; d[1][0] = sg * ax - cg * y1z;
+        d[0][1] = cg * y2z;           d[1][1] = sg * y2z;
+        d[0][2] = -(sg * y2x + cg * y1y); d[1][2] = cg * y2x - sg * y1y;
     };
     auto compute = [&](const Rec& rc, int pi, int pj, const double2& scl_i, const double2& scl_j) {
         const double X = rc.r0.x, Y = rc.r0.y, Z = rc.r1.x;
         const double v00 = rc.r1.y, v01 = rc.r2.x, v02 = rc.r2.y, v11 = rc.r3.x, v12 = rc.r3.y, v22 = rc.r4;
+        if constexpr (MODEL == AFFINE) {
+            double T[2][3];  // P_i Vinv
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                T[r][0] = Pi_[r][0] * v00 + Pi_[r][1] * v01 + Pi_[r][2] * v02;
+                T[r][1] = Pi_[r][0] * v01 + Pi_[r][1] * v11 + Pi_[r][2] * v12;
+                T[r][2] = Pi_[r][0] * v02 + Pi_[r][1] * v12 + Pi_[r][2] * v22;
+            }
+            double m[2][2];
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) m[r][c] = T[r][0] * Pj_[c][0] + T[r][1] * Pj_[c][1] + T[r][2] * Pj_[c][2];
+            if constexpr (!UNITW) {
+                const double ax = scl_i.x * scl_i.x, ay = scl_i.y * scl_i.y;
+                const double bx = scl_j.x * scl_j.x, by = scl_j.y * scl_j.y;
+                m[0][0] *= ax * bx; m[0][1] *= ax * by; m[1][0] *= ay * bx; m[1][1] *= ay * by;
+                // A_i^T m A_j
+                const double t00 = Ai_[0] * m[0][0], t01 = Ai_[0] * m[0][1];
+                const double t10 = Ai_[1] * m[0][0] + Ai_[2] * m[1][0], t11 = Ai_[1] * m[0][1] + Ai_[2] * m[1][1];
+                m[0][0] = t00 * Aj_[0]; m[0][1] = t00 * Aj_[1] + t01 * Aj_[2];
+                m[1][0] = t10 * Aj_[0]; m[1][1] = t10 * Aj_[1] + t11 * Aj_[2];
+            }
+            double Di[2][3], Dj[2][3];
+            affine_d(tri, X, Y, Z, Di);
+            affine_d(trj, X, Y, Z, Dj);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const double y0 = m[0][0] * Dj[0][q] + m[0][1] * Dj[1][q];
+                const double y1 = m[1][0] * Dj[0][q] + m[1][1] * Dj[1][q];
+#pragma unroll
+                for (int r = 0; r < 3; ++r) acc[r][q] = fma(-Di[0][r], y0, fma(-Di[1][r], y1, acc[r][q]));
+                if constexpr (NP == 5) { acc[3][q] -= y0; acc[4][q] -= y1; }
+            }
+            if constexpr (NP == 5) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) acc[r][3 + t] = fma(-Di[0][r], m[0][t], fma(-Di[1][r], m[1][t], acc[r][3 + t]));
+                    acc[3][3 + t] -= m[0][t];
+                    acc[4][3 + t] -= m[1][t];
+                }
+            }
+            return;
+        }
         double Jci[2][NP], Jpi[2][3], Jcj[2][NP], Jpj[2][3];
         if constexpr (MODEL == RPC) {
             const double2* qi = reinterpret_cast<const double2*>(a.Jpm + (size_t)pi * (2 * NP + 6));
@@ -202,40 +276,82 @@ __global__ __launch_bounds__(256) void k_schur_pairs(ObsArgs a, SchurArgs s, dou
     {
         const int C1 = s.n_chunks + 1;
         const long long lo = s.pair_ofs[pair * C1 + chunk], hi = s.pair_ofs[pair * C1 + chunk + 1];
-        // software pipeline: the next point's index and record are in flight while the current one is evaluated
         constexpr bool POS = !UNITW || MODEL == RPC;  // positions (and, weighted / robust, scales) ride along
         constexpr bool SCL = !UNITW && MODEL != RPC;
-        long long idx = lo + lane;
-        // the lists are streamed once: non-temporal loads keep them from displacing the point records in L2
-        auto ld = [&](const int* arr, long long k) { return (k < hi) ? __builtin_nontemporal_load(arr + k) : 0; };
-        int p_cur = ld(s.pair_pts, idx), p_nxt = ld(s.pair_pts, idx + 64);
-        int pi_cur = 0, pj_cur = 0, pi_nxt = 0, pj_nxt = 0;
-        double2 si_cur = make_double2(1.0, 1.0), sj_cur = si_cur;
-        if constexpr (POS) {
-            pi_cur = ld(s.pair_pi, idx); pj_cur = ld(s.pair_pj, idx);
-            pi_nxt = ld(s.pair_pi, idx + 64); pj_nxt = ld(s.pair_pj, idx + 64);
-            if constexpr (SCL) { si_cur = a.sc[pi_cur]; sj_cur = a.sc[pj_cur]; }
-        }
-        Rec r_cur = load_rec(p_cur);
-        while (idx < hi) {
-            // indices run two iterations ahead, records one: neither latency is on the critical path
-            const int p_nn = ld(s.pair_pts, idx + 128);
-            int pi_nn = 0, pj_nn = 0;
-            double2 si_nxt = make_double2(1.0, 1.0), sj_nxt = si_nxt;
+        // Cooperative record gathers.  A gather instruction costs the texture path one tag lookup per distinct line it touches;
+        // with lane = hit every one of the five loads of a record touched 64 lines (two of the five removed: -0.13 ms of 0.55
+        // at 200 x 1M x 10M).  Here the 320 16-byte pieces of the 64 records of an iteration are dealt to the lanes in order
+        // (load t, lane l: piece 64 t + l = piece (64 t + l) % 5 of record (64 t + l) / 5), so an instruction touches 13-14 lines.
+        // The pieces are written to LDS lane-linearly -- which IS the record-major image with stride 80 bytes, and with that
+        // stride the 16 lanes of a ds_read_b128 phase fall into disjoint banks -- and every lane reads its own record back.
+        // All lanes run the same number of iterations (cooperating lanes must be active): lanes past the end of the list are
+        // pointed at record N, which is all zeros -- Vinv = 0 makes every term vanish.
+        const int n_it = (int)((hi - lo + 63) >> 6);
+        if (n_it > 0) {
+            const long long last = hi - 1;
+            // the lists are streamed once: non-temporal loads keep them from displacing the point records in L2
+            auto ld = [&](const int* arr, long long k) { return __builtin_nontemporal_load(arr + (k < last ? k : last)); };
+            auto ldp = [&](long long k) { const int v = ld(s.pair_pts, k); return (k < hi) ? v : a.N; };
+            // piece g = 64 t + lane of the 320 pieces (64 records x 5) in load t: record g / 5, piece g % 5
+            struct Coop { double2 c0, c1, c2, c3, c4; };
+            int rsrc[5];
+            const double2* psrc[5];
+#pragma unroll
+            for (int t = 0; t < 5; ++t) { rsrc[t] = (64 * t + lane) / 5; psrc[t] = s.PV + (64 * t + lane) % 5; }
+            auto coop_load = [&](int p) {
+                Coop o;
+                o.c0 = psrc[0][(PV_STRIDE / 2) * (size_t)__shfl(p, rsrc[0])];
+                o.c1 = psrc[1][(PV_STRIDE / 2) * (size_t)__shfl(p, rsrc[1])];
+                o.c2 = psrc[2][(PV_STRIDE / 2) * (size_t)__shfl(p, rsrc[2])];
+                o.c3 = psrc[3][(PV_STRIDE / 2) * (size_t)__shfl(p, rsrc[3])];
+                o.c4 = psrc[4][(PV_STRIDE / 2) * (size_t)__shfl(p, rsrc[4])];
+                return o;
+            };
+            char* my = reinterpret_cast<char*>(s_coop) + wave * (64 * 80);
+            double2* wr = reinterpret_cast<double2*>(my) + lane;  // piece g at 16 g bytes: record stride 80
+            const double2* mine = reinterpret_cast<const double2*>(my + lane * 80);
+            auto transpose = [&](const Coop& o) {
+                Rec r;
+                asm volatile("" ::: "memory");
+                wr[0] = o.c0; wr[64] = o.c1; wr[128] = o.c2; wr[192] = o.c3; wr[256] = o.c4;
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+                r.r0 = mine[0]; r.r1 = mine[1]; r.r2 = mine[2]; r.r3 = mine[3]; r.r4 = mine[4].x;
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+                return r;
+            };
+            long long idx = lo + lane;
+            int p_nxt = ldp(idx + 64);
+            int pi_cur = 0, pj_cur = 0, pi_nxt = 0, pj_nxt = 0;
+            double2 si_cur = make_double2(1.0, 1.0), sj_cur = si_cur;
             if constexpr (POS) {
-                pi_nn = ld(s.pair_pi, idx + 128); pj_nn = ld(s.pair_pj, idx + 128);
-                if constexpr (SCL) { si_nxt = a.sc[pi_nxt]; sj_nxt = a.sc[pj_nxt]; }
+                pi_cur = ld(s.pair_pi, idx); pj_cur = ld(s.pair_pj, idx);
+                pi_nxt = ld(s.pair_pi, idx + 64); pj_nxt = ld(s.pair_pj, idx + 64);
+                if constexpr (SCL) { si_cur = a.sc[pi_cur]; sj_cur = a.sc[pj_cur]; }
             }
-            const Rec r_nxt = load_rec(p_nxt);
-            // keep the gathers above the arithmetic: without the barrier the scheduler sinks them below compute() to
-            // save registers and every iteration pays the full memory latency
-            __builtin_amdgcn_sched_barrier(0);
-            compute(r_cur, pi_cur, pj_cur, si_cur, sj_cur);
-            __builtin_amdgcn_sched_barrier(0);
-            p_cur = p_nxt; p_nxt = p_nn; r_cur = r_nxt;
-            pi_cur = pi_nxt; pj_cur = pj_nxt; pi_nxt = pi_nn; pj_nxt = pj_nn;
-            si_cur = si_nxt; sj_cur = sj_nxt;
-            idx += 64;
+            Coop c_cur = coop_load(ldp(idx));
+            for (int it = 0; it < n_it; ++it) {
+                const Rec r_cur = transpose(c_cur);  // first: its wait covers only loads of the previous iteration
+                // indices run two iterations ahead, records one: neither latency is on the critical path
+                const int p_nn = ldp(idx + 128);
+                int pi_nn = 0, pj_nn = 0;
+                double2 si_nxt = make_double2(1.0, 1.0), sj_nxt = si_nxt;
+                if constexpr (POS) {
+                    pi_nn = ld(s.pair_pi, idx + 128); pj_nn = ld(s.pair_pj, idx + 128);
+                    if constexpr (SCL) { si_nxt = a.sc[pi_nxt]; sj_nxt = a.sc[pj_nxt]; }
+                }
+                const Coop c_nxt = coop_load(p_nxt);
+                // keep the gathers above the arithmetic: without the barrier the scheduler sinks them below compute() to
+                // save registers and every iteration pays the full memory latency
+                __builtin_amdgcn_sched_barrier(0);
+                compute(r_cur, pi_cur, pj_cur, si_cur, sj_cur);
+                __builtin_amdgcn_sched_barrier(0);
+                p_nxt = p_nn; c_cur = c_nxt;
+                pi_cur = pi_nxt; pj_cur = pj_nxt; pi_nxt = pi_nn; pj_nxt = pj_nn;
+                si_cur = si_nxt; sj_cur = sj_nxt;
+                idx += 64;
+            }
         }
     }
 
@@ -290,79 +406,177 @@ __global__ __launch_bounds__(LINC_THREADS) void k_schur_diag(ObsArgs a, CamMajor
     double acc[CU];
 #pragma unroll
     for (int k = 0; k < CU; ++k) acc[k] = 0.0;
-    // Software pipeline: point indices run two iterations ahead, the 128-byte point records one (the loop was a chain
-    // of two dependent gathers per iteration, ~18 iterations per thread).
+    // Software pipeline: point indices run two iterations ahead, the point records one.  The records are gathered cooperatively
+    // (see k_schur_pairs): the 384 16-byte pieces of a wave's 64 records are dealt to the lanes in order (load t, lane l: piece
+    // (64 t + l) % 6 of record (64 t + l) / 6), so a gather instruction touches 11 lines instead of 64, and transposed through
+    // LDS (record stride 7 pieces = 112 bytes: the 16 lanes of a ds_read_b128 phase fall into disjoint banks).  All threads run
+    // the same number of iterations; threads past the end of the list are pointed at record N (zeros) and masked.
     struct Rec { double2 r0, r1, r2, r3, r4, r5; };
-    auto load_rec = [&](int p) {
-        const double2* pv = s.PV + (PV_STRIDE / 2) * (size_t)p;
+    __shared__ double2 s_coop[(LINC_THREADS / 64) * 64 * 7];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double2* my = s_coop + wave * (64 * 7);
+    int rsrc[6];
+    const double2* psrc[6];
+    double2* wdst[6];
+#pragma unroll
+    for (int t = 0; t < 6; ++t) {
+        const int g = 64 * t + lane;
+        rsrc[t] = g / 6; psrc[t] = s.PV + g % 6; wdst[t] = my + (g / 6) * 7 + g % 6;
+    }
+    struct Coop { double2 c0, c1, c2, c3, c4, c5; };
+    auto coop_load = [&](int p) {
+        Coop o;
+        o.c0 = psrc[0][(PV_STRIDE / 2) * (size_t)__shfl(p, rsrc[0])];
+        o.c1 = psrc[1][(PV_STRIDE / 2) * (size_t)__shfl(p, rsrc[1])];
+        o.c2 = psrc[2][(PV_STRIDE / 2) * (size_t)__shfl(p, rsrc[2])];
+        o.c3 = psrc[3][(PV_STRIDE / 2) * (size_t)__shfl(p, rsrc[3])];
+        o.c4 = psrc[4][(PV_STRIDE / 2) * (size_t)__shfl(p, rsrc[4])];
+        o.c5 = psrc[5][(PV_STRIDE / 2) * (size_t)__shfl(p, rsrc[5])];
+        return o;
+    };
+    const double2* mine = my + lane * 7;
+    auto transpose = [&](const Coop& o) {
         Rec r;
-        r.r0 = pv[0]; r.r1 = pv[1]; r.r2 = pv[2]; r.r3 = pv[3]; r.r4 = pv[4]; r.r5 = pv[5];
+        asm volatile("" ::: "memory");
+        *wdst[0] = o.c0; *wdst[1] = o.c1; *wdst[2] = o.c2; *wdst[3] = o.c3; *wdst[4] = o.c4; *wdst[5] = o.c5;
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        r.r0 = mine[0]; r.r1 = mine[1]; r.r2 = mine[2]; r.r3 = mine[3]; r.r4 = mine[4]; r.r5 = mine[5];
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
         return r;
     };
-    auto ldp = [&](int q) { return q < hi ? c.pt[q] : 0; };
-    int pos = lo + threadIdx.x;
-    int p_cur = ldp(pos), p_nxt = ldp(pos + LINC_THREADS);
-    Rec rc = load_rec(p_cur);
-    for (; pos < hi; pos += LINC_THREADS) {
-        const int p_nn = ldp(pos + 2 * LINC_THREADS);
-        const Rec rn = load_rec(p_nxt);
-        __builtin_amdgcn_sched_barrier(0);
-        const double2 r0 = rc.r0, r1 = rc.r1, r2 = rc.r2, r3 = rc.r3, r4 = rc.r4, r5 = rc.r5;
-        p_cur = p_nxt; p_nxt = p_nn; rc = rn;
-        double Jc[2][NP], Jp[2][3];
-        double sx = 1.0, sy = 1.0;  // squared row scales times the fixed-point mask, applied to the 2 x 2 middle matrix
-        double ux = 1.0, uy = 1.0;  // squared row scales on the J_c^T J_c term (no point mask there)
-        if constexpr (MODEL == RPC) {  // the blocks the linearize kernel stored (scales and masks included)
-            ObsEval<MODEL, NP, true> e2;
-            e2.load_jac(a, c.io[pos]);
+    // affine cameras (block-uniform): J_c = A [D(X) | I], J_p = A R  (see k_schur_pairs)
+    double Pm[2][3], Au[3] = {0.0, 0.0, 0.0}, tr[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    if constexpr (MODEL == AFFINE) {
+        const double fx = cc[17], fy = cc[18], sk = cc[19];
+        Au[0] = fx; Au[1] = sk; Au[2] = fy;
 #pragma unroll
-            for (int k = 0; k < NP; ++k) { Jc[0][k] = e2.Jc[0][k]; Jc[1][k] = e2.Jc[1][k]; }
+        for (int k = 0; k < 3; ++k) { Pm[0][k] = fx * cc[6 + k] + sk * cc[9 + k]; Pm[1][k] = fy * cc[9 + k]; }
 #pragma unroll
-            for (int k = 0; k < 3; ++k) { Jp[0][k] = e2.Jp[0][k]; Jp[1][k] = e2.Jp[1][k]; }
-        } else {
-            double u, v;
-            project<MODEL, NP, true>(cc, nullptr, r0.x, r0.y, r1.x, false, u, v, Jc, Jp);
-            if (a.sc) { const double2 t = a.sc[c.io[pos]]; ux = t.x * t.x; uy = t.y * t.y; }
-            sx = ux; sy = uy;  // the fixed-point mask rides in the record's Vinv
-        }
-        const double v00 = r1.y, v01 = r2.x, v02 = r2.y, v11 = r3.x, v12 = r3.y, v22 = r4.x;
-        double A[2][3];
+        for (int k = 0; k < 6; ++k) tr[k] = cc[k];
+    }
+    const int n_it = (hi - lo + LINC_THREADS - 1) / LINC_THREADS;
+    if (n_it > 0) {
+        auto ldp = [&](int q) { const int v = c.pt[q < hi ? q : hi - 1]; return q < hi ? v : a.N; };
+        int pos = lo + threadIdx.x;
+        int p_nxt = ldp(pos + LINC_THREADS);
+        Coop cur = coop_load(ldp(pos));
+        for (int it = 0; it < n_it; ++it, pos += LINC_THREADS) {
+            const Rec rc = transpose(cur);  // first: its wait covers only loads of the previous iteration
+            const int p_nn = ldp(pos + 2 * LINC_THREADS);
+            const Coop nxt = coop_load(p_nxt);
+            __builtin_amdgcn_sched_barrier(0);
+            const double2 r0 = rc.r0, r1 = rc.r1, r2 = rc.r2, r3 = rc.r3, r4 = rc.r4, r5 = rc.r5;
+            p_nxt = p_nn; cur = nxt;
+            const bool valid = pos < hi;
+            const int posc = valid ? pos : hi - 1;
+            const double vm = valid ? 1.0 : 0.0;
+            double sx = vm, sy = vm;  // squared row scales times the fixed-point mask, applied to the 2 x 2 middle matrix
+            double ux = vm, uy = vm;  // squared row scales on the J_c^T J_c term (no point mask there)
+            const double v00 = r1.y, v01 = r2.x, v02 = r2.y, v11 = r3.x, v12 = r3.y, v22 = r4.x;
+            if constexpr (MODEL == AFFINE) {
+                if (a.sc) { const double2 t = a.sc[c.io[posc]]; ux = vm * t.x * t.x; uy = vm * t.y * t.y; }
+                sx = ux; sy = uy;  // the fixed-point mask rides in the record's Vinv
+                double T[2][3];  // J_p Vinv
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            A[r][0] = Jp[r][0] * v00 + Jp[r][1] * v01 + Jp[r][2] * v02;
-            A[r][1] = Jp[r][0] * v01 + Jp[r][1] * v11 + Jp[r][2] * v12;
-            A[r][2] = Jp[r][0] * v02 + Jp[r][1] * v12 + Jp[r][2] * v22;
-        }
-        // W Vinv W^T = Jc^T [diag(s) Jp Vinv Jp^T diag(s)] Jc with s = row scale^2 (both blocks carry the row scale) -- one more
-        // factor s on each side comes from Jc: (s_r Jp_r) Vinv (s_q Jp_q)^T sandwiched by (s Jc)
-        const double m00 = sx * ux * (A[0][0] * Jp[0][0] + A[0][1] * Jp[0][1] + A[0][2] * Jp[0][2]);
-        const double m01 = sx * uy * (A[0][0] * Jp[1][0] + A[0][1] * Jp[1][1] + A[0][2] * Jp[1][2]);
-        const double m11 = sy * uy * (A[1][0] * Jp[1][0] + A[1][1] * Jp[1][1] + A[1][2] * Jp[1][2]);
-        // rhs: W Vinv g_p = Jc^T diag(s) Jp Vinv g_p
-        const double ag0 = sx * (A[0][0] * r4.y + A[0][1] * r5.x + A[0][2] * r5.y);
-        const double ag1 = sy * (A[1][0] * r4.y + A[1][1] * r5.x + A[1][2] * r5.y);
-        int k = 0;
+                for (int r = 0; r < 2; ++r) {
+                    T[r][0] = Pm[r][0] * v00 + Pm[r][1] * v01 + Pm[r][2] * v02;
+                    T[r][1] = Pm[r][0] * v01 + Pm[r][1] * v11 + Pm[r][2] * v12;
+                    T[r][2] = Pm[r][0] * v02 + Pm[r][1] * v12 + Pm[r][2] * v22;
+                }
+                // N = diag(u) - diag(s u) (J_p Vinv J_p^T), the 2 x 2 middle matrix of J_c^T J_c - W Vinv W^T; then A^T N A
+                const double n00 = ux - sx * ux * (T[0][0] * Pm[0][0] + T[0][1] * Pm[0][1] + T[0][2] * Pm[0][2]);
+                const double n01 = -sx * uy * (T[0][0] * Pm[1][0] + T[0][1] * Pm[1][1] + T[0][2] * Pm[1][2]);
+                const double n11 = uy - sy * uy * (T[1][0] * Pm[1][0] + T[1][1] * Pm[1][1] + T[1][2] * Pm[1][2]);
+                const double ag0 = sx * (T[0][0] * r4.y + T[0][1] * r5.x + T[0][2] * r5.y);
+                const double ag1 = sy * (T[1][0] * r4.y + T[1][1] * r5.x + T[1][2] * r5.y);
+                // A = (fx sk; 0 fy):  A^T N A, A^T ag
+                const double t00 = Au[0] * n00, t01 = Au[0] * n01;
+                const double t10 = Au[1] * n00 + Au[2] * n01, t11 = Au[1] * n01 + Au[2] * n11;
+                const double e00 = t00 * Au[0], e01 = t00 * Au[1] + t01 * Au[2], e11 = t10 * Au[1] + t11 * Au[2];
+                const double b0 = Au[0] * ag0, b1 = Au[1] * ag0 + Au[2] * ag1;
+                // rows 0, 1 of the three angle derivatives of R X
+                double D[2][3];
+                {
+                    const double X = r0.x, Y = r0.y, Z = r1.x;
+                    const double ca = tr[0], sa = tr[1], cb = tr[2], sb = tr[3], cg = tr[4], sg = tr[5];
+                    const double y1y = ca * Y - sa * Z, y1z = sa * Y + ca * Z;
+                    const double y2x = cb * X + sb * y1z, y2z = -sb * X + cb * y1z;
+                    const double ax = sb * y1y;
+                    D[0][0] = cg * ax + sg * y1z; D[1][0] = sg * ax - cg * y1z;
+                    D[0][1] = cg * y2z;           D[1][1] = sg * y2z;
+                    D[0][2] = -(sg * y2x + cg * y1y); D[1][2] = cg * y2x - sg * y1y;
+                }
+                // [D | I]^T E [D | I], upper triangle row by row (the order of cam_acc_len: (r, q >= r)), then the right-hand side
+                double y0[3], y1[3];
 #pragma unroll
-        for (int r = 0; r < NP; ++r) {
-            const double y0 = m00 * Jc[0][r] + m01 * Jc[1][r];
-            const double y1 = m01 * Jc[0][r] + m11 * Jc[1][r];
+                for (int q = 0; q < 3; ++q) { y0[q] = e00 * D[0][q] + e01 * D[1][q]; y1[q] = e01 * D[0][q] + e11 * D[1][q]; }
+                int k = 0;
 #pragma unroll
-            for (int q = r; q < NP; ++q) {
-                acc[k] -= Jc[0][q] * y0 + Jc[1][q] * y1;
-                acc[k] += ux * Jc[0][r] * Jc[0][q] + uy * Jc[1][r] * Jc[1][q];
-                ++k;
+                for (int r = 0; r < 3; ++r) {
+#pragma unroll
+                    for (int q = r; q < 3; ++q) acc[k++] += D[0][r] * y0[q] + D[1][r] * y1[q];
+                    if constexpr (NP == 5) { acc[k++] += y0[r]; acc[k++] += y1[r]; }
+                }
+                if constexpr (NP == 5) { acc[k++] += e00; acc[k++] += e01; acc[k++] += e11; }
+#pragma unroll
+                for (int r = 0; r < 3; ++r) acc[k++] -= D[0][r] * b0 + D[1][r] * b1;
+                if constexpr (NP == 5) { acc[k++] -= b0; acc[k++] -= b1; }
+            } else {
+                double Jc[2][NP], Jp[2][3];
+                if constexpr (MODEL == RPC) {  // the blocks the linearize kernel stored (scales and masks included)
+                    ObsEval<MODEL, NP, true> e2;
+                    e2.load_jac(a, c.io[posc]);
+#pragma unroll
+                    for (int k = 0; k < NP; ++k) { Jc[0][k] = vm * e2.Jc[0][k]; Jc[1][k] = vm * e2.Jc[1][k]; }
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) { Jp[0][k] = e2.Jp[0][k]; Jp[1][k] = e2.Jp[1][k]; }
+                    ux = uy = sx = sy = 1.0;
+                } else {
+                    double u, v;
+                    project<MODEL, NP, true>(cc, nullptr, r0.x, r0.y, r1.x, false, u, v, Jc, Jp);
+                    if (a.sc) { const double2 t = a.sc[c.io[posc]]; ux = vm * t.x * t.x; uy = vm * t.y * t.y; }
+                    sx = ux; sy = uy;  // the fixed-point mask rides in the record's Vinv
+                }
+                double A[2][3];
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    A[r][0] = Jp[r][0] * v00 + Jp[r][1] * v01 + Jp[r][2] * v02;
+                    A[r][1] = Jp[r][0] * v01 + Jp[r][1] * v11 + Jp[r][2] * v12;
+                    A[r][2] = Jp[r][0] * v02 + Jp[r][1] * v12 + Jp[r][2] * v22;
+                }
+                // W Vinv W^T = Jc^T [diag(s) Jp Vinv Jp^T diag(s)] Jc with s = row scale^2 (both blocks carry the row scale) -- one
+                // more factor s on each side comes from Jc: (s_r Jp_r) Vinv (s_q Jp_q)^T sandwiched by (s Jc)
+                const double m00 = sx * ux * (A[0][0] * Jp[0][0] + A[0][1] * Jp[0][1] + A[0][2] * Jp[0][2]);
+                const double m01 = sx * uy * (A[0][0] * Jp[1][0] + A[0][1] * Jp[1][1] + A[0][2] * Jp[1][2]);
+                const double m11 = sy * uy * (A[1][0] * Jp[1][0] + A[1][1] * Jp[1][1] + A[1][2] * Jp[1][2]);
+                // rhs: W Vinv g_p = Jc^T diag(s) Jp Vinv g_p
+                const double ag0 = sx * (A[0][0] * r4.y + A[0][1] * r5.x + A[0][2] * r5.y);
+                const double ag1 = sy * (A[1][0] * r4.y + A[1][1] * r5.x + A[1][2] * r5.y);
+                int k = 0;
+#pragma unroll
+                for (int r = 0; r < NP; ++r) {
+                    const double y0 = m00 * Jc[0][r] + m01 * Jc[1][r];
+                    const double y1 = m01 * Jc[0][r] + m11 * Jc[1][r];
+#pragma unroll
+                    for (int q = r; q < NP; ++q) {
+                        acc[k] -= Jc[0][q] * y0 + Jc[1][q] * y1;
+                        acc[k] += ux * Jc[0][r] * Jc[0][q] + uy * Jc[1][r] * Jc[1][q];
+                        ++k;
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < NP; ++r) acc[k++] -= Jc[0][r] * ag0 + Jc[1][r] * ag1;
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
-#pragma unroll
-        for (int r = 0; r < NP; ++r) acc[k++] -= Jc[0][r] * ag0 + Jc[1][r] * ag1;
-        __builtin_amdgcn_sched_barrier(0);
     }
     if (MODEL != RPC && cam < a.n_cam_fix) {  // fixed camera (block-uniform); RPC: the stored blocks carry the mask
 #pragma unroll
         for (int k = 0; k < CU; ++k) acc[k] = 0.0;
     }
     __shared__ double s_red[LINC_THREADS / 64][CU];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int k = 0; k < CU; ++k) {
         const double t = wave_sum(acc[k]);
