@@ -66,6 +66,7 @@ struct satba_problem {
     double *d_scale_inv = nullptr, *d_g = nullptr, *d_gh = nullptr, *d_gn = nullptr, *d_q1 = nullptr, *d_wv = nullptr;
     double *d_U = nullptr, *d_gc = nullptr, *d_V = nullptr, *d_Vinv = nullptr, *d_PV = nullptr, *d_dc = nullptr, *d_dch = nullptr;
     double2 *d_f = nullptr, *d_ftmp = nullptr;  // residual pairs of the current linearisation / of satba_residuals, ELL order
+    bool f_valid = false;                       // d_f holds the residuals of the current linearisation
     double2* d_sc = nullptr;                  // Jacobian row scales of the current linearisation, io order
     double* d_Jpm = nullptr;                  // RPC: Jacobian blocks of the current linearisation, io order
     double *d_part = nullptr, *d_part3 = nullptr, *d_pair_part = nullptr;
@@ -227,7 +228,7 @@ static int launch_lin(satba_problem* p, const ObsArgs& a) {
     constexpr bool BIGL = MODEL == RPC;  // LinCfg of the linear-loss variants
 #define SATBA_LIN_LAUNCH(ROB, SOFT_, UNIT_, CS_, BIG_)                                                                                   \
     hipLaunchKernelGGL((k_linearize<MODEL, NP, ROB, CL, RL, SOFT_, UNIT_, CS_>), dim3(p->lin_grid), dim3(LinCfg<BIG_>::THREADS), lds, p->stream, \
-                       a, p->d_f, p->d_V, gpv, p->d_part, rb, cost, gmax)
+                       a, p->cam_sums_lds ? nullptr : p->d_f, p->d_V, gpv, p->d_part, rb, cost, gmax)
     const int v = lin_variant(p);
     if (p->cam_sums_lds) {
         if (v == 0) { if constexpr (MODEL != RPC) SATBA_LIN_LAUNCH(false, false, true, true, false); }
@@ -864,6 +865,7 @@ int satba_linearize(satba_problem* p) {
         TRY(launch_cam_sums(p, U, gc));  // fixed summation order; fills the full blocks
     }
     p->linearized = true; p->have_step = false;
+    p->f_valid = !p->cam_sums_lds;
     return 0;
 }
 
@@ -1128,6 +1130,10 @@ int satba_get_blocks(satba_problem* p, double* U, double* gc, double* V, double*
         HIP_TRY(hipMalloc((void**)&dU, sizeof(double) * nU));
         HIP_TRY(hipMalloc((void**)&dg, sizeof(double) * p->n_c));
         int rc = [&]() -> int {
+            if (!p->f_valid) {  // the default linearize kernel does not store the residuals: evaluate them for this view
+                TRY(launch_residual(p, false, p->d_f, p->d_scal));
+                p->f_valid = true;
+            }
             TRY(launch_cam_sums(p, dU, dg));
             HIP_TRY(hipStreamSynchronize(p->stream));
             HIP_TRY(hipMemcpy(U, dU, sizeof(double) * nU, hipMemcpyDeviceToHost));

@@ -360,7 +360,8 @@ __global__ __launch_bounds__(RES_THREADS) void k_residual(ObsArgs a, double2* __
 // ------------------------------------------------------------------------------------------------ K2 linearize
 // residual + analytic Jacobian -> normal-equation blocks (replaces scipy's finite differences,
 // scipy:optimize/_numdiff.py:628-705, and compute_grad, scipy:optimize/_lsq/common.py:590-595):
-//   f[pos]          true residual pair (ELL order)                       16 B / obs written
+//   f[pos]          true residual pair (ELL order), if f != null: only k_cam_sums reads it, i.e. runs without the LDS camera
+//                   table (SATBA_DETERMINISTIC, very many cameras); the default path does not write it     16 B / obs
 //   V[q] (6), g_p   per-point blocks, summed in the lane's registers     72 B / point written
 //   part[block][M][cam_acc_len]   per-workgroup camera partials (diag U_c, then g_c), accumulated with ds_add_f64 in an
 //                   LDS table (CAMSUMS); the off-diagonal entries of U_c are only needed inside S and come out of
@@ -436,12 +437,7 @@ __global__ __launch_bounds__(LinCfg<(ROBUST && !SOFT) || MODEL == RPC>::THREADS)
                 e.eval(a, cam, mp, T.cc(cam), T.tab(cam), r[0].ob, r[0].w, X, Y, Z);
                 if constexpr (MODEL == RPC) e.store_jac(a, io0 + k);
                 if (a.sc) a.sc[io0 + k] = make_double2(e.sw[0], e.sw[1]);
-#ifdef SATBA_NT_F
-                __builtin_nontemporal_store(e.ftrue[0], &f[pos].x);
-                __builtin_nontemporal_store(e.ftrue[1], &f[pos].y);
-#else
-                f[pos] = make_double2(e.ftrue[0], e.ftrue[1]);
-#endif
+                if (f) f[pos] = make_double2(e.ftrue[0], e.ftrue[1]);  // only the camera-major pass reads it (k_cam_sums)
                 cost += e.rho;
                 v[0] += e.Jp[0][0] * e.Jp[0][0] + e.Jp[1][0] * e.Jp[1][0];
                 v[1] += e.Jp[0][0] * e.Jp[0][1] + e.Jp[1][0] * e.Jp[1][1];
