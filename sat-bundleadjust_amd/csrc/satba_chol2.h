@@ -9,9 +9,10 @@
 // (W[p] = its 32 columns of panel p, [c][r]).
 //   all tiles        first apply the `npend` panels of the previous launch(es) (trailing update, v_mfma_f64_16x16x4; the operands
 //                    of two panels are in flight in registers)
-//   tile (0, 0)      wave 0 factorises D0 (lanes 32..63 carry the rows of L21 along) and publishes both behind flag[0]; three waves
-//                    form A22 - L21 L21^T (MFMA); wave 0 factorises D1 and publishes it behind flag[1].  Wave 1 carries the
-//                    right-hand side (forward substitution folded in) beside the second diagonal block -- off the chain.
+//   tile (0, 0)      the four waves factorise D0 (chol_diag_block4: 8 columns each, lanes 32..63 carry the rows of L21 along) and
+//                    publish both behind flag[0]; three waves form A22 - L21 L21^T (MFMA); the four waves factorise D1 and
+//                    publish it behind flag[1].  Wave 0 carries the right-hand side (forward substitution folded in) beside the
+//                    rest of the second diagonal block -- off the chain.
 //   tiles (i > 0, 0) wave 0 solves its 64 rows against D0 as soon as flag[0] is up while waves 1..3 fetch L21; all four waves
 //                    subtract X0 L21^T from the second half; wave 0 solves against D1 behind flag[1].
 // Tile (0, 0) is workgroup 0 of the 1-D grid and therefore resident before any waiter.  Requires n - k0 >= 64.
@@ -98,9 +99,71 @@ __device__ __forceinline__ double chol_fwd32(double v, const double (*Lb)[CH_NB]
     return v;
 }
 
+// Diagonal block by FOUR waves: wave w owns columns 8 w .. 8 w + 7 (one micro-panel of chol_diag_block) of the 32 x 32 block for
+// all 64 lanes (lanes 0..31: rows of the block, zero above the diagonal on entry; lanes 32..63: riders).  The chain moves from
+// wave to wave: wave p factorises its micro-panel in registers exactly like chol_diag_block does, puts it into LDS (pan[p]) and
+// raises lf[p]; the waves behind it apply it to their own columns (rank-8 update) as soon as it is there -- all but the update of
+// the NEXT micro-panel is off the chain.  One wave doing everything issued ~65 instructions per column (the rank-8 updates of up
+// to 24 columns behind every micro-panel): 5.5 us per block, instruction-bound; here the chain sees 8 columns + one update.
+// pan: [4][64][CH_MP] doubles of LDS, lf: 4 ints of LDS, zero on entry.  pub(c, v): publish column c of the factor (own lanes).
+// Returns true if a pivot of this wave's micro-panel was not positive and finite.
+template <class PUB>
+__device__ __forceinline__ bool chol_diag_block4(double (&a)[CH_MP], int w, int lane, double (*pan)[64][CH_MP], volatile int* lf, PUB&& pub) {
+    bool bad = false;
+#pragma unroll
+    for (int p = 0; p < CH_NB / CH_MP; ++p) {
+        if (w == p) {
+            double d = readlane_f64(a[0], CH_MP * p);
+            bad |= !(d > 1e-300) || !(d < 1e300);
+            double h = half_rsqrt(d);
+#pragma unroll
+            for (int jj = 0; jj < CH_MP; ++jj) {
+                const double a2 = a[jj] + a[jj];
+                const double l = a2 * h;  // lane j: 2 d h = sqrt(d)
+                a[jj] = l;
+                if (jj + 1 < CH_MP) {
+                    const double piv = fma(-l, l, a[jj + 1]);  // lane j + 1: its own l is L[j+1][j]
+                    d = readlane_f64(piv, CH_MP * p + jj + 1);
+                    bad |= !(d > 1e-300) || !(d < 1e300);
+                    h = half_rsqrt(d);
+#pragma unroll
+                    for (int c = jj + 1; c < CH_MP; ++c) a[c] = fma(-l, readlane_f64(l, CH_MP * p + c), a[c]);
+                }
+            }
+            double2* row = reinterpret_cast<double2*>(&pan[p][lane][0]);
+#pragma unroll
+            for (int m = 0; m < CH_MP / 2; ++m) row[m] = make_double2(a[2 * m], a[2 * m + 1]);
+            asm volatile("" ::: "memory");
+            if (lane == 0) lf[p] = 1;  // the LDS unit executes a wave's operations in order: the data are in place before the flag
+#pragma unroll
+            for (int jj = 0; jj < CH_MP; ++jj) pub(CH_MP * p + jj, a[jj]);
+        } else if (w > p) {
+            while (lf[p] == 0) __builtin_amdgcn_s_sleep(1);
+            asm volatile("" ::: "memory");
+            const double2* row = reinterpret_cast<const double2*>(&pan[p][lane][0]);
+            double r[CH_MP];
+#pragma unroll
+            for (int m = 0; m < CH_MP / 2; ++m) { const double2 t = row[m]; r[2 * m] = t.x; r[2 * m + 1] = t.y; }
+#pragma unroll
+            for (int jj = 0; jj < CH_MP; ++jj) {
+                const double2* lc = reinterpret_cast<const double2*>(&pan[p][CH_MP * w + jj][0]);  // row c of the panel: the same address for every lane
+                double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+                for (int m = 0; m < CH_MP / 2; ++m) {
+                    const double2 t = lc[m];
+                    s0 = fma(r[2 * m], t.x, s0);
+                    s1 = fma(r[2 * m + 1], t.y, s1);
+                }
+                a[jj] -= s0 + s1;
+            }
+        }
+    }
+    return bad;
+}
+
 // dynamic LDS of k_chol_dstep (more than the 64 KB a kernel may declare statically)
 constexpr size_t chol_dstep_lds() {
-    return sizeof(double) * (2 * CH_NB * CH_LD + CH_NB * CH_LS + 2 * CH_NB * CH_NB + 64 * CH_MP + 64 + 64 + 2 * CH_NB + 8);
+    return sizeof(double) * (2 * CH_NB * CH_LD + CH_NB * CH_LS + 2 * CH_NB * CH_NB + 4 * 64 * CH_MP + 64 + 64 + 2 * CH_NB + 8);
 }
 
 __global__ __launch_bounds__(256) void k_chol_dstep(double* __restrict__ A, int n, int npend, int k0, int* __restrict__ fail,
@@ -110,15 +173,15 @@ __global__ __launch_bounds__(256) void k_chol_dstep(double* __restrict__ A, int 
     // ts (tools only, normally null): CH_TS wall-clock stamps of this launch, 8 per row tile 0..2 of tile column 0:
     //   0 start, 1 trailing update done, 2 + p: panel p done (tile 0: diagonal block published; others: rows solved)
     extern __shared__ double s_ds[];
-    // W[2][32][CH_LD] (during the trailing update: its operands) | Lr[32][CH_LS] | Lb[2][32][32] | pan[64][CH_MP] | brow[64] | lcol[64]
-    // | yv[2][32] | lf (int)           (chol_dstep_lds)
+    // W[2][32][CH_LD] (during the trailing update: its operands) | Lr[32][CH_LS] | Lb[2][32][32] | pan[4][64][CH_MP] | brow[64] | lcol[64]
+    // | yv[2][32] | lf[16] (ints)           (chol_dstep_lds)
     double (*W)[CH_NB][CH_LD] = reinterpret_cast<double (*)[CH_NB][CH_LD]>(s_ds);
     double* Pi = &W[0][0][0];
     double* Pj = &W[1][0][0];
     double (*Lr)[CH_LS] = reinterpret_cast<double (*)[CH_LS]>(s_ds + 2 * CH_NB * CH_LD);
     double (*Lb)[CH_NB][CH_NB] = reinterpret_cast<double (*)[CH_NB][CH_NB]>(s_ds + 2 * CH_NB * CH_LD + CH_NB * CH_LS);
-    double (*pan)[CH_MP] = reinterpret_cast<double (*)[CH_MP]>(&Lb[0][0][0] + 2 * CH_NB * CH_NB);
-    double* brow = &pan[0][0] + 64 * CH_MP;
+    double (*pan)[64][CH_MP] = reinterpret_cast<double (*)[64][CH_MP]>(&Lb[0][0][0] + 2 * CH_NB * CH_NB);
+    double* brow = &pan[0][0][0] + 4 * 64 * CH_MP;
     double* lcol = brow + 64;
     double (*yv)[CH_NB] = reinterpret_cast<double (*)[CH_NB]>(lcol + 64);
     int* lf = reinterpret_cast<int*>(&yv[0][0] + 2 * CH_NB);
@@ -139,7 +202,7 @@ __global__ __launch_bounds__(256) void k_chol_dstep(double* __restrict__ A, int 
     const int e16 = lane & 15, g4 = lane >> 4;
     const bool stamp = ts && col0 && bi < 3 && tid == 0;
     if (stamp) ts[bi * 8 + 0] = wall_clock64();
-    if (col0 && tid == 0) lf[0] = 0;
+    if (col0 && tid < 16) lf[tid] = 0;
 
     // ------------------------------------------------------------------ trailing update with the pending panels
     // A[r0.., c0..] -= P_i P_j^T, b[r0..] -= P_i y_prev.  Wave w owns the 16 tile columns 16 w .. 16 w + 15 and all 64 rows (four
@@ -205,7 +268,7 @@ __global__ __launch_bounds__(256) void k_chol_dstep(double* __restrict__ A, int 
                     W[col >> 5][col & 31][row] = v;  // the tile stays in LDS
                 } else {
                     const int r = r0 + row, c = c0 + col;
-                    if (r < n && c < n && r >= c) A[(size_t)r + (size_t)c * n] = v;
+                    if (r < n && c < n && r >= c) __hip_atomic_store(A + (size_t)r + (size_t)c * n, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // write-through: nothing left to flush at the end of the kernel
                 }
             }
     }
@@ -215,30 +278,40 @@ __global__ __launch_bounds__(256) void k_chol_dstep(double* __restrict__ A, int 
 
     if (bi == 0) {
         // ---------------------------------------------------------------- tile (0, 0): D0 + L21, A22 -= L21 L21^T, D1
-        double a[CH_NB];
-        bool bad = false;
-        if (wave == 0) {
+        // lf: [0..3] micro-panels of D0, [4..7] of D1, [8] waves done with D0 (stores acknowledged), [9] the same for D1
+        volatile int* vlf = lf;
+        double a[CH_MP];
+        {
 #pragma unroll
-            for (int c = 0; c < CH_NB; ++c) {
+            for (int jj = 0; jj < CH_MP; ++jj) {
+                const int c = CH_MP * wave + jj;
                 double v = W[0][c][lane];
                 if (lane < CH_NB && c > lane) v = 0.0;  // above the diagonal
-                a[c] = v;
+                a[jj] = v;
             }
             // published as it is formed: agent-scope stores (write through to the coherence point), then the flag -- no release
             // fence (a fence writes back the whole L2 of this XCD, ~2.5 us, while the other tiles are still storing)
-            bad = chol_diag_block(a, lane, pan, [&](int c, double v) {
+            const bool bad = chol_diag_block4(a, wave, lane, pan, vlf, [&](int c, double v) {
                 if (lane >= CH_NB || c <= lane)
                     __hip_atomic_store(A + (size_t)(k0 + lane) + (size_t)(k0 + c) * n, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             });
-            __builtin_amdgcn_s_waitcnt(0);  // the stores above are acknowledged
-            if (lane == 0) __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (stamp) ts[2] = wall_clock64();
+            if (bad && lane == 0) atomicOr(fail, 1);
+            __builtin_amdgcn_s_waitcnt(0);  // my stores are acknowledged
+            if (wave < 3) {
+                if (lane == 0) __hip_atomic_fetch_add(&lf[8], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            } else {  // the last micro-panel: the other three waves stored theirs long ago
+                while (vlf[8] < 3) __builtin_amdgcn_s_sleep(1);
+                if (lane == 0) __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (ts && lane == 0) ts[2] = wall_clock64();
+            }
 #pragma unroll
-            for (int c = 0; c < CH_NB; ++c) {
-                if (lane >= CH_NB) W[0][c][lane] = a[c];  // L21: operand of the update below and of the right-hand side
-                else Lb[0][c][lane] = a[c];
+            for (int jj = 0; jj < CH_MP; ++jj) {
+                const int c = CH_MP * wave + jj;
+                if (lane >= CH_NB) W[0][c][lane] = a[jj];  // L21: operand of the update below and of the right-hand side
+                else Lb[0][c][lane] = a[jj];
             }
         }
+        if (stamp) ts[4] = wall_clock64();
         __syncthreads();
         if (wave != 1) {
             // A22 (rows / columns 32..63 of the tile: W[1][c][32 + r]) -= L21 L21^T: the three 16 x 16 blocks of its lower part, one
@@ -250,26 +323,35 @@ __global__ __launch_bounds__(256) void k_chol_dstep(double* __restrict__ A, int 
             for (int reg = 0; reg < 4; ++reg) W[1][16 * cb + g4 + 4 * reg][32 + 16 * rb + e16] -= u[0][reg];
         }
         __syncthreads();
-        if (wave == 0) {
+        {
 #pragma unroll
-            for (int c = 0; c < CH_NB; ++c) a[c] = (lane < CH_NB && c <= lane) ? W[1][c][CH_NB + lane] : 0.0;  // no riders
-            bad |= chol_diag_block(a, lane, pan, [&](int c, double v) {
+            for (int jj = 0; jj < CH_MP; ++jj) {
+                const int c = CH_MP * wave + jj;
+                a[jj] = (lane < CH_NB && c <= lane) ? W[1][c][CH_NB + lane] : 0.0;  // no riders
+            }
+            const bool bad = chol_diag_block4(a, wave, lane, pan, vlf + 4, [&](int c, double v) {
                 if (lane < CH_NB && c <= lane)
                     __hip_atomic_store(A + (size_t)(k0 + CH_NB + lane) + (size_t)(k0 + CH_NB + c) * n, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             });
-            __builtin_amdgcn_s_waitcnt(0);
-            if (lane == 0) __hip_atomic_store(flag + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (stamp) ts[3] = wall_clock64();
             if (bad && lane == 0) atomicOr(fail, 1);
             if (lane < CH_NB) {
 #pragma unroll
-                for (int c = 0; c < CH_NB; ++c) Lb[1][c][lane] = a[c];
+                for (int jj = 0; jj < CH_MP; ++jj) Lb[1][CH_MP * wave + jj][lane] = a[jj];
             }
-            __builtin_amdgcn_s_waitcnt(0);  // ... and written, before the hand-over to wave 1
-            if (lane == 0) *(volatile int*)&lf[0] = 1;
-        } else if (wave == 1) {
-            // the right-hand side, beside the second diagonal block: y0 = D0^-1 b (rows 0..31), b (rows 32..63) -= L21 y0, then
-            // y1 = D1^-1 b (rows 32..63) once wave 0 has handed D1 over
+            __builtin_amdgcn_s_waitcnt(0);  // my stores are acknowledged, my columns of D1 are in LDS
+            if (wave < 3) {
+                if (lane == 0) __hip_atomic_fetch_add(&lf[9], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            } else {
+                while (vlf[9] < 3) __builtin_amdgcn_s_sleep(1);
+                if (lane == 0) __hip_atomic_store(flag + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (ts && lane == 0) ts[3] = wall_clock64();
+                if (lane == 0) __hip_atomic_fetch_add(&lf[9], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            if (wave > 0) return;
+        }
+        // wave 0 (its micro-panel of D1 was the first): the right-hand side, beside the rest of the second diagonal block:
+        // y0 = D0^-1 b (rows 0..31), b (rows 32..63) -= L21 y0, then y1 = D1^-1 b (rows 32..63) once D1 is complete
+        {
             double v = chol_fwd32((lane < CH_NB) ? brow[lane] : 0.0, Lb[0], lane);
             if (lane < CH_NB) { yv[0][lane] = v; b[k0 + lane] = v; }
             __builtin_amdgcn_wave_barrier();
@@ -282,7 +364,8 @@ __global__ __launch_bounds__(256) void k_chol_dstep(double* __restrict__ A, int 
                 bv = brow[lane] - s;
             }
             bv = __shfl(bv, CH_NB + (lane & (CH_NB - 1)));  // row 32 + l to lane l
-            chol_spin_lds(&lf[0]);
+            while (vlf[9] < 4) __builtin_amdgcn_s_sleep(1);
+            asm volatile("" ::: "memory");
             v = chol_fwd32((lane < CH_NB) ? bv : 0.0, Lb[1], lane);
             if (lane < CH_NB) b[k0 + CH_NB + lane] = v;
         }
