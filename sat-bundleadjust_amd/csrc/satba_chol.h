@@ -499,6 +499,10 @@ __global__ __launch_bounds__(64) void k_chol_dinv(const double* __restrict__ L, 
     }
 }
 
+// (Round 2 also tried superblocks of 128 rows -- 128 x 128 diagonal blocks inverted by 32 -> 64 -> 128 block recursion in LDS,
+// 8 steps instead of 32: the inversion took 70 us on its one workgroup per block and the substitution 134 us, because a
+// 1024-thread workgroup has 128 registers per thread: one 16-row chunk of operands in flight per thread, and the 16 waves run
+// in step behind the barriers, so every chunk paid the full ~2 us load latency.  Dropped.)
 // L^T z = y for n <= 1024 with the inverted diagonal blocks: right-looking, one workgroup, thread = column.  Per 32-row block
 // (bottom up): z_k = D_k^-T y_k is a 32 x 32 matrix-vector product in one wave (no dependent chain: the triangular solve of
 // k_trsv_back_rl took 2 us per block), then every thread c < k0 subtracts its 32-term dot product L[k0:k0+32, c] . z_k, reading

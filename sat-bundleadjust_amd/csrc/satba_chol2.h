@@ -17,6 +17,9 @@
 //                    subtract X0 L21^T from the second half; wave 0 solves against D1 behind flag[1].
 // Tile (0, 0) is workgroup 0 of the 1-D grid and therefore resident before any waiter.  Requires n - k0 >= 64.
 //
+// Tried and dropped in round 2: handing the diagonal blocks over through NaN-initialised mailboxes that the waiting tiles poll
+// instead of a flag behind the data (one memory trip less on paper): the solved rows arrived at the same time (21.0 vs 21.2 us
+// into the launch) and the kernel ended 1.5 us later.
 // Round 2 tried four panels per launch (row tile 1 takes the chain over after two diagonal blocks): 57 us per 128 columns
 // against 2 x 27.5 here -- the trailing update of four pending panels on one CU costs what the saved launch gap gains.
 #pragma once

@@ -121,7 +121,7 @@ __device__ inline int rs_index(int lane) {
 // of being recomputed (they carry scales and masks).
 template <int MODEL, int NP, bool UNITW>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 3))) void k_schur_pairs(ObsArgs a, SchurArgs s, double* __restrict__ S) {
-    __shared__ double2 s_coop[4 * 64 * 5];  // per wave: 64 records x 80 bytes (the quad-cooperative gathers are transposed here)
+    __shared__ double2 s_coop[4 * 64 * 7];  // per wave: 64 records x 80 bytes, or 64 Jacobian rows x 112 (the cooperative gathers are transposed here)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long long n_pairs = (long long)a.M * (a.M - 1) / 2;
     const int2 item = s.items[blockIdx.x * 4u + (unsigned)wave];
@@ -175,7 +175,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 3))) voi
         d[0][1] = cg * y2z;           d[1][1] = sg * y2z;
         d[0][2] = -(sg * y2x + cg * y1y); d[1][2] = cg * y2x - sg * y1y;
     };
-    auto compute = [&](const Rec& rc, int pi, int pj, const double2& scl_i, const double2& scl_j) {
+    // JROWS: the stored Jacobian rows of both observations come in ti / tj (RPC, gathered cooperatively by the caller)
+    constexpr bool JROWS = MODEL == RPC && NP == 3;
+    constexpr int JLEN = 2 * NP + 6;
+    auto compute = [&](const Rec& rc, int pi, int pj, const double2& scl_i, const double2& scl_j, const double* tip, const double* tjp) {
         const double X = rc.r0.x, Y = rc.r0.y, Z = rc.r1.x;
         const double v00 = rc.r1.y, v01 = rc.r2.x, v02 = rc.r2.y, v11 = rc.r3.x, v12 = rc.r3.y, v22 = rc.r4;
         if constexpr (MODEL == AFFINE) {
@@ -225,13 +228,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 3))) voi
         }
         double Jci[2][NP], Jpi[2][3], Jcj[2][NP], Jpj[2][3];
         if constexpr (MODEL == RPC) {
-            const double2* qi = reinterpret_cast<const double2*>(a.Jpm + (size_t)pi * (2 * NP + 6));
-            const double2* qj = reinterpret_cast<const double2*>(a.Jpm + (size_t)pj * (2 * NP + 6));
-            double ti[2 * NP + 6], tj[2 * NP + 6];
+            double ti[JLEN], tj[JLEN];
+            if constexpr (JROWS) {
 #pragma unroll
-            for (int k = 0; k < NP + 3; ++k) {
-                const double2 vi = qi[k], vj = qj[k];
-                ti[2 * k] = vi.x; ti[2 * k + 1] = vi.y; tj[2 * k] = vj.x; tj[2 * k + 1] = vj.y;
+                for (int k = 0; k < JLEN; ++k) { ti[k] = tip[k]; tj[k] = tjp[k]; }
+            } else {
+                const double2* qi = reinterpret_cast<const double2*>(a.Jpm + (size_t)pi * JLEN);
+                const double2* qj = reinterpret_cast<const double2*>(a.Jpm + (size_t)pj * JLEN);
+#pragma unroll
+                for (int k = 0; k < NP + 3; ++k) {
+                    const double2 vi = qi[k], vj = qj[k];
+                    ti[2 * k] = vi.x; ti[2 * k + 1] = vi.y; tj[2 * k] = vj.x; tj[2 * k + 1] = vj.y;
+                }
             }
 #pragma unroll
             for (int k = 0; k < NP; ++k) { Jci[0][k] = ti[k]; Jci[1][k] = ti[NP + k]; Jcj[0][k] = tj[k]; Jcj[1][k] = tj[NP + k]; }
@@ -307,7 +315,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 3))) voi
                 o.c4 = psrc[4][(PV_STRIDE / 2) * (size_t)__shfl(p, rsrc[4])];
                 return o;
             };
-            char* my = reinterpret_cast<char*>(s_coop) + wave * (64 * 80);
+            char* my = reinterpret_cast<char*>(s_coop) + wave * (64 * 112);
             double2* wr = reinterpret_cast<double2*>(my) + lane;  // piece g at 16 g bytes: record stride 80
             const double2* mine = reinterpret_cast<const double2*>(my + lane * 80);
             auto transpose = [&](const Coop& o) {
@@ -317,6 +325,42 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 3))) voi
                 asm volatile("" ::: "memory");
                 __builtin_amdgcn_wave_barrier();
                 r.r0 = mine[0]; r.r1 = mine[1]; r.r2 = mine[2]; r.r3 = mine[3]; r.r4 = mine[4].x;
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+                return r;
+            };
+            // RPC, rotation only: the stored Jacobian rows (12 doubles = 6 pieces per observation, io order) of both observations are
+            // gathered the same way (piece 64 t + lane: row (64 t + lane) / 6, piece (64 t + lane) % 6; 11 lines per instruction
+            // instead of 64, twelve instructions per iteration) and transposed through the same LDS buffer, row stride 7 pieces
+            struct JCoop { double2 c0, c1, c2, c3, c4, c5; };
+            struct JRow { double v[JLEN]; };
+            int jsrc[6];
+            const double2* jp[6];
+            double2* jw[6];
+#pragma unroll
+            for (int t = 0; t < 6; ++t) {
+                const int g = 64 * t + lane;
+                jsrc[t] = g / 6; jp[t] = reinterpret_cast<const double2*>(a.Jpm) + g % 6; jw[t] = reinterpret_cast<double2*>(my) + (g / 6) * 7 + g % 6;
+            }
+            auto jcoop_load = [&](int io) {
+                JCoop o;
+                o.c0 = jp[0][6 * (size_t)__shfl(io, jsrc[0])];
+                o.c1 = jp[1][6 * (size_t)__shfl(io, jsrc[1])];
+                o.c2 = jp[2][6 * (size_t)__shfl(io, jsrc[2])];
+                o.c3 = jp[3][6 * (size_t)__shfl(io, jsrc[3])];
+                o.c4 = jp[4][6 * (size_t)__shfl(io, jsrc[4])];
+                o.c5 = jp[5][6 * (size_t)__shfl(io, jsrc[5])];
+                return o;
+            };
+            const double2* jmine = reinterpret_cast<const double2*>(my) + lane * 7;
+            auto jtranspose = [&](const JCoop& o) {
+                JRow r;
+                asm volatile("" ::: "memory");
+                *jw[0] = o.c0; *jw[1] = o.c1; *jw[2] = o.c2; *jw[3] = o.c3; *jw[4] = o.c4; *jw[5] = o.c5;
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int k = 0; k < 6; ++k) { const double2 t = jmine[k]; r.v[2 * k] = t.x; r.v[2 * k + 1] = t.y; }
                 asm volatile("" ::: "memory");
                 __builtin_amdgcn_wave_barrier();
                 return r;
@@ -331,8 +375,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 3))) voi
                 if constexpr (SCL) { si_cur = a.sc[pi_cur]; sj_cur = a.sc[pj_cur]; }
             }
             Coop c_cur = coop_load(ldp(idx));
+            JCoop ji_cur, jj_cur;
+            if constexpr (JROWS) { ji_cur = jcoop_load(pi_cur); jj_cur = jcoop_load(pj_cur); }
             for (int it = 0; it < n_it; ++it) {
                 const Rec r_cur = transpose(c_cur);  // first: its wait covers only loads of the previous iteration
+                JRow ti, tj;
+                if constexpr (JROWS) { ti = jtranspose(ji_cur); tj = jtranspose(jj_cur); }
                 // indices run two iterations ahead, records one: neither latency is on the critical path
                 const int p_nn = ldp(idx + 128);
                 int pi_nn = 0, pj_nn = 0;
@@ -342,12 +390,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 3))) voi
                     if constexpr (SCL) { si_nxt = a.sc[pi_nxt]; sj_nxt = a.sc[pj_nxt]; }
                 }
                 const Coop c_nxt = coop_load(p_nxt);
+                JCoop ji_nxt, jj_nxt;
+                if constexpr (JROWS) { ji_nxt = jcoop_load(pi_nxt); jj_nxt = jcoop_load(pj_nxt); }
                 // keep the gathers above the arithmetic: without the barrier the scheduler sinks them below compute() to
                 // save registers and every iteration pays the full memory latency
                 __builtin_amdgcn_sched_barrier(0);
-                compute(r_cur, pi_cur, pj_cur, si_cur, sj_cur);
+                compute(r_cur, pi_cur, pj_cur, si_cur, sj_cur, ti.v, tj.v);
                 __builtin_amdgcn_sched_barrier(0);
                 p_nxt = p_nn; c_cur = c_nxt;
+                if constexpr (JROWS) { ji_cur = ji_nxt; jj_cur = jj_nxt; }
                 pi_cur = pi_nxt; pj_cur = pj_nxt; pi_nxt = pi_nn; pj_nxt = pj_nn;
                 si_cur = si_nxt; sj_cur = sj_nxt;
                 idx += 64;
