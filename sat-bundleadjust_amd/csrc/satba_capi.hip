@@ -71,6 +71,7 @@ struct satba_problem {
     double* d_Jpm = nullptr;                  // RPC: Jacobian blocks of the current linearisation, io order
     double *d_part = nullptr, *d_part3 = nullptr, *d_pair_part = nullptr;
     int2* d_items = nullptr;  // (pair, chunk) work items of the Schur pair kernel in dispatch order
+    SchurItem* d_item_desc = nullptr;
     int n_item_blocks = 0;
 
     int lin_grid = 0, cm_chunks = 1;
@@ -291,7 +292,7 @@ static SchurArgs schur_args(const satba_problem* p) {
     SchurArgs s;
     s.PV = reinterpret_cast<const double2*>(p->d_PV);
     s.pair_ofs = p->L.pair_ofs; s.pair_pts = p->L.pair_pts; s.pair_pi = p->L.pair_pi; s.pair_pj = p->L.pair_pj;
-    s.pair_ij = p->L.pair_ij; s.pair_part = p->d_pair_part; s.n_chunks = p->L.C; s.items = p->d_items;
+    s.pair_ij = p->L.pair_ij; s.pair_part = p->d_pair_part; s.n_chunks = p->L.C; s.items = p->d_items; s.desc = p->d_item_desc;
     return s;
 }
 
@@ -430,6 +431,10 @@ static int schur_item_table(satba_problem* p) {
     p->n_item_blocks = (int)(table.size() / 4);
     TRY(dev_alloc(p, &p->d_items, table.size()));
     HIP_TRY(hipMemcpy(p->d_items, table.data(), sizeof(int2) * table.size(), hipMemcpyHostToDevice));
+    TRY(dev_alloc(p, &p->d_item_desc, table.size()));
+    hipLaunchKernelGGL(k_schur_item_desc, dim3((unsigned)((table.size() + 255) / 256)), dim3(256), 0, p->stream, (long long)table.size(), p->d_items,
+                       p->L.pair_ij, p->L.pair_ofs, C, p->d_item_desc);
+    HIP_TRY(hipGetLastError());
     return 0;
 }
 

@@ -66,6 +66,12 @@ __global__ void k_schur_init(int M, int NP, double lam, const double* __restrict
     }
 }
 
+// one work item of k_schur_pairs, flattened: without it a wave starts with three dependent loads (item -> pair_ij, pair_ofs)
+struct SchurItem {
+    long long lo, hi;  // entry range of the (pair, chunk) list
+    int i, j;          // cameras, i < j; i < 0: padding
+    int pair, chunk;
+};
 struct SchurArgs {
     const double2* __restrict__ PV;          // N x 8 double2: X0 X1 | X2 v00 | v01 v02 | v11 v12 | v22 g0 | g1 g2 | pad
     const long long* __restrict__ pair_ofs;  // n_pairs x (n_chunks + 1): offsets into the lists
@@ -75,6 +81,7 @@ struct SchurArgs {
     const int2* __restrict__ pair_ij;        // pair index -> (i, j), i < j
     double* __restrict__ pair_part;          // n_chunks x n_pairs x NP*NP partial blocks (n_chunks > 1)
     const int2* __restrict__ items;          // work items in dispatch order: (pair, chunk), pair < 0: padding
+    const struct SchurItem* __restrict__ desc;  // the same items with everything a wave needs to start (k_schur_item_desc)
     int n_chunks;
 };
 
@@ -109,6 +116,22 @@ __device__ inline int rs_index(int lane) {
     return idx;
 }
 
+__global__ void k_schur_item_desc(long long n_items, const int2* __restrict__ items, const int2* __restrict__ pair_ij,
+                                  const long long* __restrict__ pair_ofs, int n_chunks, SchurItem* __restrict__ desc) {
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n_items) return;
+    const int2 it = items[e];
+    SchurItem d;
+    if (it.x < 0) { d.lo = d.hi = 0; d.i = d.j = -1; d.pair = -1; d.chunk = 0; }
+    else {
+        const int2 ij = pair_ij[it.x];
+        d.lo = pair_ofs[(long long)it.x * (n_chunks + 1) + it.y];
+        d.hi = pair_ofs[(long long)it.x * (n_chunks + 1) + it.y + 1];
+        d.i = ij.x; d.j = ij.y; d.pair = it.x; d.chunk = it.y;
+    }
+    desc[e] = d;
+}
+
 // 1-D grid, 4 waves per workgroup, one (pair, chunk) item each, taken from an item table in DISPATCH order that is built
 // for the chip's topology (satba_capi.hip: schur_item_table): workgroup b runs on XCD b % 8 (observed placement; only speed
 // depends on it), and every XCD works through the pairs (i, j) of ONE camera i and ONE point-range chunk at a time.  All those
@@ -124,13 +147,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 3))) voi
     __shared__ double2 s_coop[4 * 64 * 7];  // per wave: 64 records x 80 bytes, or 64 Jacobian rows x 112 (the cooperative gathers are transposed here)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long long n_pairs = (long long)a.M * (a.M - 1) / 2;
-    const int2 item = s.items[blockIdx.x * 4u + (unsigned)wave];
-    if (item.x < 0) return;
-    const int chunk = __builtin_amdgcn_readfirstlane(item.y);
-    const long long pair = __builtin_amdgcn_readfirstlane(item.x);
-    const int2 ij = s.pair_ij[pair];
-    const int i = __builtin_amdgcn_readfirstlane(ij.x);  // wave-uniform by construction: lets the camera constants use scalar loads
-    const int j = __builtin_amdgcn_readfirstlane(ij.y);
+    const SchurItem* dp = s.desc + (blockIdx.x * 4u + (unsigned)wave);
+    const int i = __builtin_amdgcn_readfirstlane(dp->i);  // wave-uniform by construction: lets the camera constants use scalar loads
+    if (i < 0) return;
+    const int j = __builtin_amdgcn_readfirstlane(dp->j);
+    const int chunk = __builtin_amdgcn_readfirstlane(dp->chunk);
+    const long long pair = __builtin_amdgcn_readfirstlane(dp->pair);
     const double* cci = a.camc + (size_t)i * CAMC;
     const double* ccj = a.camc + (size_t)j * CAMC;
 
@@ -282,8 +304,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 3))) voi
     };
 
     {
-        const int C1 = s.n_chunks + 1;
-        const long long lo = s.pair_ofs[pair * C1 + chunk], hi = s.pair_ofs[pair * C1 + chunk + 1];
+        const long long lo = dp->lo, hi = dp->hi;
         constexpr bool POS = !UNITW || MODEL == RPC;  // positions (and, weighted / robust, scales) ride along
         constexpr bool SCL = !UNITW && MODEL != RPC;
         // Cooperative record gathers.  A gather instruction costs the texture path one tag lookup per distinct line it touches;
