@@ -72,6 +72,9 @@ struct satba_problem {
     double *d_part = nullptr, *d_part3 = nullptr, *d_pair_part = nullptr;
     int2* d_items = nullptr;  // (pair, chunk) work items of the Schur pair kernel in dispatch order
     SchurItem* d_item_desc = nullptr;
+    int2* d_items_merged = nullptr;           // one item per pair (all chunks), for the unit-weight kernels
+    SchurItem* d_item_desc_merged = nullptr;
+    int n_item_blocks_merged = 0;
     int n_item_blocks = 0;
 
     int lin_grid = 0, cm_chunks = 1;
@@ -304,11 +307,13 @@ static int launch_schur(satba_problem* p, const ObsArgs& a, double* S, double* r
     // diagonal blocks (with J_c^T J_c) and right-hand side
     hipLaunchKernelGGL((k_schur_diag<MODEL, NP>), dim3(p->M, p->cm_chunks), dim3(LINC_THREADS), 0, p->stream, a, cm, s, p->d_part3);
     if (n_pairs > 0 && p->L.E > 0) {
-        const dim3 igrid((unsigned)p->n_item_blocks);
+        const bool merged = a.unit && p->d_item_desc_merged;  // one item per pair: straight into S, no partials
+        if (merged) { s.desc = p->d_item_desc_merged; s.items = p->d_items_merged; s.n_chunks = 1; }
+        const dim3 igrid((unsigned)(merged ? p->n_item_blocks_merged : p->n_item_blocks));
         if (a.unit) hipLaunchKernelGGL((k_schur_pairs<MODEL, NP, true>), igrid, dim3(256), 0, p->stream, a, s, S);
         else hipLaunchKernelGGL((k_schur_pairs<MODEL, NP, false>), igrid, dim3(256), 0, p->stream, a, s, S);
         HIP_TRY(hipGetLastError());
-        if (p->L.C > 1) {
+        if (p->L.C > 1 && !merged) {
             const long long outs = n_pairs * NP * NP;
             hipLaunchKernelGGL(k_schur_pairs_reduce, dim3((unsigned)((outs + 255) / 256)), dim3(256), 0, p->stream, p->M, NP, p->n_c, p->L.C,
                                p->L.pair_ij, p->d_pair_part, S);
@@ -398,14 +403,18 @@ static double ms_since(std::chrono::steady_clock::time_point t0) {
 // (all pairs (i, j > i) of one camera i) are dealt to the 8 XCDs longest-first onto the least loaded one; an XCD's items
 // are ordered row by row, chunk by chunk; workgroup b = 8 s + x takes the s-th group of 4 items of XCD x.
 // SATBA_SCHUR_ORDER=chunk restores round 1's chunk-major order (A/B runs).
-static int schur_item_table(satba_problem* p) {
-    const int M = p->M, C = p->L.C, X = 8;
+// merged: one item per pair covering all its chunks (chunk = -1 in the table): the unit-weight kernels gather nothing per
+// observation and are faster with four times fewer, longer items (0.548 vs 0.576 ms at 200 x 1M x 10M) -- the weighted / robust
+// kernels are not (their row-scale gathers want the locality of the point-range chunks: 1.58 vs 1.74 ms with two chunks).
+static int schur_item_table_build(satba_problem* p, bool merged, int2** d_items, SchurItem** d_desc, int* n_blocks) {
+    const int M = p->M, C = merged ? 1 : p->L.C, X = 8;
     const long long n_pairs = p->L.n_pairs;
     std::vector<int2> table;
     const char* ord = getenv("SATBA_SCHUR_ORDER");
+    auto item = [&](long long pr, int ch) { return make_int2((int)pr, merged ? -1 : ch); };
     if (ord && !strcmp(ord, "chunk")) {
         for (int ch = 0; ch < C; ++ch) {
-            for (long long pr = 0; pr < n_pairs; ++pr) table.push_back(make_int2((int)pr, ch));
+            for (long long pr = 0; pr < n_pairs; ++pr) table.push_back(item(pr, ch));
             while (table.size() % 4) table.push_back(make_int2(-1, 0));
         }
     } else {
@@ -416,7 +425,7 @@ static int schur_item_table(satba_problem* p) {
             for (int k = 1; k < X; ++k) if (load[k] < load[x]) x = k;
             load[x] += M - 1 - i;
             for (int ch = 0; ch < C; ++ch) {
-                for (int j = i + 1; j < M; ++j) per[x].push_back(make_int2((int)pair_index(M, i, j), ch));
+                for (int j = i + 1; j < M; ++j) per[x].push_back(item(pair_index(M, i, j), ch));
                 while (per[x].size() % 4) per[x].push_back(make_int2(-1, 0));  // a workgroup stays inside one (row, chunk) group
             }
         }
@@ -428,13 +437,20 @@ static int schur_item_table(satba_problem* p) {
                 for (int w = 0; w < 4; ++w) table[(s * X + x) * 4 + w] = per[x][s * 4 + w];
     }
     if (table.empty()) table.push_back(make_int2(-1, 0)), table.resize(4, make_int2(-1, 0));
-    p->n_item_blocks = (int)(table.size() / 4);
-    TRY(dev_alloc(p, &p->d_items, table.size()));
-    HIP_TRY(hipMemcpy(p->d_items, table.data(), sizeof(int2) * table.size(), hipMemcpyHostToDevice));
-    TRY(dev_alloc(p, &p->d_item_desc, table.size()));
-    hipLaunchKernelGGL(k_schur_item_desc, dim3((unsigned)((table.size() + 255) / 256)), dim3(256), 0, p->stream, (long long)table.size(), p->d_items,
-                       p->L.pair_ij, p->L.pair_ofs, C, p->d_item_desc);
+    *n_blocks = (int)(table.size() / 4);
+    TRY(dev_alloc(p, d_items, table.size()));
+    HIP_TRY(hipMemcpy(*d_items, table.data(), sizeof(int2) * table.size(), hipMemcpyHostToDevice));
+    TRY(dev_alloc(p, d_desc, table.size()));
+    hipLaunchKernelGGL(k_schur_item_desc, dim3((unsigned)((table.size() + 255) / 256)), dim3(256), 0, p->stream, (long long)table.size(), *d_items,
+                       p->L.pair_ij, p->L.pair_ofs, p->L.C, *d_desc);
     HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+static int schur_item_table(satba_problem* p) {
+    TRY(schur_item_table_build(p, false, &p->d_items, &p->d_item_desc, &p->n_item_blocks));
+    const char* mg = getenv("SATBA_SCHUR_MERGE");  // experiments: 0 keeps the chunked items for every kernel
+    if (p->L.C > 1 && !(mg && atoi(mg) == 0)) TRY(schur_item_table_build(p, true, &p->d_items_merged, &p->d_item_desc_merged, &p->n_item_blocks_merged));
     return 0;
 }
 

@@ -125,9 +125,10 @@ __global__ void k_schur_item_desc(long long n_items, const int2* __restrict__ it
     if (it.x < 0) { d.lo = d.hi = 0; d.i = d.j = -1; d.pair = -1; d.chunk = 0; }
     else {
         const int2 ij = pair_ij[it.x];
-        d.lo = pair_ofs[(long long)it.x * (n_chunks + 1) + it.y];
-        d.hi = pair_ofs[(long long)it.x * (n_chunks + 1) + it.y + 1];
-        d.i = ij.x; d.j = ij.y; d.pair = it.x; d.chunk = it.y;
+        const int c0 = it.y < 0 ? 0 : it.y, c1 = it.y < 0 ? n_chunks : it.y + 1;  // chunk < 0: the whole list of the pair
+        d.lo = pair_ofs[(long long)it.x * (n_chunks + 1) + c0];
+        d.hi = pair_ofs[(long long)it.x * (n_chunks + 1) + c1];
+        d.i = ij.x; d.j = ij.y; d.pair = it.x; d.chunk = c0;
     }
     desc[e] = d;
 }

@@ -251,10 +251,17 @@ def test_packed_schur_exchange(gpu):
     dev.close()
 
 
-def test_schur_matrix_and_rhs(gpu):
+# chunks: None: as sized for the problem (one chunk at this size); "3": pair lists cut into three point-range chunks -- with the
+# unit weights of this case the pair kernel then runs on the merged items (one item per pair over all its chunks)
+@pytest.mark.parametrize("chunks", [None, "3"])
+def test_schur_matrix_and_rhs(gpu, monkeypatch, chunks):
+    if chunks:
+        monkeypatch.setenv("SATBA_SCHUR_CHUNKS", chunks)  # read when the problem handle is created
     _, p, g = cases.fun_case("affine_RT")
     v = g["v"][1]
     dev, ora = HipEngine(p), L.OracleEngine(p)
+    if chunks:
+        assert dev.info()["pair_chunks"] == int(chunks)
     for e in (dev, ora):
         e.configure("linear", 1.0)
         e.set_x(v)
