@@ -208,17 +208,31 @@ __global__ __launch_bounds__(256) void k_chol_dstep(double* __restrict__ A, int 
     if (col0 && tid < 16) lf[tid] = 0;
 
     // ------------------------------------------------------------------ trailing update with the pending panels
-    // A[r0.., c0..] -= P_i P_j^T, b[r0..] -= P_i y_prev.  Wave w owns the 16 tile columns 16 w .. 16 w + 15 and all 64 rows (four
-    // 16 x 16 outputs); a lane holds rows 16 rb + (lane & 15), columns 16 w + (lane >> 4) + 4 reg  (chol_mfma_update)
+    // A[r0.., c0..] -= P_i P_j^T, b[r0..] -= P_i y_prev, 16 x 16 blocks by v_mfma_f64_16x16x4 (64 cycles each: the update of a
+    // tile is bound by the MFMA rate of its CU).  Block (rb, cb) = rows 16 rb.., columns 16 cb.. of the tile; a lane holds rows
+    // 16 rb + (lane & 15), columns 16 cb + (lane >> 4) + 4 reg.  Ordinary tiles: wave w takes the four blocks of column block w.
+    // The diagonal tile (0, 0) -- the one on the chain -- only needs its lower ten blocks; they are dealt 3 / 3 / 2 / 2, and the
+    // wave with the least takes the right-hand side, too.
     {
+        const bool diag = col0 && bi == 0;
+        int nblk = 4, rbs[4], cbs[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { rbs[t] = t; cbs[t] = wave; }
+        if (diag) {
+            if (wave == 0) { nblk = 3; }                                              // (0,0) (1,0) (2,0)
+            else if (wave == 1) { nblk = 3; rbs[0] = 1; rbs[1] = 2; rbs[2] = 3; }      // (1,1) (2,1) (3,1)
+            else if (wave == 2) { nblk = 2; rbs[0] = 2; rbs[1] = 3; }                  // (2,2) (3,2)
+            else { nblk = 2; rbs[0] = 3; rbs[1] = 3; cbs[1] = 0; }                     // (3,3) (3,0)
+        }
+        const int bwave = diag ? 3 : 0;  // the wave that carries the right-hand side of the tile's rows
         chol_d4 old[4], acc[4];
 #pragma unroll
-        for (int rb = 0; rb < 4; ++rb) {
-            acc[rb] = chol_d4{0.0, 0.0, 0.0, 0.0};
+        for (int t = 0; t < 4; ++t) {
+            acc[t] = chol_d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
-                const int r = r0 + 16 * rb + e16, c = c0 + 16 * wave + g4 + 4 * reg;
-                old[rb][reg] = (r < n && c < n && r >= c) ? A[(size_t)r + (size_t)c * n] : 0.0;
+                const int r = r0 + 16 * rbs[t] + e16, c = c0 + 16 * cbs[t] + g4 + 4 * reg;
+                old[t][reg] = (t < nblk && r < n && c < n && r >= c) ? A[(size_t)r + (size_t)c * n] : 0.0;
             }
         }
         if (col0 && tid < 64) brow[tid] = (r0 + tid < n) ? b[r0 + tid] : 0.0;
@@ -244,13 +258,24 @@ __global__ __launch_bounds__(256) void k_chol_dstep(double* __restrict__ A, int 
             }
             if (col0 && tid >= 64 && tid < 64 + CH_NB) lcol[tid - 64] = o.y;
             __syncthreads();
-            if (col0 && tid < 64) {
+            if (col0 && wave == bwave) {
                 double s = 0.0;
 #pragma unroll 8
-                for (int k = 0; k < CH_NB; ++k) s += Pi[k * CH_LD + tid] * lcol[k];
-                brow[tid] -= s;  // only this thread touches brow[tid] until the next barrier
+                for (int k = 0; k < CH_NB; ++k) s += Pi[k * CH_LD + lane] * lcol[k];
+                brow[lane] -= s;  // only this lane touches brow[lane] until the next barrier
             }
-            chol_mfma_acc<4>(Pi, CH_LD, Pj, CH_LD, wave, 0, lane, acc);
+            const int kq = lane >> 4;
+#pragma unroll
+            for (int ks = 0; ks < CH_NB / 4; ++ks) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    if (t < nblk) {
+                        const double av = Pj[(4 * ks + kq) * CH_LD + 16 * cbs[t] + e16];
+                        const double bv = Pi[(4 * ks + kq) * CH_LD + 16 * rbs[t] + e16];
+                        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[t], 0, 0, 0);
+                    }
+                }
+            }
         };
         Operands oa, ob;
         if (npend > 0) fetch(oa, k0 - CH_NB * npend);
@@ -262,16 +287,18 @@ __global__ __launch_bounds__(256) void k_chol_dstep(double* __restrict__ A, int 
         if (col0 && tid < 64 && bi > 0 && r0 + tid < n) b[r0 + tid] = brow[tid];
         if (col0) __syncthreads();  // everyone is done with the operand arrays before they become the tile
 #pragma unroll
-        for (int rb = 0; rb < 4; ++rb)
+        for (int t = 0; t < 4; ++t)
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
-                const int row = 16 * rb + e16, col = 16 * wave + g4 + 4 * reg;
-                const double v = old[rb][reg] - acc[rb][reg];
-                if (col0) {
-                    W[col >> 5][col & 31][row] = v;  // the tile stays in LDS
-                } else {
-                    const int r = r0 + row, c = c0 + col;
-                    if (r < n && c < n && r >= c) __hip_atomic_store(A + (size_t)r + (size_t)c * n, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // write-through: nothing left to flush at the end of the kernel
+                const int row = 16 * rbs[t] + e16, col = 16 * cbs[t] + g4 + 4 * reg;
+                const double v = old[t][reg] - acc[t][reg];
+                if (t < nblk) {
+                    if (col0) {
+                        W[col >> 5][col & 31][row] = v;  // the tile stays in LDS
+                    } else {
+                        const int r = r0 + row, c = c0 + col;
+                        if (r < n && c < n && r >= c) __hip_atomic_store(A + (size_t)r + (size_t)c * n, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // write-through: nothing left to flush at the end of the kernel
+                    }
                 }
             }
     }
