@@ -8,6 +8,7 @@ mkdir -p $out
 cd $GRAFT_REPO_ROOT
 timeout 900 python -m pytest tests -m gpu -q > $out/pytest_gpu.log 2>&1
 grep -E "passed|failed|rror" $out/pytest_gpu.log | tail -3
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $out/smoke.log 2>&1; tail -1 $out/smoke.log
 python bench.py "$@" > $out/bench.json 2> $out/bench.err
 python bench.py --loss soft_l1 --cpu-sample-pts 0 > $out/bench_soft_l1.json 2>> $out/bench.err
 for s in C2 C3 P3 C5; do python bench.py --shape $s --cpu-sample-pts 0 > $out/bench_$s.json 2>> $out/bench.err; done
@@ -19,7 +20,8 @@ rocprofv3 --kernel-trace --stats -d $out/prof5 -o stats -- python3 $GRAFT_REPO_R
 python3 $GRAFT_REPO_ROOT/tools/rocpd_stats.py $out/prof5/stats_results.db > $out/kernel_stats_C5.txt
 cd $GRAFT_REPO_ROOT
 bash tools/gpu_pmc.sh $tag/pmc C4 linear "k_linearize|k_schur_pairs|k_schur_diag|k_residual|k_backsub|k_jvp" > /dev/null 2>&1
-bash tools/gpu_pmc.sh $tag/pmc5 C5 linear "k_linearize|k_residual" > /dev/null 2>&1
+bash tools/gpu_pmc.sh $tag/pmc5 C5 linear "k_linearize|k_residual|k_schur_pairs" > /dev/null 2>&1
+bash tools/gpu_pmc_mem.sh $tag/pmcm C4 linear "k_schur_pairs<|k_schur_diag<" > /dev/null 2>&1
 find $out -name "*.db" -size +2M -delete
 head -14 $out/kernel_stats.txt
 cat $out/bench.json
