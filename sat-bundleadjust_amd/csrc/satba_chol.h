@@ -475,13 +475,37 @@ __global__ __launch_bounds__(1024) void k_trsv_back_rl(const double* __restrict_
 
 // Inverse of every 32 x 32 diagonal block of the factor (lower triangular), one wave per block: lane c solves D x = e_c by
 // forward substitution in registers, the entries of D come as LDS broadcasts (every lane reads the same address).
-// dinv: n_blocks x 32 x 32, [r][c] row-major, identity padded.  All blocks at once, off the factorisation's chain (~2 us).
-__global__ __launch_bounds__(64) void k_chol_dinv(const double* __restrict__ L, int n, double* __restrict__ dinv) {
-    __shared__ double D[CH_NB][CH_NB + 1];
-    const int kb = blockIdx.x, k0 = kb * CH_NB, nb = min(CH_NB, n - k0), lane = threadIdx.x;
+// dinv: n_blocks x 32 x 32, [r][c] row-major, identity padded.  Part of k_chol_finish below.
+
+// The mirror (k_mirror_lower) and the block inverses in one launch (they read the same finished factor and write different things): the first
+// `n_mirror` workgroups mirror 32 x 32 tiles, the others invert one diagonal block each with their first wave -- one launch gap
+// less on the chain, and the 12 us of the inversions run beside the 5 us of the mirror instead of behind it.
+__global__ __launch_bounds__(256) void k_chol_finish(double* __restrict__ A, int n, int n_mirror, double* __restrict__ dinv) {
+    __shared__ double t[32][33];
+    if ((int)blockIdx.x < n_mirror) {
+        int bi = 0, idx = blockIdx.x;  // lower tiles (bi >= bj), row by row
+        while (idx > bi) { idx -= bi + 1; ++bi; }
+        const int bj = idx;
+        const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int r = bi * 32 + tx, c = bj * 32 + ty + 8 * k;
+            t[ty + 8 * k][tx] = (r < n && c < n) ? A[(size_t)r + (size_t)c * n] : 0.0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = bj * 32 + tx, r = bi * 32 + ty + 8 * k;  // element (r, c) of the lower triangle goes to (c, r)
+            if (r < n && c < n && r > c) A[(size_t)c + (size_t)r * n] = t[tx][ty + 8 * k];
+        }
+        return;
+    }
+    if (threadIdx.x >= 64) return;
+    double (*D)[CH_NB + 1] = t;
+    const int kb = blockIdx.x - n_mirror, k0 = kb * CH_NB, nb = min(CH_NB, n - k0), lane = threadIdx.x;
     for (int idx = lane; idx < CH_NB * CH_NB; idx += 64) {
         const int r = idx % CH_NB, c = idx / CH_NB;
-        D[r][c] = (r < nb && c <= r) ? L[(size_t)(k0 + r) + (size_t)(k0 + c) * n] : ((r == c) ? 1.0 : 0.0);
+        D[r][c] = (r < nb && c <= r) ? A[(size_t)(k0 + r) + (size_t)(k0 + c) * n] : ((r == c) ? 1.0 : 0.0);
     }
     __builtin_amdgcn_wave_barrier();
     const int c = min(lane, CH_NB - 1);
@@ -593,11 +617,11 @@ inline void cholesky_solve(double* A, int n, double* b, int* fail, int* flags, i
     }
     if (n <= 1024) {
         const int T = (n + 31) / 32;
-        hipLaunchKernelGGL(k_mirror_lower, dim3(T * (T + 1) / 2), dim3(256), 0, stream, A, n);
         if (dinv) {
-            hipLaunchKernelGGL(k_chol_dinv, dim3(T), dim3(64), 0, stream, A, n, dinv);
+            hipLaunchKernelGGL(k_chol_finish, dim3(T * (T + 1) / 2 + T), dim3(256), 0, stream, A, n, T * (T + 1) / 2, dinv);
             hipLaunchKernelGGL(k_trsv_back_dinv, dim3(1), dim3(1024), 0, stream, A, dinv, n, b);
         } else {
+            hipLaunchKernelGGL(k_mirror_lower, dim3(T * (T + 1) / 2), dim3(256), 0, stream, A, n);
             hipLaunchKernelGGL(k_trsv_back_rl, dim3(1), dim3(1024), 0, stream, A, n, b);
         }
     }
