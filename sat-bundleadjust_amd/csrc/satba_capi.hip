@@ -909,14 +909,17 @@ int satba_prepare(satba_problem* p, int32_t first) {
 
 static int schur_impl(satba_problem* p, double lam, const double* lam_dev) {
     const size_t nS = (size_t)p->n_c * p->n_c + p->n_c;
-    HIP_TRY(hipMemsetAsync(p->d_xb, 0, sizeof(double) * (p->hdr + nS), p->stream));
+    // header always; S and rhs only when no pair kernel will run (every block of the lower triangle is otherwise written by the
+    // kernels below: k_schur_init the diagonal blocks and rhs, the pair kernels every off-diagonal block)
+    const bool pairs_run = p->L.n_pairs > 0 && p->L.E > 0;
+    HIP_TRY(hipMemsetAsync(p->d_xb, 0, sizeof(double) * (p->hdr + (pairs_run ? 0 : nS)), p->stream));
     if (p->N > 0) {
         hipLaunchKernelGGL(k_vinv, dim3((p->N + 255) / 256), dim3(256), 0, p->stream, p->N, lam, lam_dev, p->d_V,
                            p->d_scale_inv + p->n_c, p->d_Vinv, p->d_x + p->n_c, p->d_g + p->n_c, p->d_PV, p->L.perm, p->n_pts_fix);
         HIP_TRY(hipGetLastError());
     }
     double* S = p->payload();
-    hipLaunchKernelGGL(k_schur_init, dim3((p->n_c + 255) / 256), dim3(256), 0, p->stream, p->M, p->NP, lam, lam_dev,
+    hipLaunchKernelGGL(k_schur_init, dim3((p->n_c * p->NP + 255) / 256), dim3(256), 0, p->stream, p->M, p->NP, lam, lam_dev,
                        p->lead, p->d_gc, p->d_scale_inv, S, S + (size_t)p->n_c * p->n_c);
     HIP_TRY(hipGetLastError());
     TRY(launch_schur_kernel(p));

@@ -51,19 +51,26 @@ __global__ void k_vinv(int N, double lam, const double* __restrict__ lam_dev, co
     q[3] = make_double2(mp * o3, mp * o4); q[4] = make_double2(mp * o5, g0); q[5] = make_double2(g1, g2);
 }
 
-// S <- (lead) * lam Dc^2 on the diagonal, rhs <- (lead) * g_c ; S column-major n_c x n_c (already zeroed).  The J_c^T J_c
-// blocks are added by k_schur_diag.
+// Diagonal blocks of S <- (lead) * lam Dc^2 on the diagonal and zero elsewhere, rhs <- (lead) * g_c; S column-major n_c x n_c.
+// The J_c^T J_c blocks are added by k_schur_diag_finish.  Every block of the lower triangle is written by a kernel of the Schur
+// phase (the off-diagonal ones by k_schur_pairs / k_schur_pairs_reduce, also for pairs without a common point), so S is not
+// cleared first (an 8 MB fill per iteration at 200 cameras x 5); the strict upper triangle is never read.
 __global__ void k_schur_init(int M, int NP, double lam, const double* __restrict__ lam_dev, double lead,
                              const double* __restrict__ gc, const double* __restrict__ scale_inv,
                              double* __restrict__ S, double* __restrict__ rhs) {
     if (lam_dev) lam = *lam_dev;
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     const int n_c = M * NP;
-    if (idx < n_c) {
-        const double s = scale_inv[idx];
-        S[(size_t)idx + (size_t)idx * n_c] = lead * lam * s * s;
-        rhs[idx] = lead * gc[idx];
+    if (idx >= n_c * NP) return;
+    const int col = idx / NP, q = idx % NP;  // column col = cam * NP + r of S, row cam * NP + q
+    const int cam = col / NP, r = col % NP;
+    double v = 0.0;
+    if (q == r) {
+        const double s = scale_inv[col];
+        v = lead * lam * s * s;
+        rhs[col] = lead * gc[col];
     }
+    S[(size_t)(cam * NP + q) + (size_t)col * n_c] = v;
 }
 
 // one work item of k_schur_pairs, flattened: without it a wave starts with three dependent loads (item -> pair_ij, pair_ofs)
