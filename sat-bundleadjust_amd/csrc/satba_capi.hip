@@ -370,28 +370,9 @@ static int dense_solve(satba_problem* p, double* S, double* b) {
     return 0;
 }
 
-// start of satba_schur_auto: the (already all-reduced) prepare header -> keep[1] = |g|_inf, keep[2..4] = |g_h|^2,
-// |J_h g_h|^2, |x_h|^2; trust radius (scipy trf.py:440-442 when Delta <= 0: first iteration) -> keep[6]; damping of the
-// Gauss-Newton system from the Cauchy step (scipy trf.py:473-477, common.py:302-322) -> keep[5]
+// one-thread form of schur_lambda for problems without points (k_vinv is not launched then)
 __global__ void k_lambda(const double* __restrict__ hdr, double Delta, double lam_floor, double* __restrict__ keep) {
-    const double gh_sq = hdr[1], jg_sq = hdr[2], xs_sq = hdr[3];
-    keep[1] = fmax(keep[1], hdr[4]);
-    keep[2] = gh_sq; keep[3] = jg_sq; keep[4] = xs_sq;
-    if (!(Delta > 0.0)) {
-        Delta = sqrt(xs_sq);
-        if (Delta == 0.0) Delta = 1.0;
-    }
-    // minimum of a t^2 + b t on [0, ub]
-    const double a = 0.5 * jg_sq, b = -gh_sq, ub = Delta / sqrt(gh_sq);
-    double best = fmin(0.0, a * ub * ub + b * ub);
-    if (a != 0.0) {
-        const double ext = -0.5 * b / a;
-        if (0.0 < ext && ext < ub) best = fmin(best, a * ext * ext + b * ext);
-    }
-    double lam = -best / (Delta * Delta);
-    if (!(lam >= lam_floor)) lam = lam_floor;  // also catches NaN (zero gradient)
-    keep[5] = lam;
-    keep[6] = Delta;
+    (void)schur_lambda(hdr, Delta, lam_floor, keep, true);
 }
 
 static double ms_since(std::chrono::steady_clock::time_point t0) {
@@ -907,20 +888,25 @@ int satba_prepare(satba_problem* p, int32_t first) {
     return 0;
 }
 
-static int schur_impl(satba_problem* p, double lam, const double* lam_dev) {
+// automatic: the damping comes from the prepare header and the trust radius Delta (satba_schur_auto)
+static int schur_impl(satba_problem* p, double lam, bool automatic, double Delta, double lam_floor) {
     const size_t nS = (size_t)p->n_c * p->n_c + p->n_c;
-    // header always; S and rhs only when no pair kernel will run (every block of the lower triangle is otherwise written by the
-    // kernels below: k_schur_init the diagonal blocks and rhs, the pair kernels every off-diagonal block)
     const bool pairs_run = p->L.n_pairs > 0 && p->L.E > 0;
-    HIP_TRY(hipMemsetAsync(p->d_xb, 0, sizeof(double) * (p->hdr + (pairs_run ? 0 : nS)), p->stream));
+    const double* lam_dev = automatic ? p->d_keep + 5 : nullptr;
     if (p->N > 0) {
-        hipLaunchKernelGGL(k_vinv, dim3((p->N + 255) / 256), dim3(256), 0, p->stream, p->N, lam, lam_dev, p->d_V,
-                           p->d_scale_inv + p->n_c, p->d_Vinv, p->d_x + p->n_c, p->d_g + p->n_c, p->d_PV, p->L.perm, p->n_pts_fix);
-        HIP_TRY(hipGetLastError());
+        hipLaunchKernelGGL(k_vinv, dim3((p->N + 255) / 256), dim3(256), 0, p->stream, p->N, lam, automatic ? p->d_xb : nullptr, Delta, lam_floor,
+                           p->d_keep, p->d_V, p->d_scale_inv + p->n_c, p->d_Vinv, p->d_x + p->n_c, p->d_g + p->n_c, p->d_PV, p->L.perm, p->n_pts_fix);
+    } else if (automatic) {
+        hipLaunchKernelGGL(k_lambda, dim3(1), dim3(1), 0, p->stream, p->d_xb, Delta, lam_floor, p->d_keep);
     }
+    HIP_TRY(hipGetLastError());
+    // The header is cleared by k_schur_init (behind k_vinv, which reads it).  S and rhs are only cleared when no pair kernel will
+    // run: every block of the lower triangle is otherwise written by the kernels below (k_schur_init the diagonal blocks and rhs,
+    // the pair kernels every off-diagonal block).
+    if (!pairs_run) HIP_TRY(hipMemsetAsync(p->d_xb + p->hdr, 0, sizeof(double) * nS, p->stream));
     double* S = p->payload();
-    hipLaunchKernelGGL(k_schur_init, dim3((p->n_c * p->NP + 255) / 256), dim3(256), 0, p->stream, p->M, p->NP, lam, lam_dev,
-                       p->lead, p->d_gc, p->d_scale_inv, S, S + (size_t)p->n_c * p->n_c);
+    hipLaunchKernelGGL(k_schur_init, dim3((std::max<long long>((long long)p->n_c * p->NP, p->hdr) + 255) / 256), dim3(256), 0, p->stream, p->M, p->NP,
+                       lam, lam_dev, p->lead, p->d_gc, p->d_scale_inv, S, S + (size_t)p->n_c * p->n_c, p->d_xb, (int)p->hdr);
     HIP_TRY(hipGetLastError());
     TRY(launch_schur_kernel(p));
     return 0;
@@ -930,17 +916,15 @@ int satba_schur(satba_problem* p, double lam) {
     if (!p) return fail(SATBA_E_ARG, "null handle");
     if (!p->linearized) return fail(SATBA_E_STATE, "schur before linearize");
     HIP_TRY(hipSetDevice(p->device));
-    return schur_impl(p, lam, nullptr);
+    return schur_impl(p, lam, false, 0.0, 0.0);
 }
 
 int satba_schur_auto(satba_problem* p, double Delta, double lam_floor) {
     if (!p) return fail(SATBA_E_ARG, "null handle");
     if (!p->linearized || !p->prepared) return fail(SATBA_E_STATE, "schur_auto before prepare");
     HIP_TRY(hipSetDevice(p->device));
-    hipLaunchKernelGGL(k_lambda, dim3(1), dim3(1), 0, p->stream, p->d_xb, Delta, lam_floor, p->d_keep);
-    HIP_TRY(hipGetLastError());
     p->prepared = false;  // the prepare header is gone after this call
-    return schur_impl(p, 0.0, p->d_keep + 5);
+    return schur_impl(p, 0.0, true, Delta, lam_floor);
 }
 
 int satba_solve(satba_problem* p) {

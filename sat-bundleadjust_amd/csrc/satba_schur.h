@@ -21,15 +21,44 @@ namespace satba {
 constexpr int PV_STRIDE = 16;  // doubles per packed point record: 12 used, padded to 16 so that a record is exactly one
                                // 128-byte line (96-byte records straddle lines: 1.5 lines per gather; Schur 0.945 -> 0.845 ms)
 // PV: packed per-point record X(3) | Vinv(6) | g_p(3) for the gather-heavy Schur kernels
-// lam_dev (optional): the damping is read from device memory (satba_schur_auto) instead of the argument
 // The copy of Vinv inside PV is multiplied by the point's fixed mask (0 for a frozen point, 1 otherwise): every Schur term
 // contains Vinv_p exactly once, so the Schur kernels need no mask of their own (a gather of perm[] per hit otherwise).
-__global__ void k_vinv(int N, double lam, const double* __restrict__ lam_dev, const double* __restrict__ V,
+// Start of satba_schur_auto: the (already all-reduced) prepare header -> keep[1] = |g|_inf, keep[2..4] = |g_h|^2, |J_h g_h|^2,
+// |x_h|^2; trust radius (scipy trf.py:440-442 when Delta <= 0: first iteration) -> keep[6]; damping of the Gauss-Newton system
+// from the Cauchy step (scipy trf.py:473-477, common.py:302-322) -> keep[5].  Returns the damping.  Every thread of k_vinv
+// evaluates it from the header (a dozen operations; a one-thread kernel in front cost a launch), one thread writes `keep`.
+__device__ inline double schur_lambda(const double* __restrict__ hdr, double Delta, double lam_floor, double* __restrict__ keep, bool write) {
+    const double gh_sq = hdr[1], jg_sq = hdr[2], xs_sq = hdr[3];
+    if (!(Delta > 0.0)) {
+        Delta = sqrt(xs_sq);
+        if (Delta == 0.0) Delta = 1.0;
+    }
+    // minimum of a t^2 + b t on [0, ub]
+    const double a = 0.5 * jg_sq, b = -gh_sq, ub = Delta / sqrt(gh_sq);
+    double best = fmin(0.0, a * ub * ub + b * ub);
+    if (a != 0.0) {
+        const double ext = -0.5 * b / a;
+        if (0.0 < ext && ext < ub) best = fmin(best, a * ext * ext + b * ext);
+    }
+    double lam = -best / (Delta * Delta);
+    if (!(lam >= lam_floor)) lam = lam_floor;  // also catches NaN (zero gradient)
+    if (write) {
+        keep[1] = fmax(keep[1], hdr[4]);
+        keep[2] = gh_sq; keep[3] = jg_sq; keep[4] = xs_sq;
+        keep[5] = lam;
+        keep[6] = Delta;
+    }
+    return lam;
+}
+
+// hdr_auto (optional): the damping comes from the prepare header (schur_lambda, Delta / lam_floor / keep as there) instead of `lam`
+__global__ void k_vinv(int N, double lam, const double* __restrict__ hdr_auto, double Delta, double lam_floor, double* __restrict__ keep,
+                       const double* __restrict__ V,
                        const double* __restrict__ scale_inv_p, double* __restrict__ Vinv, const double* __restrict__ xp,
                        const double* __restrict__ gp, double* __restrict__ PV, const int* __restrict__ perm, int n_pts_fix) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= N) return;
-    if (lam_dev) lam = *lam_dev;
+    if (hdr_auto) lam = schur_lambda(hdr_auto, Delta, lam_floor, keep, p == 0);
     // 16-byte accesses: V and Vinv rows are 48 bytes apart, records 128 (hipMalloc aligns the arrays to 256 bytes)
     const double2* v2 = reinterpret_cast<const double2*>(V + 6 * (size_t)p);
     const double2 va = v2[0], vb = v2[1], vc = v2[2];
@@ -55,11 +84,14 @@ __global__ void k_vinv(int N, double lam, const double* __restrict__ lam_dev, co
 // The J_c^T J_c blocks are added by k_schur_diag_finish.  Every block of the lower triangle is written by a kernel of the Schur
 // phase (the off-diagonal ones by k_schur_pairs / k_schur_pairs_reduce, also for pairs without a common point), so S is not
 // cleared first (an 8 MB fill per iteration at 200 cameras x 5); the strict upper triangle is never read.
+// lam_dev (optional): the damping is read from device memory (keep[5], written by k_vinv) instead of the argument.
+// The same launch clears the exchange header (hdr_len doubles at xb), which the phases after this one accumulate into.
 __global__ void k_schur_init(int M, int NP, double lam, const double* __restrict__ lam_dev, double lead,
                              const double* __restrict__ gc, const double* __restrict__ scale_inv,
-                             double* __restrict__ S, double* __restrict__ rhs) {
+                             double* __restrict__ S, double* __restrict__ rhs, double* __restrict__ xb, int hdr_len) {
     if (lam_dev) lam = *lam_dev;
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < hdr_len) xb[idx] = 0.0;
     const int n_c = M * NP;
     if (idx >= n_c * NP) return;
     const int col = idx / NP, q = idx % NP;  // column col = cam * NP + r of S, row cam * NP + q
