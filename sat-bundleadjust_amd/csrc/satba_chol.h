@@ -579,16 +579,106 @@ __global__ __launch_bounds__(1024) void k_trsv_back_dinv(const double* __restric
     if (c < n) b[c] = yb[c];
 }
 
+
+// L^T z = y for n <= 1024 by SEVERAL workgroups: workgroup k owns the 128 rows k0 = 128 k .. of the solution ("superblock").
+// Bottom up, every workgroup subtracts L[J rows, k columns]^T z_J from its y_k for the superblocks J below it as their z_J
+// appear (published in b behind flag[J]) and then solves its own 128 x 128 triangle with the four inverted 32 x 32 diagonal
+// blocks.  One workgroup alone (k_trsv_back_dinv) pays the load latency of a 32 x 1000 operand block 32 times (2.6 us per
+// step: 1024 threads x 128 registers hold exactly one step's operands): 82 us.  Here the operands of a workgroup's NEXT product
+// are requested before it waits for the z they meet, every workgroup holds its diagonal triangle in registers from the start,
+// and the chain is 8 hand-overs.  512 threads: thread (c, g) = column c of the superblock, rows 32 g .. 32 g + 31 of an operand
+// block.  L^T is read from the mirrored upper triangle (k_chol_finish): consecutive columns are consecutive addresses.
+// flag: one int per superblock, zero on entry.  All workgroups are resident (at most 8 of them).
+constexpr int CH_SB = 128;
+__global__ __launch_bounds__(512) void k_trsv_back_mw(const double* __restrict__ L, const double* __restrict__ dinv, int n, double* __restrict__ b,
+                                                      int* __restrict__ flag) {
+    __shared__ double ys[CH_SB], zs[CH_SB], part[4][CH_SB];
+    __shared__ double Dk[4][CH_NB][CH_NB + 1];  // Dk[blk][r][c] = (D_blk^-1)[r][c] of my four diagonal blocks
+    const int k = blockIdx.x, nsb = gridDim.x, k0 = k * CH_SB, tid = threadIdx.x;
+    const int c = tid & (CH_SB - 1), g = tid >> 7, lane = tid & 63, wave = tid >> 6;
+    const int col = min(k0 + c, n - 1);  // columns past the end of the matrix (last superblock) read a valid address, weight 0
+    auto load_block = [&](double (&dst)[CH_NB], int row0, bool lower_only) {
+        // dst[r] = L[row0 + 32 g + r][k0 + c] from the mirrored triangle; lower_only: my own triangle, rows in blocks below c's block
+#pragma unroll
+        for (int r = 0; r < CH_NB; ++r) {
+            const int row = row0 + CH_NB * g + r;
+            const bool ok = row < n && k0 + c < n && (!lower_only || g > (c >> 5));
+            dst[r] = ok ? L[(size_t)col + (size_t)min(row, n - 1) * n] : 0.0;
+        }
+    };
+    double Ld[CH_NB], La[CH_NB], Lb[CH_NB];
+    load_block(Ld, k0, true);
+    if (k + 1 < nsb) load_block(La, (nsb - 1) * CH_SB, false);  // operands of the first product
+    if (tid < CH_SB) ys[tid] = (k0 + tid < n) ? b[k0 + tid] : 0.0;
+    for (int idx = tid; idx < 4 * CH_NB * CH_NB; idx += 512) {
+        const int blk = idx / (CH_NB * CH_NB), e = idx % (CH_NB * CH_NB), r = e / CH_NB, cc = e % CH_NB;
+        const int kb = 4 * k + blk;
+        Dk[blk][r][cc] = (kb * CH_NB < n) ? dinv[((size_t)kb * CH_NB + r) * CH_NB + cc] : ((r == cc) ? 1.0 : 0.0);
+    }
+    __syncthreads();
+    // ---- the superblocks below me, bottom up; the operands of product J - 1 are requested before the wait for z_J
+    auto product = [&](const double (&Lx)[CH_NB], int J) {
+        if (wave == 0) {
+            while (__hip_atomic_load(flag + J, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(1);
+        }
+        __syncthreads();
+        if (tid < CH_SB) zs[tid] = (J * CH_SB + tid < n) ? __hip_atomic_load(b + J * CH_SB + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+        __syncthreads();
+        double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+        for (int r = 0; r < CH_NB; r += 2) { s0 = fma(Lx[r], zs[CH_NB * g + r], s0); s1 = fma(Lx[r + 1], zs[CH_NB * g + r + 1], s1); }
+        part[g][c] = s0 + s1;
+        __syncthreads();
+        if (tid < CH_SB) ys[tid] -= part[0][tid] + part[1][tid] + part[2][tid] + part[3][tid];
+        // (the barrier in front of the next reader of ys follows below or in the next product)
+    };
+    for (int J = nsb - 1; J > k; J -= 2) {
+        if (J - 1 > k) load_block(Lb, (J - 1) * CH_SB, false);
+        product(La, J);
+        if (J - 1 > k) {
+            if (J - 2 > k) load_block(La, (J - 2) * CH_SB, false);
+            product(Lb, J - 1);
+        }
+    }
+    __syncthreads();
+    // ---- my own triangle, 32-row blocks bottom up: z_blk = D_blk^-T y_blk (wave 0), then the columns in front of the block
+    for (int blk = 3; blk >= 0; --blk) {
+        if (wave == 0) {  // z_j = sum_r Dinv[r][j] y[32 blk + r]; lanes 32..63 take the second half of the sum
+            const int j = lane & (CH_NB - 1), h = lane >> 5;
+            double v = 0.0;
+#pragma unroll
+            for (int r = 0; r < CH_NB / 2; ++r) v = fma(Dk[blk][h * (CH_NB / 2) + r][j], ys[CH_NB * blk + h * (CH_NB / 2) + r], v);
+            v += __shfl_xor(v, 32);
+            __builtin_amdgcn_wave_barrier();  // every lane has read y_blk
+            if (lane < CH_NB) { zs[CH_NB * blk + lane] = v; ys[CH_NB * blk + lane] = v; }
+        }
+        __syncthreads();
+        if (blk > 0 && g == blk && c < CH_NB * blk) {  // rows of block blk are exactly the rows thread (c, g = blk) holds
+            double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+            for (int r = 0; r < CH_NB; r += 2) { s0 = fma(Ld[r], zs[CH_NB * blk + r], s0); s1 = fma(Ld[r + 1], zs[CH_NB * blk + r + 1], s1); }
+            ys[c] -= s0 + s1;
+        }
+        __syncthreads();
+    }
+    // ---- publish z_k (it is also the result): write-through stores, then the flag
+    if (tid < CH_SB && k0 + tid < n) __hip_atomic_store(b + k0 + tid, ys[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(flag + k, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 }  // namespace satba
 #include "satba_chol2.h"
 namespace satba {
 
 constexpr int CH_MAX_STEPS = 256;  // panels (n <= 8192); one flag word per panel
+constexpr int CH_TRSV_FLAGS = 64;  // k_trsv_back_mw's flags (n <= 1024: the factorisation uses the first 32 + 2)
 
 // Factorise A (n x n, column-major lower, in place) and solve A z = b in place.  *fail != 0 if A was not SPD.
 // flags: CH_MAX_STEPS ints of scratch directly behind *fail (flags == fail + 1); both are cleared here.
 // mode 0: double steps (k_chol_dstep, satba_chol2.h) while at least 64 columns remain, then single steps; 2: single steps
-// only (k_chol_step)
+// only (k_chol_step); 5: like 0 with the one-workgroup backward substitution (k_trsv_back_dinv)
 // dinv: (n / 32 rounded up) x 1024 doubles of scratch for the inverted diagonal blocks (n <= 1024), or null
 // ts (tools): CH_TS time stamps per launch
 inline void cholesky_solve(double* A, int n, double* b, int* fail, int* flags, int mode, hipStream_t stream,
@@ -602,7 +692,7 @@ inline void cholesky_solve(double* A, int n, double* b, int* fail, int* flags, i
     int k0 = 0, npend = 0, step = 0;  // step: launches so far
     int* fl = flags;
     auto tsk = [&] { return ts ? ts + CH_TS * step : nullptr; };
-    if (mode == 0) {
+    if (mode == 0 || mode == 5) {
         for (; n - k0 >= 2 * CH_NB; k0 += 2 * CH_NB, fl += 2, npend = 2, ++step) {
             const int T = (n - k0 + 63) / 64;
             hipLaunchKernelGGL(k_chol_dstep, dim3(T * (T + 1) / 2), dim3(256), chol_dstep_lds(), stream, A, n, npend, k0, fail, fl, b, tsk());
@@ -619,7 +709,8 @@ inline void cholesky_solve(double* A, int n, double* b, int* fail, int* flags, i
         const int T = (n + 31) / 32;
         if (dinv) {
             hipLaunchKernelGGL(k_chol_finish, dim3(T * (T + 1) / 2 + T), dim3(256), 0, stream, A, n, T * (T + 1) / 2, dinv);
-            hipLaunchKernelGGL(k_trsv_back_dinv, dim3(1), dim3(1024), 0, stream, A, dinv, n, b);
+            if (mode == 5) hipLaunchKernelGGL(k_trsv_back_dinv, dim3(1), dim3(1024), 0, stream, A, dinv, n, b);  // one workgroup
+            else hipLaunchKernelGGL(k_trsv_back_mw, dim3((n + CH_SB - 1) / CH_SB), dim3(512), 0, stream, A, dinv, n, b, flags + CH_TRSV_FLAGS);
         } else {
             hipLaunchKernelGGL(k_mirror_lower, dim3(T * (T + 1) / 2), dim3(256), 0, stream, A, n);
             hipLaunchKernelGGL(k_trsv_back_rl, dim3(1), dim3(1024), 0, stream, A, n, b);
