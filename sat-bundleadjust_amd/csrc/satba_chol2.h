@@ -17,6 +17,9 @@
 //                    subtract X0 L21^T from the second half; wave 0 solves against D1 behind flag[1].
 // Tile (0, 0) is workgroup 0 of the 1-D grid and therefore resident before any waiter.  Requires n - k0 >= 64.
 //
+// Tried and dropped in round 2: per-micro-panel flags for D1 with the waiting tiles' solve staged behind them (the steps of the
+// first 24 columns before the block is complete, only an 8 x 8 fetch at the end): rows solved 0.8 us earlier by the stamps,
+// nothing in the LM loop (649 it/s either way).
 // Tried and dropped in round 2: handing the diagonal blocks over through NaN-initialised mailboxes that the waiting tiles poll
 // instead of a flag behind the data (one memory trip less on paper): the solved rows arrived at the same time (21.0 vs 21.2 us
 // into the launch) and the kernel ended 1.5 us later.
