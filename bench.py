@@ -83,6 +83,16 @@ def lm_step(eng, comm, st, trf):
     st["cost"] = cost_new if actual > 0 else cost
 
 
+def lm_step_native(eng, st):
+    """The same iteration with the host side in C++ (satba_lm_step): what a single-rank solve runs (satba_solve_lm's loop body)."""
+    r = eng.lm_step(st["first"], st.get("Delta", -1.0), 1e-14)
+    st["first"] = False
+    st["Delta"] = r["Delta"]
+    st["interior"] = st.get("interior", 0) + int(r["newton"])
+    st["accepted"] += int(r["accepted"])
+    st["cost"] = r["cost_new"] if r["accepted"] else r["cost"]
+
+
 def cpu_baseline(scene, n_pts_sample, corr, full_c3=False):
     """
     The reference's scipy path (oracle/ba_oracle.solve_scipy == ref ba_core.py:284-297 on the numpy restatement of fun),
@@ -163,6 +173,8 @@ def main():
                     help="points of the CPU-baseline sub-problem (0 = skip); 20000 points = 200 k observations, ~20 s")
     ap.add_argument("--kernel-reps", type=int, default=20)
     ap.add_argument("--loss", default="linear", help="linear (headline) | soft_l1 | huber | cauchy | arctan")
+    ap.add_argument("--driver", default="auto", help="host side of an LM iteration: native (C++, satba_lm_step; one rank) | python (phase "
+                    "entry points + all-reduces) | auto (native for one rank)")
     ap.add_argument("--cpu-c3", action="store_true", help="also run the measured C3 CPU baseline (max_nfev=3, ~10 min)")
     args = ap.parse_args()
 
@@ -210,13 +222,19 @@ def main():
         if world > 1:
             dist.barrier()
 
+    # single rank: the host side of an iteration is the library's C++ (satba_lm_step, the loop body of satba_solve_lm, which is
+    # what ba_core's solve runs); several ranks: the Python phases with the all-reduces between them
+    driver = args.driver if args.driver != "auto" else ("native" if world == 1 else "python")
+    if driver == "native" and world > 1:
+        raise SystemExit("--driver native drives one rank")
+    step = (lambda: lm_step_native(eng, st)) if driver == "native" else (lambda: lm_step(eng, comm, st, trf))
     st = {"first": True, "accepted": 0, "fail": 0, "cost": None}
     for _ in range(args.warmup):
-        lm_step(eng, comm, st, trf)
+        step()
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        lm_step(eng, comm, st, trf)
+        step()
     sync()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -247,6 +265,7 @@ def main():
             "value": args.steps / dt, "unit": "LM iters/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic", "loss": args.loss,
+            "host_driver": driver,
             "config": {"workload": "{}: {} cams x {} pts x {} obs, {}, correction {}, 1 fixed camera, seed 1"
                        .format(args.shape, n_cam, n_pts, p.n_obs, model, "+".join(corr)),
                        "sharding": "points over {} rank(s)".format(world),

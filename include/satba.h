@@ -165,6 +165,14 @@ int satba_accept(satba_problem *p);
 /* synchronise the stream and copy the exchange header to the host. */
 int satba_read_header(satba_problem *p, double *host_hdr);
 
+/* One fixed-work Levenberg-Marquardt iteration of a single-rank handle with the host side in C++: linearize, prepare, damped
+ * Gauss-Newton step, 2-D trust-region subproblem, trial point, accept if the cost went down -- the body of satba_solve_lm's
+ * loop without its termination tests (ref: scipy optimize/_lsq/trf.py:trf_no_bounds, one pass).  bench.py times this.
+ * first != 0: first iteration (Jacobian scaling and trust radius are initialised; Delta is ignored).
+ * out[8]: cost at x, cost at the trial point, new trust radius, accepted (0/1), interior Newton step (0/1), predicted reduction,
+ * actual reduction, damping. */
+int satba_lm_step(satba_problem* p, int32_t first, double Delta, double lam_floor, double* out);
+
 /* ---- one-shot solve: the whole trust-region loop (scipy:optimize/_lsq/trf.py:401-560 as ba_core.py:284-297 configures it,
  * with the exact damped step of this library) below the ABI, for callers that do not want to drive the phases themselves.
  * Starts from the current x (satba_set_x), leaves the solution in the handle (satba_get_x, satba_residuals).  Single-rank

@@ -1008,6 +1008,79 @@ int satba_read_header(satba_problem* p, double* host_hdr) {
 // ---------------------------------------------------------------------------------------------------- one-shot solve
 // The loop of satba/trf.py (scipy's trf_no_bounds with an exact damped step) below the ABI: single rank only -- with several
 // ranks the exchange buffer has to be all-reduced between the phases, which is the caller's side of the contract.
+// quadratic model of the cost on the orthonormal basis of span{g_h, gn_h} (satba/trf.py:subspace_model): B (2 x 2, entries Ba Bb Bc),
+// gradient (gS0, gS1), and what maps a step (p0, p1) on that basis back to coefficients of (g_h, gn_h).  h: header of the solve
+// phase; tmp: scratch header.  Launches the subspace phases only when the Gram matrix is too ill-conditioned to do without.
+struct LmModel { double Ba, Bb, Bc, gS0, gS1, sa, alpha, nw; bool one_dim; };
+static int lm_subspace_model(satba_problem* p, const double* h, double* tmp, double reg, double jg_sq, LmModel& m) {
+    enum { GRAM_A = 1, GRAM_B = 2, GRAM_C = 3, WW = 1, B11 = 3, B12 = 4, B22 = 5, GHW = 6 };
+    const double ga = h[GRAM_A], gb = h[GRAM_B], gc = h[GRAM_C];
+    const double sa = std::sqrt(ga), alpha = gb / ga;
+    double ww = gc - gb * alpha, nw = 0.0, b11, b12, b22, ghw = 0.0;
+    bool one_dim = false;
+    if (ww > 1e-6 * gc) {
+        nw = std::sqrt(ww);
+        const double m11 = jg_sq, m12 = ga - reg * gb, m22 = gb - reg * gc;
+        b11 = m11 / ga;
+        b12 = (m12 - alpha * m11) / sa;
+        b22 = m22 - 2.0 * alpha * m12 + alpha * alpha * m11;
+    } else {
+        TRY(satba_subspace(p, alpha, 1.0 / sa));
+        TRY(satba_read_header(p, tmp));
+        ww = tmp[WW]; ghw = tmp[GHW];
+        if (!(ww > 1e-24 * gc && ww > 0)) {
+            one_dim = true;
+            b11 = jg_sq / ga; b12 = 0.0; b22 = 1.0; nw = 1.0; ww = 1.0; ghw = 0.0;
+        } else {
+            nw = std::sqrt(ww);
+            TRY(satba_subspace_products(p));
+            TRY(satba_read_header(p, tmp));
+            b11 = tmp[B11]; b12 = tmp[B12]; b22 = tmp[B22];
+        }
+    }
+    m.Ba = b11; m.Bb = one_dim ? 0.0 : b12 / nw; m.Bc = one_dim ? 1.0 : b22 / ww;
+    m.gS0 = sa; m.gS1 = one_dim ? 0.0 : ghw / nw;
+    m.sa = sa; m.alpha = alpha; m.nw = nw; m.one_dim = one_dim;
+    return 0;
+}
+
+// One fixed-work LM iteration of a single-rank handle, the host side in C++ (what bench.py's lm_step does in Python, phase by
+// phase): linearize -> prepare -> damped Gauss-Newton step -> 2-D trust-region subproblem -> trial point -> accept if the cost
+// went down.  first: first iteration (Jacobian scaling and trust radius are initialised); Delta: trust radius (ignored when
+// first).  out[8]: cost at x, cost at the trial point, new trust radius, accepted (0/1), interior Newton step (0/1), predicted and
+// actual reduction, damping.
+int satba_lm_step(satba_problem* p, int32_t first, double Delta, double lam_floor, double* out) {
+    if (!p || !out) return fail(SATBA_E_ARG, "null argument");
+    if (p->world != 1) return fail(SATBA_E_ARG, "satba_lm_step drives a single-rank handle (world = %d): use the phase entry points", p->world);
+    enum { COST_NEW = 1, K_COST = SATBA_HDR_KEEP, K_GINF, K_GH_SQ, K_JG_SQ, K_XS_SQ, K_LAM, K_DELTA };
+    std::vector<double> hbuf((size_t)p->hdr), tbuf((size_t)p->hdr);
+    double* h = hbuf.data();
+    TRY(satba_linearize(p));
+    TRY(satba_prepare(p, first ? 1 : 0));
+    TRY(satba_schur_auto(p, first ? -1.0 : Delta, lam_floor));
+    TRY(satba_solve(p));
+    TRY(satba_read_header(p, h));
+    const double cost = h[K_COST], reg = h[K_LAM], jg_sq = h[K_JG_SQ];
+    Delta = h[K_DELTA];
+    LmModel md;
+    TRY(lm_subspace_model(p, h, tbuf.data(), reg, jg_sq, md));
+    double p0, p1;
+    const bool newton = satba_lm::solve_trust_region_2d(md.Ba, md.Bb, md.Bc, md.gS0, md.gS1, Delta, p0, p1);
+    const double predicted = -(0.5 * (p0 * (md.Ba * p0 + md.Bb * p1) + p1 * (md.Bb * p0 + md.Bc * p1)) + md.gS0 * p0 + md.gS1 * p1);
+    const double ca = md.one_dim ? p0 / md.sa : p0 / md.sa - p1 * md.alpha / md.nw, cb = md.one_dim ? 0.0 : p1 / md.nw;
+    TRY(satba_trial_gn(p, ca, cb));
+    TRY(satba_read_header(p, tbuf.data()));
+    const double cost_new = tbuf[COST_NEW];
+    const double step_h_norm = std::hypot(p0, p1);
+    const double actual = std::isfinite(cost_new) ? cost - cost_new : -1.0;
+    double ratio;
+    const double Delta_new = satba_lm::update_tr_radius(Delta, actual, predicted, step_h_norm, step_h_norm > 0.95 * Delta, ratio);
+    if (actual > 0) TRY(satba_accept(p));
+    out[0] = cost; out[1] = cost_new; out[2] = Delta_new; out[3] = actual > 0 ? 1.0 : 0.0; out[4] = newton ? 1.0 : 0.0;
+    out[5] = predicted; out[6] = actual; out[7] = reg;
+    return 0;
+}
+
 int satba_solve_lm(satba_problem* p, const satba_lm_opts* o, satba_lm_stats* out) {
     if (!p || !o || !out) return fail(SATBA_E_ARG, "null argument");
     if (p->world != 1) return fail(SATBA_E_ARG, "satba_solve_lm drives a single-rank handle (world = %d): use the phase entry points", p->world);
@@ -1052,33 +1125,10 @@ int satba_solve_lm(satba_problem* p, const satba_lm_opts* o, satba_lm_stats* out
             TRY(satba_read_header(p, h));
         }
         if (attempt == 10) return fail(SATBA_E_STATE, "reduced camera system could not be factorised");
-        const double ga = h[GRAM_A], gb = h[GRAM_B], gc = h[GRAM_C];
-        // quadratic model on the orthonormal basis of span{g_h, gn_h} (satba/trf.py:subspace_model)
-        const double sa = std::sqrt(ga), alpha = gb / ga;
-        double ww = gc - gb * alpha, nw = 0.0, b11, b12, b22, ghw = 0.0;
-        bool one_dim = false;
-        if (ww > 1e-6 * gc) {
-            nw = std::sqrt(ww);
-            const double m11 = jg_sq, m12 = ga - reg * gb, m22 = gb - reg * gc;
-            b11 = m11 / ga;
-            b12 = (m12 - alpha * m11) / sa;
-            b22 = m22 - 2.0 * alpha * m12 + alpha * alpha * m11;
-        } else {
-            TRY(satba_subspace(p, alpha, 1.0 / sa));
-            TRY(satba_read_header(p, tbuf.data()));
-            ww = tbuf[WW]; ghw = tbuf[GHW];
-            if (!(ww > 1e-24 * gc && ww > 0)) {
-                one_dim = true;
-                b11 = jg_sq / ga; b12 = 0.0; b22 = 1.0; nw = 1.0; ww = 1.0; ghw = 0.0;
-            } else {
-                nw = std::sqrt(ww);
-                TRY(satba_subspace_products(p));
-                TRY(satba_read_header(p, tbuf.data()));
-                b11 = tbuf[B11]; b12 = tbuf[B12]; b22 = tbuf[B22];
-            }
-        }
-        const double Ba = b11, Bb = one_dim ? 0.0 : b12 / nw, Bc = one_dim ? 1.0 : b22 / ww;
-        const double gS0 = sa, gS1 = one_dim ? 0.0 : ghw / nw;
+        LmModel md;
+        TRY(lm_subspace_model(p, h, tbuf.data(), reg, jg_sq, md));
+        const double Ba = md.Ba, Bb = md.Bb, Bc = md.Bc, gS0 = md.gS0, gS1 = md.gS1, sa = md.sa, alpha = md.alpha, nw = md.nw;
+        const bool one_dim = md.one_dim;
 
         actual = -1.0;
         while (actual <= 0 && nfev < max_nfev) {

@@ -30,7 +30,7 @@ SYMBOLS = [
     "satba_accept", "satba_read_header", "satba_get_blocks", "satba_get_jacobian", "satba_get_exchange",
     "satba_set_exchange", "satba_get_vector", "satba_time_kernel",
     "satba_packed_schur_len", "satba_pack_schur", "satba_unpack_schur",
-    "satba_solve_lm", "satba_outliers", "satba_layout_len", "satba_get_layout", "satba_get_info",
+    "satba_solve_lm", "satba_lm_step", "satba_outliers", "satba_layout_len", "satba_get_layout", "satba_get_info",
 ]
 
 FLAG_DETERMINISTIC = 1
@@ -114,6 +114,7 @@ def load_library(path=None):
     lib.satba_get_vector.argtypes = [h, C.c_int32, _dp]
     lib.satba_time_kernel.argtypes = [h, C.c_int32, C.c_int32, C.POINTER(C.c_float)]
     lib.satba_solve_lm.argtypes = [h, C.POINTER(LmOpts), C.POINTER(LmStats)]
+    lib.satba_lm_step.argtypes = [h, C.c_int32, C.c_double, C.c_double, C.POINTER(C.c_double)]
     lib.satba_outliers.argtypes = [h, _dp, C.c_double, C.c_double, _dp, C.POINTER(C.c_uint8), C.POINTER(C.c_int64)]
     lib.satba_layout_len.argtypes = [h, C.c_int32]
     lib.satba_layout_len.restype = C.c_int64
@@ -296,6 +297,13 @@ class HipEngine:
         _check(self.lib, self.lib.satba_accept(self._h))
 
     # -- whole solve below the ABI (single rank)
+    def lm_step(self, first, Delta, lam_floor=0.0):
+        """satba_lm_step: one fixed-work LM iteration, host side in C++ (single rank).  Returns a dict of the eight scalars."""
+        out = np.zeros(8)
+        _check(self.lib, self.lib.satba_lm_step(self._h, 1 if first else 0, float(Delta), float(lam_floor), _ptr(out)))
+        keys = ["cost", "cost_new", "Delta", "accepted", "newton", "predicted", "actual", "lam"]
+        return dict(zip(keys, out))
+
     def solve_lm(self, ftol=1e-8, xtol=1e-8, gtol=1e-8, max_nfev=None, loss="linear", f_scale=1.0, verbose=0):
         """satba_solve_lm: the loop of satba/trf.py in C++; returns the LmStats structure."""
         if loss not in LOSSES:

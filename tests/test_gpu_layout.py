@@ -112,6 +112,32 @@ def test_solve_lm_matches_python_loop(gpu, name, loss, tight):
     assert np.abs(xa - xb).max() <= 1e-12 * np.abs(xa).max()
 
 
+def test_lm_step_matches_python_iteration(gpu):
+    """satba_lm_step (the iteration bench.py times) against the same iteration driven from Python phase by phase."""
+    import bench
+
+    _, make_p, _, _ = cases.solve_case("affine_small_R")
+    runs = []
+    for native in (False, True):
+        eng = HipEngine(make_p(), deterministic=True)  # bitwise-repeatable sums: both drivers see identical scalars
+        eng.configure("linear", 1.0)
+        st = {"first": True, "accepted": 0, "fail": 0, "cost": None}
+        trace = []
+        for _ in range(6):
+            if native:
+                bench.lm_step_native(eng, st)
+            else:
+                bench.lm_step(eng, trf.SingleComm(), st, trf)
+            trace.append((st["cost"], st["Delta"], st["accepted"], st.get("interior", 0)))
+        runs.append((trace, eng.get_x()))
+        eng.close()
+    (ta, xa), (tb, xb) = runs
+    for a, b in zip(ta, tb):
+        assert a[2:] == b[2:]
+        assert abs(a[0] - b[0]) <= 1e-13 * abs(a[0]) and abs(a[1] - b[1]) <= 1e-12 * abs(a[1])
+    assert np.abs(xa - xb).max() <= 1e-12 * np.abs(xa).max()
+
+
 def test_solve_lm_rejects_multi_rank_handles_and_bad_loss(gpu):
     from satba import sharding
 
