@@ -677,7 +677,7 @@ constexpr int CH_TRSV_FLAGS = 64;  // k_trsv_back_mw's flags (n <= 1024: the fac
 
 // Factorise A (n x n, column-major lower, in place) and solve A z = b in place.  *fail != 0 if A was not SPD.
 // flags: CH_MAX_STEPS ints of scratch directly behind *fail (flags == fail + 1); both are cleared here.
-// mode 0: double steps (k_chol_dstep, satba_chol2.h) while at least 64 columns remain, then single steps; 2: single steps
+// mode 0: double steps (k_chol_dstep, satba_chol2.h) while more than 32 columns remain, then one single step; 2: single steps
 // only (k_chol_step); 5: like 0 with the one-workgroup backward substitution (k_trsv_back_dinv)
 // dinv: (n / 32 rounded up) x 1024 doubles of scratch for the inverted diagonal blocks (n <= 1024), or null
 // ts (tools): CH_TS time stamps per launch
@@ -693,7 +693,7 @@ inline void cholesky_solve(double* A, int n, double* b, int* fail, int* flags, i
     int* fl = flags;
     auto tsk = [&] { return ts ? ts + CH_TS * step : nullptr; };
     if (mode == 0 || mode == 5) {
-        for (; n - k0 >= 2 * CH_NB; k0 += 2 * CH_NB, fl += 2, npend = 2, ++step) {
+        for (; n - k0 > CH_NB; k0 += 2 * CH_NB, fl += 2, npend = 2, ++step) {  // the last one may have a partial second panel
             const int T = (n - k0 + 63) / 64;
             hipLaunchKernelGGL(k_chol_dstep, dim3(T * (T + 1) / 2), dim3(256), chol_dstep_lds(), stream, A, n, npend, k0, fail, fl, b, tsk());
         }

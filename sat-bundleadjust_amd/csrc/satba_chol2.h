@@ -15,7 +15,8 @@
 //                    rest of the second diagonal block -- off the chain.
 //   tiles (i > 0, 0) wave 0 solves its 64 rows against D0 as soon as flag[0] is up while waves 1..3 fetch L21; all four waves
 //                    subtract X0 L21^T from the second half; wave 0 solves against D1 behind flag[1].
-// Tile (0, 0) is workgroup 0 of the 1-D grid and therefore resident before any waiter.  Requires n - k0 >= 64.
+// Tile (0, 0) is workgroup 0 of the 1-D grid and therefore resident before any waiter.  Requires n - k0 > 32 (the second panel
+// may be partial: the last launch of a matrix whose size is not a multiple of 64).
 //
 // Tried and dropped in round 2: per-micro-panel flags for D1 with the waiting tiles' solve staged behind them (the steps of the
 // first 24 columns before the block is complete, only an 8 x 8 fetch at the end): rows solved 0.8 us earlier by the stamps,
@@ -312,6 +313,9 @@ __global__ __launch_bounds__(256) void k_chol_dstep(double* __restrict__ A, int 
     if (bi == 0) {
         // ---------------------------------------------------------------- tile (0, 0): D0 + L21, A22 -= L21 L21^T, D1
         // lf: [0..3] micro-panels of D0, [4..7] of D1, [8] waves done with D0 (stores acknowledged), [9] the same for D1
+        // nb2 < 32: the matrix ends inside the second panel (then this is its last launch and its only tile): the missing rows and
+        // columns of D1 are padded with the identity, nothing is stored for them
+        const int nb2 = min(CH_NB, n - k0 - CH_NB);
         volatile int* vlf = lf;
         double a[CH_MP];
         {
@@ -325,7 +329,7 @@ __global__ __launch_bounds__(256) void k_chol_dstep(double* __restrict__ A, int 
             // published as it is formed: agent-scope stores (write through to the coherence point), then the flag -- no release
             // fence (a fence writes back the whole L2 of this XCD, ~2.5 us, while the other tiles are still storing)
             const bool bad = chol_diag_block4(a, wave, lane, pan, vlf, [&](int c, double v) {
-                if (lane >= CH_NB || c <= lane)
+                if (lane >= CH_NB ? lane < CH_NB + nb2 : c <= lane)
                     __hip_atomic_store(A + (size_t)(k0 + lane) + (size_t)(k0 + c) * n, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             });
             if (bad && lane == 0) atomicOr(fail, 1);
@@ -360,10 +364,13 @@ __global__ __launch_bounds__(256) void k_chol_dstep(double* __restrict__ A, int 
 #pragma unroll
             for (int jj = 0; jj < CH_MP; ++jj) {
                 const int c = CH_MP * wave + jj;
-                a[jj] = (lane < CH_NB && c <= lane) ? W[1][c][CH_NB + lane] : 0.0;  // no riders
+                double v = 0.0;  // no riders
+                if (lane < nb2 && c <= lane) v = W[1][c][CH_NB + lane];
+                else if (lane < CH_NB && c == lane) v = 1.0;  // identity padding
+                a[jj] = v;
             }
             const bool bad = chol_diag_block4(a, wave, lane, pan, vlf + 4, [&](int c, double v) {
-                if (lane < CH_NB && c <= lane)
+                if (lane < nb2 && c <= lane)
                     __hip_atomic_store(A + (size_t)(k0 + CH_NB + lane) + (size_t)(k0 + CH_NB + c) * n, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             });
             if (bad && lane == 0) atomicOr(fail, 1);
@@ -400,7 +407,7 @@ __global__ __launch_bounds__(256) void k_chol_dstep(double* __restrict__ A, int 
             while (vlf[9] < 4) __builtin_amdgcn_s_sleep(1);
             asm volatile("" ::: "memory");
             v = chol_fwd32((lane < CH_NB) ? bv : 0.0, Lb[1], lane);
-            if (lane < CH_NB) b[k0 + CH_NB + lane] = v;
+            if (lane < nb2) b[k0 + CH_NB + lane] = v;
         }
         return;
     }
