@@ -228,6 +228,13 @@ int satba_get_vector(satba_problem *p, int32_t which, double *host_out);
  *        3 dense Cholesky solve, 4 back-substitution, 5 the Jacobian-vector product of the prepare phase */
 int satba_time_kernel(satba_problem *p, int32_t phase, int32_t reps, float *ms_avg);
 
+/* ---- measurement inside a running solve: with on != 0 every satba_linearize brackets its k_linearize launch with two HIP
+ * events on the handle's stream (up to 4096 launches are kept); satba_profile_read waits for the stream, returns the number of
+ * bracketed launches and the sum of their durations in milliseconds since the last read, and clears the record.  bench.py's
+ * roofline figure is this average over the timed LM iterations. */
+int satba_profile_linearize(satba_problem *p, int32_t on);
+int satba_profile_read(satba_problem *p, int64_t *n_launches, double *ms_total);
+
 #ifdef __cplusplus
 }
 #endif

@@ -67,6 +67,9 @@ struct satba_problem {
     double *d_U = nullptr, *d_gc = nullptr, *d_V = nullptr, *d_Vinv = nullptr, *d_PV = nullptr, *d_dc = nullptr, *d_dch = nullptr;
     double2 *d_f = nullptr, *d_ftmp = nullptr;  // residual pairs of the current linearisation / of satba_residuals, ELL order
     bool f_valid = false;                       // d_f holds the residuals of the current linearisation
+    bool prof_lin = false;                      // satba_profile_linearize: event pairs around k_linearize
+    std::vector<hipEvent_t> prof_ev;            // start, stop, start, stop, ...
+    size_t prof_used = 0;
     double2* d_sc = nullptr;                  // Jacobian row scales of the current linearisation, io order
     double* d_Jpm = nullptr;                  // RPC: Jacobian blocks of the current linearisation, io order
     double *d_part = nullptr, *d_part3 = nullptr, *d_pair_part = nullptr;
@@ -275,7 +278,20 @@ static int raise_lin_limits(satba_problem* p) {
 
 static int launch_linearize_kernel(satba_problem* p) {
     ObsArgs a = obs_args(p, false);
+    const bool prof = p->prof_lin && p->prof_used + 2 <= 2 * 4096;
+    if (prof) {
+        while (p->prof_ev.size() < p->prof_used + 2) {
+            hipEvent_t e;
+            HIP_TRY(hipEventCreate(&e));
+            p->prof_ev.push_back(e);
+        }
+        HIP_TRY(hipEventRecord(p->prof_ev[p->prof_used], p->stream));
+    }
     SATBA_DISPATCH(p, TRY((launch_lin<MODEL, NP, CL, RL>(p, a))));
+    if (prof) {
+        HIP_TRY(hipEventRecord(p->prof_ev[p->prof_used + 1], p->stream));
+        p->prof_used += 2;
+    }
     return 0;
 }
 
@@ -722,6 +738,7 @@ void satba_problem_destroy(satba_problem* p) {
     (void)hipSetDevice(p->device);
     (void)hipDeviceSynchronize();
     for (void* q : p->allocs) (void)hipFree(q);
+    for (hipEvent_t e : p->prof_ev) (void)hipEventDestroy(e);
     if (p->h_pin) (void)hipHostFree(p->h_pin);
     delete p;
 }
@@ -1256,6 +1273,28 @@ int satba_debug_chol_times(satba_problem* p, long long* host_out, int32_t* n_ste
     HIP_TRY(hipMemcpy(host_out, d_ts, sizeof(long long) * CH_TS * CH_MAX_STEPS, hipMemcpyDeviceToHost));
     HIP_TRY(hipFree(d_ts));
     *n_steps = (p->n_c + CH_NB - 1) / CH_NB;
+    return 0;
+}
+
+int satba_profile_linearize(satba_problem* p, int32_t on) {
+    if (!p) return fail(SATBA_E_ARG, "null handle");
+    p->prof_lin = on != 0;
+    return 0;
+}
+
+int satba_profile_read(satba_problem* p, int64_t* n_launches, double* ms_total) {
+    if (!p || !n_launches || !ms_total) return fail(SATBA_E_ARG, "null argument");
+    HIP_TRY(hipSetDevice(p->device));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    double tot = 0.0;
+    for (size_t i = 0; i + 1 < p->prof_used; i += 2) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, p->prof_ev[i], p->prof_ev[i + 1]));
+        tot += ms;
+    }
+    *n_launches = (int64_t)(p->prof_used / 2);
+    *ms_total = tot;
+    p->prof_used = 0;
     return 0;
 }
 

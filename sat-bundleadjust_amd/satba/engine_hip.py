@@ -30,7 +30,7 @@ SYMBOLS = [
     "satba_accept", "satba_read_header", "satba_get_blocks", "satba_get_jacobian", "satba_get_exchange",
     "satba_set_exchange", "satba_get_vector", "satba_time_kernel",
     "satba_packed_schur_len", "satba_pack_schur", "satba_unpack_schur",
-    "satba_solve_lm", "satba_lm_step", "satba_outliers", "satba_layout_len", "satba_get_layout", "satba_get_info",
+    "satba_solve_lm", "satba_lm_step", "satba_profile_linearize", "satba_profile_read", "satba_outliers", "satba_layout_len", "satba_get_layout", "satba_get_info",
 ]
 
 FLAG_DETERMINISTIC = 1
@@ -115,6 +115,8 @@ def load_library(path=None):
     lib.satba_time_kernel.argtypes = [h, C.c_int32, C.c_int32, C.POINTER(C.c_float)]
     lib.satba_solve_lm.argtypes = [h, C.POINTER(LmOpts), C.POINTER(LmStats)]
     lib.satba_lm_step.argtypes = [h, C.c_int32, C.c_double, C.c_double, C.POINTER(C.c_double)]
+    lib.satba_profile_linearize.argtypes = [h, C.c_int32]
+    lib.satba_profile_read.argtypes = [h, C.POINTER(C.c_int64), C.POINTER(C.c_double)]
     lib.satba_outliers.argtypes = [h, _dp, C.c_double, C.c_double, _dp, C.POINTER(C.c_uint8), C.POINTER(C.c_int64)]
     lib.satba_layout_len.argtypes = [h, C.c_int32]
     lib.satba_layout_len.restype = C.c_int64
@@ -297,6 +299,16 @@ class HipEngine:
         _check(self.lib, self.lib.satba_accept(self._h))
 
     # -- whole solve below the ABI (single rank)
+    def profile_linearize(self, on=True):
+        """Bracket every k_linearize launch of the following linearize calls with HIP events (satba_profile_linearize)."""
+        _check(self.lib, self.lib.satba_profile_linearize(self._h, 1 if on else 0))
+
+    def profile_read(self):
+        """(number of bracketed launches, sum of their durations in ms) since the last read."""
+        n, ms = C.c_int64(), C.c_double()
+        _check(self.lib, self.lib.satba_profile_read(self._h, C.byref(n), C.byref(ms)))
+        return n.value, ms.value
+
     def lm_step(self, first, Delta, lam_floor=0.0):
         """satba_lm_step: one fixed-work LM iteration, host side in C++ (single rank).  Returns a dict of the eight scalars."""
         out = np.zeros(8)
