@@ -281,10 +281,11 @@ def test_schur_matrix_and_rhs(gpu, monkeypatch, chunks):
 
 # n_c = 9, 65, 300, 1000, 900; 192 (double steps only), 96 (one double step + one full single step with two pending
 # panels), 129 (double steps + a one-column partial step), 66 (one double step + a two-column partial step)
-# 130, 162: double steps + a full single step with two pending panels + a two-column partial step
+# 130, 162: double steps, the last with a partial second panel; 1300: more than 1024 unknowns (one-workgroup left-looking
+# backward substitution, k_trsv_back)
 # mode (SATBA_CHOL): 0 two panels per launch where they fit (default), 2 single steps, 5 like 0 with the one-workgroup back-substitution
 @pytest.mark.parametrize("mode", ["0", "2", "5"])
-@pytest.mark.parametrize("n_cam,n_p", [(3, 3), (13, 5), (60, 5), (200, 5), (150, 6), (64, 3), (32, 3), (43, 3), (11, 6), (26, 5), (54, 3)])
+@pytest.mark.parametrize("n_cam,n_p", [(3, 3), (13, 5), (60, 5), (200, 5), (150, 6), (64, 3), (32, 3), (43, 3), (11, 6), (26, 5), (54, 3), (260, 5)])
 def test_dense_cholesky_solve(gpu, monkeypatch, n_cam, n_p, mode):
     """The reduced-system solver alone: plant a random SPD system in the exchange payload and solve it."""
     monkeypatch.setenv("SATBA_CHOL", mode)  # read when the problem handle is created
