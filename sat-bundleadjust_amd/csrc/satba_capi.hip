@@ -210,10 +210,29 @@ static int launch_residual(satba_problem* p, bool at_new, double2* f, double* co
     ObsArgs a = obs_args(p, at_new);
     const int grid = slice_grid(p, RES_THREADS / 64, 2);
     const size_t lds = table_bytes(p);
+    const TrialArgs t{};
     if (p->loss == 0 && p->unit_weights)
-        SATBA_DISPATCH(p, hipLaunchKernelGGL((k_residual<MODEL, NP, CL, RL, true>), dim3(grid), dim3(RES_THREADS), lds, p->stream, a, f, p->red(RB_RES), cost));
+        SATBA_DISPATCH(p, hipLaunchKernelGGL((k_residual<MODEL, NP, CL, RL, true, false>), dim3(grid), dim3(RES_THREADS), lds, p->stream, a, f, p->red(RB_RES), cost, t));
     else
-        SATBA_DISPATCH(p, hipLaunchKernelGGL((k_residual<MODEL, NP, CL, RL, false>), dim3(grid), dim3(RES_THREADS), lds, p->stream, a, f, p->red(RB_RES), cost));
+        SATBA_DISPATCH(p, hipLaunchKernelGGL((k_residual<MODEL, NP, CL, RL, false, false>), dim3(grid), dim3(RES_THREADS), lds, p->stream, a, f, p->red(RB_RES), cost, t));
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// trial point + cost there + |step|^2, |x|^2 in one pass over the observations (k_residual<..., TRIAL>)
+static int launch_trial(satba_problem* p, double c0, double c1, const double* v0, const double* v1) {
+    hipLaunchKernelGGL(k_trial_cams, dim3((p->M + 63) / 64), dim3(64), 0, p->stream, p->model, p->M, p->NP, p->c_p, p->d_x, v0, v1, p->d_scale_inv, c0, c1,
+                       p->d_cam_static, p->d_xnew, p->d_camc_new);
+    HIP_TRY(hipGetLastError());
+    ObsArgs a = obs_args(p, true);
+    const int grid = slice_grid(p, RES_THREADS / 64, 2);
+    const size_t lds = table_bytes(p);
+    const TrialArgs t{p->d_x, v0, v1, p->d_scale_inv, p->d_xnew, c0, c1, p->lead, p->d_xb + 2, p->d_xb + 3};
+    double* cost = p->d_xb + 1;
+    if (p->loss == 0 && p->unit_weights)
+        SATBA_DISPATCH(p, hipLaunchKernelGGL((k_residual<MODEL, NP, CL, RL, true, true>), dim3(grid), dim3(RES_THREADS), lds, p->stream, a, (double2*)nullptr, p->red(RB_RES), cost, t));
+    else
+        SATBA_DISPATCH(p, hipLaunchKernelGGL((k_residual<MODEL, NP, CL, RL, false, true>), dim3(grid), dim3(RES_THREADS), lds, p->stream, a, (double2*)nullptr, p->red(RB_RES), cost, t));
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -266,8 +285,10 @@ static int raise_lin_limits(satba_problem* p) {
         TRY(raise_lds_limit(k_linearize<MODEL, NP, true, CL, RL, true, false, true>, lds));
         TRY(raise_lds_limit(k_linearize<MODEL, NP, true, CL, RL, true, false, false>, lds));
     }
-    TRY(raise_lds_limit(k_residual<MODEL, NP, CL, RL, true>, table_bytes(p)));
-    TRY(raise_lds_limit(k_residual<MODEL, NP, CL, RL, false>, table_bytes(p)));
+    TRY(raise_lds_limit(k_residual<MODEL, NP, CL, RL, true, false>, table_bytes(p)));
+    TRY(raise_lds_limit(k_residual<MODEL, NP, CL, RL, false, false>, table_bytes(p)));
+    TRY(raise_lds_limit(k_residual<MODEL, NP, CL, RL, true, true>, table_bytes(p)));
+    TRY(raise_lds_limit(k_residual<MODEL, NP, CL, RL, false, true>, table_bytes(p)));
     const size_t t = std::max(table_bytes(p), dir_table_bytes(p));
     TRY(raise_lds_limit(k_jvp<MODEL, NP, 1, CL, RL, true>, t));
     TRY(raise_lds_limit(k_jvp<MODEL, NP, 1, CL, RL, false>, t));
@@ -984,11 +1005,7 @@ int satba_subspace_products(satba_problem* p) {
 
 static int trial_impl(satba_problem* p, double c0, double c1, const double* v0, const double* v1) {
     TRY(zero_header(p));
-    hipLaunchKernelGGL(k_trial_vec, dim3(grid_for(p->n, 256, 512)), dim3(256), 0, p->stream, p->n, p->n_c, p->lead, c0, c1,
-                       p->d_x, v0, v1, p->d_scale_inv, p->d_xnew, p->red(RB_TRIAL), p->d_xb);
-    HIP_TRY(hipGetLastError());
-    TRY(launch_cam_consts(p, true));
-    TRY(launch_residual(p, true, nullptr, p->d_xb + 1));
+    TRY(launch_trial(p, c0, c1, v0, v1));
     return 0;
 }
 

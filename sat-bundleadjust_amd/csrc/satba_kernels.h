@@ -296,6 +296,23 @@ __global__ void k_cam_consts(int model, int M, int n_p, int c_p, const double* _
     cam_constants(model, full, camc + (size_t)c * CAMC);
 }
 
+// trial point of the cameras, x_new = x + (c0 v0 + c1 v1) / scale_inv on their n_p entries, and the camera constants at x_new
+__global__ void k_trial_cams(int model, int M, int n_p, int c_p, const double* __restrict__ x, const double* __restrict__ v0,
+                             const double* __restrict__ v1, const double* __restrict__ scale_inv, double c0, double c1,
+                             const double* __restrict__ cam_static, double* __restrict__ x_new, double* __restrict__ camc_new) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= M) return;
+    double full[11];
+    for (int i = 0; i < c_p; ++i) full[i] = cam_static[(size_t)c * c_p + i];
+    for (int i = 0; i < n_p; ++i) {
+        const size_t k = (size_t)c * n_p + i;
+        const double v = x[k] + (c0 * v0[k] + c1 * v1[k]) / scale_inv[k];
+        x_new[k] = v;
+        full[i] = v;
+    }
+    cam_constants(model, full, camc_new + (size_t)c * CAMC);
+}
+
 // ------------------------------------------------------------------------------------------------ point permutation
 // caller order <-> internal order of the point part of a variable vector (cameras are copied): dir 0: out[internal] = in[caller]
 __global__ void k_permute_vec(int n_c, int N, int dim, const int* __restrict__ perm, const double* __restrict__ in,
@@ -319,21 +336,55 @@ __global__ void k_gather_obs(long long K, const int* __restrict__ obs_pos, const
 // ba_core.fun (ref:bundle_adjust/ba_core.py:157-183).  *cost = 0.5 * sum rho.  f (ELL order) may be null (cost only).
 // UNITW: every weight is 1 and the loss is linear (the weight array is not read: 8 of 28 streamed bytes per observation)
 constexpr int RES_THREADS = 512;
-template <int MODEL, int NP, bool CL, bool RL, bool UNITW = false>
-__global__ __launch_bounds__(RES_THREADS) void k_residual(ObsArgs a, double2* __restrict__ f, RedBuf rb, double* __restrict__ cost) {
+// TRIAL: the kernel forms the trial point itself -- x_new = x + (c0 v0 + c1 v1) / scale_inv for the points (the camera entries and
+// the camera constants at x_new come from k_trial_cams, launched in front) -- and returns |step|^2 and |x|^2 beside the cost: a
+// separate vector kernel moved 120 MB for this at 1 M points (27 us) and cost a launch.  a.x is not read then.
+struct TrialArgs {
+    const double* __restrict__ x;          // current variables
+    const double* __restrict__ v0;         // two direction vectors in scaled variables ...
+    const double* __restrict__ v1;
+    const double* __restrict__ scale_inv;
+    double* __restrict__ x_new;            // the trial point (camera entries already written)
+    double c0, c1, lead;                   // ... and their coefficients; weight of the camera entries in the sums (rank 0 only)
+    double* ss;                            // |step|^2 and |x|^2 (scaled variables are not involved: plain sums of squares)
+    double* xx;
+};
+template <int MODEL, int NP, bool CL, bool RL, bool UNITW = false, bool TRIAL = false>
+__global__ __launch_bounds__(RES_THREADS) void k_residual(ObsArgs a, double2* __restrict__ f, RedBuf rb, double* __restrict__ cost, TrialArgs t) {
     extern __shared__ double s_dyn_res[];
     CamTables<CL, RL> T;
     T.stage(a, s_dyn_res, RES_THREADS);
     const int lane = threadIdx.x & 63;
     constexpr int WAVES = RES_THREADS / 64;
-    double acc = 0.0;
+    double acc = 0.0, ss = 0.0, xx = 0.0;
+    if (TRIAL && blockIdx.x == 0) {  // the camera entries of the two sums (x_new of the cameras is k_trial_cams' work)
+        for (int i = threadIdx.x; i < a.n_c; i += RES_THREADS) {
+            const double step = (t.c0 * t.v0[i] + t.c1 * t.v1[i]) / t.scale_inv[i], xi = t.x[i];
+            ss += t.lead * step * step; xx += t.lead * xi * xi;
+        }
+    }
     for_each_slice(a.n_slices, WAVES, [&](const int gu) {
         const int base = a.slice_base[gu], len = (a.slice_base[gu + 1] - base) >> 6;
         const int q = gu * 64 + lane;
         const bool has = q < a.N;
         const int cnt = has ? a.pt_cnt[q] : 0;
         double X = 0.0, Y = 0.0, Z = 0.0;
-        if (has) { const double* px = a.x + a.n_c + 3 * (size_t)q; X = px[0]; Y = px[1]; Z = px[2]; }
+        if (has) {
+            const size_t ip = (size_t)a.n_c + 3 * (size_t)q;
+            if constexpr (TRIAL) {
+                double xn[3];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const double step = (t.c0 * t.v0[ip + k] + t.c1 * t.v1[ip + k]) / t.scale_inv[ip + k], xi = t.x[ip + k];
+                    xn[k] = xi + step;
+                    t.x_new[ip + k] = xn[k];
+                    ss += step * step; xx += xi * xi;
+                }
+                X = xn[0]; Y = xn[1]; Z = xn[2];
+            } else {
+                const double* px = a.x + ip; X = px[0]; Y = px[1]; Z = px[2];
+            }
+        }
         int pos = base + lane;
         // software pipeline: the records of the next two slots are in flight during the arithmetic of the current one
         ObsRec r[SATBA_PF + 1];
@@ -352,9 +403,15 @@ __global__ __launch_bounds__(RES_THREADS) void k_residual(ObsArgs a, double2* __
             for (int j = 0; j < SATBA_PF; ++j) r[j] = r[j + 1];
         }
     });
-    double v[1] = {0.5 * acc};
-    double* const dst[1] = {cost};
-    grid_sum<1>(v, dst, rb);
+    if constexpr (TRIAL) {
+        double v[3] = {0.5 * acc, ss, xx};
+        double* const dst[3] = {cost, t.ss, t.xx};
+        grid_sum<3>(v, dst, rb);
+    } else {
+        double v[1] = {0.5 * acc};
+        double* const dst[1] = {cost};
+        grid_sum<1>(v, dst, rb);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ K2 linearize
@@ -965,24 +1022,6 @@ __global__ __launch_bounds__(256) void k_subspace_vec(int n, int n_c, double lea
     double v[3] = {ww, wq, gw};
     double* const dst[3] = {hdr + 1, hdr + 2, hdr + 6};
     grid_sum<3>(v, dst, rb);
-}
-
-// x_new = x + (p0 q1 + p1 w) / scale_inv;  hdr[2] = |step|^2, hdr[3] = |x|^2
-__global__ __launch_bounds__(256) void k_trial_vec(int n, int n_c, double lead, double p0, double p1,
-                                                   const double* __restrict__ x, const double* __restrict__ q1,
-                                                   const double* __restrict__ wv, const double* __restrict__ scale_inv,
-                                                   double* __restrict__ x_new, RedBuf rb, double* __restrict__ hdr) {
-    double ss = 0.0, xx = 0.0;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const double step = (p0 * q1[i] + p1 * wv[i]) / scale_inv[i];
-        const double xi = x[i];
-        x_new[i] = xi + step;
-        const double wgt = (i < n_c) ? lead : 1.0;
-        ss += wgt * step * step; xx += wgt * xi * xi;
-    }
-    double v[2] = {ss, xx};
-    double* const dst[2] = {hdr + 2, hdr + 3};
-    grid_sum<2>(v, dst, rb);
 }
 
 // ------------------------------------------------------------------------------------------------ inspection
