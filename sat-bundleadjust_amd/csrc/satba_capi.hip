@@ -162,6 +162,7 @@ static ObsArgs obs_args(const satba_problem* p, bool at_new) {
     a.f_scale = p->f_scale;
     a.unit = (p->loss == 0 && p->unit_weights) ? 1 : 0;
     a.rep_shift = p->lin_rep_shift;
+    a.sh = 0;  // lanes per point: set by the launchers of the kernels that support it
     return a;
 }
 static CamMajor cam_major(const satba_problem* p) { return CamMajor{p->L.cam_ofs, p->L.cm_pt, p->L.cm_pos, p->L.cm_io}; }
@@ -201,14 +202,23 @@ static int zero_header(satba_problem* p) {
 
 // grid of the thread-per-point kernels: `per_cu` workgroups per CU, all resident from the start (a later round of workgroups
 // would run its slices alone at the end), every wave walking several slices (for_each_slice balances short and long tracks)
-static int slice_grid(const satba_problem* p, int waves_per_block, int per_cu) {
+// log2 of the lanes per point of the slice kernels (SliceUnit): as many as it takes to give the chip ~8 waves per SIMD
+static int slice_split(const satba_problem* p) {
+    static const int env = getenv("SATBA_SPLIT") ? atoi(getenv("SATBA_SPLIT")) : -1;  // experiments: log2
+    if (env >= 0) return std::min(env, 3);
+    int sh = 0;
+    while (sh < 3 && ((long long)p->L.n_slices << sh) < 3000) ++sh;  // measured: 2 lanes per point at 100 k points, 8 at 5 k
+    return sh;
+}
+static int slice_grid(const satba_problem* p, int waves_per_block, int per_cu, int sh = 0) {
     static const int env = getenv("SATBA_BPC") ? atoi(getenv("SATBA_BPC")) : 0;
-    return grid_for(p->L.n_slices, waves_per_block, 256 * (env > 0 ? env : per_cu));
+    return grid_for((long long)p->L.n_slices << sh, waves_per_block, 256 * (env > 0 ? env : per_cu));
 }
 
 static int launch_residual(satba_problem* p, bool at_new, double2* f, double* cost) {
     ObsArgs a = obs_args(p, at_new);
-    const int grid = slice_grid(p, RES_THREADS / 64, 2);
+    a.sh = slice_split(p);
+    const int grid = slice_grid(p, RES_THREADS / 64, 2, a.sh);
     const size_t lds = table_bytes(p);
     const TrialArgs t{};
     if (p->loss == 0 && p->unit_weights)
@@ -225,7 +235,8 @@ static int launch_trial(satba_problem* p, double c0, double c1, const double* v0
                        p->d_cam_static, p->d_xnew, p->d_camc_new);
     HIP_TRY(hipGetLastError());
     ObsArgs a = obs_args(p, true);
-    const int grid = slice_grid(p, RES_THREADS / 64, 2);
+    a.sh = slice_split(p);
+    const int grid = slice_grid(p, RES_THREADS / 64, 2, a.sh);
     const size_t lds = table_bytes(p);
     const TrialArgs t{p->d_x, v0, v1, p->d_scale_inv, p->d_xnew, c0, c1, p->lead, p->d_xb + 2, p->d_xb + 3};
     double* cost = p->d_xb + 1;
@@ -299,6 +310,7 @@ static int raise_lin_limits(satba_problem* p) {
 
 static int launch_linearize_kernel(satba_problem* p) {
     ObsArgs a = obs_args(p, false);
+    a.sh = slice_split(p);
     const bool prof = p->prof_lin && p->prof_used + 2 <= 2 * 4096;
     if (prof) {
         while (p->prof_ev.size() < p->prof_used + 2) {
@@ -718,7 +730,7 @@ int satba_problem_create(const satba_problem_desc* d, satba_problem** out) {
         TRY(dev_alloc(p, &p->d_red_cnt, RED_SLOTS));
         HIP_TRY(hipMemset(p->d_red_cnt, 0, sizeof(unsigned) * RED_SLOTS));
         // one workgroup per CU for the linearize kernel (its LDS table is flushed once per workgroup)
-        p->lin_grid = grid_for(p->L.n_slices, LinCfg<false>::WAVES, 256 * (1024 / LinCfg<false>::THREADS));
+        p->lin_grid = grid_for((long long)p->L.n_slices << slice_split(p), LinCfg<false>::WAVES, 256 * (1024 / LinCfg<false>::THREADS));
         TRY(dev_alloc(p, &p->d_part, (size_t)512 * p->M * 2 * p->NP));
         {   // chunking of the camera-major passes (k_schur_diag, k_cam_sums)
             int chunks = (2048 + p->M - 1) / p->M;

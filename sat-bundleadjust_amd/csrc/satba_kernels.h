@@ -52,6 +52,7 @@ struct ObsArgs {
     int P, n_slices, M, N, n_c, n_cam_fix, n_pts_fix, loss, f32;
     int unit;                            // every weight is 1 and the loss is linear
     int rep_shift;                       // log2 of the number of replicas of k_linearize's LDS camera table (few cameras)
+    int sh;                              // log2 of the lanes per point (slice_unit): 0 for large problems
     double f_scale;
 };
 
@@ -285,6 +286,33 @@ __device__ inline void for_each_slice(int n_slices, int waves_per_block, F&& bod
     }
 }
 
+// Lanes per point.  With lane = point a problem of 100 k points is 1 563 waves for 1 024 SIMDs, each with a serial chain of
+// (track length) dependent evaluations: the small shapes ran at well under one wave per SIMD.  A slice (64 points) can therefore
+// be processed by 2^sh "units" (waves): unit `sub` of slice gu takes the points 64 gu + sub (64 >> sh) .. and gives every point
+// 2^sh neighbouring lanes; lane g of a point takes the slots g, g + 2^sh, ...  Per-point sums are combined with xor-shuffles
+// (slice_point_sum) and per-point outputs written by the lane with g == 0.  sh = 0 is the plain lane = point walk.
+struct SliceUnit {
+    int gu, base, len, nt, q, g, pos, step, sh;
+    __device__ inline SliceUnit(const ObsArgs& a, int u, int lane) {
+        sh = a.sh;
+        gu = u >> sh;
+        const int sub = u & ((1 << sh) - 1);
+        base = a.slice_base[gu];
+        len = (a.slice_base[gu + 1] - base) >> 6;     // slots of the slice
+        nt = (len + (1 << sh) - 1) >> sh;              // iterations of a lane
+        g = lane & ((1 << sh) - 1);
+        const int ql = sub * (64 >> sh) + (lane >> sh);  // point within the slice
+        q = gu * 64 + ql;
+        pos = base + 64 * g + ql;                      // ELL position of slot g
+        step = 64 << sh;
+    }
+    __device__ inline int slot(int t) const { return (t << sh) + g; }
+};
+__device__ inline double slice_point_sum(double v, int sh) {
+    for (int m = 1; m < (1 << sh); m <<= 1) v += __shfl_xor(v, m);
+    return v;
+}
+
 // ------------------------------------------------------------------------------------------------ camera constants
 __global__ void k_cam_consts(int model, int M, int n_p, int c_p, const double* __restrict__ x,
                              const double* __restrict__ cam_static, double* __restrict__ camc) {
@@ -363,9 +391,9 @@ __global__ __launch_bounds__(RES_THREADS) void k_residual(ObsArgs a, double2* __
             ss += t.lead * step * step; xx += t.lead * xi * xi;
         }
     }
-    for_each_slice(a.n_slices, WAVES, [&](const int gu) {
-        const int base = a.slice_base[gu], len = (a.slice_base[gu + 1] - base) >> 6;
-        const int q = gu * 64 + lane;
+    for_each_slice(a.n_slices << a.sh, WAVES, [&](const int u) {
+        const SliceUnit su(a, u, lane);
+        const int q = su.q;
         const bool has = q < a.N;
         const int cnt = has ? a.pt_cnt[q] : 0;
         double X = 0.0, Y = 0.0, Z = 0.0;
@@ -377,21 +405,21 @@ __global__ __launch_bounds__(RES_THREADS) void k_residual(ObsArgs a, double2* __
                 for (int k = 0; k < 3; ++k) {
                     const double step = (t.c0 * t.v0[ip + k] + t.c1 * t.v1[ip + k]) / t.scale_inv[ip + k], xi = t.x[ip + k];
                     xn[k] = xi + step;
-                    t.x_new[ip + k] = xn[k];
-                    ss += step * step; xx += xi * xi;
+                    if (su.g == 0) { t.x_new[ip + k] = xn[k]; ss += step * step; xx += xi * xi; }
                 }
                 X = xn[0]; Y = xn[1]; Z = xn[2];
             } else {
                 const double* px = a.x + ip; X = px[0]; Y = px[1]; Z = px[2];
             }
         }
-        int pos = base + lane;
+        int pos = su.pos;
         // software pipeline: the records of the next two slots are in flight during the arithmetic of the current one
         ObsRec r[SATBA_PF + 1];
 #pragma unroll
-        for (int j = 0; j < SATBA_PF; ++j) r[j].load<UNITW>(a, pos + 64 * j, j < cnt);
-        for (int k = 0; k < len; ++k, pos += 64) {
-            r[SATBA_PF].load<UNITW>(a, pos + 64 * SATBA_PF, k + SATBA_PF < cnt);
+        for (int j = 0; j < SATBA_PF; ++j) r[j].load<UNITW>(a, pos + su.step * j, su.slot(j) < cnt);
+        for (int tt = 0; tt < su.nt; ++tt, pos += su.step) {
+            const int k = su.slot(tt);
+            r[SATBA_PF].load<UNITW>(a, pos + su.step * SATBA_PF, su.slot(tt + SATBA_PF) < cnt);
             __builtin_amdgcn_sched_barrier(0);
             if (k < cnt) {
                 ObsEval<MODEL, NP, false, !UNITW, false, UNITW> e;
@@ -467,9 +495,9 @@ __global__ __launch_bounds__(LinCfg<(ROBUST && !SOFT) || MODEL == RPC>::THREADS)
     const bool const_t = lin_const_t(MODEL, NP, ROBUST, a.unit != 0);
 
     double cost = 0.0, gmax = 0.0;
-    for_each_slice(a.n_slices, WAVES, [&](const int gu) {
-        const int base = a.slice_base[gu], len = (a.slice_base[gu + 1] - base) >> 6;
-        const int q = gu * 64 + lane;
+    for_each_slice(a.n_slices << a.sh, WAVES, [&](const int u) {
+        const SliceUnit su(a, u, lane);
+        const int q = su.q;
         const bool has = q < a.N;
         const int cnt = has ? a.pt_cnt[q] : 0;
         double X = 0.0, Y = 0.0, Z = 0.0, mp = 0.0;
@@ -479,14 +507,15 @@ __global__ __launch_bounds__(LinCfg<(ROBUST && !SOFT) || MODEL == RPC>::THREADS)
             mp = (a.perm[q] >= a.n_pts_fix) ? 1.0 : 0.0;
         }
         double v[9] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-        int pos = base + lane;
+        int pos = su.pos;
         const int io0 = has ? a.ipt_ofs[q] : 0;
         // software pipeline: the records of the next two slots are in flight during the arithmetic and the LDS atomics of this one
         ObsRec r[SATBA_PF + 1];
 #pragma unroll
-        for (int j = 0; j < SATBA_PF; ++j) r[j].load<UNITW>(a, pos + 64 * j, j < cnt);
-        for (int k = 0; k < len; ++k, pos += 64) {
-            r[SATBA_PF].load<UNITW>(a, pos + 64 * SATBA_PF, k + SATBA_PF < cnt);
+        for (int j = 0; j < SATBA_PF; ++j) r[j].load<UNITW>(a, pos + su.step * j, su.slot(j) < cnt);
+        for (int tt = 0; tt < su.nt; ++tt, pos += su.step) {
+            const int k = su.slot(tt);
+            r[SATBA_PF].load<UNITW>(a, pos + su.step * SATBA_PF, su.slot(tt + SATBA_PF) < cnt);
             __builtin_amdgcn_sched_barrier(0);
             if (k < cnt) {
                 const int cam = r[0].cam;
@@ -518,7 +547,11 @@ __global__ __launch_bounds__(LinCfg<(ROBUST && !SOFT) || MODEL == RPC>::THREADS)
 #pragma unroll
             for (int j = 0; j < SATBA_PF; ++j) r[j] = r[j + 1];
         }
-        if (has) {
+        if (su.sh) {  // several lanes per point: their sums are combined, the lane of slot 0 stores
+#pragma unroll
+            for (int k = 0; k < 9; ++k) v[k] = slice_point_sum(v[k], su.sh);
+        }
+        if (has && su.g == 0) {
             if constexpr (UNITW) {  // fixed points: their blocks are masked here
 #pragma unroll
                 for (int k = 0; k < 9; ++k) v[k] *= mp;
