@@ -206,6 +206,7 @@ static int zero_header(satba_problem* p) {
 static int slice_split(const satba_problem* p) {
     static const int env = getenv("SATBA_SPLIT") ? atoi(getenv("SATBA_SPLIT")) : -1;  // experiments: log2
     if (env >= 0) return std::min(env, 3);
+    if (p->deterministic) return 0;  // the repeatability option keeps the summation order of the plain walk (goldens were made with it)
     int sh = 0;
     while (sh < 3 && ((long long)p->L.n_slices << sh) < 3000) ++sh;  // measured: 2 lanes per point at 100 k points, 8 at 5 k
     return sh;
@@ -384,7 +385,8 @@ static int launch_schur_kernel(satba_problem* p) {
 
 static int launch_backsub_kernel(satba_problem* p) {
     ObsArgs a = obs_args(p, false);
-    const int grid = slice_grid(p, BS_THREADS / 64, 2);
+    a.sh = slice_split(p);
+    const int grid = slice_grid(p, BS_THREADS / 64, 2, a.sh);
     const size_t lds = p->model == AFFINE ? dir_table_bytes(p) : table_bytes(p);
     SATBA_DISPATCH(p, hipLaunchKernelGGL((k_backsub<MODEL, NP, CL, RL>), dim3(grid), dim3(BS_THREADS), lds, p->stream, a, p->d_dc, p->d_dch, p->lead,
                                          p->d_Vinv, p->d_g, p->d_scale_inv, p->d_gh, p->d_gn, p->red(RB_BS), p->d_xb));
@@ -395,7 +397,8 @@ static int launch_backsub_kernel(satba_problem* p) {
 // pre: q1 is already in unscaled variables (nv == 1 only)
 static int launch_jvp(satba_problem* p, int nv, const double* q1, const double* q2, double* out, bool pre = false) {
     ObsArgs a = obs_args(p, false);
-    const int grid = slice_grid(p, JVP_THREADS / 64, 2);
+    a.sh = slice_split(p);
+    const int grid = slice_grid(p, JVP_THREADS / 64, 2, a.sh);
     const RedBuf rb = p->red(RB_JVP);
     if (nv == 1 && pre) {
         const size_t lds = p->model == AFFINE ? dir_table_bytes(p) : table_bytes(p);

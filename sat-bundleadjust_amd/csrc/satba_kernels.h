@@ -791,9 +791,9 @@ __global__ __launch_bounds__(JVP_THREADS) void k_jvp(ObsArgs a, const double* __
     if constexpr (MODEL == AFFINE && PRE && NV == 1) {
         double* tab = s_dyn_jvp;  // M x JVP_ROW
         affine_dir_table<NP>(a, q1, tab, JVP_THREADS);
-        for_each_slice(a.n_slices, WAVES, [&](const int gu) {
-            const int base = a.slice_base[gu], len = (a.slice_base[gu + 1] - base) >> 6;
-            const int q = gu * 64 + lane;
+        for_each_slice(a.n_slices << a.sh, WAVES, [&](const int u) {
+            const SliceUnit su(a, u, lane);
+            const int q = su.q;
             const bool has = q < a.N;
             const int cnt = has ? a.pt_cnt[q] : 0;
             double X = 0.0, Y = 0.0, Z = 0.0, v0 = 0.0, v1 = 0.0, v2 = 0.0;
@@ -803,15 +803,17 @@ __global__ __launch_bounds__(JVP_THREADS) void k_jvp(ObsArgs a, const double* __
                 const double mp = (a.perm[q] >= a.n_pts_fix) ? 1.0 : 0.0;
                 v0 = mp * q1[ip]; v1 = mp * q1[ip + 1]; v2 = mp * q1[ip + 2];
             }
-            int pos = base + lane;
+            int pos = su.pos;
             const int io0 = has ? a.ipt_ofs[q] : 0;
             // cameras (and row scales) of the next two slots in flight
-            int c0 = (0 < cnt) ? a.e_cam[pos] : 0, c1 = (1 < cnt) ? a.e_cam[pos + 64] : 0;
-            double2 s0 = (0 < cnt && a.sc) ? a.sc[io0] : make_double2(1.0, 1.0), s1 = (1 < cnt && a.sc) ? a.sc[io0 + 1] : make_double2(1.0, 1.0);
-            for (int k = 0; k < len; ++k, pos += 64) {
+            const int k1 = su.slot(1);
+            int c0 = (su.g < cnt) ? a.e_cam[pos] : 0, c1 = (k1 < cnt) ? a.e_cam[pos + su.step] : 0;
+            double2 s0 = (su.g < cnt && a.sc) ? a.sc[io0 + su.g] : make_double2(1.0, 1.0), s1 = (k1 < cnt && a.sc) ? a.sc[io0 + k1] : make_double2(1.0, 1.0);
+            for (int tt = 0; tt < su.nt; ++tt, pos += su.step) {
+                const int k = su.slot(tt), k2 = su.slot(tt + 2);
                 int c2 = 0;
                 double2 s2 = make_double2(1.0, 1.0);
-                if (k + 2 < cnt) { c2 = a.e_cam[pos + 128]; if (a.sc) s2 = a.sc[io0 + k + 2]; }
+                if (k2 < cnt) { c2 = a.e_cam[pos + 2 * su.step]; if (a.sc) s2 = a.sc[io0 + k2]; }
                 __builtin_amdgcn_sched_barrier(0);
                 if (k < cnt) {
                     const double* row = tab + (size_t)c0 * JVP_ROW;
@@ -825,9 +827,9 @@ __global__ __launch_bounds__(JVP_THREADS) void k_jvp(ObsArgs a, const double* __
     } else {
         CamTables<CL, RL> T;
         T.stage(a, s_dyn_jvp, JVP_THREADS);
-        for_each_slice(a.n_slices, WAVES, [&](const int gu) {
-            const int base = a.slice_base[gu], len = (a.slice_base[gu + 1] - base) >> 6;
-            const int q = gu * 64 + lane;
+        for_each_slice(a.n_slices << a.sh, WAVES, [&](const int u) {
+            const SliceUnit su(a, u, lane);
+            const int q = su.q;
             const bool has = q < a.N;
             const int cnt = has ? a.pt_cnt[q] : 0;
             double X = 0.0, Y = 0.0, Z = 0.0, mp = 0.0, p1[3] = {0, 0, 0}, p2[3] = {0, 0, 0};
@@ -845,9 +847,10 @@ __global__ __launch_bounds__(JVP_THREADS) void k_jvp(ObsArgs a, const double* __
                     }
                 }
             }
-            int pos = base + lane;
+            int pos = su.pos;
             const int io0 = has ? a.ipt_ofs[q] : 0;
-            for (int k = 0; k < len; ++k, pos += 64) {
+            for (int tt = 0; tt < su.nt; ++tt, pos += su.step) {
+                const int k = su.slot(tt);
                 if (k < cnt) {
                     const int cam = a.e_cam[pos];
                     ObsEval<MODEL, NP, true> e;
@@ -967,9 +970,9 @@ __global__ __launch_bounds__(BS_THREADS) void k_backsub(ObsArgs a, const double*
     double* tab = s_dyn_bs;
     if constexpr (MODEL == AFFINE) affine_dir_table<NP>(a, dc, tab, BS_THREADS);
     else T.stage(a, s_dyn_bs, BS_THREADS);
-    for_each_slice(a.n_slices, WAVES, [&](const int gu) {
-        const int base = a.slice_base[gu], len = (a.slice_base[gu + 1] - base) >> 6;
-        const int q = gu * 64 + lane;
+    for_each_slice(a.n_slices << a.sh, WAVES, [&](const int u) {
+        const SliceUnit su(a, u, lane);
+        const int q = su.q;
         const bool has = q < a.N;
         const int cnt = has ? a.pt_cnt[q] : 0;
         double X = 0.0, Y = 0.0, Z = 0.0, mp = 0.0;
@@ -979,15 +982,17 @@ __global__ __launch_bounds__(BS_THREADS) void k_backsub(ObsArgs a, const double*
             mp = (a.perm[q] >= a.n_pts_fix) ? 1.0 : 0.0;
         }
         double t[3] = {0.0, 0.0, 0.0};
-        int pos = base + lane;
+        int pos = su.pos;
         const int io0 = has ? a.ipt_ofs[q] : 0;
         if constexpr (MODEL == AFFINE) {
-            int c0 = (0 < cnt) ? a.e_cam[pos] : 0, c1 = (1 < cnt) ? a.e_cam[pos + 64] : 0;
-            double2 w0 = (0 < cnt && a.sc) ? a.sc[io0] : make_double2(1.0, 1.0), w1 = (1 < cnt && a.sc) ? a.sc[io0 + 1] : make_double2(1.0, 1.0);
-            for (int k = 0; k < len; ++k, pos += 64) {
+            const int k1 = su.slot(1);
+            int c0 = (su.g < cnt) ? a.e_cam[pos] : 0, c1 = (k1 < cnt) ? a.e_cam[pos + su.step] : 0;
+            double2 w0 = (su.g < cnt && a.sc) ? a.sc[io0 + su.g] : make_double2(1.0, 1.0), w1 = (k1 < cnt && a.sc) ? a.sc[io0 + k1] : make_double2(1.0, 1.0);
+            for (int tt = 0; tt < su.nt; ++tt, pos += su.step) {
+                const int k = su.slot(tt), k2 = su.slot(tt + 2);
                 int c2 = 0;
                 double2 w2 = make_double2(1.0, 1.0);
-                if (k + 2 < cnt) { c2 = a.e_cam[pos + 128]; if (a.sc) w2 = a.sc[io0 + k + 2]; }
+                if (k2 < cnt) { c2 = a.e_cam[pos + 2 * su.step]; if (a.sc) w2 = a.sc[io0 + k2]; }
                 __builtin_amdgcn_sched_barrier(0);
                 const int cam = c0;
                 const double2 s2 = w0;
@@ -1002,7 +1007,8 @@ __global__ __launch_bounds__(BS_THREADS) void k_backsub(ObsArgs a, const double*
                 }
             }
         } else {
-            for (int k = 0; k < len; ++k, pos += 64) {
+            for (int tt = 0; tt < su.nt; ++tt, pos += su.step) {
+                const int k = su.slot(tt);
                 if (k < cnt) {
                     const int cam = a.e_cam[pos];
                     ObsEval<MODEL, NP, true> e;
@@ -1019,7 +1025,11 @@ __global__ __launch_bounds__(BS_THREADS) void k_backsub(ObsArgs a, const double*
                 }
             }
         }
-        if (has) {
+        if (su.sh) {  // several lanes per point: W_p^T dc is the sum of their parts, the lane of slot 0 finishes the point
+#pragma unroll
+            for (int j = 0; j < 3; ++j) t[j] = slice_point_sum(t[j], su.sh);
+        }
+        if (has && su.g == 0) {
             const double* vi = Vinv + 6 * (size_t)q;
             const size_t ib = (size_t)a.n_c + 3 * (size_t)q;
             const double r0 = g[ib] - t[0], r1 = g[ib + 1] - t[1], r2 = g[ib + 2] - t[2];
