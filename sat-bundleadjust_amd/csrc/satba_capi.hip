@@ -483,7 +483,9 @@ static int schur_item_table_build(satba_problem* p, bool merged, int2** d_items,
 static int schur_item_table(satba_problem* p) {
     TRY(schur_item_table_build(p, false, &p->d_items, &p->d_item_desc, &p->n_item_blocks));
     const char* mg = getenv("SATBA_SCHUR_MERGE");  // experiments: 0 keeps the chunked items for every kernel
-    if (p->L.C > 1 && !(mg && atoi(mg) == 0)) TRY(schur_item_table_build(p, true, &p->d_items_merged, &p->d_item_desc_merged, &p->n_item_blocks_merged));
+    // ... where the pairs alone fill the chip: with few cameras the chunks are what provides the parallelism (50 cameras: 1 225 pairs)
+    const bool enough = p->L.n_pairs >= 8192 || (mg && atoi(mg) != 0);
+    if (p->L.C > 1 && enough && !(mg && atoi(mg) == 0)) TRY(schur_item_table_build(p, true, &p->d_items_merged, &p->d_item_desc_merged, &p->n_item_blocks_merged));
     return 0;
 }
 
@@ -722,7 +724,7 @@ int satba_problem_create(const satba_problem_desc* d, satba_problem** out) {
         TRY(dev_alloc(p, &p->d_dc, p->n_c)); TRY(dev_alloc(p, &p->d_dch, p->n_c));
         const size_t Kz = (size_t)std::max<long long>(K, 1) + 64;
         TRY(dev_alloc(p, &p->d_f, Pz)); TRY(dev_alloc(p, &p->d_ftmp, Pz)); TRY(dev_alloc(p, &p->d_sc, Kz));
-        if (p->model == RPC) TRY(dev_alloc(p, &p->d_Jpm, Kz * (2 * p->NP + 6)));
+        if (p->model == RPC) TRY(dev_alloc(p, &p->d_Jpm, Kz * jrow_stride(p->NP)));
         TRY(dev_alloc(p, &p->d_fail, 1 + CH_MAX_STEPS));  // [0] not-SPD flag, then the panel-step flags
         { const char* cs = getenv("SATBA_CHOL"); p->chol_mode = cs ? atoi(cs) : 0; }
         TRY(dev_alloc(p, &p->d_dinv, (size_t)((p->n_c + CH_NB - 1) / CH_NB) * CH_NB * CH_NB));

@@ -29,6 +29,10 @@ __host__ __device__ constexpr int cam_acc_stride(int np) { return cam_acc_len(np
 __host__ __device__ constexpr int cam_sum_stride(int np) { return (2 * np) | 1; }
 
 constexpr int RPCS = 91;  // row stride of the LDS copy of the RPC tables (90 used, odd)
+// row stride (doubles) of the stored Jacobian blocks (RPC): 2 np + 6 used.  np = 3: 12 doubles in a 128-byte row -- one line per
+// gathered row instead of 1.75 with 96-byte rows (k_schur_pairs<RPC> sits on the L1-miss path); np = 6: 18 doubles in 192 bytes
+// (always two lines instead of up to three)
+__host__ __device__ constexpr int jrow_stride(int np) { return 2 * np + 6 <= 16 ? 16 : 24; }
 
 struct ObsArgs {
     const int* __restrict__ e_cam;       // P: camera of every ELL slot (-1: padding)
@@ -118,12 +122,12 @@ struct ObsEval {
         for (int k = 0; k < NP; ++k) { t[k] = Jc[0][k]; t[NP + k] = Jc[1][k]; }
 #pragma unroll
         for (int k = 0; k < 3; ++k) { t[2 * NP + k] = Jp[0][k]; t[2 * NP + 3 + k] = Jp[1][k]; }
-        double2* q = reinterpret_cast<double2*>(a.Jpm + (size_t)io * (2 * NP + 6));
+        double2* q = reinterpret_cast<double2*>(a.Jpm + (size_t)io * jrow_stride(NP));
 #pragma unroll
         for (int k = 0; k < NP + 3; ++k) q[k] = make_double2(t[2 * k], t[2 * k + 1]);
     }
     __device__ inline void load_jac(const ObsArgs& a, int io) {
-        const double2* q = reinterpret_cast<const double2*>(a.Jpm + (size_t)io * (2 * NP + 6));
+        const double2* q = reinterpret_cast<const double2*>(a.Jpm + (size_t)io * jrow_stride(NP));
         double t[2 * NP + 6];
 #pragma unroll
         for (int k = 0; k < NP + 3; ++k) { const double2 v = q[k]; t[2 * k] = v.x; t[2 * k + 1] = v.y; }

@@ -295,8 +295,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 3))) voi
 #pragma unroll
                 for (int k = 0; k < JLEN; ++k) { ti[k] = tip[k]; tj[k] = tjp[k]; }
             } else {
-                const double2* qi = reinterpret_cast<const double2*>(a.Jpm + (size_t)pi * JLEN);
-                const double2* qj = reinterpret_cast<const double2*>(a.Jpm + (size_t)pj * JLEN);
+                const double2* qi = reinterpret_cast<const double2*>(a.Jpm + (size_t)pi * jrow_stride(NP));
+                const double2* qj = reinterpret_cast<const double2*>(a.Jpm + (size_t)pj * jrow_stride(NP));
 #pragma unroll
                 for (int k = 0; k < NP + 3; ++k) {
                     const double2 vi = qi[k], vj = qj[k];
@@ -390,7 +390,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 3))) voi
                 __builtin_amdgcn_wave_barrier();
                 return r;
             };
-            // RPC, rotation only: the stored Jacobian rows (12 doubles = 6 pieces per observation, io order) of both observations are
+            // RPC, rotation only: the stored Jacobian rows (12 doubles = 6 pieces per observation in a 128-byte row, io order) of both observations are
             // gathered the same way (piece 64 t + lane: row (64 t + lane) / 6, piece (64 t + lane) % 6; 11 lines per instruction
             // instead of 64, twelve instructions per iteration) and transposed through the same LDS buffer, row stride 7 pieces
             struct JCoop { double2 c0, c1, c2, c3, c4, c5; };
@@ -405,12 +405,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 3))) voi
             }
             auto jcoop_load = [&](int io) {
                 JCoop o;
-                o.c0 = jp[0][6 * (size_t)__shfl(io, jsrc[0])];
-                o.c1 = jp[1][6 * (size_t)__shfl(io, jsrc[1])];
-                o.c2 = jp[2][6 * (size_t)__shfl(io, jsrc[2])];
-                o.c3 = jp[3][6 * (size_t)__shfl(io, jsrc[3])];
-                o.c4 = jp[4][6 * (size_t)__shfl(io, jsrc[4])];
-                o.c5 = jp[5][6 * (size_t)__shfl(io, jsrc[5])];
+                constexpr size_t RS = jrow_stride(NP) / 2;  // row stride in 16-byte pieces
+                o.c0 = jp[0][RS * (size_t)__shfl(io, jsrc[0])];
+                o.c1 = jp[1][RS * (size_t)__shfl(io, jsrc[1])];
+                o.c2 = jp[2][RS * (size_t)__shfl(io, jsrc[2])];
+                o.c3 = jp[3][RS * (size_t)__shfl(io, jsrc[3])];
+                o.c4 = jp[4][RS * (size_t)__shfl(io, jsrc[4])];
+                o.c5 = jp[5][RS * (size_t)__shfl(io, jsrc[5])];
                 return o;
             };
             const double2* jmine = reinterpret_cast<const double2*>(my) + lane * 7;
