@@ -232,8 +232,8 @@ static int launch_residual(satba_problem* p, bool at_new, double2* f, double* co
 
 // trial point + cost there + |step|^2, |x|^2 in one pass over the observations (k_residual<..., TRIAL>)
 static int launch_trial(satba_problem* p, double c0, double c1, const double* v0, const double* v1) {
-    hipLaunchKernelGGL(k_trial_cams, dim3((p->M + 63) / 64), dim3(64), 0, p->stream, p->model, p->M, p->NP, p->c_p, p->d_x, v0, v1, p->d_scale_inv, c0, c1,
-                       p->d_cam_static, p->d_xnew, p->d_camc_new);
+    hipLaunchKernelGGL(k_trial_cams, dim3((std::max(p->M, (int)p->hdr) + 63) / 64), dim3(64), 0, p->stream, p->model, p->M, p->NP, p->c_p, p->d_x, v0, v1,
+                       p->d_scale_inv, c0, c1, p->d_cam_static, p->d_xnew, p->d_camc_new, p->d_xb, (int)p->hdr);
     HIP_TRY(hipGetLastError());
     ObsArgs a = obs_args(p, true);
     a.sh = slice_split(p);
@@ -415,9 +415,9 @@ static int launch_jvp(satba_problem* p, int nv, const double* q1, const double* 
 }
 
 // S z = rhs for the reduced system (S column-major lower, destroyed; b in place)
-static int dense_solve(satba_problem* p, double* S, double* b) {
+static int dense_solve(satba_problem* p, double* S, double* b, bool cleared = false) {
     cholesky_solve(S, p->n_c, b, p->d_fail, p->d_fail + 1, p->chol_mode == 3 ? 0 : p->chol_mode, p->stream, nullptr,
-                   p->chol_mode == 3 ? nullptr : p->d_dinv);  // clears d_fail and the step flags
+                   p->chol_mode == 3 ? nullptr : p->d_dinv, cleared);  // clears d_fail and the step flags unless the caller has
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -988,9 +988,9 @@ int satba_solve(satba_problem* p) {
     double* S = p->payload();
     double* rhs = S + (size_t)p->n_c * p->n_c;
     hipLaunchKernelGGL(k_scale_system, dim3(grid_for((long long)p->n_c * p->n_c, 256, 2048)), dim3(256), 0, p->stream, p->n_c,
-                       p->d_scale_inv, S, rhs, p->d_dch);
+                       p->d_scale_inv, S, rhs, p->d_dch, p->d_fail, 1 + CH_MAX_STEPS);
     HIP_TRY(hipGetLastError());
-    TRY(dense_solve(p, S, p->d_dch));  // also clears the not-SPD flag first
+    TRY(dense_solve(p, S, p->d_dch, true));  // the not-SPD flag and the step flags were cleared by the scaling kernel
     const int nu = std::max(p->n_c, (int)p->hdr);
     hipLaunchKernelGGL(k_unscale, dim3((nu + 255) / 256), dim3(256), 0, p->stream, p->n_c, p->d_scale_inv, p->d_dch, p->d_dc, (int)p->hdr,
                        p->d_xb, p->d_fail, p->lead, p->d_keep, SATBA_HDR_KEEP, SATBA_KEEP_LEN);
@@ -1021,8 +1021,7 @@ int satba_subspace_products(satba_problem* p) {
 }
 
 static int trial_impl(satba_problem* p, double c0, double c1, const double* v0, const double* v1) {
-    TRY(zero_header(p));
-    TRY(launch_trial(p, c0, c1, v0, v1));
+    TRY(launch_trial(p, c0, c1, v0, v1));  // k_trial_cams clears the header
     return 0;
 }
 

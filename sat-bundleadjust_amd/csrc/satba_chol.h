@@ -681,14 +681,15 @@ constexpr int CH_TRSV_FLAGS = 64;  // k_trsv_back_mw's flags (n <= 1024: the fac
 // only (k_chol_step); 5: like 0 with the one-workgroup backward substitution (k_trsv_back_dinv)
 // dinv: (n / 32 rounded up) x 1024 doubles of scratch for the inverted diagonal blocks (n <= 1024), or null
 // ts (tools): CH_TS time stamps per launch
+// cleared: the caller has already zeroed *fail and the flags on the stream (satba_solve does it in its scaling kernel)
 inline void cholesky_solve(double* A, int n, double* b, int* fail, int* flags, int mode, hipStream_t stream,
-                           long long* ts = nullptr, double* dinv = nullptr) {
+                           long long* ts = nullptr, double* dinv = nullptr, bool cleared = false) {
     static const bool once = [] {  // k_chol_dstep's tile column + scratch exceed the 64 KB a kernel gets without asking
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chol_dstep), hipFuncAttributeMaxDynamicSharedMemorySize, (int)chol_dstep_lds());
         return true;
     }();
     (void)once;
-    (void)hipMemsetAsync(fail, 0, sizeof(int) * (1 + CH_MAX_STEPS), stream);  // flags == fail + 1: one fill for both
+    if (!cleared) (void)hipMemsetAsync(fail, 0, sizeof(int) * (1 + CH_MAX_STEPS), stream);  // flags == fail + 1: one fill for both
     int k0 = 0, npend = 0, step = 0;  // step: launches so far
     int* fl = flags;
     auto tsk = [&] { return ts ? ts + CH_TS * step : nullptr; };

@@ -329,10 +329,13 @@ __global__ void k_cam_consts(int model, int M, int n_p, int c_p, const double* _
 }
 
 // trial point of the cameras, x_new = x + (c0 v0 + c1 v1) / scale_inv on their n_p entries, and the camera constants at x_new
+// (the same launch clears the exchange header, hdr_len doubles at xb, which the residual kernel behind it writes into)
 __global__ void k_trial_cams(int model, int M, int n_p, int c_p, const double* __restrict__ x, const double* __restrict__ v0,
                              const double* __restrict__ v1, const double* __restrict__ scale_inv, double c0, double c1,
-                             const double* __restrict__ cam_static, double* __restrict__ x_new, double* __restrict__ camc_new) {
+                             const double* __restrict__ cam_static, double* __restrict__ x_new, double* __restrict__ camc_new,
+                             double* __restrict__ xb, int hdr_len) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < hdr_len) xb[c] = 0.0;
     if (c >= M) return;
     double full[11];
     for (int i = 0; i < c_p; ++i) full[i] = cam_static[(size_t)c * c_p + i];
@@ -901,9 +904,12 @@ __global__ __launch_bounds__(JVP_THREADS) void k_jvp(ObsArgs a, const double* __
 // Reduced system in scaled variables: S <- diag(scale) S diag(scale), rhs <- scale * rhs (scale = 1 / scale_inv).
 // x_scale="jac" makes the scaled matrix unit-diagonal up to the damping, which keeps the dense factorisation
 // well conditioned although the raw camera blocks span ~12 orders of magnitude (angles vs translations).
+// (the same launch clears the dense solver's status word and flags, n_clear ints at `clear`: one fill less)
 __global__ __launch_bounds__(256) void k_scale_system(int n_c, const double* __restrict__ scale_inv, double* __restrict__ S,
-                                                      const double* __restrict__ rhs, double* __restrict__ rhs_scaled) {
+                                                      const double* __restrict__ rhs, double* __restrict__ rhs_scaled, int* __restrict__ clear,
+                                                      int n_clear) {
     const size_t nn = (size_t)n_c * n_c;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)n_clear; i += (size_t)gridDim.x * blockDim.x) clear[i] = 0;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nn + n_c; i += (size_t)gridDim.x * blockDim.x) {
         if (i < nn) {
             const int r = (int)(i % n_c), c = (int)(i / n_c);
