@@ -949,7 +949,7 @@ static int schur_impl(satba_problem* p, double lam, bool automatic, double Delta
     const bool pairs_run = p->L.n_pairs > 0 && p->L.E > 0;
     const double* lam_dev = automatic ? p->d_keep + 5 : nullptr;
     if (p->N > 0) {
-        hipLaunchKernelGGL(k_vinv, dim3((p->N + 255) / 256), dim3(256), 0, p->stream, p->N, lam, automatic ? p->d_xb : nullptr, Delta, lam_floor,
+        hipLaunchKernelGGL(k_vinv, dim3((p->N + VINV_THREADS - 1) / VINV_THREADS), dim3(VINV_THREADS), 0, p->stream, p->N, lam, automatic ? p->d_xb : nullptr, Delta, lam_floor,
                            p->d_keep, p->d_V, p->d_scale_inv + p->n_c, p->d_Vinv, p->d_x + p->n_c, p->d_g + p->n_c, p->d_PV, p->L.perm, p->n_pts_fix);
     } else if (automatic) {
         hipLaunchKernelGGL(k_lambda, dim3(1), dim3(1), 0, p->stream, p->d_xb, Delta, lam_floor, p->d_keep);

@@ -52,14 +52,22 @@ __device__ inline double schur_lambda(const double* __restrict__ hdr, double Del
 }
 
 // hdr_auto (optional): the damping comes from the prepare header (schur_lambda, Delta / lam_floor / keep as there) instead of `lam`
-__global__ void k_vinv(int N, double lam, const double* __restrict__ hdr_auto, double Delta, double lam_floor, double* __restrict__ keep,
-                       const double* __restrict__ V,
-                       const double* __restrict__ scale_inv_p, double* __restrict__ Vinv, const double* __restrict__ xp,
-                       const double* __restrict__ gp, double* __restrict__ PV, const int* __restrict__ perm, int n_pts_fix) {
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= N) return;
-    if (hdr_auto) lam = schur_lambda(hdr_auto, Delta, lam_floor, keep, p == 0);
-    // 16-byte accesses: V and Vinv rows are 48 bytes apart, records 128 (hipMalloc aligns the arrays to 256 bytes)
+// Stores: a lane's 48-byte Vinv row and 128-byte record are strided over the wave (24 and 64 lines per store instruction: the
+// texture path handles one line per cycle); the wave's 64 rows / records are contiguous in memory, so they are transposed through
+// LDS (row strides 48 and 144 bytes: the 16 lanes of a ds_write_b128 phase fall into disjoint banks) and written as three / eight
+// fully coalesced 16-byte stores per lane.  Workgroups of 256 threads, N need not be a multiple of 64.
+constexpr int VINV_THREADS = 256;
+__global__ __launch_bounds__(VINV_THREADS) void k_vinv(int N, double lam, const double* __restrict__ hdr_auto, double Delta, double lam_floor,
+                                                       double* __restrict__ keep, const double* __restrict__ V,
+                                                       const double* __restrict__ scale_inv_p, double* __restrict__ Vinv,
+                                                       const double* __restrict__ xp, const double* __restrict__ gp, double* __restrict__ PV,
+                                                       const int* __restrict__ perm, int n_pts_fix) {
+    __shared__ double2 s_t[VINV_THREADS / 64][64 * 9];  // per wave: 64 records x 144 bytes (the Vinv rows use the front of it)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int p0 = (blockIdx.x * (VINV_THREADS / 64) + wave) * 64;  // first point of this wave
+    if (p0 >= N) return;
+    const int p = min(p0 + lane, N - 1);  // lanes past the end repeat the last point (their stores are dropped below)
+    if (hdr_auto) lam = schur_lambda(hdr_auto, Delta, lam_floor, keep, p0 + lane == 0);
     const double2* v2 = reinterpret_cast<const double2*>(V + 6 * (size_t)p);
     const double2 va = v2[0], vb = v2[1], vc = v2[2];
     const double* s = scale_inv_p + 3 * (size_t)p;
@@ -69,15 +77,42 @@ __global__ void k_vinv(int N, double lam, const double* __restrict__ hdr_auto, d
     const double idet = 1.0 / (a * c00 + b * c01 + c * c02);
     const double o0 = c00 * idet, o1 = c01 * idet, o2 = c02 * idet;
     const double o3 = (a * f - c * c) * idet, o4 = (b * c - a * e) * idet, o5 = (a * d - b * b) * idet;
-    double2* o = reinterpret_cast<double2*>(Vinv + 6 * (size_t)p);
-    o[0] = make_double2(o0, o1); o[1] = make_double2(o2, o3); o[2] = make_double2(o4, o5);
-    static_assert(PV_STRIDE % 2 == 0, "records are written as 16-byte words");
-    double2* q = reinterpret_cast<double2*>(PV + PV_STRIDE * (size_t)p);
     const double x0 = xp[3 * (size_t)p], x1 = xp[3 * (size_t)p + 1], x2 = xp[3 * (size_t)p + 2];
     const double g0 = gp[3 * (size_t)p], g1 = gp[3 * (size_t)p + 1], g2 = gp[3 * (size_t)p + 2];
     const double mp = (perm[p] >= n_pts_fix) ? 1.0 : 0.0;
-    q[0] = make_double2(x0, x1); q[1] = make_double2(x2, mp * o0); q[2] = make_double2(mp * o1, mp * o2);
-    q[3] = make_double2(mp * o3, mp * o4); q[4] = make_double2(mp * o5, g0); q[5] = make_double2(g1, g2);
+    double2* t = s_t[wave];
+    const int n_here = min(64, N - p0);  // points of this wave
+    // Vinv rows: 3 pieces per point
+    t[3 * lane] = make_double2(o0, o1); t[3 * lane + 1] = make_double2(o2, o3); t[3 * lane + 2] = make_double2(o4, o5);
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    {
+        double2* out = reinterpret_cast<double2*>(Vinv + 6 * (size_t)p0);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int g = 64 * k + lane;
+            const double2 v = t[g];
+            if (g < 3 * n_here) out[g] = v;
+        }
+    }
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    // records: 8 pieces per point (6 used), LDS row stride 9 pieces
+    static_assert(PV_STRIDE == 16, "records are eight 16-byte pieces");
+    double2* row = t + 9 * lane;
+    row[0] = make_double2(x0, x1); row[1] = make_double2(x2, mp * o0); row[2] = make_double2(mp * o1, mp * o2);
+    row[3] = make_double2(mp * o3, mp * o4); row[4] = make_double2(mp * o5, g0); row[5] = make_double2(g1, g2);
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    {
+        double2* out = reinterpret_cast<double2*>(PV + PV_STRIDE * (size_t)p0);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int g = 64 * k + lane, r = g >> 3, q = g & 7;
+            const double2 v = t[9 * r + (q < 6 ? q : 0)];
+            if (q < 6 && r < n_here) out[g] = v;  // the two pad pieces of a record are never read
+        }
+    }
 }
 
 // Diagonal blocks of S <- (lead) * lam Dc^2 on the diagonal and zero elsewhere, rhs <- (lead) * g_c; S column-major n_c x n_c.
