@@ -199,6 +199,28 @@ int satba_solve_lm(satba_problem *p, const satba_lm_opts *opts, satba_lm_stats *
 int satba_outliers(satba_problem *p, const double *err, double predef_thr, double min_thr, double *cam_thr, uint8_t *remove,
                    int64_t *n_removed);
 
+/* ---- initial triangulation of the feature tracks, the step before the path.  Stand-alone: no problem handle.
+ * cameras: n_cam x 12 (3 x 4 projection matrices, row-major; affine and perspective) or n_cam x SATBA_RPC_TABLE_LEN (rpc).
+ *
+ * satba_triangulate_pairwise replaces ft_triangulate.linear_triangulation_multiple_pts (ft_triangulate.py:18-34, the
+ * cv2.triangulatePoints call) and ft_triangulate.rpc_triangulation (ft_triangulate.py:37-54 -> s2p/triangulation.py:82-135 ->
+ * c/disp_to_h.c:40-64 `stereo_corresp_to_lonlatalt`): n correspondences (pts_i, pts_j: host, n x 2, (col, row)) between two
+ * cameras -> pts3d (host, n x 3 float64, ECEF for rpc) and, for rpc, err (host, n float32, may be NULL: distance to the epipolar
+ * curve in pixels).  kernel_ms (may be NULL): duration of the kernel from HIP events.
+ *
+ * satba_init_pts3d replaces ft_triangulate.init_pts3d (ft_triangulate.py:57-127): every track is triangulated from every listed
+ * pair (pairs: host, n_pairs x 2, the reference's pairs_to_triangulate, processed in list order; pairs naming a camera >= n_cam
+ * are skipped as at :99) whose two cameras observe it, and the results are folded into a float32 running mean with the
+ * reference's sequence of float32 operations.  The tracks come as the observation lists of ba_params.py:142-147 instead of the
+ * dense NaN-sparse C matrix: pt_ofs (host, n_pts + 1, pt_ofs[0] = 0), cam_ind (host, K), obs (host, K x 2).  Outputs: pts3d
+ * (host, n_pts x 3 float32; zero where no pair applies, like the reference), n_tri (host, n_pts, may be NULL: triangulations
+ * per track).  reps >= 1: the kernel is launched reps times (measurement), kernel_ms (may be NULL) = average duration. */
+int satba_triangulate_pairwise(int32_t cam_model, const double *cam_i, const double *cam_j, int64_t n, const double *pts_i,
+                               const double *pts_j, double *pts3d, float *err, int32_t device, float *kernel_ms);
+int satba_init_pts3d(int32_t cam_model, int32_t n_cam, int64_t n_pts, const int64_t *pt_ofs, const int32_t *cam_ind,
+                     const double *obs, const double *cameras, int32_t n_pairs, const int32_t *pairs, float *pts3d,
+                     int32_t *n_tri, int32_t device, int32_t reps, float *kernel_ms);
+
 /* ---- inspection entry points (parity tests; not used by the solver loop) */
 /* index structures built by satba_problem_create, as int32 arrays (SATBA_LAY_PAIR_OFS: int64): n must equal satba_layout_len */
 enum { SATBA_LAY_PERM = 0, SATBA_LAY_RANK, SATBA_LAY_PT_CNT, SATBA_LAY_SLICE_BASE, SATBA_LAY_E_CAM, SATBA_LAY_OBS_POS, SATBA_LAY_CAM_OFS,

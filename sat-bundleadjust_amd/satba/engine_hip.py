@@ -31,6 +31,7 @@ SYMBOLS = [
     "satba_set_exchange", "satba_get_vector", "satba_time_kernel",
     "satba_packed_schur_len", "satba_pack_schur", "satba_unpack_schur",
     "satba_solve_lm", "satba_lm_step", "satba_profile_linearize", "satba_profile_read", "satba_outliers", "satba_layout_len", "satba_get_layout", "satba_get_info",
+    "satba_triangulate_pairwise", "satba_init_pts3d",
 ]
 
 FLAG_DETERMINISTIC = 1
@@ -122,6 +123,10 @@ def load_library(path=None):
     lib.satba_layout_len.restype = C.c_int64
     lib.satba_get_layout.argtypes = [h, C.c_int32, C.c_int64, C.c_void_p]
     lib.satba_get_info.argtypes = [h, _dp, C.c_int32]
+    _fp = C.POINTER(C.c_float)
+    lib.satba_triangulate_pairwise.argtypes = [C.c_int32, _dp, _dp, C.c_int64, _dp, _dp, _dp, _fp, C.c_int32, _fp]
+    lib.satba_init_pts3d.argtypes = [C.c_int32, C.c_int32, C.c_int64, C.POINTER(C.c_int64), _ip, _dp, _dp, C.c_int32, _ip, _fp, _ip,
+                                     C.c_int32, C.c_int32, _fp]
     if path == LIB_PATH:
         _LIB = lib
     return lib

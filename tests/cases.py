@@ -43,3 +43,15 @@ def solve_case(name):
     model, M, N, opp, seed, d, losses = SOLVE_CASES[name]
     scene = synth.make_scene(model, M, N, opp, seed=seed, **SCENE_KW.get(name, {}))
     return scene, (lambda: synth.make_params(scene, dict(d, reduce=False))), golden("solve_" + name), losses
+
+# tools/gen_golden.py golden_init_pts3d: (camera model, cameras, tracks, observations per track), scenes with seed 31
+TRI_CASES = {"affine": ("affine", 7, 400, 4), "persp": ("perspective", 6, 300, 3), "rpc": ("rpc", 5, 200, 3)}
+
+
+def tri_case(name):
+    """(scene, C, pairs, golden dict) of an init_pts3d fixture; C and the pair list are the stored ones."""
+    model, M, N, opp = TRI_CASES[name]
+    scene = synth.make_scene(model, M, N, opp, seed=31)
+    g = np.load(os.path.join(GOLDEN, "init_pts3d.npz"))
+    sub = {k[len(name) + 1:]: g[k] for k in g.files if k.startswith(name + "_")}
+    return scene, sub["C"], [tuple(int(v) for v in pr) for pr in sub["pairs"]], sub

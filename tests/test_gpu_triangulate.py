@@ -1,0 +1,122 @@
+"""
+Initial triangulation on the device (satba.ft_triangulate -> satba_init_pts3d / satba_triangulate_pairwise) against the oracle
+and the vectors of the reference function (tests/golden/init_pts3d.npz).  SURVEY section 8f #3.
+
+Tolerances.  The per-pair triangulations are float64 on both sides but not the same sequence of operations (fused
+multiply-adds; the RPC cubics reduced to bivariate ones per height): they agree to ~1e-8 m, asserted at 1e-6 m for the linear
+method and 1e-4 m for the RPC method (its two nested iterations stop on thresholds, 1e-5 m of height and 5e-6 px: two
+implementations may stop one step apart).  The track means are float32 with the reference's own sequence of float32
+operations, so they are bit-identical whenever the float64 points round to the same float32 -- all but the rare entry that
+sits on a rounding boundary (ulp 0.125 - 0.5 m at ECEF magnitudes, the resolution the reference itself works at).  Given
+identical float64 points the mean IS bit-exact: test_running_mean_is_bit_exact feeds the device's own pairwise results to
+the oracle's loop.
+"""
+import numpy as np
+import pytest
+
+import cases
+from oracle import triangulate_oracle as T
+from satba import ft_triangulate as FT
+from satba import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _ulp_diff(a, b):
+    a = np.ascontiguousarray(a, np.float32).view(np.int32).astype(np.int64)
+    b = np.ascontiguousarray(b, np.float32).view(np.int32).astype(np.int64)
+    return np.abs(a - b)
+
+
+def _assert_f32_close(got, want, max_ulp=4, max_frac=0.005):
+    assert got.dtype == np.float32 and got.shape == want.shape
+    d = _ulp_diff(got, want)
+    assert d.max() <= max_ulp, "float32 means differ by {} ulp".format(d.max())
+    assert np.mean(d > 0) <= max_frac, "{:.2%} of the float32 entries differ".format(np.mean(d > 0))
+
+
+@pytest.mark.parametrize("name", list(cases.TRI_CASES))
+def test_init_pts3d_against_reference_vectors(gpu, name):
+    scene, C, pairs, g = cases.tri_case(name)
+    pts = FT.init_pts3d(C, scene.cameras, scene.cam_model, pairs)
+    _assert_f32_close(pts, g["pts3d"])
+    assert np.all(pts[5] == 0.0)
+    c_i, c_j = pairs[0]
+    if scene.cam_model == "rpc":
+        pw, err = FT.rpc_triangulation(scene.cameras[c_i], scene.cameras[c_j], g["pair_obs_i"], g["pair_obs_j"])
+        assert err.shape == g["pair_err"].shape and err.dtype == np.float32
+        assert np.abs(err - g["pair_err"]).max() < 1e-5
+        assert np.abs(pw - g["pair_pts3d"]).max() < 1e-4
+    else:
+        pw = FT.linear_triangulation_multiple_pts(scene.cameras[c_i], scene.cameras[c_j], g["pair_obs_i"], g["pair_obs_j"])
+        assert np.abs(pw - g["pair_pts3d"]).max() < 1e-6
+    assert pw.dtype == np.float64
+
+
+@pytest.mark.parametrize("model,M,N,opp", [("affine", 12, 3000, 5), ("perspective", 9, 2000, 4), ("rpc", 12, 1500, 8)])
+def test_running_mean_is_bit_exact(gpu, model, M, N, opp):
+    """The oracle's pair loop fed with the device's own float64 triangulations must reproduce the device's means bit for bit:
+    pair order, duplicate and reversed pairs, the float32 update."""
+    scene = synth.make_scene(model, M, N, opp, seed=5)
+    C = scene.to_dense_C()
+    rng = np.random.default_rng(11)
+    ok = (lambda i, j: (i + j) % 2 == 1) if model == "rpc" else (lambda i, j: True)
+    pairs = [(i, j) for i in range(M) for j in range(i + 1, M) if ok(i, j)]
+    rng.shuffle(pairs)
+    pairs = [tuple(int(v) for v in pr) for pr in pairs]
+    pairs += [pairs[2], (pairs[4][1], pairs[4][0]), (1, M + 3)]
+
+    def dev_pair(c_i, c_j, oi, oj):
+        if model == "rpc":
+            return FT.rpc_triangulation(scene.cameras[c_i], scene.cameras[c_j], oi, oj)[0]
+        return FT.linear_triangulation_multiple_pts(scene.cameras[c_i], scene.cameras[c_j], oi, oj)
+    want = T.init_pts3d(C, scene.cameras, model, pairs, triangulate=dev_pair)
+    got, info = FT.init_pts3d_from_observations(scene.pts_ind, scene.cam_ind, scene.pts2d, N, scene.cameras, model, pairs, return_info=True)
+    assert np.array_equal(got, want)
+    # as many triangulations per track as the reference's loop performs
+    seen = ~np.isnan(C[::2])
+    n_ref = np.zeros(N, dtype=np.int64)
+    for c_i, c_j in pairs:
+        if c_i < M and c_j < M:
+            n_ref += seen[c_i] & seen[c_j]
+    assert np.array_equal(info["n_tri"], n_ref)
+    assert n_ref.max() > 24  # more pairs on a track than its sorted buffer holds at a time (TRI_BUF): the refill path ran
+    # and against the oracle's own float64 chain
+    _assert_f32_close(got, T.init_pts3d(C, scene.cameras, model, pairs))
+
+
+def test_pairwise_against_oracle_float64(gpu):
+    for model in ("affine", "perspective", "rpc"):
+        scene = synth.make_scene(model, 4, 4000, 4, seed=9)
+        C = scene.to_dense_C()
+        t = np.where(~np.isnan(C[0]) & ~np.isnan(C[2]))[0]
+        oi, oj = C[0:2, t].T, C[2:4, t].T
+        if model == "rpc":
+            want, werr = T.rpc_triangulation(scene.cameras[0], scene.cameras[1], oi, oj)
+            got, gerr = FT.rpc_triangulation(scene.cameras[0], scene.cameras[1], oi, oj)
+            assert np.abs(gerr[:, 0] - werr).max() < 1e-5
+            assert np.abs(got - want).max() < 1e-4
+        else:
+            want = T.linear_triangulation_multiple_pts(scene.cameras[0], scene.cameras[1], oi, oj)
+            got = FT.linear_triangulation_multiple_pts(scene.cameras[0], scene.cameras[1], oi, oj)
+            assert np.abs(got - want).max() < 1e-6
+        assert np.isfinite(got).all() and len(t) > 500
+
+
+def test_edge_cases(gpu):
+    scene = synth.make_scene("affine", 4, 50, 3, seed=1)
+    C = scene.to_dense_C()
+    # no pairs, no tracks
+    assert np.array_equal(FT.init_pts3d(C, scene.cameras, "affine", []), np.zeros((50, 3), np.float32))
+    assert FT.init_pts3d(C[:, :0], scene.cameras, "affine", [(0, 1)]).shape == (0, 3)
+    assert FT.linear_triangulation_multiple_pts(scene.cameras[0], scene.cameras[1], np.zeros((0, 2)), np.zeros((0, 2))).shape == (0, 3)
+    # pairs that only name cameras the matrix does not have
+    assert np.all(FT.init_pts3d(C, scene.cameras, "affine", [(0, 9), (7, 1)]) == 0.0)
+    with pytest.raises(ValueError):
+        FT.init_pts3d(C, scene.cameras, "affine", [(1, 1)])
+    with pytest.raises(ValueError):
+        FT.init_pts3d(C, scene.cameras, "affine", [(-1, 2)])
+    # a track whose cameras form no listed pair keeps the zero initial value, the others do not
+    pts = FT.init_pts3d(C, scene.cameras, "affine", [(0, 1)])
+    both = ~np.isnan(C[0]) & ~np.isnan(C[2])
+    assert np.all(pts[~both] == 0.0) and np.all(np.abs(pts[both]).max(axis=1) > 1e5)

@@ -213,3 +213,70 @@ def test_host_projection_helpers_match_oracle():
         assert np.abs(a - O.project(g["v"][1], p)).max() < 1e-9
     lat, lon, alt = geo_utils.ecef_to_latlon_custom(*geo_utils.latlon_to_ecef_custom(11.0, -72.7, 3500.0))
     assert abs(lat - 11.0) < 1e-9 and abs(lon + 72.7) < 1e-9 and abs(alt - 3500.0) < 1e-6
+
+
+# ---------------------------------------------------------------------------------------------- initial triangulation
+@pytest.mark.parametrize("name", list(cases.TRI_CASES))
+def test_triangulation_oracle_reproduces_reference(name):
+    """oracle/triangulate_oracle.py vs the vectors of the imported reference function (tools/gen_golden.py golden_init_pts3d):
+    the running float32 mean over the pairs in list order is bit-exact; so is the RPC chain (the fixture ran the reference's C)."""
+    from oracle import triangulate_oracle as T
+
+    scene, C, pairs, g = cases.tri_case(name)
+    keep = np.arange(C.shape[1]) != 5  # the fixture blanked track 5 except for camera 0
+    assert np.array_equal(C[:, keep], scene.to_dense_C()[:, keep], equal_nan=True)  # the stored inputs are the seeded scene
+    pts = T.init_pts3d(C, scene.cameras, scene.cam_model, pairs)
+    assert pts.dtype == np.float32 and np.array_equal(pts, g["pts3d"])
+    assert np.all(pts[5] == 0.0)  # seen by one camera only
+    c_i, c_j = pairs[0]
+    if scene.cam_model == "rpc":
+        pw, err = T.rpc_triangulation(scene.cameras[c_i], scene.cameras[c_j], g["pair_obs_i"], g["pair_obs_j"])
+        assert np.array_equal(err.reshape(-1, 1), g["pair_err"])
+    else:
+        pw = T.linear_triangulation_multiple_pts(scene.cameras[c_i], scene.cameras[c_j], g["pair_obs_i"], g["pair_obs_j"])
+    assert np.array_equal(pw, g["pair_pts3d"])
+
+
+def test_rpc_triangulation_oracle_against_reference_c():
+    """oracle.stereo_corresp_to_lonlatalt vs the reference's own library (ref:c/disp_to_h.c:40-64, built by oracle/Makefile)."""
+    from oracle import triangulate_oracle as T
+
+    lib_path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "disp_to_h.so")
+    if not os.path.exists(lib_path):
+        pytest.skip("oracle/_ref/disp_to_h.so not built (needs /root/reference; run `make -C oracle`)")
+    lib = ctypes.CDLL(lib_path)
+
+    class Rpc(ctypes.Structure):  # struct rpc of ref:c/rpc.h:14-32
+        _fields_ = [(n, ctypes.c_double * k) for n, k in (
+            ("numx", 20), ("denx", 20), ("numy", 20), ("deny", 20), ("scale", 3), ("offset", 3), ("inumx", 20),
+            ("idenx", 20), ("inumy", 20), ("ideny", 20), ("iscale", 3), ("ioffset", 3), ("dmval", 4), ("imval", 4))] + [
+            ("delta", ctypes.c_double)]
+
+    def fill(r):  # ref:bundle_adjust/s2p/triangulation.py:43-79 with delta = 0.1 (:99-100)
+        s = Rpc()
+        s.inumx[:], s.idenx[:], s.inumy[:], s.ideny[:] = r.col_num, r.col_den, r.row_num, r.row_den
+        s.numx[:] = s.denx[:] = s.numy[:] = s.deny[:] = [float("nan")] * 20
+        s.ioffset[:] = [r.lon_offset, r.lat_offset, r.alt_offset]
+        s.iscale[:] = [r.lon_scale, r.lat_scale, r.alt_scale]
+        s.offset[:] = [r.col_offset, r.row_offset, r.alt_offset]
+        s.scale[:] = [r.col_scale, r.row_scale, r.alt_scale]
+        s.delta = 0.1
+        return s
+
+    r1, r2 = [RPCModel.from_file(f) for f in synth.default_rpc_files()]
+    rng = np.random.default_rng(3)
+    n = 500
+    lon = r1.lon_offset + rng.uniform(-0.01, 0.01, n); lat = r1.lat_offset + rng.uniform(-0.005, 0.005, n)
+    alt = r1.alt_offset + rng.uniform(-100, 100, n)
+    p1 = np.stack(r1.projection(lon, lat, alt), 1) + rng.normal(0, 0.2, (n, 2))
+    p2 = np.stack(r2.projection(lon, lat, alt), 1) + rng.normal(0, 0.2, (n, 2))
+    out = np.zeros((n, 3)); err = np.zeros((n, 1), np.float32)
+    a32, b32 = np.ascontiguousarray(p1.astype(np.float32)), np.ascontiguousarray(p2.astype(np.float32))
+    vp = ctypes.c_void_p
+    lib.stereo_corresp_to_lonlatalt(out.ctypes.data_as(vp), err.ctypes.data_as(vp), a32.ctypes.data_as(vp), b32.ctypes.data_as(vp),
+                                    ctypes.c_int(n), ctypes.byref(fill(r1)), ctypes.byref(fill(r2)))
+    lla, e = T.stereo_corresp_to_lonlatalt(r1, r2, p1, p2)
+    # same sequence of IEEE operations; a compiler that contracts a*b+c differently would still agree to these bounds
+    assert np.abs(lla[:, :2] - out[:, :2]).max() < 1e-12 and np.abs(lla[:, 2] - out[:, 2]).max() < 1e-6
+    assert np.abs(e - err[:, 0]).max() < 1e-6
+    assert np.abs(out[:, 2] - alt).max() < 5.0  # and the library triangulates the scene it was given

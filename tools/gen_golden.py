@@ -312,9 +312,89 @@ def golden_outliers():
     save("outliers", **out)
 
 
+def import_reference_triangulation():
+    """
+    ref:bundle_adjust/feature_tracks/ft_triangulate.py imported in place.  What it needs and the image lacks:
+      * cv2.triangulatePoints -> the restatement in oracle/triangulate_oracle.py (OpenCV is absent: parity of that one call is unpinned);
+      * lib/disp_to_h.so -> the reference's own C compiled by oracle/Makefile into oracle/_ref/disp_to_h.so; the reference's ctypes
+        binding (s2p/triangulation.py) is used unchanged, only the path it opens is redirected;
+      * s2p/geographiclib (pyproj, geojson): only its pyproj_crs() is touched, to name the default output CRS.
+    """
+    import ctypes
+    sys.path.insert(0, ROOT)
+    from oracle import triangulate_oracle as T
+
+    cv2 = types.ModuleType("cv2")
+
+    def triangulate_points(P1, P2, a, b):
+        X = T.linear_triangulation_multiple_pts(P1, P2, np.asarray(a).T, np.asarray(b).T)
+        return np.vstack([X.T, np.ones((1, X.shape[0]))])
+    cv2.triangulatePoints = triangulate_points
+    sys.modules["cv2"] = cv2
+    s2p = types.ModuleType("bundle_adjust.s2p")
+    s2p.__path__ = ["/root/reference/bundle_adjust/s2p"]
+    sys.modules["bundle_adjust.s2p"] = s2p
+    geo = types.ModuleType("bundle_adjust.s2p.geographiclib")
+    geo.pyproj_crs = lambda name: name
+    sys.modules["bundle_adjust.s2p.geographiclib"] = geo
+    s2p.geographiclib = geo
+    ft = types.ModuleType("bundle_adjust.feature_tracks")
+    ft.__path__ = ["/root/reference/bundle_adjust/feature_tracks"]
+    sys.modules["bundle_adjust.feature_tracks"] = ft
+    real_cdll = ctypes.CDLL
+
+    def cdll(path, *a, **k):
+        if str(path).endswith("disp_to_h.so"):
+            path = os.path.join(ROOT, "oracle", "_ref", "disp_to_h.so")
+        return real_cdll(path, *a, **k)
+    ctypes.CDLL = cdll
+    try:
+        return importlib.import_module("bundle_adjust.feature_tracks.ft_triangulate")
+    finally:
+        ctypes.CDLL = real_cdll
+
+
+def tri_pairs(M, rng, ok=lambda i, j: True):
+    """pairs_to_triangulate as a pipeline could hand them over, plus the cases the loop has to survive: arbitrary order, a pair listed
+    twice, a reversed pair, a pair naming a camera the matrix does not have"""
+    pairs = [(i, j) for i in range(M) for j in range(i + 1, M) if rng.random() < 0.6 and ok(i, j)]
+    rng.shuffle(pairs)
+    pairs = [tuple(int(v) for v in pr) for pr in pairs]
+    pairs.insert(3, pairs[0])
+    pairs.insert(5, (pairs[1][1], pairs[1][0]))
+    pairs.insert(2, (0, M + 1))
+    return pairs
+
+
+def golden_init_pts3d():
+    """ref:bundle_adjust/feature_tracks/ft_triangulate.py:57-127 on seeded scenes of the three camera models."""
+    tri = import_reference_triangulation()
+    out = {}
+    for name, model, M, N, opp in (("affine", "affine", 7, 400, 4), ("persp", "perspective", 6, 300, 3), ("rpc", "rpc", 5, 200, 3)):
+        scene = synth.make_scene(model, M, N, opp, seed=31)
+        C = scene.to_dense_C()
+        C[:, 5] = np.nan; C[0:2, 5] = [10.0, 20.0]       # a track seen by one camera only: stays (0, 0, 0)
+        # the rpc scene cycles two real RPCs over its cameras: only pairs of different models have a baseline
+        pairs = tri_pairs(M, np.random.default_rng(7), (lambda i, j: (i + j) % 2 == 1) if model == "rpc" else (lambda i, j: True))
+        pts = tri.init_pts3d(C, scene.cameras, model, pairs, verbose=False)
+        c_i, c_j = pairs[0]
+        t = np.where(~np.isnan(C[2 * c_i]) & ~np.isnan(C[2 * c_j]))[0]
+        oi, oj = C[2 * c_i:2 * c_i + 2, t].T, C[2 * c_j:2 * c_j + 2, t].T
+        if model == "rpc":
+            pw, err = tri.rpc_triangulation(scene.cameras[c_i], scene.cameras[c_j], oi, oj)
+            out[name + "_pair_err"] = err
+        else:
+            pw = tri.linear_triangulation_multiple_pts(scene.cameras[c_i], scene.cameras[c_j], oi, oj)
+        out.update({name + "_C": C, name + "_pairs": np.array(pairs), name + "_pts3d": pts, name + "_pair_obs_i": oi, name + "_pair_obs_j": oj,
+                    name + "_pair_pts3d": pw})
+        d = np.linalg.norm(pts[t].astype(np.float64) - np.asarray(scene.pts3d_true if hasattr(scene, "pts3d_true") else scene.pts3d)[t], axis=1)
+        print("init_pts3d", name, pts.dtype, pts.shape, "pairs", len(pairs), "median distance to the scene points", np.median(d))
+    save("init_pts3d", **out)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["fun", "params", "solves", "tight2", "outliers"]
+    which = sys.argv[1:] or ["fun", "params", "solves", "tight2", "outliers", "init_pts3d"]
     if "fun" in which:
         golden_fun_and_jac()
     if "params" in which:
@@ -325,3 +405,5 @@ if __name__ == "__main__":
         golden_tight_rpc_persp()
     if "outliers" in which:
         golden_outliers()
+    if "init_pts3d" in which:
+        golden_init_pts3d()
