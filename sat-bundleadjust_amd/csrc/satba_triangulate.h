@@ -6,21 +6,24 @@
 //       RPC triangulation: height iteration along the epipolar curve, each step two localisations (Newton inversion of the
 //       projection, ref:c/rpc.c:372-408) and two projections
 //
-// One thread per track.  The reference walks the pairs and touches every track they share; the mean is float32 and therefore
-// depends on the order, so a track replays exactly that order: it enumerates the ordered camera pairs of its own observations,
-// looks their list indices up in an M x M table, and consumes them in ascending index (a bounded sorted buffer in LDS, refilled
-// until the track's pairs are exhausted).  The mean is updated with the reference's sequence of float32 operations (no fused
-// multiply-add).  The triangulations themselves are float64 and use fused multiply-adds: they agree with the reference's to
-// ~1e-9 m, which the float32 store (ulp 0.125 - 0.5 m at ECEF magnitudes) almost always hides.
+// The reference walks the pairs and touches every track they share; the mean is float32 and therefore depends on the order, so a
+// track replays exactly that order: it enumerates the ordered camera pairs of its own observations, looks their list indices up
+// in an M x M table, and lists them in ascending index (a bounded sorted buffer in LDS, refilled until the track's pairs are
+// exhausted).  The triangulations of all tracks then form one flat work list (one thread each: the tracks are few and of very
+// different lengths, the triangulations many), and a last pass folds each track's slice into the mean with the reference's
+// sequence of float32 operations (no fused multiply-add).  The triangulations themselves are float64 and use fused
+// multiply-adds: they agree with the reference's to ~1e-8 m, which the float32 store (ulp 0.125 - 0.5 m at ECEF magnitudes)
+// almost always hides.
 //
 // RPC: VALU-bound (about 30 k float64 instructions per triangulation, two thirds of them in the cubic polynomials); the tables of
 // all cameras sit in LDS with an odd stride (91 doubles) when they fit, because the lanes of a wave work on different cameras.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
 
 namespace satba {
 
-constexpr int TRI_THREADS = 128;   // threads per workgroup of k_init_pts3d
+constexpr int TRI_THREADS = 128;   // threads per workgroup of k_tri_list
 constexpr int TRI_BUF = 24;        // pair indices a track holds sorted at a time
 constexpr int TRI_RPC_STRIDE = 91; // doubles per camera of the LDS copy of the RPC tables
 constexpr int TRI_LOC_MAXIT = 100; // the reference's localisation loops without a bound (ref:c/rpc.c:394)
@@ -244,25 +247,40 @@ struct TriArgs {
     const int* pair_first;  // M x M: first list index of the ordered pair (c_i, c_j), -1 if none
     const int* pair_next;   // n_pairs: next list index with the same ordered pair, -1 at the end
     const int* pairs;       // n_pairs x 2
+    int* n_tri;             // N + 1: triangulations per track (k_tri_count; the last entry stays 0)
+    const int* tri_ofs;     // N + 1: exclusive prefix sum of n_tri
+    int2* entries;          // per triangulation, track-major and in list order within a track: the two observations
+    float* res;             // per triangulation: the point, rounded to float32
     float* out;             // N x 3
-    int* n_tri;             // N, may be null: triangulations folded into the mean
 };
 
-// MODEL 2 = rpc, else linear; TAB_LDS: RPC tables staged in (dynamic) LDS
-template <int MODEL, bool TAB_LDS>
-__global__ __launch_bounds__(TRI_THREADS) void k_init_pts3d(const TriArgs a) {
-    __shared__ int s_buf[TRI_BUF][TRI_THREADS];
-    extern __shared__ double s_tab[];
-    if constexpr (MODEL == 2 && TAB_LDS) {
-        for (int i = threadIdx.x; i < a.M * 90; i += TRI_THREADS) s_tab[(i / 90) * TRI_RPC_STRIDE + i % 90] = a.cams[i];
-        __syncthreads();
+// Four passes.  (1) k_tri_count: triangulations per track = listed ordered pairs among its cameras; a prefix sum gives every track
+// its slice of the work list.  (2) k_tri_list: the track writes its triangulations into the slice in the order the reference's pair
+// loop reaches them.  (3) k_tri_points: one thread per triangulation -- the arithmetic, spread over the whole chip whatever the
+// track lengths are.  (4) k_tri_mean: the float32 running mean of a track over its slice.
+__global__ __launch_bounds__(256) void k_tri_count(const TriArgs a) {
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= a.N) return;
+    const int o0 = a.pt_ofs[q], k = a.pt_ofs[q + 1] - o0;
+    int total = 0;
+    for (int ia = 0; ia < k; ++ia) {
+        const int ca = a.cam_ind[o0 + ia];
+        for (int ib = 0; ib < k; ++ib) {
+            if (ib == ia) continue;
+            for (int id = a.pair_first[(size_t)ca * a.M + a.cam_ind[o0 + ib]]; id >= 0; id = a.pair_next[id]) ++total;
+        }
     }
+    a.n_tri[q] = total;
+}
+
+__global__ __launch_bounds__(TRI_THREADS) void k_tri_list(const TriArgs a) {
+    __shared__ int s_buf[TRI_BUF][TRI_THREADS];
     const int q = blockIdx.x * TRI_THREADS + threadIdx.x;
     if (q >= a.N) return;
     const int tid = threadIdx.x;
     const int o0 = a.pt_ofs[q], k = a.pt_ofs[q + 1] - o0;
-    float avg[3] = {0.f, 0.f, 0.f}, cnt = 0.f;
-    int last = -1, total = 0;
+    int last = -1, w = a.tri_ofs[q];
+    if (a.tri_ofs[q + 1] == w) return;
     while (true) {
         // the TRI_BUF smallest list indices above `last` among the ordered camera pairs of the track, ascending
         int nb = 0;
@@ -289,27 +307,48 @@ __global__ __launch_bounds__(TRI_THREADS) void k_init_pts3d(const TriArgs a) {
                 if (c == ci) ia = t;
                 if (c == cj) ib = t;
             }
-            const double xi = a.obs[2 * (size_t)(o0 + ia)], yi = a.obs[2 * (size_t)(o0 + ia) + 1];
-            const double xj = a.obs[2 * (size_t)(o0 + ib)], yj = a.obs[2 * (size_t)(o0 + ib) + 1];
-            double X[3];
-            if constexpr (MODEL == 2) {
-                if constexpr (TAB_LDS) tri_rpc(TabLds{s_tab + ci * TRI_RPC_STRIDE}, TabLds{s_tab + cj * TRI_RPC_STRIDE}, xi, yi, xj, yj, X);
-                else tri_rpc(TabGlobal{a.cams + (size_t)ci * 90}, TabGlobal{a.cams + (size_t)cj * 90}, xi, yi, xj, yj, X);
-            } else {
-                tri_linear(a.cams + (size_t)ci * 12, a.cams + (size_t)cj * 12, xi, yi, xj, yj, X);
-            }
-            // count += 1; avg = ((count - 1) * avg + new) / count, every operation rounded to float32 (ft_triangulate.py:77-81)
-            cnt += 1.f;
-            const float cm1 = cnt - 1.f;
-#pragma unroll
-            for (int d = 0; d < 3; ++d) avg[d] = tri_mean_update(avg[d], cm1, (float)X[d], cnt);
+            a.entries[w++] = make_int2(o0 + ia, o0 + ib);
         }
-        total += nb;
         if (nb < TRI_BUF) break;
         last = s_buf[nb - 1][tid];
     }
+}
+
+// MODEL 2 = rpc, else linear; TAB_LDS: RPC tables staged in (dynamic) LDS
+template <int MODEL, bool TAB_LDS>
+__global__ __launch_bounds__(256) void k_tri_points(const TriArgs a, int n_entries) {
+    extern __shared__ double s_tab[];
+    if constexpr (MODEL == 2 && TAB_LDS) {
+        for (int i = threadIdx.x; i < a.M * 90; i += 256) s_tab[(i / 90) * TRI_RPC_STRIDE + i % 90] = a.cams[i];
+        __syncthreads();
+    }
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < n_entries; e += gridDim.x * 256) {
+        const int2 ob = a.entries[e];
+        const int ci = a.cam_ind[ob.x], cj = a.cam_ind[ob.y];
+        const double2 pi = reinterpret_cast<const double2*>(a.obs)[ob.x], pj = reinterpret_cast<const double2*>(a.obs)[ob.y];
+        double X[3];
+        if constexpr (MODEL == 2) {
+            if constexpr (TAB_LDS) tri_rpc(TabLds{s_tab + ci * TRI_RPC_STRIDE}, TabLds{s_tab + cj * TRI_RPC_STRIDE}, pi.x, pi.y, pj.x, pj.y, X);
+            else tri_rpc(TabGlobal{a.cams + (size_t)ci * 90}, TabGlobal{a.cams + (size_t)cj * 90}, pi.x, pi.y, pj.x, pj.y, X);
+        } else {
+            tri_linear(a.cams + (size_t)ci * 12, a.cams + (size_t)cj * 12, pi.x, pi.y, pj.x, pj.y, X);
+        }
+        a.res[3 * (size_t)e] = (float)X[0]; a.res[3 * (size_t)e + 1] = (float)X[1]; a.res[3 * (size_t)e + 2] = (float)X[2];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_tri_mean(const TriArgs a) {
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= a.N) return;
+    float avg[3] = {0.f, 0.f, 0.f}, cnt = 0.f;
+    for (int e = a.tri_ofs[q]; e < a.tri_ofs[q + 1]; ++e) {
+        // count += 1; avg = ((count - 1) * avg + new) / count, every operation rounded to float32 (ft_triangulate.py:77-81)
+        cnt += 1.f;
+        const float cm1 = cnt - 1.f;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) avg[d] = tri_mean_update(avg[d], cm1, a.res[3 * (size_t)e + d], cnt);
+    }
     a.out[3 * (size_t)q] = avg[0]; a.out[3 * (size_t)q + 1] = avg[1]; a.out[3 * (size_t)q + 2] = avg[2];
-    if (a.n_tri) a.n_tri[q] = total;
 }
 
 }  // namespace satba

@@ -6,8 +6,8 @@ Outlier rejection between the soft-L1 and the L2 solve (the names of ref:bundle_
 device (satba_outliers, csrc/satba_outliers.h) and is index-exact against the reference (tests/golden/outliers_*.npz);
 `compute_obs_mask` is the same without the dense correspondence matrix (problems built by
 BundleAdjustmentParameters.from_observations have none), and `rm_outliers` rebuilds the parameters from the surviving
-observations the way ref:bundle_adjust/ba_outliers.py:61-109 does, except that the surviving points keep their current
-coordinates instead of being re-triangulated (triangulation is outside this package).
+observations the way ref:bundle_adjust/ba_outliers.py:61-109 does: the surviving tracks are re-triangulated from the observations
+left (satba.ft_triangulate, on the device) unless the caller hands over coordinates to carry on with (`pts3d=`).
 """
 import numpy as np
 
@@ -60,7 +60,9 @@ def rm_outliers(err, p, predef_thr=None, min_thr=1.0, verbose=False, pts3d=None)
     """
     New BundleAdjustmentParameters without the outlier observations (ref:bundle_adjust/ba_outliers.py:158-185 and :61-109):
     tracks left with fewer than two observations, or without any pair of pairs_to_triangulate, are dropped; fixed points
-    that survive stay fixed and first.  pts3d: (N, 3) coordinates of the current points to carry over (default p.pts3d).
+    that survive stay fixed and first.  The surviving tracks are re-triangulated from their remaining observations
+    (ref:bundle_adjust/ba_outliers.py:89-93: init_pts3d, fixed points keep p.pts3d); pts3d: (N, 3) coordinates to carry over
+    instead (e.g. the points of the solve that has just finished).
     """
     from .ba_params import BundleAdjustmentParameters
 
@@ -81,8 +83,17 @@ def rm_outliers(err, p, predef_thr=None, min_thr=1.0, verbose=False, pts3d=None)
     new_index = np.full(p.n_pts, -1, dtype=np.int64)
     new_index[left] = np.arange(left.size)
     sel = ok[pts_ind]
-    pts = np.asarray(p.pts3d if pts3d is None else pts3d)[left]
-    d = {"n_cam_fix": int(p.n_cam_fix), "n_pts_fix": int(np.sum(left < p.n_pts_fix)), "reduce": False, "verbose": verbose,
+    n_fix_new = int(np.sum(left < p.n_pts_fix))
+    if pts3d is None:
+        from .ft_triangulate import init_pts3d_from_observations
+
+        pts = init_pts3d_from_observations(new_index[pts_ind[sel]], cam_ind[sel], pts2d[sel], left.size, p.cameras, p.cam_model,
+                                           p.pairs_to_triangulate)
+        if n_fix_new > 0:
+            pts[:n_fix_new] = np.asarray(p.pts3d)[left[:n_fix_new]]
+    else:
+        pts = np.asarray(pts3d)[left]
+    d = {"n_cam_fix": int(p.n_cam_fix), "n_pts_fix": n_fix_new, "reduce": False, "verbose": verbose,
          "correction_params": p.cam_params_to_optimize, "ref_cam_weight": p.ref_cam_weight}
     new_p = BundleAdjustmentParameters.from_observations(new_index[pts_ind[sel]], cam_ind[sel], pts2d[sel], pts, p.cameras, p.cam_model,
                                                          p.pairs_to_triangulate, p.camera_centers, d)

@@ -215,18 +215,23 @@ def test_pipeline_shaped_driver_through_dropin_names(gpu, tmp_path):
     C = scene.to_dense_C()
     scene.pairs_to_triangulate = [(i, j) for i in range(8) for j in range(i + 1, 8)]  # every pair has enough baseline
     d = {"n_cam_fix": 0, "n_pts_fix": 0, "ref_cam_weight": 1.0, "correction_params": ["R"], "verbose": False}
-    p = ba_params.BundleAdjustmentParameters(C, scene.pts3d, scene.cameras, "affine", scene.pairs_to_triangulate, scene.camera_centers, d)
+    # ba_pipeline.py:292-307: the initial points are triangulated from the tracks
+    from satba import ft_triangulate
+
+    pts3d_init = ft_triangulate.init_pts3d(C, scene.cameras, "affine", scene.pairs_to_triangulate)
+    assert pts3d_init.dtype == np.float32 and np.median(np.linalg.norm(pts3d_init - scene.pts3d_true, axis=1)) < 100.0
+    p = ba_params.BundleAdjustmentParameters(C, pts3d_init, scene.cameras, "affine", scene.pairs_to_triangulate, scene.camera_centers, d)
     ba_iters = 0
     _, ba_sol, init_e, ba_e, iters = ba_core.run_ba_optimization(p, {"loss": "soft_l1", "f_scale": 1.0, "max_iter": 300, "verbose": 0}, False, False)
     ba_iters += iters
     n_before = p.n_obs
-    pts3d_now, _ = p.reconstruct_vars(ba_sol, scene.pts3d, scene.cameras)
-    p = ba_outliers.rm_outliers(ba_e, p, verbose=False, pts3d=pts3d_now[p.pts_prev_indices] if len(pts3d_now) != p.n_pts else pts3d_now)
+    p.reconstruct_vars(ba_sol, pts3d_init, scene.cameras)
+    p = ba_outliers.rm_outliers(ba_e, p, verbose=False)  # re-triangulates the surviving tracks (ba_outliers.py:89-93)
     removed = n_before - p.n_obs
     assert 0.5 * bad.sum() < removed < 3 * bad.sum() + 50  # the injected gross errors (and little else) are gone
     _, ba_sol, init_e2, ba_e, iters = ba_core.run_ba_optimization(p, None, False, False)
     ba_iters += iters
-    corrected_pts3d, corrected_cameras = p.reconstruct_vars(ba_sol, scene.pts3d, scene.cameras)
+    corrected_pts3d, corrected_cameras = p.reconstruct_vars(ba_sol, pts3d_init, scene.cameras)
     assert ba_e.mean() < 0.5 and len(corrected_cameras) == 8 and len(p.estimated_params) == 8
     ba_core.save_histogram_of_errors(str(tmp_path / "ba_figures" / "error_histograms.png"), init_e, ba_e)
     lat, lon, _ = geo_utils.ecef_to_latlon_custom(*np.asarray(scene.pts3d, dtype=np.float64).T)

@@ -83,7 +83,7 @@ def test_point_sharding_partitions_observations():
 
 def test_c_abi_library_exports_every_declared_symbol():
     header = open(os.path.join(ROOT, "include", "satba.h")).read()
-    declared = set(re.findall(r"\b(satba_[a-z_]+)\s*\(", header))
+    declared = set(re.findall(r"\b(satba_[a-z0-9_]+)\s*\(", header))
     assert declared == set(engine_hip.SYMBOLS), declared ^ set(engine_hip.SYMBOLS)
     lib = engine_hip.load_library()  # raises OSError if the library was not built: the build is part of the contract
     for sym in declared:
@@ -118,6 +118,28 @@ def test_product_path_fails_loudly_without_device_or_library(tmp_path):
         ba_core.fun(p.params_opt.copy(), p)
     with pytest.raises((engine_hip.SatbaError, RuntimeError)):
         ba_core.run_ba_optimization(p, {"verbose": 0}, False, False)
+    from satba import ft_triangulate
+
+    with pytest.raises((engine_hip.SatbaError, RuntimeError)):
+        ft_triangulate.init_pts3d(scene.to_dense_C(), scene.cameras, "affine", [(0, 1)])
+    with pytest.raises((engine_hip.SatbaError, RuntimeError)):
+        ft_triangulate.linear_triangulation_multiple_pts(scene.cameras[0], scene.cameras[1], np.zeros((2, 2)), np.zeros((2, 2)))
+
+
+def test_triangulation_arguments_are_checked_before_the_device_is_touched():
+    """satba_init_pts3d validates its lists on the host (SATBA_E_ARG -> ValueError), GPU or not."""
+    from satba import ft_triangulate
+
+    scene = synth.make_affine_scene(3, 20, 3, seed=9)
+    C = scene.to_dense_C()
+    with pytest.raises(ValueError):
+        ft_triangulate.init_pts3d(C, scene.cameras, "affine", [(1, 1)])
+    with pytest.raises(ValueError):
+        ft_triangulate.init_pts3d(C, scene.cameras, "affine", [(0, -2)])
+    with pytest.raises(ValueError):
+        ft_triangulate.init_pts3d_from_observations([0, 25], [0, 1], np.zeros((2, 2)), 20, scene.cameras, "affine", [(0, 1)])
+    with pytest.raises(ValueError):
+        ft_triangulate.init_pts3d_from_observations([0, 0], [0, 7], np.zeros((2, 2)), 20, scene.cameras, "affine", [(0, 1)])
 
 
 # ----------------------------------------------------------------------------- figure helpers of the drop-in surface
