@@ -240,6 +240,8 @@ __global__ __launch_bounds__(256) void k_tri_pairwise(long long n, const double*
 
 struct TriArgs {
     int M, N, n_pairs, cam_len;
+    int ordered;            // the pair list ascends lexicographically with c_i < c_j and the cameras of every track ascend: the nested
+                            // enumeration of a track's cameras already meets its pairs in list order
     const int* pt_ofs;      // N + 1
     const int* cam_ind;     // K, the cameras of a track (any order)
     const double* obs;      // K x 2
@@ -265,12 +267,25 @@ __global__ __launch_bounds__(256) void k_tri_count(const TriArgs a) {
     int total = 0;
     for (int ia = 0; ia < k; ++ia) {
         const int ca = a.cam_ind[o0 + ia];
-        for (int ib = 0; ib < k; ++ib) {
+        for (int ib = a.ordered ? ia + 1 : 0; ib < k; ++ib) {
             if (ib == ia) continue;
             for (int id = a.pair_first[(size_t)ca * a.M + a.cam_ind[o0 + ib]]; id >= 0; id = a.pair_next[id]) ++total;
         }
     }
     a.n_tri[q] = total;
+}
+// ordered lists (what a pipeline's pair selection produces): no sorting
+__global__ __launch_bounds__(256) void k_tri_list_ordered(const TriArgs a) {
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= a.N) return;
+    const int o0 = a.pt_ofs[q], k = a.pt_ofs[q + 1] - o0;
+    int w = a.tri_ofs[q];
+    if (a.tri_ofs[q + 1] == w) return;
+    for (int ia = 0; ia < k; ++ia) {
+        const int ca = a.cam_ind[o0 + ia];
+        for (int ib = ia + 1; ib < k; ++ib)
+            if (a.pair_first[(size_t)ca * a.M + a.cam_ind[o0 + ib]] >= 0) a.entries[w++] = make_int2(o0 + ia, o0 + ib);
+    }
 }
 
 __global__ __launch_bounds__(TRI_THREADS) void k_tri_list(const TriArgs a) {

@@ -85,6 +85,28 @@ def test_running_mean_is_bit_exact(gpu, model, M, N, opp):
     _assert_f32_close(got, T.init_pts3d(C, scene.cameras, model, pairs))
 
 
+@pytest.mark.parametrize("model", ["affine", "rpc"])
+def test_ordered_pair_lists_take_the_direct_path(gpu, model, monkeypatch):
+    """A pair list in ascending order (what a pipeline's pair selection produces) is enumerated without sorting: same bits as the
+    general path (SATBA_TRI_GENERAL) and as the oracle's loop fed with the device's triangulations."""
+    M, N = 10, 2500
+    scene = synth.make_scene(model, M, N, 6, seed=8)
+    ok = (lambda i, j: (i + j) % 2 == 1) if model == "rpc" else (lambda i, j: (i * 7 + j) % 5 != 0)
+    pairs = [(i, j) for i in range(M) for j in range(i + 1, M + 2) if ok(i, j)]  # includes pairs naming cameras >= M
+    args = (scene.pts_ind, scene.cam_ind, scene.pts2d, N, scene.cameras, model, pairs)
+    direct, info = FT.init_pts3d_from_observations(*args, return_info=True)
+    monkeypatch.setenv("SATBA_TRI_GENERAL", "1")
+    general, info_g = FT.init_pts3d_from_observations(*args, return_info=True)
+    monkeypatch.delenv("SATBA_TRI_GENERAL")
+    assert np.array_equal(direct, general) and np.array_equal(info["n_tri"], info_g["n_tri"]) and info["n_tri"].sum() > 3 * N
+
+    def dev_pair(c_i, c_j, oi, oj):
+        if model == "rpc":
+            return FT.rpc_triangulation(scene.cameras[c_i], scene.cameras[c_j], oi, oj)[0]
+        return FT.linear_triangulation_multiple_pts(scene.cameras[c_i], scene.cameras[c_j], oi, oj)
+    assert np.array_equal(direct, T.init_pts3d(scene.to_dense_C(), scene.cameras, model, pairs, triangulate=dev_pair))
+
+
 def test_pairwise_against_oracle_float64(gpu):
     for model in ("affine", "perspective", "rpc"):
         scene = synth.make_scene(model, 4, 4000, 4, seed=9)

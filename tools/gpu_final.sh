@@ -1,7 +1,7 @@
 #!/bin/bash
 # Runs ON the GPU box: the evidence set of a round -- GPU tests, the default bench line (with the CPU baseline leg),
 # the soft_l1 line and the other shapes, rocprofv3 --kernel-trace --stats of `python3 bench.py`, and the PMC passes the
-# roofline `traffic` figure comes from.  usage: tools/gpu_final.sh TAG [--cpu-c3]
+# roofline `traffic` figure comes from, and the triangulation evidence (tools/gpu_tri.sh).  usage: tools/gpu_final.sh TAG [--cpu-c3]
 tag=$1; shift
 out=$GRAFT_REPO_ROOT/gpurun_out/$tag
 mkdir -p $out
@@ -22,6 +22,7 @@ cd $GRAFT_REPO_ROOT
 bash tools/gpu_pmc.sh $tag/pmc C4 linear "k_linearize|k_schur_pairs|k_schur_diag|k_residual|k_backsub|k_jvp" > /dev/null 2>&1
 bash tools/gpu_pmc.sh $tag/pmc5 C5 linear "k_linearize|k_residual|k_schur_pairs" > /dev/null 2>&1
 bash tools/gpu_pmc_mem.sh $tag/pmcm C4 linear "k_schur_pairs<|k_schur_diag<" > /dev/null 2>&1
+bash tools/gpu_tri.sh $tag > $out/tri_summary.txt 2>&1
 find $out -name "*.db" -size +2M -delete
 head -14 $out/kernel_stats.txt
 cat $out/bench.json
