@@ -700,10 +700,15 @@ int satba_problem_create(const satba_problem_desc* d, satba_problem** out) {
         TRY(build_layout(p, d));
         // LDS budget of the observation kernels: camera-sum table first, then the camera constants, then the RPC tables
         const size_t budget = 150 * 1024;
-        while (p->lin_rep_shift < 4 && (p->M << (p->lin_rep_shift + 1)) <= 256) ++p->lin_rep_shift;  // >= ~128 rows
+        const size_t camc_b = sizeof(double) * (size_t)p->M * CAMC, rpc_b = sizeof(double) * (size_t)p->M * RPCS;
+        // replicas of the camera-sum table: same-address and same-bank atomics of a wave spread over them.  Measured at 200 cameras
+        // (k_linearize in the loop): 1 replica 0.1206 ms, 2: 0.1136, 4: 0.1117 although only one workgroup per CU fits then; at 50
+        // cameras 16 replicas are as good as or better than 4 (C3 0.038 vs 0.040, P3 0.040 vs 0.047, C5 0.118 vs 0.119)
+        while (p->lin_rep_shift < 4 && (p->M << (p->lin_rep_shift + 1)) <= 1024 &&
+               sizeof(double) * (size_t)(p->M << (p->lin_rep_shift + 1)) * cam_sum_stride(p->NP) + camc_b <= 112 * 1024)
+            ++p->lin_rep_shift;
         if (const char* rs = getenv("SATBA_LIN_REP")) p->lin_rep_shift = std::min(4, std::max(0, atoi(rs)));  // experiments
         const size_t acc_b = sizeof(double) * (size_t)(p->M << p->lin_rep_shift) * cam_sum_stride(p->NP);
-        const size_t camc_b = sizeof(double) * (size_t)p->M * CAMC, rpc_b = sizeof(double) * (size_t)p->M * RPCS;
         p->cam_sums_lds = (acc_b <= budget && !p->deterministic && !getenv("SATBA_CAM_SUMS")) ? 1 : 0;
         size_t used = p->cam_sums_lds ? acc_b : 0;
         p->camc_lds = (camc_b <= 48 * 1024 && used + camc_b <= budget && !getenv("SATBA_CAMC_GLOBAL")) ? 1 : 0;
