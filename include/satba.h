@@ -199,6 +199,10 @@ int satba_solve_lm(satba_problem *p, const satba_lm_opts *opts, satba_lm_stats *
 int satba_outliers(satba_problem *p, const double *err, double predef_thr, double min_thr, double *cam_thr, uint8_t *remove,
                    int64_t *n_removed);
 
+/* device-side copy of the current point (no host transfer): restore == 0 keeps x, restore != 0 returns to the kept x, as
+ * satba_set_x with the same vector would.  bench.py restarts its solve with it; a caller can use it to retry a solve. */
+int satba_snapshot_x(satba_problem *p, int32_t restore);
+
 /* ---- initial triangulation of the feature tracks, the step before the path.  Stand-alone: no problem handle.
  * cameras: n_cam x 12 (3 x 4 projection matrices, row-major; affine and perspective) or n_cam x SATBA_RPC_TABLE_LEN (rpc).
  *

@@ -95,6 +95,7 @@ struct satba_problem {
     double *d_xb_own = nullptr, *d_xb = nullptr;
     long long xb_len = 0;
     double* h_pin = nullptr;  // pinned staging for header reads
+    double* d_x0 = nullptr;   // satba_snapshot_x
     bool linearized = false, have_step = false;
     double create_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     std::vector<void*> allocs;
@@ -879,6 +880,22 @@ int satba_set_x(satba_problem* p, const double* host_x) {
     TRY(upload_permuted(p, host_x, p->d_x, p->n_c, 3));
     TRY(launch_cam_consts(p, false));
     p->linearized = false; p->have_step = false; p->prepared = false;
+    return 0;
+}
+
+// device-side copy of the current point: restore == 0 keeps it, restore != 0 goes back to it (no host transfer)
+int satba_snapshot_x(satba_problem* p, int32_t restore) {
+    if (!p) return fail(SATBA_E_ARG, "null handle");
+    HIP_TRY(hipSetDevice(p->device));
+    if (!restore) {
+        if (!p->d_x0) TRY(dev_alloc(p, &p->d_x0, p->n));
+        HIP_TRY(hipMemcpyAsync(p->d_x0, p->d_x, sizeof(double) * p->n, hipMemcpyDeviceToDevice, p->stream));
+        return 0;
+    }
+    if (!p->d_x0) return fail(SATBA_E_STATE, "restore before snapshot");
+    HIP_TRY(hipMemcpyAsync(p->d_x, p->d_x0, sizeof(double) * p->n, hipMemcpyDeviceToDevice, p->stream));
+    TRY(launch_cam_consts(p, false));
+    p->linearized = false; p->have_step = false; p->prepared = false; p->f_valid = false;
     return 0;
 }
 

@@ -31,7 +31,7 @@ SYMBOLS = [
     "satba_set_exchange", "satba_get_vector", "satba_time_kernel",
     "satba_packed_schur_len", "satba_pack_schur", "satba_unpack_schur",
     "satba_solve_lm", "satba_lm_step", "satba_profile_linearize", "satba_profile_read", "satba_outliers", "satba_layout_len", "satba_get_layout", "satba_get_info",
-    "satba_triangulate_pairwise", "satba_init_pts3d",
+    "satba_triangulate_pairwise", "satba_init_pts3d", "satba_snapshot_x",
 ]
 
 FLAG_DETERMINISTIC = 1
@@ -123,6 +123,7 @@ def load_library(path=None):
     lib.satba_layout_len.restype = C.c_int64
     lib.satba_get_layout.argtypes = [h, C.c_int32, C.c_int64, C.c_void_p]
     lib.satba_get_info.argtypes = [h, _dp, C.c_int32]
+    lib.satba_snapshot_x.argtypes = [h, C.c_int32]
     _fp = C.POINTER(C.c_float)
     lib.satba_triangulate_pairwise.argtypes = [C.c_int32, _dp, _dp, C.c_int64, _dp, _dp, _dp, _fp, C.c_int32, _fp]
     lib.satba_init_pts3d.argtypes = [C.c_int32, C.c_int32, C.c_int64, C.POINTER(C.c_int64), _ip, _dp, _dp, C.c_int32, _ip, _fp, _ip,
@@ -313,6 +314,10 @@ class HipEngine:
         n, ms = C.c_int64(), C.c_double()
         _check(self.lib, self.lib.satba_profile_read(self._h, C.byref(n), C.byref(ms)))
         return n.value, ms.value
+
+    def snapshot_x(self, restore=False):
+        """satba_snapshot_x: keep / return to a device-side copy of the current point."""
+        _check(self.lib, self.lib.satba_snapshot_x(self._h, 1 if restore else 0))
 
     def lm_step(self, first, Delta, lam_floor=0.0):
         """satba_lm_step: one fixed-work LM iteration, host side in C++ (single rank).  Returns a dict of the eight scalars."""

@@ -1,0 +1,17 @@
+import sys, time, os
+sys.path[:0] = ['/root/repo/sat-bundleadjust_amd', '/root/repo']
+import torch
+from satba import sharding, synth
+from satba.engine_hip import HipEngine
+import bench
+model, corr, n_cam, n_pts, opp = synth.CONFIGS["C4"]
+scene = synth.make_scene(model, n_cam, n_pts, opp, seed=1, sigma_theta=float(sys.argv[1]) if len(sys.argv) > 1 else 2e-6)
+p = synth.make_params(scene, {"correction_params": corr, "n_cam_fix": 1})
+eng = HipEngine(p, sharding.make_shard(p, 0, 1)); eng.configure("linear", 1.0)
+st = {"first": True, "accepted": 0, "fail": 0, "cost": None}
+for i in range(24):
+    torch.cuda.synchronize(); t = time.perf_counter()
+    r = eng.lm_step(st["first"], st.get("Delta", -1.0), 1e-14)
+    torch.cuda.synchronize(); dt = time.perf_counter() - t
+    st["first"] = False; st["Delta"] = r["Delta"]
+    print(i, "cost %.6f -> %.6f" % (r["cost"], r["cost_new"]), "acc", r["accepted"], "newton", r["newton"], "Delta %.3g" % r["Delta"], "ms %.3f" % (dt * 1e3))
