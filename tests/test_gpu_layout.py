@@ -138,6 +138,34 @@ def test_lm_step_matches_python_iteration(gpu):
     assert np.abs(xa - xb).max() <= 1e-12 * np.abs(xa).max()
 
 
+def test_snapshot_restores_the_point_and_the_solve_repeats(gpu):
+    """satba_snapshot_x (what bench.py restarts its solve with): the point comes back bit for bit, and in fixed-order mode the
+    solve that follows repeats the first one exactly."""
+    import bench
+
+    _, make_p, _, _ = cases.solve_case("affine_small_R")
+    p = make_p()
+    eng = HipEngine(p, deterministic=True)
+    eng.configure("linear", 1.0)
+    with pytest.raises(Exception):
+        eng.snapshot_x(True)  # nothing kept yet
+    x0 = eng.get_x()
+    eng.snapshot_x(False)
+    traces = []
+    for _ in range(2):
+        st = {"first": True, "accepted": 0, "fail": 0, "cost": None}
+        trace = []
+        for _ in range(4):
+            bench.lm_step_native(eng, st)
+            trace.append((st["cost"], st["Delta"], st["accepted"]))
+        traces.append((trace, eng.get_x()))
+        assert np.abs(traces[-1][1] - x0).max() > 0
+        eng.snapshot_x(True)
+        assert np.array_equal(eng.get_x(), x0)
+    assert traces[0][0] == traces[1][0] and np.array_equal(traces[0][1], traces[1][1])
+    eng.close()
+
+
 def test_solve_lm_rejects_multi_rank_handles_and_bad_loss(gpu):
     from satba import sharding
 
