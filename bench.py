@@ -244,6 +244,23 @@ def main():
         restart = max(1, int(ls.nfev) - 1)
         solve_stats = {"nfev": int(ls.nfev), "status": int(ls.status), "cost": float(ls.cost), "initial_cost": float(ls.initial_cost)}
         eng.snapshot_x(True)
+    elif args.restart_every < 0:
+        # several ranks (phase driver): the same count from the loop itself -- iterations until an accepted step reduces the cost
+        # by less than ftol x cost (scipy's check_termination), every rank sees the same all-reduced scalars
+        eng.snapshot_x(False)
+        n_it, prev = 0, None
+        while n_it < 300:
+            acc = st["accepted"]
+            step()
+            n_it += 1
+            if st["accepted"] > acc and prev is not None and prev - st["cost"] < 1e-4 * prev:
+                break
+            prev = st["cost"]
+        restart = n_it
+        solve_stats = {"nfev": n_it + 1, "status": 2 if n_it < 300 else 0, "cost": float(st["cost"]), "initial_cost": None}
+        eng.snapshot_x(True)
+        st.update(first=True, accepted=0)
+        st.pop("interior", None)
     elif restart:
         eng.snapshot_x(False)
     n_step = [0]
