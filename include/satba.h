@@ -225,6 +225,18 @@ int satba_init_pts3d(int32_t cam_model, int32_t n_cam, int64_t n_pts, const int6
                      const double *obs, const double *cameras, int32_t n_pairs, const int32_t *pairs, float *pts3d,
                      int32_t *n_tri, int32_t device, int32_t reps, float *kernel_ms);
 
+/* ---- RPC re-fit after the solve, the step behind the path.  Stand-alone: no problem handle.
+ * satba_rpc_fit replaces ba_rpcfit.weighted_lsq (ba_rpcfit.py:88-153, with initialize_rpc / scaling_params :156-198), batched over
+ * cameras: target (host, n_cam x n_samples x 2: col, row), locs (host, n_cam x n_samples x 3: lon, lat, alt) -> tables (host,
+ * n_cam x SATBA_RPC_TABLE_LEN records of the fitted models), rmse (host, n_cam, may be NULL: the loop's last RMSE in pixels),
+ * iters (host, n_cam, may be NULL: re-weighted passes that ran).  h, tol, max_iter: the reference's defaults are 1e-3, 1e-2, 20.
+ * satba_rpc_localization replaces rpcm.RPCModel.localization as ba_rpcfit.py:245,323 calls it: image points at given altitudes
+ * -> lon, lat by inverting the projection of one camera (table: one record). */
+int satba_rpc_fit(int32_t n_cam, int32_t n_samples, const double *target, const double *locs, double h, double tol,
+                  int32_t max_iter, double *tables, double *rmse, int32_t *iters, int32_t device);
+int satba_rpc_localization(const double *table, int64_t n, const double *col, const double *row, const double *alt, double *lon,
+                           double *lat, int32_t device);
+
 /* ---- inspection entry points (parity tests; not used by the solver loop) */
 /* index structures built by satba_problem_create, as int32 arrays (SATBA_LAY_PAIR_OFS: int64): n must equal satba_layout_len */
 enum { SATBA_LAY_PERM = 0, SATBA_LAY_RANK, SATBA_LAY_PT_CNT, SATBA_LAY_SLICE_BASE, SATBA_LAY_E_CAM, SATBA_LAY_OBS_POS, SATBA_LAY_CAM_OFS,

@@ -24,6 +24,7 @@
 #include "satba_lm.h"
 #include "satba_outliers.h"
 #include "satba_triangulate.h"
+#include "satba_rpcfit.h"
 #include "satba_schur.h"
 
 using namespace satba;
@@ -1463,5 +1464,6 @@ int satba_time_kernel(satba_problem* p, int32_t phase, int32_t reps, float* ms_a
 
 #include "satba_outliers_api.inc"
 #include "satba_triangulate_api.inc"
+#include "satba_rpcfit_api.inc"
 
 }  // extern "C"

@@ -67,3 +67,11 @@ def apply_rpc_projection(rpc, pts3d):
     lat, lon, alt = geo_utils.ecef_to_latlon_custom(pts3d[:, 0], pts3d[:, 1], pts3d[:, 2])
     col, row = rpc.projection(lon, lat, alt)
     return np.vstack((col, row)).T
+
+
+def generate_point_mesh(col_range, row_range, alt_range):
+    """(col, row, alt) coordinates of the n_col x n_row x n_alt grid given by three (min, max, n) triplets, flattened with the
+    columns running fastest and the altitudes slowest (ref:bundle_adjust/cam_utils.py:280-306)."""
+    cols, rows, alts = [np.linspace(v[0], v[1], int(v[2])) for v in (col_range, row_range, alt_range)]
+    a, r, c = np.meshgrid(alts, rows, cols, indexing="ij")
+    return c.reshape(-1), r.reshape(-1), a.reshape(-1)

@@ -73,6 +73,44 @@ class RPCModel:
         row = np.tensordot(self.row_num, m, 1) / np.tensordot(self.row_den, m, 1)
         return col * self.col_scale + self.col_offset, row * self.row_scale + self.row_offset
 
+    @classmethod
+    def from_table(cls, t):
+        """inverse of to_table"""
+        t = np.asarray(t, dtype=np.float64)
+        return cls(col_num=t[0:20], col_den=t[20:40], row_num=t[40:60], row_den=t[60:80], lon_offset=t[80], lon_scale=t[81],
+                   lat_offset=t[82], lat_scale=t[83], alt_offset=t[84], alt_scale=t[85], col_offset=t[86], col_scale=t[87],
+                   row_offset=t[88], row_scale=t[89])
+
+    def localization(self, col, row, alt):
+        """(col, row [px], alt [m]) -> (lon, lat) degrees by inverting the projection on the device (satba_rpc_localization); same
+        signature as rpcm.RPCModel.localization for a model without inverse coefficients (call sites ref:bundle_adjust/ba_rpcfit.py:245,323)."""
+        import ctypes as C
+
+        from . import engine_hip as E
+
+        lib = E.load_library()
+        col, row, alt = np.broadcast_arrays(np.asarray(col, dtype=np.float64), np.asarray(row, dtype=np.float64), np.asarray(alt, dtype=np.float64))
+        shape = col.shape
+        c, r, a = [np.ascontiguousarray(v.reshape(-1)) for v in (col, row, alt)]
+        lon, lat = np.zeros_like(c), np.zeros_like(c)
+        tab = np.ascontiguousarray(self.to_table())
+        import os
+        E._check(lib, lib.satba_rpc_localization(E._ptr(tab), c.size, E._ptr(c), E._ptr(r), E._ptr(a), E._ptr(lon), E._ptr(lat),
+                                                 int(os.environ.get("LOCAL_RANK", "0"))))
+        return lon.reshape(shape), lat.reshape(shape)
+
+    def write_to_file(self, path):
+        """The `KEY: value unit` text format of the reference's outputs (ref:tests/data/outdir/ba_bruteforce/rpcs_adj/*.rpc_adj,
+        written there by rpcm.RPCModel.write_to_file from ref:bundle_adjust/ba_pipeline.py:379-427); read back by from_file."""
+        units = {"LINE_OFF": "pixels", "SAMP_OFF": "pixels", "LAT_OFF": "degrees", "LONG_OFF": "degrees", "HEIGHT_OFF": "meters",
+                 "LINE_SCALE": "pixels", "SAMP_SCALE": "pixels", "LAT_SCALE": "degrees", "LONG_SCALE": "degrees", "HEIGHT_SCALE": "meters"}
+        with open(path, "w") as f:
+            for key, attr in _SCALARS:
+                f.write("{}: {:.12f} {}\n".format(key, getattr(self, attr), units[key]))
+            for key, attr in _POLYS:
+                for i, v in enumerate(getattr(self, attr)):
+                    f.write("{}_{}: {:.12f}\n".format(key, i + 1, v))
+
     def to_table(self):
         """[col_num(20) col_den(20) row_num(20) row_den(20) lon_off lon_scale lat_off lat_scale alt_off alt_scale
         col_off col_scale row_off row_scale] -- the per-camera record of include/satba.h."""

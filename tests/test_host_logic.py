@@ -212,3 +212,29 @@ def test_host_elbow_matches_reference_vectors():
             continue
         e, s = ba_outliers.get_elbow_value(v)
         assert e == elbow and bool(s) == bool(ok)
+
+
+def test_output_writers(tmp_path):
+    """pts3d_adj.ply, cam_params/*.params and rpcs_adj/*.rpc_adj in the reference's layouts (ref:bundle_adjust/loader.py:232-238,384-406,
+    ref:bundle_adjust/ba_pipeline.py:606-620)."""
+    from satba import loader
+    from satba.rpc_model import RPCModel
+
+    pts = np.array([[1704018.25, -5904285.5, 1201842.125], [1.5, -2.25, 3.0]])
+    ply = tmp_path / "pts3d_adj.ply"
+    loader.write_point_cloud_ply(str(ply), pts)
+    text = ply.read_text().splitlines()
+    assert text[:7] == ["ply", "format ascii 1.0", "element vertex 2", "property float x", "property float y", "property float z", "end_header"]
+    assert text[7] == "1704018.25 -5904285.5 1201842.125" and len(text) == 9
+    assert np.array_equal(loader.read_point_cloud_ply(str(ply)), pts)
+    loader.write_point_cloud_ply(str(ply), pts, color=(255, 0, 7))
+    text = ply.read_text().splitlines()
+    assert text[12] == "end_header" and text[13].endswith(" 255 0 7 255") and np.array_equal(loader.read_point_cloud_ply(str(ply)), pts)
+    est = [{"R": np.array([1e-6, -2e-6, 3e-6]), "T": np.array([0.0, 0.0, 0.0]), "C": np.array([1.0, 2.0, 3.0])}]
+    loader.save_estimated_params(str(tmp_path), ["img_a"], est)
+    lines = (tmp_path / "cam_params" / "img_a.params").read_text().splitlines()
+    assert lines[0] == "R" and lines[1] == "0.0000010000000000 -0.0000020000000000 0.0000030000000000" and lines[4] == "C" and len(lines) == 6
+    r = RPCModel.from_file(synth.default_rpc_files()[0])
+    fn = tmp_path / "rpcs_adj" / "img_a.rpc_adj"
+    loader.save_rpcs([str(fn)], [r])
+    assert np.allclose(RPCModel.from_file(str(fn)).to_table(), r.to_table(), rtol=1e-10, atol=1e-12)

@@ -280,3 +280,36 @@ def test_rpc_triangulation_oracle_against_reference_c():
     assert np.abs(lla[:, :2] - out[:, :2]).max() < 1e-12 and np.abs(lla[:, 2] - out[:, 2]).max() < 1e-6
     assert np.abs(e - err[:, 0]).max() < 1e-6
     assert np.abs(out[:, 2] - alt).max() < 5.0  # and the library triangulates the scene it was given
+
+
+# ---------------------------------------------------------------------------------------------- RPC re-fit
+@pytest.mark.parametrize("name", ["rpc0", "rpc1", "affine"])
+def test_rpcfit_oracle_reproduces_reference(name):
+    """oracle/rpcfit_oracle.weighted_lsq vs the vectors of the imported reference function (tools/gen_golden.py rpcfit): same numpy
+    calls, so coefficients and errors agree to rounding."""
+    from oracle import rpcfit_oracle as F
+
+    g = np.load(os.path.join(cases.GOLDEN, "rpcfit.npz"))
+    m, _ = F.weighted_lsq(g[name + "_target"], g[name + "_locs"])
+    tab = np.concatenate([m["col_num"], m["col_den"], m["row_num"], m["row_den"],
+                          [m["lon_offset"], m["lon_scale"], m["lat_offset"], m["lat_scale"], m["alt_offset"], m["alt_scale"],
+                           m["col_offset"], m["col_scale"], m["row_offset"], m["row_scale"]]])
+    assert np.abs(tab - g[name + "_table"]).max() <= 1e-9 * np.abs(g[name + "_table"]).max()
+    assert np.abs(F.check_errors(m, g[name + "_locs"], g[name + "_target"]) - g[name + "_err"]).max() < 1e-6
+    # and satba.rpc_model.RPCModel evaluates the fitted model like the reference's container did
+    r = RPCModel.from_table(g[name + "_table"])
+    col, row = r.projection(*g[name + "_locs"].T)
+    assert np.abs(np.linalg.norm(np.stack([col, row], 1) - g[name + "_target"], axis=1) - g[name + "_err"]).max() < 1e-9
+
+
+def test_rpc_text_round_trip(tmp_path):
+    """RPCModel.write_to_file writes the `KEY: value unit` format of the reference's .rpc_adj outputs; from_file reads it back."""
+    for k, path in enumerate(synth.default_rpc_files()):
+        r = RPCModel.from_file(path)
+        out = tmp_path / "{}.rpc_adj".format(k)
+        r.write_to_file(str(out))
+        lines = out.read_text().splitlines()
+        assert len(lines) == 90 and lines[0].startswith("LINE_OFF: ") and lines[0].endswith(" pixels") and lines[10].startswith("LINE_NUM_COEFF_1: ")
+        assert lines[89].startswith("SAMP_DEN_COEFF_20: ")
+        back = RPCModel.from_file(str(out))
+        assert np.abs(back.to_table() - r.to_table()).max() <= 1e-12 * 1.0 + 1e-12 * np.abs(r.to_table()).max()

@@ -392,9 +392,63 @@ def golden_init_pts3d():
     save("init_pts3d", **out)
 
 
+def rpcfit_cases():
+    """(name, target (n, 2), input_locs (n, 3)) of the RPC re-fit fixtures: a 10 x 10 x 10 grid over the footprint of a shipped RPC,
+    projected through the RPC behind a small corrective rotation (what ba_rpcfit.fit_Rt_corrected_rpc feeds to weighted_lsq), and a
+    7 x 7 x 7 grid through an affine camera (fit_rpc_from_projection_matrix)."""
+    from satba import geo_utils as G
+    from satba.ba_core import adjust_pts3d
+    from satba.rpc_model import RPCModel
+
+    out = []
+    for k, f in enumerate(synth.default_rpc_files()):
+        r = RPCModel.from_file(f)
+        lon, lat, alt = [a.reshape(-1) for a in np.meshgrid(np.linspace(r.lon_offset - 0.9 * r.lon_scale, r.lon_offset + 0.9 * r.lon_scale, 10),
+                                                            np.linspace(r.lat_offset - 0.9 * r.lat_scale, r.lat_offset + 0.9 * r.lat_scale, 10),
+                                                            np.linspace(r.alt_offset - r.alt_scale, r.alt_offset + r.alt_scale, 10), indexing="ij")]
+        X = np.stack(G.latlon_to_ecef_custom(lat, lon, alt), 1)
+        up = X.mean(0) / np.linalg.norm(X.mean(0))
+        Rt = np.concatenate([[3e-6 * (k + 1), -2e-6, 4e-6], [0.0, 0.0, 0.0], X.mean(0) + 5e5 * up]).reshape(1, 9)
+        Xa = adjust_pts3d(X, Rt)
+        la, lo, al = G.ecef_to_latlon_custom(Xa[:, 0], Xa[:, 1], Xa[:, 2])
+        col, row = r.projection(lo, la, al)
+        out.append(("rpc%d" % k, np.stack([col, row], 1), np.stack([lon, lat, alt], 1)))
+    scene = synth.make_scene("affine", 3, 50, 3, seed=4)
+    la, lo, al = G.ecef_to_latlon_custom(*scene.pts3d_true.T)
+    lon, lat, alt = [a.reshape(-1) for a in np.meshgrid(np.linspace(lo.min(), lo.max(), 7), np.linspace(la.min(), la.max(), 7),
+                                                        np.linspace(al.min() - 500, al.max() + 500, 7), indexing="ij")]
+    X = np.stack(G.latlon_to_ecef_custom(lat, lon, alt), 1)
+    P = np.asarray(scene.cameras[0])
+    proj = P @ np.hstack([X, np.ones((len(X), 1))]).T
+    out.append(("affine", (proj[:2] / proj[2]).T, np.stack([lon, lat, alt], 1)))
+    return out
+
+
+def golden_rpcfit():
+    """ref:bundle_adjust/ba_rpcfit.py:88-153 weighted_lsq (+ check_errors) through the imported reference module."""
+    from satba.rpc_model import RPCModel
+
+    class RefRpc(RPCModel):  # rpcm.RPCModel as ba_rpcfit.initialize_rpc uses it: built from a dict of "0" strings, then filled
+        def __init__(self, d, dict_format="geotiff"):
+            for a in ("row_offset", "col_offset", "lat_offset", "lon_offset", "alt_offset", "row_scale", "col_scale", "lat_scale",
+                      "lon_scale", "alt_scale"):
+                setattr(self, a, 0.0)
+            for a in ("row_num", "row_den", "col_num", "col_den"):
+                setattr(self, a, [0.0] * 20)
+    sys.modules["rpcm"].RPCModel = RefRpc
+    fit = importlib.import_module("bundle_adjust.ba_rpcfit")
+    out = {}
+    for name, target, locs in rpcfit_cases():
+        r = fit.weighted_lsq(target.copy(), locs.copy())
+        err = fit.check_errors(r, locs, target)
+        out.update({name + "_target": target, name + "_locs": locs, name + "_err": err, name + "_table": r.to_table()})
+        print("rpcfit", name, "n", len(target), "fit error max / median [px]: %.3g / %.3g" % (err.max(), np.median(err)))
+    save("rpcfit", **out)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["fun", "params", "solves", "tight2", "outliers", "init_pts3d"]
+    which = sys.argv[1:] or ["fun", "params", "solves", "tight2", "outliers", "init_pts3d", "rpcfit"]
     if "fun" in which:
         golden_fun_and_jac()
     if "params" in which:
@@ -407,3 +461,5 @@ if __name__ == "__main__":
         golden_outliers()
     if "init_pts3d" in which:
         golden_init_pts3d()
+    if "rpcfit" in which:
+        golden_rpcfit()
