@@ -128,3 +128,34 @@ def fit_rpc_from_projection_matrix(P, global_transform, original_rpc, crop_offse
     shift = np.array([crop_offset["col0"], crop_offset["row0"]], dtype=np.float64)
     return _fit_with_growing_margin(lambda X: cam_utils.apply_projection_matrix(np.asarray(P, dtype=np.float64), X) + shift, original_rpc,
                                     crop_offset, alt_range, n_samples, global_transform)
+
+
+def fit_Rt_corrected_rpcs(Rt_vecs, global_transform, original_rpcs, crop_offsets, n_samples=10):
+    """
+    fit_Rt_corrected_rpc for a list of cameras with ONE fit launch per margin round (what ba_pipeline.save_corrected_rpcs loops
+    over, ref:bundle_adjust/ba_pipeline.py:406-423).  Returns a list of (rpc_calib, err, margin).
+    """
+    M = len(original_rpcs)
+    out, margins, todo = [None] * M, [10] * M, list(range(M))
+    while todo:
+        grids, targets, locs = [], [], []
+        for k in todo:
+            r, crop = original_rpcs[k], crop_offsets[k]
+            alt_range = [r.alt_offset - r.alt_scale, r.alt_offset + r.alt_scale, n_samples]
+            grid, pts3d, input_locs = _grid_through_rpc(r, crop, alt_range, margins[k], n_samples, global_transform)
+            Rt = np.asarray(Rt_vecs[k], dtype=np.float64).reshape(1, 9)
+            grids.append(grid); locs.append(input_locs)
+            targets.append(cam_utils.apply_rpc_projection(r, ba_core.adjust_pts3d(pts3d, Rt)))
+        rpcs = weighted_lsq_batch(np.stack(targets), np.stack(locs))
+        nxt = []
+        for k, rpc, grid, target, input_locs in zip(todo, rpcs, grids, targets, locs):
+            crop = crop_offsets[k]
+            x0, y0, w, h = crop["col0"], crop["row0"], crop["width"], crop["height"]
+            corners = np.array([[x0, y0], [x0, y0 + h], [x0 + w, y0 + h], [x0 + w, y0]], dtype=np.float64)
+            if margins[k] > 1000 or check_correspondences_are_good(cam_utils.apply_rpc_projection(rpc, grid), corners):
+                out[k] = (rpc, check_errors(rpc, input_locs, target), margins[k])
+            else:
+                margins[k] *= 2
+                nxt.append(k)
+        todo = nxt
+    return out

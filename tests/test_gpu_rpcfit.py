@@ -103,6 +103,13 @@ def test_fit_Rt_corrected_rpc_reproduces_the_corrected_projection(gpu):
     got = cam_utils.apply_rpc_projection(rpc, pts)
     assert np.abs(got - want).max() < 0.05  # pixels; the correction itself moves the points by tens of pixels
     assert np.abs(cam_utils.apply_rpc_projection(r, pts) - want).max() > 1.0
+    # several cameras in one launch: the same models as one by one
+    r1 = RPCModel.from_file(synth.default_rpc_files()[1])
+    crop1 = {"col0": 0, "row0": 0, "width": int(2 * r1.col_scale), "height": int(2 * r1.row_scale)}
+    many = ba_rpcfit.fit_Rt_corrected_rpcs([Rt, Rt * np.r_[2.0 * np.ones(3), np.ones(6)]], None, [r, r1], [crop, crop1])
+    assert np.array_equal(many[0][0].to_table(), rpc.to_table()) and many[0][2] == margin and np.array_equal(many[0][1], err)
+    one = ba_rpcfit.fit_Rt_corrected_rpc(Rt * np.r_[2.0 * np.ones(3), np.ones(6)], None, r1, crop1, pts)
+    assert np.array_equal(many[1][0].to_table(), one[0].to_table())
     # the affine route (ba_rpcfit.py:201-267): an RPC copying a projection matrix that maps into a crop at (col0, row0)
     scene = synth.make_scene("affine", 2, 300, 2, seed=3)
     P = np.asarray(scene.cameras[0], dtype=np.float64).copy()
