@@ -128,3 +128,48 @@ def test_fit_Rt_corrected_rpc_reproduces_the_corrected_projection(gpu):
     rpc2, err2, margin2 = ba_rpcfit.fit_rpc_from_projection_matrix(P, None, base, crop, X, n_samples=8)
     assert err2.shape == (512,) and err2.max() < 0.05 and margin2 >= 10  # the regularised fit (h = 1e-3) leaves ~1e-2 px on this box
     assert np.abs(cam_utils.apply_rpc_projection(rpc2, X) - (proj + shift)).max() < 0.05
+
+
+def test_rpc_pipeline_from_tracks_to_refitted_rpcs(gpu, tmp_path):
+    """The reference's main use (tests/config1.json: cam_model "rpc") through the drop-in names, ref:bundle_adjust/ba_pipeline.py:700-728
+    minus feature tracking: triangulate the tracks -> BundleAdjustmentParameters -> soft L1 -> outlier rejection (re-triangulates) ->
+    L2 -> reconstruct_vars -> re-fit one RPC per camera -> write / read .rpc_adj.  The re-fitted RPCs, applied to the adjusted points
+    with no correction, must explain the observations as well as the corrected cameras do."""
+    from satba import ba_core, ba_outliers, ba_params, ft_triangulate, loader
+
+    M = 4
+    scene = synth.make_scene("rpc", M, 1200, 4, seed=12, sigma_theta=5e-6)
+    rng = np.random.default_rng(2)
+    bad = rng.random(scene.n_obs) < 0.02
+    scene.pts2d[bad] += rng.normal(0, 25.0, (int(bad.sum()), 2))
+    C = scene.to_dense_C()
+    pairs = [(i, j) for i in range(M) for j in range(i + 1, M) if (i + j) % 2 == 1]  # the two shipped models alternate
+    pts0 = ft_triangulate.init_pts3d(C, scene.cameras, "rpc", pairs)
+    keep = np.abs(pts0).max(axis=1) > 0  # tracks seen only by same-model cameras have no pair
+    C, pts0 = C[:, keep], pts0[keep]
+    d = {"n_cam_fix": 0, "n_pts_fix": 0, "ref_cam_weight": 1.0, "correction_params": ["R"], "verbose": False}
+    p = ba_params.BundleAdjustmentParameters(C, pts0, scene.cameras, "rpc", pairs, scene.camera_centers, d)
+    _, sol, e0, e1, _ = ba_core.run_ba_optimization(p, {"loss": "soft_l1", "f_scale": 1.0, "max_iter": 300, "verbose": 0}, False, False)
+    p.reconstruct_vars(sol, pts0, scene.cameras)
+    n_before = p.n_obs
+    p = ba_outliers.rm_outliers(e1, p, verbose=False)
+    assert 0.3 * bad[np.isin(scene.pts_ind, np.nonzero(keep)[0])].sum() < n_before - p.n_obs
+    _, sol, e2, e3, _ = ba_core.run_ba_optimization(p, None, False, False)
+    pts_ba, cams_ba = p.reconstruct_vars(sol, np.asarray(pts0, dtype=np.float64), list(scene.cameras))
+    assert e3.mean() < 0.5 and e3.mean() < 0.2 * e0.mean()
+    crops = [{"col0": 0, "row0": 0, "width": int(2 * r.col_scale), "height": int(2 * r.row_scale)} for r in scene.cameras]
+    fits = ba_rpcfit.fit_Rt_corrected_rpcs([np.asarray(c).reshape(1, 9) for c in cams_ba], None, scene.cameras, crops)
+    names = [str(tmp_path / "rpcs_adj" / "im{}.rpc_adj".format(k)) for k in range(M)]
+    loader.save_rpcs(names, [f[0] for f in fits])
+    loader.write_point_cloud_ply(str(tmp_path / "pts3d_adj.ply"), p.pts3d_ba)
+    loader.save_estimated_params(str(tmp_path), ["im{}".format(k) for k in range(M)], p.estimated_params)
+    new_rpcs = [RPCModel.from_file(fn) for fn in names]
+    # the observations through the re-fitted models, no correction any more
+    err_new = np.zeros(p.n_obs)
+    for k in range(M):
+        sel = p.cam_ind == k
+        proj = cam_utils.apply_rpc_projection(new_rpcs[k], p.pts3d_ba[p.pts_ind[sel]])
+        err_new[sel] = np.linalg.norm(proj - p.pts2d[sel], axis=1)
+        assert fits[k][1].max() < 0.05
+    assert abs(err_new.mean() - e3.mean()) < 0.02, (err_new.mean(), e3.mean())
+    assert np.abs(loader.read_point_cloud_ply(str(tmp_path / "pts3d_adj.ply")) - p.pts3d_ba).max() < 1e-6
