@@ -48,9 +48,10 @@ __device__ inline void tri_null_vector4(double (&a)[4][4], double (&x)[4]) {
                 for (int r = 0; r < 4; ++r) { al += a[r][p] * a[r][p]; be += a[r][q] * a[r][q]; ga += a[r][p] * a[r][q]; }
                 if (fabs(ga) > 1e-16 * sqrt(al * be) && ga != 0.0) {
                     rotated = true;
-                    const double zeta = (be - al) / (2.0 * ga);
-                    const double t = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-                    const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
+                    // t = sign(zeta) / (|zeta| + sqrt(1 + zeta^2)), zeta = (be - al) / (2 ga), with one division and one square root
+                    const double d = be - al, g2 = 2.0 * ga;
+                    const double t = copysign(1.0, d) * g2 / (fabs(d) + sqrt(d * d + g2 * g2));
+                    const double c = rsqrt(1.0 + t * t), s = c * t;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const double ap = a[r][p], aq = a[r][q], vp = v[r][p], vq = v[r][q];
