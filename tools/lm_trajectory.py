@@ -1,9 +1,14 @@
-import sys, time, os
-sys.path[:0] = ['/root/repo/sat-bundleadjust_amd', '/root/repo']
+"""Runs ON the GPU box: the LM iterations of the headline shape from x0, one line each (cost before / after, accepted, interior
+Newton step, new trust radius, wall time with a synchronisation around the step).   usage: python tools/lm_trajectory.py [sigma_theta]"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [os.path.join(ROOT, 'sat-bundleadjust_amd'), ROOT]
 import torch
 from satba import sharding, synth
 from satba.engine_hip import HipEngine
-import bench
 model, corr, n_cam, n_pts, opp = synth.CONFIGS["C4"]
 scene = synth.make_scene(model, n_cam, n_pts, opp, seed=1, sigma_theta=float(sys.argv[1]) if len(sys.argv) > 1 else 2e-6)
 p = synth.make_params(scene, {"correction_params": corr, "n_cam_fix": 1})
