@@ -10,7 +10,7 @@ import torch
 from satba import sharding, synth
 from satba.engine_hip import HipEngine
 model, corr, n_cam, n_pts, opp = synth.CONFIGS["C4"]
-scene = synth.make_scene(model, n_cam, n_pts, opp, seed=1, sigma_theta=float(sys.argv[1]) if len(sys.argv) > 1 else 2e-6)
+scene = synth.make_scene(model, n_cam, n_pts, opp, seed=1, sigma_theta=float(sys.argv[1]) if len(sys.argv) > 1 else 1e-4)  # bench.py default
 p = synth.make_params(scene, {"correction_params": corr, "n_cam_fix": 1})
 eng = HipEngine(p, sharding.make_shard(p, 0, 1)); eng.configure("linear", 1.0)
 st = {"first": True, "accepted": 0, "fail": 0, "cost": None}
