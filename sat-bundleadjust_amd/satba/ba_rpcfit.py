@@ -44,6 +44,8 @@ def weighted_lsq_batch(targets, input_locs, h=1e-3, tol=1e-2, max_iter=20, retur
     tables = np.zeros((M, 90)); rmse = np.zeros(M); iters = np.zeros(M, dtype=np.int32)
     E._check(lib, lib.satba_rpc_fit(M, n, E._ptr(t), E._ptr(x), float(h), float(tol), int(max_iter), E._ptr(tables), E._ptr(rmse),
                                     E._ptr(iters, E._ip), int(os.environ.get("LOCAL_RANK", "0"))))
+    if not np.isfinite(tables).all():  # degenerate samples (a constant coordinate, fewer distinct points than unknowns): the
+        raise np.linalg.LinAlgError("Singular matrix")  # reference's numpy.linalg.inv raises the same
     rpcs = [RPCModel.from_table(tab) for tab in tables]
     return (rpcs, {"rmse": rmse, "iters": iters}) if return_info else rpcs
 

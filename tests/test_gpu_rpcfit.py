@@ -55,6 +55,10 @@ def test_batch_equals_single_fits(gpu):
         assert info["iters"][k] == it and abs(info["rmse"][k] - F.rmse_row_col(m, x[k], t[k])) < 1e-3
     with pytest.raises(ValueError):
         ba_rpcfit.weighted_lsq(t[0][:10], x[0][:10])  # fewer samples than unknowns
+    flat = x[0].copy(); flat[:, 2] = 100.0  # constant altitude: zero scale, singular normal equations
+    with pytest.raises(np.linalg.LinAlgError):
+        ba_rpcfit.weighted_lsq(t[0], flat)
+    assert ba_rpcfit.weighted_lsq_batch(t[:0], x[:0]) == []
     bad = t[0].copy(); bad[3, 0] = np.nan
     with pytest.raises(ValueError):
         ba_rpcfit.weighted_lsq(bad, x[0])
