@@ -270,3 +270,30 @@ def test_pipeline_shaped_driver_through_dropin_names(gpu, tmp_path):
         ba_core.save_heatmap_of_reprojection_error(str(path), p, e, fp, None, smooth=2, global_transform=None)
         assert path.stat().st_size > 1000
     assert (tmp_path / "ba_figures" / "error_histograms.png").stat().st_size > 1000 and ba_iters > 2
+
+
+@pytest.mark.parametrize("driver", ["native", "python"])
+def test_bench_line_contract(gpu, driver):
+    """bench.py on the small shape, as a child process: one JSON line with the keys the driver's contract names, both host drivers."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--shape", "C2", "--steps", "8", "--warmup", "2", "--cpu-sample-pts", "0",
+                          "--driver", driver], capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "restart_every"):  # cpu_baseline: the default run's extra leg, skipped here (--cpu-sample-pts 0)
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 8 and d["warmup"] == 2 and d["dtype"] == "f64" and d["vs_baseline"] is None
+    assert d["unit"] == "LM iters/sec" and d["higher_is_better"] is True and "workload" in d["config"]
+    assert abs(d["value"] - 1000.0 / d["ms_per_step"]) < 1e-6 * d["value"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and 0.0 < r["frac"] < 1.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert r["launches_timed"] == 8 and d["restart_every"] >= 1 and d["host_driver"] == driver
+    assert d["accepted_steps"] >= 4  # restarts keep the timed steps productive
