@@ -35,16 +35,30 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 
-# HBM bytes per k_linearize launch from rocprofv3 PMC passes of this same command (profiles/r2_pmc_hbm_traffic.txt):
-# 2 x FETCH_SIZE (gfx950 counts 128-B requests as 64 B, MI355X_MICROARCH.md section HBM) + WRITE_SIZE.
-# PMC counters cannot be read from inside an unprofiled run, so the committed measurement is quoted for the shape
-# it was taken on (one GPU) and the field is null otherwise.
-def profiled_traffic(shape, world):
-    path = os.path.join(ROOT, "profiles", "r2_pmc_hbm_traffic.json")
+# HBM bytes per k_linearize launch from rocprofv3 PMC passes of this same command (profiles/r3_pmc_hbm_traffic.json, written by
+# tools/pmc_summary.py): 2 x FETCH_SIZE (gfx950 counts 128-B requests as 64 B, MI355X_MICROARCH.md section HBM) + WRITE_SIZE.
+# PMC counters cannot be read from inside an unprofiled run, so the committed measurement is quoted for the (shape, loss) --
+# i.e. the kernel instantiation -- it was taken on (one GPU), and the field is null otherwise.
+def profiled_traffic(shape, loss, world):
+    path = os.path.join(ROOT, "profiles", "r3_pmc_hbm_traffic.json")
     if world != 1 or not os.path.exists(path):
         return None
     with open(path) as fh:
-        return json.load(fh).get(shape)
+        return json.load(fh).get("{}:{}".format(shape, loss))
+
+
+def compulsory_bytes(K, N, model, n_params, loss, unit_weights):
+    """
+    HBM bytes k_linearize has to move AS BUILT (csrc/satba_kernels.h), per launch: per observation the camera index (4) and the
+    observed pixel (16), the weight (8) unless every weight is 1 and the loss is linear, the Jacobian row scales it stores for the
+    later passes (16) on weighted / robust runs, and for RPC cameras the stored Jacobian rows (128 B for 3, 192 B for 6 parameters);
+    per point x (24) in, V (48) and g_p (24) out.  The per-camera sums stay in LDS; the residuals are not stored.
+    """
+    unit = unit_weights and loss == "linear"
+    per_obs = 20 + (0 if unit else 8 + 16)
+    if model == "rpc":
+        per_obs += 8 * (16 if 2 * n_params + 6 <= 16 else 24)
+    return float(per_obs) * K + 96.0 * N
 
 
 def lm_step(eng, comm, st, trf):
@@ -178,6 +192,8 @@ def main():
     ap.add_argument("--driver", default="auto", help="host side of an LM iteration: native (C++, satba_lm_step; one rank) | python (phase "
                     "entry points + all-reduces) | auto (native for one rank)")
     ap.add_argument("--cpu-c3", action="store_true", help="also run the measured C3 CPU baseline (max_nfev=3, ~10 min)")
+    ap.add_argument("--camera-major", action="store_true", help="form the per-camera sums with the camera-major float64 pass from the "
+                    "start (SATBA_FLAG_CAMERA_MAJOR_SUMS: the route the fixed-point sums fall back to)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -216,7 +232,7 @@ def main():
     p = synth.make_params(scene, {"correction_params": corr, "n_cam_fix": 1})
     t_gen = time.perf_counter() - t_gen
     comm = trf.TorchComm() if world > 1 else trf.SingleComm()
-    eng = HipEngine(p, sharding.make_shard(p, rank, world))
+    eng = HipEngine(p, sharding.make_shard(p, rank, world), deterministic=args.camera_major)
     eng.configure(args.loss, 1.0)
 
     def sync():
@@ -312,22 +328,37 @@ def main():
         # leaves part of the working set in the Infinity Cache)
         t_lin = (ms_lin / n_lin if n_lin else kern["linearize"]) * 1e-3
         achieved = alg_bytes / t_lin / 1e9
-        traffic = profiled_traffic(args.shape, world)
+        traffic = profiled_traffic(args.shape, args.loss, world)
+        info = eng.info()
+        comp_bytes = compulsory_bytes(K_loc, N_loc, model, p.n_params, args.loss, bool(info["unit_weights"]))
+        rate_as_built = comp_bytes / t_lin / 1e9
+        rate_counter = (traffic / t_lin / 1e9) if traffic else None
+        # what bounds the kernel: it moves `compulsory_bytes_as_built` (the counters agree to a few %), and when that rate is below
+        # half the HBM peak the memory system is not the limit -- the LDS pipe is (fixed-point atomics and gathers of the per-camera
+        # tables on random rows, profiles/r3_pmc_kernels_*.txt)
+        bound = "hbm" if (rate_counter if rate_counter is not None else rate_as_built) >= 0.5 * HBM_PEAK_GBPS else "lds"
         out = {
             "metric": "LM iters/sec at 200 cams x 1M pts x 10M obs (affine, R+T)" if args.shape == "C4" else
                       "LM iters/sec, config {}".format(args.shape),
             "value": args.steps / dt, "unit": "LM iters/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic", "loss": args.loss,
+            # every reduction has a fixed order or is integer arithmetic: repeated runs give the same bits on both routes
+            "deterministic": True, "camera_sums": "fixed_point_lds" if info["cam_sums_lds"] else "camera_major_pass",
+            "fixed_point_fallbacks": int(info["fx_fallbacks"]),
             "host_driver": driver, "restart_every": restart, "solve_shipped_tolerances": solve_stats,
             "config": {"workload": "{}: {} cams x {} pts x {} obs, {}, correction {}, 1 fixed camera, seed 1"
                        .format(args.shape, n_cam, n_pts, p.n_obs, model, "+".join(corr)),
                        "sharding": "points over {} rank(s)".format(world),
                        "obs_per_rank0": K_loc},
             "obs_per_sec_residual_jacobian": world * K_loc / t_lin,
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            # achieved / frac: SURVEY 8d's algorithmic bytes (48 K + 96 N: a throughput-equivalent, the kernel no longer moves all
+            # of them); *_as_built: the bytes this kernel has to move; achieved_counter: the bytes the PMC counters saw it move
+            "roofline": {"bound": bound, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "achieved_counter": (traffic / t_lin / 1e9) if traffic else None,  # counter bytes / time, GB/s
+                         "achieved_counter": rate_counter,
+                         "compulsory_bytes_as_built": comp_bytes, "achieved_as_built": rate_as_built,
+                         "frac_as_built": rate_as_built / HBM_PEAK_GBPS,
                          "kernel": "k_linearize",
                          "algorithmic_bytes_per_launch": alg_bytes, "ms_per_launch": 1e3 * t_lin, "launches_timed": n_lin,
                          "ms_per_launch_back_to_back": kern["linearize"]},

@@ -54,17 +54,23 @@ enum {
 #define SATBA_HDR_FIXED 16
 /* after satba_solve, header slots SATBA_HDR_KEEP .. +SATBA_KEEP_LEN-1 repeat the scalars of the earlier phases of the
  * same iteration: cost, |g|_inf, |g_h|^2, |J_h g_h|^2, |x_h|^2, damping used, trust radius used (0 unless
- * satba_schur_auto computed them) */
+ * satba_schur_auto computed them), and SATBA_HDR_FX_BAD: non-zero when the fixed-point camera sums of the linearisation left
+ * their range (the iteration is void: call satba_camera_sums_fallback and repeat it; satba_solve_lm / satba_lm_step and
+ * satba/trf.py do) */
 #define SATBA_HDR_KEEP 8
-#define SATBA_KEEP_LEN 7
+#define SATBA_KEEP_LEN 8
+#define SATBA_HDR_FX_BAD 15
 
 typedef struct satba_problem satba_problem;
 
-/* satba_problem_desc.flags.  DETERMINISTIC: bitwise-repeatable runs -- the per-camera sums of the linearisation are formed by a
- * camera-major pass with a fixed order instead of LDS float atomics (every other reduction of the library has a fixed order
- * anyway); costs one extra pass over the observations per linearisation.  Also switched on by the environment variable
- * SATBA_DETERMINISTIC. */
+/* satba_problem_desc.flags.  Every run is bitwise repeatable: all reductions of the library have a fixed order except the
+ * per-camera sums of the linearisation, and those are accumulated in 64-bit fixed point (integer addition does not depend on the
+ * order; csrc/satba_kernels.h, k_linearize).  CAMERA_MAJOR_SUMS (the former DETERMINISTIC flag, same value; environment
+ * variable SATBA_DETERMINISTIC) selects the other route to the same property from the start: a camera-major pass in float64 with
+ * a fixed order (k_cam_sums; one extra pass over the observations per linearisation, one lane per point) -- the route a solve
+ * falls back to when a term leaves the fixed-point range (satba_camera_sums_fallback). */
 #define SATBA_FLAG_DETERMINISTIC 1
+#define SATBA_FLAG_CAMERA_MAJOR_SUMS 1
 
 typedef struct satba_problem_desc {
     int32_t cam_model;      /* SATBA_AFFINE | SATBA_PERSPECTIVE | SATBA_RPC  (BundleAdjustmentParameters.cam_model) */
@@ -162,6 +168,10 @@ int satba_trial(satba_problem *p, double p0, double p1);
 /* the same step written on (g_h, gn_h): x_new = x + scale * (ca g_h + cb gn_h); needs no satba_subspace.           */
 int satba_trial_gn(satba_problem *p, double ca, double cb);
 int satba_accept(satba_problem *p);
+/* Form the per-camera sums of the following linearisations with the camera-major float64 pass instead of the fixed-point LDS
+ * table.  For callers that drive the phases themselves: call it when header slot SATBA_HDR_FX_BAD is non-zero after satba_solve
+ * and repeat the iteration from satba_linearize.  (No counterpart in the reference.) */
+int satba_camera_sums_fallback(satba_problem *p);
 /* synchronise the stream and copy the exchange header to the host. */
 int satba_read_header(satba_problem *p, double *host_hdr);
 
@@ -246,7 +256,8 @@ int satba_get_layout(satba_problem *p, int32_t which, int64_t n, void *host_out)
 /* n >= 16 doubles: [0..4] milliseconds since the start of satba_problem_create when the uploads were queued, the layout sizes were
  * known, the ELL + camera-major lists were queued, the pair lists were finished, the handle was complete; [5] padded ELL length,
  * [6] pair-list entries, [7] pair-list chunks, [8] unit weights, [9] camera constants in LDS, [10] RPC tables in LDS,
- * [11] camera sums by LDS atomics, [12] deterministic, [13] chunks of the camera-major passes, [14] workgroups of k_linearize */
+ * [11] camera sums by (fixed-point) LDS atomics, [12] camera-major sums requested, [13] chunks of the camera-major passes,
+ * [14] workgroups of k_linearize, [15] fall-backs from the fixed-point sums so far */
 int satba_get_info(const satba_problem *p, double *out, int32_t n);
 /* normal-equation blocks of the last linearize: U (M n_p n_p), g_c (M n_p) as written to the exchange
  * payload, V (N x 6: xx xy xz yy yz zz), g_p (N x 3), points in the caller's order. Any pointer may be NULL.

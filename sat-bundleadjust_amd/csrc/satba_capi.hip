@@ -58,6 +58,14 @@ struct satba_problem {
     int cam_sums_lds = 1;           // k_linearize accumulates diag U_c / g_c with LDS atomics (0: camera-major pass k_cam_sums)
     int lin_rep_shift = 0;          // log2 of the replicas of that LDS table (few cameras: same-address atomics serialise)
     int deterministic = 0;
+    // fixed-point camera sums of k_linearize (satba_kernels.h): scales / bounds / inverse scales per slot, overflow flag, bounding
+    // box of the points at the last satba_set_x, largest weight, most observations of one camera, and the cost of this shard at x
+    // (linear loss: bound of a residual) with its copy for the trial point
+    double *d_fx = nullptr, *d_bbox = nullptr, *d_fxcost = nullptr, *d_fxcost_new = nullptr, *d_fxcost0 = nullptr;
+    int *d_fxflag = nullptr, *d_fxe = nullptr;
+    bool fxcost_valid = false, fxcost_new_valid = false, fxcost0_valid = false;
+    double w_max = 1.0, n_max_cam = 1.0, fx_shrink = 1.0;
+    int fx_fallbacks = 0;
     double f_scale = 1.0, lead = 1.0;
     hipStream_t stream = nullptr;
     Layout L;
@@ -165,6 +173,7 @@ static ObsArgs obs_args(const satba_problem* p, bool at_new) {
     a.f_scale = p->f_scale;
     a.unit = (p->loss == 0 && p->unit_weights) ? 1 : 0;
     a.rep_shift = p->lin_rep_shift;
+    a.fxe = p->d_fxe; a.fx_flag = p->d_fxflag;
     a.sh = 0;  // lanes per point: set by the launchers of the kernels that support it
     return a;
 }
@@ -242,7 +251,8 @@ static int launch_trial(satba_problem* p, double c0, double c1, const double* v0
     a.sh = slice_split(p);
     const int grid = slice_grid(p, RES_THREADS / 64, 2, a.sh);
     const size_t lds = table_bytes(p);
-    const TrialArgs t{p->d_x, v0, v1, p->d_scale_inv, p->d_xnew, c0, c1, p->lead, p->d_xb + 2, p->d_xb + 3};
+    const TrialArgs t{p->d_x, v0, v1, p->d_scale_inv, p->d_xnew, c0, c1, p->lead, p->d_xb + 2, p->d_xb + 3, p->d_fxcost_new};
+    p->fxcost_new_valid = true;
     double* cost = p->d_xb + 1;
     if (p->loss == 0 && p->unit_weights)
         SATBA_DISPATCH(p, hipLaunchKernelGGL((k_residual<MODEL, NP, CL, RL, true, true>), dim3(grid), dim3(RES_THREADS), lds, p->stream, a, (double2*)nullptr, p->red(RB_RES), cost, t));
@@ -269,7 +279,7 @@ static int launch_lin(satba_problem* p, const ObsArgs& a) {
     constexpr bool BIGL = MODEL == RPC;  // LinCfg of the linear-loss variants
 #define SATBA_LIN_LAUNCH(ROB, SOFT_, UNIT_, CS_, BIG_)                                                                                   \
     hipLaunchKernelGGL((k_linearize<MODEL, NP, ROB, CL, RL, SOFT_, UNIT_, CS_>), dim3(p->lin_grid), dim3(LinCfg<BIG_>::THREADS), lds, p->stream, \
-                       a, p->cam_sums_lds ? nullptr : p->d_f, p->d_V, gpv, p->d_part, rb, cost, gmax)
+                       a, (p->cam_sums_lds || MODEL != RPC) ? nullptr : p->d_f, p->d_V, gpv, p->d_part, rb, cost, gmax)
     const int v = lin_variant(p);
     if (p->cam_sums_lds) {
         if (v == 0) { if constexpr (MODEL != RPC) SATBA_LIN_LAUNCH(false, false, true, true, false); }
@@ -591,6 +601,8 @@ static int build_layout(satba_problem* p, const satba_problem_desc* d) {
             default: return fail(SATBA_E_ARG, "cameras must ascend strictly inside a point (ba_params.py:142-147 order)");
         }
         p->unit_weights = h_flags[1] ? 0 : 1;
+        memcpy(&p->w_max, h_flags + 2, sizeof(double));  // largest |weight| (bound of the fixed-point camera sums)
+        if (!(p->w_max > 0.0)) p->w_max = 1.0;
         L.P = h_P; L.E = h_E;
         if ((long long)L.P >= (1ll << 31) - 128 || L.E >= (1ll << 31)) return fail(SATBA_E_ARG, "observation or pair lists exceed 2^31 entries per shard");
         p->create_ms[1] = ms_since(t0);
@@ -653,7 +665,14 @@ static int build_layout(satba_problem* p, const satba_problem_desc* d) {
             }
             HIP_TRY(hipGetLastError());
         }
-        HIP_TRY(hipStreamSynchronize(st));
+        {   // most observations of one camera (range of the fixed-point camera sums)
+            std::vector<int> h_ofs((size_t)M + 1);
+            HIP_TRY(hipMemcpyAsync(h_ofs.data(), L.cam_ofs, sizeof(int) * (M + 1), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            int mx = 1;
+            for (int c = 0; c < M; ++c) mx = std::max(mx, h_ofs[c + 1] - h_ofs[c]);
+            p->n_max_cam = (double)mx;
+        }
         p->create_ms[3] = ms_since(t0);
         return 0;
     }();
@@ -711,7 +730,7 @@ int satba_problem_create(const satba_problem_desc* d, satba_problem** out) {
             ++p->lin_rep_shift;
         if (const char* rs = getenv("SATBA_LIN_REP")) p->lin_rep_shift = std::min(4, std::max(0, atoi(rs)));  // experiments
         const size_t acc_b = sizeof(double) * (size_t)(p->M << p->lin_rep_shift) * cam_sum_stride(p->NP);
-        p->cam_sums_lds = (acc_b <= budget && !p->deterministic && !getenv("SATBA_CAM_SUMS")) ? 1 : 0;
+        p->cam_sums_lds = (acc_b <= budget && !p->deterministic && !getenv("SATBA_CAM_SUMS") && p->n_max_cam <= (double)(1 << 28)) ? 1 : 0;
         size_t used = p->cam_sums_lds ? acc_b : 0;
         p->camc_lds = (camc_b <= 48 * 1024 && used + camc_b <= budget && !getenv("SATBA_CAMC_GLOBAL")) ? 1 : 0;
         used += p->camc_lds ? camc_b : 0;
@@ -738,6 +757,11 @@ int satba_problem_create(const satba_problem_desc* d, satba_problem** out) {
         { const char* cs = getenv("SATBA_CHOL"); p->chol_mode = cs ? atoi(cs) : 0; }
         TRY(dev_alloc(p, &p->d_dinv, (size_t)((p->n_c + CH_NB - 1) / CH_NB) * CH_NB * CH_NB));
         TRY(dev_alloc(p, &p->d_scal, 8));
+        TRY(dev_alloc(p, &p->d_fx, 2 * 6)); TRY(dev_alloc(p, &p->d_fxe, 6 + 3)); TRY(dev_alloc(p, &p->d_bbox, 6)); TRY(dev_alloc(p, &p->d_fxflag, 1));
+        TRY(dev_alloc(p, &p->d_fxcost, 1)); TRY(dev_alloc(p, &p->d_fxcost_new, 1)); TRY(dev_alloc(p, &p->d_fxcost0, 1));
+        HIP_TRY(hipMemset(p->d_bbox, 0, sizeof(double) * 6));
+        HIP_TRY(hipMemset(p->d_fxflag, 0, sizeof(int)));
+        if (const char* fs = getenv("SATBA_FX_SHRINK")) p->fx_shrink = atof(fs);  // tests: shrink the bounds to force the fall-back
         TRY(dev_alloc(p, &p->d_keep, SATBA_KEEP_LEN));
         HIP_TRY(hipMemset(p->d_keep, 0, sizeof(double) * SATBA_KEEP_LEN));
         TRY(dev_alloc(p, &p->d_red, (size_t)RED_SLOTS * RED_MAX_NV * RED_MAX_GRID));
@@ -745,7 +769,7 @@ int satba_problem_create(const satba_problem_desc* d, satba_problem** out) {
         HIP_TRY(hipMemset(p->d_red_cnt, 0, sizeof(unsigned) * RED_SLOTS));
         // one workgroup per CU for the linearize kernel (its LDS table is flushed once per workgroup)
         p->lin_grid = grid_for((long long)p->L.n_slices << slice_split(p), LinCfg<false>::WAVES, 256 * (1024 / LinCfg<false>::THREADS));
-        TRY(dev_alloc(p, &p->d_part, (size_t)512 * p->M * 2 * p->NP));
+        TRY(dev_alloc(p, &p->d_part, (size_t)512 * p->M * cam_sum_len(p->NP)));
         {   // chunking of the camera-major passes (k_schur_diag, k_cam_sums)
             int chunks = (2048 + p->M - 1) / p->M;
             if (chunks > 64) chunks = 64;
@@ -850,7 +874,10 @@ int satba_configure(satba_problem* p, int32_t loss, double f_scale) {
     if (!p) return fail(SATBA_E_ARG, "null handle");
     if (loss < 0 || loss > 4) return fail(SATBA_E_ARG, "unknown loss %d", loss);
     if (!(f_scale > 0.0)) return fail(SATBA_E_ARG, "f_scale must be positive");
-    if (loss != p->loss || f_scale != p->f_scale) { p->linearized = false; p->have_step = false; p->prepared = false; }
+    if (loss != p->loss || f_scale != p->f_scale) {
+        p->linearized = false; p->have_step = false; p->prepared = false;
+        p->fxcost_valid = false; p->fxcost_new_valid = false; p->fxcost0_valid = false;  // the kept costs belong to the old loss
+    }
     p->loss = loss; p->f_scale = f_scale;
     return 0;
 }
@@ -880,7 +907,9 @@ int satba_set_x(satba_problem* p, const double* host_x) {
     HIP_TRY(hipSetDevice(p->device));
     TRY(upload_permuted(p, host_x, p->d_x, p->n_c, 3));
     TRY(launch_cam_consts(p, false));
-    p->linearized = false; p->have_step = false; p->prepared = false;
+    hipLaunchKernelGGL(k_bbox, dim3(1), dim3(1024), 0, p->stream, p->N, p->d_x + p->n_c, p->d_bbox);
+    HIP_TRY(hipGetLastError());
+    p->linearized = false; p->have_step = false; p->prepared = false; p->fxcost_valid = false; p->fxcost_new_valid = false;
     return 0;
 }
 
@@ -889,13 +918,24 @@ int satba_snapshot_x(satba_problem* p, int32_t restore) {
     if (!p) return fail(SATBA_E_ARG, "null handle");
     HIP_TRY(hipSetDevice(p->device));
     if (!restore) {
-        if (!p->d_x0) TRY(dev_alloc(p, &p->d_x0, p->n));
+        if (!p->d_x0) TRY(dev_alloc(p, &p->d_x0, p->n + 6));  // x | bounding box of its points
         HIP_TRY(hipMemcpyAsync(p->d_x0, p->d_x, sizeof(double) * p->n, hipMemcpyDeviceToDevice, p->stream));
+        HIP_TRY(hipMemcpyAsync(p->d_x0 + p->n, p->d_bbox, sizeof(double) * 6, hipMemcpyDeviceToDevice, p->stream));
+        // the cost at the kept point travels with it (scales of the fixed-point camera sums, linear loss)
+        if (p->loss == 0 && !p->fxcost_valid) {
+            TRY(launch_residual(p, false, nullptr, p->d_fxcost));
+            p->fxcost_valid = true;
+        }
+        p->fxcost0_valid = p->fxcost_valid;
+        if (p->fxcost_valid) HIP_TRY(hipMemcpyAsync(p->d_fxcost0, p->d_fxcost, sizeof(double), hipMemcpyDeviceToDevice, p->stream));
         return 0;
     }
     if (!p->d_x0) return fail(SATBA_E_STATE, "restore before snapshot");
     HIP_TRY(hipMemcpyAsync(p->d_x, p->d_x0, sizeof(double) * p->n, hipMemcpyDeviceToDevice, p->stream));
+    HIP_TRY(hipMemcpyAsync(p->d_bbox, p->d_x0 + p->n, sizeof(double) * 6, hipMemcpyDeviceToDevice, p->stream));
     TRY(launch_cam_consts(p, false));
+    p->fxcost_valid = p->fxcost0_valid; p->fxcost_new_valid = false;
+    if (p->fxcost0_valid) HIP_TRY(hipMemcpyAsync(p->d_fxcost, p->d_fxcost0, sizeof(double), hipMemcpyDeviceToDevice, p->stream));
     p->linearized = false; p->have_step = false; p->prepared = false; p->f_valid = false;
     return 0;
 }
@@ -931,7 +971,20 @@ int satba_linearize(satba_problem* p) {
     if (!p) return fail(SATBA_E_ARG, "null handle");
     HIP_TRY(hipSetDevice(p->device));
     const size_t nU = (size_t)p->M * p->NP * p->NP;
-    HIP_TRY(hipMemsetAsync(p->d_xb, 0, sizeof(double) * (p->hdr + nU + p->n_c), p->stream));  // header, U (only its diagonal is written), g_c
+    const int n_clear = (int)(p->hdr + nU + p->n_c);  // header, U (only its diagonal is written), g_c
+    if (p->cam_sums_lds) {
+        // scales of the fixed-point camera sums: the linear loss bounds a residual by sqrt(2 cost(x)) -- the cost of the trial
+        // evaluation that led here (satba_accept), else one cost-only pass
+        if (p->loss == 0 && !p->fxcost_valid) {
+            TRY(launch_residual(p, false, nullptr, p->d_fxcost));
+            p->fxcost_valid = true;
+        }
+        SATBA_DISPATCH(p, hipLaunchKernelGGL((k_lin_scales<MODEL, NP>), dim3(1), dim3(256), 0, p->stream, p->M, p->d_camc, p->d_rpc, p->d_bbox, p->w_max,
+                                             p->loss, p->f_scale, p->d_fxcost, p->n_max_cam, p->fx_shrink, p->d_fx, p->d_fxe, p->d_fxflag, p->d_xb, n_clear));
+        HIP_TRY(hipGetLastError());
+    } else {
+        HIP_TRY(hipMemsetAsync(p->d_xb, 0, sizeof(double) * n_clear, p->stream));
+    }
     TRY(launch_linearize_kernel(p));
     double* U = p->payload();
     double* gc = U + nU;
@@ -941,13 +994,13 @@ int satba_linearize(satba_problem* p) {
         const int const_t = lin_const_t(p->model, p->NP, p->loss != 0, p->loss == 0 && p->unit_weights) && lin_variant(p) == 0;
         const int total = p->M * 2 * p->NP;
         hipLaunchKernelGGL(k_lin_finish, dim3((total + 63) / 64), dim3(1024), 0, p->stream, p->M, p->NP, p->lin_grid, p->d_part, U, gc,
-                           p->L.cam_ofs, p->d_camc, p->n_cam_fix, const_t);
+                           p->L.cam_ofs, p->d_camc, p->n_cam_fix, const_t, p->d_fx, p->d_fxflag, p->d_xb + SATBA_HDR_FX);
         HIP_TRY(hipGetLastError());
     } else {
-        TRY(launch_cam_sums(p, U, gc));  // fixed summation order; fills the full blocks
+        TRY(launch_cam_sums(p, U, gc));  // camera-major pass, fixed summation order; fills the full blocks
     }
     p->linearized = true; p->have_step = false;
-    p->f_valid = !p->cam_sums_lds;
+    p->f_valid = !p->cam_sums_lds && p->model == RPC;
     return 0;
 }
 
@@ -962,7 +1015,7 @@ int satba_prepare(satba_problem* p, int32_t first) {
     HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(k_prepare_vec, dim3(grid_for(p->n, 256, 1024)),  // measured at 3 M entries: 512 workgroups 51 us, 1024: 45, 2048: 55
                        dim3(256), 0, p->stream, p->n, p->n_c, p->NP, first,
-                       p->lead, p->d_U, p->d_gc, p->d_V, p->d_x, p->d_g, p->d_scale_inv, p->d_gh, p->d_q1, p->red(RB_PREP), p->d_xb);
+                       p->lead, p->d_U, p->d_gc, p->d_V, p->d_x, p->d_g, p->d_scale_inv, p->d_gh, p->d_q1, p->red(RB_PREP), p->d_xb, p->d_keep);
     HIP_TRY(hipGetLastError());
     TRY(launch_jvp(p, 1, p->d_q1, p->d_q1, p->d_xb + 2, true));  // d_q1 is free until the subspace phase
     p->prepared = true;
@@ -1069,6 +1122,15 @@ int satba_accept(satba_problem* p) {
     if (!p) return fail(SATBA_E_ARG, "null handle");
     std::swap(p->d_x, p->d_xnew);
     std::swap(p->d_camc, p->d_camc_new);
+    std::swap(p->d_fxcost, p->d_fxcost_new);  // the cost of the trial evaluation is the cost at the new x
+    p->fxcost_valid = p->fxcost_new_valid; p->fxcost_new_valid = false;
+    p->linearized = false; p->have_step = false; p->prepared = false;
+    return 0;
+}
+
+int satba_camera_sums_fallback(satba_problem* p) {
+    if (!p) return fail(SATBA_E_ARG, "null handle");
+    if (p->cam_sums_lds) { p->cam_sums_lds = 0; ++p->fx_fallbacks; }
     p->linearized = false; p->have_step = false; p->prepared = false;
     return 0;
 }
@@ -1131,11 +1193,15 @@ int satba_lm_step(satba_problem* p, int32_t first, double Delta, double lam_floo
     enum { COST_NEW = 1, K_COST = SATBA_HDR_KEEP, K_GINF, K_GH_SQ, K_JG_SQ, K_XS_SQ, K_LAM, K_DELTA };
     std::vector<double> hbuf((size_t)p->hdr), tbuf((size_t)p->hdr);
     double* h = hbuf.data();
-    TRY(satba_linearize(p));
-    TRY(satba_prepare(p, first ? 1 : 0));
-    TRY(satba_schur_auto(p, first ? -1.0 : Delta, lam_floor));
-    TRY(satba_solve(p));
-    TRY(satba_read_header(p, h));
+    for (;;) {
+        TRY(satba_linearize(p));
+        TRY(satba_prepare(p, first ? 1 : 0));
+        TRY(satba_schur_auto(p, first ? -1.0 : Delta, lam_floor));
+        TRY(satba_solve(p));
+        TRY(satba_read_header(p, h));
+        if (h[SATBA_HDR_FX_BAD] == 0.0 || !p->cam_sums_lds) break;
+        TRY(satba_camera_sums_fallback(p));  // a term left the fixed-point range: camera-major sums from here on
+    }
     const double cost = h[K_COST], reg = h[K_LAM], jg_sq = h[K_JG_SQ];
     Delta = h[K_DELTA];
     LmModel md;
@@ -1166,11 +1232,15 @@ int satba_solve_lm(satba_problem* p, const satba_lm_opts* o, satba_lm_stats* out
     std::vector<double> hbuf((size_t)p->hdr), tbuf((size_t)p->hdr);
     double* h = hbuf.data();
     auto front = [&](double Delta, bool first) -> int {
-        TRY(satba_linearize(p));
-        TRY(satba_prepare(p, first ? 1 : 0));
-        TRY(satba_schur_auto(p, first ? -1.0 : Delta, 0.0));
-        TRY(satba_solve(p));
-        return satba_read_header(p, h);
+        for (;;) {
+            TRY(satba_linearize(p));
+            TRY(satba_prepare(p, first ? 1 : 0));
+            TRY(satba_schur_auto(p, first ? -1.0 : Delta, 0.0));
+            TRY(satba_solve(p));
+            TRY(satba_read_header(p, h));
+            if (h[SATBA_HDR_FX_BAD] == 0.0 || !p->cam_sums_lds) return 0;
+            TRY(satba_camera_sums_fallback(p));  // a term left the fixed-point range: camera-major sums from here on
+        }
     };
     enum { COST_NEW = 1, STEP_SQ = 2, X_SQ = 3, GRAM_A = 1, GRAM_B = 2, GRAM_C = 3, CHOL_FAIL = 4, WW = 1, B11 = 3, B12 = 4, B22 = 5, GHW = 6,
            K_COST = SATBA_HDR_KEEP, K_GINF, K_GH_SQ, K_JG_SQ, K_XS_SQ, K_LAM, K_DELTA };
@@ -1419,7 +1489,7 @@ int satba_get_info(const satba_problem* p, double* out, int32_t n) {
     for (int i = 0; i < n; ++i) out[i] = 0.0;
     for (int i = 0; i < 5; ++i) out[i] = p->create_ms[i];
     out[5] = p->L.P; out[6] = (double)p->L.E; out[7] = p->L.C; out[8] = p->unit_weights; out[9] = p->camc_lds; out[10] = p->rpc_lds;
-    out[11] = p->cam_sums_lds; out[12] = p->deterministic; out[13] = p->cm_chunks; out[14] = p->lin_grid;
+    out[11] = p->cam_sums_lds; out[12] = p->deterministic; out[13] = p->cm_chunks; out[14] = p->lin_grid; out[15] = p->fx_fallbacks;
     return 0;
 }
 

@@ -25,10 +25,17 @@ __host__ __device__ constexpr int cam_acc_len(int np) { return np * (np + 1) / 2
 // row stride of the LDS camera table: odd, so that (stride * cam + k) visits all 32 bank pairs (an even stride such
 // as 20 folds the cameras onto 8 of them: 8-way conflicts of the ds_add_f64)
 __host__ __device__ constexpr int cam_acc_stride(int np) { return cam_acc_len(np) | 1; }
-// k_linearize's LDS table holds diag(U_c) and g_c only: 2 np sums per camera, odd row stride (7, 11, 13)
-__host__ __device__ constexpr int cam_sum_stride(int np) { return (2 * np) | 1; }
+// k_linearize's LDS table holds diag(U_c) and g_c only, g_c in two 64-bit limbs: 3 np sums per camera, odd row stride (9, 15, 19)
+__host__ __device__ constexpr int cam_sum_len(int np) { return 3 * np; }
+__host__ __device__ constexpr int cam_sum_stride(int np) { return (3 * np) | 1; }
+constexpr int FX_LO_SHIFT = 40;  // the low limb of a g_c term holds its remainder below the high limb's unit, scaled by 2^40
 
 constexpr int RPCS = 91;  // row stride of the LDS copy of the RPC tables (90 used, odd)
+// double -> 64-bit fixed point through one fma (k_linearize's camera sums): bits(t 2^e + 1.5 * 2^52) = FX_MAGIC_BITS + round(t 2^e)
+constexpr int SATBA_HDR_FX = 5;  // linearize header: a term of the fixed-point camera sums exceeded its bound (summed over ranks)
+constexpr int SATBA_K_FX = 7;    // ... and its place among the kept scalars (header slot SATBA_HDR_KEEP + 7 after satba_solve)
+constexpr double FX_MAGIC = 6755399441055744.0;
+constexpr unsigned long long FX_MAGIC_BITS = 0x4338000000000000ull;
 // row stride (doubles) of the stored Jacobian blocks (RPC): 2 np + 6 used.  np = 3: 12 doubles in a 128-byte row -- one line per
 // gathered row instead of 1.75 with 96-byte rows (k_schur_pairs<RPC> sits on the L1-miss path); np = 6: 18 doubles in 192 bytes
 // (always two lines instead of up to three)
@@ -58,6 +65,9 @@ struct ObsArgs {
     int rep_shift;                       // log2 of the number of replicas of k_linearize's LDS camera table (few cameras)
     int sh;                              // log2 of the lanes per point (slice_unit): 0 for large problems
     double f_scale;
+    const int* __restrict__ fxe;         // fixed-point scales of k_linearize's camera sums (k_lin_scales): exponents a_0 .. a_{NP-1}, b, then
+                                         // the two constants of the range check
+    int* __restrict__ fx_flag;           // set when a term leaves its range (the sums are then formed by k_cam_sums instead)
 };
 
 // deterministic grid-wide sums: every workgroup writes its partial, the last one to arrive adds them up in index order
@@ -383,6 +393,7 @@ struct TrialArgs {
     double c0, c1, lead;                   // ... and their coefficients; weight of the camera entries in the sums (rank 0 only)
     double* ss;                            // |step|^2 and |x|^2 (scaled variables are not involved: plain sums of squares)
     double* xx;
+    double* cost2;                         // second copy of this shard's cost (bound of the fixed-point camera sums at x_new)
 };
 template <int MODEL, int NP, bool CL, bool RL, bool UNITW = false, bool TRIAL = false>
 __global__ __launch_bounds__(RES_THREADS) void k_residual(ObsArgs a, double2* __restrict__ f, RedBuf rb, double* __restrict__ cost, TrialArgs t) {
@@ -439,9 +450,9 @@ __global__ __launch_bounds__(RES_THREADS) void k_residual(ObsArgs a, double2* __
         }
     });
     if constexpr (TRIAL) {
-        double v[3] = {0.5 * acc, ss, xx};
-        double* const dst[3] = {cost, t.ss, t.xx};
-        grid_sum<3>(v, dst, rb);
+        double v[4] = {0.5 * acc, ss, xx, 0.5 * acc};
+        double* const dst[4] = {cost, t.ss, t.xx, t.cost2};
+        grid_sum<4>(v, dst, rb);
     } else {
         double v[1] = {0.5 * acc};
         double* const dst[1] = {cost};
@@ -455,8 +466,18 @@ __global__ __launch_bounds__(RES_THREADS) void k_residual(ObsArgs a, double2* __
 //   f[pos]          true residual pair (ELL order), if f != null: only k_cam_sums reads it, i.e. runs without the LDS camera
 //                   table (SATBA_DETERMINISTIC, very many cameras); the default path does not write it     16 B / obs
 //   V[q] (6), g_p   per-point blocks, summed in the lane's registers     72 B / point written
-//   part[block][M][cam_acc_len]   per-workgroup camera partials (diag U_c, then g_c), accumulated with ds_add_f64 in an
-//                   LDS table (CAMSUMS); the off-diagonal entries of U_c are only needed inside S and come out of
+//   part[block][M][2 NP]   per-workgroup camera partials (diag U_c, then g_c), accumulated in 64-BIT FIXED POINT with
+//                   ds_add_u64 in an LDS table (CAMSUMS): integer addition is associative, so the sums do not depend on the
+//                   order in which the lanes, waves and workgroups arrive -- runs repeat bit for bit (float atomics did not:
+//                   round 2 needed a separate fixed-order pass for that).  A term t becomes the integer r = round(t 2^e)
+//                   through bits(ldexp(t, e) + 1.5 * 2^52) = bits(1.5 * 2^52) + r for |r| < 2^51; the n copies of the
+//                   constant are taken off by k_lin_finish (n = observations of the camera), all arithmetic modulo 2^64 --
+//                   only the FINAL sum has to fit.  The exponents come from k_lin_scales: a_i for the Jacobian column i, b for
+//                   the residual, so that the diag(U_c) terms scale by 2 a_i and the g_c terms by a_i + b (NP + 1 scalars in
+//                   SGPRs), chosen from a bound on the Jacobian at the corners of the points' bounding box and the cost at x
+//                   such that |r| stays below 2^Q, Q = min(50, 62 - log2(most observations of a camera)).  Every r is checked
+//                   against that range (two 32-bit operations on the high word) and a violation raises a flag: the caller then
+//                   forms the sums with k_cam_sums.  The off-diagonal entries of U_c are only needed inside S and come out of
 //                   k_schur_diag's registers
 //   *hdr_cost = cost;  *hdr_gpmax = max |g_p|
 // Affine cameras with R+T corrected, unit weights, linear loss: d(col,row)/dT = [[fx, skew], [0, fy]] for every
@@ -488,13 +509,22 @@ __global__ __launch_bounds__(LinCfg<(ROBUST && !SOFT) || MODEL == RPC>::THREADS)
     using Cfg = LinCfg<(ROBUST && !SOFT) || MODEL == RPC>;
     constexpr int THREADS = Cfg::THREADS, WAVES = Cfg::WAVES;
     extern __shared__ double s_lin[];
-    double* s_acc = s_lin;
+    unsigned long long* s_acc = reinterpret_cast<unsigned long long*>(s_lin);
     // With few cameras the 64 lanes of an atomic hit the same few addresses and serialise (10 cameras: 58 of the kernel's 75 us
     // at 10 x 5 k x 30 k): the table is replicated 2^rep_shift times, a lane adds to replica (lane mod replicas), the flush
-    // adds the replicas up in order.
+    // adds the replicas up.
     const int n_rows = a.M << a.rep_shift;
-    if constexpr (CAMSUMS)
-        for (int i = threadIdx.x; i < n_rows * CUS; i += THREADS) s_acc[i] = 0.0;
+    unsigned long long bad = 0ull;  // wave mask of the lanes that saw a term outside the fixed-point range (SALU: s_or_b64)
+    int fea[NP], feb = 0, fc1 = 0, fc2 = 0;
+    if constexpr (CAMSUMS) {
+        for (int i = threadIdx.x; i < n_rows * CUS; i += THREADS) s_acc[i] = 0ull;
+        // wave-uniform scalars, read once (left to the compiler they were re-fetched with vector loads in every iteration)
+#pragma unroll
+        for (int i = 0; i < NP; ++i) fea[i] = __builtin_amdgcn_readfirstlane(a.fxe[i]);
+        feb = __builtin_amdgcn_readfirstlane(a.fxe[NP]);
+        fc1 = __builtin_amdgcn_readfirstlane(a.fxe[NP + 1]);
+        fc2 = __builtin_amdgcn_readfirstlane(a.fxe[NP + 2]);
+    }
     CamTables<CL, RL> T;
     T.stage(a, s_lin + (CAMSUMS ? (size_t)n_rows * CUS : 0), THREADS);
     if constexpr (CAMSUMS && !CL && !RL) __syncthreads();
@@ -542,13 +572,28 @@ __global__ __launch_bounds__(LinCfg<(ROBUST && !SOFT) || MODEL == RPC>::THREADS)
                 v[7] += e.Jp[0][1] * e.fs[0] + e.Jp[1][1] * e.fs[1];
                 v[8] += e.Jp[0][2] * e.fs[0] + e.Jp[1][2] * e.fs[1];
                 if constexpr (CAMSUMS) {
-                    // camera block: LDS atomics (ds_add_f64) into this workgroup's table
-                    double* acc = s_acc + (size_t)((cam << a.rep_shift) | (lane & ((1 << a.rep_shift) - 1))) * CUS;
+                    // camera block: fixed-point LDS atomics (ds_add_u64) into this workgroup's table
+                    unsigned long long* acc = s_acc + (size_t)((cam << a.rep_shift) | (lane & ((1 << a.rep_shift) - 1))) * CUS;
 #pragma unroll
                     for (int i = 0; i < NP; ++i)
-                        if (!(const_t && i >= 3)) atomicAdd(acc + i, e.Jc[0][i] * e.Jc[0][i] + e.Jc[1][i] * e.Jc[1][i]);
+                        if (!(const_t && i >= 3)) {
+                            const double y = ldexp(e.Jc[0][i] * e.Jc[0][i] + e.Jc[1][i] * e.Jc[1][i], 2 * fea[i]) + FX_MAGIC;
+                            bad |= __ballot((unsigned)(__double2hiint(y) + fc1) >= (unsigned)fc2);
+                            atomicAdd(acc + i, (unsigned long long)__double_as_longlong(y));
+                        }
 #pragma unroll
-                    for (int i = 0; i < NP; ++i) atomicAdd(acc + NP + i, e.Jc[0][i] * e.fs[0] + e.Jc[1][i] * e.fs[1]);
+                    for (int i = 0; i < NP; ++i) {
+                        // g_c in two limbs: the integer part of the scaled term, and its exact remainder (|rem| <= 1/2) times 2^40.
+                        // The gradient is what the minimiser is defined by (its cancellation at the solution happens exactly, in
+                        // integers; k_lin_finish rounds once, relative to the SUM): one limb of 46 .. 50 bits left the tight runs
+                        // 1e-5 from the reference along flat directions, where float64 sums in a fixed order reach 1e-7
+                        const double ts = ldexp(e.Jc[0][i] * e.fs[0] + e.Jc[1][i] * e.fs[1], fea[i] + feb);
+                        const double y = ts + FX_MAGIC;
+                        bad |= __ballot((unsigned)(__double2hiint(y) + fc1) >= (unsigned)fc2);
+                        const double y2 = ldexp(ts - (y - FX_MAGIC), FX_LO_SHIFT) + FX_MAGIC;
+                        atomicAdd(acc + NP + i, (unsigned long long)__double_as_longlong(y));
+                        atomicAdd(acc + 2 * NP + i, (unsigned long long)__double_as_longlong(y2));
+                    }
                 }
             }
 #pragma unroll
@@ -574,13 +619,14 @@ __global__ __launch_bounds__(LinCfg<(ROBUST && !SOFT) || MODEL == RPC>::THREADS)
     gmax = wave_max(gmax);
     if (lane == 0 && gmax > 0.0) atomic_max_pos(hdr_gpmax, gmax);
     if constexpr (CAMSUMS) {
+        if (bad != 0ull && lane == 0) atomicOr(a.fx_flag, 1);
         __syncthreads();
-        double* out = part + (size_t)blockIdx.x * a.M * 2 * NP;
-        for (int i = threadIdx.x; i < a.M * 2 * NP; i += THREADS) {
-            const int cam = i / (2 * NP), k = i % (2 * NP);
-            double t = 0.0;
+        unsigned long long* out = reinterpret_cast<unsigned long long*>(part) + (size_t)blockIdx.x * a.M * 3 * NP;
+        for (int i = threadIdx.x; i < a.M * 3 * NP; i += THREADS) {
+            const int cam = i / (3 * NP), k = i % (3 * NP);
+            unsigned long long t = 0ull;
             for (int r = 0; r < (1 << a.rep_shift); ++r) t += s_acc[(size_t)((cam << a.rep_shift) | r) * CUS + k];
-            out[i] = (UNITW && cam < a.n_cam_fix) ? 0.0 : t;  // fixed cameras: masked here on the unit-weight path
+            out[i] = t;  // fixed cameras (unmasked on the unit-weight path) are zeroed by k_lin_finish
         }
     }
     double cv[1] = {0.5 * cost};
@@ -588,37 +634,152 @@ __global__ __launch_bounds__(LinCfg<(ROBUST && !SOFT) || MODEL == RPC>::THREADS)
     grid_sum<1>(cv, dst, rb);
 }
 
-// sum the per-workgroup camera partials (diag U_c | g_c per camera) in workgroup order and expand to the exchange payload:
-// U (M x NP x NP, diagonal only, rest zero), g_c (M x NP).  64 outputs per workgroup, 16 waves each summing a strided
-// subset of the workgroups, combined through LDS in a fixed order.
+// sum the per-workgroup camera partials (diag U_c | g_c per camera; 64-bit fixed point, so any order gives the same bits), take
+// off the n_obs(camera) copies of the conversion constant, scale back and expand to the exchange payload: U (M x NP x NP,
+// diagonal only, rest zero), g_c (M x NP).  64 outputs per workgroup, 16 waves each summing a strided subset of the
+// workgroups.  hdr_flag (the linearize header's FX slot) receives 1 when a term of this shard left its range.
 __global__ __launch_bounds__(1024) void k_lin_finish(int M, int NP, int nblocks, const double* __restrict__ part, double* __restrict__ U,
                                                      double* __restrict__ gc, const int* __restrict__ cam_ofs,
-                                                     const double* __restrict__ camc, int n_cam_fix, int const_t) {
-    const int W = 2 * NP;
+                                                     const double* __restrict__ camc, int n_cam_fix, int const_t,
+                                                     const double* __restrict__ fx, const int* __restrict__ fx_flag,
+                                                     double* __restrict__ hdr_flag) {
+    const int W = 3 * NP;  // diag U_c | g_c high limbs | g_c low limbs
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int idx = blockIdx.x * 64 + lane;
-    __shared__ double s_sum[16][64];
-    double s = 0.0;
-    if (idx < M * W)
-        for (int b = wave; b < nblocks; b += 16) s += part[(size_t)b * M * W + idx];
-    s_sum[wave][lane] = s;
+    const int idx = blockIdx.x * 64 + lane;  // output (camera, k), k < 2 NP
+    const int cam = idx / (2 * NP), k = idx % (2 * NP);
+    const unsigned long long* pu = reinterpret_cast<const unsigned long long*>(part);
+    __shared__ unsigned long long s_sum[2][16][64];
+    unsigned long long s = 0ull, s2 = 0ull;
+    if (idx < M * 2 * NP)
+        for (int b = wave; b < nblocks; b += 16) {
+            const unsigned long long* row = pu + ((size_t)b * M + cam) * W;
+            s += row[k];
+            if (k >= NP) s2 += row[k + NP];
+        }
+    s_sum[0][wave][lane] = s;
+    s_sum[1][wave][lane] = s2;
     __syncthreads();
-    if (wave != 0 || idx >= M * W) return;
-    s = 0.0;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && *fx_flag) *hdr_flag = 1.0;
+    if (wave != 0 || idx >= M * 2 * NP) return;
+    s = 0ull; s2 = 0ull;
 #pragma unroll
-    for (int w = 0; w < 16; ++w) s += s_sum[w][lane];
-    const int cam = idx / W, k = idx % W;
+    for (int w = 0; w < 16; ++w) { s += s_sum[0][w][lane]; s2 += s_sum[1][w][lane]; }
+    const unsigned long long n_obs = (unsigned long long)(cam_ofs[cam + 1] - cam_ofs[cam]);
+    double v = (double)(long long)(s - n_obs * FX_MAGIC_BITS);
+    if (k >= NP) v += ldexp((double)(long long)(s2 - n_obs * FX_MAGIC_BITS), -FX_LO_SHIFT);  // one rounding, relative to the sum
+    v *= fx[k];
+    if (cam < n_cam_fix) v = 0.0;
     if (k >= NP) {
-        gc[cam * NP + (k - NP)] = s;
+        gc[cam * NP + (k - NP)] = v;
         return;
     }
     if (const_t && k >= 3) {  // lin_const_t: translation entries of diag(U_c) in closed form
         const double* cc = camc + (size_t)cam * CAMC;
-        const double fx = cc[17], fy = cc[18], sk = cc[19];
+        const double fxx = cc[17], fy = cc[18], sk = cc[19];
         const double cnt = cam >= n_cam_fix ? (double)(cam_ofs[cam + 1] - cam_ofs[cam]) : 0.0;
-        s = cnt * (k == 3 ? fx * fx : sk * sk + fy * fy);
+        v = cnt * (k == 3 ? fxx * fxx : sk * sk + fy * fy);
     }
-    U[(size_t)cam * NP * NP + k * NP + k] = s;
+    U[(size_t)cam * NP * NP + k * NP + k] = v;
+}
+
+// Scales of the fixed-point camera sums of k_linearize, one workgroup, launched in front of it (the same launch clears the
+// exchange header and the linearize payload, n_clear doubles at `clear`).  Slot k < NP is the diag(U_c) entry k (terms
+// (s0 Jc0k)^2 + (s1 Jc1k)^2 >= 0), slot NP + k the g_c entry (terms s0 Jc0k fs0 + s1 Jc1k fs1).  Bounds:
+//   JB_k = 2 w_max max |Jc[.][k]| over the cameras and the 8 corners of the (inflated) bounding box of the points -- exact for the
+//          affine model (Jc is linear in X), representative for the other two; row scales are <= w_max (rho' + 2 rho'' z <= 1);
+//   FB   = bound of |rho'(f^2) f|: sqrt(2 cost(x)) for the linear loss, f_scale for the robust ones;
+//   |U term| <= 2 JB_k^2, |g term| <= 2 JB_k FB.
+// Range of a converted term: |r| < 2^Q with Q = min(50, 62 - ceil(log2 n_max)) (conversion range; the final sum of n_max terms
+// stays inside 63 bits).  Exponents: JB_k 2^a_k < 2^h and FB 2^b < 2^h with h = (Q - 1) / 2 (integer division), so that the U
+// terms, scaled by 2^(2 a_k), and the g terms, scaled by 2^(a_k + b), stay below 2^Q.
+// fxe: a_0 .. a_{NP-1} | b | c1 | c2  -- the range check of k_linearize is (hi32(y) + c1) <u c2, i.e. r >> 32 in [-L, L), L = 2^(Q-32);
+// fx:  [2 NP] inverse scales 2^-(2 a_k), 2^-(a_k + b).  The bounds need not be rigorous: every term is checked.
+template <int MODEL, int NP>
+__global__ __launch_bounds__(256) void k_lin_scales(int M, const double* __restrict__ camc, const double* __restrict__ rpc,
+                                                    const double* __restrict__ bbox, double w_max, int loss, double f_scale,
+                                                    const double* __restrict__ cost, double n_max, double shrink,
+                                                    double* __restrict__ fx, int* __restrict__ fxe, int* __restrict__ fx_flag,
+                                                    double* __restrict__ clear, int n_clear) {
+    __shared__ unsigned long long s_max[NP];
+    __shared__ int s_a[NP + 1];
+    for (int i = threadIdx.x; i < n_clear; i += 256) clear[i] = 0.0;
+    if (threadIdx.x < NP) s_max[threadIdx.x] = 0ull;
+    if (threadIdx.x == 0) *fx_flag = 0;
+    __syncthreads();
+    double c[3], h[3], m[NP];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        c[k] = 0.5 * (bbox[k] + bbox[3 + k]);
+        h[k] = (bbox[3 + k] - bbox[k]) + 100.0;  // twice the half extent + 100 m: the points move during the solve
+    }
+#pragma unroll
+    for (int i = 0; i < NP; ++i) m[i] = 0.0;
+    for (int cam = threadIdx.x; cam < M; cam += 256) {
+        for (int corner = 0; corner < 8; ++corner) {
+            const double X = c[0] + ((corner & 1) ? h[0] : -h[0]), Y = c[1] + ((corner & 2) ? h[1] : -h[1]), Z = c[2] + ((corner & 4) ? h[2] : -h[2]);
+            double u, v, Jc[2][NP], Jp[2][3];
+            project<MODEL, NP, true>(camc + (size_t)cam * CAMC, MODEL == RPC ? rpc + (size_t)cam * 90 : nullptr, X, Y, Z, false, u, v, Jc, Jp);
+#pragma unroll
+            for (int i = 0; i < NP; ++i) m[i] = fmax(m[i], fmax(fabs(Jc[0][i]), fabs(Jc[1][i])));
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const double t = wave_max(m[i]);  // maxima of non-negative values (fmax drops NaNs): their bit patterns order like integers
+        if ((threadIdx.x & 63) == 0 && t > 0.0) atomicMax(&s_max[i], (unsigned long long)__double_as_longlong(t));
+    }
+    __syncthreads();
+    int lg_n = 0;
+    while (lg_n < 40 && ldexp(1.0, lg_n) < n_max) ++lg_n;  // ceil(log2 n_max)
+    const int Q = max(34, min(50, 62 - lg_n)), hq = (Q - 1) / 2;
+    if (threadIdx.x <= NP) {
+        const int i = threadIdx.x;
+        double bound = i < NP ? shrink * 2.0 * w_max * __longlong_as_double((long long)s_max[i < NP ? i : 0])
+                              : (loss == 0 ? 1.0001 * sqrt(2.0 * *cost) : f_scale);
+        int x = 0, a;
+        if (!(bound < 1e300)) a = -900;          // non-finite cost or Jacobian: the solve stops on the cost; every term becomes 0
+        else if (!(bound > 1e-300)) a = 900;     // nothing to add in this column
+        else { (void)frexp(bound, &x); a = max(-900, min(900, hq - x)); }  // bound < 2^x
+        s_a[i] = a;
+        fxe[i] = a;
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 * NP) {
+        const int k = threadIdx.x, i = k % NP;
+        fx[k] = ldexp(1.0, -(k < NP ? 2 * s_a[i] : s_a[i] + s_a[NP]));
+    }
+    if (threadIdx.x == 0) {
+        const int L = 1 << (Q - 32);
+        fxe[NP + 1] = (int)((unsigned)L - 0x43380000u);
+        fxe[NP + 2] = 2 * L;
+    }
+}
+
+// bounding box of the points of x (lo xyz | hi xyz), one workgroup; no points: zeros
+__global__ __launch_bounds__(1024) void k_bbox(int N, const double* __restrict__ pts, double* __restrict__ bbox) {
+    __shared__ double s_lo[16][3], s_hi[16][3];
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    for (int q = threadIdx.x; q < N; q += 1024) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const double v = pts[3 * (size_t)q + k];
+            lo[k] = fmin(lo[k], v); hi[k] = fmax(hi[k], v);
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const double a = -wave_max(-lo[k]), b = wave_max(hi[k]);
+        if (lane == 0) { s_lo[wave][k] = a; s_hi[wave][k] = b; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        double a = 1e300, b = -1e300;
+        for (int w = 0; w < 16; ++w) { a = fmin(a, s_lo[w][threadIdx.x]); b = fmax(b, s_hi[w][threadIdx.x]); }
+        if (N == 0) { a = 0.0; b = 0.0; }
+        bbox[threadIdx.x] = a;
+        bbox[3 + threadIdx.x] = b;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ camera-major camera sums
@@ -648,17 +809,21 @@ __global__ __launch_bounds__(LINC_THREADS) void k_cam_sums(ObsArgs a, CamMajor c
     for (int k = 0; k < CU; ++k) acc[k] = 0.0;
     for (int i = lo + threadIdx.x; i < hi; i += LINC_THREADS) {
         const int pos = c.pos[i], q = c.pt[i], io = c.io[i];
-        const double2 ff = f[pos];
+        double2 ff;
         double Jc[2][NP], Jp[2][3];
-        if constexpr (MODEL == RPC) {  // the blocks k_linearize stored (scales and masks included)
+        if constexpr (MODEL == RPC) {  // the blocks and residuals k_linearize stored (scales and masks included)
+            ff = f[pos];
             ObsEval<MODEL, NP, true> e2;
             e2.load_jac(a, io);
 #pragma unroll
             for (int k = 0; k < NP; ++k) { Jc[0][k] = e2.Jc[0][k]; Jc[1][k] = e2.Jc[1][k]; }
-        } else {
+        } else {  // the projection is evaluated for the Jacobian anyway: the residual comes with it (no 16 B / observation store)
             const double* px = a.x + a.n_c + 3 * (size_t)q;
             double u, v;
             project<MODEL, NP, true>(cc, nullptr, px[0], px[1], px[2], false, u, v, Jc, Jp);
+            const double2 ob = a.e_obs[pos];
+            const double w = a.unit ? 1.0 : a.e_w[pos];
+            ff = make_double2(w * (u - ob.x), w * (v - ob.y));
             double s0 = mc, s1 = mc;
             if (a.sc) { const double2 t = a.sc[io]; s0 *= t.x; s1 *= t.y; }
 #pragma unroll
@@ -718,8 +883,11 @@ __global__ __launch_bounds__(256) void k_prepare_vec(int n, int n_c, int NP, int
                                                      const double* __restrict__ U, const double* __restrict__ gc_red,
                                                      const double* __restrict__ V, const double* __restrict__ x,
                                                      double* __restrict__ g, double* __restrict__ scale_inv,
-                                                     double* __restrict__ gh, double* __restrict__ ghs, RedBuf rb, double* __restrict__ hdr) {
+                                                     double* __restrict__ gh, double* __restrict__ ghs, RedBuf rb, double* __restrict__ hdr,
+                                                     const double* __restrict__ keep) {
     // ghs = g_h / scale_inv: the unscaled direction of g_h, input of the Jacobian-vector product that follows
+    if (keep[SATBA_K_FX] != 0.0) return;  // the camera sums of this linearisation overflowed their fixed-point range: the caller
+                                          // repeats it with k_cam_sums; the running maximum of scale_inv must not see the garbage
     double s_gh = 0.0, s_xs = 0.0, m_gc = 0.0;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         double diag, gi, wgt;
@@ -950,6 +1118,7 @@ __global__ __launch_bounds__(1024) void k_prepare_stash(int nU, int n_c, int wor
         for (int r = 0; r < world; ++r) m = fmax(m, xb[hdr_fixed + r]);
         keep[0] = xb[0];
         keep[1] = m;
+        keep[SATBA_K_FX] = xb[SATBA_HDR_FX];
     }
     __syncthreads();
     if ((int)threadIdx.x < hdr_len) xb[threadIdx.x] = 0.0;

@@ -50,10 +50,13 @@ struct Layout {
 enum { LAY_OK = 0, LAY_E_CAM = 1, LAY_E_PT = 2, LAY_E_ORDER = 3, LAY_E_CAM_ORDER = 4 };
 
 // indices in range, points non-decreasing, cameras strictly ascending inside a point; flags[0] = first error code,
-// flags[1] = 1 if some weight differs from 1
+// flags[1] = 1 if some weight differs from 1, flags[2..3] = bit pattern of the largest |weight| (a double; the bit patterns of
+// non-negative doubles order like integers)
 __global__ void k_lay_validate(long long K, int M, int N, const int* __restrict__ cam, const int* __restrict__ pt,
                                const double* __restrict__ w, int* __restrict__ flags) {
+    double wm = 0.0;
     for (long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x; o < K; o += (long long)gridDim.x * blockDim.x) {
+        wm = fmax(wm, fabs(w[o]));
         const int c = cam[o], p = pt[o];
         int err = 0;
         if (c < 0 || c >= M) err = LAY_E_CAM;
@@ -66,6 +69,9 @@ __global__ void k_lay_validate(long long K, int M, int N, const int* __restrict_
         if (err) atomicCAS(flags, 0, err);
         if (w[o] != 1.0) flags[1] = 1;
     }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) wm = fmax(wm, __shfl_down(wm, d));
+    if ((threadIdx.x & 63) == 0 && wm > 0.0) atomicMax(reinterpret_cast<unsigned long long*>(flags + 2), (unsigned long long)__double_as_longlong(wm));
 }
 
 // CSR offsets of a sorted key list: ofs[v] = first index whose key is >= v, for v = 0 .. n_keys (ofs[n_keys] = K)

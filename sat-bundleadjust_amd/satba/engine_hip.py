@@ -27,7 +27,7 @@ SYMBOLS = [
     "satba_last_error", "satba_version", "satba_problem_create", "satba_problem_destroy", "satba_set_stream",
     "satba_exchange_len", "satba_header_len", "satba_bind_exchange", "satba_configure", "satba_set_x", "satba_get_x",
     "satba_residuals", "satba_linearize", "satba_prepare", "satba_schur", "satba_schur_auto", "satba_solve", "satba_subspace", "satba_subspace_products", "satba_trial", "satba_trial_gn",
-    "satba_accept", "satba_read_header", "satba_get_blocks", "satba_get_jacobian", "satba_get_exchange",
+    "satba_accept", "satba_camera_sums_fallback", "satba_read_header", "satba_get_blocks", "satba_get_jacobian", "satba_get_exchange",
     "satba_set_exchange", "satba_get_vector", "satba_time_kernel",
     "satba_packed_schur_len", "satba_pack_schur", "satba_unpack_schur",
     "satba_solve_lm", "satba_lm_step", "satba_profile_linearize", "satba_profile_read", "satba_outliers", "satba_layout_len", "satba_get_layout", "satba_get_info",
@@ -96,7 +96,7 @@ def load_library(path=None):
     lib.satba_set_x.argtypes = [h, _dp]
     lib.satba_get_x.argtypes = [h, _dp]
     lib.satba_residuals.argtypes = [h, _dp, _dp]
-    for name in ("satba_linearize", "satba_solve", "satba_accept", "satba_subspace_products"):
+    for name in ("satba_linearize", "satba_solve", "satba_accept", "satba_subspace_products", "satba_camera_sums_fallback"):
         getattr(lib, name).argtypes = [h]
     lib.satba_prepare.argtypes = [h, C.c_int32]
     lib.satba_schur.argtypes = [h, C.c_double]
@@ -307,6 +307,16 @@ class HipEngine:
     def accept(self):
         _check(self.lib, self.lib.satba_accept(self._h))
 
+    def camera_sums_fallback(self):
+        """
+        Switch the per-camera sums of the linearisation from the fixed-point LDS table to the camera-major pass (header slot
+        K_FX_BAD was raised).  Returns False when the engine is already on that route.
+        """
+        if not self.info()["cam_sums_lds"]:
+            return False
+        _check(self.lib, self.lib.satba_camera_sums_fallback(self._h))
+        return True
+
     # -- whole solve below the ABI (single rank)
     def profile_linearize(self, on=True):
         """Bracket every k_linearize launch of the following linearize calls with HIP events (satba_profile_linearize)."""
@@ -368,7 +378,7 @@ class HipEngine:
         v = np.zeros(16)
         _check(self.lib, self.lib.satba_get_info(self._h, _ptr(v), 16))
         keys = ["ms_uploads", "ms_sizes", "ms_ell", "ms_pairs", "ms_create", "ell_len", "pair_entries", "pair_chunks", "unit_weights",
-                "camc_lds", "rpc_lds", "cam_sums_lds", "deterministic", "cm_chunks", "lin_grid"]
+                "camc_lds", "rpc_lds", "cam_sums_lds", "deterministic", "cm_chunks", "lin_grid", "fx_fallbacks"]
         return dict(zip(keys, v[: len(keys)]))
 
     def get_blocks(self):

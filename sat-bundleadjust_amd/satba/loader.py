@@ -1,4 +1,4 @@
-"""Tiny host helpers that `ba_core` imports from the reference's loader (ref:bundle_adjust/loader.py:23-24, 27-40)."""
+"""Host helpers of the reference's loader that the path and its output step use (ref:bundle_adjust/loader.py:23-40, 74-88, 232-268, 384-406)."""
 import sys
 
 
@@ -66,3 +66,46 @@ def save_estimated_params(out_dir, cam_ids, estimated_params):
                 f.write("{}\n".format(k))
                 f.write(" ".join(["{:.16f}".format(v) for v in params[k]]))
                 f.write("\n")
+
+
+def save_dict_to_json(input_dict, output_json_fname):
+    """ref:bundle_adjust/loader.py:74-79 (indent 2)."""
+    import json
+
+    with open(output_json_fname, "w") as f:
+        json.dump(input_dict, f, indent=2)
+
+
+def load_dict_from_json(input_json_fname):
+    """ref:bundle_adjust/loader.py:82-88."""
+    import json
+
+    with open(input_json_fname) as f:
+        return json.load(f)
+
+
+def save_projection_matrices(filenames, projection_matrices, crop_offsets):
+    """
+    P_init/<id>_pinhole.json and P_adj/<id>_pinhole_adj.json of the pipeline (ref:bundle_adjust/loader.py:255-268, written by
+    ref:bundle_adjust/ba_pipeline.py:361-378 for affine / perspective runs): the three rows of the 3 x 4 matrix under "P" and the
+    crop rectangle of the image as height, width, col_offset, row_offset.
+    """
+    import os
+
+    import numpy as np
+
+    for fn, P, offset in zip(filenames, projection_matrices, crop_offsets):
+        os.makedirs(os.path.dirname(fn) or ".", exist_ok=True)
+        P = np.asarray(P, dtype=np.float64)
+        save_dict_to_json({"P": [P[0, :].tolist(), P[1, :].tolist(), P[2, :].tolist()],
+                           "height": int(offset["height"]), "width": int(offset["width"]),
+                           "col_offset": int(offset["col0"]), "row_offset": int(offset["row0"])}, fn)
+
+
+def load_projection_matrix(filename):
+    """(P / P[2, 3], crop offset) of a file written by save_projection_matrices (ref:bundle_adjust/loader.py:271-300)."""
+    import numpy as np
+
+    d = load_dict_from_json(filename)
+    P = np.array(d["P"], dtype=np.float64)
+    return P / P[2, 3], {"col0": d["col_offset"], "row0": d["row_offset"], "width": d["width"], "height": d["height"]}

@@ -48,7 +48,7 @@ GRAM_A, GRAM_B, GRAM_C, CHOL_FAIL = 1, 2, 3, 4
 WW, WQ1, B11, B12, B22, GHW = 1, 2, 3, 4, 5, 6
 COST_NEW, STEP_SQ, X_SQ = 1, 2, 3
 # after solve(): scalars kept from the linearize / prepare / schur_auto phases of the same iteration
-K_COST, K_GINF, K_GH_SQ, K_JG_SQ, K_XS_SQ, K_LAM, K_DELTA = 8, 9, 10, 11, 12, 13, 14
+K_COST, K_GINF, K_GH_SQ, K_JG_SQ, K_XS_SQ, K_LAM, K_DELTA, K_FX_BAD = 8, 9, 10, 11, 12, 13, 14, 15
 
 TERMINATION_MESSAGES = {
     -1: "Improper input parameters status returned from `leastsq`",
@@ -328,14 +328,19 @@ def trf_solve(engine, comm=None, ftol=1e-8, xtol=1e-8, gtol=1e-8, max_nfev=None,
         One header read returns what scipy computes at the top of an iteration (cost, |g|_inf, ...) together with
         the Gram matrix of the step; scipy's gtol / max_nfev tests are taken right after it.
         """
-        engine.linearize()
-        comm.allreduce(engine, engine.len_lin)
-        engine.prepare(Delta is None)
-        comm.allreduce(engine, hdr)
-        engine.schur_auto(-1.0 if Delta is None else Delta, 0.0)
-        comm.allreduce_schur(engine)
-        engine.solve()
-        return exchange(hdr)
+        while True:
+            engine.linearize()
+            comm.allreduce(engine, engine.len_lin)
+            engine.prepare(Delta is None)
+            comm.allreduce(engine, hdr)
+            engine.schur_auto(-1.0 if Delta is None else Delta, 0.0)
+            comm.allreduce_schur(engine)
+            engine.solve()
+            h = exchange(hdr)
+            # K_FX_BAD (summed over the ranks): a term of some shard's fixed-point camera sums left its range -- every rank
+            # switches to the camera-major sums and repeats the iteration (include/satba.h, SATBA_HDR_FX_BAD)
+            if h[K_FX_BAD] == 0 or not getattr(engine, "camera_sums_fallback", None) or not engine.camera_sums_fallback():
+                return h
 
     engine.configure(loss, f_scale)
     h = front(None)

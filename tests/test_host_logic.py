@@ -238,3 +238,59 @@ def test_output_writers(tmp_path):
     fn = tmp_path / "rpcs_adj" / "img_a.rpc_adj"
     loader.save_rpcs([str(fn)], [r])
     assert np.allclose(RPCModel.from_file(str(fn)).to_table(), r.to_table(), rtol=1e-10, atol=1e-12)
+
+
+def test_projection_matrix_json_writer(tmp_path):
+    """P_adj/<id>_pinhole_adj.json of affine / perspective runs (ref:bundle_adjust/loader.py:255-268, ba_pipeline.py:370-378)."""
+    import json
+
+    from satba import loader
+
+    P = np.array([[1.5, 0.25, -3.0, 1200.5], [0.0, 2.0, 0.125, -77.0], [1e-7, 2e-7, -3e-7, 4.0]])
+    off = {"col0": 12, "row0": 34, "width": 5600, "height": 4100}
+    fn = tmp_path / "P_adj" / "img_a_pinhole_adj.json"
+    loader.save_projection_matrices([str(fn)], [P], [off])
+    d = json.loads(fn.read_text())
+    assert list(d.keys()) == ["P", "height", "width", "col_offset", "row_offset"]  # the reference's key order
+    assert d["P"] == P.tolist() and (d["height"], d["width"], d["col_offset"], d["row_offset"]) == (4100, 5600, 12, 34)
+    assert fn.read_text().startswith('{\n  "P": [\n    [\n      1.5,')  # json.dump(..., indent=2)
+    P2, off2 = loader.load_projection_matrix(str(fn))
+    assert np.allclose(P2, P / P[2, 3], rtol=0, atol=0) and off2 == off
+
+
+def test_track_filter_counts_only_pairs_written_i_lt_j():
+    """
+    satba.ba_outliers._tracks_with_a_listed_pair against a literal restatement of
+    ref:bundle_adjust/feature_tracks/ft_utils.py:37-62: a track survives iff one of ITS camera pairs (i < j) is in
+    pairs_to_triangulate -- a pair listed as (j, i) never matches.
+    """
+    from satba import ba_outliers
+
+    rng = np.random.default_rng(3)
+    M, N = 7, 300
+    seen = rng.random((N, M)) < 0.4
+    pts_ind, cam_ind = np.nonzero(seen)
+    for pairs in ([(0, 1), (2, 5), (3, 6)], [(1, 0), (5, 2)], [(0, 1), (4, 2), (2, 4), (6, 9)], []):
+        want = np.array([len({(a, b) for a in np.nonzero(seen[q])[0] for b in np.nonzero(seen[q])[0] if a < b} & set(pairs)) > 0
+                         for q in range(N)])
+        got = ba_outliers._tracks_with_a_listed_pair(pts_ind, cam_ind, N, M, pairs)
+        assert np.array_equal(got, want)
+
+
+def test_device_percentile_index_is_numpys():
+    """
+    csrc/satba_outliers.h evaluates np.percentile(v, 80) with the virtual index (n - 1) * 0.8 of numpy's "linear" method and
+    numpy's two-sided lerp: the same sequence of IEEE operations restated here must reproduce np.percentile bit for bit for every
+    length (including n = 1 mod 5, where 0.8 (n - 1) is an integer).
+    """
+    rng = np.random.default_rng(0)
+    for n in range(1, 3000):
+        v = np.sort(rng.random(n) * 10)
+        vi = (n - 1) * 0.8
+        lo = int(np.floor(vi))
+        hi = min(lo + 1, n - 1)
+        t, a, b = vi - lo, v[lo], v[hi]
+        pct = a + (b - a) * t
+        if t >= 0.5:
+            pct = b - (b - a) * (1 - t)
+        assert pct == np.percentile(v, 80), n
