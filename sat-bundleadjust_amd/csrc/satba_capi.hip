@@ -190,7 +190,7 @@ static size_t table_bytes(const satba_problem* p) {
     return sizeof(double) * ((p->camc_lds ? (size_t)p->M * CAMC : 0) + ((p->model == RPC && p->rpc_lds) ? (size_t)p->M * RPCS : 0));
 }
 static size_t lin_lds(const satba_problem* p) {
-    return table_bytes(p) + (p->cam_sums_lds ? sizeof(double) * (size_t)(p->M << p->lin_rep_shift) * cam_sum_stride(p->NP) : 0);
+    return table_bytes(p) + (p->cam_sums_lds ? cam_sum_bytes(p->NP, (size_t)(p->M << p->lin_rep_shift)) : 0);
 }
 static size_t dir_table_bytes(const satba_problem* p) { return sizeof(double) * (size_t)p->M * JVP_ROW; }
 
@@ -723,13 +723,14 @@ int satba_problem_create(const satba_problem_desc* d, satba_problem** out) {
         const size_t budget = 150 * 1024;
         const size_t camc_b = sizeof(double) * (size_t)p->M * CAMC, rpc_b = sizeof(double) * (size_t)p->M * RPCS;
         // replicas of the camera-sum table: same-address and same-bank atomics of a wave spread over them.  Measured at 200 cameras
-        // (k_linearize in the loop): 1 replica 0.1206 ms, 2: 0.1136, 4: 0.1117 although only one workgroup per CU fits then; at 50
-        // cameras 16 replicas are as good as or better than 4 (C3 0.038 vs 0.040, P3 0.040 vs 0.047, C5 0.118 vs 0.119)
+        // (k_linearize in the loop, fixed-point sums of round 3): 1 replica 0.112 ms, 2: 0.109, 4: 0.105 although only one workgroup
+        // per CU fits then (the sums are integers: every replica count gives the same bits); at 50 cameras 16 replicas are as good as
+        // or better than 4 (round 2, float atomics: C3 0.038 vs 0.040, P3 0.040 vs 0.047, C5 0.118 vs 0.119)
         while (p->lin_rep_shift < 4 && (p->M << (p->lin_rep_shift + 1)) <= 1024 &&
-               sizeof(double) * (size_t)(p->M << (p->lin_rep_shift + 1)) * cam_sum_stride(p->NP) + camc_b <= 112 * 1024)
+               cam_sum_bytes(p->NP, (size_t)(p->M << (p->lin_rep_shift + 1))) + camc_b <= 128 * 1024)
             ++p->lin_rep_shift;
         if (const char* rs = getenv("SATBA_LIN_REP")) p->lin_rep_shift = std::min(4, std::max(0, atoi(rs)));  // experiments
-        const size_t acc_b = sizeof(double) * (size_t)(p->M << p->lin_rep_shift) * cam_sum_stride(p->NP);
+        const size_t acc_b = cam_sum_bytes(p->NP, (size_t)(p->M << p->lin_rep_shift));
         p->cam_sums_lds = (acc_b <= budget && !p->deterministic && !getenv("SATBA_CAM_SUMS") && p->n_max_cam <= (double)(1 << 28)) ? 1 : 0;
         size_t used = p->cam_sums_lds ? acc_b : 0;
         p->camc_lds = (camc_b <= 48 * 1024 && used + camc_b <= budget && !getenv("SATBA_CAMC_GLOBAL")) ? 1 : 0;
@@ -757,7 +758,7 @@ int satba_problem_create(const satba_problem_desc* d, satba_problem** out) {
         { const char* cs = getenv("SATBA_CHOL"); p->chol_mode = cs ? atoi(cs) : 0; }
         TRY(dev_alloc(p, &p->d_dinv, (size_t)((p->n_c + CH_NB - 1) / CH_NB) * CH_NB * CH_NB));
         TRY(dev_alloc(p, &p->d_scal, 8));
-        TRY(dev_alloc(p, &p->d_fx, 2 * 6)); TRY(dev_alloc(p, &p->d_fxe, 6 + 3)); TRY(dev_alloc(p, &p->d_bbox, 6)); TRY(dev_alloc(p, &p->d_fxflag, 1));
+        TRY(dev_alloc(p, &p->d_fx, 2 * 6)); TRY(dev_alloc(p, &p->d_fxe, 6 + 4)); TRY(dev_alloc(p, &p->d_bbox, 6)); TRY(dev_alloc(p, &p->d_fxflag, 1));
         TRY(dev_alloc(p, &p->d_fxcost, 1)); TRY(dev_alloc(p, &p->d_fxcost_new, 1)); TRY(dev_alloc(p, &p->d_fxcost0, 1));
         HIP_TRY(hipMemset(p->d_bbox, 0, sizeof(double) * 6));
         HIP_TRY(hipMemset(p->d_fxflag, 0, sizeof(int)));
@@ -994,7 +995,7 @@ int satba_linearize(satba_problem* p) {
         const int const_t = lin_const_t(p->model, p->NP, p->loss != 0, p->loss == 0 && p->unit_weights) && lin_variant(p) == 0;
         const int total = p->M * 2 * p->NP;
         hipLaunchKernelGGL(k_lin_finish, dim3((total + 63) / 64), dim3(1024), 0, p->stream, p->M, p->NP, p->lin_grid, p->d_part, U, gc,
-                           p->L.cam_ofs, p->d_camc, p->n_cam_fix, const_t, p->d_fx, p->d_fxflag, p->d_xb + SATBA_HDR_FX);
+                           p->L.cam_ofs, p->d_camc, p->n_cam_fix, const_t, p->d_fx, p->d_fxe, p->d_fxflag, p->d_xb + SATBA_HDR_FX);
         HIP_TRY(hipGetLastError());
     } else {
         TRY(launch_cam_sums(p, U, gc));  // camera-major pass, fixed summation order; fills the full blocks

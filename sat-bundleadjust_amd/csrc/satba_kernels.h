@@ -25,10 +25,13 @@ __host__ __device__ constexpr int cam_acc_len(int np) { return np * (np + 1) / 2
 // row stride of the LDS camera table: odd, so that (stride * cam + k) visits all 32 bank pairs (an even stride such
 // as 20 folds the cameras onto 8 of them: 8-way conflicts of the ds_add_f64)
 __host__ __device__ constexpr int cam_acc_stride(int np) { return cam_acc_len(np) | 1; }
-// k_linearize's LDS table holds diag(U_c) and g_c only, g_c in two 64-bit limbs: 3 np sums per camera, odd row stride (9, 15, 19)
+// k_linearize's LDS tables hold diag(U_c) and g_c only: 2 np 64-bit sums per camera (odd row stride 7, 11, 13) and np 32-bit
+// sums, the low limbs of g_c (odd row stride 3, 5, 7 dwords); the per-workgroup partials are 3 np 64-bit words per camera
 __host__ __device__ constexpr int cam_sum_len(int np) { return 3 * np; }
-__host__ __device__ constexpr int cam_sum_stride(int np) { return (3 * np) | 1; }
-constexpr int FX_LO_SHIFT = 40;  // the low limb of a g_c term holds its remainder below the high limb's unit, scaled by 2^40
+__host__ __device__ constexpr int cam_sum_stride(int np) { return (2 * np) | 1; }
+__host__ __device__ constexpr int cam_lo_stride(int np) { return np | 1; }
+// bytes of both tables for `rows` (camera, replica) rows; the 32-bit table follows the 64-bit one
+__host__ __device__ constexpr size_t cam_sum_bytes(int np, size_t rows) { return ((rows * (cam_sum_stride(np) * 8 + cam_lo_stride(np) * 4) + 7) / 8) * 8; }
 
 constexpr int RPCS = 91;  // row stride of the LDS copy of the RPC tables (90 used, odd)
 // double -> 64-bit fixed point through one fma (k_linearize's camera sums): bits(t 2^e + 1.5 * 2^52) = FX_MAGIC_BITS + round(t 2^e)
@@ -505,7 +508,7 @@ template <int MODEL, int NP, bool ROBUST, bool CL, bool RL, bool SOFT, bool UNIT
 __global__ __launch_bounds__(LinCfg<(ROBUST && !SOFT) || MODEL == RPC>::THREADS) void k_linearize(
     ObsArgs a, double2* __restrict__ f, double* __restrict__ V, double* __restrict__ gp, double* __restrict__ part, RedBuf rb,
     double* __restrict__ hdr_cost, double* __restrict__ hdr_gpmax) {
-    constexpr int CUS = cam_sum_stride(NP);
+    constexpr int CUS = cam_sum_stride(NP), CLS = cam_lo_stride(NP);
     using Cfg = LinCfg<(ROBUST && !SOFT) || MODEL == RPC>;
     constexpr int THREADS = Cfg::THREADS, WAVES = Cfg::WAVES;
     extern __shared__ double s_lin[];
@@ -515,18 +518,21 @@ __global__ __launch_bounds__(LinCfg<(ROBUST && !SOFT) || MODEL == RPC>::THREADS)
     // adds the replicas up.
     const int n_rows = a.M << a.rep_shift;
     unsigned long long bad = 0ull;  // wave mask of the lanes that saw a term outside the fixed-point range (SALU: s_or_b64)
-    int fea[NP], feb = 0, fc1 = 0, fc2 = 0;
+    int fea[NP], feb = 0, fc1 = 0, fc2 = 0, flo = 0;
+    unsigned* s_lo = reinterpret_cast<unsigned*>(s_acc + (size_t)n_rows * CUS);
     if constexpr (CAMSUMS) {
         for (int i = threadIdx.x; i < n_rows * CUS; i += THREADS) s_acc[i] = 0ull;
+        for (int i = threadIdx.x; i < n_rows * CLS; i += THREADS) s_lo[i] = 0u;
         // wave-uniform scalars, read once (left to the compiler they were re-fetched with vector loads in every iteration)
 #pragma unroll
         for (int i = 0; i < NP; ++i) fea[i] = __builtin_amdgcn_readfirstlane(a.fxe[i]);
         feb = __builtin_amdgcn_readfirstlane(a.fxe[NP]);
         fc1 = __builtin_amdgcn_readfirstlane(a.fxe[NP + 1]);
         fc2 = __builtin_amdgcn_readfirstlane(a.fxe[NP + 2]);
+        flo = __builtin_amdgcn_readfirstlane(a.fxe[NP + 3]);
     }
     CamTables<CL, RL> T;
-    T.stage(a, s_lin + (CAMSUMS ? (size_t)n_rows * CUS : 0), THREADS);
+    T.stage(a, s_lin + (CAMSUMS ? cam_sum_bytes(NP, n_rows) / 8 : 0), THREADS);
     if constexpr (CAMSUMS && !CL && !RL) __syncthreads();
     const int lane = threadIdx.x & 63;
     const bool const_t = lin_const_t(MODEL, NP, ROBUST, a.unit != 0);
@@ -573,7 +579,9 @@ __global__ __launch_bounds__(LinCfg<(ROBUST && !SOFT) || MODEL == RPC>::THREADS)
                 v[8] += e.Jp[0][2] * e.fs[0] + e.Jp[1][2] * e.fs[1];
                 if constexpr (CAMSUMS) {
                     // camera block: fixed-point LDS atomics (ds_add_u64) into this workgroup's table
-                    unsigned long long* acc = s_acc + (size_t)((cam << a.rep_shift) | (lane & ((1 << a.rep_shift) - 1))) * CUS;
+                    const int row = (cam << a.rep_shift) | (lane & ((1 << a.rep_shift) - 1));
+                    unsigned long long* acc = s_acc + (size_t)row * CUS;
+                    unsigned* acc_lo = s_lo + (size_t)row * CLS;
 #pragma unroll
                     for (int i = 0; i < NP; ++i)
                         if (!(const_t && i >= 3)) {
@@ -583,16 +591,17 @@ __global__ __launch_bounds__(LinCfg<(ROBUST && !SOFT) || MODEL == RPC>::THREADS)
                         }
 #pragma unroll
                     for (int i = 0; i < NP; ++i) {
-                        // g_c in two limbs: the integer part of the scaled term, and its exact remainder (|rem| <= 1/2) times 2^40.
-                        // The gradient is what the minimiser is defined by (its cancellation at the solution happens exactly, in
-                        // integers; k_lin_finish rounds once, relative to the SUM): one limb of 46 .. 50 bits left the tight runs
-                        // 1e-5 from the reference along flat directions, where float64 sums in a fixed order reach 1e-7
+                        // g_c in two limbs: the integer part of the scaled term (64 bits), and its exact remainder (|rem| <= 1/2) times
+                        // 2^S (32 bits, S <= 20 with n_max 2^(S-1) < 2^31: ds_add_u32 costs half a 64-bit atomic).  The gradient is
+                        // what the minimiser is defined by: its cancellation at the solution happens exactly, in integers, and
+                        // k_lin_finish rounds once, relative to the SUM.  One limb of 46 .. 50 bits left the tight runs 1e-5 from
+                        // the reference along flat directions, where float64 sums in a fixed order reach 1e-7
                         const double ts = ldexp(e.Jc[0][i] * e.fs[0] + e.Jc[1][i] * e.fs[1], fea[i] + feb);
                         const double y = ts + FX_MAGIC;
                         bad |= __ballot((unsigned)(__double2hiint(y) + fc1) >= (unsigned)fc2);
-                        const double y2 = ldexp(ts - (y - FX_MAGIC), FX_LO_SHIFT) + FX_MAGIC;
+                        const double y2 = ldexp(ts - (y - FX_MAGIC), flo) + FX_MAGIC;
                         atomicAdd(acc + NP + i, (unsigned long long)__double_as_longlong(y));
-                        atomicAdd(acc + 2 * NP + i, (unsigned long long)__double_as_longlong(y2));
+                        atomicAdd(acc_lo + i, (unsigned)__double2loint(y2));
                     }
                 }
             }
@@ -625,7 +634,10 @@ __global__ __launch_bounds__(LinCfg<(ROBUST && !SOFT) || MODEL == RPC>::THREADS)
         for (int i = threadIdx.x; i < a.M * 3 * NP; i += THREADS) {
             const int cam = i / (3 * NP), k = i % (3 * NP);
             unsigned long long t = 0ull;
-            for (int r = 0; r < (1 << a.rep_shift); ++r) t += s_acc[(size_t)((cam << a.rep_shift) | r) * CUS + k];
+            for (int r = 0; r < (1 << a.rep_shift); ++r) {
+                const size_t row = (size_t)((cam << a.rep_shift) | r);
+                t += k < 2 * NP ? s_acc[row * CUS + k] : (unsigned long long)s_lo[row * CLS + (k - 2 * NP)];  // low limbs: modulo 2^32
+            }
             out[i] = t;  // fixed cameras (unmasked on the unit-weight path) are zeroed by k_lin_finish
         }
     }
@@ -641,8 +653,8 @@ __global__ __launch_bounds__(LinCfg<(ROBUST && !SOFT) || MODEL == RPC>::THREADS)
 __global__ __launch_bounds__(1024) void k_lin_finish(int M, int NP, int nblocks, const double* __restrict__ part, double* __restrict__ U,
                                                      double* __restrict__ gc, const int* __restrict__ cam_ofs,
                                                      const double* __restrict__ camc, int n_cam_fix, int const_t,
-                                                     const double* __restrict__ fx, const int* __restrict__ fx_flag,
-                                                     double* __restrict__ hdr_flag) {
+                                                     const double* __restrict__ fx, const int* __restrict__ fxe,
+                                                     const int* __restrict__ fx_flag, double* __restrict__ hdr_flag) {
     const int W = 3 * NP;  // diag U_c | g_c high limbs | g_c low limbs
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int idx = blockIdx.x * 64 + lane;  // output (camera, k), k < 2 NP
@@ -666,7 +678,7 @@ __global__ __launch_bounds__(1024) void k_lin_finish(int M, int NP, int nblocks,
     for (int w = 0; w < 16; ++w) { s += s_sum[0][w][lane]; s2 += s_sum[1][w][lane]; }
     const unsigned long long n_obs = (unsigned long long)(cam_ofs[cam + 1] - cam_ofs[cam]);
     double v = (double)(long long)(s - n_obs * FX_MAGIC_BITS);
-    if (k >= NP) v += ldexp((double)(long long)(s2 - n_obs * FX_MAGIC_BITS), -FX_LO_SHIFT);  // one rounding, relative to the sum
+    if (k >= NP) v += ldexp((double)(int)(unsigned)s2, -fxe[NP + 3]);  // low limbs: sum modulo 2^32 (the constant's low word is 0)
     v *= fx[k];
     if (cam < n_cam_fix) v = 0.0;
     if (k >= NP) {
@@ -692,7 +704,7 @@ __global__ __launch_bounds__(1024) void k_lin_finish(int M, int NP, int nblocks,
 // Range of a converted term: |r| < 2^Q with Q = min(50, 62 - ceil(log2 n_max)) (conversion range; the final sum of n_max terms
 // stays inside 63 bits).  Exponents: JB_k 2^a_k < 2^h and FB 2^b < 2^h with h = (Q - 1) / 2 (integer division), so that the U
 // terms, scaled by 2^(2 a_k), and the g terms, scaled by 2^(a_k + b), stay below 2^Q.
-// fxe: a_0 .. a_{NP-1} | b | c1 | c2  -- the range check of k_linearize is (hi32(y) + c1) <u c2, i.e. r >> 32 in [-L, L), L = 2^(Q-32);
+// fxe: a_0 .. a_{NP-1} | b | c1 | c2 | S  -- S: scale exponent of the 32-bit low limbs of g_c; the range check of k_linearize is (hi32(y) + c1) <u c2, i.e. r >> 32 in [-L, L), L = 2^(Q-32);
 // fx:  [2 NP] inverse scales 2^-(2 a_k), 2^-(a_k + b).  The bounds need not be rigorous: every term is checked.
 template <int MODEL, int NP>
 __global__ __launch_bounds__(256) void k_lin_scales(int M, const double* __restrict__ camc, const double* __restrict__ rpc,
@@ -752,6 +764,7 @@ __global__ __launch_bounds__(256) void k_lin_scales(int M, const double* __restr
         const int L = 1 << (Q - 32);
         fxe[NP + 1] = (int)((unsigned)L - 0x43380000u);
         fxe[NP + 2] = 2 * L;
+        fxe[NP + 3] = max(1, min(20, 31 - lg_n));  // S: low limbs of g_c, |sum| <= n_max 2^(S-1) < 2^31
     }
 }
 
