@@ -102,6 +102,7 @@ def lm_step_native(eng, st):
     r = eng.lm_step(st["first"], st.get("Delta", -1.0), 1e-14)
     st["first"] = False
     st["Delta"] = r["Delta"]
+    st["lam"] = r["lam"]
     st["interior"] = st.get("interior", 0) + int(r["newton"])
     st["accepted"] += int(r["accepted"])
     st["cost"] = r["cost_new"] if r["accepted"] else r["cost"]
@@ -189,8 +190,9 @@ def main():
                     help="points of the CPU-baseline sub-problem (0 = skip); 20000 points = 200 k observations, ~20 s")
     ap.add_argument("--kernel-reps", type=int, default=20)
     ap.add_argument("--loss", default="linear", help="linear (headline) | soft_l1 | huber | cauchy | arctan")
-    ap.add_argument("--driver", default="auto", help="host side of an LM iteration: native (C++, satba_lm_step; one rank) | python (phase "
-                    "entry points + all-reduces) | auto (native for one rank)")
+    ap.add_argument("--driver", default="auto", help="host side of an LM iteration: native (device-resident loop, satba_lm_ticks; one rank) | "
+                    "native-sync (C++ host loop, satba_lm_step: two header reads per iteration) | python (phase entry points + all-reduces) | "
+                    "auto (native for one rank)")
     ap.add_argument("--cpu-c3", action="store_true", help="also run the measured C3 CPU baseline (max_nfev=3, ~10 min)")
     ap.add_argument("--camera-major", action="store_true", help="form the per-camera sums with the camera-major float64 pass from the "
                     "start (SATBA_FLAG_CAMERA_MAJOR_SUMS: the route the fixed-point sums fall back to)")
@@ -243,9 +245,9 @@ def main():
     # single rank: the host side of an iteration is the library's C++ (satba_lm_step, the loop body of satba_solve_lm, which is
     # what ba_core's solve runs); several ranks: the Python phases with the all-reduces between them
     driver = args.driver if args.driver != "auto" else ("native" if world == 1 else "python")
-    if driver == "native" and world > 1:
+    if driver.startswith("native") and world > 1:
         raise SystemExit("--driver native drives one rank")
-    step = (lambda: lm_step_native(eng, st)) if driver == "native" else (lambda: lm_step(eng, comm, st, trf))
+    step = (lambda: lm_step_native(eng, st)) if driver.startswith("native") else (lambda: lm_step(eng, comm, st, trf))
     st = {"first": True, "accepted": 0, "fail": 0, "cost": None}
     # Every timed step is an iteration a real solve performs.  The solve from x0 under the shipped tolerances (ftol 1e-4, xtol 1e-10,
     # max_iter 300: ba_core.init_optimization_config) is run once, untimed, and takes `restart` LM iterations (linear loss at the
@@ -254,7 +256,7 @@ def main():
     # solve starts.  Without restarts all but the first steps would sit on the converged point, where the trust radius collapses to
     # 1e-15 and the loop's degenerate-subspace fallbacks run (extra passes, and run-dependent: 632 - 684 it/s over repeated runs).
     restart, solve_stats = max(args.restart_every, 0), None
-    if args.restart_every < 0 and driver == "native":
+    if args.restart_every < 0 and driver.startswith("native"):
         eng.snapshot_x(False)
         ls = eng.solve_lm(ftol=1e-4, xtol=1e-10, gtol=1e-8, max_nfev=300, loss=args.loss, f_scale=1.0)
         restart = max(1, int(ls.nfev) - 1)
@@ -288,22 +290,55 @@ def main():
             st["first"] = True
         plain_step()
         n_step[0] += 1
-    for _ in range(args.warmup):
-        step()
+
+    # One rank: the iterations run on the device-resident loop (satba_lm_run, csrc/satba_lmdev.h: the same phases, the decisions
+    # between them -- and the return to x0 every `restart` iterations -- taken by one-thread kernels on the device; the host only
+    # queues launches); `--driver native-sync` times the round-2 host side instead (satba_lm_step: two blocking header reads per
+    # iteration, a failed factorisation is not repeated).
+    ticks = driver == "native" and not os.environ.get("SATBA_HOST_LOOP") and (args.driver == "native" or bool(eng.info()["device_loop"]))
+    if driver == "native" and not ticks:
+        driver = "native-sync"  # what satba_solve_lm uses at this size (auto), or forced by the environment
+    ls = None
+
+    def run(n):
+        """n iterations, the point going back to x0 every `restart` of them"""
+        if ticks:
+            return eng.lm_run(n, cycle_len=restart, lam_floor=1e-14)
+        for _ in range(n):
+            step()
+        return None
+
+    if args.warmup:
+        run(args.warmup)
     sync()
     st["accepted"] = 0
     n_step[0] = 0
     if restart:
         eng.snapshot_x(True)
         st["first"] = True
-    eng.profile_linearize(True)  # HIP events around every k_linearize launch of the timed iterations, on its launch stream
+    sync()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    ls = run(args.steps)
     sync()
     dt = time.perf_counter() - t0
+    # the roofline kernel inside LM iterations: a second pass over the same iterations with HIP events around every k_linearize
+    # launch, on its launch stream (the timed pass replays a captured graph per iteration: no events inside it)
+    if restart:
+        eng.snapshot_x(True)
+        st["first"] = True
+    n_step[0] = 0
+    keep = dict(st)
+    eng.profile_linearize(True)
+    run(min(args.steps, 40))
     n_lin, ms_lin = eng.profile_read()
     eng.profile_linearize(False)
+    st.clear()
+    st.update(keep)
+    if ticks:
+        if int(ls["phase"]) == 2:
+            raise SystemExit("the device-resident loop stopped for the host (reason {}): use --driver native-sync".format(int(ls["host_reason"])))
+        assert int(ls["iterations"]) == args.steps, ls
+        st.update(accepted=int(ls["accepted"]), interior=int(ls["newton"]), cost=ls["cost_new"] if ls["actual"] > 0 else ls["cost"])
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -364,6 +399,7 @@ def main():
                          "ms_per_launch_back_to_back": kern["linearize"]},
             "kernel_ms": kern,
             "accepted_steps": st["accepted"], "interior_2d_steps": st.get("interior", 0), "final_cost": st["cost"], "scene_gen_s": t_gen,
+            "launch_patterns_executed": int(ls["ticks"]) if ls else None,  # > steps when a factorisation had to be repeated with more damping
         }
         if args.cpu_sample_pts > 0 and world == 1:
             out["cpu_baseline"] = cpu_baseline(scene, min(args.cpu_sample_pts, n_pts), corr, full_c3=args.cpu_c3)

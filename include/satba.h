@@ -105,8 +105,11 @@ int satba_version(void);
 int satba_problem_create(const satba_problem_desc *desc, satba_problem **out);
 void satba_problem_destroy(satba_problem *p);
 
-/* All kernels of this handle are launched on `hip_stream` (a hipStream_t; NULL = default stream). */
-int satba_set_stream(satba_problem *p, void *hip_stream);
+/* A handle launches everything on a stream of its own (created non-blocking with the handle).  satba_set_stream moves it to
+ * `hip_stream` (a hipStream_t; NULL = the legacy default stream) -- e.g. the stream torch.distributed queues its collectives on --
+ * or, with use_own != 0, back to its own.  The device-resident loop replays a captured hipGraph per iteration where the stream
+ * can be captured (not the legacy default stream: direct launches there). */
+int satba_set_stream(satba_problem *p, void *hip_stream, int32_t use_own);
 
 /* Length in doubles of the exchange buffer: header + max(M n_p^2 + M n_p, (M n_p)^2 + M n_p). */
 int64_t satba_exchange_len(const satba_problem *p);
@@ -183,6 +186,21 @@ int satba_read_header(satba_problem *p, double *host_hdr);
  * actual reduction, damping. */
 int satba_lm_step(satba_problem* p, int32_t first, double Delta, double lam_floor, double* out);
 
+/* The same iterations WITHOUT a host round trip (round 3; csrc/satba_lmdev.h): the loop's decisions -- scipy's top-of-loop tests,
+ * damping escalation after a failed factorisation, the 2-D trust-region subproblem, radius update, accept / reject -- are taken by
+ * one-thread kernels on the device, every kernel of an iteration reads a gate word of the loop's state in device memory, accepted
+ * points are copied on the device, and the host only queues launches (a few iterations ahead of the device's progress reports in
+ * pinned memory).  satba_lm_run performs n_iterations fixed-work iterations (no termination tests: satba_lm_step's semantics) from
+ * the current x; cycle_len > 0: every cycle_len iterations the solve starts again from the point kept by satba_snapshot_x (what
+ * bench.py does with the solve that the shipped tolerances end after that many iterations).  It returns when the device is done.
+ * out (may be NULL; n_out >= 16), also returned by satba_lm_state: [0..7] as satba_lm_step for the last iteration ([3], [4]: totals
+ * of accepted and interior steps), [8] phase (0 running, 1 finished, 2 stopped for the host), [9] scipy status, [10] nfev, [11] njev,
+ * [12] iterations, [13] launch patterns ("ticks") executed, [14] reason of phase 2 (1 fixed-point overflow of the camera sums,
+ * 2 factorisation failed ten times, 3 non-finite residuals at the start), [15] |g|_inf.  satba_solve_lm runs on the same
+ * machinery with scipy's termination tests switched on.  Single-rank handles only. */
+int satba_lm_run(satba_problem* p, int64_t n_iterations, int32_t cycle_len, double lam_floor, double* out, int32_t n_out);
+int satba_lm_state(satba_problem* p, double* out, int32_t n);
+
 /* ---- one-shot solve: the whole trust-region loop (scipy:optimize/_lsq/trf.py:401-560 as ba_core.py:284-297 configures it,
  * with the exact damped step of this library) below the ABI, for callers that do not want to drive the phases themselves.
  * Starts from the current x (satba_set_x), leaves the solution in the handle (satba_get_x, satba_residuals).  Single-rank
@@ -257,7 +275,8 @@ int satba_get_layout(satba_problem *p, int32_t which, int64_t n, void *host_out)
  * known, the ELL + camera-major lists were queued, the pair lists were finished, the handle was complete; [5] padded ELL length,
  * [6] pair-list entries, [7] pair-list chunks, [8] unit weights, [9] camera constants in LDS, [10] RPC tables in LDS,
  * [11] camera sums by (fixed-point) LDS atomics, [12] camera-major sums requested, [13] chunks of the camera-major passes,
- * [14] workgroups of k_linearize, [15] fall-backs from the fixed-point sums so far */
+ * [14] workgroups of k_linearize, [15] fall-backs from the fixed-point sums so far, [16] satba_solve_lm runs on the
+ * device-resident loop (n >= 17), [17] column ranges of the overlapped factorisation (1: not overlapped; n >= 18) */
 int satba_get_info(const satba_problem *p, double *out, int32_t n);
 /* normal-equation blocks of the last linearize: U (M n_p n_p), g_c (M n_p) as written to the exchange
  * payload, V (N x 6: xx xy xz yy yz zz), g_p (N x 3), points in the caller's order. Any pointer may be NULL.

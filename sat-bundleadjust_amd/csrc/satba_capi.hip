@@ -22,6 +22,7 @@
 #include "satba_kernels.h"
 #include "satba_layout.h"
 #include "satba_lm.h"
+#include "satba_lmdev.h"
 #include "satba_outliers.h"
 #include "satba_triangulate.h"
 #include "satba_rpcfit.h"
@@ -66,6 +67,31 @@ struct satba_problem {
     bool fxcost_valid = false, fxcost_new_valid = false, fxcost0_valid = false;
     double w_max = 1.0, n_max_cam = 1.0, fx_shrink = 1.0;
     int fx_fallbacks = 0;
+    // device-resident LM loop (satba_lmdev.h): while a tick is being queued, `gate` points at the word of the loop's state that
+    // switches the kernels of the current part of the pattern on or off, and the trust radius / first-iteration flag / trial
+    // coefficients are read from the state instead of the launch arguments
+    const int* gate = nullptr;
+    const double* Delta_dev = nullptr;
+    const int* first_dev = nullptr;
+    const double* coef_dev = nullptr;
+    const double* lam_force_dev = nullptr;
+    const double* sub_args_dev = nullptr;
+    struct LmDev* d_lm = nullptr;
+    struct LmSummary* h_lm = nullptr;  // pinned, mapped: the device posts the progress of the loop here
+    struct LmSummary* h_lm_dev = nullptr;
+    long long lm_ticks_queued = 0;
+    hipGraphExec_t lm_graph = nullptr;  // the captured tick
+    bool lm_no_graph = false;           // the handle's stream cannot be captured (the legacy default stream): direct launches
+    hipStream_t own_stream = nullptr;   // created with the handle: the stream of every launch unless satba_set_stream names another
+    struct LmGraphKey {
+        const void *x, *xnew, *camc, *fxcost, *xb, *x0;
+        hipStream_t stream;
+        int loss;
+        double f_scale;
+        int cam_sums_lds;
+        double lam_floor;
+        bool fxcost_valid;
+    } lm_key{};
     double f_scale = 1.0, lead = 1.0;
     hipStream_t stream = nullptr;
     Layout L;
@@ -89,6 +115,15 @@ struct satba_problem {
     SchurItem* d_item_desc_merged = nullptr;
     int n_item_blocks_merged = 0;
     int n_item_blocks = 0;
+    // factorisation overlapped with the Schur pass (cholesky_solve_overlapped): column ranges of S, the camera rows that complete
+    // them, an item table per range (chunked and merged), the second stream and its events
+    CholOverlap ov;
+    int seg_cam_end[CH_MAX_SEG] = {0, 0, 0, 0};
+    int2* d_seg_items[2][CH_MAX_SEG] = {};
+    SchurItem* d_seg_desc[2][CH_MAX_SEG] = {};
+    int n_seg_blocks[2][CH_MAX_SEG] = {};
+    hipStream_t stream2 = nullptr;
+    hipEvent_t ev_done = nullptr;
 
     int lin_grid = 0, cm_chunks = 1;
     double* d_red = nullptr;  // RED_SLOTS x (RED_MAX_NV x RED_MAX_GRID doubles) partials of the deterministic grid sums
@@ -173,7 +208,7 @@ static ObsArgs obs_args(const satba_problem* p, bool at_new) {
     a.f_scale = p->f_scale;
     a.unit = (p->loss == 0 && p->unit_weights) ? 1 : 0;
     a.rep_shift = p->lin_rep_shift;
-    a.fxe = p->d_fxe; a.fx_flag = p->d_fxflag;
+    a.fxe = p->d_fxe; a.fx_flag = p->d_fxflag; a.gate = p->gate;
     a.sh = 0;  // lanes per point: set by the launchers of the kernels that support it
     return a;
 }
@@ -202,7 +237,7 @@ static int raise_lds_limit(K kernel, size_t bytes) {
 
 static int launch_cam_consts(satba_problem* p, bool at_new) {
     hipLaunchKernelGGL(k_cam_consts, dim3((p->M + 63) / 64), dim3(64), 0, p->stream, p->model, p->M, p->NP, p->c_p,
-                       at_new ? p->d_xnew : p->d_x, p->d_cam_static, at_new ? p->d_camc_new : p->d_camc);
+                       at_new ? p->d_xnew : p->d_x, p->d_cam_static, at_new ? p->d_camc_new : p->d_camc, p->gate);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -245,13 +280,13 @@ static int launch_residual(satba_problem* p, bool at_new, double2* f, double* co
 // trial point + cost there + |step|^2, |x|^2 in one pass over the observations (k_residual<..., TRIAL>)
 static int launch_trial(satba_problem* p, double c0, double c1, const double* v0, const double* v1) {
     hipLaunchKernelGGL(k_trial_cams, dim3((std::max(p->M, (int)p->hdr) + 63) / 64), dim3(64), 0, p->stream, p->model, p->M, p->NP, p->c_p, p->d_x, v0, v1,
-                       p->d_scale_inv, c0, c1, p->d_cam_static, p->d_xnew, p->d_camc_new, p->d_xb, (int)p->hdr);
+                       p->d_scale_inv, c0, c1, p->d_cam_static, p->d_xnew, p->d_camc_new, p->d_xb, (int)p->hdr, p->coef_dev, p->gate);
     HIP_TRY(hipGetLastError());
     ObsArgs a = obs_args(p, true);
     a.sh = slice_split(p);
     const int grid = slice_grid(p, RES_THREADS / 64, 2, a.sh);
     const size_t lds = table_bytes(p);
-    const TrialArgs t{p->d_x, v0, v1, p->d_scale_inv, p->d_xnew, c0, c1, p->lead, p->d_xb + 2, p->d_xb + 3, p->d_fxcost_new};
+    const TrialArgs t{p->d_x, v0, v1, p->d_scale_inv, p->d_xnew, c0, c1, p->lead, p->d_xb + 2, p->d_xb + 3, p->d_fxcost_new, p->coef_dev};
     p->fxcost_new_valid = true;
     double* cost = p->d_xb + 1;
     if (p->loss == 0 && p->unit_weights)
@@ -349,7 +384,7 @@ static int launch_cam_sums(satba_problem* p, double* U, double* gc) {
     SATBA_DISPATCH(p, hipLaunchKernelGGL((k_cam_sums<MODEL, NP>), dim3(p->M, p->cm_chunks), dim3(LINC_THREADS), 0, p->stream, a, cm, p->d_f, p->d_part3));
     HIP_TRY(hipGetLastError());
     const int total = p->M * cam_acc_len(p->NP);
-    hipLaunchKernelGGL(k_cam_sums_finish, dim3((total + 255) / 256), dim3(256), 0, p->stream, p->M, p->NP, p->cm_chunks, p->d_part3, U, gc);
+    hipLaunchKernelGGL(k_cam_sums_finish, dim3((total + 255) / 256), dim3(256), 0, p->stream, p->M, p->NP, p->cm_chunks, p->d_part3, U, gc, p->gate);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -379,12 +414,43 @@ static int launch_schur(satba_problem* p, const ObsArgs& a, double* S, double* r
         if (p->L.C > 1 && !merged) {
             const long long outs = n_pairs * NP * NP;
             hipLaunchKernelGGL(k_schur_pairs_reduce, dim3((unsigned)((outs + 255) / 256)), dim3(256), 0, p->stream, p->M, NP, p->n_c, p->L.C,
-                               p->L.pair_ij, p->d_pair_part, S);
+                               p->L.pair_ij, p->d_pair_part, S, p->gate, 0ll, n_pairs);
         }
     }
     const int total = p->M * cam_acc_len(NP);
-    hipLaunchKernelGGL(k_schur_diag_finish, dim3((total + 255) / 256), dim3(256), 0, p->stream, p->M, NP, p->n_c, p->cm_chunks, p->d_part3, S, rhs);
+    hipLaunchKernelGGL(k_schur_diag_finish, dim3((total + 255) / 256), dim3(256), 0, p->stream, p->M, NP, p->n_c, p->cm_chunks, p->d_part3, S, rhs, p->gate);
     HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// the Schur kernels of the overlapped path: diagonal blocks first, then the pair kernel once per column range with an event behind it
+template <int MODEL, int NP>
+static int launch_schur_segments(satba_problem* p, const ObsArgs& a, double* S, double* rhs) {
+    CamMajor cm = cam_major(p);
+    SchurArgs s0 = schur_args(p);
+    hipLaunchKernelGGL((k_schur_diag<MODEL, NP>), dim3(p->M, p->cm_chunks), dim3(LINC_THREADS), 0, p->stream, a, cm, s0, p->d_part3);
+    const int total = p->M * cam_acc_len(NP);
+    hipLaunchKernelGGL(k_schur_diag_finish, dim3((total + 255) / 256), dim3(256), 0, p->stream, p->M, NP, p->n_c, p->cm_chunks, p->d_part3, S, rhs, p->gate);
+    HIP_TRY(hipGetLastError());
+    const bool merged = a.unit && p->d_seg_desc[1][0];
+    for (int sg = 0; sg < p->ov.n_seg; ++sg) {
+        SchurArgs s = s0;
+        s.desc = p->d_seg_desc[merged ? 1 : 0][sg]; s.items = p->d_seg_items[merged ? 1 : 0][sg];
+        if (merged) s.n_chunks = 1;
+        const dim3 igrid((unsigned)p->n_seg_blocks[merged ? 1 : 0][sg]);
+        if (a.unit) hipLaunchKernelGGL((k_schur_pairs<MODEL, NP, true>), igrid, dim3(256), 0, p->stream, a, s, S);
+        else hipLaunchKernelGGL((k_schur_pairs<MODEL, NP, false>), igrid, dim3(256), 0, p->stream, a, s, S);
+        if (p->L.C > 1 && !merged) {
+            const int lo = sg ? p->seg_cam_end[sg - 1] : 0, hi = std::min(p->seg_cam_end[sg], p->M - 1);
+            const long long p_lo = pair_index(p->M, lo, lo + 1), p_hi = hi > lo ? pair_index(p->M, hi - 1, p->M - 1) + 1 : p_lo;
+            const long long cnt = p_hi - p_lo;
+            if (cnt > 0)
+                hipLaunchKernelGGL(k_schur_pairs_reduce, dim3((unsigned)((cnt * NP * NP + 255) / 256)), dim3(256), 0, p->stream, p->M, NP, p->n_c, p->L.C,
+                                   p->L.pair_ij, p->d_pair_part, S, p->gate, p_lo, cnt);
+        }
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(p->ov.ready[sg], p->stream));
+    }
     return 0;
 }
 
@@ -430,13 +496,17 @@ static int launch_jvp(satba_problem* p, int nv, const double* q1, const double* 
 // S z = rhs for the reduced system (S column-major lower, destroyed; b in place)
 static int dense_solve(satba_problem* p, double* S, double* b, bool cleared = false) {
     cholesky_solve(S, p->n_c, b, p->d_fail, p->d_fail + 1, p->chol_mode == 3 ? 0 : p->chol_mode, p->stream, nullptr,
-                   p->chol_mode == 3 ? nullptr : p->d_dinv, cleared);  // clears d_fail and the step flags unless the caller has
+                   p->chol_mode == 3 ? nullptr : p->d_dinv, cleared, getenv("SATBA_NOGATE_CHOL") ? nullptr : p->gate);  // clears d_fail and the step flags unless the caller has
     HIP_TRY(hipGetLastError());
     return 0;
 }
 
 // one-thread form of schur_lambda for problems without points (k_vinv is not launched then)
-__global__ void k_lambda(const double* __restrict__ hdr, double Delta, double lam_floor, double* __restrict__ keep) {
+__global__ void k_lambda(const double* __restrict__ hdr, double Delta, double lam_floor, double* __restrict__ keep, const double* __restrict__ Delta_dev,
+                         const double* __restrict__ lam_force, const int* gate) {
+    SATBA_GATE(gate);
+    if (Delta_dev) Delta = *Delta_dev;
+    if (lam_force && *lam_force > 0.0) { keep[5] = *lam_force; return; }
     (void)schur_lambda(hdr, Delta, lam_floor, keep, true);
 }
 
@@ -452,8 +522,10 @@ static double ms_since(std::chrono::steady_clock::time_point t0) {
 // merged: one item per pair covering all its chunks (chunk = -1 in the table): the unit-weight kernels gather nothing per
 // observation and are faster with four times fewer, longer items (0.548 vs 0.576 ms at 200 x 1M x 10M) -- the weighted / robust
 // kernels are not (their row-scale gathers want the locality of the point-range chunks: 1.58 vs 1.74 ms with two chunks).
-static int schur_item_table_build(satba_problem* p, bool merged, int2** d_items, SchurItem** d_desc, int* n_blocks) {
+static int schur_item_table_build(satba_problem* p, bool merged, int2** d_items, SchurItem** d_desc, int* n_blocks, int cam_lo = 0, int cam_hi = -1) {
+    // cam_lo, cam_hi: only the pairs (i, j > i) of the camera rows cam_lo <= i < cam_hi (default: all)
     const int M = p->M, C = merged ? 1 : p->L.C, X = 8;
+    if (cam_hi < 0) cam_hi = M;
     const long long n_pairs = p->L.n_pairs;
     std::vector<int2> table;
     const char* ord = getenv("SATBA_SCHUR_ORDER");
@@ -463,10 +535,11 @@ static int schur_item_table_build(satba_problem* p, bool merged, int2** d_items,
             for (long long pr = 0; pr < n_pairs; ++pr) table.push_back(item(pr, ch));
             while (table.size() % 4) table.push_back(make_int2(-1, 0));
         }
+        (void)cam_lo;  // (the chunk-major order of round 1 is kept for A/B runs of the whole table only)
     } else {
         std::vector<std::vector<int2>> per(X);
         std::vector<long long> load(X, 0);
-        for (int i = 0; i + 1 < M; ++i) {  // rows by decreasing length: i ascending
+        for (int i = cam_lo; i + 1 < M && i < cam_hi; ++i) {  // rows by decreasing length: i ascending
             int x = 0;
             for (int k = 1; k < X; ++k) if (load[k] < load[x]) x = k;
             load[x] += M - 1 - i;
@@ -499,6 +572,48 @@ static int schur_item_table(satba_problem* p) {
     // ... where the pairs alone fill the chip: with few cameras the chunks are what provides the parallelism (50 cameras: 1 225 pairs)
     const bool enough = p->L.n_pairs >= 8192 || (mg && atoi(mg) != 0);
     if (p->L.C > 1 && enough && !(mg && atoi(mg) == 0)) TRY(schur_item_table_build(p, true, &p->d_items_merged, &p->d_item_desc_merged, &p->n_item_blocks_merged));
+    // Column ranges for the overlapped factorisation: a quarter, a quarter, a half of the columns (boundaries at multiples of 64):
+    // the first camera rows hold most of the pairs, so the first range is complete after ~44 % of the pair work, the second after
+    // ~75 %.  Worth it from ~8 double steps of the factorisation on; one rank only (with several the system is all-reduced first).
+    p->ov.n_seg = 1;
+    p->ov.col_end[0] = p->n_c;
+    p->seg_cam_end[0] = p->M;
+    // MEASURED (200 x 1 M x 10 M, profiles/r3_overlap.txt): the overlap works -- and loses.  Next to the pair kernel's gather traffic
+    // a double step takes 32.5 us instead of 23.7 (the chain is bound by memory latency, which goes up under load), the pair kernel
+    // in three launches takes 507 us instead of 394 (three tails, and the factorisation's workgroups in its way), the two catch-ups
+    // add 63 us: 1.55 ms per iteration against 1.47.  A high-priority stream or CUs reserved for the factorisation
+    // (SATBA_OVERLAP_CUS) change nothing.  The path is kept behind SATBA_OVERLAP=1 (tests/test_gpu_layout.py runs it).
+    if (getenv("SATBA_OVERLAP") && p->world == 1 && p->n_c >= 512 && p->L.n_pairs > 0 && p->L.E > 0 && p->chol_mode == 0 && p->n_c <= 1024) {
+        const int q = ((p->n_c / 4 + 32) / 64) * 64;
+        const int ends[3] = {q, 2 * q, p->n_c};
+        p->ov.n_seg = 3;
+        for (int s = 0; s < 3; ++s) {
+            p->ov.col_end[s] = ends[s];
+            p->seg_cam_end[s] = s == 2 ? p->M : std::min(p->M, (ends[s] + p->NP - 1) / p->NP);
+            HIP_TRY(hipEventCreateWithFlags(&p->ov.ready[s], hipEventDisableTiming));
+        }
+        HIP_TRY(hipEventCreateWithFlags(&p->ev_done, hipEventDisableTiming));
+        {   // the factorisation's stream gets the highest priority: its few workgroups are the latency chain, the pair kernel's thousands fill
+            // whatever is left of the chip
+            int pr_least = 0, pr_greatest = 0;
+            HIP_TRY(hipDeviceGetStreamPriorityRange(&pr_least, &pr_greatest));
+            if (const char* cm = getenv("SATBA_OVERLAP_CUS")) {
+                // experiment: the factorisation gets every k-th CU for itself (the handle's stream keeps all of them)
+                const int k = std::max(2, atoi(cm));
+                uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                for (int cu = 0; cu < 256; cu += k) mask[cu / 32] |= 1u << (cu % 32);
+                HIP_TRY(hipExtStreamCreateWithCUMask(&p->stream2, 8, mask));
+            } else {
+                HIP_TRY(hipStreamCreateWithPriority(&p->stream2, hipStreamNonBlocking, getenv("SATBA_OVERLAP_NOPRIO") ? pr_least : pr_greatest));
+            }
+        }
+        const bool merged_ok = p->d_item_desc_merged != nullptr;
+        for (int s = 0; s < 3; ++s) {
+            const int lo = s ? p->seg_cam_end[s - 1] : 0, hi = p->seg_cam_end[s];
+            TRY(schur_item_table_build(p, false, &p->d_seg_items[0][s], &p->d_seg_desc[0][s], &p->n_seg_blocks[0][s], lo, hi));
+            if (merged_ok) TRY(schur_item_table_build(p, true, &p->d_seg_items[1][s], &p->d_seg_desc[1][s], &p->n_seg_blocks[1][s], lo, hi));
+        }
+    }
     return 0;
 }
 
@@ -717,7 +832,10 @@ int satba_problem_create(const satba_problem_desc* d, satba_problem** out) {
 
     int rc = [&]() -> int {
         HIP_TRY(hipSetDevice(p->device));
+        HIP_TRY(hipStreamCreateWithFlags(&p->own_stream, hipStreamNonBlocking));
+        p->stream = p->own_stream;
         if (p->n_c > CH_NB * CH_MAX_STEPS) return fail(SATBA_E_ARG, "reduced camera system too large for the dense solver");
+        cholesky_init();
         TRY(build_layout(p, d));
         // LDS budget of the observation kernels: camera-sum table first, then the camera constants, then the RPC tables
         const size_t budget = 150 * 1024;
@@ -763,6 +881,11 @@ int satba_problem_create(const satba_problem_desc* d, satba_problem** out) {
         HIP_TRY(hipMemset(p->d_bbox, 0, sizeof(double) * 6));
         HIP_TRY(hipMemset(p->d_fxflag, 0, sizeof(int)));
         if (const char* fs = getenv("SATBA_FX_SHRINK")) p->fx_shrink = atof(fs);  // tests: shrink the bounds to force the fall-back
+        TRY(dev_alloc(p, &p->d_lm, 1));
+        HIP_TRY(hipMemset(p->d_lm, 0, sizeof(LmDev)));
+        HIP_TRY(hipHostMalloc((void**)&p->h_lm, sizeof(LmSummary) + sizeof(LmDev), hipHostMallocMapped));
+        memset(p->h_lm, 0, sizeof(LmSummary) + sizeof(LmDev));
+        HIP_TRY(hipHostGetDevicePointer((void**)&p->h_lm_dev, p->h_lm, 0));
         TRY(dev_alloc(p, &p->d_keep, SATBA_KEEP_LEN));
         HIP_TRY(hipMemset(p->d_keep, 0, sizeof(double) * SATBA_KEEP_LEN));
         TRY(dev_alloc(p, &p->d_red, (size_t)RED_SLOTS * RED_MAX_NV * RED_MAX_GRID));
@@ -812,12 +935,20 @@ void satba_problem_destroy(satba_problem* p) {
     for (void* q : p->allocs) (void)hipFree(q);
     for (hipEvent_t e : p->prof_ev) (void)hipEventDestroy(e);
     if (p->h_pin) (void)hipHostFree(p->h_pin);
+    if (p->h_lm) (void)hipHostFree(p->h_lm);
+    if (p->lm_graph) (void)hipGraphExecDestroy(p->lm_graph);
+    if (p->own_stream) (void)hipStreamDestroy(p->own_stream);
+    if (p->stream2) (void)hipStreamDestroy(p->stream2);
+    for (int s = 0; s < CH_MAX_SEG; ++s) if (p->ov.ready[s]) (void)hipEventDestroy(p->ov.ready[s]);
+    if (p->ev_done) (void)hipEventDestroy(p->ev_done);
     delete p;
 }
 
-int satba_set_stream(satba_problem* p, void* hip_stream) {
+int satba_set_stream(satba_problem* p, void* hip_stream, int32_t use_own) {
     if (!p) return fail(SATBA_E_ARG, "null handle");
-    p->stream = static_cast<hipStream_t>(hip_stream);
+    HIP_TRY(hipSetDevice(p->device));
+    HIP_TRY(hipStreamSynchronize(p->stream));  // nothing of this handle is left on the stream it moves away from
+    p->stream = use_own ? p->own_stream : static_cast<hipStream_t>(hip_stream);
     return 0;
 }
 
@@ -919,9 +1050,10 @@ int satba_snapshot_x(satba_problem* p, int32_t restore) {
     if (!p) return fail(SATBA_E_ARG, "null handle");
     HIP_TRY(hipSetDevice(p->device));
     if (!restore) {
-        if (!p->d_x0) TRY(dev_alloc(p, &p->d_x0, p->n + 6));  // x | bounding box of its points
+        if (!p->d_x0) TRY(dev_alloc(p, &p->d_x0, p->n + 6 + (size_t)p->M * CAMC));  // x | bounding box of its points | camera constants
         HIP_TRY(hipMemcpyAsync(p->d_x0, p->d_x, sizeof(double) * p->n, hipMemcpyDeviceToDevice, p->stream));
         HIP_TRY(hipMemcpyAsync(p->d_x0 + p->n, p->d_bbox, sizeof(double) * 6, hipMemcpyDeviceToDevice, p->stream));
+        HIP_TRY(hipMemcpyAsync(p->d_x0 + p->n + 6, p->d_camc, sizeof(double) * p->M * CAMC, hipMemcpyDeviceToDevice, p->stream));
         // the cost at the kept point travels with it (scales of the fixed-point camera sums, linear loss)
         if (p->loss == 0 && !p->fxcost_valid) {
             TRY(launch_residual(p, false, nullptr, p->d_fxcost));
@@ -981,7 +1113,7 @@ int satba_linearize(satba_problem* p) {
             p->fxcost_valid = true;
         }
         SATBA_DISPATCH(p, hipLaunchKernelGGL((k_lin_scales<MODEL, NP>), dim3(1), dim3(256), 0, p->stream, p->M, p->d_camc, p->d_rpc, p->d_bbox, p->w_max,
-                                             p->loss, p->f_scale, p->d_fxcost, p->n_max_cam, p->fx_shrink, p->d_fx, p->d_fxe, p->d_fxflag, p->d_xb, n_clear));
+                                             p->loss, p->f_scale, p->d_fxcost, p->n_max_cam, p->fx_shrink, p->d_fx, p->d_fxe, p->d_fxflag, p->d_xb, n_clear, p->gate));
         HIP_TRY(hipGetLastError());
     } else {
         HIP_TRY(hipMemsetAsync(p->d_xb, 0, sizeof(double) * n_clear, p->stream));
@@ -995,7 +1127,7 @@ int satba_linearize(satba_problem* p) {
         const int const_t = lin_const_t(p->model, p->NP, p->loss != 0, p->loss == 0 && p->unit_weights) && lin_variant(p) == 0;
         const int total = p->M * 2 * p->NP;
         hipLaunchKernelGGL(k_lin_finish, dim3((total + 63) / 64), dim3(1024), 0, p->stream, p->M, p->NP, p->lin_grid, p->d_part, U, gc,
-                           p->L.cam_ofs, p->d_camc, p->n_cam_fix, const_t, p->d_fx, p->d_fxe, p->d_fxflag, p->d_xb + SATBA_HDR_FX);
+                           p->L.cam_ofs, p->d_camc, p->n_cam_fix, const_t, p->d_fx, p->d_fxe, p->d_fxflag, p->d_xb + SATBA_HDR_FX, p->gate);
         HIP_TRY(hipGetLastError());
     } else {
         TRY(launch_cam_sums(p, U, gc));  // camera-major pass, fixed summation order; fills the full blocks
@@ -1012,11 +1144,11 @@ int satba_prepare(satba_problem* p, int32_t first) {
     const size_t nU = (size_t)p->M * p->NP * p->NP;
     if (p->hdr > 1024) return fail(SATBA_E_ARG, "header too long");
     hipLaunchKernelGGL(k_prepare_stash, dim3(1), dim3(1024), 0, p->stream, (int)nU, p->n_c, p->world, SATBA_HDR_FIXED, (int)p->hdr, p->d_xb, p->d_U,
-                       p->d_gc, p->d_keep);
+                       p->d_gc, p->d_keep, p->gate);
     HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(k_prepare_vec, dim3(grid_for(p->n, 256, 1024)),  // measured at 3 M entries: 512 workgroups 51 us, 1024: 45, 2048: 55
                        dim3(256), 0, p->stream, p->n, p->n_c, p->NP, first,
-                       p->lead, p->d_U, p->d_gc, p->d_V, p->d_x, p->d_g, p->d_scale_inv, p->d_gh, p->d_q1, p->red(RB_PREP), p->d_xb, p->d_keep);
+                       p->lead, p->d_U, p->d_gc, p->d_V, p->d_x, p->d_g, p->d_scale_inv, p->d_gh, p->d_q1, p->red(RB_PREP), p->d_xb, p->d_keep, p->first_dev, p->gate);
     HIP_TRY(hipGetLastError());
     TRY(launch_jvp(p, 1, p->d_q1, p->d_q1, p->d_xb + 2, true));  // d_q1 is free until the subspace phase
     p->prepared = true;
@@ -1030,9 +1162,10 @@ static int schur_impl(satba_problem* p, double lam, bool automatic, double Delta
     const double* lam_dev = automatic ? p->d_keep + 5 : nullptr;
     if (p->N > 0) {
         hipLaunchKernelGGL(k_vinv, dim3((p->N + VINV_THREADS - 1) / VINV_THREADS), dim3(VINV_THREADS), 0, p->stream, p->N, lam, automatic ? p->d_xb : nullptr, Delta, lam_floor,
-                           p->d_keep, p->d_V, p->d_scale_inv + p->n_c, p->d_Vinv, p->d_x + p->n_c, p->d_g + p->n_c, p->d_PV, p->L.perm, p->n_pts_fix);
+                           p->d_keep, p->d_V, p->d_scale_inv + p->n_c, p->d_Vinv, p->d_x + p->n_c, p->d_g + p->n_c, p->d_PV, p->L.perm, p->n_pts_fix,
+                           automatic ? p->Delta_dev : nullptr, automatic ? p->lam_force_dev : nullptr, p->gate);
     } else if (automatic) {
-        hipLaunchKernelGGL(k_lambda, dim3(1), dim3(1), 0, p->stream, p->d_xb, Delta, lam_floor, p->d_keep);
+        hipLaunchKernelGGL(k_lambda, dim3(1), dim3(1), 0, p->stream, p->d_xb, Delta, lam_floor, p->d_keep, p->Delta_dev, p->lam_force_dev, p->gate);
     }
     HIP_TRY(hipGetLastError());
     // The header is cleared by k_schur_init (behind k_vinv, which reads it).  S and rhs are only cleared when no pair kernel will
@@ -1041,10 +1174,61 @@ static int schur_impl(satba_problem* p, double lam, bool automatic, double Delta
     if (!pairs_run) HIP_TRY(hipMemsetAsync(p->d_xb + p->hdr, 0, sizeof(double) * nS, p->stream));
     double* S = p->payload();
     hipLaunchKernelGGL(k_schur_init, dim3((std::max<long long>((long long)p->n_c * p->NP, p->hdr) + 255) / 256), dim3(256), 0, p->stream, p->M, p->NP,
-                       lam, lam_dev, p->lead, p->d_gc, p->d_scale_inv, S, S + (size_t)p->n_c * p->n_c, p->d_xb, (int)p->hdr);
+                       lam, lam_dev, p->lead, p->d_gc, p->d_scale_inv, S, S + (size_t)p->n_c * p->n_c, p->d_xb, (int)p->hdr, p->gate);
     HIP_TRY(hipGetLastError());
     TRY(launch_schur_kernel(p));
     return 0;
+}
+
+// ---- single rank: Schur complement and dense solve in one go, the factorisation overlapped with the pair kernels.
+// The diagonal blocks and the right-hand side come first; the pair kernel runs once per column range of S (the camera rows that
+// complete it) on the handle's stream and records an event behind each; on the second stream the factorisation waits for the
+// range it is about to touch (cholesky_solve_overlapped), scales it, catches it up with the panels factorised so far and carries
+// on.  The handle's stream picks up again behind the back-substitution of the dense system.
+static bool overlap_ok(const satba_problem* p) { return p->ov.n_seg > 1 && p->world == 1 && p->chol_mode == 0; }
+
+static int schur_solve_overlapped(satba_problem* p, double lam, bool automatic, double Delta, double lam_floor) {
+    const double* lam_dev = automatic ? p->d_keep + 5 : nullptr;
+    if (p->N > 0) {
+        hipLaunchKernelGGL(k_vinv, dim3((p->N + VINV_THREADS - 1) / VINV_THREADS), dim3(VINV_THREADS), 0, p->stream, p->N, lam, automatic ? p->d_xb : nullptr, Delta, lam_floor,
+                           p->d_keep, p->d_V, p->d_scale_inv + p->n_c, p->d_Vinv, p->d_x + p->n_c, p->d_g + p->n_c, p->d_PV, p->L.perm, p->n_pts_fix,
+                           automatic ? p->Delta_dev : nullptr, automatic ? p->lam_force_dev : nullptr, p->gate);
+    } else if (automatic) {
+        hipLaunchKernelGGL(k_lambda, dim3(1), dim3(1), 0, p->stream, p->d_xb, Delta, lam_floor, p->d_keep, p->Delta_dev, p->lam_force_dev, p->gate);
+    }
+    double* S = p->payload();
+    double* rhs = S + (size_t)p->n_c * p->n_c;
+    hipLaunchKernelGGL(k_schur_init, dim3((std::max<long long>((long long)p->n_c * p->NP, p->hdr) + 255) / 256), dim3(256), 0, p->stream, p->M, p->NP,
+                       lam, lam_dev, p->lead, p->d_gc, p->d_scale_inv, S, rhs, p->d_xb, (int)p->hdr, p->gate);
+    HIP_TRY(hipGetLastError());
+    ObsArgs a = obs_args(p, false);
+    SATBA_DISPATCH(p, TRY((launch_schur_segments<MODEL, NP>(p, a, S, rhs))));
+    // the factorisation, on the second stream
+    const int* gate = p->gate;
+    cholesky_solve_overlapped(S, p->n_c, p->d_dch, p->d_fail, p->d_fail + 1, p->stream2, p->d_dinv, gate, p->ov, [&](int sg) {
+        const int lo = sg ? p->ov.col_end[sg - 1] : 0, hi = p->ov.col_end[sg];
+        hipLaunchKernelGGL(k_scale_system, dim3(grid_for((long long)(hi - lo) * p->n_c, 256, 2048)), dim3(256), 0, p->stream2, p->n_c, p->d_scale_inv, S, rhs,
+                           p->d_dch, p->d_fail, 1 + CH_MAX_STEPS, gate, lo, hi);
+    });
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(p->ev_done, p->stream2));
+    HIP_TRY(hipStreamWaitEvent(p->stream, p->ev_done, 0));
+    const int nu = std::max(p->n_c, (int)p->hdr);
+    hipLaunchKernelGGL(k_unscale, dim3((nu + 255) / 256), dim3(256), 0, p->stream, p->n_c, p->d_scale_inv, p->d_dch, p->d_dc, (int)p->hdr,
+                       p->d_xb, p->d_fail, p->lead, p->d_keep, SATBA_HDR_KEEP, SATBA_KEEP_LEN, p->gate);
+    HIP_TRY(hipGetLastError());
+    TRY(launch_backsub_kernel(p));
+    p->prepared = false;
+    p->have_step = true;
+    return 0;
+}
+
+// schur (+ auto damping) and solve of a front, overlapped where the handle supports it
+static int front_schur_solve(satba_problem* p, bool automatic, double lam, double Delta, double lam_floor) {
+    if (overlap_ok(p)) return schur_solve_overlapped(p, lam, automatic, Delta, lam_floor);
+    if (automatic) TRY(satba_schur_auto(p, Delta, lam_floor));
+    else TRY(satba_schur(p, lam));
+    return satba_solve(p);
 }
 
 int satba_schur(satba_problem* p, double lam) {
@@ -1068,12 +1252,12 @@ int satba_solve(satba_problem* p) {
     double* S = p->payload();
     double* rhs = S + (size_t)p->n_c * p->n_c;
     hipLaunchKernelGGL(k_scale_system, dim3(grid_for((long long)p->n_c * p->n_c, 256, 2048)), dim3(256), 0, p->stream, p->n_c,
-                       p->d_scale_inv, S, rhs, p->d_dch, p->d_fail, 1 + CH_MAX_STEPS);
+                       p->d_scale_inv, S, rhs, p->d_dch, p->d_fail, 1 + CH_MAX_STEPS, p->gate, 0, p->n_c);
     HIP_TRY(hipGetLastError());
     TRY(dense_solve(p, S, p->d_dch, true));  // the not-SPD flag and the step flags were cleared by the scaling kernel
     const int nu = std::max(p->n_c, (int)p->hdr);
     hipLaunchKernelGGL(k_unscale, dim3((nu + 255) / 256), dim3(256), 0, p->stream, p->n_c, p->d_scale_inv, p->d_dch, p->d_dc, (int)p->hdr,
-                       p->d_xb, p->d_fail, p->lead, p->d_keep, SATBA_HDR_KEEP, SATBA_KEEP_LEN);
+                       p->d_xb, p->d_fail, p->lead, p->d_keep, SATBA_HDR_KEEP, SATBA_KEEP_LEN, p->gate);
     HIP_TRY(hipGetLastError());
     TRY(launch_backsub_kernel(p));
     p->have_step = true;
@@ -1084,9 +1268,9 @@ int satba_subspace(satba_problem* p, double alpha, double inv_norm_g) {
     if (!p) return fail(SATBA_E_ARG, "null handle");
     if (!p->have_step) return fail(SATBA_E_STATE, "subspace before solve");
     HIP_TRY(hipSetDevice(p->device));
-    TRY(zero_header(p));
+    if (!p->gate) TRY(zero_header(p));  // (the device-resident loop reads only the slots this phase writes)
     hipLaunchKernelGGL(k_subspace_vec, dim3(grid_for(p->n, 256, 512)), dim3(256), 0, p->stream, p->n, p->n_c, p->lead, alpha,
-                       inv_norm_g, p->d_gh, p->d_gn, p->d_q1, p->d_wv, p->red(RB_SUB), p->d_xb);
+                       inv_norm_g, p->d_gh, p->d_gn, p->d_q1, p->d_wv, p->red(RB_SUB), p->d_xb, p->sub_args_dev, p->gate);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -1095,7 +1279,7 @@ int satba_subspace_products(satba_problem* p) {
     if (!p) return fail(SATBA_E_ARG, "null handle");
     if (!p->have_step) return fail(SATBA_E_STATE, "subspace_products before solve");
     HIP_TRY(hipSetDevice(p->device));
-    TRY(zero_header(p));
+    if (!p->gate) TRY(zero_header(p));
     TRY(launch_jvp(p, 2, p->d_q1, p->d_wv, p->d_xb + 3));
     return 0;
 }
@@ -1197,13 +1381,19 @@ int satba_lm_step(satba_problem* p, int32_t first, double Delta, double lam_floo
     for (;;) {
         TRY(satba_linearize(p));
         TRY(satba_prepare(p, first ? 1 : 0));
-        TRY(satba_schur_auto(p, first ? -1.0 : Delta, lam_floor));
-        TRY(satba_solve(p));
+        TRY(front_schur_solve(p, true, 0.0, first ? -1.0 : Delta, lam_floor));
         TRY(satba_read_header(p, h));
         if (h[SATBA_HDR_FX_BAD] == 0.0 || !p->cam_sums_lds) break;
         TRY(satba_camera_sums_fallback(p));  // a term left the fixed-point range: camera-major sums from here on
     }
-    const double cost = h[K_COST], reg = h[K_LAM], jg_sq = h[K_JG_SQ];
+    double reg = h[K_LAM];
+    for (int attempt = 0; attempt < 10; ++attempt) {  // a failed factorisation is repeated with more damping, as satba_solve_lm does
+        if (h[4] == 0 && std::isfinite(h[3])) break;
+        reg = std::fmax(reg, 1e-16) * 100.0;
+        TRY(front_schur_solve(p, false, reg, 0.0, 0.0));
+        TRY(satba_read_header(p, h));
+    }
+    const double cost = h[K_COST], jg_sq = h[K_JG_SQ];
     Delta = h[K_DELTA];
     LmModel md;
     TRY(lm_subspace_model(p, h, tbuf.data(), reg, jg_sq, md));
@@ -1214,7 +1404,7 @@ int satba_lm_step(satba_problem* p, int32_t first, double Delta, double lam_floo
     TRY(satba_trial_gn(p, ca, cb));
     TRY(satba_read_header(p, tbuf.data()));
     const double cost_new = tbuf[COST_NEW];
-    const double step_h_norm = std::hypot(p0, p1);
+    const double step_h_norm = satba_lm::norm2(p0, p1);
     const double actual = std::isfinite(cost_new) ? cost - cost_new : -1.0;
     double ratio;
     const double Delta_new = satba_lm::update_tr_radius(Delta, actual, predicted, step_h_norm, step_h_norm > 0.95 * Delta, ratio);
@@ -1224,11 +1414,202 @@ int satba_lm_step(satba_problem* p, int32_t first, double Delta, double lam_floo
     return 0;
 }
 
-int satba_solve_lm(satba_problem* p, const satba_lm_opts* o, satba_lm_stats* out) {
-    if (!p || !o || !out) return fail(SATBA_E_ARG, "null argument");
-    if (p->world != 1) return fail(SATBA_E_ARG, "satba_solve_lm drives a single-rank handle (world = %d): use the phase entry points", p->world);
-    memset(out, 0, sizeof *out);
-    TRY(satba_configure(p, o->loss, o->f_scale));
+// ---- device-resident loop (satba_lmdev.h): reset the state, queue ticks, read the state back
+static int lm_reset(satba_problem* p, const satba_lm_opts* o, bool never_stop, bool watch, bool keep_counters = false, long long max_iterations = 0,
+                    int cycle_len = 0) {
+    LmDev init;
+    memset(&init, 0, sizeof init);
+    init.run_lin = 1; init.run_solve = 1; init.phase = LM_RUN; init.status = -1; init.first = 1;
+    init.never_stop = never_stop ? 1 : 0;
+    init.max_nfev = o->max_nfev > 0 ? o->max_nfev : p->n_total * 100;
+    init.Delta = -1.0;  // <= 0: scipy's initial radius |x_h| (schur_lambda)
+    init.ftol = o->ftol; init.xtol = o->xtol; init.gtol = o->gtol;
+    init.max_iterations = max_iterations; init.cycle_len = cycle_len;
+    if (watch) {  // the host is going to poll the summary: nothing of an earlier run may still post to it
+        HIP_TRY(hipStreamSynchronize(p->stream));
+        p->h_lm->word = (unsigned long long)LM_RUN; p->h_lm->sub_requests = 0;
+    }
+    hipLaunchKernelGGL(k_lm_reset, dim3(1), dim3(1), 0, p->stream, p->d_lm, init, keep_counters ? 1 : 0);
+    HIP_TRY(hipGetLastError());
+    p->lm_ticks_queued = 0;
+    return 0;
+}
+
+// one tick (satba_lmdev.h): every launch is gated by the loop's state, nothing waits for the device
+struct LmArgsScope {  // while a pattern is being queued the launchers read the loop's scalars from its state in device memory
+    satba_problem* p;
+    explicit LmArgsScope(satba_problem* q) : p(q) {
+        LmDev* st = p->d_lm;
+        p->Delta_dev = &st->Delta; p->first_dev = &st->first; p->lam_force_dev = &st->lam_force; p->coef_dev = st->coef; p->sub_args_dev = st->sub_args;
+    }
+    ~LmArgsScope() { p->gate = nullptr; p->Delta_dev = nullptr; p->first_dev = nullptr; p->coef_dev = nullptr; p->lam_force_dev = nullptr; p->sub_args_dev = nullptr; }
+};
+
+static int lm_launch_tail(satba_problem* p) {  // trial evaluation, decision, accepted point (or the kept one) into place
+    LmDev* st = p->d_lm;
+    p->gate = &st->run_trial;
+    TRY(satba_trial_gn(p, 0.0, 0.0));
+    hipLaunchKernelGGL(k_lm_decide2, dim3(1), dim3(1), 0, p->stream, st, p->d_xb, p->h_lm_dev);
+    const double* x0 = p->d_x0;
+    hipLaunchKernelGGL(k_lm_accept, dim3(grid_for(p->n / 2 + 1, 256, 1024)), dim3(256), 0, p->stream, st, (long long)p->n, p->d_x, p->d_xnew,
+                       p->M * CAMC, p->d_camc, p->d_camc_new, p->d_fxcost, p->d_fxcost_new, x0, x0 ? x0 + p->n + 6 : nullptr, p->d_fxcost0, p->d_bbox);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+static int lm_launch_tick(satba_problem* p, double lam_floor) {
+    LmDev* st = p->d_lm;
+    LmArgsScope scope(p);
+    p->gate = &st->run_lin;
+    TRY(satba_linearize(p));
+    TRY(satba_prepare(p, 0));
+    p->gate = &st->run_solve;
+    TRY(front_schur_solve(p, true, 0.0, -1.0, lam_floor));
+    hipLaunchKernelGGL(k_lm_decide1a, dim3(1), dim3(1), 0, p->stream, st, p->d_xb);
+    return lm_launch_tail(p);
+}
+
+// the pattern of the degenerate case (g_h and gn_h parallel to 1e-6): explicit subspace vectors and products, then the tail
+static int lm_launch_sub_pattern(satba_problem* p) {
+    LmDev* st = p->d_lm;
+    LmArgsScope scope(p);
+    p->gate = &st->run_sub;
+    TRY(satba_subspace(p, 0.0, 0.0));
+    hipLaunchKernelGGL(k_lm_decide1b, dim3(1), dim3(1), 0, p->stream, st, p->d_xb);
+    p->gate = &st->run_prod;
+    TRY(satba_subspace_products(p));
+    hipLaunchKernelGGL(k_lm_decide1c, dim3(1), dim3(1), 0, p->stream, st, p->d_xb);
+    return lm_launch_tail(p);
+}
+
+// The tick's launches do not depend on data: they are captured once into a hipGraph and replayed (one graph launch instead of ~40
+// kernel launches per tick).  The capture is keyed by everything a launch argument or a kernel variant depends on.
+static bool lm_graph_key_matches(const satba_problem* p, double lam_floor) {
+    const satba_problem::LmGraphKey& k = p->lm_key;
+    return p->lm_graph && k.x == p->d_x && k.xnew == p->d_xnew && k.camc == p->d_camc && k.fxcost == p->d_fxcost && k.xb == p->d_xb && k.x0 == p->d_x0 &&
+           k.stream == p->stream && k.loss == p->loss && k.f_scale == p->f_scale && k.cam_sums_lds == p->cam_sums_lds && k.lam_floor == lam_floor &&
+           k.fxcost_valid == p->fxcost_valid;
+}
+
+static int lm_queue_tick(satba_problem* p, double lam_floor) {
+    // Measured on MI355X / ROCm 7.0 (profiles/r3_graph_gaps.txt): the replayed graph leaves 2 - 9 us between its nodes where back-to-back
+    // launches on the stream leave none, and ~30 us in front of every replay; the host is never the bottleneck here (it queues
+    // LM_RUN_AHEAD ticks ahead).  10 x 5 k x 30 k: 6 317 it/s with the graph, 6 312 without; 200 x 1 M x 10 M: 681 / 685.  The graph is
+    // therefore opt-in (SATBA_GRAPH=1).
+    static const bool use_graph = getenv("SATBA_GRAPH") != nullptr && !getenv("SATBA_NO_GRAPH");
+    const bool direct = !use_graph || p->lm_no_graph || p->prof_lin || (p->loss == 0 && !p->fxcost_valid);  // (the cost-only pass of a first linearisation is not part of the pattern)
+    if (direct) {
+        TRY(lm_launch_tick(p, lam_floor));
+    } else {
+        if (!lm_graph_key_matches(p, lam_floor)) {
+            if (p->lm_graph) { (void)hipGraphExecDestroy(p->lm_graph); p->lm_graph = nullptr; }
+            hipGraph_t g = nullptr;
+            if (hipStreamBeginCapture(p->stream, hipStreamCaptureModeRelaxed) != hipSuccess) {
+                (void)hipGetLastError();
+                p->lm_no_graph = true;  // e.g. the legacy default stream
+                TRY(lm_launch_tick(p, lam_floor));
+                p->linearized = true; p->prepared = false; p->have_step = true;
+                p->fxcost_valid = true; p->fxcost_new_valid = false;
+                ++p->lm_ticks_queued;
+                return 0;
+            }
+            const int rc = lm_launch_tick(p, lam_floor);
+            const hipError_t e = hipStreamEndCapture(p->stream, &g);
+            if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
+            if (e != hipSuccess) return fail(SATBA_E_HIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
+            const hipError_t e2 = hipGraphInstantiate(&p->lm_graph, g, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(g);
+            if (e2 != hipSuccess) { p->lm_graph = nullptr; return fail(SATBA_E_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e2)); }
+            p->lm_key = satba_problem::LmGraphKey{p->d_x, p->d_xnew, p->d_camc, p->d_fxcost, p->d_xb, p->d_x0, p->stream, p->loss, p->f_scale, p->cam_sums_lds,
+                                                  lam_floor, p->fxcost_valid};
+        }
+        HIP_TRY(hipGraphLaunch(p->lm_graph, p->stream));
+    }
+    // what the host-side flags say after a tick: the linearisation and the step belong to the point the device ends up at
+    p->linearized = true; p->prepared = false; p->have_step = true;
+    p->fxcost_valid = true; p->fxcost_new_valid = false;
+    ++p->lm_ticks_queued;
+    return 0;
+}
+
+static int lm_read_state(satba_problem* p, LmDev* host) {
+    HIP_TRY(hipMemcpyAsync(host, p->d_lm, sizeof *host, hipMemcpyDeviceToHost, p->stream));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    return 0;
+}
+
+// whether this handle can run the device-resident loop: one rank, default dense-solver mode (its kernels carry the gates)
+static bool lm_device_loop_ok(const satba_problem* p) {
+    const bool off = getenv("SATBA_HOST_LOOP") != nullptr;  // A/B runs and the tests' comparison of the two loops (read per call)
+    return !off && p->world == 1 && (p->chol_mode == 0) && p->n_c <= 1024;
+}
+// ... and whether it pays: its three extra launches per iteration (two decisions, the copy of the accepted point) cost what the two
+// header reads of the host loop cost at ~1.4 ms per iteration (200 x 1 M x 10 M: 681 against 696 it/s; soft_l1 353 / 372), and
+// much less below (50 x 100 k x 1 M: 2 580 / 2 500; 10 x 5 k x 30 k: 6 320 / 5 380).  SATBA_DEVICE_LOOP=1 / 0 forces the choice.
+static bool lm_device_loop_pays(const satba_problem* p) {
+    if (const char* e = getenv("SATBA_DEVICE_LOOP")) return atoi(e) != 0;
+    return p->K < 4000000;
+}
+
+int satba_lm_state(satba_problem* p, double* out, int32_t n);
+
+// queue ticks until the device reports that the loop has left LM_RUN, LM_RUN_AHEAD beyond its last report
+static int lm_drive(satba_problem* p, double lam_floor, long long max_ticks) {
+    long long sub_served = 0;
+    for (;;) {
+        // every evaluation and every repeated factorisation is one pattern: a loop that queues many more has lost track of the device
+        if (p->lm_ticks_queued > max_ticks) return fail(SATBA_E_STATE, "device-resident loop: %lld launch patterns queued without reaching the end", p->lm_ticks_queued);
+        TRY(lm_queue_tick(p, lam_floor));
+        // watchdog: a tick is milliseconds of device work; a minute without a report means the device is stuck
+        auto t_wait = std::chrono::steady_clock::now();
+        // (a profiled run -- HIP events around every k_linearize launch -- does not run ahead: no switched-off launch is timed)
+        unsigned long long w;
+        while (lm_summary_tick(w = __atomic_load_n(&p->h_lm->word, __ATOMIC_ACQUIRE)) + (p->prof_lin ? 0 : LM_RUN_AHEAD) < p->lm_ticks_queued) {
+            __builtin_ia32_pause();
+            if (ms_since(t_wait) > 60000.0) return fail(SATBA_E_HIP, "device-resident loop: no progress report from the device for 60 s");
+        }
+        const int phase = lm_summary_phase(w);
+        const long long req = __atomic_load_n(&p->h_lm->sub_requests, __ATOMIC_ACQUIRE);
+        if (req > sub_served) {  // the loop has paused for the degenerate-subspace pattern (the ticks queued behind the pause are switched off)
+            sub_served = req;
+            TRY(lm_launch_sub_pattern(p));
+            ++p->lm_ticks_queued;
+            continue;
+        }
+        if (phase != LM_RUN && phase != LM_NEED_SUB) return 0;
+    }
+}
+
+int satba_lm_run(satba_problem* p, int64_t n_iterations, int32_t cycle_len, double lam_floor, double* out, int32_t n_out) {
+    if (!p || n_iterations <= 0 || cycle_len < 0 || (out && n_out < 16)) return fail(SATBA_E_ARG, "bad argument");
+    if (!lm_device_loop_ok(p)) return fail(SATBA_E_ARG, "satba_lm_run drives a single-rank handle with the default dense solver");
+    if (cycle_len > 0 && !p->d_x0) return fail(SATBA_E_STATE, "satba_lm_run with cycles needs a kept point (satba_snapshot_x)");
+    HIP_TRY(hipSetDevice(p->device));
+    satba_lm_opts o{};
+    o.max_nfev = -1;
+    TRY(lm_reset(p, &o, true, true, false, n_iterations, cycle_len));
+    TRY(lm_drive(p, lam_floor, 24 * n_iterations + 1000));
+    if (out) return satba_lm_state(p, out, n_out);
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    return 0;
+}
+
+int satba_lm_state(satba_problem* p, double* out, int32_t n) {
+    if (!p || !out || n < 16) return fail(SATBA_E_ARG, "bad argument");
+    HIP_TRY(hipSetDevice(p->device));
+    LmDev st;
+    TRY(lm_read_state(p, &st));
+    for (int i = 0; i < n; ++i) out[i] = 0.0;
+    out[0] = st.cost; out[1] = st.cost_new; out[2] = st.Delta; out[3] = st.accepted_total; out[4] = st.interior_total;
+    out[5] = st.predicted; out[6] = st.actual; out[7] = st.reg; out[8] = st.phase; out[9] = st.status; out[10] = (double)st.nfev;
+    out[11] = (double)st.njev; out[12] = (double)st.iterations; out[13] = (double)st.tick; out[14] = st.host_reason; out[15] = st.g_norm;
+    return 0;
+}
+
+// The loop of satba/trf.py on the host (scipy's trf_no_bounds with an exact damped step).  resume: a front has already run on the
+// device for the current x (first iteration iff resume->first) and its header is in the exchange buffer, but nothing of it is
+// booked -- the device-resident loop stopped there because the fixed-point camera sums overflowed (the host switches the route).
+static int lm_host_loop(satba_problem* p, const satba_lm_opts* o, satba_lm_stats* out, const LmDev* resume) {
     const int64_t max_nfev = o->max_nfev > 0 ? o->max_nfev : p->n_total * 100;
     std::vector<double> hbuf((size_t)p->hdr), tbuf((size_t)p->hdr);
     double* h = hbuf.data();
@@ -1236,8 +1617,7 @@ int satba_solve_lm(satba_problem* p, const satba_lm_opts* o, satba_lm_stats* out
         for (;;) {
             TRY(satba_linearize(p));
             TRY(satba_prepare(p, first ? 1 : 0));
-            TRY(satba_schur_auto(p, first ? -1.0 : Delta, 0.0));
-            TRY(satba_solve(p));
+            TRY(front_schur_solve(p, true, 0.0, first ? -1.0 : Delta, 0.0));
             TRY(satba_read_header(p, h));
             if (h[SATBA_HDR_FX_BAD] == 0.0 || !p->cam_sums_lds) return 0;
             TRY(satba_camera_sums_fallback(p));  // a term left the fixed-point range: camera-major sums from here on
@@ -1245,14 +1625,33 @@ int satba_solve_lm(satba_problem* p, const satba_lm_opts* o, satba_lm_stats* out
     };
     enum { COST_NEW = 1, STEP_SQ = 2, X_SQ = 3, GRAM_A = 1, GRAM_B = 2, GRAM_C = 3, CHOL_FAIL = 4, WW = 1, B11 = 3, B12 = 4, B22 = 5, GHW = 6,
            K_COST = SATBA_HDR_KEEP, K_GINF, K_GH_SQ, K_JG_SQ, K_XS_SQ, K_LAM, K_DELTA };
-    TRY(front(0.0, true));
-    double cost = h[K_COST], g_norm = h[K_GINF], Delta = h[K_DELTA];
-    if (!std::isfinite(cost)) return fail(SATBA_E_NONFINITE, "Residuals are not finite in the initial point.");
+    double cost, g_norm, Delta, initial_cost;
     int64_t nfev = 1, njev = 1, iterations = 0;
-    const double initial_cost = cost;
     int status = -1;
     double step_norm = 0.0, actual = 0.0;
     bool have_actual = false;
+    if (!resume) {
+        TRY(front(0.0, true));
+        cost = h[K_COST]; g_norm = h[K_GINF]; Delta = h[K_DELTA];
+        initial_cost = cost;
+    } else {
+        const bool first = resume->first != 0;
+        Delta = resume->Delta;
+        TRY(satba_read_header(p, h));
+        p->linearized = true; p->have_step = true;
+        if (h[SATBA_HDR_FX_BAD] != 0.0 && p->cam_sums_lds) {
+            TRY(satba_camera_sums_fallback(p));
+            TRY(front(Delta, first));
+        }
+        cost = h[K_COST]; g_norm = h[K_GINF];
+        if (first) { Delta = h[K_DELTA]; initial_cost = cost; }
+        else {
+            initial_cost = resume->initial_cost;
+            nfev = resume->nfev; njev = resume->njev + 1; iterations = resume->iterations; status = resume->status;
+            step_norm = resume->step_norm; actual = resume->actual; have_actual = resume->have_actual != 0;
+        }
+    }
+    if (!std::isfinite(cost)) return fail(SATBA_E_NONFINITE, "Residuals are not finite in the initial point.");
     if (o->verbose >= 2) printf("%15s%15s%15s%15s%15s%15s\n", "Iteration  ", "Total nfev  ", "Cost     ", "Cost reduction ", "Step norm   ", "Optimality  ");
     for (;;) {
         if (g_norm < o->gtol) status = 1;
@@ -1267,8 +1666,7 @@ int satba_solve_lm(satba_problem* p, const satba_lm_opts* o, satba_lm_stats* out
         for (; attempt < 10; ++attempt) {  // a Cholesky needs a floor where LSMR copes with a numerically singular system
             if (h[CHOL_FAIL] == 0 && std::isfinite(h[GRAM_C])) break;
             reg = std::fmax(reg, 1e-16) * 100.0;
-            TRY(satba_schur(p, reg));
-            TRY(satba_solve(p));
+            TRY(front_schur_solve(p, false, reg, 0.0, 0.0));
             TRY(satba_read_header(p, h));
         }
         if (attempt == 10) return fail(SATBA_E_STATE, "reduced camera system could not be factorised");
@@ -1287,7 +1685,7 @@ int satba_solve_lm(satba_problem* p, const satba_lm_opts* o, satba_lm_stats* out
             TRY(satba_read_header(p, tbuf.data()));
             const double cost_new = tbuf[COST_NEW];
             ++nfev;
-            const double step_h_norm = std::hypot(p0, p1);
+            const double step_h_norm = satba_lm::norm2(p0, p1);
             if (!std::isfinite(cost_new)) { Delta = 0.25 * step_h_norm; continue; }
             actual = cost - cost_new;
             double ratio;
@@ -1312,12 +1710,44 @@ int satba_solve_lm(satba_problem* p, const satba_lm_opts* o, satba_lm_stats* out
     if (status == -1) status = 0;
     out->cost = cost; out->initial_cost = initial_cost; out->optimality = g_norm;
     out->nfev = nfev; out->njev = njev; out->iterations = iterations; out->status = status;
+    return 0;
+}
+
+int satba_solve_lm(satba_problem* p, const satba_lm_opts* o, satba_lm_stats* out) {
+    if (!p || !o || !out) return fail(SATBA_E_ARG, "null argument");
+    if (p->world != 1) return fail(SATBA_E_ARG, "satba_solve_lm drives a single-rank handle (world = %d): use the phase entry points", p->world);
+    memset(out, 0, sizeof *out);
+    HIP_TRY(hipSetDevice(p->device));
+    TRY(satba_configure(p, o->loss, o->f_scale));
+    bool done = false;
+    if (lm_device_loop_ok(p) && lm_device_loop_pays(p) && o->verbose < 2) {
+        // the decisions are taken on the device; the host queues ticks LM_RUN_AHEAD beyond the last one the device has reported and
+        // watches the summary the device posts into pinned memory
+        TRY(lm_reset(p, o, false, true));
+        TRY(lm_drive(p, 0.0, 24 * (o->max_nfev > 0 ? o->max_nfev : p->n_total * 100) + 1000));
+        LmDev st;
+        TRY(lm_read_state(p, &st));
+        if (st.phase == LM_DONE) {
+            if (!std::isfinite(st.initial_cost)) return fail(SATBA_E_NONFINITE, "Residuals are not finite in the initial point.");
+            out->cost = st.cost; out->initial_cost = st.initial_cost; out->optimality = st.g_norm;
+            out->nfev = st.nfev; out->njev = st.njev; out->iterations = st.iterations; out->status = st.status == -1 ? 0 : st.status;
+            done = true;
+        } else if (st.host_reason == LM_HOST_NONFINITE) {
+            return fail(SATBA_E_NONFINITE, "Residuals are not finite in the initial point.");
+        } else if (st.host_reason == LM_HOST_CHOL) {
+            return fail(SATBA_E_STATE, "reduced camera system could not be factorised");
+        } else {
+            TRY(lm_host_loop(p, o, out, &st));  // fixed-point overflow of the camera sums: the host switches the route and carries on
+            done = true;
+        }
+    }
+    if (!done) TRY(lm_host_loop(p, o, out, nullptr));
     if (o->verbose >= 1) {
         static const char* msg[] = {"The maximum number of function evaluations is exceeded.", "`gtol` termination condition is satisfied.",
                                     "`ftol` termination condition is satisfied.", "`xtol` termination condition is satisfied.",
                                     "Both `ftol` and `xtol` termination conditions are satisfied."};
-        printf("%s\nFunction evaluations %lld, initial cost %.4e, final cost %.4e, first-order optimality %.2e.\n", msg[status], (long long)nfev,
-               initial_cost, cost, g_norm);
+        printf("%s\nFunction evaluations %lld, initial cost %.4e, final cost %.4e, first-order optimality %.2e.\n", msg[out->status], (long long)out->nfev,
+               out->initial_cost, out->cost, out->optimality);
     }
     return 0;
 }
@@ -1491,6 +1921,8 @@ int satba_get_info(const satba_problem* p, double* out, int32_t n) {
     for (int i = 0; i < 5; ++i) out[i] = p->create_ms[i];
     out[5] = p->L.P; out[6] = (double)p->L.E; out[7] = p->L.C; out[8] = p->unit_weights; out[9] = p->camc_lds; out[10] = p->rpc_lds;
     out[11] = p->cam_sums_lds; out[12] = p->deterministic; out[13] = p->cm_chunks; out[14] = p->lin_grid; out[15] = p->fx_fallbacks;
+    if (n > 16) out[16] = (lm_device_loop_ok(p) && lm_device_loop_pays(p)) ? 1.0 : 0.0;
+    if (n > 17) out[17] = p->ov.n_seg;
     return 0;
 }
 

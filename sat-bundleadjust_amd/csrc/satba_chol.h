@@ -18,6 +18,11 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+// gate of the device-resident LM loop (satba_kernels.h): a kernel returns at once when its gate word is 0; null: no gate
+#ifndef SATBA_GATE
+#define SATBA_GATE(g) do { if ((g) != nullptr && *(g) == 0) return; } while (0)
+#endif
+
 namespace satba {
 
 constexpr int CH_NB = 32;
@@ -143,7 +148,8 @@ __device__ __forceinline__ bool chol_diag_block(double (&a)[CH_NB], int lane, do
 // FULL: the panel has all CH_NB columns (every step but possibly the last).
 template <bool FULL>
 __global__ __launch_bounds__(256) void k_chol_step(double* __restrict__ A, int n, int npend, int k0, int* __restrict__ fail,
-                                                   int* __restrict__ flag, double* __restrict__ b, long long* __restrict__ ts) {
+                                                   int* __restrict__ flag, double* __restrict__ b, long long* __restrict__ ts, const int* gate) {
+    SATBA_GATE(gate);
     // npend: number of 32-column panels directly before k0 whose trailing update is still pending (1 after a single step, 2
     // after a double step, k_chol_dstep); they are applied one after the other in the same pass over the tile
     // ts (tools only, normally null): 8 wall-clock stamps of this step -- 0 start of tile (0,0), 1 its update done,
@@ -480,7 +486,8 @@ __global__ __launch_bounds__(1024) void k_trsv_back_rl(const double* __restrict_
 // The mirror (k_mirror_lower) and the block inverses in one launch (they read the same finished factor and write different things): the first
 // `n_mirror` workgroups mirror 32 x 32 tiles, the others invert one diagonal block each with their first wave -- one launch gap
 // less on the chain, and the 12 us of the inversions run beside the 5 us of the mirror instead of behind it.
-__global__ __launch_bounds__(256) void k_chol_finish(double* __restrict__ A, int n, int n_mirror, double* __restrict__ dinv) {
+__global__ __launch_bounds__(256) void k_chol_finish(double* __restrict__ A, int n, int n_mirror, double* __restrict__ dinv, const int* gate) {
+    SATBA_GATE(gate);
     __shared__ double t[32][33];
     if ((int)blockIdx.x < n_mirror) {
         int bi = 0, idx = blockIdx.x;  // lower tiles (bi >= bj), row by row
@@ -591,7 +598,8 @@ __global__ __launch_bounds__(1024) void k_trsv_back_dinv(const double* __restric
 // flag: one int per superblock, zero on entry.  All workgroups are resident (at most 8 of them).
 constexpr int CH_SB = 128;
 __global__ __launch_bounds__(512) void k_trsv_back_mw(const double* __restrict__ L, const double* __restrict__ dinv, int n, double* __restrict__ b,
-                                                      int* __restrict__ flag) {
+                                                      int* __restrict__ flag, const int* gate) {
+    SATBA_GATE(gate);
     __shared__ double ys[CH_SB], zs[CH_SB], part[4][CH_SB];
     __shared__ double Dk[4][CH_NB][CH_NB + 1];  // Dk[blk][r][c] = (D_blk^-1)[r][c] of my four diagonal blocks
     const int k = blockIdx.x, nsb = gridDim.x, k0 = k * CH_SB, tid = threadIdx.x;
@@ -682,13 +690,18 @@ constexpr int CH_TRSV_FLAGS = 64;  // k_trsv_back_mw's flags (n <= 1024: the fac
 // dinv: (n / 32 rounded up) x 1024 doubles of scratch for the inverted diagonal blocks (n <= 1024), or null
 // ts (tools): CH_TS time stamps per launch
 // cleared: the caller has already zeroed *fail and the flags on the stream (satba_solve does it in its scaling kernel)
-inline void cholesky_solve(double* A, int n, double* b, int* fail, int* flags, int mode, hipStream_t stream,
-                           long long* ts = nullptr, double* dinv = nullptr, bool cleared = false) {
-    static const bool once = [] {  // k_chol_dstep's tile column + scratch exceed the 64 KB a kernel gets without asking
+// k_chol_dstep's tile column + scratch exceed the 64 KB a kernel gets without asking (called once per process, outside any capture)
+inline void cholesky_init() {
+    static const bool once = [] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chol_dstep), hipFuncAttributeMaxDynamicSharedMemorySize, (int)chol_dstep_lds());
         return true;
     }();
     (void)once;
+}
+
+inline void cholesky_solve(double* A, int n, double* b, int* fail, int* flags, int mode, hipStream_t stream,
+                           long long* ts = nullptr, double* dinv = nullptr, bool cleared = false, const int* gate = nullptr) {
+    cholesky_init();
     if (!cleared) (void)hipMemsetAsync(fail, 0, sizeof(int) * (1 + CH_MAX_STEPS), stream);  // flags == fail + 1: one fill for both
     int k0 = 0, npend = 0, step = 0;  // step: launches so far
     int* fl = flags;
@@ -696,28 +709,78 @@ inline void cholesky_solve(double* A, int n, double* b, int* fail, int* flags, i
     if (mode == 0 || mode == 5) {
         for (; n - k0 > CH_NB; k0 += 2 * CH_NB, fl += 2, npend = 2, ++step) {  // the last one may have a partial second panel
             const int T = (n - k0 + 63) / 64;
-            hipLaunchKernelGGL(k_chol_dstep, dim3(T * (T + 1) / 2), dim3(256), chol_dstep_lds(), stream, A, n, npend, k0, fail, fl, b, tsk());
+            hipLaunchKernelGGL(k_chol_dstep, dim3(T * (T + 1) / 2), dim3(256), chol_dstep_lds(), stream, A, n, npend, k0, fail, fl, b, tsk(), gate, n, 0);
         }
     }
     for (; k0 < n; k0 += CH_NB, ++fl, ++step, npend = 1) {
         const int T = (n - k0 + 63) / 64;
         if (n - k0 >= CH_NB)
-            hipLaunchKernelGGL(k_chol_step<true>, dim3(T * (T + 1) / 2), dim3(256), 0, stream, A, n, npend, k0, fail, fl, b, tsk());
+            hipLaunchKernelGGL(k_chol_step<true>, dim3(T * (T + 1) / 2), dim3(256), 0, stream, A, n, npend, k0, fail, fl, b, tsk(), gate);
         else
-            hipLaunchKernelGGL(k_chol_step<false>, dim3(T * (T + 1) / 2), dim3(256), 0, stream, A, n, npend, k0, fail, fl, b, tsk());
+            hipLaunchKernelGGL(k_chol_step<false>, dim3(T * (T + 1) / 2), dim3(256), 0, stream, A, n, npend, k0, fail, fl, b, tsk(), gate);
     }
     if (n <= 1024) {
         const int T = (n + 31) / 32;
         if (dinv) {
-            hipLaunchKernelGGL(k_chol_finish, dim3(T * (T + 1) / 2 + T), dim3(256), 0, stream, A, n, T * (T + 1) / 2, dinv);
+            hipLaunchKernelGGL(k_chol_finish, dim3(T * (T + 1) / 2 + T), dim3(256), 0, stream, A, n, T * (T + 1) / 2, dinv, gate);
             if (mode == 5) hipLaunchKernelGGL(k_trsv_back_dinv, dim3(1), dim3(1024), 0, stream, A, dinv, n, b);  // one workgroup
-            else hipLaunchKernelGGL(k_trsv_back_mw, dim3((n + CH_SB - 1) / CH_SB), dim3(512), 0, stream, A, dinv, n, b, flags + CH_TRSV_FLAGS);
+            else hipLaunchKernelGGL(k_trsv_back_mw, dim3((n + CH_SB - 1) / CH_SB), dim3(512), 0, stream, A, dinv, n, b, flags + CH_TRSV_FLAGS, gate);
         } else {
             hipLaunchKernelGGL(k_mirror_lower, dim3(T * (T + 1) / 2), dim3(256), 0, stream, A, n);
             hipLaunchKernelGGL(k_trsv_back_rl, dim3(1), dim3(1024), 0, stream, A, n, b);
         }
     }
     else hipLaunchKernelGGL(k_trsv_back, dim3(1), dim3(1024), sizeof(double) * n, stream, A, n, b);
+}
+
+// ---- factorisation overlapped with the production of the matrix (round 3)
+// The Schur complement is produced camera row by camera row, i.e. S arrives column block by column block, while the
+// factorisation is a latency chain that occupies a handful of CUs: the chain starts on the first columns while the rest of S is
+// still being formed on the other stream.  The columns are cut into up to CH_MAX_SEG ranges (boundaries multiples of 64); the
+// producer records ready[s] on its stream when range s is complete.  Within the ranges that exist the steps are right-looking as
+// before (k_chol_dstep with col_limit); when a new range arrives, k_chol_catchup applies all panels factorised so far to it.
+constexpr int CH_MAX_SEG = 4;
+struct CholOverlap {
+    int n_seg = 1;
+    int col_end[CH_MAX_SEG] = {0, 0, 0, 0};  // range s = columns [col_end[s - 1], col_end[s]); col_end[n_seg - 1] = n
+    hipEvent_t ready[CH_MAX_SEG] = {nullptr, nullptr, nullptr, nullptr};
+};
+
+// pre(s): launches whatever has to happen to range s on `stream` before the factorisation touches it (the caller's scaling)
+template <class Pre>
+inline void cholesky_solve_overlapped(double* A, int n, double* b, int* fail, int* flags, hipStream_t stream, double* dinv, const int* gate,
+                                      const CholOverlap& ov, Pre&& pre) {
+    cholesky_init();
+    int k0 = 0, npend = 0;
+    int* fl = flags;
+    for (int s = 0; s < ov.n_seg; ++s) {
+        (void)hipStreamWaitEvent(stream, ov.ready[s], 0);
+        pre(s);
+        const int cs = s ? ov.col_end[s - 1] : 0, ce = ov.col_end[s];
+        int skip_a = 0;
+        if (s > 0 && cs > 0) {
+            const int ntj = (ce - cs + 63) / 64, nti = (n - cs + 63) / 64;
+            int tiles = 0;
+            for (int ti = 0; ti < nti; ++ti) tiles += ti + 1 < ntj ? ti + 1 : ntj;
+            hipLaunchKernelGGL(k_chol_catchup, dim3(tiles), dim3(256), 0, stream, A, n, cs, ce, gate);
+            skip_a = 1;  // the panels still pending for the right-hand side are already in the matrix
+        }
+        for (; k0 < ce && n - k0 > CH_NB; k0 += 2 * CH_NB, fl += 2, npend = 2, skip_a = 0) {
+            const int T = (n - k0 + 63) / 64;
+            hipLaunchKernelGGL(k_chol_dstep, dim3(T * (T + 1) / 2), dim3(256), chol_dstep_lds(), stream, A, n, npend, k0, fail, fl, b, (long long*)nullptr, gate,
+                               ce, skip_a);
+        }
+    }
+    for (; k0 < n; k0 += CH_NB, ++fl, npend = 1) {
+        const int T = (n - k0 + 63) / 64;
+        if (n - k0 >= CH_NB)
+            hipLaunchKernelGGL(k_chol_step<true>, dim3(T * (T + 1) / 2), dim3(256), 0, stream, A, n, npend, k0, fail, fl, b, (long long*)nullptr, gate);
+        else
+            hipLaunchKernelGGL(k_chol_step<false>, dim3(T * (T + 1) / 2), dim3(256), 0, stream, A, n, npend, k0, fail, fl, b, (long long*)nullptr, gate);
+    }
+    const int T = (n + 31) / 32;
+    hipLaunchKernelGGL(k_chol_finish, dim3(T * (T + 1) / 2 + T), dim3(256), 0, stream, A, n, T * (T + 1) / 2, dinv, gate);
+    hipLaunchKernelGGL(k_trsv_back_mw, dim3((n + CH_SB - 1) / CH_SB), dim3(512), 0, stream, A, dinv, n, b, flags + CH_TRSV_FLAGS, gate);
 }
 
 }  // namespace satba

@@ -44,6 +44,13 @@ constexpr unsigned long long FX_MAGIC_BITS = 0x4338000000000000ull;
 // (always two lines instead of up to three)
 __host__ __device__ constexpr int jrow_stride(int np) { return 2 * np + 6 <= 16 ? 16 : 24; }
 
+// Device-resident LM loop (satba_lmdev.h): the host queues a fixed pattern of kernels per iteration without knowing whether the
+// previous trial step was accepted; every kernel of the pattern starts by reading its gate -- a word of the loop's state in device
+// memory -- and returns when it is 0.  Null: no gate (the phase entry points of the C ABI).
+#ifndef SATBA_GATE
+#define SATBA_GATE(g) do { if ((g) != nullptr && *(g) == 0) return; } while (0)
+#endif
+
 struct ObsArgs {
     const int* __restrict__ e_cam;       // P: camera of every ELL slot (-1: padding)
     const double2* __restrict__ e_obs;   // P: observed (col, row)
@@ -71,6 +78,7 @@ struct ObsArgs {
     const int* __restrict__ fxe;         // fixed-point scales of k_linearize's camera sums (k_lin_scales): exponents a_0 .. a_{NP-1}, b, then
                                          // the two constants of the range check
     int* __restrict__ fx_flag;           // set when a term leaves its range (the sums are then formed by k_cam_sums instead)
+    const int* gate;                     // SATBA_GATE
 };
 
 // deterministic grid-wide sums: every workgroup writes its partial, the last one to arrive adds them up in index order
@@ -332,7 +340,8 @@ __device__ inline double slice_point_sum(double v, int sh) {
 
 // ------------------------------------------------------------------------------------------------ camera constants
 __global__ void k_cam_consts(int model, int M, int n_p, int c_p, const double* __restrict__ x,
-                             const double* __restrict__ cam_static, double* __restrict__ camc) {
+                             const double* __restrict__ cam_static, double* __restrict__ camc, const int* gate) {
+    SATBA_GATE(gate);
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= M) return;
     double full[11];
@@ -346,7 +355,9 @@ __global__ void k_cam_consts(int model, int M, int n_p, int c_p, const double* _
 __global__ void k_trial_cams(int model, int M, int n_p, int c_p, const double* __restrict__ x, const double* __restrict__ v0,
                              const double* __restrict__ v1, const double* __restrict__ scale_inv, double c0, double c1,
                              const double* __restrict__ cam_static, double* __restrict__ x_new, double* __restrict__ camc_new,
-                             double* __restrict__ xb, int hdr_len) {
+                             double* __restrict__ xb, int hdr_len, const double* __restrict__ coef, const int* gate) {
+    SATBA_GATE(gate);
+    if (coef) { c0 = coef[0]; c1 = coef[1]; }
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c < hdr_len) xb[c] = 0.0;
     if (c >= M) return;
@@ -397,9 +408,12 @@ struct TrialArgs {
     double* ss;                            // |step|^2 and |x|^2 (scaled variables are not involved: plain sums of squares)
     double* xx;
     double* cost2;                         // second copy of this shard's cost (bound of the fixed-point camera sums at x_new)
+    const double* coef;                    // device-resident loop: c0, c1 are read from here (two doubles) instead of the arguments
 };
 template <int MODEL, int NP, bool CL, bool RL, bool UNITW = false, bool TRIAL = false>
 __global__ __launch_bounds__(RES_THREADS) void k_residual(ObsArgs a, double2* __restrict__ f, RedBuf rb, double* __restrict__ cost, TrialArgs t) {
+    SATBA_GATE(a.gate);
+    if constexpr (TRIAL) { if (t.coef) { t.c0 = t.coef[0]; t.c1 = t.coef[1]; } }
     extern __shared__ double s_dyn_res[];
     CamTables<CL, RL> T;
     T.stage(a, s_dyn_res, RES_THREADS);
@@ -508,6 +522,7 @@ template <int MODEL, int NP, bool ROBUST, bool CL, bool RL, bool SOFT, bool UNIT
 __global__ __launch_bounds__(LinCfg<(ROBUST && !SOFT) || MODEL == RPC>::THREADS) void k_linearize(
     ObsArgs a, double2* __restrict__ f, double* __restrict__ V, double* __restrict__ gp, double* __restrict__ part, RedBuf rb,
     double* __restrict__ hdr_cost, double* __restrict__ hdr_gpmax) {
+    SATBA_GATE(a.gate);
     constexpr int CUS = cam_sum_stride(NP), CLS = cam_lo_stride(NP);
     using Cfg = LinCfg<(ROBUST && !SOFT) || MODEL == RPC>;
     constexpr int THREADS = Cfg::THREADS, WAVES = Cfg::WAVES;
@@ -654,7 +669,8 @@ __global__ __launch_bounds__(1024) void k_lin_finish(int M, int NP, int nblocks,
                                                      double* __restrict__ gc, const int* __restrict__ cam_ofs,
                                                      const double* __restrict__ camc, int n_cam_fix, int const_t,
                                                      const double* __restrict__ fx, const int* __restrict__ fxe,
-                                                     const int* __restrict__ fx_flag, double* __restrict__ hdr_flag) {
+                                                     const int* __restrict__ fx_flag, double* __restrict__ hdr_flag, const int* gate) {
+    SATBA_GATE(gate);
     const int W = 3 * NP;  // diag U_c | g_c high limbs | g_c low limbs
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int idx = blockIdx.x * 64 + lane;  // output (camera, k), k < 2 NP
@@ -711,7 +727,8 @@ __global__ __launch_bounds__(256) void k_lin_scales(int M, const double* __restr
                                                     const double* __restrict__ bbox, double w_max, int loss, double f_scale,
                                                     const double* __restrict__ cost, double n_max, double shrink,
                                                     double* __restrict__ fx, int* __restrict__ fxe, int* __restrict__ fx_flag,
-                                                    double* __restrict__ clear, int n_clear) {
+                                                    double* __restrict__ clear, int n_clear, const int* gate) {
+    SATBA_GATE(gate);
     __shared__ unsigned long long s_max[NP];
     __shared__ int s_a[NP + 1];
     for (int i = threadIdx.x; i < n_clear; i += 256) clear[i] = 0.0;
@@ -810,6 +827,7 @@ constexpr int LINC_THREADS = 256;
 // full blocks, (b) SATBA_DETERMINISTIC runs, (c) camera counts whose accumulator table does not fit the LDS.
 template <int MODEL, int NP>
 __global__ __launch_bounds__(LINC_THREADS) void k_cam_sums(ObsArgs a, CamMajor c, const double2* __restrict__ f, double* __restrict__ part) {
+    SATBA_GATE(a.gate);
     constexpr int CU = cam_acc_len(NP);
     const int cam = blockIdx.x, chunk = blockIdx.y, n_chunks = gridDim.y;
     const int b = c.cam_ofs[cam], e = c.cam_ofs[cam + 1];
@@ -872,7 +890,9 @@ __global__ __launch_bounds__(LINC_THREADS) void k_cam_sums(ObsArgs a, CamMajor c
 }
 
 // chunk partials -> U (M x NP x NP, both triangles), g_c (M x NP)
-__global__ void k_cam_sums_finish(int M, int NP, int n_chunks, const double* __restrict__ part, double* __restrict__ U, double* __restrict__ gc) {
+__global__ void k_cam_sums_finish(int M, int NP, int n_chunks, const double* __restrict__ part, double* __restrict__ U, double* __restrict__ gc,
+                                  const int* gate) {
+    SATBA_GATE(gate);
     const int CU = cam_acc_len(NP);
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= M * CU) return;
@@ -897,8 +917,10 @@ __global__ __launch_bounds__(256) void k_prepare_vec(int n, int n_c, int NP, int
                                                      const double* __restrict__ V, const double* __restrict__ x,
                                                      double* __restrict__ g, double* __restrict__ scale_inv,
                                                      double* __restrict__ gh, double* __restrict__ ghs, RedBuf rb, double* __restrict__ hdr,
-                                                     const double* __restrict__ keep) {
+                                                     const double* __restrict__ keep, const int* __restrict__ first_dev, const int* gate) {
     // ghs = g_h / scale_inv: the unscaled direction of g_h, input of the Jacobian-vector product that follows
+    SATBA_GATE(gate);
+    if (first_dev) first = *first_dev;  // device-resident loop: the first linearisation of a solve initialises the scaling
     if (keep[SATBA_K_FX] != 0.0) return;  // the camera sums of this linearisation overflowed their fixed-point range: the caller
                                           // repeats it with k_cam_sums; the running maximum of scale_inv must not see the garbage
     double s_gh = 0.0, s_xs = 0.0, m_gc = 0.0;
@@ -972,6 +994,7 @@ __device__ inline void affine_dir_table(const ObsArgs& a, const double* __restri
 template <int MODEL, int NP, int NV, bool CL, bool RL, bool PRE>
 __global__ __launch_bounds__(JVP_THREADS) void k_jvp(ObsArgs a, const double* __restrict__ q1, const double* __restrict__ q2,
                                                      const double* __restrict__ scale_inv, RedBuf rb, double* __restrict__ out) {
+    SATBA_GATE(a.gate);
     extern __shared__ double s_dyn_jvp[];
     const int lane = threadIdx.x & 63;
     constexpr int WAVES = JVP_THREADS / 64;
@@ -1086,12 +1109,17 @@ __global__ __launch_bounds__(JVP_THREADS) void k_jvp(ObsArgs a, const double* __
 // x_scale="jac" makes the scaled matrix unit-diagonal up to the damping, which keeps the dense factorisation
 // well conditioned although the raw camera blocks span ~12 orders of magnitude (angles vs translations).
 // (the same launch clears the dense solver's status word and flags, n_clear ints at `clear`: one fill less)
+// col_lo, col_hi: only the columns of that range (the overlapped factorisation scales every range of columns as it arrives);
+// the right-hand side and the flags go with the range that starts at column 0
 __global__ __launch_bounds__(256) void k_scale_system(int n_c, const double* __restrict__ scale_inv, double* __restrict__ S,
                                                       const double* __restrict__ rhs, double* __restrict__ rhs_scaled, int* __restrict__ clear,
-                                                      int n_clear) {
-    const size_t nn = (size_t)n_c * n_c;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)n_clear; i += (size_t)gridDim.x * blockDim.x) clear[i] = 0;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nn + n_c; i += (size_t)gridDim.x * blockDim.x) {
+                                                      int n_clear, const int* gate, int col_lo, int col_hi) {
+    SATBA_GATE(gate);
+    const size_t lo = (size_t)col_lo * n_c, nn = (size_t)col_hi * n_c;
+    const bool head = col_lo == 0;
+    if (head)
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)n_clear; i += (size_t)gridDim.x * blockDim.x) clear[i] = 0;
+    for (size_t i = lo + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nn + (head ? n_c : 0); i += (size_t)gridDim.x * blockDim.x) {
         if (i < nn) {
             const int r = (int)(i % n_c), c = (int)(i / n_c);
             if (r >= c) S[i] /= scale_inv[r] * scale_inv[c];
@@ -1106,7 +1134,8 @@ __global__ __launch_bounds__(256) void k_scale_system(int n_c, const double* __r
 // kept from the earlier phases of this iteration in slots SATBA_HDR_KEEP.. (rank 0 only: headers are summed over ranks)
 __global__ void k_unscale(int n_c, const double* __restrict__ scale_inv, const double* __restrict__ dch, double* __restrict__ dc,
                           int hdr_len, double* __restrict__ hdr, const int* __restrict__ fail_flag, double lead,
-                          const double* __restrict__ keep, int keep_at, int keep_len) {
+                          const double* __restrict__ keep, int keep_at, int keep_len, const int* gate) {
+    SATBA_GATE(gate);
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n_c) dc[i] = dch[i] / scale_inv[i];
     if (i < hdr_len) {
@@ -1120,7 +1149,8 @@ __global__ void k_unscale(int n_c, const double* __restrict__ scale_inv, const d
 // start of the prepare phase, one launch: the (already all-reduced) linearize payload U | g_c is copied out of the
 // exchange buffer, keep[0] = cost and keep[1] = max_rank |g_p|_inf are taken from its header, the header is zeroed
 __global__ __launch_bounds__(1024) void k_prepare_stash(int nU, int n_c, int world, int hdr_fixed, int hdr_len, double* __restrict__ xb,
-                                                        double* __restrict__ U, double* __restrict__ gc, double* __restrict__ keep) {
+                                                        double* __restrict__ U, double* __restrict__ gc, double* __restrict__ keep, const int* gate) {
+    SATBA_GATE(gate);
     const double* payload = xb + hdr_len;
     for (int i = threadIdx.x; i < nU + n_c; i += blockDim.x) {
         if (i < nU) U[i] = payload[i];
@@ -1147,6 +1177,7 @@ __global__ __launch_bounds__(BS_THREADS) void k_backsub(ObsArgs a, const double*
                                                         double lead, const double* __restrict__ Vinv, const double* __restrict__ g,
                                                         const double* __restrict__ scale_inv, const double* __restrict__ gh,
                                                         double* __restrict__ gn, RedBuf rb, double* __restrict__ hdr) {
+    SATBA_GATE(a.gate);
     extern __shared__ double s_dyn_bs[];
     const int lane = threadIdx.x & 63;
     constexpr int WAVES = BS_THREADS / 64;
@@ -1245,7 +1276,9 @@ __global__ __launch_bounds__(BS_THREADS) void k_backsub(ObsArgs a, const double*
 __global__ __launch_bounds__(256) void k_subspace_vec(int n, int n_c, double lead, double alpha, double s,
                                                       const double* __restrict__ gh, const double* __restrict__ gn,
                                                       double* __restrict__ q1, double* __restrict__ wv, RedBuf rb,
-                                                      double* __restrict__ hdr) {
+                                                      double* __restrict__ hdr, const double* __restrict__ args_dev, const int* gate) {
+    SATBA_GATE(gate);
+    if (args_dev) { alpha = args_dev[0]; s = args_dev[1]; }  // device-resident loop
     double ww = 0.0, wq = 0.0, gw = 0.0;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const double h = gh[i], q = s * h, w = gn[i] - alpha * h;

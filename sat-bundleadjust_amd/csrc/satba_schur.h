@@ -61,7 +61,15 @@ __global__ __launch_bounds__(VINV_THREADS) void k_vinv(int N, double lam, const 
                                                        double* __restrict__ keep, const double* __restrict__ V,
                                                        const double* __restrict__ scale_inv_p, double* __restrict__ Vinv,
                                                        const double* __restrict__ xp, const double* __restrict__ gp, double* __restrict__ PV,
-                                                       const int* __restrict__ perm, int n_pts_fix) {
+                                                       const int* __restrict__ perm, int n_pts_fix, const double* __restrict__ Delta_dev,
+                                                       const double* __restrict__ lam_force, const int* gate) {
+    SATBA_GATE(gate);
+    if (Delta_dev) Delta = *Delta_dev;  // device-resident loop: the trust radius lives in the loop's state (<= 0: first iteration)
+    if (lam_force && *lam_force > 0.0) {  // ... and so does the escalated damping after a failed factorisation (the prepare header is gone then)
+        hdr_auto = nullptr;
+        lam = *lam_force;
+        if (blockIdx.x == 0 && threadIdx.x == 0) keep[5] = lam;
+    }
     __shared__ double2 s_t[VINV_THREADS / 64][64 * 9];  // per wave: 64 records x 144 bytes (the Vinv rows use the front of it)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int p0 = (blockIdx.x * (VINV_THREADS / 64) + wave) * 64;  // first point of this wave
@@ -123,7 +131,8 @@ __global__ __launch_bounds__(VINV_THREADS) void k_vinv(int N, double lam, const 
 // The same launch clears the exchange header (hdr_len doubles at xb), which the phases after this one accumulate into.
 __global__ void k_schur_init(int M, int NP, double lam, const double* __restrict__ lam_dev, double lead,
                              const double* __restrict__ gc, const double* __restrict__ scale_inv,
-                             double* __restrict__ S, double* __restrict__ rhs, double* __restrict__ xb, int hdr_len) {
+                             double* __restrict__ S, double* __restrict__ rhs, double* __restrict__ xb, int hdr_len, const int* gate) {
+    SATBA_GATE(gate);
     if (lam_dev) lam = *lam_dev;
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx < hdr_len) xb[idx] = 0.0;
@@ -219,6 +228,7 @@ __global__ void k_schur_item_desc(long long n_items, const int2* __restrict__ it
 // of being recomputed (they carry scales and masks).
 template <int MODEL, int NP, bool UNITW>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 3))) void k_schur_pairs(ObsArgs a, SchurArgs s, double* __restrict__ S) {
+    SATBA_GATE(a.gate);
     __shared__ double2 s_coop[4 * 64 * 7];  // per wave: 64 records x 80 bytes, or 64 Jacobian rows x 112 (the cooperative gathers are transposed here)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long long n_pairs = (long long)a.M * (a.M - 1) / 2;
@@ -524,12 +534,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 3))) voi
 
 // several point-range chunks: S block of each pair = sum of its chunk partials (chunk order: repeatable)
 __global__ __launch_bounds__(256) void k_schur_pairs_reduce(int M, int NP, int n_c, int n_chunks, const int2* __restrict__ pair_ij,
-                                                            const double* __restrict__ part, double* __restrict__ S) {
+                                                            const double* __restrict__ part, double* __restrict__ S, const int* gate,
+                                                            long long pair_lo, long long pair_cnt) {
+    // pair_lo, pair_cnt: the pairs of a range of camera rows (their indices are contiguous)
+    SATBA_GATE(gate);
     const long long n_pairs = (long long)M * (M - 1) / 2;
     const int NB2 = NP * NP;
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= n_pairs * NB2) return;
-    const long long pair = idx / NB2;
+    if (idx >= pair_cnt * NB2) return;
+    const long long pair = pair_lo + idx / NB2;
     const int e = (int)(idx % NB2);
     double t = 0.0;
     for (int ch = 0; ch < n_chunks; ++ch) t += part[((size_t)ch * n_pairs + pair) * NB2 + e];
@@ -545,6 +558,7 @@ __global__ __launch_bounds__(256) void k_schur_pairs_reduce(int M, int NP, int n
 // point range) are dispatched together and share their point records in L2.
 template <int MODEL, int NP>
 __global__ __launch_bounds__(LINC_THREADS) void k_schur_diag(ObsArgs a, CamMajor c, SchurArgs s, double* __restrict__ part) {
+    SATBA_GATE(a.gate);
     constexpr int CU = cam_acc_len(NP);
     const int cam = blockIdx.x, chunk = blockIdx.y, n_chunks = gridDim.y;
     const int b = c.cam_ofs[cam], e = c.cam_ofs[cam + 1];
@@ -740,7 +754,8 @@ __global__ __launch_bounds__(LINC_THREADS) void k_schur_diag(ObsArgs a, CamMajor
 
 // S_ii (lower incl. diagonal, both triangles of the block are written) and rhs_i += chunk partials
 __global__ void k_schur_diag_finish(int M, int NP, int n_c, int n_chunks, const double* __restrict__ part,
-                                    double* __restrict__ S, double* __restrict__ rhs) {
+                                    double* __restrict__ S, double* __restrict__ rhs, const int* gate) {
+    SATBA_GATE(gate);
     const int CU = cam_acc_len(NP);
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= M * CU) return;

@@ -30,7 +30,7 @@ SYMBOLS = [
     "satba_accept", "satba_camera_sums_fallback", "satba_read_header", "satba_get_blocks", "satba_get_jacobian", "satba_get_exchange",
     "satba_set_exchange", "satba_get_vector", "satba_time_kernel",
     "satba_packed_schur_len", "satba_pack_schur", "satba_unpack_schur",
-    "satba_solve_lm", "satba_lm_step", "satba_profile_linearize", "satba_profile_read", "satba_outliers", "satba_layout_len", "satba_get_layout", "satba_get_info",
+    "satba_solve_lm", "satba_lm_step", "satba_lm_run", "satba_lm_state", "satba_profile_linearize", "satba_profile_read", "satba_outliers", "satba_layout_len", "satba_get_layout", "satba_get_info",
     "satba_triangulate_pairwise", "satba_init_pts3d", "satba_snapshot_x",
     "satba_rpc_fit", "satba_rpc_localization",
 ]
@@ -86,7 +86,7 @@ def load_library(path=None):
     lib.satba_problem_create.argtypes = [C.POINTER(ProblemDesc), C.POINTER(h)]
     lib.satba_problem_destroy.argtypes = [h]
     lib.satba_problem_destroy.restype = None
-    lib.satba_set_stream.argtypes = [h, C.c_void_p]
+    lib.satba_set_stream.argtypes = [h, C.c_void_p, C.c_int32]
     lib.satba_exchange_len.argtypes = [h]
     lib.satba_exchange_len.restype = C.c_int64
     lib.satba_header_len.argtypes = [h]
@@ -117,6 +117,8 @@ def load_library(path=None):
     lib.satba_time_kernel.argtypes = [h, C.c_int32, C.c_int32, C.POINTER(C.c_float)]
     lib.satba_solve_lm.argtypes = [h, C.POINTER(LmOpts), C.POINTER(LmStats)]
     lib.satba_lm_step.argtypes = [h, C.c_int32, C.c_double, C.c_double, C.POINTER(C.c_double)]
+    lib.satba_lm_run.argtypes = [h, C.c_int64, C.c_int32, C.c_double, C.POINTER(C.c_double), C.c_int32]
+    lib.satba_lm_state.argtypes = [h, C.POINTER(C.c_double), C.c_int32]
     lib.satba_profile_linearize.argtypes = [h, C.c_int32]
     lib.satba_profile_read.argtypes = [h, C.POINTER(C.c_int64), C.POINTER(C.c_double)]
     lib.satba_outliers.argtypes = [h, _dp, C.c_double, C.c_double, _dp, C.POINTER(C.c_uint8), C.POINTER(C.c_int64)]
@@ -211,8 +213,11 @@ class HipEngine:
         if self._torch is not None:
             torch = self._torch
             self.xb = torch.zeros(self.xb_len, dtype=torch.float64, device="cuda:{}".format(self.device))
+            torch.cuda.synchronize(self.device)  # the fill ran on torch's stream; the handle launches on its own
             _check(self.lib, self.lib.satba_bind_exchange(self._h, C.c_void_p(self.xb.data_ptr()), self.xb_len))
-            self.use_stream(torch.cuda.current_stream(self.device))
+            if self.world > 1:
+                # several ranks: the kernels must order with the collectives torch.distributed queues on torch's current stream
+                self.use_stream(torch.cuda.current_stream(self.device))
         self._hdr_host = np.zeros(self.hdr)
         self.xp = None  # packed Schur payload (header | lower triangle of S | rhs), allocated on first use
         self.len_schur_packed = int(self.lib.satba_packed_schur_len(self._h))
@@ -244,10 +249,15 @@ class HipEngine:
         """Copy the (all-reduced) packed payload back into the exchange buffer."""
         _check(self.lib, self.lib.satba_unpack_schur(self._h, C.c_void_p(self.xp.data_ptr())))
 
-    def use_stream(self, stream):
-        """Launch on a torch.cuda.Stream (or None for the default stream)."""
+    def use_torch_stream(self):
+        """Launch on torch's current stream, so that the kernels order with the collectives torch.distributed queues there."""
+        if self._torch is not None:
+            self.use_stream(self._torch.cuda.current_stream(self.device))
+
+    def use_stream(self, stream, own=False):
+        """Launch on a torch.cuda.Stream (None: the legacy default stream); own=True: back to the handle's own stream."""
         handle = stream.cuda_stream if stream is not None else 0
-        _check(self.lib, self.lib.satba_set_stream(self._h, C.c_void_p(handle)))
+        _check(self.lib, self.lib.satba_set_stream(self._h, C.c_void_p(handle), 1 if own else 0))
 
     # -- state transfer
     def configure(self, loss, f_scale):
@@ -339,6 +349,25 @@ class HipEngine:
         keys = ["cost", "cost_new", "Delta", "accepted", "newton", "predicted", "actual", "lam"]
         return dict(zip(keys, out))
 
+    LM_KEYS = ["cost", "cost_new", "Delta", "accepted", "newton", "predicted", "actual", "lam", "phase", "status", "nfev", "njev",
+               "iterations", "ticks", "host_reason", "g_norm"]
+
+    def lm_run(self, n_iterations, cycle_len=0, lam_floor=0.0):
+        """
+        satba_lm_run: n fixed-work LM iterations on the device-resident loop (decisions taken by one-thread kernels on the device, no
+        host round trip inside an iteration); cycle_len > 0: back to the point kept by snapshot_x every cycle_len iterations.
+        Returns the loop's scalars as a dict once the device is done.
+        """
+        out = np.zeros(16)
+        _check(self.lib, self.lib.satba_lm_run(self._h, int(n_iterations), int(cycle_len), float(lam_floor), _ptr(out), 16))
+        return dict(zip(self.LM_KEYS, out))
+
+    def lm_state(self):
+        """satba_lm_state: wait for the stream and return the scalars of the device-resident loop as a dict."""
+        out = np.zeros(16)
+        _check(self.lib, self.lib.satba_lm_state(self._h, _ptr(out), 16))
+        return dict(zip(self.LM_KEYS, out))
+
     def solve_lm(self, ftol=1e-8, xtol=1e-8, gtol=1e-8, max_nfev=None, loss="linear", f_scale=1.0, verbose=0):
         """satba_solve_lm: the loop of satba/trf.py in C++; returns the LmStats structure."""
         if loss not in LOSSES:
@@ -375,10 +404,10 @@ class HipEngine:
         return out
 
     def info(self):
-        v = np.zeros(16)
-        _check(self.lib, self.lib.satba_get_info(self._h, _ptr(v), 16))
+        v = np.zeros(18)
+        _check(self.lib, self.lib.satba_get_info(self._h, _ptr(v), 18))
         keys = ["ms_uploads", "ms_sizes", "ms_ell", "ms_pairs", "ms_create", "ell_len", "pair_entries", "pair_chunks", "unit_weights",
-                "camc_lds", "rpc_lds", "cam_sums_lds", "deterministic", "cm_chunks", "lin_grid", "fx_fallbacks"]
+                "camc_lds", "rpc_lds", "cam_sums_lds", "deterministic", "cm_chunks", "lin_grid", "fx_fallbacks", "device_loop", "overlap_ranges"]
         return dict(zip(keys, v[: len(keys)]))
 
     def get_blocks(self):

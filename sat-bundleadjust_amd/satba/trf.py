@@ -312,6 +312,8 @@ def trf_solve(engine, comm=None, ftol=1e-8, xtol=1e-8, gtol=1e-8, max_nfev=None,
             print("Function evaluations {}, initial cost {:.4e}, final cost {:.4e}, first-order optimality {:.2e}."
                   .format(res.nfev, res.initial_cost, res.cost, res.optimality))
         return res
+    if isinstance(comm, TorchComm) and (comm.world > 1 or comm.always) and hasattr(engine, "use_torch_stream"):
+        engine.use_torch_stream()  # the all-reduces are queued on torch's stream: the phases must order with them
     hdr = engine.hdr
     slots = slice(engine.HDR_FIXED, engine.HDR_FIXED + comm.world)
     if max_nfev is None:
