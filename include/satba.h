@@ -265,6 +265,19 @@ int satba_rpc_fit(int32_t n_cam, int32_t n_samples, const double *target, const 
 int satba_rpc_localization(const double *table, int64_t n, const double *col, const double *row, const double *alt, double *lon,
                            double *lat, int32_t device);
 
+/* satba_rpc_refit replaces the loop of ba_pipeline.save_corrected_rpcs over ba_rpcfit.fit_Rt_corrected_rpc (ba_rpcfit.py:270-345,
+ * ba_pipeline.py:406-423) for a batch of cameras, device resident: per camera the n_samples^3 mesh over its crop (+ margin) is built,
+ * localised through the original RPC (tables_in: n_cam records), moved by global_transform (3 doubles or NULL), pushed through the
+ * corrected projection x = P(R (X - T - C) + C) (rt: n_cam x 9 = Euler angles, T, C; the vector ba_params.reconstruct_vars keeps per
+ * camera), fitted (satba_rpc_fit's loop) and checked: the margin (10 px at first) doubles until the convex hull of the mesh
+ * re-projected through the FITTED model covers the crop (crops: n_cam x 4 = col0, row0, width, height) or exceeds 1000.
+ * alt_ranges: n_cam x 2 (lowest, highest altitude of the mesh).  Outputs: tables_out (n_cam records), margins (n_cam: the last
+ * margin), err (n_cam x n_samples^3 reprojection errors of the fitted model, check_errors; may be NULL), locs_out / target_out
+ * (the last mesh: lon, lat, alt / col, row; may be NULL).  4 <= n_samples <= 16. */
+int satba_rpc_refit(int32_t n_cam, const double *tables_in, const double *rt, const double *crops, const double *alt_ranges,
+                    const double *global_transform, int32_t n_samples, double h, double tol, int32_t max_iter, double *tables_out, double *err,
+                    double *margins, double *locs_out, double *target_out, int32_t device);
+
 /* ---- inspection entry points (parity tests; not used by the solver loop) */
 /* index structures built by satba_problem_create, as int32 arrays (SATBA_LAY_PAIR_OFS: int64): n must equal satba_layout_len */
 enum { SATBA_LAY_PERM = 0, SATBA_LAY_RANK, SATBA_LAY_PT_CNT, SATBA_LAY_SLICE_BASE, SATBA_LAY_E_CAM, SATBA_LAY_OBS_POS, SATBA_LAY_CAM_OFS,

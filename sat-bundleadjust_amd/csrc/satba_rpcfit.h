@@ -219,4 +219,150 @@ __global__ __launch_bounds__(256) void k_rpc_localize(long long n, const double*
     lon[i] = lo; lat[i] = la;
 }
 
+// ------------------------------------------------------------------------------------------------ re-fit, device resident (round 3)
+// fit_Rt_corrected_rpc for a batch of cameras without the host in the data path (ref:bundle_adjust/ba_rpcfit.py:270-345; round 2
+// built the grids with numpy and ran one localisation launch per camera and margin round: 1 s for 50 cameras, 6 ms of it on the
+// device).  Per margin round, for the cameras still to do:
+//   k_refit_grid   thread = grid node: (col, row, alt) of the n x n x n mesh over the crop + margin (numpy.linspace's arithmetic,
+//                  columns fastest), localisation through the ORIGINAL RPC, geodetic -> ECEF (grid), + global transform, the
+//                  corrected projection x = P(R (X - T - C) + C) (satba_models.h: project<RPC, 6>) -> target;
+//   k_rpc_fit      the fit (above), one workgroup per camera;
+//   k_refit_check  one workgroup per camera: reprojection error of the fitted model per sample (check_errors, :357-370) and the
+//                  coverage test (:347-355): the grid re-projected through the FITTED model, its convex hull (gift wrapping from the
+//                  lowest point, cross products in the reference's float64), the four image corners against every hull edge with
+//                  the tolerance of the host version (1e-9 on unit normals).
+// The host reads one flag per camera and round (covered / not), doubles the margin of the others and goes again.
+constexpr int REFIT_MAX_N = 16;  // grid nodes per axis (the reference uses 10)
+
+struct RefitCam {          // per camera, device memory
+    double table[90];      // original RPC
+    double rt[9];          // Euler angles, T, C of the correction
+    double crop[4];        // col0, row0, width, height
+    double alt[2];         // altitude range of the mesh
+    double margin;
+    int slot, pad;         // position in the output arrays
+};
+
+__device__ inline double refit_linspace(double lo, double hi, int n, int i) {  // numpy.linspace(lo, hi, n)[i]: start + i * step, the end point exact
+#pragma clang fp contract(off)  // numpy multiplies, then adds: two roundings
+    if (n == 1) return lo;
+    if (i == n - 1) return hi;
+    const double step = (hi - lo) / (double)(n - 1);
+    return lo + (double)i * step;
+}
+
+__device__ inline void refit_to_ecef(double lat, double lon, double alt, double& x, double& y, double& z) {  // ref:bundle_adjust/geo_utils.py:218-233
+    const double rl = lat * (M_PI / 180.0), ro = lon * (M_PI / 180.0);
+    const double f = 1.0 / 298.257223563, e2 = 1.0 - (1.0 - f) * (1.0 - f);
+    double sl, cl, so, co;
+    sincos(rl, &sl, &cl); sincos(ro, &so, &co);
+    const double v = WGS84_A / sqrt(1.0 - e2 * sl * sl);
+    x = (v + alt) * cl * co; y = (v + alt) * cl * so; z = (v * (1.0 - e2) + alt) * sl;
+}
+
+// grid: n_cam x n^3 x 3 ECEF nodes (without the global transform), locs: lon, lat, alt, target: corrected projection
+__global__ __launch_bounds__(256) void k_refit_grid(int n, const RefitCam* __restrict__ cams, const double* __restrict__ gt, double* __restrict__ grid,
+                                                    double* __restrict__ locs, double* __restrict__ target) {
+    __shared__ double s_tab[TRI_RPC_STRIDE];
+    __shared__ double s_cc[CAMC];
+    const int cam = blockIdx.y, n3 = n * n * n;
+    const RefitCam& c = cams[cam];
+    if (threadIdx.x < 90) s_tab[threadIdx.x] = c.table[threadIdx.x];
+    if (threadIdx.x == 0) cam_constants(RPC, c.rt, s_cc);
+    __syncthreads();
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n3) return;
+    const int ic = i % n, ir = (i / n) % n, ia = i / (n * n);
+    const double col = refit_linspace(c.crop[0] - c.margin, c.crop[0] + c.crop[2] + c.margin, n, ic);
+    const double row = refit_linspace(c.crop[1] - c.margin, c.crop[1] + c.crop[3] + c.margin, n, ir);
+    const double alt = refit_linspace(c.alt[0], c.alt[1], n, ia);
+    double lon, lat;
+    tri_localize(TabLds{s_tab}, col, row, alt, lon, lat);
+    double x, y, z;
+    refit_to_ecef(lat, lon, alt, x, y, z);
+    const size_t o = (size_t)c.slot * n3 + i;
+    grid[3 * o] = x; grid[3 * o + 1] = y; grid[3 * o + 2] = z;
+    locs[3 * o] = lon; locs[3 * o + 1] = lat; locs[3 * o + 2] = alt;
+    double u, v, Jc[2][6], Jp[2][3];
+    project<RPC, 6, false>(s_cc, s_tab, x + gt[0], y + gt[1], z + gt[2], false, u, v, Jc, Jp);
+    target[2 * o] = u; target[2 * o + 1] = v;
+}
+
+// err: n_cam x n^3 reprojection errors of the fitted model; covered[slot] = 1 if the hull of the re-projected grid holds the crop
+__global__ __launch_bounds__(256) void k_refit_check(int n, const RefitCam* __restrict__ cams, const double* __restrict__ tables,
+                                                     const double* __restrict__ grid, const double* __restrict__ locs, const double* __restrict__ target,
+                                                     double* __restrict__ err, int* __restrict__ covered) {
+    constexpr int MAXP = REFIT_MAX_N * REFIT_MAX_N * REFIT_MAX_N;
+    __shared__ double s_tab[TRI_RPC_STRIDE];
+    __shared__ double2 s_p[MAXP];
+    __shared__ double s_key[256];
+    __shared__ int s_idx[256];
+    __shared__ int s_bad;
+    const int cam = blockIdx.x, tid = threadIdx.x, n3 = n * n * n;
+    const RefitCam& c = cams[cam];
+    const size_t base = (size_t)c.slot * n3;
+    if (tid < 90) s_tab[tid] = tables[(size_t)c.slot * 90 + tid];
+    if (tid == 0) s_bad = 0;
+    __syncthreads();
+    for (int i = tid; i < n3; i += 256) {
+        const size_t o = base + i;
+        double u, v;
+        tri_project(TabLds{s_tab}, locs[3 * o], locs[3 * o + 1], locs[3 * o + 2], u, v);
+        err[o] = hypot(u - target[2 * o], v - target[2 * o + 1]);
+        // the coverage test projects the ECEF grid: geodetic coordinates by the reference's closed form, not the localised ones
+        double geo[3], G[3][3];
+        geodetic<false>(grid[3 * o], grid[3 * o + 1], grid[3 * o + 2], geo, G);
+        tri_project(TabLds{s_tab}, geo[1], geo[0], geo[2], u, v);
+        s_p[i] = make_double2(u, v);
+    }
+    __syncthreads();
+    // gift wrapping: start at the lowest (then leftmost) point; the next vertex is the one all others lie to the left of
+    auto arg_best = [&](auto better) {  // index of the best point under `better(a, b)` = a beats b; block-wide
+        int bi = -1;
+        for (int i = tid; i < n3; i += 256)
+            if (bi < 0 || better(i, bi)) bi = i;
+        s_idx[tid] = bi;
+        __syncthreads();
+        for (int st = 128; st > 0; st >>= 1) {
+            if (tid < st) {
+                const int a = s_idx[tid], b = s_idx[tid + st];
+                if (a < 0 || (b >= 0 && better(b, a))) s_idx[tid] = b;
+            }
+            __syncthreads();
+        }
+        const int r = s_idx[0];
+        __syncthreads();
+        return r;
+    };
+    const int start = arg_best([&](int a, int b) { return s_p[a].y < s_p[b].y || (s_p[a].y == s_p[b].y && s_p[a].x < s_p[b].x); });
+    const double cx[4] = {c.crop[0], c.crop[0], c.crop[0] + c.crop[2], c.crop[0] + c.crop[2]};
+    const double cy[4] = {c.crop[1], c.crop[1] + c.crop[3], c.crop[1] + c.crop[3], c.crop[1]};
+    int cur = start;
+    for (int guard = 0; guard <= n3; ++guard) {
+        const double2 pc = s_p[cur];
+        // next hull vertex (counter-clockwise): q such that no point is to the right of pc -> q; ties: the farthest
+        const int nxt = arg_best([&](int a, int b) {
+            if (a == cur) return false;
+            if (b == cur) return true;
+            const double ax = s_p[a].x - pc.x, ay = s_p[a].y - pc.y, bx = s_p[b].x - pc.x, by = s_p[b].y - pc.y;
+            const double cr = bx * ay - by * ax;  // > 0: a is to the left of pc -> b, i.e. b is the more clockwise one
+            if (cr < 0) return true;              // a is to the right of pc -> b: a wraps tighter
+            if (cr > 0) return false;
+            return ax * ax + ay * ay > bx * bx + by * by;
+        });
+        if (nxt < 0) break;
+        if (tid == 0) {  // the image corners against the edge pc -> pn: outward normal (dy, -dx) / |d|, tolerance 1e-9 like the host version
+            const double dx = s_p[nxt].x - pc.x, dy = s_p[nxt].y - pc.y, len = sqrt(dx * dx + dy * dy);
+            if (len > 0.0)
+                for (int k = 0; k < 4; ++k)
+                    if ((dy * (cx[k] - pc.x) - dx * (cy[k] - pc.y)) / len > 1e-9) s_bad = 1;
+        }
+        cur = nxt;
+        if (cur == start) break;
+    }
+    __syncthreads();
+    if (tid == 0) covered[c.slot] = s_bad ? 0 : 1;
+    (void)s_key;
+}
+
 }  // namespace satba

@@ -5,7 +5,9 @@ corrected projection of a camera on a 3-D grid over its image.
 `weighted_lsq`, `fit_Rt_corrected_rpc`, `fit_rpc_from_projection_matrix`, `check_errors`, `poly_vect`, `scaling_params` keep the
 reference's signatures and return values (RPC objects are `satba.rpc_model.RPCModel`, which carries the attribute names of
 `rpcm.RPCModel`).  The fit itself (`satba_rpc_fit`, csrc/satba_rpcfit.h) and the localisation of the grid through the original RPC
-(`satba_rpc_localization`) run on the device; `fit_Rt_corrected_rpcs` fits many cameras in one launch.  There is no CPU fallback.
+(`satba_rpc_localization`) run on the device; `fit_Rt_corrected_rpcs` does the whole loop of the pipeline's output step for all
+cameras on the device (`satba_rpc_refit`: meshes, localisation, corrected projection, fit, errors, coverage test).  There is no CPU
+fallback.
 
 The coverage test of the reference (`check_correspondences_are_good`: the convex hull of the re-projected grid must contain the
 image rectangle, via shapely there) is done with scipy.spatial.ConvexHull here: a convex hull contains a rectangle exactly when it
@@ -132,32 +134,32 @@ def fit_rpc_from_projection_matrix(P, global_transform, original_rpc, crop_offse
                                     crop_offset, alt_range, n_samples, global_transform)
 
 
-def fit_Rt_corrected_rpcs(Rt_vecs, global_transform, original_rpcs, crop_offsets, n_samples=10):
+def fit_Rt_corrected_rpcs(Rt_vecs, global_transform, original_rpcs, crop_offsets, n_samples=10, return_info=False):
     """
-    fit_Rt_corrected_rpc for a list of cameras with ONE fit launch per margin round (what ba_pipeline.save_corrected_rpcs loops
-    over, ref:bundle_adjust/ba_pipeline.py:406-423).  Returns a list of (rpc_calib, err, margin).
+    fit_Rt_corrected_rpc for a list of cameras, device resident (what ba_pipeline.save_corrected_rpcs loops over,
+    ref:bundle_adjust/ba_pipeline.py:406-423): mesh generation, localisation through the original RPCs, corrected projection, fit,
+    reprojection errors and the coverage test all run on the device for all cameras at once (satba_rpc_refit, csrc/satba_rpcfit.h);
+    the host only doubles the margins of the cameras whose mesh does not cover their crop yet.  Returns a list of
+    (rpc_calib, err, margin) like fit_Rt_corrected_rpc; with return_info also a dict with the last mesh of every camera
+    (input_locs (M, n^3, 3), target (M, n^3, 2)).
     """
-    M = len(original_rpcs)
-    out, margins, todo = [None] * M, [10] * M, list(range(M))
-    while todo:
-        grids, targets, locs = [], [], []
-        for k in todo:
-            r, crop = original_rpcs[k], crop_offsets[k]
-            alt_range = [r.alt_offset - r.alt_scale, r.alt_offset + r.alt_scale, n_samples]
-            grid, pts3d, input_locs = _grid_through_rpc(r, crop, alt_range, margins[k], n_samples, global_transform)
-            Rt = np.asarray(Rt_vecs[k], dtype=np.float64).reshape(1, 9)
-            grids.append(grid); locs.append(input_locs)
-            targets.append(cam_utils.apply_rpc_projection(r, ba_core.adjust_pts3d(pts3d, Rt)))
-        rpcs = weighted_lsq_batch(np.stack(targets), np.stack(locs))
-        nxt = []
-        for k, rpc, grid, target, input_locs in zip(todo, rpcs, grids, targets, locs):
-            crop = crop_offsets[k]
-            x0, y0, w, h = crop["col0"], crop["row0"], crop["width"], crop["height"]
-            corners = np.array([[x0, y0], [x0, y0 + h], [x0 + w, y0 + h], [x0 + w, y0]], dtype=np.float64)
-            if margins[k] > 1000 or check_correspondences_are_good(cam_utils.apply_rpc_projection(rpc, grid), corners):
-                out[k] = (rpc, check_errors(rpc, input_locs, target), margins[k])
-            else:
-                margins[k] *= 2
-                nxt.append(k)
-        todo = nxt
-    return out
+    lib = E.load_library()
+    M, n3 = len(original_rpcs), int(n_samples) ** 3
+    if M == 0:
+        return ([], {}) if return_info else []
+    tabs = np.ascontiguousarray(np.stack([np.asarray(r.to_table(), dtype=np.float64) for r in original_rpcs]))
+    rt = np.ascontiguousarray(np.stack([np.asarray(v, dtype=np.float64).reshape(9) for v in Rt_vecs]))
+    crops = np.ascontiguousarray(np.array([[c["col0"], c["row0"], c["width"], c["height"]] for c in crop_offsets], dtype=np.float64))
+    alts = np.ascontiguousarray(np.array([[r.alt_offset - r.alt_scale, r.alt_offset + r.alt_scale] for r in original_rpcs], dtype=np.float64))
+    gt = None if global_transform is None else np.ascontiguousarray(np.asarray(global_transform, dtype=np.float64).reshape(3))
+    tables = np.zeros((M, 90)); err = np.zeros((M, n3)); margins = np.zeros(M)
+    locs = np.zeros((M, n3, 3)) if return_info else None
+    target = np.zeros((M, n3, 2)) if return_info else None
+    rc = lib.satba_rpc_refit(M, E._ptr(tabs), E._ptr(rt), E._ptr(crops), E._ptr(alts), E._ptr(gt) if gt is not None else None, int(n_samples),
+                             1e-3, 1e-2, 20, E._ptr(tables), E._ptr(err), E._ptr(margins), E._ptr(locs) if return_info else None,
+                             E._ptr(target) if return_info else None, int(os.environ.get("LOCAL_RANK", "0")))
+    if rc == -4:
+        raise np.linalg.LinAlgError("Singular matrix")  # the reference's numpy.linalg.inv raises the same on degenerate samples
+    E._check(lib, rc)
+    out = [(RPCModel.from_table(tables[k]), err[k], int(margins[k])) for k in range(M)]
+    return (out, {"input_locs": locs, "target": target}) if return_info else out

@@ -32,7 +32,7 @@ SYMBOLS = [
     "satba_packed_schur_len", "satba_pack_schur", "satba_unpack_schur",
     "satba_solve_lm", "satba_lm_step", "satba_lm_run", "satba_lm_state", "satba_profile_linearize", "satba_profile_read", "satba_outliers", "satba_layout_len", "satba_get_layout", "satba_get_info",
     "satba_triangulate_pairwise", "satba_init_pts3d", "satba_snapshot_x",
-    "satba_rpc_fit", "satba_rpc_localization",
+    "satba_rpc_fit", "satba_rpc_localization", "satba_rpc_refit",
 ]
 
 FLAG_DETERMINISTIC = 1
@@ -129,6 +129,7 @@ def load_library(path=None):
     lib.satba_snapshot_x.argtypes = [h, C.c_int32]
     lib.satba_rpc_fit.argtypes = [C.c_int32, C.c_int32, _dp, _dp, C.c_double, C.c_double, C.c_int32, _dp, _dp, _ip, C.c_int32]
     lib.satba_rpc_localization.argtypes = [_dp, C.c_int64, _dp, _dp, _dp, _dp, _dp, C.c_int32]
+    lib.satba_rpc_refit.argtypes = [C.c_int32, _dp, _dp, _dp, _dp, _dp, C.c_int32, C.c_double, C.c_double, C.c_int32, _dp, _dp, _dp, _dp, _dp, C.c_int32]
     _fp = C.POINTER(C.c_float)
     lib.satba_triangulate_pairwise.argtypes = [C.c_int32, _dp, _dp, C.c_int64, _dp, _dp, _dp, _fp, C.c_int32, _fp]
     lib.satba_init_pts3d.argtypes = [C.c_int32, C.c_int32, C.c_int64, C.POINTER(C.c_int64), _ip, _dp, _dp, C.c_int32, _ip, _fp, _ip,
