@@ -799,7 +799,7 @@ static int build_layout(satba_problem* p, const satba_problem_desc* d) {
 extern "C" {
 
 const char* satba_last_error(void) { return g_err.c_str(); }
-int satba_version(void) { return 2; }
+int satba_version(void) { return 3; }
 
 int satba_problem_create(const satba_problem_desc* d, satba_problem** out) {
     if (!d || !out) return fail(SATBA_E_ARG, "null argument");
