@@ -74,6 +74,8 @@ struct satba_problem {
     const double* Delta_dev = nullptr;
     const int* first_dev = nullptr;
     const double* coef_dev = nullptr;
+    int fuse_prep = -1;        // >= 0 while a loop queues a front: k_linearize does the point part of the prepare phase (value: `first`)
+    bool prep_fused = false;   // the linearisation in place did (satba_prepare then only visits the camera entries)
     const double* lam_force_dev = nullptr;
     const double* sub_args_dev = nullptr;
     struct LmDev* d_lm = nullptr;
@@ -209,6 +211,7 @@ static ObsArgs obs_args(const satba_problem* p, bool at_new) {
     a.unit = (p->loss == 0 && p->unit_weights) ? 1 : 0;
     a.rep_shift = p->lin_rep_shift;
     a.fxe = p->d_fxe; a.fx_flag = p->d_fxflag; a.gate = p->gate;
+    a.prep_scale = nullptr; a.prep_gh = nullptr; a.prep_ghs = nullptr; a.prep_first_dev = nullptr; a.prep_first = 0;
     a.sh = 0;  // lanes per point: set by the launchers of the kernels that support it
     return a;
 }
@@ -360,6 +363,10 @@ static int raise_lin_limits(satba_problem* p) {
 static int launch_linearize_kernel(satba_problem* p) {
     ObsArgs a = obs_args(p, false);
     a.sh = slice_split(p);
+    if (p->fuse_prep >= 0) {  // single-rank loops: the point part of the prepare phase rides in this kernel
+        a.prep_scale = p->d_scale_inv; a.prep_gh = p->d_gh; a.prep_ghs = p->d_q1;
+        a.prep_first = p->fuse_prep; a.prep_first_dev = p->first_dev;
+    }
     const bool prof = p->prof_lin && p->prof_used + 2 <= 2 * 4096;
     if (prof) {
         while (p->prof_ev.size() < p->prof_used + 2) {
@@ -845,7 +852,7 @@ int satba_problem_create(const satba_problem_desc* d, satba_problem** out) {
         // per CU fits then (the sums are integers: every replica count gives the same bits); at 50 cameras 16 replicas are as good as
         // or better than 4 (round 2, float atomics: C3 0.038 vs 0.040, P3 0.040 vs 0.047, C5 0.118 vs 0.119)
         while (p->lin_rep_shift < 4 && (p->M << (p->lin_rep_shift + 1)) <= 1024 &&
-               cam_sum_bytes(p->NP, (size_t)(p->M << (p->lin_rep_shift + 1))) + camc_b <= 128 * 1024)
+               cam_sum_bytes(p->NP, (size_t)(p->M << (p->lin_rep_shift + 1))) + camc_b <= 140 * 1024)
             ++p->lin_rep_shift;
         if (const char* rs = getenv("SATBA_LIN_REP")) p->lin_rep_shift = std::min(4, std::max(0, atoi(rs)));  // experiments
         const size_t acc_b = cam_sum_bytes(p->NP, (size_t)(p->M << p->lin_rep_shift));
@@ -1134,6 +1141,7 @@ int satba_linearize(satba_problem* p) {
     }
     p->linearized = true; p->have_step = false;
     p->f_valid = !p->cam_sums_lds && p->model == RPC;
+    p->prep_fused = p->fuse_prep >= 0;
     return 0;
 }
 
@@ -1146,8 +1154,9 @@ int satba_prepare(satba_problem* p, int32_t first) {
     hipLaunchKernelGGL(k_prepare_stash, dim3(1), dim3(1024), 0, p->stream, (int)nU, p->n_c, p->world, SATBA_HDR_FIXED, (int)p->hdr, p->d_xb, p->d_U,
                        p->d_gc, p->d_keep, p->gate);
     HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(k_prepare_vec, dim3(grid_for(p->n, 256, 1024)),  // measured at 3 M entries: 512 workgroups 51 us, 1024: 45, 2048: 55
-                       dim3(256), 0, p->stream, p->n, p->n_c, p->NP, first,
+    const int n_prep = p->prep_fused ? p->n_c : p->n;  // fused: the point entries are done
+    hipLaunchKernelGGL(k_prepare_vec, dim3(grid_for(n_prep, 256, 1024)),  // measured at 3 M entries: 512 workgroups 51 us, 1024: 45, 2048: 55
+                       dim3(256), 0, p->stream, n_prep, p->n_c, p->NP, first,
                        p->lead, p->d_U, p->d_gc, p->d_V, p->d_x, p->d_g, p->d_scale_inv, p->d_gh, p->d_q1, p->red(RB_PREP), p->d_xb, p->d_keep, p->first_dev, p->gate);
     HIP_TRY(hipGetLastError());
     TRY(launch_jvp(p, 1, p->d_q1, p->d_q1, p->d_xb + 2, true));  // d_q1 is free until the subspace phase
@@ -1331,6 +1340,14 @@ int satba_read_header(satba_problem* p, double* host_hdr) {
 // ---------------------------------------------------------------------------------------------------- one-shot solve
 // The loop of satba/trf.py (scipy's trf_no_bounds with an exact damped step) below the ABI: single rank only -- with several
 // ranks the exchange buffer has to be all-reduced between the phases, which is the caller's side of the contract.
+// single-rank loops: linearize with the point part of the prepare phase fused into k_linearize (ObsArgs::prep_*)
+static int linearize_fused(satba_problem* p, bool first) {
+    p->fuse_prep = first ? 1 : 0;
+    const int rc = satba_linearize(p);
+    p->fuse_prep = -1;
+    return rc;
+}
+
 // quadratic model of the cost on the orthonormal basis of span{g_h, gn_h} (satba/trf.py:subspace_model): B (2 x 2, entries Ba Bb Bc),
 // gradient (gS0, gS1), and what maps a step (p0, p1) on that basis back to coefficients of (g_h, gn_h).  h: header of the solve
 // phase; tmp: scratch header.  Launches the subspace phases only when the Gram matrix is too ill-conditioned to do without.
@@ -1379,7 +1396,7 @@ int satba_lm_step(satba_problem* p, int32_t first, double Delta, double lam_floo
     std::vector<double> hbuf((size_t)p->hdr), tbuf((size_t)p->hdr);
     double* h = hbuf.data();
     for (;;) {
-        TRY(satba_linearize(p));
+        TRY(linearize_fused(p, first != 0));
         TRY(satba_prepare(p, first ? 1 : 0));
         TRY(front_schur_solve(p, true, 0.0, first ? -1.0 : Delta, lam_floor));
         TRY(satba_read_header(p, h));
@@ -1461,7 +1478,10 @@ static int lm_launch_tick(satba_problem* p, double lam_floor) {
     LmDev* st = p->d_lm;
     LmArgsScope scope(p);
     p->gate = &st->run_lin;
-    TRY(satba_linearize(p));
+    p->fuse_prep = 0;  // (`first` comes from the loop's state)
+    const int rc_lin = satba_linearize(p);
+    p->fuse_prep = -1;
+    TRY(rc_lin);
     TRY(satba_prepare(p, 0));
     p->gate = &st->run_solve;
     TRY(front_schur_solve(p, true, 0.0, -1.0, lam_floor));
@@ -1615,7 +1635,7 @@ static int lm_host_loop(satba_problem* p, const satba_lm_opts* o, satba_lm_stats
     double* h = hbuf.data();
     auto front = [&](double Delta, bool first) -> int {
         for (;;) {
-            TRY(satba_linearize(p));
+            TRY(linearize_fused(p, first));
             TRY(satba_prepare(p, first ? 1 : 0));
             TRY(front_schur_solve(p, true, 0.0, first ? -1.0 : Delta, 0.0));
             TRY(satba_read_header(p, h));

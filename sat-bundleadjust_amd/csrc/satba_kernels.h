@@ -25,16 +25,20 @@ __host__ __device__ constexpr int cam_acc_len(int np) { return np * (np + 1) / 2
 // row stride of the LDS camera table: odd, so that (stride * cam + k) visits all 32 bank pairs (an even stride such
 // as 20 folds the cameras onto 8 of them: 8-way conflicts of the ds_add_f64)
 __host__ __device__ constexpr int cam_acc_stride(int np) { return cam_acc_len(np) | 1; }
-// k_linearize's LDS tables hold diag(U_c) and g_c only: 2 np 64-bit sums per camera (odd row stride 7, 11, 13) and np 32-bit
-// sums, the low limbs of g_c (odd row stride 3, 5, 7 dwords); the per-workgroup partials are 3 np 64-bit words per camera
+// k_linearize's LDS table holds diag(U_c) and g_c only, g_c in two 64-bit limbs: 3 np sums per camera, odd row stride (9, 15, 19);
+// the per-workgroup partials have the same 3 np words per camera.  (A 32-bit low limb -- half the cost of a 64-bit atomic, 0.105
+// instead of 0.112 ms at 200 x 1M x 10M -- carries 15 bits with 50 000 observations per camera: 61 bits below the term bound in
+// all.  That is coarser than a float64 sum in a fixed order resolves near the solution, and the ratio test of scipy's ftol
+// criterion, which lives on differences of 1e-10 of the cost there, tripped four evaluations later: nfev 9 instead of 5 for the
+// headline solve.  With 40 more bits the sums are exact and the solve ends where round 2's did.)
 __host__ __device__ constexpr int cam_sum_len(int np) { return 3 * np; }
-__host__ __device__ constexpr int cam_sum_stride(int np) { return (2 * np) | 1; }
-__host__ __device__ constexpr int cam_lo_stride(int np) { return np | 1; }
-// bytes of both tables for `rows` (camera, replica) rows; the 32-bit table follows the 64-bit one
-__host__ __device__ constexpr size_t cam_sum_bytes(int np, size_t rows) { return ((rows * (cam_sum_stride(np) * 8 + cam_lo_stride(np) * 4) + 7) / 8) * 8; }
+__host__ __device__ constexpr int cam_sum_stride(int np) { return (3 * np) | 1; }
+constexpr int FX_LO_SHIFT = 40;  // the low limb of a g_c term holds its remainder below the high limb's unit, scaled by 2^40
+__host__ __device__ constexpr size_t cam_sum_bytes(int np, size_t rows) { return rows * cam_sum_stride(np) * 8; }
 
 constexpr int RPCS = 91;  // row stride of the LDS copy of the RPC tables (90 used, odd)
 // double -> 64-bit fixed point through one fma (k_linearize's camera sums): bits(t 2^e + 1.5 * 2^52) = FX_MAGIC_BITS + round(t 2^e)
+constexpr int SATBA_HDR_PREP_GH = 6, SATBA_HDR_PREP_XS = 7;  // linearize header: point sums of |g_h|^2, |x_h|^2 (prepare fused into k_linearize)
 constexpr int SATBA_HDR_FX = 5;  // linearize header: a term of the fixed-point camera sums exceeded its bound (summed over ranks)
 constexpr int SATBA_K_FX = 7;    // ... and its place among the kept scalars (header slot SATBA_HDR_KEEP + 7 after satba_solve)
 constexpr double FX_MAGIC = 6755399441055744.0;
@@ -79,6 +83,14 @@ struct ObsArgs {
                                          // the two constants of the range check
     int* __restrict__ fx_flag;           // set when a term leaves its range (the sums are then formed by k_cam_sums instead)
     const int* gate;                     // SATBA_GATE
+    // k_linearize, single-rank loops: the point part of the prepare phase (x_scale="jac" update, g_h, g_h / scale_inv, and the point
+    // sums of |g_h|^2 and |x_h|^2) is done in the lane that has just formed the point's blocks -- the vector kernel of the prepare
+    // phase then only visits the camera entries (it read V, g, x, scale_inv of 3 N entries again: 43 us at 1 M points).  Null: not fused.
+    double* prep_scale;                  // scale_inv (whole vector, indexed like x)
+    double* prep_gh;                     // g_h
+    double* prep_ghs;                    // g_h / scale_inv
+    const int* prep_first_dev;           // first linearisation of a solve (device-resident loop), else prep_first
+    int prep_first;
 };
 
 // deterministic grid-wide sums: every workgroup writes its partial, the last one to arrive adds them up in index order
@@ -523,7 +535,7 @@ __global__ __launch_bounds__(LinCfg<(ROBUST && !SOFT) || MODEL == RPC>::THREADS)
     ObsArgs a, double2* __restrict__ f, double* __restrict__ V, double* __restrict__ gp, double* __restrict__ part, RedBuf rb,
     double* __restrict__ hdr_cost, double* __restrict__ hdr_gpmax) {
     SATBA_GATE(a.gate);
-    constexpr int CUS = cam_sum_stride(NP), CLS = cam_lo_stride(NP);
+    constexpr int CUS = cam_sum_stride(NP);
     using Cfg = LinCfg<(ROBUST && !SOFT) || MODEL == RPC>;
     constexpr int THREADS = Cfg::THREADS, WAVES = Cfg::WAVES;
     extern __shared__ double s_lin[];
@@ -533,18 +545,15 @@ __global__ __launch_bounds__(LinCfg<(ROBUST && !SOFT) || MODEL == RPC>::THREADS)
     // adds the replicas up.
     const int n_rows = a.M << a.rep_shift;
     unsigned long long bad = 0ull;  // wave mask of the lanes that saw a term outside the fixed-point range (SALU: s_or_b64)
-    int fea[NP], feb = 0, fc1 = 0, fc2 = 0, flo = 0;
-    unsigned* s_lo = reinterpret_cast<unsigned*>(s_acc + (size_t)n_rows * CUS);
+    int fea[NP], feb = 0, fc1 = 0, fc2 = 0;
     if constexpr (CAMSUMS) {
         for (int i = threadIdx.x; i < n_rows * CUS; i += THREADS) s_acc[i] = 0ull;
-        for (int i = threadIdx.x; i < n_rows * CLS; i += THREADS) s_lo[i] = 0u;
         // wave-uniform scalars, read once (left to the compiler they were re-fetched with vector loads in every iteration)
 #pragma unroll
         for (int i = 0; i < NP; ++i) fea[i] = __builtin_amdgcn_readfirstlane(a.fxe[i]);
         feb = __builtin_amdgcn_readfirstlane(a.fxe[NP]);
         fc1 = __builtin_amdgcn_readfirstlane(a.fxe[NP + 1]);
         fc2 = __builtin_amdgcn_readfirstlane(a.fxe[NP + 2]);
-        flo = __builtin_amdgcn_readfirstlane(a.fxe[NP + 3]);
     }
     CamTables<CL, RL> T;
     T.stage(a, s_lin + (CAMSUMS ? cam_sum_bytes(NP, n_rows) / 8 : 0), THREADS);
@@ -552,7 +561,8 @@ __global__ __launch_bounds__(LinCfg<(ROBUST && !SOFT) || MODEL == RPC>::THREADS)
     const int lane = threadIdx.x & 63;
     const bool const_t = lin_const_t(MODEL, NP, ROBUST, a.unit != 0);
 
-    double cost = 0.0, gmax = 0.0;
+    double cost = 0.0, gmax = 0.0, s_gh = 0.0, s_xs = 0.0;
+    const int prep_first = a.prep_first_dev ? *a.prep_first_dev : a.prep_first;
     for_each_slice(a.n_slices << a.sh, WAVES, [&](const int u) {
         const SliceUnit su(a, u, lane);
         const int q = su.q;
@@ -596,7 +606,6 @@ __global__ __launch_bounds__(LinCfg<(ROBUST && !SOFT) || MODEL == RPC>::THREADS)
                     // camera block: fixed-point LDS atomics (ds_add_u64) into this workgroup's table
                     const int row = (cam << a.rep_shift) | (lane & ((1 << a.rep_shift) - 1));
                     unsigned long long* acc = s_acc + (size_t)row * CUS;
-                    unsigned* acc_lo = s_lo + (size_t)row * CLS;
 #pragma unroll
                     for (int i = 0; i < NP; ++i)
                         if (!(const_t && i >= 3)) {
@@ -606,17 +615,16 @@ __global__ __launch_bounds__(LinCfg<(ROBUST && !SOFT) || MODEL == RPC>::THREADS)
                         }
 #pragma unroll
                     for (int i = 0; i < NP; ++i) {
-                        // g_c in two limbs: the integer part of the scaled term (64 bits), and its exact remainder (|rem| <= 1/2) times
-                        // 2^S (32 bits, S <= 20 with n_max 2^(S-1) < 2^31: ds_add_u32 costs half a 64-bit atomic).  The gradient is
-                        // what the minimiser is defined by: its cancellation at the solution happens exactly, in integers, and
-                        // k_lin_finish rounds once, relative to the SUM.  One limb of 46 .. 50 bits left the tight runs 1e-5 from
-                        // the reference along flat directions, where float64 sums in a fixed order reach 1e-7
+                        // g_c in two 64-bit limbs: the integer part of the scaled term, and its exact remainder (|rem| <= 1/2) times
+                        // 2^40.  The gradient is what the minimiser is defined by: its cancellation at the solution happens exactly, in
+                        // integers, and k_lin_finish rounds once, relative to the SUM.  One limb of 46 .. 50 bits left the tight runs
+                        // 1e-5 from the reference along flat directions, where float64 sums in a fixed order reach 1e-7
                         const double ts = ldexp(e.Jc[0][i] * e.fs[0] + e.Jc[1][i] * e.fs[1], fea[i] + feb);
                         const double y = ts + FX_MAGIC;
                         bad |= __ballot((unsigned)(__double2hiint(y) + fc1) >= (unsigned)fc2);
-                        const double y2 = ldexp(ts - (y - FX_MAGIC), flo) + FX_MAGIC;
+                        const double y2 = ldexp(ts - (y - FX_MAGIC), FX_LO_SHIFT) + FX_MAGIC;
                         atomicAdd(acc + NP + i, (unsigned long long)__double_as_longlong(y));
-                        atomicAdd(acc_lo + i, (unsigned)__double2loint(y2));
+                        atomicAdd(acc + 2 * NP + i, (unsigned long long)__double_as_longlong(y2));
                     }
                 }
             }
@@ -637,6 +645,23 @@ __global__ __launch_bounds__(LinCfg<(ROBUST && !SOFT) || MODEL == RPC>::THREADS)
             double* go = gp + 3 * (size_t)q;
             go[0] = v[6]; go[1] = v[7]; go[2] = v[8];
             gmax = fmax(gmax, fmax(fabs(v[6]), fmax(fabs(v[7]), fabs(v[8]))));
+            if (a.prep_scale) {  // scipy:optimize/_lsq/common.py:598-610 for this point's three variables (k_prepare_vec's arithmetic)
+                const size_t ib = (size_t)a.n_c + 3 * (size_t)q;
+                const double dg[3] = {v[0], v[3], v[5]}, xv[3] = {X, Y, Z};
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    double si = sqrt(dg[k]);
+                    if (prep_first) si = (si == 0.0) ? 1.0 : si;
+                    else si = fmax(si, a.prep_scale[ib + k]);
+                    a.prep_scale[ib + k] = si;
+                    const double h = v[6 + k] / si;
+                    a.prep_gh[ib + k] = h;
+                    a.prep_ghs[ib + k] = h / si;
+                    s_gh += h * h;
+                    const double xs = xv[k] * si;
+                    s_xs += xs * xs;
+                }
+            }
         }
     });
     // per-workgroup epilogue
@@ -649,16 +674,14 @@ __global__ __launch_bounds__(LinCfg<(ROBUST && !SOFT) || MODEL == RPC>::THREADS)
         for (int i = threadIdx.x; i < a.M * 3 * NP; i += THREADS) {
             const int cam = i / (3 * NP), k = i % (3 * NP);
             unsigned long long t = 0ull;
-            for (int r = 0; r < (1 << a.rep_shift); ++r) {
-                const size_t row = (size_t)((cam << a.rep_shift) | r);
-                t += k < 2 * NP ? s_acc[row * CUS + k] : (unsigned long long)s_lo[row * CLS + (k - 2 * NP)];  // low limbs: modulo 2^32
-            }
+            for (int r = 0; r < (1 << a.rep_shift); ++r) t += s_acc[(size_t)((cam << a.rep_shift) | r) * CUS + k];
             out[i] = t;  // fixed cameras (unmasked on the unit-weight path) are zeroed by k_lin_finish
         }
     }
-    double cv[1] = {0.5 * cost};
-    double* const dst[1] = {hdr_cost};
-    grid_sum<1>(cv, dst, rb);
+    // cost, and the point sums of the fused prepare part (zero when not fused) in the linearize header
+    double cv[3] = {0.5 * cost, s_gh, s_xs};
+    double* const dst[3] = {hdr_cost, hdr_cost + SATBA_HDR_PREP_GH, hdr_cost + SATBA_HDR_PREP_XS};
+    grid_sum<3>(cv, dst, rb);
 }
 
 // sum the per-workgroup camera partials (diag U_c | g_c per camera; 64-bit fixed point, so any order gives the same bits), take
@@ -694,7 +717,7 @@ __global__ __launch_bounds__(1024) void k_lin_finish(int M, int NP, int nblocks,
     for (int w = 0; w < 16; ++w) { s += s_sum[0][w][lane]; s2 += s_sum[1][w][lane]; }
     const unsigned long long n_obs = (unsigned long long)(cam_ofs[cam + 1] - cam_ofs[cam]);
     double v = (double)(long long)(s - n_obs * FX_MAGIC_BITS);
-    if (k >= NP) v += ldexp((double)(int)(unsigned)s2, -fxe[NP + 3]);  // low limbs: sum modulo 2^32 (the constant's low word is 0)
+    if (k >= NP) v += ldexp((double)(long long)(s2 - n_obs * FX_MAGIC_BITS), -FX_LO_SHIFT);  // one rounding, relative to the sum
     v *= fx[k];
     if (cam < n_cam_fix) v = 0.0;
     if (k >= NP) {
@@ -720,7 +743,7 @@ __global__ __launch_bounds__(1024) void k_lin_finish(int M, int NP, int nblocks,
 // Range of a converted term: |r| < 2^Q with Q = min(50, 62 - ceil(log2 n_max)) (conversion range; the final sum of n_max terms
 // stays inside 63 bits).  Exponents: JB_k 2^a_k < 2^h and FB 2^b < 2^h with h = (Q - 1) / 2 (integer division), so that the U
 // terms, scaled by 2^(2 a_k), and the g terms, scaled by 2^(a_k + b), stay below 2^Q.
-// fxe: a_0 .. a_{NP-1} | b | c1 | c2 | S  -- S: scale exponent of the 32-bit low limbs of g_c; the range check of k_linearize is (hi32(y) + c1) <u c2, i.e. r >> 32 in [-L, L), L = 2^(Q-32);
+// fxe: a_0 .. a_{NP-1} | b | c1 | c2  -- the range check of k_linearize is (hi32(y) + c1) <u c2, i.e. r >> 32 in [-L, L), L = 2^(Q-32);
 // fx:  [2 NP] inverse scales 2^-(2 a_k), 2^-(a_k + b).  The bounds need not be rigorous: every term is checked.
 template <int MODEL, int NP>
 __global__ __launch_bounds__(256) void k_lin_scales(int M, const double* __restrict__ camc, const double* __restrict__ rpc,
@@ -781,7 +804,6 @@ __global__ __launch_bounds__(256) void k_lin_scales(int M, const double* __restr
         const int L = 1 << (Q - 32);
         fxe[NP + 1] = (int)((unsigned)L - 0x43380000u);
         fxe[NP + 2] = 2 * L;
-        fxe[NP + 3] = max(1, min(20, 31 - lg_n));  // S: low limbs of g_c, |sum| <= n_max 2^(S-1) < 2^31
     }
 }
 
@@ -921,7 +943,9 @@ __global__ __launch_bounds__(256) void k_prepare_vec(int n, int n_c, int NP, int
     // ghs = g_h / scale_inv: the unscaled direction of g_h, input of the Jacobian-vector product that follows
     SATBA_GATE(gate);
     if (first_dev) first = *first_dev;  // device-resident loop: the first linearisation of a solve initialises the scaling
-    if (keep[SATBA_K_FX] != 0.0) return;  // the camera sums of this linearisation overflowed their fixed-point range: the caller
+    if (keep[SATBA_K_FX] != 0.0) return;
+    // n == n_c: the point entries were done by k_linearize (ObsArgs::prep_*); their sums wait in keep[2], keep[4] (k_prepare_stash)
+    const bool fused = n == n_c;  // the camera sums of this linearisation overflowed their fixed-point range: the caller
                                           // repeats it with k_cam_sums; the running maximum of scale_inv must not see the garbage
     double s_gh = 0.0, s_xs = 0.0, m_gc = 0.0;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
@@ -952,6 +976,7 @@ __global__ __launch_bounds__(256) void k_prepare_vec(int n, int n_c, int NP, int
     }
     m_gc = wave_max(m_gc);
     if ((threadIdx.x & 63) == 0 && m_gc > 0.0) atomic_max_pos(hdr + 4, lead * m_gc);
+    if (fused && blockIdx.x == 0 && threadIdx.x == 0) { s_gh += keep[2]; s_xs += keep[4]; }
     double v[2] = {s_gh, s_xs};
     double* const dst[2] = {hdr + 1, hdr + 3};
     grid_sum<2>(v, dst, rb);
@@ -1161,6 +1186,7 @@ __global__ __launch_bounds__(1024) void k_prepare_stash(int nU, int n_c, int wor
         for (int r = 0; r < world; ++r) m = fmax(m, xb[hdr_fixed + r]);
         keep[0] = xb[0];
         keep[1] = m;
+        keep[2] = xb[SATBA_HDR_PREP_GH]; keep[4] = xb[SATBA_HDR_PREP_XS];  // (replaced by the totals in the Schur phase)
         keep[SATBA_K_FX] = xb[SATBA_HDR_FX];
     }
     __syncthreads();
