@@ -52,18 +52,18 @@ def make_shard(p, rank, world):
 
 
 def assemble_x(p, shard, x_local, comm):
-    """Global variable vector from per-shard solutions: cameras are identical on all ranks, points are disjoint."""
+    """
+    Global variable vector from per-shard solutions: cameras are identical on all ranks, points are disjoint contiguous ranges, so the
+    point parts are all-gathered (each rank contributes its 3 (p1 - p0) doubles; round 2 all-reduced a zero-padded full-size array).
+    """
     n_c = p.n_cam * p.n_params
     if comm.world == 1:
         return x_local
-    pts = np.zeros(3 * p.n_pts)
-    pts[3 * shard.p0: 3 * shard.p1] = x_local[n_c:]
-    return np.concatenate((x_local[:n_c], comm.sum_array(pts)))
+    return np.concatenate((x_local[:n_c], comm.gather_array(x_local[n_c:])))
 
 
 def assemble_residuals(p, shard, r_local, comm):
+    """Residual vector in the caller's observation order: the shards hold contiguous observation ranges in rank order."""
     if comm.world == 1:
         return r_local
-    r = np.zeros(2 * p.n_obs)
-    r[2 * shard.o0: 2 * shard.o1] = r_local
-    return comm.sum_array(r)
+    return comm.gather_array(r_local)

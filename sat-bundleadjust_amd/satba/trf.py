@@ -73,6 +73,9 @@ class SingleComm:
     def sum_array(self, a):
         return a
 
+    def gather_array(self, a):
+        return a
+
 
 class TorchComm:
     """Sum all-reduce over torch.distributed (backend nccl == RCCL on ROCm, gloo in the CPU tests)."""
@@ -115,6 +118,26 @@ class TorchComm:
         t = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(dev)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
         return t.cpu().numpy()
+
+    def gather_array(self, a):
+        """Concatenation, in rank order, of the host float64 arrays of all ranks (their lengths may differ): one all-gather of the
+        lengths and one of the padded pieces (used to assemble sharded results: every rank moves its own piece, not the whole)."""
+        import torch
+
+        if self.world == 1:
+            return a
+        dev = "cuda" if self.dist.get_backend(self.group) == "nccl" else "cpu"
+        a = np.ascontiguousarray(a, dtype=np.float64).reshape(-1)
+        n = torch.tensor([a.size], dtype=torch.int64, device=dev)
+        sizes = [torch.zeros_like(n) for _ in range(self.world)]
+        self.dist.all_gather(sizes, n, group=self.group)
+        sizes = [int(s.item()) for s in sizes]
+        m = max(sizes)
+        piece = torch.zeros(m, dtype=torch.float64, device=dev)
+        piece[: a.size] = torch.from_numpy(a).to(dev)
+        out = [torch.empty_like(piece) for _ in range(self.world)]
+        self.dist.all_gather(out, piece, group=self.group)
+        return np.concatenate([o[:k].cpu().numpy() for o, k in zip(out, sizes)])
 
 
 class Result(dict):
@@ -301,7 +324,8 @@ def trf_solve(engine, comm=None, ftol=1e-8, xtol=1e-8, gtol=1e-8, max_nfev=None,
     """
     comm = comm or SingleComm()
     if native is None:
-        native = comm.world == 1 and not getattr(comm, "always", False) and verbose < 2 and hasattr(engine, "solve_lm")
+        # (the per-phase counts of `timers` only exist in this Python loop)
+        native = comm.world == 1 and not getattr(comm, "always", False) and verbose < 2 and hasattr(engine, "solve_lm") and timers is None
     if native:
         st = engine.solve_lm(ftol=ftol, xtol=xtol, gtol=gtol, max_nfev=max_nfev, loss=loss, f_scale=f_scale, verbose=0)
         res = Result(cost=st.cost, optimality=st.optimality, nfev=int(st.nfev), njev=int(st.njev), status=int(st.status),

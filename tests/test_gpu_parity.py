@@ -582,6 +582,14 @@ def test_full_size_properties(gpu, shape, loss, sigma_theta):
         # the least-squares floor after the robust solve, at the floor after the L2 solve
         if res.status > 0:
             assert abs(err1.mean() - floor) < 0.05 * floor + 0.01
+        else:
+            # 300 evaluations used up (the pipeline's max_iter; what the reference's scipy would have needed at this size cannot be
+            # run here): the run must at least have left the radius-shrinking phase and be descending -- its robust cost within 50 %
+            # of the value at the least-squares solution the L2 solve finds next -- or the pipeline's second solve starts from rubbish
+            eng.configure("soft_l1", 1.0)
+            _, cost_at_l2 = eng.residuals(with_cost=True)
+            eng.configure("linear", 1.0)
+            assert res.cost < 1.5 * cost_at_l2, (res.cost, cost_at_l2)
         assert res2.status > 0 and abs(err.mean() - floor) < 0.01
     eng.close()
 
