@@ -47,18 +47,20 @@ def profiled_traffic(shape, loss, world):
         return json.load(fh).get("{}:{}".format(shape, loss))
 
 
-def compulsory_bytes(K, N, model, n_params, loss, unit_weights):
+def compulsory_bytes(K, N, model, n_params, loss, unit_weights, fused_prepare):
     """
     HBM bytes k_linearize has to move AS BUILT (csrc/satba_kernels.h), per launch: per observation the camera index (4) and the
     observed pixel (16), the weight (8) unless every weight is 1 and the loss is linear, the Jacobian row scales it stores for the
     later passes (16) on weighted / robust runs, and for RPC cameras the stored Jacobian rows (128 B for 3, 192 B for 6 parameters);
-    per point x (24) in, V (48) and g_p (24) out.  The per-camera sums stay in LDS; the residuals are not stored.
+    per point x (24) in, V (48) and g_p (24) out, and -- single-rank loops, where the point part of the prepare phase rides in this
+    kernel -- scale_inv (24) in, scale_inv, g_h and g_h / scale_inv (72) out.  The per-camera sums stay in LDS; the residuals are not
+    stored.
     """
     unit = unit_weights and loss == "linear"
     per_obs = 20 + (0 if unit else 8 + 16)
     if model == "rpc":
         per_obs += 8 * (16 if 2 * n_params + 6 <= 16 else 24)
-    return float(per_obs) * K + 96.0 * N
+    return float(per_obs) * K + (96.0 + (96.0 if fused_prepare else 0.0)) * N
 
 
 def lm_step(eng, comm, st, trf):
@@ -365,7 +367,7 @@ def main():
         achieved = alg_bytes / t_lin / 1e9
         traffic = profiled_traffic(args.shape, args.loss, world)
         info = eng.info()
-        comp_bytes = compulsory_bytes(K_loc, N_loc, model, p.n_params, args.loss, bool(info["unit_weights"]))
+        comp_bytes = compulsory_bytes(K_loc, N_loc, model, p.n_params, args.loss, bool(info["unit_weights"]), driver.startswith("native"))
         rate_as_built = comp_bytes / t_lin / 1e9
         rate_counter = (traffic / t_lin / 1e9) if traffic else None
         # what bounds the kernel: it moves `compulsory_bytes_as_built` (the counters agree to a few %), and when that rate is below

@@ -25,6 +25,16 @@ t_create = time.perf_counter() - t0
 eng.configure(loss, 1.0)
 out = {"shape": shape, "loss": loss, "env": {k: v for k, v in os.environ.items() if k.startswith("SATBA_")}, "create_s": t_create,
        "info": eng.info()}
+if "--loop" in sys.argv:
+    # LM iterations as a solve runs them (satba_lm_step: k_linearize with the point part of the prepare phase fused in) -- for the PMC
+    # passes that measure the traffic of the kernel as it runs inside the loop
+    eng.snapshot_x(False)
+    for i in range(reps):
+        if i % 3 == 0:
+            eng.snapshot_x(True)
+        eng.lm_step(i % 3 == 0, 1.0, 1e-14)
+    print(json.dumps({"loop_iterations": reps}))
+    sys.exit(0)
 for name in ("linearize", "residual", "jvp", "backsub", "schur", "cholesky"):
     eng.linearize(); eng.prepare(False); eng.schur(1e-6)
     out[name] = round(eng.time_kernel(name, reps if name not in ("schur", "cholesky") else max(2, reps // 4)), 5)
