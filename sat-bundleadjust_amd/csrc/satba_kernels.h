@@ -130,8 +130,8 @@ struct ObsEval {
         double r0, r1, js0 = 1.0, js1 = 1.0;
         if constexpr (ROBUST) {
             const int loss = SOFT ? 1 : a.loss;
-            robust(loss, a.f_scale, ftrue[0], r0, fs[0], js0);
-            robust(loss, a.f_scale, ftrue[1], r1, fs[1], js1);
+            robust(loss, a.f_scale, ftrue[0], r0, fs[0], js0, MODEL != RPC);
+            robust(loss, a.f_scale, ftrue[1], r1, fs[1], js1, MODEL != RPC);
         } else {  // linear loss, specialised at compile time (no transcendental code, far fewer registers)
             fs[0] = ftrue[0]; fs[1] = ftrue[1];
             r0 = ftrue[0] * ftrue[0]; r1 = ftrue[1] * ftrue[1];
@@ -885,8 +885,8 @@ __global__ __launch_bounds__(LINC_THREADS) void k_cam_sums(ObsArgs a, CamMajor c
         double fs0 = ff.x, fs1 = ff.y;
         if (a.loss != 0) {
             double r, js;
-            robust(a.loss, a.f_scale, ff.x, r, fs0, js);
-            robust(a.loss, a.f_scale, ff.y, r, fs1, js);
+            robust(a.loss, a.f_scale, ff.x, r, fs0, js, MODEL != RPC);
+            robust(a.loss, a.f_scale, ff.y, r, fs1, js, MODEL != RPC);
         }
         int k = 0;
 #pragma unroll

@@ -281,7 +281,10 @@ __device__ inline void project(const double* __restrict__ cc, const double* __re
 // Robust loss of one scalar residual, scipy semantics
 // (scipy:optimize/_lsq/least_squares.py:172-227, scipy:optimize/_lsq/common.py:720-731):
 //   rho0 = f_scale^2 rho(z), z = (f / f_scale)^2;  js = sqrt(max(rho' + 2 rho'' z, eps));  fs = f rho' / js
-__device__ inline void robust(int loss, double f_scale, double f, double& rho0, double& fs, double& js) {
+__device__ inline void robust(int loss, double f_scale, double f, double& rho0, double& fs, double& js, bool fast_soft = false) {
+    // no contraction: the kernels that evaluate the loss at the same point (k_linearize, k_residual, k_cam_sums; their host loops
+    // compare the costs) must round the same way whatever they inline this into
+#pragma clang fp contract(off)
     if (loss == 0) {
         rho0 = f * f;
         fs = f;
@@ -292,7 +295,22 @@ __device__ inline void robust(int loss, double f_scale, double f, double& rho0, 
     const double z = q * q;
     double r0, r1, r2;
     if (loss == 1) {  // soft_l1
-        const double t = 1.0 + z, st = sqrt(t);
+        // rho' = t^-1/2 and rho' + 2 rho'' z = t^-1/2 - z t^-3/2 = t^-3/2 with t = 1 + z, so that js = t^-3/4 and
+        // fs = f rho' / js = f t^1/4: two reciprocal square roots (t^-1/2, then (t^1/2)^-1/2) instead of the two square roots and
+        // three divisions of the generic form below -- 8 divisions and 4 square roots per observation were half of the
+        // arithmetic of the soft_l1 linearize kernel.  The generic form takes over where its clamp would act (t^-3/2 < eps).
+        // fast_soft: affine and perspective cameras (every kernel of a model takes the same form).  The RPC chain keeps the generic
+        // form: its tight runs against the 3-point reference stop on 1e-15 tests along a flat direction and moved by 1e-6 with it.
+        const double t = 1.0 + z;
+        if (fast_soft && t < 1.0e10) {
+            const double r = rsqrt(t), st = t * r;  // t^-1/2, t^1/2
+            const double q4 = rsqrt(st);            // t^-1/4
+            rho0 = f_scale * f_scale * (2.0 * (st - 1.0));
+            js = r * q4;
+            fs = f * (st * q4);
+            return;
+        }
+        const double st = sqrt(t);
         r0 = 2.0 * (st - 1.0); r1 = 1.0 / st; r2 = -0.5 / (t * st);
     } else if (loss == 2) {  // huber
         if (z <= 1.0) { r0 = z; r1 = 1.0; r2 = 0.0; }

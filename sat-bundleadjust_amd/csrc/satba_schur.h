@@ -226,10 +226,14 @@ __global__ void k_schur_item_desc(long long n_items, const int2* __restrict__ it
 // Otherwise (weighted / robust): unit-weight Jacobians times the row scales k_linearize stored (a.sc) -- the scales multiply
 // the 2 x 2 middle matrix (4 products instead of 32 on the blocks).  RPC: the stored Jacobian blocks are gathered instead
 // of being recomputed (they carry scales and masks).
+#ifndef SATBA_PAIRS_OCC_U
+#define SATBA_PAIRS_OCC_U 3
+#endif
 template <int MODEL, int NP, bool UNITW>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 3))) void k_schur_pairs(ObsArgs a, SchurArgs s, double* __restrict__ S) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((MODEL == AFFINE && UNITW) ? SATBA_PAIRS_OCC_U : 1, (MODEL == AFFINE && UNITW) ? SATBA_PAIRS_OCC_U : 3))) void k_schur_pairs(ObsArgs a, SchurArgs s, double* __restrict__ S) {
     SATBA_GATE(a.gate);
-    __shared__ double2 s_coop[4 * 64 * 7];  // per wave: 64 records x 80 bytes, or 64 Jacobian rows x 112 (the cooperative gathers are transposed here)
+    __shared__ double2 s_coop[4 * 64 * 7];  // per wave: 64 records x 80 (112: with the scales) bytes, or 64 Jacobian rows x 112 (the cooperative gathers are transposed here)
+    __shared__ unsigned s_idx[4][3 * 64];   // weighted / robust: the three gather indices of a wave's 64 hits
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long long n_pairs = (long long)a.M * (a.M - 1) / 2;
     const SchurItem* dp = s.desc + (blockIdx.x * 4u + (unsigned)wave);
@@ -259,14 +263,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 3))) voi
     if constexpr (MODEL == AFFINE) {
 #pragma unroll
         for (int k = 0; k < 6; ++k) { tri[k] = cci[k]; trj[k] = ccj[k]; }
+        // (wave-uniform values computed by the vector ALU go back to scalar registers: 12 doubles that live through the whole loop)
+        auto uni = [](double x) {
+            return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(x)), __builtin_amdgcn_readfirstlane(__double2loint(x)));
+        };
         auto cam_p = [&](const double* cc, double (&P)[2][3], double (&Au)[3]) {
             const double fx = cc[17], fy = cc[18], sk = cc[19];
             Au[0] = fx; Au[1] = sk; Au[2] = fy;
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
                 const double p0 = fx * cc[6 + k] + sk * cc[9 + k], p1 = fy * cc[9 + k];  // A R
-                if constexpr (UNITW) { P[0][k] = fx * p0; P[1][k] = sk * p0 + fy * p1; }  // A^T (A R)
-                else { P[0][k] = p0; P[1][k] = p1; }
+                if constexpr (UNITW) { P[0][k] = uni(fx * p0); P[1][k] = uni(sk * p0 + fy * p1); }  // A^T (A R)
+                else { P[0][k] = uni(p0); P[1][k] = uni(p1); }
             }
         };
         cam_p(cci, Pi_, Ai_);
@@ -406,31 +414,58 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 3))) voi
             // the lists are streamed once: non-temporal loads keep them from displacing the point records in L2
             auto ld = [&](const int* arr, long long k) { return __builtin_nontemporal_load(arr + (k < last ? k : last)); };
             auto ldp = [&](long long k) { const int v = ld(s.pair_pts, k); return (k < hi) ? v : a.N; };
-            // piece g = 64 t + lane of the 320 pieces (64 records x 5) in load t: record g / 5, piece g % 5
-            struct Coop { double2 c0, c1, c2, c3, c4; };
-            int rsrc[5];
-            const double2* psrc[5];
+            // piece g = 64 t + lane of the 64 NPC pieces (64 records x NPC) in load t: record g / NPC, piece g % NPC.
+            // Weighted / robust (SCL): NPC = 7 -- pieces 5 and 6 of a "record" are the row scales of the hit's two observations
+            // (a.sc, io order: a track's scales are contiguous, so the two usually share a line).  Gathered with lane = hit they were
+            // two more instructions of 64 lines each per iteration; dealt to the lanes with the record pieces an instruction
+            // touches ~9 records x 2 lines.
+            constexpr int NPC = SCL ? 7 : 5;
+            struct Coop { double2 c0, c1, c2, c3, c4, c5, c6; };  // (named members: an array here ends up in scratch)
+            int rsrc[NPC];
+            const double2* psrc[NPC];
+            int kind[NPC];  // LDS slot of the index that addresses the piece: 64 x (0 record, 1 / 2 scale of observation i / j) + source lane
 #pragma unroll
-            for (int t = 0; t < 5; ++t) { rsrc[t] = (64 * t + lane) / 5; psrc[t] = s.PV + (64 * t + lane) % 5; }
-            auto coop_load = [&](int p) {
+            for (int t = 0; t < NPC; ++t) {
+                const int g = 64 * t + lane, pc = g % NPC;
+                rsrc[t] = g / NPC;
+                kind[t] = 64 * (pc < 5 ? 0 : pc - 4) + g / NPC;
+                psrc[t] = pc < 5 ? s.PV + pc : reinterpret_cast<const double2*>(a.sc);
+            }
+            unsigned* sidx = s_idx[wave];
+            auto coop_load = [&](int p, int pi, int pj) {
                 Coop o;
-                o.c0 = psrc[0][(PV_STRIDE / 2) * (size_t)__shfl(p, rsrc[0])];
-                o.c1 = psrc[1][(PV_STRIDE / 2) * (size_t)__shfl(p, rsrc[1])];
-                o.c2 = psrc[2][(PV_STRIDE / 2) * (size_t)__shfl(p, rsrc[2])];
-                o.c3 = psrc[3][(PV_STRIDE / 2) * (size_t)__shfl(p, rsrc[3])];
-                o.c4 = psrc[4][(PV_STRIDE / 2) * (size_t)__shfl(p, rsrc[4])];
+                if constexpr (SCL) {
+                    // the three indices of every hit go through LDS (one bpermute per piece would need all three per source lane)
+                    asm volatile("" ::: "memory");
+                    sidx[lane] = (unsigned)p * (unsigned)(PV_STRIDE / 2); sidx[64 + lane] = (unsigned)pi; sidx[128 + lane] = (unsigned)pj;
+                    asm volatile("" ::: "memory");
+                    __builtin_amdgcn_wave_barrier();
+                    const unsigned o0 = sidx[kind[0]], o1 = sidx[kind[1]], o2 = sidx[kind[2]], o3 = sidx[kind[3]], o4 = sidx[kind[4]],
+                                   o5 = sidx[kind[NPC - 2]], o6 = sidx[kind[NPC - 1]];
+                    asm volatile("" ::: "memory");
+                    __builtin_amdgcn_wave_barrier();
+                    o.c0 = psrc[0][o0]; o.c1 = psrc[1][o1]; o.c2 = psrc[2][o2]; o.c3 = psrc[3][o3]; o.c4 = psrc[4][o4];
+                    o.c5 = psrc[NPC - 2][o5]; o.c6 = psrc[NPC - 1][o6];
+                } else {
+#define SATBA_CL(t) psrc[t][(PV_STRIDE / 2) * (size_t)__shfl(p, rsrc[t])]
+                    o.c0 = SATBA_CL(0); o.c1 = SATBA_CL(1); o.c2 = SATBA_CL(2); o.c3 = SATBA_CL(3); o.c4 = SATBA_CL(4);
+#undef SATBA_CL
+                }
                 return o;
             };
             char* my = reinterpret_cast<char*>(s_coop) + wave * (64 * 112);
-            double2* wr = reinterpret_cast<double2*>(my) + lane;  // piece g at 16 g bytes: record stride 80
-            const double2* mine = reinterpret_cast<const double2*>(my + lane * 80);
+            double2* wr = reinterpret_cast<double2*>(my) + lane;  // piece g at 16 g bytes: record stride 16 NPC bytes
+            const double2* mine = reinterpret_cast<const double2*>(my + lane * (16 * NPC));
+            double2 si_cur = make_double2(1.0, 1.0), sj_cur = si_cur;
             auto transpose = [&](const Coop& o) {
                 Rec r;
                 asm volatile("" ::: "memory");
                 wr[0] = o.c0; wr[64] = o.c1; wr[128] = o.c2; wr[192] = o.c3; wr[256] = o.c4;
+                if constexpr (SCL) { wr[320] = o.c5; wr[384] = o.c6; }
                 asm volatile("" ::: "memory");
                 __builtin_amdgcn_wave_barrier();
                 r.r0 = mine[0]; r.r1 = mine[1]; r.r2 = mine[2]; r.r3 = mine[3]; r.r4 = mine[4].x;
+                if constexpr (SCL) { si_cur = mine[5]; sj_cur = mine[6]; }
                 asm volatile("" ::: "memory");
                 __builtin_amdgcn_wave_barrier();
                 return r;
@@ -475,28 +510,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 3))) voi
             long long idx = lo + lane;
             int p_nxt = ldp(idx + 64);
             int pi_cur = 0, pj_cur = 0, pi_nxt = 0, pj_nxt = 0;
-            double2 si_cur = make_double2(1.0, 1.0), sj_cur = si_cur;
             if constexpr (POS) {
                 pi_cur = ld(s.pair_pi, idx); pj_cur = ld(s.pair_pj, idx);
                 pi_nxt = ld(s.pair_pi, idx + 64); pj_nxt = ld(s.pair_pj, idx + 64);
-                if constexpr (SCL) { si_cur = a.sc[pi_cur]; sj_cur = a.sc[pj_cur]; }
             }
-            Coop c_cur = coop_load(ldp(idx));
+            Coop c_cur = coop_load(ldp(idx), pi_cur, pj_cur);
             JCoop ji_cur, jj_cur;
             if constexpr (JROWS) { ji_cur = jcoop_load(pi_cur); jj_cur = jcoop_load(pj_cur); }
             for (int it = 0; it < n_it; ++it) {
-                const Rec r_cur = transpose(c_cur);  // first: its wait covers only loads of the previous iteration
+                const Rec r_cur = transpose(c_cur);  // first: its wait covers only loads of the previous iteration (sets si_cur, sj_cur)
                 JRow ti, tj;
                 if constexpr (JROWS) { ti = jtranspose(ji_cur); tj = jtranspose(jj_cur); }
                 // indices run two iterations ahead, records one: neither latency is on the critical path
                 const int p_nn = ldp(idx + 128);
                 int pi_nn = 0, pj_nn = 0;
-                double2 si_nxt = make_double2(1.0, 1.0), sj_nxt = si_nxt;
-                if constexpr (POS) {
-                    pi_nn = ld(s.pair_pi, idx + 128); pj_nn = ld(s.pair_pj, idx + 128);
-                    if constexpr (SCL) { si_nxt = a.sc[pi_nxt]; sj_nxt = a.sc[pj_nxt]; }
-                }
-                const Coop c_nxt = coop_load(p_nxt);
+                if constexpr (POS) { pi_nn = ld(s.pair_pi, idx + 128); pj_nn = ld(s.pair_pj, idx + 128); }
+                const Coop c_nxt = coop_load(p_nxt, pi_nxt, pj_nxt);
                 JCoop ji_nxt, jj_nxt;
                 if constexpr (JROWS) { ji_nxt = jcoop_load(pi_nxt); jj_nxt = jcoop_load(pj_nxt); }
                 // keep the gathers above the arithmetic: without the barrier the scheduler sinks them below compute() to
@@ -507,7 +536,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 3))) voi
                 p_nxt = p_nn; c_cur = c_nxt;
                 if constexpr (JROWS) { ji_cur = ji_nxt; jj_cur = jj_nxt; }
                 pi_cur = pi_nxt; pj_cur = pj_nxt; pi_nxt = pi_nn; pj_nxt = pj_nn;
-                si_cur = si_nxt; sj_cur = sj_nxt;
                 idx += 64;
             }
         }
