@@ -676,6 +676,32 @@ __global__ __launch_bounds__(512) void k_trsv_back_mw(const double* __restrict__
     if (tid == 0) __hip_atomic_store(flag + k, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// L^T z = y for n <= 64, one wave, straight from the factor's lower triangle (no mirror, no block inverses): lane c holds column c
+// of L below the diagonal in registers (= row c of L^T) and its running right-hand side; step k (bottom up) broadcasts z_k and
+// every lane in front of it takes its term off.  Few cameras are the common case of the reference's pipelines (2 .. 20 images x 3
+// parameters); at 10 x 5 the mirror + inverses kernel and the multi-workgroup back-substitution were 19 us of a 165 us iteration,
+// this is 5.  (Tried with it: the factorisation in the same single wave, lane = row -- 38 us against 21 + 5 for k_chol_dstep's
+// four-wave diagonal blocks plus this kernel: dropped.)
+constexpr int CH_SMALL = 64;
+__global__ __launch_bounds__(64) void k_trsv_back_small(const double* __restrict__ L, int n, double* __restrict__ b, const int* gate) {
+    SATBA_GATE(gate);
+    const int c = threadIdx.x;
+    const int cc = min(c, n - 1);
+    double t[CH_SMALL];
+#pragma unroll
+    for (int k = 0; k < CH_SMALL; ++k) t[k] = (k < n && k > c) ? L[(size_t)k + (size_t)cc * n] : 0.0;
+    const double inv = 1.0 / L[(size_t)cc + (size_t)cc * n];
+    double y = (c < n) ? b[c] : 0.0;
+#pragma unroll
+    for (int k = CH_SMALL - 1; k >= 0; --k) {
+        if (k < n) {  // (uniform)
+            const double zk = readlane_f64(y * inv, k);
+            y = (c == k) ? zk : fma(-t[k], zk, y);  // t[k] is zero at and behind the diagonal (lanes >= k)
+        }
+    }
+    if (c < n) b[c] = y;
+}
+
 }  // namespace satba
 #include "satba_chol2.h"
 namespace satba {
@@ -721,7 +747,9 @@ inline void cholesky_solve(double* A, int n, double* b, int* fail, int* flags, i
     }
     if (n <= 1024) {
         const int T = (n + 31) / 32;
-        if (dinv) {
+        if (dinv && n <= CH_SMALL && mode == 0 && !getenv("SATBA_NO_SMALL_TRSV")) {
+            hipLaunchKernelGGL(k_trsv_back_small, dim3(1), dim3(64), 0, stream, A, n, b, gate);
+        } else if (dinv) {
             hipLaunchKernelGGL(k_chol_finish, dim3(T * (T + 1) / 2 + T), dim3(256), 0, stream, A, n, T * (T + 1) / 2, dinv, gate);
             if (mode == 5) hipLaunchKernelGGL(k_trsv_back_dinv, dim3(1), dim3(1024), 0, stream, A, dinv, n, b);  // one workgroup
             else hipLaunchKernelGGL(k_trsv_back_mw, dim3((n + CH_SB - 1) / CH_SB), dim3(512), 0, stream, A, dinv, n, b, flags + CH_TRSV_FLAGS, gate);
