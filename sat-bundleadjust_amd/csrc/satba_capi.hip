@@ -503,7 +503,7 @@ static int launch_jvp(satba_problem* p, int nv, const double* q1, const double* 
 // S z = rhs for the reduced system (S column-major lower, destroyed; b in place)
 static int dense_solve(satba_problem* p, double* S, double* b, bool cleared = false) {
     cholesky_solve(S, p->n_c, b, p->d_fail, p->d_fail + 1, p->chol_mode == 3 ? 0 : p->chol_mode, p->stream, nullptr,
-                   p->chol_mode == 3 ? nullptr : p->d_dinv, cleared, getenv("SATBA_NOGATE_CHOL") ? nullptr : p->gate);  // clears d_fail and the step flags unless the caller has
+                   p->chol_mode == 3 ? nullptr : p->d_dinv, cleared, p->gate);  // clears d_fail and the step flags unless the caller has
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -588,8 +588,8 @@ static int schur_item_table(satba_problem* p) {
     // MEASURED (200 x 1 M x 10 M, profiles/r3_overlap.txt): the overlap works -- and loses.  Next to the pair kernel's gather traffic
     // a double step takes 32.5 us instead of 23.7 (the chain is bound by memory latency, which goes up under load), the pair kernel
     // in three launches takes 507 us instead of 394 (three tails, and the factorisation's workgroups in its way), the two catch-ups
-    // add 63 us: 1.55 ms per iteration against 1.47.  A high-priority stream or CUs reserved for the factorisation
-    // (SATBA_OVERLAP_CUS) change nothing.  The path is kept behind SATBA_OVERLAP=1 (tests/test_gpu_layout.py runs it).
+    // add 63 us: 1.55 ms per iteration against 1.47.  A lowest-priority stream or every fourth CU reserved for the factorisation
+    // (hipExtStreamCreateWithCUMask) changed nothing (switches removed).  The path is kept behind SATBA_OVERLAP=1 (tests/test_gpu_layout.py runs it).
     if (getenv("SATBA_OVERLAP") && p->world == 1 && p->n_c >= 512 && p->L.n_pairs > 0 && p->L.E > 0 && p->chol_mode == 0 && p->n_c <= 1024) {
         const int q = ((p->n_c / 4 + 32) / 64) * 64;
         const int ends[3] = {q, 2 * q, p->n_c};
@@ -604,15 +604,7 @@ static int schur_item_table(satba_problem* p) {
             // whatever is left of the chip
             int pr_least = 0, pr_greatest = 0;
             HIP_TRY(hipDeviceGetStreamPriorityRange(&pr_least, &pr_greatest));
-            if (const char* cm = getenv("SATBA_OVERLAP_CUS")) {
-                // experiment: the factorisation gets every k-th CU for itself (the handle's stream keeps all of them)
-                const int k = std::max(2, atoi(cm));
-                uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-                for (int cu = 0; cu < 256; cu += k) mask[cu / 32] |= 1u << (cu % 32);
-                HIP_TRY(hipExtStreamCreateWithCUMask(&p->stream2, 8, mask));
-            } else {
-                HIP_TRY(hipStreamCreateWithPriority(&p->stream2, hipStreamNonBlocking, getenv("SATBA_OVERLAP_NOPRIO") ? pr_least : pr_greatest));
-            }
+            HIP_TRY(hipStreamCreateWithPriority(&p->stream2, hipStreamNonBlocking, pr_greatest));
         }
         const bool merged_ok = p->d_item_desc_merged != nullptr;
         for (int s = 0; s < 3; ++s) {
@@ -1521,7 +1513,7 @@ static int lm_queue_tick(satba_problem* p, double lam_floor) {
     // launches on the stream leave none, and ~30 us in front of every replay; the host is never the bottleneck here (it queues
     // LM_RUN_AHEAD ticks ahead).  10 x 5 k x 30 k: 6 317 it/s with the graph, 6 312 without; 200 x 1 M x 10 M: 681 / 685.  The graph is
     // therefore opt-in (SATBA_GRAPH=1).
-    static const bool use_graph = getenv("SATBA_GRAPH") != nullptr && !getenv("SATBA_NO_GRAPH");
+    static const bool use_graph = getenv("SATBA_GRAPH") != nullptr;
     const bool direct = !use_graph || p->lm_no_graph || p->prof_lin || (p->loss == 0 && !p->fxcost_valid);  // (the cost-only pass of a first linearisation is not part of the pattern)
     if (direct) {
         TRY(lm_launch_tick(p, lam_floor));

@@ -747,7 +747,7 @@ inline void cholesky_solve(double* A, int n, double* b, int* fail, int* flags, i
     }
     if (n <= 1024) {
         const int T = (n + 31) / 32;
-        if (dinv && n <= CH_SMALL && mode == 0 && !getenv("SATBA_NO_SMALL_TRSV")) {
+        if (dinv && n <= CH_SMALL && mode == 0) {
             hipLaunchKernelGGL(k_trsv_back_small, dim3(1), dim3(64), 0, stream, A, n, b, gate);
         } else if (dinv) {
             hipLaunchKernelGGL(k_chol_finish, dim3(T * (T + 1) / 2 + T), dim3(256), 0, stream, A, n, T * (T + 1) / 2, dinv, gate);

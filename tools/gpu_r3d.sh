@@ -6,7 +6,7 @@ timeout 900 python -m pytest tests/test_gpu_layout.py -m gpu -x -q > $out/pytest
 tail -12 $out/pytest_layout.log
 timeout 1200 python -m pytest tests/test_gpu_parity.py -m gpu -q -x > $out/pytest_parity.log 2>&1
 tail -6 $out/pytest_parity.log
-BENCH_ARGS="" bash tools/gpu_ab.sh $tag - SATBA_NO_GRAPH=1 SATBA_HOST_LOOP=1
+BENCH_ARGS="" bash tools/gpu_ab.sh $tag - SATBA_HOST_LOOP=1
 python bench.py --cpu-sample-pts 0 --driver native-sync --steps 80 --warmup 8 > $out/sync.json 2>>$out/ab.err; python -c "
 import json; d=json.load(open('$out/sync.json')); print('native-sync', round(d['value'],1), d['final_cost'], d['accepted_steps'])"
 for s in C2 C3 C5; do for drv in native native-sync; do python bench.py --shape $s --cpu-sample-pts 0 --driver $drv > $out/bench_${s}_$drv.json 2>> $out/ab.err; python -c "
