@@ -188,8 +188,9 @@ def main():
     ap.add_argument("--restart-every", type=int, default=-1,
                     help="iterations per solve before the point returns to x0 (-1: 3 for the linear loss on one rank, else 0 = never)")
     ap.add_argument("--sigma-theta", type=float, default=1e-4, help="initial camera angle error [rad]")
-    ap.add_argument("--cpu-sample-pts", type=int, default=20000,
-                    help="points of the CPU-baseline sub-problem (0 = skip); 20000 points = 200 k observations, ~20 s")
+    ap.add_argument("--cpu-sample-pts", type=int, default=12000,
+                    help="points of the CPU-baseline sub-problem (0 = skip); 12000 points = 120 k observations, ~25 s on the GPU box's host "
+                         "(20000 points took 45 s there)")
     ap.add_argument("--kernel-reps", type=int, default=20)
     ap.add_argument("--loss", default="linear", help="linear (headline) | soft_l1 | huber | cauchy | arctan")
     ap.add_argument("--driver", default="auto", help="host side of an LM iteration: native (device-resident loop, satba_lm_ticks; one rank) | "
