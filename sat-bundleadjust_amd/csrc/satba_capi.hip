@@ -127,7 +127,7 @@ struct satba_problem {
     hipStream_t stream2 = nullptr;
     hipEvent_t ev_done = nullptr;
 
-    int lin_grid = 0, cm_chunks = 1;
+    int lin_grid = 0, cm_chunks = 1, cm_chunks_w = 1;  // chunks of the camera-major passes (unit weights and k_cam_sums | weighted / robust k_schur_diag)
     double* d_red = nullptr;  // RED_SLOTS x (RED_MAX_NV x RED_MAX_GRID doubles) partials of the deterministic grid sums
     unsigned* d_red_cnt = nullptr;
     double* d_stage = nullptr;  // staging for host transfers in the caller's order
@@ -410,7 +410,9 @@ static int launch_schur(satba_problem* p, const ObsArgs& a, double* S, double* r
     SchurArgs s = schur_args(p);
     const long long n_pairs = p->L.n_pairs;
     // diagonal blocks (with J_c^T J_c) and right-hand side
-    hipLaunchKernelGGL((k_schur_diag<MODEL, NP>), dim3(p->M, p->cm_chunks), dim3(LINC_THREADS), 0, p->stream, a, cm, s, p->d_part3);
+    const int dchunks = (a.sc && MODEL != RPC) ? p->cm_chunks_w : p->cm_chunks;
+    s.diag_xcd = (dchunks % 8 == 0 && !getenv("SATBA_NO_DIAG_XCD")) ? 1 : 0;
+    hipLaunchKernelGGL((k_schur_diag<MODEL, NP>), dim3(p->M, dchunks), dim3(LINC_THREADS), 0, p->stream, a, cm, s, p->d_part3);
     if (n_pairs > 0 && p->L.E > 0) {
         const bool merged = a.unit && p->d_item_desc_merged;  // one item per pair: straight into S, no partials
         if (merged) { s.desc = p->d_item_desc_merged; s.items = p->d_items_merged; s.n_chunks = 1; }
@@ -425,7 +427,7 @@ static int launch_schur(satba_problem* p, const ObsArgs& a, double* S, double* r
         }
     }
     const int total = p->M * cam_acc_len(NP);
-    hipLaunchKernelGGL(k_schur_diag_finish, dim3((total + 255) / 256), dim3(256), 0, p->stream, p->M, NP, p->n_c, p->cm_chunks, p->d_part3, S, rhs, p->gate);
+    hipLaunchKernelGGL(k_schur_diag_finish, dim3((total + 255) / 256), dim3(256), 0, p->stream, p->M, NP, p->n_c, dchunks, p->d_part3, S, rhs, p->gate);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -435,9 +437,11 @@ template <int MODEL, int NP>
 static int launch_schur_segments(satba_problem* p, const ObsArgs& a, double* S, double* rhs) {
     CamMajor cm = cam_major(p);
     SchurArgs s0 = schur_args(p);
-    hipLaunchKernelGGL((k_schur_diag<MODEL, NP>), dim3(p->M, p->cm_chunks), dim3(LINC_THREADS), 0, p->stream, a, cm, s0, p->d_part3);
+    const int dchunks = (a.sc && MODEL != RPC) ? p->cm_chunks_w : p->cm_chunks;
+    s0.diag_xcd = (dchunks % 8 == 0 && !getenv("SATBA_NO_DIAG_XCD")) ? 1 : 0;
+    hipLaunchKernelGGL((k_schur_diag<MODEL, NP>), dim3(p->M, dchunks), dim3(LINC_THREADS), 0, p->stream, a, cm, s0, p->d_part3);
     const int total = p->M * cam_acc_len(NP);
-    hipLaunchKernelGGL(k_schur_diag_finish, dim3((total + 255) / 256), dim3(256), 0, p->stream, p->M, NP, p->n_c, p->cm_chunks, p->d_part3, S, rhs, p->gate);
+    hipLaunchKernelGGL(k_schur_diag_finish, dim3((total + 255) / 256), dim3(256), 0, p->stream, p->M, NP, p->n_c, dchunks, p->d_part3, S, rhs, p->gate);
     HIP_TRY(hipGetLastError());
     const bool merged = a.unit && p->d_seg_desc[1][0];
     for (int sg = 0; sg < p->ov.n_seg; ++sg) {
@@ -902,9 +906,18 @@ int satba_problem_create(const satba_problem_desc* d, satba_problem** out) {
             int chunks = (2048 + p->M - 1) / p->M;
             if (chunks > 64) chunks = 64;
             while (chunks > 1 && K / ((long long)p->M * chunks) < 512) --chunks;  // keep >= ~2 obs per thread
-            if (const char* dc = getenv("SATBA_CM_CHUNKS")) chunks = std::max(1, std::min(256, atoi(dc)));  // experiments
-            p->cm_chunks = chunks;
-            TRY(dev_alloc(p, &p->d_part3, (size_t)p->M * chunks * cam_acc_len(p->NP)));
+            // From 8 chunks on they are dealt to the XCDs (k_schur_diag: s.diag_xcd), in multiples of 8; the weighted / robust pass, which
+            // is bound by its memory traffic (record + scale line per entry), takes twice as many (200 x 1M x 10M: unit weights 134 us
+            // with 11 chunks, 125 with 16 dealt; soft_l1 288 with 11, 239 / 217 / 210 / 252 with 16 / 32 / 40 / 64 dealt)
+            int chunks_w = chunks;
+            if (chunks >= 8) {
+                chunks = (chunks + 7) / 8 * 8;
+                chunks_w = std::min(64, 2 * chunks);
+                while (chunks_w > chunks && K / ((long long)p->M * chunks_w) < 512) chunks_w -= 8;
+            }
+            if (const char* dc = getenv("SATBA_CM_CHUNKS")) chunks_w = chunks = std::max(1, std::min(256, atoi(dc)));  // experiments, tests
+            p->cm_chunks = chunks; p->cm_chunks_w = chunks_w;
+            TRY(dev_alloc(p, &p->d_part3, (size_t)p->M * std::max(chunks, chunks_w) * cam_acc_len(p->NP)));
         }
         if (p->L.C > 1) TRY(dev_alloc(p, &p->d_pair_part, (size_t)p->L.C * std::max<long long>(p->L.n_pairs, 1) * p->NP * p->NP));
         TRY(schur_item_table(p));

@@ -166,6 +166,7 @@ struct SchurArgs {
     const int2* __restrict__ items;          // work items in dispatch order: (pair, chunk), pair < 0: padding
     const struct SchurItem* __restrict__ desc;  // the same items with everything a wave needs to start (k_schur_item_desc)
     int n_chunks;
+    int diag_xcd = 0;                        // k_schur_diag: chunks dealt to the XCDs (see there)
 };
 
 // Wave "reduce-scatter": N (power of two) values per lane are summed over the 64 lanes with N - 1 + (6 - log2 N)
@@ -588,7 +589,15 @@ template <int MODEL, int NP>
 __global__ __launch_bounds__(LINC_THREADS) void k_schur_diag(ObsArgs a, CamMajor c, SchurArgs s, double* __restrict__ part) {
     SATBA_GATE(a.gate);
     constexpr int CU = cam_acc_len(NP);
-    const int cam = blockIdx.x, chunk = blockIdx.y, n_chunks = gridDim.y;
+    // s.diag_xcd (chunk count a multiple of 8): workgroup L = y M + x of the launch runs on XCD L % 8 (observed placement); XCD x takes
+    // the chunks = x (mod 8), every camera's slice of one chunk in a row, so that the records (and, weighted runs, the scale lines)
+    // of a point range are fetched by ONE XCD instead of by the ~6 that hold one of the point's cameras
+    int cam = blockIdx.x, chunk = blockIdx.y;
+    const int n_chunks = gridDim.y;
+    if (s.diag_xcd) {
+        const int L = blockIdx.y * gridDim.x + blockIdx.x, x = L & 7, q = L >> 3, M = gridDim.x;
+        cam = q % M; chunk = (q / M) * 8 + x;
+    }
     const int b = c.cam_ofs[cam], e = c.cam_ofs[cam + 1];
     const long long len = e - b;
     const int lo = b + (int)(len * chunk / n_chunks), hi = b + (int)(len * (chunk + 1) / n_chunks);
