@@ -463,7 +463,7 @@ __global__ __launch_bounds__(RES_THREADS) void k_residual(ObsArgs a, double2* __
         // software pipeline: the records of the next two slots are in flight during the arithmetic of the current one
         ObsRec r[SATBA_PF + 1];
 #pragma unroll
-        for (int j = 0; j < SATBA_PF; ++j) r[j].load<UNITW>(a, pos + su.step * j, su.slot(j) < cnt);
+        for (int j = 0; j < SATBA_PF; ++j) r[j].template load<UNITW>(a, pos + su.step * j, su.slot(j) < cnt);
         for (int tt = 0; tt < su.nt; ++tt, pos += su.step) {
             const int k = su.slot(tt);
             r[SATBA_PF].load<UNITW>(a, pos + su.step * SATBA_PF, su.slot(tt + SATBA_PF) < cnt);
@@ -578,18 +578,23 @@ __global__ __launch_bounds__(LinCfg<(ROBUST && !SOFT) || MODEL == RPC>::THREADS)
         int pos = su.pos;
         const int io0 = has ? a.ipt_ofs[q] : 0;
         // software pipeline: the records of the next two slots are in flight during the arithmetic and the LDS atomics of this one
-        ObsRec r[SATBA_PF + 1];
+        // (one slot for the robust variants: with two the soft_l1 kernel spilled 13 registers at its 128-VGPR limit)
+        constexpr int PF = ROBUST ? 1 : SATBA_PF;
+        ObsRec r[PF + 1];
 #pragma unroll
-        for (int j = 0; j < SATBA_PF; ++j) r[j].load<UNITW>(a, pos + su.step * j, su.slot(j) < cnt);
+        for (int j = 0; j < PF; ++j) r[j].template load<UNITW>(a, pos + su.step * j, su.slot(j) < cnt);
         for (int tt = 0; tt < su.nt; ++tt, pos += su.step) {
             const int k = su.slot(tt);
-            r[SATBA_PF].load<UNITW>(a, pos + su.step * SATBA_PF, su.slot(tt + SATBA_PF) < cnt);
+            r[PF].template load<UNITW>(a, pos + su.step * PF, su.slot(tt + PF) < cnt);
             __builtin_amdgcn_sched_barrier(0);
             if (k < cnt) {
                 const int cam = r[0].cam;
                 ObsEval<MODEL, NP, true, ROBUST, SOFT, UNITW> e;
                 e.eval(a, cam, mp, T.cc(cam), T.tab(cam), r[0].ob, r[0].w, X, Y, Z);
                 if constexpr (MODEL == RPC) e.store_jac(a, io0 + k);
+                // (this strided 16-byte store is 68 us of the weighted / robust kernel's 250 at 200 x 1M x 10M -- measured by leaving it
+                // out; non-temporal: 439 us; whole 32-byte sectors from two buffered slots: 243 us.  The io order is what the Schur
+                // kernels' gathers need, section 3 of DESIGN.md)
                 if (a.sc) a.sc[io0 + k] = make_double2(e.sw[0], e.sw[1]);
                 if (f) f[pos] = make_double2(e.ftrue[0], e.ftrue[1]);  // only the camera-major pass reads it (k_cam_sums)
                 cost += e.rho;
@@ -629,7 +634,7 @@ __global__ __launch_bounds__(LinCfg<(ROBUST && !SOFT) || MODEL == RPC>::THREADS)
                 }
             }
 #pragma unroll
-            for (int j = 0; j < SATBA_PF; ++j) r[j] = r[j + 1];
+            for (int j = 0; j < PF; ++j) r[j] = r[j + 1];
         }
         if (su.sh) {  // several lanes per point: their sums are combined, the lane of slot 0 stores
 #pragma unroll
