@@ -427,7 +427,7 @@ static int launch_schur(satba_problem* p, const ObsArgs& a, double* S, double* r
         }
     }
     const int total = p->M * cam_acc_len(NP);
-    hipLaunchKernelGGL(k_schur_diag_finish, dim3((total + 255) / 256), dim3(256), 0, p->stream, p->M, NP, p->n_c, dchunks, p->d_part3, S, rhs, p->gate);
+    hipLaunchKernelGGL(k_schur_diag_finish, dim3((8 * total + 255) / 256), dim3(256), 0, p->stream, p->M, NP, p->n_c, dchunks, p->d_part3, S, rhs, p->gate);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -441,7 +441,7 @@ static int launch_schur_segments(satba_problem* p, const ObsArgs& a, double* S, 
     s0.diag_xcd = (dchunks % 8 == 0 && !getenv("SATBA_NO_DIAG_XCD")) ? 1 : 0;
     hipLaunchKernelGGL((k_schur_diag<MODEL, NP>), dim3(p->M, dchunks), dim3(LINC_THREADS), 0, p->stream, a, cm, s0, p->d_part3);
     const int total = p->M * cam_acc_len(NP);
-    hipLaunchKernelGGL(k_schur_diag_finish, dim3((total + 255) / 256), dim3(256), 0, p->stream, p->M, NP, p->n_c, dchunks, p->d_part3, S, rhs, p->gate);
+    hipLaunchKernelGGL(k_schur_diag_finish, dim3((8 * total + 255) / 256), dim3(256), 0, p->stream, p->M, NP, p->n_c, dchunks, p->d_part3, S, rhs, p->gate);
     HIP_TRY(hipGetLastError());
     const bool merged = a.unit && p->d_seg_desc[1][0];
     for (int sg = 0; sg < p->ov.n_seg; ++sg) {

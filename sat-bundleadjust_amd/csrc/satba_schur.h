@@ -800,16 +800,22 @@ __global__ __launch_bounds__(LINC_THREADS) void k_schur_diag(ObsArgs a, CamMajor
     }
 }
 
-// S_ii (lower incl. diagonal, both triangles of the block are written) and rhs_i += chunk partials
+// S_ii (lower incl. diagonal, both triangles of the block are written) and rhs_i += chunk partials.  Eight threads per output, each
+// over every eighth chunk, combined in a fixed order (up to 64 chunks: a single thread's dependent loads were 18 us with 32 chunks)
 __global__ void k_schur_diag_finish(int M, int NP, int n_c, int n_chunks, const double* __restrict__ part,
                                     double* __restrict__ S, double* __restrict__ rhs, const int* gate) {
     SATBA_GATE(gate);
     const int CU = cam_acc_len(NP);
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= M * CU) return;
-    const int cam = idx / CU, k = idx % CU;
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x, idx = gid >> 3, sub = gid & 7;
+    const bool live = idx < M * CU;
+    const int cam = live ? idx / CU : 0, k = live ? idx % CU : 0;
     double t = 0.0;
-    for (int ch = 0; ch < n_chunks; ++ch) t += part[((size_t)cam * n_chunks + ch) * CU + k];
+    if (live)
+        for (int ch = sub; ch < n_chunks; ch += 8) t += part[((size_t)cam * n_chunks + ch) * CU + k];
+    t += __shfl_xor(t, 1);
+    t += __shfl_xor(t, 2);
+    t += __shfl_xor(t, 4);
+    if (!live || sub != 0) return;
     const int ntri = NP * (NP + 1) / 2;
     if (k >= ntri) {
         rhs[cam * NP + (k - ntri)] += t;
