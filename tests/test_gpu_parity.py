@@ -285,7 +285,9 @@ def test_schur_matrix_and_rhs(gpu, monkeypatch, chunks):
 # backward substitution, k_trsv_back)
 # mode (SATBA_CHOL): 0 two panels per launch where they fit (default), 2 single steps, 5 like 0 with the one-workgroup back-substitution
 @pytest.mark.parametrize("mode", ["0", "2", "5"])
-@pytest.mark.parametrize("n_cam,n_p", [(3, 3), (13, 5), (60, 5), (200, 5), (150, 6), (64, 3), (32, 3), (43, 3), (11, 6), (26, 5), (54, 3), (260, 5)])
+# n_c <= 64 (mode 0): one-wave back-substitution from the factor's lower triangle (k_trsv_back_small): 9, 30, 33, 60, 63 unknowns
+@pytest.mark.parametrize("n_cam,n_p", [(3, 3), (13, 5), (60, 5), (200, 5), (150, 6), (64, 3), (32, 3), (43, 3), (11, 6), (26, 5), (54, 3), (260, 5),
+                                       (6, 5), (11, 3), (12, 5), (21, 3)])
 def test_dense_cholesky_solve(gpu, monkeypatch, n_cam, n_p, mode):
     """The reduced-system solver alone: plant a random SPD system in the exchange payload and solve it."""
     monkeypatch.setenv("SATBA_CHOL", mode)  # read when the problem handle is created
