@@ -704,6 +704,7 @@ __global__ __launch_bounds__(64) void k_trsv_back_small(const double* __restrict
 
 }  // namespace satba
 #include "satba_chol2.h"
+#include "satba_chol3.h"
 namespace satba {
 
 constexpr int CH_MAX_STEPS = 256;  // panels (n <= 8192); one flag word per panel
@@ -758,6 +759,49 @@ inline void cholesky_solve(double* A, int n, double* b, int* fail, int* flags, i
             hipLaunchKernelGGL(k_trsv_back_rl, dim3(1), dim3(1024), 0, stream, A, n, b);
         }
     }
+    else hipLaunchKernelGGL(k_trsv_back, dim3(1), dim3(1024), sizeof(double) * n, stream, A, n, b);
+}
+
+// ---- round 4: the factorisation as one persistent launch (satba_chol3.h) + the multi-workgroup backward substitution
+// Scratch of the tile kernel (per handle): tile flags (zeroed once: they carry epochs), the inverted 64 x 64 diagonal blocks,
+// the tiles' shares of the forward substitution, the ticket counters.
+struct CholWork {
+    int* flags = nullptr;
+    double* Linv = nullptr;
+    double* Cc = nullptr;
+    int* ctr = nullptr;
+    int epoch = 0;
+};
+inline hipError_t chol_work_alloc(CholWork& w, int n) {
+    const size_t T = (size_t)(n + 63) / 64;
+    hipError_t e;
+    if ((e = hipMalloc((void**)&w.flags, sizeof(int) * T * T)) != hipSuccess) return e;
+    if ((e = hipMalloc((void**)&w.Linv, sizeof(double) * T * 4096)) != hipSuccess) return e;
+    if ((e = hipMalloc((void**)&w.Cc, sizeof(double) * T * T * 64)) != hipSuccess) return e;
+    if ((e = hipMalloc((void**)&w.ctr, sizeof(int) * 4)) != hipSuccess) return e;
+    if ((e = hipMemset(w.flags, 0, sizeof(int) * T * T)) != hipSuccess) return e;
+    if ((e = hipMemset(w.ctr, 0, sizeof(int) * 4)) != hipSuccess) return e;
+    w.epoch = 0;
+    return hipSuccess;
+}
+inline void chol_work_free(CholWork& w) {
+    (void)hipFree(w.flags); (void)hipFree(w.Linv); (void)hipFree(w.Cc); (void)hipFree(w.ctr);
+    w = CholWork();
+}
+
+// A z = b in place (A: n x n column-major lower, destroyed).  *fail and the CH_TRSV_FLAGS.. flags behind it are zero on entry
+// (the caller's scaling kernel clears them).  dinv: (n / 32 rounded up) x 1024 doubles.
+inline void cholesky_solve_tiles(double* A, int n, double* b, int* fail, int* flags, hipStream_t stream, CholWork& w, double* dinv,
+                                 const int* gate, long long* ts = nullptr) {
+    chol_tiles_init();
+    C3Args g;
+    g.A = A; g.n = n; g.b = b; g.fail = fail; g.flags = w.flags; g.epoch = ++w.epoch; g.Linv = w.Linv; g.Cc = w.Cc; g.ctr = w.ctr;
+    const bool mw = n > CH_SMALL && n <= 1024;  // the multi-workgroup backward substitution reads L^T from the mirror and the 32 x 32 inverses
+    g.dinv = mw ? dinv : nullptr; g.ts = ts; g.mirror = mw ? 1 : 0;
+    if (getenv("SATBA_NO_MIRROR")) g.mirror = 0;  // experiment
+    hipLaunchKernelGGL(k_chol_tiles, dim3(chol_tiles_grid(n)), dim3(1024), c3_lds_bytes(), stream, g, gate);
+    if (n <= CH_SMALL) hipLaunchKernelGGL(k_trsv_back_small, dim3(1), dim3(64), 0, stream, A, n, b, gate);
+    else if (n <= 1024) hipLaunchKernelGGL(k_trsv_back_mw, dim3((n + CH_SB - 1) / CH_SB), dim3(512), 0, stream, A, dinv, n, b, flags + CH_TRSV_FLAGS, gate);
     else hipLaunchKernelGGL(k_trsv_back, dim3(1), dim3(1024), sizeof(double) * n, stream, A, n, b);
 }
 

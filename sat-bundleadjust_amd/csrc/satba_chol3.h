@@ -1,0 +1,862 @@
+// satba_chol3.h -- the dense Cholesky of the reduced camera system as ONE persistent launch (round 4).
+//
+// Replaces the launch-per-double-step factorisation of rounds 1-3 (16 launches of 23.7 us at 1 000 unknowns: launch gap, cold
+// start, trailing update of the diagonal tile, two 32-column diagonal blocks and a panel solve behind a flag -- all on the
+// chain).  Here the matrix is cut into 64 x 64 tiles and every workgroup is one of two things:
+//
+//   the CHAIN workgroup (ticket 0)   walks down the diagonal.  At step k it holds the diagonal tile D = A'(k,k) and the tile
+//       below it R = A'(k+1,k), both with every earlier panel applied, one row per lane in registers.  Twelve waves -- three
+//       row sets (D, R and the identity, whose rows end up as L_kk^-T) x four column quarters -- run a right-looking
+//       factorisation in micro-panels of 8 columns: the owner of a micro-panel factorises (D) or solves (R, identity) its 8
+//       columns in registers, puts them into LDS and raises an LDS flag; the waves to its right apply the rank-8 update.  The
+//       serial chain sees 8 dependent columns + one hand-over + one rank-8 update per micro-panel and nothing else: no launch
+//       gap, no global memory.  Four more waves form the next diagonal tile A'(k+1,k+1) - R R^T by fp64 MFMA while R is being
+//       solved (rank-8 updates as its micro-panels appear) and hand it over through LDS, carry the right-hand side
+//       (y_k = L_kk^-1 b_k: the forward substitution is folded in) and publish.
+//   OWNER workgroups (tickets 1..)   hold ONE tile (i, j) in MFMA accumulators for its whole life: apply panels m = 0 .. as the
+//       tiles L(i,m), L(j,m) are published, then (i >= j + 2) multiply by L_jj^-T -- the panel solve is a GEMM -- and publish
+//       L(i,j) and its share L(i,j) y_j of the forward substitution; the tiles on and directly below the diagonal are handed
+//       to the chain with all panels but the last applied.
+//
+// Everything a workgroup reads from another one is published with write-through (sc1) stores, a drain and a flag word
+// (guide: Guideline 16, form R1 with 8-byte agent-scope accesses on both sides); flags hold 4 x epoch + stage, the epoch counts
+// launches, so nothing has to be cleared between launches.  Tasks are handed out by a ticket counter in column-major tile order:
+// a workgroup only ever waits for tiles with smaller tickets (or for the chain, ticket 0), so the kernel makes progress whatever
+// part of the grid is resident.  Every spin is bounded (fail |= 2 after ~1 s).
+#pragma once
+
+namespace satba {
+
+constexpr int C3_RS = 10;                  // row stride (doubles) of a micro-panel row in LDS: 20 banks, conflict-free b128 row reads
+constexpr int C3_BLK = 64 * C3_RS + 2;     // one (row set, micro-panel) block; + 2: the 8 blocks of a set start 4 banks apart
+constexpr int C3_TBS = 65;                 // column stride of the hand-over buffer of the next diagonal tile
+constexpr int C3_LD = 80;                  // row stride of an owner's operand tiles [k][r] (MFMA operand loads: disjoint bank ranges)
+constexpr int C3_S1 = 1, C3_S2 = 2;        // stages of a tile flag: 1 = A' (all panels but the chain's) published, 2 = L published
+constexpr int C3_SPIN_LIMIT = 1 << 22;
+constexpr int C3_TS = 32;                  // time stamps per step (tools): 0..5 phases, 8 + 8 set + p: micro-panel p of a row set flagged
+
+struct C3Args {
+    double* A;        // n x n, column-major, lower triangle valid; L in place on return (and L^T in the strict upper triangle if mirror)
+    int n;
+    double* b;        // right-hand side; y = L^-1 b on return
+    int* fail;        // |= 1 not positive definite, |= 2 a wait timed out
+    int* flags;       // T x T tile flags (never cleared: epochs)
+    int epoch;        // > 0, larger at every launch
+    double* Linv;     // T x 64 x 64: column-major inverses of the diagonal blocks
+    double* Cc;       // T x T x 64: L(i,j) y_j
+    int* ctr;         // [0] ticket counter, [1] workgroups done; zero on entry, zero on exit
+    double* dinv;     // 32 x 32 inverses of the diagonal blocks, [blk][r][c], for k_trsv_back_mw (or null)
+    long long* ts;    // tools: C3_TS wall-clock stamps per step (or null)
+    int mirror;       // also store L^T into the strict upper triangle (k_trsv_back_mw reads it)
+};
+
+constexpr size_t c3_lds_bytes() {
+    return sizeof(double) * (3 * 8 * C3_BLK + 64 * C3_TBS + 64 + 64 + 128 + 512) + sizeof(int) * 64;
+}
+
+// time stamps inside the kernel are compiled in for tools/chol only (-DC3_STAMPS): their pointers are loop invariants the
+// compiler keeps in registers, which pushed LDS addresses of the riders' loop into scratch
+#ifdef C3_STAMPS
+#define C3_STAMP(ts, idx, cond) do { if ((ts) && (cond)) { long long* t_ = (ts); asm volatile("" : "+v"(t_)); *(c3_gll*)(t_ + (idx)) = wall_clock64(); } } while (0)
+#else
+#define C3_STAMP(ts, idx, cond) do { } while (0)
+#endif
+
+#ifdef C3_STAMPS_IWAVE  // (experiment: the time line of wave 3 of the identity at the end of a step, in the slots of the diagonal tile's micro-panels)
+#define C3_STAMPI(ts, i, cond) do { if ((ts) && (cond)) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); long long* t_ = (ts); asm volatile("" : "+v"(t_)); *(c3_gll*)(t_ + (i)) = wall_clock64(); } } while (0)
+#else
+#define C3_STAMPI(ts, i, cond) do { } while (0)
+#endif
+
+// nothing moves across: neither memory operations nor arithmetic (an empty asm with a memory clobber alone lets the scheduler sink
+// the multiply-adds below it: every broadcast of an update was then in flight at once -- kilobytes of spills)
+#define C3_FENCE() do { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+// ... and register-only instructions are ordered against an asm statement only through its operands: the values named here are
+// complete before the fence, the loads behind it start after it
+#define C3_PIN4(w, x, y, z) do { asm volatile("" : "+v"(w), "+v"(x), "+v"(y), "+v"(z) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define C3_PIN2(w, x) do { asm volatile("" : "+v"(w), "+v"(x) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define C3_PIN1(w) do { asm volatile("" : "+v"(w) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+
+// Global memory is addressed through address-space-1 pointers: the role functions are not inlined, their pointer arguments are
+// generic, and generic accesses become flat_* instructions, which count on lgkmcnt as well -- every wait for an LDS read then also
+// waits for the outstanding global accesses (the identity's waves took 15 us for 32 LDS read -> store pairs that way).
+typedef __attribute__((address_space(1))) double c3_gdouble;
+typedef __attribute__((address_space(1))) int c3_gint;
+typedef __attribute__((address_space(1))) long long c3_gll;
+__device__ __forceinline__ double c3_ld(const double* p) { return __hip_atomic_load((const c3_gdouble*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double c3_gld(const double* p) { return *(const c3_gdouble*)p; }       // plain global load
+__device__ __forceinline__ void c3_gst(double* p, double v) { *(c3_gdouble*)p = v; }               // plain global store
+__device__ __forceinline__ int c3_ld_flag(const int* p) { return __hip_atomic_load((const c3_gint*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void c3_st_flag(int* p, int v) { __hip_atomic_store((c3_gint*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// element (row, col) of the n x n matrix if `ok`, else `other`: the load itself is unconditional (clamped address) -- a load under a
+// condition gets its own s_waitcnt, and sixteen of them in a row were ten microseconds on the chain's critical hand-over
+__device__ __forceinline__ double c3_ld_at(const double* A, int n, int row, int col, bool ok, double other = 0.0) {
+    const int r = row < n ? row : n - 1, c = col < n ? col : n - 1;
+    const double v = c3_ld(A + (size_t)r + (size_t)c * n);
+    return ok ? v : other;
+}
+__device__ __forceinline__ void c3_st(double* p, double v) { __hip_atomic_store((c3_gdouble*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// wait until a global flag word reaches `want` (wrap-safe); false after the time-out or when another wait has timed out
+__device__ __forceinline__ bool c3_wait(const int* f, int want, int* fail) {
+    int spins = 0;
+    while ((int)(c3_ld_flag(f) - want) < 0) {
+        __builtin_amdgcn_s_sleep(1);
+        if ((++spins & 1023) == 0) {
+            if (spins > C3_SPIN_LIMIT) { atomicOr(fail, 2); return false; }
+            if (c3_ld_flag(fail) & 2) return false;
+        }
+    }
+    return true;
+}
+// (LDS words: workgroup-scope atomics on plain pointers -- a volatile access through a pointer the compiler cannot prove to be LDS
+// becomes a flat load)
+__device__ __forceinline__ int c3_lds_get(const int* f) { return __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void c3_lds_set(int* f, int v) { __hip_atomic_store(f, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void c3_lds_inc(int* f) { __hip_atomic_fetch_add(f, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ bool c3_wait_lds(const int* f, int want, int* fail) {
+    int spins = 0;
+    while (c3_lds_get(f) < want) {
+        __builtin_amdgcn_s_sleep(1);
+        if ((++spins & 4095) == 0) {
+            if (spins > 4 * C3_SPIN_LIMIT) { atomicOr(fail, 2); return false; }
+            if (c3_ld_flag(fail) & 2) return false;
+        }
+    }
+    asm volatile("" ::: "memory");
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------------------------- chain
+// One step of a wave of the diagonal tile (column quarter q): a[16] = its 16 columns of its row (lane), see the file comment.
+// pan: the LDS blocks of the diagonal tile's micro-panels ([p][row][C3_RS]); lf their flags (value: step + 1).
+// The loop over the pairs of micro-panels is a run-time loop on purpose: unrolled over all eight micro-panels the row sets were
+// 110 KB of straight-line code executed once per step -- more than the instruction cache holds -- and a step took 54 us.
+// Tried and dropped: the wave's 16 columns factorised entirely in registers (column j's multipliers by v_readlane applied to all
+// 15 - j later columns, the last foreign micro-panel's share of columns 8 .. 15 issued inside the factorisation): the registers
+// ran out, five spills per column sat on the chain -- 7.6 us per pair of micro-panels against 3.7.
+__device__ __forceinline__ bool c3_panel(double (&a)[16], int q, int lane, double* pan, double* pinv, int* lf, int step1, int* fail, long long* tsp) {
+    bool bad = false;
+    for (int pp = 0; pp < q; ++pp) {
+        // ---- the two micro-panels of the waves to my left: rank-8 updates of my 16 columns, as they appear
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int p = 2 * pp + h;
+            if (!c3_wait_lds(lf + p, step1, fail)) return true;
+            const double2* row = reinterpret_cast<const double2*>(pan + p * C3_BLK + lane * C3_RS);
+            double r[8];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) { const double2 t = row[m]; r[2 * m] = t.x; r[2 * m + 1] = t.y; }
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                const double2* lc = reinterpret_cast<const double2*>(pan + p * C3_BLK + (16 * q + c) * C3_RS);
+                double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const double2 t = lc[m];
+                    s0 = fma(r[2 * m], t.x, s0);
+                    s1 = fma(r[2 * m + 1], t.y, s1);
+                }
+                a[c] -= s0 + s1;
+                if ((c & 3) == 3) C3_PIN4(a[c - 3], a[c - 2], a[c - 1], a[c]);  // at most four columns' broadcasts in flight (registers)
+            }
+        }
+    }
+    // ---- my own two micro-panels
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int p = 2 * q + h;
+        double inv_[8];  // 1 / L_jj (wave-uniform; written once per micro-panel: a store under `lane == 0` per column cost the chain 60 %)
+        double d = readlane_f64(a[8 * h], 8 * p);
+        bad |= !(d > 1e-300) || !(d < 1e300);
+        double hh = half_rsqrt(d);
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+            const double a2 = a[8 * h + jj] + a[8 * h + jj];
+            const double l = a2 * hh;  // lane of the pivot: 2 d h = sqrt(d)
+            a[8 * h + jj] = l;
+            inv_[jj] = hh + hh;
+            if (jj + 1 < 8) {
+                const double piv = fma(-l, l, a[8 * h + jj + 1]);
+                d = readlane_f64(piv, 8 * p + jj + 1);
+                bad |= !(d > 1e-300) || !(d < 1e300);
+                hh = half_rsqrt(d);
+#pragma unroll
+                for (int c = jj + 1; c < 8; ++c) a[8 * h + c] = fma(-l, readlane_f64(l, 8 * p + c), a[8 * h + c]);
+            }
+        }
+        double2* row = reinterpret_cast<double2*>(pan + p * C3_BLK + lane * C3_RS);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) row[m] = make_double2(a[8 * h + 2 * m], a[8 * h + 2 * m + 1]);
+        if (lane == 0) {
+            double2* pi = reinterpret_cast<double2*>(pinv + 8 * p);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) pi[m] = make_double2(inv_[2 * m], inv_[2 * m + 1]);
+        }
+        asm volatile("" ::: "memory");
+        if (lane == 0) c3_lds_set(lf + p, step1);  // the LDS unit executes a wave's operations in order: the data are in place before the flag
+        C3_STAMP(tsp, p, lane == 0);
+        if (h == 0) {  // the micro-panel's share of my columns 8 .. 15
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const double2* lc = reinterpret_cast<const double2*>(pan + p * C3_BLK + (16 * q + 8 + c) * C3_RS);
+                double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const double2 t = lc[m];
+                    s0 = fma(a[2 * m], t.x, s0);
+                    s1 = fma(a[2 * m + 1], t.y, s1);
+                }
+                a[8 + c] -= s0 + s1;
+                if ((c & 3) == 3) C3_PIN4(a[8 + c - 3], a[8 + c - 2], a[8 + c - 1], a[8 + c]);
+            }
+        }
+    }
+    return bad;
+}
+
+// LDS of the chain workgroup
+struct C3Lds {
+    double* pan;            // [3][8][C3_BLK]: D | R | identity, micro-panel blocks [row][C3_RS]
+    double* Tb;             // [64][C3_TBS]: next diagonal tile, [column][row]
+    double* pinv;           // 1 / L_jj of the diagonal tile
+    double* yv;             // y_k
+    double* bcur;           // [2][64]: right-hand side of the current / next diagonal tile, all panels applied
+    double* inv8;           // [8][8][8]: inverses of the 8 x 8 diagonal blocks of the micro-panels, [p][row][column]
+    int* lf;                // [0..7] micro-panel p of D published (value: step + 1); [8..15], [16..23]: waves of R / the identity
+                            // that have published micro-panel p (4 per step)
+    int* tb_cnt;            // += 1 per wave of the next diagonal tile (two) and step: its blocks are in Tb
+    int* pub_cnt;           // += 1 per storing wave of L_kk^-1, y_k and step (4 + 1)
+    int* pubR_cnt;          // += 1 per storing wave of R and step (4)
+    int* mir_cnt;           // += 1 per wave of the identity and step: its rows of L^T (diagonal tile and R) are written
+    int* prod_cnt;          // += 1 per wave of R and step: its share of the next input is formed (R's rows in LDS may go)
+    int* b_rdy;             // = step + 1 when bcur[step & 1] is ready
+    int* inv_flag;          // [8]: inv8[p] is ready (value: step + 1)
+};
+__device__ __forceinline__ C3Lds c3_carve(double* lds) {
+    C3Lds l;
+    l.pan = lds;
+    l.Tb = l.pan + 3 * 8 * C3_BLK;
+    l.pinv = l.Tb + 64 * C3_TBS;
+    l.yv = l.pinv + 64;
+    l.bcur = l.yv + 64;
+    l.inv8 = l.bcur + 128;
+    int* li = reinterpret_cast<int*>(l.inv8 + 512);
+    l.lf = li; l.tb_cnt = li + 24; l.pub_cnt = li + 25; l.b_rdy = li + 26; l.pubR_cnt = li + 27; l.prod_cnt = li + 28; l.mir_cnt = li + 29; l.inv_flag = li + 32;
+    return l;
+}
+
+// L^T of a step's tiles into the strict upper triangle (for the back-substitution kernel): row r of L is one wave store of 64
+// consecutive addresses, read from the micro-panel blocks in LDS (lane = column); rows 16 w .. 16 w + 15 of the diagonal tile and of R
+// per call, by the two waves that form the next diagonal tile, behind its hand-over.  All rows are read before the first store and
+// counted: the next step may reuse the blocks while the stores go out.  (History: as 8-byte stores scattered over 64 lines by the
+// waves that hold the tiles, in front of their drains: +25 us per factorisation; in the riders' function, an LDS address reloaded from
+// scratch per row, whose s_waitcnt vmcnt(0) waited for the previous store: 11 us per step.)
+__device__ __forceinline__ void c3_mirror_rows(double* A, int n, int r0, int w, int has_r, int* done_cnt) {
+    extern __shared__ __attribute__((aligned(16))) double c3_lds[];
+    const int lane = threadIdx.x & 63;
+    const double* src = c3_lds + (lane >> 3) * C3_BLK + (lane & 7);  // column `lane` of a row: micro-panel lane / 8, entry lane % 8
+    double vd[16], vr[16];
+#pragma unroll
+    for (int rr = 0; rr < 16; ++rr) { vd[rr] = src[(16 * w + rr) * C3_RS]; vr[rr] = src[8 * C3_BLK + (16 * w + rr) * C3_RS]; }
+    C3_PIN4(vd[15], vr[15], vd[14], vr[14]);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (lane == 0) c3_lds_inc(done_cnt);  // the rows are in registers: the micro-panel blocks may be reused while the stores go out
+#pragma unroll
+    for (int rr = 0; rr < 16; ++rr) {
+        const int r = 16 * w + rr;
+        if (r0 + r < n && lane < r && r0 + lane < n) c3_gst(A + (size_t)(r0 + lane) + (size_t)(r0 + r) * n, vd[rr]);
+        if (has_r && r0 + 64 + r < n) c3_gst(A + (size_t)(r0 + lane) + (size_t)(r0 + 64 + r) * n, vr[rr]);
+    }
+}
+
+// Next diagonal tile, A'(k+1,k+1) - R R^T: its ten lower 16 x 16 blocks by two of the helper waves, five blocks each, as rank-8
+// updates (two MFMAs per block) when a micro-panel of R appears in LDS -- ten MFMAs per micro-panel and wave, well inside the 1.6 us
+// a micro-panel takes, so that after R's last micro-panel only ten more are left.  The accumulators start from the base -- the tile
+// with every earlier panel applied, from its owner, which is about a step ahead.
+// (History: in one function with other roles, or without scheduling fences, the compiler had every operand of a step in flight and
+// spilled around each MFMA -- the tile was ready 6 to 12 us after R; one shot after R over the idle waves of the diagonal tile:
+// their share arrived 4 us after the helpers'.)
+template <int Q>
+__device__ __forceinline__ bool c3_dnext_blocks(const C3Lds& l, const double* A, int n, int T, int k, int* fail, const int* flags, int want1, int lane) {
+    constexpr int RB[2][5] = {{0, 1, 1, 2, 2}, {2, 3, 3, 3, 3}};
+    constexpr int CB[2][5] = {{0, 0, 1, 0, 1}, {2, 0, 1, 2, 3}};
+    const int e16 = lane & 15, g4 = lane >> 4, r0 = 64 * k, step1 = k + 1;
+    const double* panR = l.pan + 8 * C3_BLK;
+    if (k + 1 >= 2 && !c3_wait(flags + (k + 1) * T + (k + 1), want1, fail)) return false;
+    chol_d4 dn[5];  // (the base in the accumulators: held beside them it did not fit the 128 registers of a 16-wave workgroup)
+#pragma unroll
+    for (int t = 0; t < 5; ++t) {
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int rr = 16 * RB[Q][t] + e16, cc = 16 * CB[Q][t] + g4 + 4 * reg;
+            dn[t][reg] = c3_ld_at(A, n, r0 + 64 + rr, r0 + 64 + cc, r0 + 64 + rr < n && cc <= rr, (rr == cc) ? 1.0 : 0.0);  // identity padding
+        }
+    }
+    for (int p = 0; p < 8; ++p) {
+        if (!c3_wait_lds(l.lf + 8 + p, 4 * step1, fail)) return false;
+        // the micro-panel's rows of the four row blocks, as MFMA operands (k = 4 ks + lane / 16)
+        double op[4][2];
+#pragma unroll
+        for (int b4 = 0; b4 < 4; ++b4)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) op[b4][ks] = panR[p * C3_BLK + (16 * b4 + e16) * C3_RS + 4 * ks + g4];
+#pragma unroll
+        for (int t = 0; t < 5; ++t) {
+            dn[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(op[CB[Q][t]][0], -op[RB[Q][t]][0], dn[t], 0, 0, 0);
+            dn[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(op[CB[Q][t]][1], -op[RB[Q][t]][1], dn[t], 0, 0, 0);
+        }
+        C3_FENCE();
+    }
+#pragma unroll
+    for (int t = 0; t < 5; ++t)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) l.Tb[(16 * CB[Q][t] + g4 + 4 * reg) * C3_TBS + 16 * RB[Q][t] + e16] = dn[t][reg];
+    asm volatile("" ::: "memory");
+    if (lane == 0) c3_lds_inc(l.tb_cnt);
+    return true;
+}
+
+// the four waves of the diagonal tile: one row per lane, column quarter q (c3_panel)
+__device__ __noinline__ void c3_chain_diag(int q, double* A, int n, int T, int* fail, int mirror, long long* ts) {
+    extern __shared__ __attribute__((aligned(16))) double c3_lds[];  // (declared here, not passed: the pointers stay in the LDS address space)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const C3Lds l = c3_carve(c3_lds);
+    double a[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        const int col = 16 * q + c;
+        double v = (col == lane) ? 1.0 : 0.0;
+        if (lane < n && col <= lane) v = c3_gld(A + (size_t)lane + (size_t)col * n);
+        a[c] = v;
+    }
+    for (int k = 0; k < T; ++k) {
+        const int step1 = k + 1;
+        const int r0 = 64 * k;
+        const bool has_r = k + 1 < T;
+        // the identity's riders still read the micro-panels of the previous step (R's are done: the hand-over buffer is complete)
+        if (k > 0 && !c3_wait_lds(l.lf + 16 + 7, 4 * k, fail)) return;
+        if (mirror && k > 0 && !c3_wait_lds(l.mir_cnt, 4 * k, fail)) return;  // ... and have written L^T of the previous step from LDS
+        C3_STAMP(ts, k * C3_TS + 0, tid == 0);
+        const bool bad = c3_panel(a, q, lane, l.pan, l.pinv, l.lf, step1, fail, ts ? ts + k * C3_TS + 8 : nullptr);
+        if (bad && lane == 0) atomicOr(fail, 1);
+        C3_STAMP(ts, k * C3_TS + 1, lane == 0 && q == 3);
+        // ---- my 16 columns of L_kk: plain stores -- nothing in this launch reads L_kk (the tiles below are multiplied by L_kk^-1),
+        // so no write-through, no drain, no flag; L^T for the back-substitution is written by the identity's waves from LDS
+        asm volatile("" : "+v"(n), "+v"(A));  // (keeps the address arithmetic of the stores out of the registers of the factorisation)
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            const int row = r0 + lane, col = r0 + 16 * q + c;
+            if (row < n && col <= row) c3_gst(A + (size_t)row + (size_t)col * n, a[c]);
+        }
+        // ---- the next diagonal tile, formed by two of the helper waves (c3_dnext_blocks), from LDS, one row per lane
+        if (has_r) {
+            if (!c3_wait_lds(l.tb_cnt, 2 * step1, fail)) return;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                const int col = 16 * q + c;
+                a[c] = (col <= lane) ? l.Tb[col * C3_TBS + lane] : 0.0;
+            }
+            // (the hand-over buffer is rewritten at the end of the next step, long after these reads)
+            C3_STAMP(ts, k * C3_TS + 6, tid == 0);
+        }
+    }
+}
+
+// The riders -- R = A'(k+1, k) and the identity -- on the matrix cores: wave w of a set holds rows 16 w .. 16 w + 15 of its tile as
+// four MFMA accumulator blocks (block cb: row 16 w + (lane & 15), column 16 cb + (lane >> 4) + 4 reg).  The accumulator layout of
+// the 8 columns of a micro-panel (registers 2 h, 2 h + 1 of block p >> 1) IS the layout of an MFMA operand with k = column, so
+//   solve     x = cur L_pp^-T      two MFMAs against the inverted 8 x 8 diagonal block (inv8, by the inverter wave), in place
+//   trailing  acc -= x L[c, p]^T   two MFMAs per 16-column block to the right, operands: the L rows of the micro-panel from LDS
+// need no transposition and no LDS round trip; only x goes to LDS (for the next diagonal tile A'(k+1,k+1) - R R^T, which two of
+// the other waves accumulate -- in R's own waves its accumulators were spilled around every MFMA -- and for the right-hand side).  Round 4 first ran the riders like the
+// diagonal tile (one row per lane, LDS broadcasts on the vector ALU): 3.5 us per micro-panel against 1.6 for the diagonal tile
+// they follow, twelve waves on four SIMDs.
+__device__ __noinline__ void c3_chain_rider(int set, int w, double* A, int n, int T, int* fail, const int* flags, int want1, double* Linv, double* dinv,
+                                            int mirror, long long* ts) {
+    extern __shared__ __attribute__((aligned(16))) double c3_lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int e16 = lane & 15, g4 = lane >> 4;
+    const C3Lds l = c3_carve(c3_lds);
+    const bool isR = set == 1;
+    double* panS = l.pan + set * 8 * C3_BLK;
+    int* cntS = l.lf + 8 * set;
+    chol_d4 acc[4];
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) acc[cb] = chol_d4{0.0, 0.0, 0.0, 0.0};
+    if (isR && T > 1) {  // step 0: tile (1, 0) of the input
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int cc = 16 * cb + g4 + 4 * reg, row = 64 + 16 * w + e16;
+                acc[cb][reg] = (row < n) ? c3_gld(A + (size_t)row + (size_t)cc * n) : 0.0;
+            }
+    }
+    for (int k = 0; k < T; ++k) {
+        const int step1 = k + 1;
+        const int r0 = 64 * k;
+        const bool has_r = k + 1 < T;
+        if (!isR) {
+            int wi = w;
+            asm volatile("" : "+v"(wi));  // (the identity is set up again at every step: hoisted out of the loop its 16 values sat in scratch)
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) acc[cb][reg] = (cb == wi && e16 == g4 + 4 * reg) ? 1.0 : 0.0;
+        }
+        if (!isR || has_r) {
+            // the right-hand side's wave is done with this set's rows of the previous step, and so are the products of R's four waves
+            if (k > 0 && !c3_wait_lds(l.b_rdy, step1, fail)) return;
+            if (isR && k > 0 && !c3_wait_lds(l.prod_cnt, 4 * k, fail)) return;
+            if (isR && mirror && k > 0 && !c3_wait_lds(l.mir_cnt, 4 * k, fail)) return;
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                const int cb = p >> 1, h = p & 1;
+                if (!c3_wait_lds(l.inv_flag + p, step1, fail)) return;
+                // ---- solve: x[row][jj] = sum_m cur[row][m] Linv8[jj][m]  (first operand: indexed by the output column)
+                const double i0 = (e16 < 8) ? l.inv8[p * 64 + e16 * 8 + g4] : 0.0;
+                const double i1 = (e16 < 8) ? l.inv8[p * 64 + e16 * 8 + 4 + g4] : 0.0;
+                chol_d4 x = chol_d4{0.0, 0.0, 0.0, 0.0};
+#ifndef C3_EXP_NO_RIDER_MFMA
+                x = __builtin_amdgcn_mfma_f64_16x16x4f64(i0, acc[cb][2 * h], x, 0, 0, 0);
+                x = __builtin_amdgcn_mfma_f64_16x16x4f64(i1, acc[cb][2 * h + 1], x, 0, 0, 0);
+#endif
+                acc[cb][2 * h] = x[0]; acc[cb][2 * h + 1] = x[1];
+                panS[p * C3_BLK + (16 * w + e16) * C3_RS + g4] = x[0];
+                panS[p * C3_BLK + (16 * w + e16) * C3_RS + 4 + g4] = x[1];
+                asm volatile("" ::: "memory");
+                if (lane == 0) c3_lds_inc(cntS + p);  // (a wave's LDS operations execute in order: the rows are in place before the count)
+                C3_STAMP(ts, k * C3_TS + 8 + 8 * set + p, lane == 0 && w == 3);
+                const double xn0 = -x[0], xn1 = -x[1];
+                // ---- trailing update of the columns to the right (h == 0: the second half of this block, too)
+#pragma unroll
+                for (int cb2 = 0; cb2 < 4; ++cb2) {
+                    if (cb2 > cb || (cb2 == cb && h == 0)) {
+                        double v0 = l.pan[p * C3_BLK + (16 * cb2 + e16) * C3_RS + g4];
+                        double v1 = l.pan[p * C3_BLK + (16 * cb2 + e16) * C3_RS + 4 + g4];
+                        if (cb2 == cb && e16 < 8) { v0 = 0.0; v1 = 0.0; }  // the solved columns stay
+#ifndef C3_EXP_NO_RIDER_MFMA
+                        acc[cb2] = __builtin_amdgcn_mfma_f64_16x16x4f64(v0, xn0, acc[cb2], 0, 0, 0);
+                        acc[cb2] = __builtin_amdgcn_mfma_f64_16x16x4f64(v1, xn1, acc[cb2], 0, 0, 0);
+#else
+                        acc[cb2][0] += v0 * xn0; acc[cb2][1] += v1 * xn1;
+#endif
+                    }
+                }
+            }
+        }
+        C3_STAMP(ts, k * C3_TS + 1 + set, lane == 0 && w == 3);
+        // (the address arithmetic of the stores and loads below must not be hoisted out of the step loop: held in registers across
+        // the micro-panels it pushed the loop's own LDS addresses into scratch -- four reloads per micro-panel on the riders' path)
+        asm volatile("" : "+v"(n), "+v"(A), "+v"(Linv), "+v"(dinv));
+        // ---- publish (write-through); the mirror and the 32 x 32 block inverses are plain stores: read by later kernels only
+        if (isR) {
+            if (has_r) {
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) {
+                        const int row = r0 + 64 + 16 * w + e16, col = r0 + 16 * cb + g4 + 4 * reg;
+                        if (row < n) c3_st(A + (size_t)row + (size_t)col * n, acc[cb][reg]);
+                    }
+            }
+        } else {
+            const int m = 16 * w + e16;  // row m of L^-T = column m of L^-1
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int c = 16 * cb + g4 + 4 * reg;
+                    c3_st(Linv + (size_t)k * 4096 + (size_t)m * 64 + c, acc[cb][reg]);
+                }
+        }
+        C3_STAMPI(ts, k * C3_TS + 8 + 8, !isR && lane == 0 && w == 3);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // my stores are acknowledged
+        if (lane == 0) c3_lds_inc(isR ? l.pubR_cnt : l.pub_cnt);
+        C3_STAMPI(ts, k * C3_TS + 8 + 9, !isR && lane == 0 && w == 3);
+        if (!isR) {
+            // ---- plain stores for the back-substitution kernel: the 32 x 32 block inverses
+            const int hb = w >> 1;
+            if (dinv && 32 * (2 * k + hb) < n) {
+                const int m = 16 * w + e16;
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) {
+                        const int c = 16 * cb + g4 + 4 * reg;  // [blk][row of the inverse][column]; identity padding inverts to itself
+                        if ((cb >> 1) == hb) c3_gst(dinv + ((size_t)(2 * k + hb) * 32 + (c - 32 * hb)) * 32 + (m - 32 * hb), acc[cb][reg]);
+                    }
+            }
+        }
+        // ---- R: input of the next step.  Tile (k+2, k+1) comes from its owner with every panel but this step's applied (published
+        // a step ago); this step's panel is applied here: - L(k+2, k) R^T, the rows of L(k+2, k) straight from memory in the layout of
+        // an MFMA operand (row 16 w + (lane & 15), column 4 ks + (lane >> 4)), R from LDS
+        if (isR && k + 2 < T) {
+            if (k + 1 >= 2 && !c3_wait(flags + (k + 2) * T + (k + 1), want1, fail)) return;
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int cc = 16 * cb + g4 + 4 * reg, row = r0 + 128 + 16 * w + e16;
+                    acc[cb][reg] = c3_ld_at(A, n, row, r0 + 64 + cc, row < n);
+                }
+            if (!c3_wait(flags + (k + 2) * T + k, 4 * (want1 >> 2) + C3_S2, fail)) return;
+            double lv[16];
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks) lv[ks] = c3_ld_at(A, n, r0 + 128 + 16 * w + e16, r0 + 4 * ks + g4, r0 + 128 + 16 * w + e16 < n);
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks) lv[ks] = -lv[ks];
+            if (!c3_wait_lds(cntS + 7, 4 * step1, fail)) return;  // every row of R is in LDS
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+#pragma unroll
+                for (int ks2 = 0; ks2 < 2; ++ks2) {
+#pragma unroll
+                    for (int cb = 0; cb < 4; ++cb) {
+                        const double av = panS[p * C3_BLK + (16 * cb + e16) * C3_RS + 4 * ks2 + g4];
+                        acc[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, lv[2 * p + ks2], acc[cb], 0, 0, 0);
+                    }
+                }
+            }
+            asm volatile("" ::: "memory");
+            if (lane == 0) c3_lds_inc(l.prod_cnt);  // this wave is done with R's rows in LDS
+        }
+    }
+}
+
+// the two helper waves that form the next diagonal tile (their own function: compiled together with the inverter and the right-hand
+// side's wave the five bases were spilled -- the tile was ready 12 us after R instead of 2)
+template <int Q>
+__device__ __noinline__ void c3_chain_dnext(double* A, int n, int T, int* fail, const int* flags, int want1, int mirror, long long* ts) {
+    extern __shared__ __attribute__((aligned(16))) double c3_lds[];
+    const int lane = threadIdx.x & 63;
+    const C3Lds l = c3_carve(c3_lds);
+    for (int k = 0; k < T; ++k) {
+        const bool has_r = k + 1 < T;
+        if (has_r) {
+            if (!c3_dnext_blocks<Q>(l, A, n, T, k, fail, flags, want1, lane)) return;
+            C3_STAMP(ts, k * C3_TS + 4, lane == 0 && Q == 1);
+        } else if (mirror && !c3_wait_lds(l.lf + 7, k + 1, fail)) return;  // last step: the diagonal tile is complete
+        // L^T of this step's tiles for the back-substitution kernel (32 rows per wave): the rows are read from LDS first and counted,
+        // then stored -- the next step may reuse the micro-panel blocks meanwhile
+        if (mirror) {
+            c3_mirror_rows(A, n, 64 * k, 2 * Q, has_r ? 1 : 0, l.mir_cnt);
+            c3_mirror_rows(A, n, 64 * k, 2 * Q + 1, has_r ? 1 : 0, l.mir_cnt);
+        }
+    }
+}
+
+// the other four waves of the chain workgroup: 0 inverts the 8 x 8 diagonal blocks of the micro-panels for the riders, 1 carries the
+// right-hand side and publishes the step, 2 and 3 form the next diagonal tile (c3_dnext_blocks)
+__device__ __noinline__ void c3_chain_aux(int q, double* A, int n, int T, int* fail, int* flags, int want1, int want2, double* b, const double* Cc, long long* ts) {
+    extern __shared__ __attribute__((aligned(16))) double c3_lds[];
+    const int lane = threadIdx.x & 63;
+    const C3Lds l = c3_carve(c3_lds);
+
+    for (int k = 0; k < T; ++k) {
+        const int step1 = k + 1;
+        const int r0 = 64 * k;
+        const bool has_r = k + 1 < T;
+        if (q == 0) {
+            // ---- X = L_pp^-1, lane c (< 8) solves column c by forward substitution; the L entries come as LDS broadcasts
+            // (inv8[p] of the previous step has been read by every rider: D's micro-panel p of this step exists)
+            const int c = lane & 7;
+            for (int p = 0; p < 8; ++p) {
+                if (!c3_wait_lds(l.lf + p, step1, fail)) return;
+                const double* Lp = l.pan + p * C3_BLK + 8 * p * C3_RS;
+                double x[8];
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    double s0 = (r == c) ? 1.0 : 0.0, s1 = 0.0;
+#pragma unroll
+                    for (int m = 0; m < r; ++m) {
+                        if (m & 1) s1 = fma(-Lp[r * C3_RS + m], x[m], s1);
+                        else s0 = fma(-Lp[r * C3_RS + m], x[m], s0);
+                    }
+                    x[r] = (s0 + s1) * l.pinv[8 * p + r];
+                }
+                if (lane < 8) {
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) l.inv8[p * 64 + r * 8 + c] = x[r];
+                }
+                asm volatile("" ::: "memory");
+                if (lane == 0) c3_lds_set(l.inv_flag + p, step1);
+            }
+        } else {
+            // ---- right-hand side: y_k = L_kk^-1 b'_k (lane = row: sum_c (L^-T)[c][r] b'[c]), then b'_{k+1}
+            if (!c3_wait_lds(l.lf + 16 + 7, 4 * step1, fail)) return;
+            const double* panI = l.pan + 16 * C3_BLK + (lane >> 3) * C3_BLK + (lane & 7);
+            const double* bk = l.bcur + 64 * (k & 1);
+            double y0 = 0.0, y1 = 0.0;
+#pragma unroll
+            for (int c = 0; c < 64; c += 2) {
+                y0 = fma(panI[c * C3_RS], bk[c], y0);
+                y1 = fma(panI[(c + 1) * C3_RS], bk[c + 1], y1);
+                if ((c & 14) == 14) C3_PIN2(y0, y1);  // sixteen entries' operands in flight
+            }
+            const double y = y0 + y1;
+            l.yv[lane] = y;
+            if (r0 + lane < n) c3_st(b + r0 + lane, y);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) c3_lds_inc(l.pub_cnt);
+            // ---- publish L_kk^-1 and y_k as soon as their five storing waves have drained: the panel solves of the tiles below
+            // start while R is still on its way
+            if (!c3_wait_lds(l.pub_cnt, 5 * step1, fail)) return;
+            if (lane == 0) c3_st_flag(flags + k * T + k, want2);
+            if (has_r) {
+                // ---- publish R = L(k+1, k) as soon as its four storing waves have drained
+                if (!c3_wait_lds(l.pubR_cnt, 4 * step1, fail)) return;
+                if (lane == 0) c3_st_flag(flags + (k + 1) * T + k, want2);
+                // ---- b'_{k+1} = b_{k+1} - sum_{m < k} L(k+1, m) y_m - R y_k, in this fixed order
+                // (R's input was read behind the S1 flag of tile (k+1, k): every L(k+1, m), m < k, and its share of b are published)
+                const int row = r0 + 64 + lane;
+                double bn = (row < n) ? c3_gld(b + row) : 0.0;
+                for (int m0 = 0; m0 < k; m0 += 8) {  // eight loads in flight
+                    double cv[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const double cc_ = c3_ld(Cc + ((size_t)(k + 1) * T + (m0 + u < k ? m0 + u : k - 1)) * 64 + lane);
+                        cv[u] = (m0 + u < k) ? cc_ : 0.0;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) bn -= cv[u];
+                }
+                double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+                for (int p = 0; p < 8; ++p) {
+                    const double2* row_ = reinterpret_cast<const double2*>(l.pan + 8 * C3_BLK + p * C3_BLK + lane * C3_RS);
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) {
+                        const double2 t = row_[m];
+                        s0 = fma(t.x, l.yv[8 * p + 2 * m], s0);
+                        s1 = fma(t.y, l.yv[8 * p + 2 * m + 1], s1);
+                    }
+                    if (p & 1) C3_PIN2(s0, s1);
+                }
+                bn -= s0 + s1;
+                l.bcur[64 * ((k + 1) & 1) + lane] = bn;
+                asm volatile("" ::: "memory");
+                if (lane == 0) c3_lds_set(l.b_rdy, step1 + 1);  // also: this wave is done with the riders' rows of this step
+            }
+            C3_STAMP(ts, k * C3_TS + 5, lane == 0);
+        }
+    }
+}
+
+__device__ __forceinline__ void c3_chain(const C3Args& g, int T) {
+    extern __shared__ __attribute__((aligned(16))) double c3_lds[];
+    const int tid = threadIdx.x;
+    const C3Lds l = c3_carve(c3_lds);
+    if (tid < 60) l.lf[tid] = 0;
+    if (tid < 64) l.bcur[tid] = (tid < g.n) ? c3_gld(g.b + tid) : 0.0;
+    __syncthreads();
+    if (tid == 0) c3_lds_set(l.b_rdy, 1);
+    const int want2 = 4 * g.epoch + C3_S2, want1 = 4 * g.epoch + C3_S1;
+    // Roles by wave.  The four waves of the diagonal tile are waves 0, 4, 8, 12: with waves dealt to the four SIMDs in turn they share
+    // ONE SIMD, and every wave that issues MFMAs sits on the other three -- a 64-cycle fp64 MFMA in front of it delays a dependent
+    // operation of the pivot chain (with one wave of every role per SIMD the diagonal tile took 16 us per step instead of 12.5).
+    const int wave = tid >> 6;
+    const int oth = (wave >> 2) * 3 + (wave & 3) - 1;  // 0 .. 11 over the waves that are not of the diagonal tile
+    if ((wave & 3) == 0) c3_chain_diag(wave >> 2, g.A, g.n, T, g.fail, g.mirror, g.ts);
+    else if (oth < 8) c3_chain_rider(1 + (oth >> 2), oth & 3, g.A, g.n, T, g.fail, g.flags, want1, g.Linv, g.dinv, g.mirror, g.ts);
+    else if (oth == 10) c3_chain_dnext<0>(g.A, g.n, T, g.fail, g.flags, want1, g.mirror, g.ts);
+    else if (oth == 11) c3_chain_dnext<1>(g.A, g.n, T, g.fail, g.flags, want1, g.mirror, g.ts);
+    else c3_chain_aux(oth - 8, g.A, g.n, T, g.fail, g.flags, want1, want2, g.b, g.Cc, g.ts);
+}
+
+// ---------------------------------------------------------------------------------------------------------------- owners
+// Tasks behind the chain (ticket 0), column by column j: the diagonal tile (j, j) and the tile below it (j+1, j) (j >= 2) get all
+// panels but the LAST one applied and are handed to the chain, which applies the last panel itself -- it has just produced it
+// (R R^T for the diagonal tile, L(j+1, j-1) R^T for the tile below: c3_chain_rider); the other tiles (i, j), i >= j + 2, get all
+// panels, are multiplied by L_jj^-T and published.  Of everything the chain reads only L(k+2, k) is younger than a step.
+// (Round 4 on the way here: (j+1, j) with all panels applied by its owner -- 13 us from the chain's publication to its next
+// input, through four hand-overs; one workgroup for (j+2, j) and (j+2, j+1) -- 10 us.)
+// kind: 0 diagonal, 1 below the diagonal, 2 ordinary
+__host__ __device__ inline int c3_task_count(int T) {
+    int cnt = 1;
+    for (int j = 0; j < T; ++j) {
+        if (j >= 2) ++cnt;
+        if (j >= 2 && j + 1 <= T - 1) ++cnt;
+        if (T - 1 >= j + 2) cnt += T - 1 - (j + 2) + 1;
+    }
+    return cnt;
+}
+__device__ inline void c3_task(int T, int idx, int& i, int& j, int& kind) {  // idx >= 1
+    --idx;
+    for (j = 0; j < T; ++j) {
+        if (j >= 2) { if (idx == 0) { i = j; kind = 0; return; } --idx; }
+        if (j >= 2 && j + 1 <= T - 1) { if (idx == 0) { i = j + 1; kind = 1; return; } --idx; }
+        const int cnt = T - 1 >= j + 2 ? T - 1 - (j + 2) + 1 : 0;
+        if (idx < cnt) { i = j + 2 + idx; kind = 2; return; }
+        idx -= cnt;
+    }
+    i = j = 0; kind = -1;
+}
+
+__device__ __noinline__ void c3_owner(C3Args g, int T, int i, int j, int kind) {
+    extern __shared__ __attribute__((aligned(16))) double c3_lds[];  // (declared here, not passed: the pointers stay in the LDS address space)
+    double* lds = c3_lds;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int rb = wave & 3, cb = wave >> 2, e16 = lane & 15, g4 = lane >> 4;
+    const int n = g.n;
+    double* A = g.A;
+    double* Li = lds;                       // [64][C3_LD]: [k][row] of L(i, m)
+    double* Lj = Li + 64 * C3_LD;           // L(j, m)
+    double* part = Lj + 64 * C3_LD;         // [4][64]
+    double* yv = part + 256;                // [64]
+    int* s_ok = reinterpret_cast<int*>(lds + 3 * 8 * C3_BLK + 64 * C3_TBS + 64 + 64 + 128 + 512) + 61;
+    const int want2 = 4 * g.epoch + C3_S2, want1 = 4 * g.epoch + C3_S1;
+    const int r0 = 64 * i, c0 = 64 * j;
+    const bool diag = kind == 0;
+    const int rr = 16 * rb + e16;
+    chol_d4 old, acc = chol_d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+        const int cc = 16 * cb + g4 + 4 * reg;
+        const int row = r0 + rr, col = c0 + cc;
+        double v = 0.0;
+        if (row < n && col < n && (!diag || cc <= rr)) v = c3_gld(A + (size_t)row + (size_t)col * n);
+        old[reg] = v;
+    }
+    const int n_upd = kind == 2 ? j : j - 1;
+    for (int m = 0; m < n_upd; ++m) {
+        if (tid == 0) {
+            bool ok = c3_wait(g.flags + i * T + m, want2, g.fail);
+            if (ok && !diag) ok = c3_wait(g.flags + j * T + m, want2, g.fail);
+            c3_lds_set(s_ok, ok ? 1 : 0);
+        }
+        __syncthreads();  // also: the previous product is done with the operand tiles
+        if (!c3_lds_get(s_ok)) return;
+        double vi[4], vj[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int idx = tid + 1024 * t, r = idx & 63, kk = idx >> 6;
+            vi[t] = c3_ld_at(A, n, r0 + r, 64 * m + kk, r0 + r < n);
+            vj[t] = c3_ld_at(A, n, c0 + r, 64 * m + kk, !diag && c0 + r < n);
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int idx = tid + 1024 * t, r = idx & 63, kk = idx >> 6;
+            Li[kk * C3_LD + r] = vi[t];
+            if (!diag) Lj[kk * C3_LD + r] = vj[t];
+        }
+        __syncthreads();
+        const double* Pj = diag ? Li : Lj;
+        if (!diag || cb <= rb) {
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks) {
+                const double av = Pj[(4 * ks + g4) * C3_LD + 16 * cb + e16];
+                const double bv = Li[(4 * ks + g4) * C3_LD + 16 * rb + e16];
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+            }
+        }
+    }
+    if (kind != 2) {
+        // ---- hand the tile to the chain: all panels but the last applied
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int cc = 16 * cb + g4 + 4 * reg;
+            const int row = r0 + rr, col = c0 + cc;
+            if (row < n && col < n && (!diag || cc <= rr)) c3_st(A + (size_t)row + (size_t)col * n, old[reg] - acc[reg]);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) c3_st_flag(g.flags + i * T + j, want1);
+        return;
+    }
+    // ---- panel solve as a product: L(i,j) = A' L_jj^-T, X[r][c] = sum_m A'[r][m] Linv[c][m]
+    __syncthreads();  // the last product is done with the operand tiles
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) Li[(16 * cb + g4 + 4 * reg) * C3_LD + 16 * rb + e16] = old[reg] - acc[reg];  // [m][r]
+    if (tid == 0) c3_lds_set(s_ok, c3_wait(g.flags + j * T + j, want2, g.fail) ? 1 : 0);
+    __syncthreads();
+    if (!c3_lds_get(s_ok)) return;
+    {
+        double v[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) v[t] = c3_ld(g.Linv + (size_t)j * 4096 + tid + 1024 * t);  // [m][c]: column m of L^-1
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { const int idx = tid + 1024 * t; Lj[(idx >> 6) * C3_LD + (idx & 63)] = v[t]; }
+        if (tid < 64) { const double yy = c3_ld(g.b + (c0 + tid < n ? c0 + tid : n - 1)); yv[tid] = (c0 + tid < n) ? yy : 0.0; }
+    }
+    __syncthreads();
+    chol_d4 x = chol_d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+        const double av = Lj[(4 * ks + g4) * C3_LD + 16 * cb + e16];
+        const double bv = Li[(4 * ks + g4) * C3_LD + 16 * rb + e16];
+        x = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, x, 0, 0, 0);
+    }
+    double s = 0.0;
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+        const int cc = 16 * cb + g4 + 4 * reg;
+        const int row = r0 + rr, col = c0 + cc;
+        if (row < n && col < n) c3_st(A + (size_t)row + (size_t)col * n, x[reg]);
+        s = fma(x[reg], yv[cc], s);
+    }
+    s += __shfl_xor(s, 16);
+    s += __shfl_xor(s, 32);
+    if (g4 == 0) part[cb * 64 + 16 * rb + e16] = s;
+    __syncthreads();
+    if (tid < 64) c3_st(g.Cc + ((size_t)i * T + j) * 64 + tid, (part[tid] + part[64 + tid]) + (part[128 + tid] + part[192 + tid]));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) c3_st_flag(g.flags + i * T + j, want2);
+    if (g.mirror) {
+        // ---- L^T for the back-substitution kernel, behind the flag: the tile goes through LDS ([column][row], stride 65) so that a
+        // wave stores 64 consecutive addresses (as 8-byte stores scattered over 64 lines they sat in front of the drain: +25 us)
+        double* Xt = Lj;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) Xt[(16 * cb + g4 + 4 * reg) * 65 + rr] = x[reg];
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int idx = tid + 1024 * t, c = idx & 63, r = idx >> 6;
+            if (r0 + r < n && c0 + c < n) c3_gst(A + (size_t)(c0 + c) + (size_t)(r0 + r) * n, Xt[c * 65 + r]);
+        }
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_chol_tiles(C3Args g, const int* gate) {
+    SATBA_GATE(gate);
+    extern __shared__ __attribute__((aligned(16))) double c3_lds[];
+    int* s_task = reinterpret_cast<int*>(c3_lds + 3 * 8 * C3_BLK + 64 * C3_TBS + 64 + 64 + 128 + 512) + 60;  // (all LDS in the dynamic region: 16-byte aligned base)
+    const int T = (g.n + 63) / 64;
+    const int n_tasks = c3_task_count(T);
+    for (;;) {
+        __syncthreads();
+        if (threadIdx.x == 0) c3_lds_set(s_task, atomicAdd(g.ctr, 1));
+        __syncthreads();
+        const int task = c3_lds_get(s_task);
+        if (task >= n_tasks) break;
+        if (task == 0) {
+            c3_chain(g, T);
+        } else {
+            int i, j, kind;
+            c3_task(T, task, i, j, kind);
+            c3_owner(g, T, i, j, kind);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int done = atomicAdd(g.ctr + 1, 1);
+        if (done == (int)gridDim.x - 1) { g.ctr[0] = 0; g.ctr[1] = 0; }  // the last workgroup leaves the counters clean
+    }
+}
+
+inline int chol_tiles_grid(int n) {
+    const int n_tasks = c3_task_count((n + 63) / 64);
+    return n_tasks < 256 ? n_tasks : 256;
+}
+
+inline void chol_tiles_init() {
+    static const bool once = [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chol_tiles), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c3_lds_bytes());
+        return true;
+    }();
+    (void)once;
+}
+
+}  // namespace satba
