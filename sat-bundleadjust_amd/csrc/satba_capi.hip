@@ -82,18 +82,7 @@ struct satba_problem {
     struct LmSummary* h_lm = nullptr;  // pinned, mapped: the device posts the progress of the loop here
     struct LmSummary* h_lm_dev = nullptr;
     long long lm_ticks_queued = 0;
-    hipGraphExec_t lm_graph = nullptr;  // the captured tick
-    bool lm_no_graph = false;           // the handle's stream cannot be captured (the legacy default stream): direct launches
     hipStream_t own_stream = nullptr;   // created with the handle: the stream of every launch unless satba_set_stream names another
-    struct LmGraphKey {
-        const void *x, *xnew, *camc, *fxcost, *xb, *x0;
-        hipStream_t stream;
-        int loss;
-        double f_scale;
-        int cam_sums_lds;
-        double lam_floor;
-        bool fxcost_valid;
-    } lm_key{};
     double f_scale = 1.0, lead = 1.0;
     hipStream_t stream = nullptr;
     Layout L;
@@ -117,24 +106,14 @@ struct satba_problem {
     SchurItem* d_item_desc_merged = nullptr;
     int n_item_blocks_merged = 0;
     int n_item_blocks = 0;
-    // factorisation overlapped with the Schur pass (cholesky_solve_overlapped): column ranges of S, the camera rows that complete
-    // them, an item table per range (chunked and merged), the second stream and its events
-    CholOverlap ov;
-    int seg_cam_end[CH_MAX_SEG] = {0, 0, 0, 0};
-    int2* d_seg_items[2][CH_MAX_SEG] = {};
-    SchurItem* d_seg_desc[2][CH_MAX_SEG] = {};
-    int n_seg_blocks[2][CH_MAX_SEG] = {};
-    hipStream_t stream2 = nullptr;
-    hipEvent_t ev_done = nullptr;
-
     int lin_grid = 0, cm_chunks = 1, cm_chunks_w = 1;  // chunks of the camera-major passes (unit weights and k_cam_sums | weighted / robust k_schur_diag)
     double* d_red = nullptr;  // RED_SLOTS x (RED_MAX_NV x RED_MAX_GRID doubles) partials of the deterministic grid sums
     unsigned* d_red_cnt = nullptr;
     double* d_stage = nullptr;  // staging for host transfers in the caller's order
     size_t stage_len = 0;
     int* d_fail = nullptr;
-    int chol_mode = 0;  // SATBA_CHOL: 0 double steps (default), 2 single steps, 3 double steps + triangular backward substitution
-    double* d_dinv = nullptr;  // inverted diagonal blocks of the factor
+    double* d_dinv = nullptr;  // inverted 32 x 32 diagonal blocks of the factor (backward substitution)
+    CholWork chol;             // scratch of the tile factorisation (satba_chol3.h)
     double* d_scal = nullptr;  // 8 private scalars (costs of satba_residuals, timing sinks)
     double* d_keep = nullptr;  // SATBA_KEEP_LEN scalars of the running iteration that outlive the per-phase headers
     bool prepared = false;
@@ -432,39 +411,6 @@ static int launch_schur(satba_problem* p, const ObsArgs& a, double* S, double* r
     return 0;
 }
 
-// the Schur kernels of the overlapped path: diagonal blocks first, then the pair kernel once per column range with an event behind it
-template <int MODEL, int NP>
-static int launch_schur_segments(satba_problem* p, const ObsArgs& a, double* S, double* rhs) {
-    CamMajor cm = cam_major(p);
-    SchurArgs s0 = schur_args(p);
-    const int dchunks = (a.sc && MODEL != RPC) ? p->cm_chunks_w : p->cm_chunks;
-    s0.diag_xcd = (dchunks % 8 == 0 && !getenv("SATBA_NO_DIAG_XCD")) ? 1 : 0;
-    hipLaunchKernelGGL((k_schur_diag<MODEL, NP>), dim3(p->M, dchunks), dim3(LINC_THREADS), 0, p->stream, a, cm, s0, p->d_part3);
-    const int total = p->M * cam_acc_len(NP);
-    hipLaunchKernelGGL(k_schur_diag_finish, dim3((8 * total + 255) / 256), dim3(256), 0, p->stream, p->M, NP, p->n_c, dchunks, p->d_part3, S, rhs, p->gate);
-    HIP_TRY(hipGetLastError());
-    const bool merged = a.unit && p->d_seg_desc[1][0];
-    for (int sg = 0; sg < p->ov.n_seg; ++sg) {
-        SchurArgs s = s0;
-        s.desc = p->d_seg_desc[merged ? 1 : 0][sg]; s.items = p->d_seg_items[merged ? 1 : 0][sg];
-        if (merged) s.n_chunks = 1;
-        const dim3 igrid((unsigned)p->n_seg_blocks[merged ? 1 : 0][sg]);
-        if (a.unit) hipLaunchKernelGGL((k_schur_pairs<MODEL, NP, true>), igrid, dim3(256), 0, p->stream, a, s, S);
-        else hipLaunchKernelGGL((k_schur_pairs<MODEL, NP, false>), igrid, dim3(256), 0, p->stream, a, s, S);
-        if (p->L.C > 1 && !merged) {
-            const int lo = sg ? p->seg_cam_end[sg - 1] : 0, hi = std::min(p->seg_cam_end[sg], p->M - 1);
-            const long long p_lo = pair_index(p->M, lo, lo + 1), p_hi = hi > lo ? pair_index(p->M, hi - 1, p->M - 1) + 1 : p_lo;
-            const long long cnt = p_hi - p_lo;
-            if (cnt > 0)
-                hipLaunchKernelGGL(k_schur_pairs_reduce, dim3((unsigned)((cnt * NP * NP + 255) / 256)), dim3(256), 0, p->stream, p->M, NP, p->n_c, p->L.C,
-                                   p->L.pair_ij, p->d_pair_part, S, p->gate, p_lo, cnt);
-        }
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipEventRecord(p->ov.ready[sg], p->stream));
-    }
-    return 0;
-}
-
 static int launch_schur_kernel(satba_problem* p) {
     ObsArgs a = obs_args(p, false);
     double* S = p->payload();
@@ -506,8 +452,7 @@ static int launch_jvp(satba_problem* p, int nv, const double* q1, const double* 
 
 // S z = rhs for the reduced system (S column-major lower, destroyed; b in place)
 static int dense_solve(satba_problem* p, double* S, double* b, bool cleared = false) {
-    cholesky_solve(S, p->n_c, b, p->d_fail, p->d_fail + 1, p->chol_mode == 3 ? 0 : p->chol_mode, p->stream, nullptr,
-                   p->chol_mode == 3 ? nullptr : p->d_dinv, cleared, p->gate);  // clears d_fail and the step flags unless the caller has
+    cholesky_solve(S, p->n_c, b, p->d_fail, p->d_fail + 1, p->stream, p->chol, p->d_dinv, cleared, p->gate);  // clears d_fail and the flags unless the caller has
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -529,28 +474,17 @@ static double ms_since(std::chrono::steady_clock::time_point t0) {
 // Dispatch order of the (pair, chunk) items of k_schur_pairs (see the kernel's comment).  The rows of the pair triangle
 // (all pairs (i, j > i) of one camera i) are dealt to the 8 XCDs longest-first onto the least loaded one; an XCD's items
 // are ordered row by row, chunk by chunk; workgroup b = 8 s + x takes the s-th group of 4 items of XCD x.
-// SATBA_SCHUR_ORDER=chunk restores round 1's chunk-major order (A/B runs).
 // merged: one item per pair covering all its chunks (chunk = -1 in the table): the unit-weight kernels gather nothing per
 // observation and are faster with four times fewer, longer items (0.548 vs 0.576 ms at 200 x 1M x 10M) -- the weighted / robust
 // kernels are not (their row-scale gathers want the locality of the point-range chunks: 1.58 vs 1.74 ms with two chunks).
-static int schur_item_table_build(satba_problem* p, bool merged, int2** d_items, SchurItem** d_desc, int* n_blocks, int cam_lo = 0, int cam_hi = -1) {
-    // cam_lo, cam_hi: only the pairs (i, j > i) of the camera rows cam_lo <= i < cam_hi (default: all)
+static int schur_item_table_build(satba_problem* p, bool merged, int2** d_items, SchurItem** d_desc, int* n_blocks) {
     const int M = p->M, C = merged ? 1 : p->L.C, X = 8;
-    if (cam_hi < 0) cam_hi = M;
-    const long long n_pairs = p->L.n_pairs;
     std::vector<int2> table;
-    const char* ord = getenv("SATBA_SCHUR_ORDER");
     auto item = [&](long long pr, int ch) { return make_int2((int)pr, merged ? -1 : ch); };
-    if (ord && !strcmp(ord, "chunk")) {
-        for (int ch = 0; ch < C; ++ch) {
-            for (long long pr = 0; pr < n_pairs; ++pr) table.push_back(item(pr, ch));
-            while (table.size() % 4) table.push_back(make_int2(-1, 0));
-        }
-        (void)cam_lo;  // (the chunk-major order of round 1 is kept for A/B runs of the whole table only)
-    } else {
+    {
         std::vector<std::vector<int2>> per(X);
         std::vector<long long> load(X, 0);
-        for (int i = cam_lo; i + 1 < M && i < cam_hi; ++i) {  // rows by decreasing length: i ascending
+        for (int i = 0; i + 1 < M; ++i) {  // rows by decreasing length: i ascending
             int x = 0;
             for (int k = 1; k < X; ++k) if (load[k] < load[x]) x = k;
             load[x] += M - 1 - i;
@@ -583,40 +517,6 @@ static int schur_item_table(satba_problem* p) {
     // ... where the pairs alone fill the chip: with few cameras the chunks are what provides the parallelism (50 cameras: 1 225 pairs)
     const bool enough = p->L.n_pairs >= 8192 || (mg && atoi(mg) != 0);
     if (p->L.C > 1 && enough && !(mg && atoi(mg) == 0)) TRY(schur_item_table_build(p, true, &p->d_items_merged, &p->d_item_desc_merged, &p->n_item_blocks_merged));
-    // Column ranges for the overlapped factorisation: a quarter, a quarter, a half of the columns (boundaries at multiples of 64):
-    // the first camera rows hold most of the pairs, so the first range is complete after ~44 % of the pair work, the second after
-    // ~75 %.  Worth it from ~8 double steps of the factorisation on; one rank only (with several the system is all-reduced first).
-    p->ov.n_seg = 1;
-    p->ov.col_end[0] = p->n_c;
-    p->seg_cam_end[0] = p->M;
-    // MEASURED (200 x 1 M x 10 M, profiles/r3_overlap.txt): the overlap works -- and loses.  Next to the pair kernel's gather traffic
-    // a double step takes 32.5 us instead of 23.7 (the chain is bound by memory latency, which goes up under load), the pair kernel
-    // in three launches takes 507 us instead of 394 (three tails, and the factorisation's workgroups in its way), the two catch-ups
-    // add 63 us: 1.55 ms per iteration against 1.47.  A lowest-priority stream or every fourth CU reserved for the factorisation
-    // (hipExtStreamCreateWithCUMask) changed nothing (switches removed).  The path is kept behind SATBA_OVERLAP=1 (tests/test_gpu_layout.py runs it).
-    if (getenv("SATBA_OVERLAP") && p->world == 1 && p->n_c >= 512 && p->L.n_pairs > 0 && p->L.E > 0 && p->chol_mode == 0 && p->n_c <= 1024) {
-        const int q = ((p->n_c / 4 + 32) / 64) * 64;
-        const int ends[3] = {q, 2 * q, p->n_c};
-        p->ov.n_seg = 3;
-        for (int s = 0; s < 3; ++s) {
-            p->ov.col_end[s] = ends[s];
-            p->seg_cam_end[s] = s == 2 ? p->M : std::min(p->M, (ends[s] + p->NP - 1) / p->NP);
-            HIP_TRY(hipEventCreateWithFlags(&p->ov.ready[s], hipEventDisableTiming));
-        }
-        HIP_TRY(hipEventCreateWithFlags(&p->ev_done, hipEventDisableTiming));
-        {   // the factorisation's stream gets the highest priority: its few workgroups are the latency chain, the pair kernel's thousands fill
-            // whatever is left of the chip
-            int pr_least = 0, pr_greatest = 0;
-            HIP_TRY(hipDeviceGetStreamPriorityRange(&pr_least, &pr_greatest));
-            HIP_TRY(hipStreamCreateWithPriority(&p->stream2, hipStreamNonBlocking, pr_greatest));
-        }
-        const bool merged_ok = p->d_item_desc_merged != nullptr;
-        for (int s = 0; s < 3; ++s) {
-            const int lo = s ? p->seg_cam_end[s - 1] : 0, hi = p->seg_cam_end[s];
-            TRY(schur_item_table_build(p, false, &p->d_seg_items[0][s], &p->d_seg_desc[0][s], &p->n_seg_blocks[0][s], lo, hi));
-            if (merged_ok) TRY(schur_item_table_build(p, true, &p->d_seg_items[1][s], &p->d_seg_desc[1][s], &p->n_seg_blocks[1][s], lo, hi));
-        }
-    }
     return 0;
 }
 
@@ -881,8 +781,15 @@ int satba_problem_create(const satba_problem_desc* d, satba_problem** out) {
         TRY(dev_alloc(p, &p->d_f, Pz)); TRY(dev_alloc(p, &p->d_ftmp, Pz)); TRY(dev_alloc(p, &p->d_sc, Kz));
         if (p->model == RPC) TRY(dev_alloc(p, &p->d_Jpm, Kz * jrow_stride(p->NP)));
         TRY(dev_alloc(p, &p->d_fail, 1 + CH_MAX_STEPS));  // [0] not-SPD flag, then the panel-step flags
-        { const char* cs = getenv("SATBA_CHOL"); p->chol_mode = cs ? atoi(cs) : 0; }
         TRY(dev_alloc(p, &p->d_dinv, (size_t)((p->n_c + CH_NB - 1) / CH_NB) * CH_NB * CH_NB));
+        {   // scratch of the tile factorisation: tile flags (zeroed once: they carry epochs), inverted 64 x 64 diagonal blocks, the tiles'
+            // shares of the forward substitution, ticket counters
+            const size_t T = (size_t)(p->n_c + 63) / 64;
+            TRY(dev_alloc(p, &p->chol.flags, T * T + 1)); TRY(dev_alloc(p, &p->chol.Linv, T * 4096 + 1)); TRY(dev_alloc(p, &p->chol.Cc, T * T * 64 + 1));
+            TRY(dev_alloc(p, &p->chol.ctr, 4));
+            HIP_TRY(hipMemset(p->chol.flags, 0, sizeof(int) * (T * T + 1)));
+            HIP_TRY(hipMemset(p->chol.ctr, 0, sizeof(int) * 4));
+        }
         TRY(dev_alloc(p, &p->d_scal, 8));
         TRY(dev_alloc(p, &p->d_fx, 2 * 6)); TRY(dev_alloc(p, &p->d_fxe, 6 + 4)); TRY(dev_alloc(p, &p->d_bbox, 6)); TRY(dev_alloc(p, &p->d_fxflag, 1));
         TRY(dev_alloc(p, &p->d_fxcost, 1)); TRY(dev_alloc(p, &p->d_fxcost_new, 1)); TRY(dev_alloc(p, &p->d_fxcost0, 1));
@@ -953,11 +860,7 @@ void satba_problem_destroy(satba_problem* p) {
     for (hipEvent_t e : p->prof_ev) (void)hipEventDestroy(e);
     if (p->h_pin) (void)hipHostFree(p->h_pin);
     if (p->h_lm) (void)hipHostFree(p->h_lm);
-    if (p->lm_graph) (void)hipGraphExecDestroy(p->lm_graph);
     if (p->own_stream) (void)hipStreamDestroy(p->own_stream);
-    if (p->stream2) (void)hipStreamDestroy(p->stream2);
-    for (int s = 0; s < CH_MAX_SEG; ++s) if (p->ov.ready[s]) (void)hipEventDestroy(p->ov.ready[s]);
-    if (p->ev_done) (void)hipEventDestroy(p->ev_done);
     delete p;
 }
 
@@ -1199,52 +1102,8 @@ static int schur_impl(satba_problem* p, double lam, bool automatic, double Delta
     return 0;
 }
 
-// ---- single rank: Schur complement and dense solve in one go, the factorisation overlapped with the pair kernels.
-// The diagonal blocks and the right-hand side come first; the pair kernel runs once per column range of S (the camera rows that
-// complete it) on the handle's stream and records an event behind each; on the second stream the factorisation waits for the
-// range it is about to touch (cholesky_solve_overlapped), scales it, catches it up with the panels factorised so far and carries
-// on.  The handle's stream picks up again behind the back-substitution of the dense system.
-static bool overlap_ok(const satba_problem* p) { return p->ov.n_seg > 1 && p->world == 1 && p->chol_mode == 0; }
-
-static int schur_solve_overlapped(satba_problem* p, double lam, bool automatic, double Delta, double lam_floor) {
-    const double* lam_dev = automatic ? p->d_keep + 5 : nullptr;
-    if (p->N > 0) {
-        hipLaunchKernelGGL(k_vinv, dim3((p->N + VINV_THREADS - 1) / VINV_THREADS), dim3(VINV_THREADS), 0, p->stream, p->N, lam, automatic ? p->d_xb : nullptr, Delta, lam_floor,
-                           p->d_keep, p->d_V, p->d_scale_inv + p->n_c, p->d_Vinv, p->d_x + p->n_c, p->d_g + p->n_c, p->d_PV, p->L.perm, p->n_pts_fix,
-                           automatic ? p->Delta_dev : nullptr, automatic ? p->lam_force_dev : nullptr, p->gate);
-    } else if (automatic) {
-        hipLaunchKernelGGL(k_lambda, dim3(1), dim3(1), 0, p->stream, p->d_xb, Delta, lam_floor, p->d_keep, p->Delta_dev, p->lam_force_dev, p->gate);
-    }
-    double* S = p->payload();
-    double* rhs = S + (size_t)p->n_c * p->n_c;
-    hipLaunchKernelGGL(k_schur_init, dim3((std::max<long long>((long long)p->n_c * p->NP, p->hdr) + 255) / 256), dim3(256), 0, p->stream, p->M, p->NP,
-                       lam, lam_dev, p->lead, p->d_gc, p->d_scale_inv, S, rhs, p->d_xb, (int)p->hdr, p->gate);
-    HIP_TRY(hipGetLastError());
-    ObsArgs a = obs_args(p, false);
-    SATBA_DISPATCH(p, TRY((launch_schur_segments<MODEL, NP>(p, a, S, rhs))));
-    // the factorisation, on the second stream
-    const int* gate = p->gate;
-    cholesky_solve_overlapped(S, p->n_c, p->d_dch, p->d_fail, p->d_fail + 1, p->stream2, p->d_dinv, gate, p->ov, [&](int sg) {
-        const int lo = sg ? p->ov.col_end[sg - 1] : 0, hi = p->ov.col_end[sg];
-        hipLaunchKernelGGL(k_scale_system, dim3(grid_for((long long)(hi - lo) * p->n_c, 256, 2048)), dim3(256), 0, p->stream2, p->n_c, p->d_scale_inv, S, rhs,
-                           p->d_dch, p->d_fail, 1 + CH_MAX_STEPS, gate, lo, hi);
-    });
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(p->ev_done, p->stream2));
-    HIP_TRY(hipStreamWaitEvent(p->stream, p->ev_done, 0));
-    const int nu = std::max(p->n_c, (int)p->hdr);
-    hipLaunchKernelGGL(k_unscale, dim3((nu + 255) / 256), dim3(256), 0, p->stream, p->n_c, p->d_scale_inv, p->d_dch, p->d_dc, (int)p->hdr,
-                       p->d_xb, p->d_fail, p->lead, p->d_keep, SATBA_HDR_KEEP, SATBA_KEEP_LEN, p->gate);
-    HIP_TRY(hipGetLastError());
-    TRY(launch_backsub_kernel(p));
-    p->prepared = false;
-    p->have_step = true;
-    return 0;
-}
-
-// schur (+ auto damping) and solve of a front, overlapped where the handle supports it
+// schur (+ auto damping) and solve of a front
 static int front_schur_solve(satba_problem* p, bool automatic, double lam, double Delta, double lam_floor) {
-    if (overlap_ok(p)) return schur_solve_overlapped(p, lam, automatic, Delta, lam_floor);
     if (automatic) TRY(satba_schur_auto(p, Delta, lam_floor));
     else TRY(satba_schur(p, lam));
     return satba_solve(p);
@@ -1512,49 +1371,10 @@ static int lm_launch_sub_pattern(satba_problem* p) {
     return lm_launch_tail(p);
 }
 
-// The tick's launches do not depend on data: they are captured once into a hipGraph and replayed (one graph launch instead of ~40
-// kernel launches per tick).  The capture is keyed by everything a launch argument or a kernel variant depends on.
-static bool lm_graph_key_matches(const satba_problem* p, double lam_floor) {
-    const satba_problem::LmGraphKey& k = p->lm_key;
-    return p->lm_graph && k.x == p->d_x && k.xnew == p->d_xnew && k.camc == p->d_camc && k.fxcost == p->d_fxcost && k.xb == p->d_xb && k.x0 == p->d_x0 &&
-           k.stream == p->stream && k.loss == p->loss && k.f_scale == p->f_scale && k.cam_sums_lds == p->cam_sums_lds && k.lam_floor == lam_floor &&
-           k.fxcost_valid == p->fxcost_valid;
-}
-
+// one tick (direct launches: a captured hipGraph of the pattern was measured in round 3 -- 2 - 9 us between its nodes where back-to-back
+// launches leave none, ~30 us in front of every replay, profiles/r3_graph_gaps.txt -- and removed in round 4)
 static int lm_queue_tick(satba_problem* p, double lam_floor) {
-    // Measured on MI355X / ROCm 7.0 (profiles/r3_graph_gaps.txt): the replayed graph leaves 2 - 9 us between its nodes where back-to-back
-    // launches on the stream leave none, and ~30 us in front of every replay; the host is never the bottleneck here (it queues
-    // LM_RUN_AHEAD ticks ahead).  10 x 5 k x 30 k: 6 317 it/s with the graph, 6 312 without; 200 x 1 M x 10 M: 681 / 685.  The graph is
-    // therefore opt-in (SATBA_GRAPH=1).
-    static const bool use_graph = getenv("SATBA_GRAPH") != nullptr;
-    const bool direct = !use_graph || p->lm_no_graph || p->prof_lin || (p->loss == 0 && !p->fxcost_valid);  // (the cost-only pass of a first linearisation is not part of the pattern)
-    if (direct) {
-        TRY(lm_launch_tick(p, lam_floor));
-    } else {
-        if (!lm_graph_key_matches(p, lam_floor)) {
-            if (p->lm_graph) { (void)hipGraphExecDestroy(p->lm_graph); p->lm_graph = nullptr; }
-            hipGraph_t g = nullptr;
-            if (hipStreamBeginCapture(p->stream, hipStreamCaptureModeRelaxed) != hipSuccess) {
-                (void)hipGetLastError();
-                p->lm_no_graph = true;  // e.g. the legacy default stream
-                TRY(lm_launch_tick(p, lam_floor));
-                p->linearized = true; p->prepared = false; p->have_step = true;
-                p->fxcost_valid = true; p->fxcost_new_valid = false;
-                ++p->lm_ticks_queued;
-                return 0;
-            }
-            const int rc = lm_launch_tick(p, lam_floor);
-            const hipError_t e = hipStreamEndCapture(p->stream, &g);
-            if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
-            if (e != hipSuccess) return fail(SATBA_E_HIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
-            const hipError_t e2 = hipGraphInstantiate(&p->lm_graph, g, nullptr, nullptr, 0);
-            (void)hipGraphDestroy(g);
-            if (e2 != hipSuccess) { p->lm_graph = nullptr; return fail(SATBA_E_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e2)); }
-            p->lm_key = satba_problem::LmGraphKey{p->d_x, p->d_xnew, p->d_camc, p->d_fxcost, p->d_xb, p->d_x0, p->stream, p->loss, p->f_scale, p->cam_sums_lds,
-                                                  lam_floor, p->fxcost_valid};
-        }
-        HIP_TRY(hipGraphLaunch(p->lm_graph, p->stream));
-    }
+    TRY(lm_launch_tick(p, lam_floor));
     // what the host-side flags say after a tick: the linearisation and the step belong to the point the device ends up at
     p->linearized = true; p->prepared = false; p->have_step = true;
     p->fxcost_valid = true; p->fxcost_new_valid = false;
@@ -1571,7 +1391,7 @@ static int lm_read_state(satba_problem* p, LmDev* host) {
 // whether this handle can run the device-resident loop: one rank, default dense-solver mode (its kernels carry the gates)
 static bool lm_device_loop_ok(const satba_problem* p) {
     const bool off = getenv("SATBA_HOST_LOOP") != nullptr;  // A/B runs and the tests' comparison of the two loops (read per call)
-    return !off && p->world == 1 && (p->chol_mode == 0) && p->n_c <= 1024;
+    return !off && p->world == 1 && p->n_c <= 1024;
 }
 // ... and whether it pays: its three extra launches per iteration (two decisions, the copy of the accepted point) cost what the two
 // header reads of the host loop cost at ~1.4 ms per iteration (200 x 1 M x 10 M: 681 against 696 it/s; soft_l1 353 / 372), and
@@ -1595,7 +1415,9 @@ static int lm_drive(satba_problem* p, double lam_floor, long long max_ticks) {
         // (a profiled run -- HIP events around every k_linearize launch -- does not run ahead: no switched-off launch is timed)
         unsigned long long w;
         while (lm_summary_tick(w = __atomic_load_n(&p->h_lm->word, __ATOMIC_ACQUIRE)) + (p->prof_lin ? 0 : LM_RUN_AHEAD) < p->lm_ticks_queued) {
+#if defined(__x86_64__)
             __builtin_ia32_pause();
+#endif
             if (ms_since(t_wait) > 60000.0) return fail(SATBA_E_HIP, "device-resident loop: no progress report from the device for 60 s");
         }
         const int phase = lm_summary_phase(w);
@@ -1851,21 +1673,6 @@ int satba_set_exchange(satba_problem* p, int64_t offset, int64_t n, const double
     return 0;
 }
 
-// tools only (tools/chol_times.py): wall-clock stamps (100 MHz) of every launch of one factorisation of the current reduced
-// system in the configured mode (SATBA_CHOL); host_out holds CH_TS * CH_MAX_STEPS values, CH_TS per launch.  Destroys S.
-int satba_debug_chol_times(satba_problem* p, long long* host_out, int32_t* n_steps) {
-    if (!p || !host_out || !n_steps) return fail(SATBA_E_ARG, "null argument");
-    long long* d_ts = nullptr;
-    HIP_TRY(hipMalloc((void**)&d_ts, sizeof(long long) * CH_TS * CH_MAX_STEPS));
-    HIP_TRY(hipMemset(d_ts, 0, sizeof(long long) * CH_TS * CH_MAX_STEPS));
-    cholesky_solve(p->payload(), p->n_c, p->d_dch, p->d_fail, p->d_fail + 1, p->chol_mode == 3 ? 0 : p->chol_mode, p->stream, d_ts);
-    HIP_TRY(hipStreamSynchronize(p->stream));
-    HIP_TRY(hipMemcpy(host_out, d_ts, sizeof(long long) * CH_TS * CH_MAX_STEPS, hipMemcpyDeviceToHost));
-    HIP_TRY(hipFree(d_ts));
-    *n_steps = (p->n_c + CH_NB - 1) / CH_NB;
-    return 0;
-}
-
 int satba_profile_linearize(satba_problem* p, int32_t on) {
     if (!p) return fail(SATBA_E_ARG, "null handle");
     p->prof_lin = on != 0;
@@ -1952,7 +1759,6 @@ int satba_get_info(const satba_problem* p, double* out, int32_t n) {
     out[5] = p->L.P; out[6] = (double)p->L.E; out[7] = p->L.C; out[8] = p->unit_weights; out[9] = p->camc_lds; out[10] = p->rpc_lds;
     out[11] = p->cam_sums_lds; out[12] = p->deterministic; out[13] = p->cm_chunks; out[14] = p->lin_grid; out[15] = p->fx_fallbacks;
     if (n > 16) out[16] = (lm_device_loop_ok(p) && lm_device_loop_pays(p)) ? 1.0 : 0.0;
-    if (n > 17) out[17] = p->ov.n_seg;
     return 0;
 }
 

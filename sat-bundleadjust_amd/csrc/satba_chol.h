@@ -4,17 +4,13 @@
 // block pairs (a, b) with a <= b, which land in the column-major lower triangle).  This replaces the LSMR
 // iteration of scipy:optimize/_lsq/trf.py:479-480 by an exact factorisation.
 //
-// Blocked right-looking Cholesky, 32-column panels, ONE launch per panel (k_chol_step): the workgroup that owns
-// 64x64 tile (i, j) of the trailing matrix first applies the previous panel to it (4x4 outputs per thread, panel
-// staged in LDS); the tiles of the first tile column then go on to the current panel.  Tile (0, 0) holds the next
-// diagonal block and 32 panel rows: one wave factorises it in registers (lane = row, column broadcasts by
-// v_readlane, no LDS, no barriers; the panel rows ride along in lanes 32..63), publishes L_kk and raises a flag in
-// global memory; the waves of tiles (i > 0, 0) wait for the flag and solve their 64 panel rows against L_kk, again
-// by readlane broadcasts.  Tile (0, 0) is workgroup 0 of a 1-D grid, so the flag setter is always resident before
-// any waiter.  The right-hand side is carried along (forward substitution folded in).  k_trsv_back finishes with
-// a left-looking backward substitution in one workgroup.
+// More than 64 unknowns: ONE persistent launch factorises the matrix in 64 x 64 tiles and carries the right-hand side along
+// (k_chol_tiles, satba_chol3.h), then the multi-workgroup backward substitution (k_trsv_back_mw).  Up to 64 unknowns (one tile; the
+// reference's usual 2 .. 20 images x 3 parameters): the panel steps of rounds 1 - 2 below -- k_chol_dstep (two 32-column panels per
+// launch, satba_chol2.h) or k_chol_step (one) -- and a one-wave backward substitution; there the tile kernel's fixed cost
+// (31 us against 16 - 27) does not pay.
 // fp64 MFMA runs at the vector rate on gfx950 and the matrix is tiny: the solve is bound by the latency of the
-// dependent panel chain, not by flops; see DESIGN.md.
+// dependent pivot chain (tools/ubench/dp_latency.hip: 92 ns per column at best), not by flops; see DESIGN.md.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -395,206 +391,14 @@ __global__ __launch_bounds__(1024) void k_trsv_back(const double* __restrict__ L
     for (int i = tid; i < n; i += 1024) b[i] = yb[i];
 }
 
-// Copy the strict lower triangle of A to the upper one (A[c + r n] = A[r + c n], r > c), 32 x 32 tiles through LDS.
-// The Schur kernels never touch the upper triangle; the backward substitution below reads L^T from it so that
-// neighbouring threads (columns) read neighbouring addresses.
-__global__ __launch_bounds__(256) void k_mirror_lower(double* __restrict__ A, int n) {
-    __shared__ double t[32][33];
-    const int T = (n + 31) / 32;
-    int bi = 0, idx = blockIdx.x;  // lower tiles (bi >= bj), row by row
-    while (idx > bi) { idx -= bi + 1; ++bi; }
-    const int bj = idx;
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    (void)T;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int r = bi * 32 + tx, c = bj * 32 + ty + 8 * k;
-        t[ty + 8 * k][tx] = (r < n && c < n) ? A[(size_t)r + (size_t)c * n] : 0.0;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int c = bj * 32 + tx, r = bi * 32 + ty + 8 * k;  // element (r, c) of the lower triangle goes to (c, r)
-        if (r < n && c < n && r > c) A[(size_t)c + (size_t)r * n] = t[tx][ty + 8 * k];
-    }
-}
-
-// L^T z = y for n <= 1024, right-looking, one workgroup, thread = column.  Per 32-row block (bottom up): wave 0
-// solves the diagonal block (readlane chain), then every thread c < k0 subtracts its 32-term dot product
-// L[k0:k0+32, c] . z_block  from its own entry, reading L^T from the mirrored upper triangle (coalesced).
-// L is static, so the operands of a step, and the next diagonal block, are requested BEFORE the solve of that step
-// and arrive behind it.  Measured alternatives that were slower (108 us at n = 1000 for this one): 8- and 16-row
-// blocks with 2-4 steps of operands in flight (145-250 us: the fixed cost per step, two workgroup barriers and the
-// LDS hand-offs, dominates, and the extra registers spill).
-__global__ __launch_bounds__(1024) void k_trsv_back_rl(const double* __restrict__ L, int n, double* __restrict__ b) {
-    __shared__ double yb[1024];
-    __shared__ double zs[CH_NB];
-    __shared__ double Dk[2][CH_NB][CH_NB + 1];  // Dk[.][r][c] = L[k0 + r][k0 + c], identity padded
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = tid;
-    const int nblk = (n + CH_NB - 1) / CH_NB;
-    auto load_diag = [&](int kb) {
-        const int k0 = kb * CH_NB, nb = min(CH_NB, n - k0);
-        const int r = tid % CH_NB, cc = tid / CH_NB;
-        Dk[kb & 1][r][cc] = (r < nb && cc <= r) ? L[(size_t)(k0 + r) + (size_t)(k0 + cc) * n] : ((r == cc) ? 1.0 : 0.0);
-    };
-    double yc = (c < n) ? b[c] : 0.0;
-    yb[c] = yc;
-    load_diag(nblk - 1);
-    __syncthreads();
-    for (int kb = nblk - 1; kb >= 0; --kb) {
-        const int k0 = kb * CH_NB, nb = min(CH_NB, n - k0);
-        double lv[CH_NB];
-        if (c < k0) {
-            const double* src = L + (size_t)c + (size_t)k0 * n;  // (row c, column k0 + r) of the upper triangle = L[k0 + r][c]
-#pragma unroll
-            for (int r = 0; r < CH_NB; ++r) lv[r] = (r < nb) ? src[(size_t)r * n] : 0.0;
-        }
-        if (kb > 0) load_diag(kb - 1);
-        if (wave == 0) {  // L_kk^T z = y_k, bottom up; lane = entry
-            const int cl = min(lane, CH_NB - 1);
-            double v = (lane < nb) ? yb[k0 + lane] : 0.0;
-            const double dinv = 1.0 / Dk[kb & 1][cl][cl];
-            double col[CH_NB];  // col[j] = L[j][lane]
-#pragma unroll
-            for (int j = 0; j < CH_NB; ++j) col[j] = Dk[kb & 1][j][cl];
-#pragma unroll
-            for (int j = CH_NB - 1; j >= 0; --j) {
-                const double zj = readlane_f64(v, j) * readlane_f64(dinv, j);
-                v = (lane == j) ? zj : ((lane < j) ? fma(-col[j], zj, v) : v);
-            }
-            if (lane < CH_NB) zs[lane] = v;
-            if (lane < nb) yb[k0 + lane] = v;
-        }
-        __syncthreads();
-        if (c < k0) {
-            double s0 = 0.0, s1 = 0.0;
-#pragma unroll
-            for (int r = 0; r < CH_NB; r += 2) { s0 = fma(lv[r], zs[r], s0); s1 = fma(lv[r + 1], zs[r + 1], s1); }
-            yc -= s0 + s1;
-            yb[c] = yc;
-        }
-        __syncthreads();
-    }
-    if (c < n) b[c] = yb[c];
-}
-
-
-// Inverse of every 32 x 32 diagonal block of the factor (lower triangular), one wave per block: lane c solves D x = e_c by
-// forward substitution in registers, the entries of D come as LDS broadcasts (every lane reads the same address).
-// dinv: n_blocks x 32 x 32, [r][c] row-major, identity padded.  Part of k_chol_finish below.
-
-// The mirror (k_mirror_lower) and the block inverses in one launch (they read the same finished factor and write different things): the first
-// `n_mirror` workgroups mirror 32 x 32 tiles, the others invert one diagonal block each with their first wave -- one launch gap
-// less on the chain, and the 12 us of the inversions run beside the 5 us of the mirror instead of behind it.
-__global__ __launch_bounds__(256) void k_chol_finish(double* __restrict__ A, int n, int n_mirror, double* __restrict__ dinv, const int* gate) {
-    SATBA_GATE(gate);
-    __shared__ double t[32][33];
-    if ((int)blockIdx.x < n_mirror) {
-        int bi = 0, idx = blockIdx.x;  // lower tiles (bi >= bj), row by row
-        while (idx > bi) { idx -= bi + 1; ++bi; }
-        const int bj = idx;
-        const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int r = bi * 32 + tx, c = bj * 32 + ty + 8 * k;
-            t[ty + 8 * k][tx] = (r < n && c < n) ? A[(size_t)r + (size_t)c * n] : 0.0;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int c = bj * 32 + tx, r = bi * 32 + ty + 8 * k;  // element (r, c) of the lower triangle goes to (c, r)
-            if (r < n && c < n && r > c) A[(size_t)c + (size_t)r * n] = t[tx][ty + 8 * k];
-        }
-        return;
-    }
-    if (threadIdx.x >= 64) return;
-    double (*D)[CH_NB + 1] = t;
-    const int kb = blockIdx.x - n_mirror, k0 = kb * CH_NB, nb = min(CH_NB, n - k0), lane = threadIdx.x;
-    for (int idx = lane; idx < CH_NB * CH_NB; idx += 64) {
-        const int r = idx % CH_NB, c = idx / CH_NB;
-        D[r][c] = (r < nb && c <= r) ? A[(size_t)(k0 + r) + (size_t)(k0 + c) * n] : ((r == c) ? 1.0 : 0.0);
-    }
-    __builtin_amdgcn_wave_barrier();
-    const int c = min(lane, CH_NB - 1);
-    double x[CH_NB];
-#pragma unroll
-    for (int r = 0; r < CH_NB; ++r) {
-        double s = (r == c) ? 1.0 : 0.0;
-#pragma unroll
-        for (int m = 0; m < r; ++m) s = fma(-D[r][m], x[m], s);
-        x[r] = s / D[r][r];
-    }
-    if (lane < CH_NB) {
-#pragma unroll
-        for (int r = 0; r < CH_NB; ++r) dinv[((size_t)kb * CH_NB + r) * CH_NB + c] = x[r];
-    }
-}
-
-// (Round 2 also tried superblocks of 128 rows -- 128 x 128 diagonal blocks inverted by 32 -> 64 -> 128 block recursion in LDS,
-// 8 steps instead of 32: the inversion took 70 us on its one workgroup per block and the substitution 134 us, because a
-// 1024-thread workgroup has 128 registers per thread: one 16-row chunk of operands in flight per thread, and the 16 waves run
-// in step behind the barriers, so every chunk paid the full ~2 us load latency.  Dropped.)
-// L^T z = y for n <= 1024 with the inverted diagonal blocks: right-looking, one workgroup, thread = column.  Per 32-row block
-// (bottom up): z_k = D_k^-T y_k is a 32 x 32 matrix-vector product in one wave (no dependent chain: the triangular solve of
-// k_trsv_back_rl took 2 us per block), then every thread c < k0 subtracts its 32-term dot product L[k0:k0+32, c] . z_k, reading
-// L^T from the mirrored upper triangle (coalesced).  The operands of a step and the next inverse block are requested before
-// the product of that step and arrive behind it.
-__global__ __launch_bounds__(1024) void k_trsv_back_dinv(const double* __restrict__ L, const double* __restrict__ dinv, int n,
-                                                         double* __restrict__ b) {
-    __shared__ double yb[1024 + CH_NB];
-    __shared__ double zs[CH_NB];
-    __shared__ double Dk[2][CH_NB][CH_NB + 1];  // Dk[.][r][c] = (D_k^-1)[r][c]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = tid;
-    const int nblk = (n + CH_NB - 1) / CH_NB;
-    auto load_dinv = [&](int kb) {
-        const int r = tid / CH_NB, cc = tid % CH_NB;
-        Dk[kb & 1][r][cc] = dinv[((size_t)kb * CH_NB + r) * CH_NB + cc];
-    };
-    double yc = (c < n) ? b[c] : 0.0;
-    yb[c] = yc;
-    if (tid < CH_NB) yb[1024 + tid] = 0.0;
-    load_dinv(nblk - 1);
-    __syncthreads();
-    for (int kb = nblk - 1; kb >= 0; --kb) {
-        const int k0 = kb * CH_NB, nb = min(CH_NB, n - k0);
-        double lv[CH_NB];
-        if (c < k0) {
-            const double* src = L + (size_t)c + (size_t)k0 * n;  // (row c, column k0 + r) of the upper triangle = L[k0 + r][c]
-#pragma unroll
-            for (int r = 0; r < CH_NB; ++r) lv[r] = (r < nb) ? src[(size_t)r * n] : 0.0;
-        }
-        if (kb > 0) load_dinv(kb - 1);
-        if (wave == 0) {  // z_j = sum_r Dinv[r][j] y[k0 + r]; lanes 32..63 take the second half of the sum
-            const int j = lane & (CH_NB - 1), h = lane >> 5;
-            double v = 0.0;
-#pragma unroll
-            for (int r = 0; r < CH_NB / 2; ++r) v = fma(Dk[kb & 1][h * (CH_NB / 2) + r][j], yb[k0 + h * (CH_NB / 2) + r], v);
-            v += __shfl_xor(v, 32);
-            __builtin_amdgcn_wave_barrier();  // every lane has read y_k
-            if (lane < CH_NB) { zs[lane] = v; yb[k0 + lane] = v; }
-        }
-        __syncthreads();
-        if (c < k0) {
-            double s0 = 0.0, s1 = 0.0;
-#pragma unroll
-            for (int r = 0; r < CH_NB; r += 2) { s0 = fma(lv[r], zs[r], s0); s1 = fma(lv[r + 1], zs[r + 1], s1); }
-            yc -= s0 + s1;
-            yb[c] = yc;
-        }
-        __syncthreads();
-    }
-    if (c < n) b[c] = yb[c];
-}
-
-
 // L^T z = y for n <= 1024 by SEVERAL workgroups: workgroup k owns the 128 rows k0 = 128 k .. of the solution ("superblock").
 // Bottom up, every workgroup subtracts L[J rows, k columns]^T z_J from its y_k for the superblocks J below it as their z_J
 // appear (published in b behind flag[J]) and then solves its own 128 x 128 triangle with the four inverted 32 x 32 diagonal
-// blocks.  One workgroup alone (k_trsv_back_dinv) pays the load latency of a 32 x 1000 operand block 32 times (2.6 us per
+// blocks.  One workgroup alone (round 2) paid the load latency of a 32 x 1000 operand block 32 times (2.6 us per
 // step: 1024 threads x 128 registers hold exactly one step's operands): 82 us.  Here the operands of a workgroup's NEXT product
 // are requested before it waits for the z they meet, every workgroup holds its diagonal triangle in registers from the start,
 // and the chain is 8 hand-overs.  512 threads: thread (c, g) = column c of the superblock, rows 32 g .. 32 g + 31 of an operand
-// block.  L^T is read from the mirrored upper triangle (k_chol_finish): consecutive columns are consecutive addresses.
+// block.  L^T is read from the strict upper triangle (written by k_chol_tiles): consecutive columns are consecutive addresses.
 // flag: one int per superblock, zero on entry.  All workgroups are resident (at most 8 of them).
 constexpr int CH_SB = 128;
 __global__ __launch_bounds__(512) void k_trsv_back_mw(const double* __restrict__ L, const double* __restrict__ dinv, int n, double* __restrict__ b,
@@ -707,64 +511,21 @@ __global__ __launch_bounds__(64) void k_trsv_back_small(const double* __restrict
 #include "satba_chol3.h"
 namespace satba {
 
-constexpr int CH_MAX_STEPS = 256;  // panels (n <= 8192); one flag word per panel
-constexpr int CH_TRSV_FLAGS = 64;  // k_trsv_back_mw's flags (n <= 1024: the factorisation uses the first 32 + 2)
+constexpr int CH_MAX_STEPS = 256;  // flag words behind the not-SPD flag (the small path's panel flags, then the backward substitution's)
+constexpr int CH_TRSV_FLAGS = 64;  // k_trsv_back_mw's flags
 
-// Factorise A (n x n, column-major lower, in place) and solve A z = b in place.  *fail != 0 if A was not SPD.
-// flags: CH_MAX_STEPS ints of scratch directly behind *fail (flags == fail + 1); both are cleared here.
-// mode 0: double steps (k_chol_dstep, satba_chol2.h) while more than 32 columns remain, then one single step; 2: single steps
-// only (k_chol_step); 5: like 0 with the one-workgroup backward substitution (k_trsv_back_dinv)
-// dinv: (n / 32 rounded up) x 1024 doubles of scratch for the inverted diagonal blocks (n <= 1024), or null
-// ts (tools): CH_TS time stamps per launch
-// cleared: the caller has already zeroed *fail and the flags on the stream (satba_solve does it in its scaling kernel)
-// k_chol_dstep's tile column + scratch exceed the 64 KB a kernel gets without asking (called once per process, outside any capture)
+// k_chol_dstep's tile column + scratch exceed the 64 KB a kernel gets without asking (called once per process)
 inline void cholesky_init() {
     static const bool once = [] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chol_dstep), hipFuncAttributeMaxDynamicSharedMemorySize, (int)chol_dstep_lds());
         return true;
     }();
     (void)once;
+    chol_tiles_init();
 }
 
-inline void cholesky_solve(double* A, int n, double* b, int* fail, int* flags, int mode, hipStream_t stream,
-                           long long* ts = nullptr, double* dinv = nullptr, bool cleared = false, const int* gate = nullptr) {
-    cholesky_init();
-    if (!cleared) (void)hipMemsetAsync(fail, 0, sizeof(int) * (1 + CH_MAX_STEPS), stream);  // flags == fail + 1: one fill for both
-    int k0 = 0, npend = 0, step = 0;  // step: launches so far
-    int* fl = flags;
-    auto tsk = [&] { return ts ? ts + CH_TS * step : nullptr; };
-    if (mode == 0 || mode == 5) {
-        for (; n - k0 > CH_NB; k0 += 2 * CH_NB, fl += 2, npend = 2, ++step) {  // the last one may have a partial second panel
-            const int T = (n - k0 + 63) / 64;
-            hipLaunchKernelGGL(k_chol_dstep, dim3(T * (T + 1) / 2), dim3(256), chol_dstep_lds(), stream, A, n, npend, k0, fail, fl, b, tsk(), gate, n, 0);
-        }
-    }
-    for (; k0 < n; k0 += CH_NB, ++fl, ++step, npend = 1) {
-        const int T = (n - k0 + 63) / 64;
-        if (n - k0 >= CH_NB)
-            hipLaunchKernelGGL(k_chol_step<true>, dim3(T * (T + 1) / 2), dim3(256), 0, stream, A, n, npend, k0, fail, fl, b, tsk(), gate);
-        else
-            hipLaunchKernelGGL(k_chol_step<false>, dim3(T * (T + 1) / 2), dim3(256), 0, stream, A, n, npend, k0, fail, fl, b, tsk(), gate);
-    }
-    if (n <= 1024) {
-        const int T = (n + 31) / 32;
-        if (dinv && n <= CH_SMALL && mode == 0) {
-            hipLaunchKernelGGL(k_trsv_back_small, dim3(1), dim3(64), 0, stream, A, n, b, gate);
-        } else if (dinv) {
-            hipLaunchKernelGGL(k_chol_finish, dim3(T * (T + 1) / 2 + T), dim3(256), 0, stream, A, n, T * (T + 1) / 2, dinv, gate);
-            if (mode == 5) hipLaunchKernelGGL(k_trsv_back_dinv, dim3(1), dim3(1024), 0, stream, A, dinv, n, b);  // one workgroup
-            else hipLaunchKernelGGL(k_trsv_back_mw, dim3((n + CH_SB - 1) / CH_SB), dim3(512), 0, stream, A, dinv, n, b, flags + CH_TRSV_FLAGS, gate);
-        } else {
-            hipLaunchKernelGGL(k_mirror_lower, dim3(T * (T + 1) / 2), dim3(256), 0, stream, A, n);
-            hipLaunchKernelGGL(k_trsv_back_rl, dim3(1), dim3(1024), 0, stream, A, n, b);
-        }
-    }
-    else hipLaunchKernelGGL(k_trsv_back, dim3(1), dim3(1024), sizeof(double) * n, stream, A, n, b);
-}
-
-// ---- round 4: the factorisation as one persistent launch (satba_chol3.h) + the multi-workgroup backward substitution
 // Scratch of the tile kernel (per handle): tile flags (zeroed once: they carry epochs), the inverted 64 x 64 diagonal blocks,
-// the tiles' shares of the forward substitution, the ticket counters.
+// the tiles' shares of the forward substitution, the ticket counters (zero between launches).
 struct CholWork {
     int* flags = nullptr;
     double* Linv = nullptr;
@@ -772,14 +533,14 @@ struct CholWork {
     int* ctr = nullptr;
     int epoch = 0;
 };
-inline hipError_t chol_work_alloc(CholWork& w, int n) {
+inline hipError_t chol_work_alloc(CholWork& w, int n) {  // (tools; the library allocates through its handle)
     const size_t T = (size_t)(n + 63) / 64;
     hipError_t e;
-    if ((e = hipMalloc((void**)&w.flags, sizeof(int) * T * T)) != hipSuccess) return e;
-    if ((e = hipMalloc((void**)&w.Linv, sizeof(double) * T * 4096)) != hipSuccess) return e;
-    if ((e = hipMalloc((void**)&w.Cc, sizeof(double) * T * T * 64)) != hipSuccess) return e;
+    if ((e = hipMalloc((void**)&w.flags, sizeof(int) * (T * T + 1))) != hipSuccess) return e;
+    if ((e = hipMalloc((void**)&w.Linv, sizeof(double) * (T * 4096 + 1))) != hipSuccess) return e;
+    if ((e = hipMalloc((void**)&w.Cc, sizeof(double) * (T * T * 64 + 1))) != hipSuccess) return e;
     if ((e = hipMalloc((void**)&w.ctr, sizeof(int) * 4)) != hipSuccess) return e;
-    if ((e = hipMemset(w.flags, 0, sizeof(int) * T * T)) != hipSuccess) return e;
+    if ((e = hipMemset(w.flags, 0, sizeof(int) * (T * T + 1))) != hipSuccess) return e;
     if ((e = hipMemset(w.ctr, 0, sizeof(int) * 4)) != hipSuccess) return e;
     w.epoch = 0;
     return hipSuccess;
@@ -789,70 +550,45 @@ inline void chol_work_free(CholWork& w) {
     w = CholWork();
 }
 
-// A z = b in place (A: n x n column-major lower, destroyed).  *fail and the CH_TRSV_FLAGS.. flags behind it are zero on entry
-// (the caller's scaling kernel clears them).  dinv: (n / 32 rounded up) x 1024 doubles.
-inline void cholesky_solve_tiles(double* A, int n, double* b, int* fail, int* flags, hipStream_t stream, CholWork& w, double* dinv,
-                                 const int* gate, long long* ts = nullptr) {
-    chol_tiles_init();
+// the tile kernel alone: factor in place, y = L^-1 b, L^T in the strict upper triangle and the 32 x 32 block inverses if asked
+inline void cholesky_tiles(double* A, int n, double* b, int* fail, hipStream_t stream, CholWork& w, double* dinv, bool mirror, const int* gate,
+                           long long* ts = nullptr) {
     C3Args g;
     g.A = A; g.n = n; g.b = b; g.fail = fail; g.flags = w.flags; g.epoch = ++w.epoch; g.Linv = w.Linv; g.Cc = w.Cc; g.ctr = w.ctr;
-    const bool mw = n > CH_SMALL && n <= 1024;  // the multi-workgroup backward substitution reads L^T from the mirror and the 32 x 32 inverses
-    g.dinv = mw ? dinv : nullptr; g.ts = ts; g.mirror = mw ? 1 : 0;
-    if (getenv("SATBA_NO_MIRROR")) g.mirror = 0;  // experiment
+    g.dinv = dinv; g.ts = ts; g.mirror = mirror ? 1 : 0;
     hipLaunchKernelGGL(k_chol_tiles, dim3(chol_tiles_grid(n)), dim3(1024), c3_lds_bytes(), stream, g, gate);
-    if (n <= CH_SMALL) hipLaunchKernelGGL(k_trsv_back_small, dim3(1), dim3(64), 0, stream, A, n, b, gate);
-    else if (n <= 1024) hipLaunchKernelGGL(k_trsv_back_mw, dim3((n + CH_SB - 1) / CH_SB), dim3(512), 0, stream, A, dinv, n, b, flags + CH_TRSV_FLAGS, gate);
-    else hipLaunchKernelGGL(k_trsv_back, dim3(1), dim3(1024), sizeof(double) * n, stream, A, n, b);
 }
 
-// ---- factorisation overlapped with the production of the matrix (round 3)
-// The Schur complement is produced camera row by camera row, i.e. S arrives column block by column block, while the
-// factorisation is a latency chain that occupies a handful of CUs: the chain starts on the first columns while the rest of S is
-// still being formed on the other stream.  The columns are cut into up to CH_MAX_SEG ranges (boundaries multiples of 64); the
-// producer records ready[s] on its stream when range s is complete.  Within the ranges that exist the steps are right-looking as
-// before (k_chol_dstep with col_limit); when a new range arrives, k_chol_catchup applies all panels factorised so far to it.
-constexpr int CH_MAX_SEG = 4;
-struct CholOverlap {
-    int n_seg = 1;
-    int col_end[CH_MAX_SEG] = {0, 0, 0, 0};  // range s = columns [col_end[s - 1], col_end[s]); col_end[n_seg - 1] = n
-    hipEvent_t ready[CH_MAX_SEG] = {nullptr, nullptr, nullptr, nullptr};
-};
-
-// pre(s): launches whatever has to happen to range s on `stream` before the factorisation touches it (the caller's scaling)
-template <class Pre>
-inline void cholesky_solve_overlapped(double* A, int n, double* b, int* fail, int* flags, hipStream_t stream, double* dinv, const int* gate,
-                                      const CholOverlap& ov, Pre&& pre) {
+// Factorise A (n x n, column-major lower, in place) and solve A z = b in place.  *fail != 0 if A was not SPD (or a wait inside the
+// tile kernel timed out: bit 1).  flags: CH_MAX_STEPS ints of scratch directly behind *fail (flags == fail + 1); both are cleared here
+// unless `cleared` (satba_solve does it in its scaling kernel).  dinv: (n / 32 rounded up) x 1024 doubles of scratch.
+// ts (tools): C3_TS time stamps per step of the tile kernel (a build with -DC3_STAMPS).
+inline void cholesky_solve(double* A, int n, double* b, int* fail, int* flags, hipStream_t stream, CholWork& w, double* dinv, bool cleared = false,
+                           const int* gate = nullptr, long long* ts = nullptr) {
     cholesky_init();
-    int k0 = 0, npend = 0;
-    int* fl = flags;
-    for (int s = 0; s < ov.n_seg; ++s) {
-        (void)hipStreamWaitEvent(stream, ov.ready[s], 0);
-        pre(s);
-        const int cs = s ? ov.col_end[s - 1] : 0, ce = ov.col_end[s];
-        int skip_a = 0;
-        if (s > 0 && cs > 0) {
-            const int ntj = (ce - cs + 63) / 64, nti = (n - cs + 63) / 64;
-            int tiles = 0;
-            for (int ti = 0; ti < nti; ++ti) tiles += ti + 1 < ntj ? ti + 1 : ntj;
-            hipLaunchKernelGGL(k_chol_catchup, dim3(tiles), dim3(256), 0, stream, A, n, cs, ce, gate);
-            skip_a = 1;  // the panels still pending for the right-hand side are already in the matrix
-        }
-        for (; k0 < ce && n - k0 > CH_NB; k0 += 2 * CH_NB, fl += 2, npend = 2, skip_a = 0) {
+    if (!cleared) (void)hipMemsetAsync(fail, 0, sizeof(int) * (1 + CH_MAX_STEPS), stream);  // flags == fail + 1: one fill for both
+    if (n <= CH_SMALL) {
+        // one tile: panel steps (two panels per launch while more than 32 columns remain, then one) + the one-wave backward substitution
+        int k0 = 0, npend = 0;
+        int* fl = flags;
+        for (; n - k0 > CH_NB; k0 += 2 * CH_NB, fl += 2, npend = 2) {  // (the second panel may be partial)
             const int T = (n - k0 + 63) / 64;
-            hipLaunchKernelGGL(k_chol_dstep, dim3(T * (T + 1) / 2), dim3(256), chol_dstep_lds(), stream, A, n, npend, k0, fail, fl, b, (long long*)nullptr, gate,
-                               ce, skip_a);
+            hipLaunchKernelGGL(k_chol_dstep, dim3(T * (T + 1) / 2), dim3(256), chol_dstep_lds(), stream, A, n, npend, k0, fail, fl, b, (long long*)nullptr, gate);
         }
+        for (; k0 < n; k0 += CH_NB, ++fl, npend = 1) {
+            const int T = (n - k0 + 63) / 64;
+            if (n - k0 >= CH_NB)
+                hipLaunchKernelGGL(k_chol_step<true>, dim3(T * (T + 1) / 2), dim3(256), 0, stream, A, n, npend, k0, fail, fl, b, (long long*)nullptr, gate);
+            else
+                hipLaunchKernelGGL(k_chol_step<false>, dim3(T * (T + 1) / 2), dim3(256), 0, stream, A, n, npend, k0, fail, fl, b, (long long*)nullptr, gate);
+        }
+        hipLaunchKernelGGL(k_trsv_back_small, dim3(1), dim3(64), 0, stream, A, n, b, gate);
+        return;
     }
-    for (; k0 < n; k0 += CH_NB, ++fl, npend = 1) {
-        const int T = (n - k0 + 63) / 64;
-        if (n - k0 >= CH_NB)
-            hipLaunchKernelGGL(k_chol_step<true>, dim3(T * (T + 1) / 2), dim3(256), 0, stream, A, n, npend, k0, fail, fl, b, (long long*)nullptr, gate);
-        else
-            hipLaunchKernelGGL(k_chol_step<false>, dim3(T * (T + 1) / 2), dim3(256), 0, stream, A, n, npend, k0, fail, fl, b, (long long*)nullptr, gate);
-    }
-    const int T = (n + 31) / 32;
-    hipLaunchKernelGGL(k_chol_finish, dim3(T * (T + 1) / 2 + T), dim3(256), 0, stream, A, n, T * (T + 1) / 2, dinv, gate);
-    hipLaunchKernelGGL(k_trsv_back_mw, dim3((n + CH_SB - 1) / CH_SB), dim3(512), 0, stream, A, dinv, n, b, flags + CH_TRSV_FLAGS, gate);
+    const bool mw = n <= 1024;  // the multi-workgroup backward substitution reads L^T from the upper triangle and the 32 x 32 inverses
+    cholesky_tiles(A, n, b, fail, stream, w, mw ? dinv : nullptr, mw, gate, ts);
+    if (mw) hipLaunchKernelGGL(k_trsv_back_mw, dim3((n + CH_SB - 1) / CH_SB), dim3(512), 0, stream, A, dinv, n, b, flags + CH_TRSV_FLAGS, gate);
+    else hipLaunchKernelGGL(k_trsv_back, dim3(1), dim3(1024), sizeof(double) * n, stream, A, n, b);
 }
 
 }  // namespace satba

@@ -174,12 +174,7 @@ constexpr size_t chol_dstep_lds() {
 }
 
 __global__ __launch_bounds__(256) void k_chol_dstep(double* __restrict__ A, int n, int npend, int k0, int* __restrict__ fail,
-                                                    int* __restrict__ flag, double* __restrict__ b, long long* __restrict__ ts, const int* gate,
-                                                    int col_limit, int skip_a) {
-    // col_limit, skip_a: factorisation overlapped with the kernels that still PRODUCE the matrix (cholesky_overlapped in
-    // satba_chol.h): only the columns below col_limit exist yet -- trailing tiles beyond it are left alone, k_chol_catchup applies
-    // the panels they missed when their columns arrive -- and in the first launch behind a catch-up (skip_a) the pending panels
-    // are already in the matrix: they are only applied to the right-hand side.
+                                                    int* __restrict__ flag, double* __restrict__ b, long long* __restrict__ ts, const int* gate) {
     SATBA_GATE(gate);
     // npend: number of 32-column panels directly before k0 whose trailing update is still pending (0, 1 or 2)
     // flag: two ints per launch, zero on entry: [p] diagonal block p (and, p = 0, L21) is visible
@@ -210,9 +205,8 @@ __global__ __launch_bounds__(256) void k_chol_dstep(double* __restrict__ A, int 
         bj = idx + 1;
     }
     const bool col0 = bj == 0;
-    if (!col0 && (npend == 0 || skip_a)) return;  // first launch (of the matrix / behind a catch-up): nothing to apply to the trailing tiles
+    if (!col0 && npend == 0) return;  // first launch: nothing to apply to the trailing tiles
     const int r0 = k0 + bi * 64, c0 = k0 + bj * 64;
-    if (c0 >= col_limit) return;                  // columns that do not exist yet
     const int e16 = lane & 15, g4 = lane >> 4;
     const bool stamp = ts && col0 && bi < 3 && tid == 0;
     if (stamp) ts[bi * 8 + 0] = wall_clock64();
@@ -276,7 +270,6 @@ __global__ __launch_bounds__(256) void k_chol_dstep(double* __restrict__ A, int 
                 brow[lane] -= s;  // only this lane touches brow[lane] until the next barrier
             }
             const int kq = lane >> 4;
-            if (!skip_a)
 #pragma unroll
             for (int ks = 0; ks < CH_NB / 4; ++ks) {
 #pragma unroll
@@ -486,71 +479,6 @@ __global__ __launch_bounds__(256) void k_chol_dstep(double* __restrict__ A, int 
         for (int c = 0; c < CH_NB; ++c) A[row + (size_t)(k0 + CH_NB + c) * n] = x[c];
         if (stamp) ts[bi * 8 + 3] = wall_clock64();
     }
-}
-
-// Catch-up of a column range [cs, ce) that has just arrived (overlapped factorisation): all panels in front of it, columns
-// 0 .. cs - 1 of the factor, are applied to its lower tiles in one pass:  A[r, c] -= sum_{k < cs} L[r, k] L[c, k]  for cs <= c < ce,
-// r >= c.  One workgroup per 64 x 64 tile (grid: tiles (ti, tj), tj over the range, ti >= tj, row by row), the operands of the next
-// 32-column panel in flight in registers while the current one is multiplied (v_mfma_f64_16x16x4, as k_chol_dstep's update).
-// cs is a multiple of 64 (the double steps end there).
-__global__ __launch_bounds__(256) void k_chol_catchup(double* __restrict__ A, int n, int cs, int ce, const int* gate) {
-    SATBA_GATE(gate);
-    __shared__ double Pi[CH_NB * CH_LD], Pj[CH_NB * CH_LD];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int ntj = (ce - cs + 63) / 64, nti = (n - cs + 63) / 64;  // tile (ti, tj): rows cs + 64 ti, columns cs + 64 tj, tj < ntj, ti >= tj
-    int ti = 0, tj = 0, idx = blockIdx.x;
-    for (ti = 0; ti < nti; ++ti) {
-        const int w = min(ti + 1, ntj);
-        if (idx < w) { tj = idx; break; }
-        idx -= w;
-    }
-    if (ti >= nti) return;
-    const int r0 = cs + 64 * ti, c0 = cs + 64 * tj;
-    const int e16 = lane & 15, g4 = lane >> 4;
-    chol_d4 acc[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) acc[t] = chol_d4{0.0, 0.0, 0.0, 0.0};
-    constexpr int PF = CH_NB * 64 / 256;
-    double oi[PF], oj[PF], ni[PF], nj[PF];
-    auto fetch = [&](double (&di)[PF], double (&dj)[PF], int kq) {
-#pragma unroll
-        for (int t = 0; t < PF; ++t) {
-            const int q = tid + t * 256, r = q & 63, k = q >> 6;
-            const size_t col = (size_t)(kq + k) * n;
-            di[t] = (r0 + r < n) ? A[(size_t)(r0 + r) + col] : 0.0;
-            dj[t] = (c0 + r < n) ? A[(size_t)(c0 + r) + col] : 0.0;
-        }
-    };
-    fetch(oi, oj, 0);
-    for (int kq = 0; kq < cs; kq += CH_NB) {
-        if (kq + CH_NB < cs) fetch(ni, nj, kq + CH_NB);
-        __syncthreads();  // the previous panel's products are done with the operand arrays
-#pragma unroll
-        for (int t = 0; t < PF; ++t) {
-            const int q = tid + t * 256, r = q & 63, k = q >> 6;
-            Pi[k * CH_LD + r] = oi[t]; Pj[k * CH_LD + r] = oj[t];
-        }
-        __syncthreads();
-        const int kk = lane >> 4;
-#pragma unroll
-        for (int ks = 0; ks < CH_NB / 4; ++ks) {
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {  // wave w: column block w of the tile, row blocks t
-                const double av = Pj[(4 * ks + kk) * CH_LD + 16 * wave + e16];
-                const double bv = Pi[(4 * ks + kk) * CH_LD + 16 * t + e16];
-                acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[t], 0, 0, 0);
-            }
-        }
-#pragma unroll
-        for (int t = 0; t < PF; ++t) { oi[t] = ni[t]; oj[t] = nj[t]; }
-    }
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-            const int r = r0 + 16 * t + e16, c = c0 + 16 * wave + g4 + 4 * reg;
-            if (r < n && c < ce && r >= c) A[(size_t)r + (size_t)c * n] -= acc[t][reg];
-        }
 }
 
 }  // namespace satba

@@ -27,10 +27,9 @@
 // summation route -- the state switches every later tick off; the host notices through `LmSummary` (pinned host memory the
 // device posts to) and stops queueing.  A handful of empty ticks may have been queued by then (at most LM_RUN_AHEAD).
 //
-// The pattern is data independent, so it CAN be captured once into a hipGraph and replayed (SATBA_GRAPH=1): one graph launch per
-// tick instead of ~40 kernel launches.  Measured (profiles/r3_graph_gaps.txt), the replay is not faster on this stack -- the graph
-// leaves 2 - 9 us between its nodes where back-to-back launches leave none, and the host, which queues LM_RUN_AHEAD ticks ahead,
-// is never the bottleneck -- so direct launches are the default.
+// The pattern is data independent; capturing it into a hipGraph was measured in round 3 (profiles/r3_graph_gaps.txt: the replay leaves
+// 2 - 9 us between its nodes where back-to-back launches leave none, and the host, which queues LM_RUN_AHEAD ticks ahead, is never the
+// bottleneck) and removed in round 4: the ticks are direct launches.
 #pragma once
 #include <hip/hip_runtime.h>
 

@@ -199,29 +199,6 @@ def test_device_resident_solve_matches_host_loop(gpu, monkeypatch, name, loss, t
     assert outs[0][0] == outs[1][0] and np.array_equal(outs[0][1], outs[1][1])
 
 
-def test_overlapped_factorisation_gives_the_same_solve(gpu, monkeypatch):
-    """
-    SATBA_OVERLAP=1: the dense factorisation runs on a second stream while the pair kernel still produces the later column ranges
-    of the reduced system (cholesky_solve_overlapped: range events, k_chol_catchup, k_chol_dstep with a column limit).  Same
-    iterations as the plain sequence up to the rounding of the catch-up's summation order.  (Measured slower at the headline
-    shape -- csrc/satba_capi.hip, schur_item_table -- hence opt-in; this keeps the path honest.)
-    """
-    scene = synth.make_affine_scene(180, 6000, 12, seed=7, sigma_theta=2e-5)  # 180 cameras x 3 parameters = 540 columns
-    opts = {"correction_params": ["R"], "n_cam_fix": 1}  # rotations only: a well-determined minimum
-    outs = []
-    for overlap in (False, True):
-        if overlap:
-            monkeypatch.setenv("SATBA_OVERLAP", "1")
-        eng = HipEngine(synth.make_params(scene, opts))
-        assert eng.info()["overlap_ranges"] == (3 if overlap else 1)
-        st = eng.solve_lm(ftol=1e-8, xtol=1e-10, gtol=1e-12, max_nfev=30, loss="linear")
-        outs.append((st.cost, st.nfev, st.status, eng.get_x()))
-        eng.close()
-    assert outs[0][1] == outs[1][1] and outs[0][2] > 0 and outs[1][2] > 0
-    assert abs(outs[0][0] - outs[1][0]) < 1e-10 * outs[0][0]
-    assert np.abs(outs[0][3] - outs[1][3]).max() < 1e-8 * np.abs(outs[0][3]).max()
-
-
 def test_snapshot_restores_the_point_and_the_solve_repeats(gpu):
     """satba_snapshot_x (what bench.py restarts its solve with): the point comes back bit for bit, and the solve that follows
     repeats the first one exactly (default path: fixed-point camera sums)."""

@@ -279,18 +279,14 @@ def test_schur_matrix_and_rhs(gpu, monkeypatch, chunks):
     dev.close()
 
 
-# n_c = 9, 65, 300, 1000, 900; 192 (double steps only), 96 (one double step + one full single step with two pending
-# panels), 129 (double steps + a one-column partial step), 66 (one double step + a two-column partial step)
-# 130, 162: double steps, the last with a partial second panel; 1300: more than 1024 unknowns (one-workgroup left-looking
-# backward substitution, k_trsv_back)
-# mode (SATBA_CHOL): 0 two panels per launch where they fit (default), 2 single steps, 5 like 0 with the one-workgroup back-substitution
-@pytest.mark.parametrize("mode", ["0", "2", "5"])
-# n_c <= 64 (mode 0): one-wave back-substitution from the factor's lower triangle (k_trsv_back_small): 9, 30, 33, 60, 63 unknowns
+# n_c = 9 ... 1300 unknowns.  Up to 64 (one tile): panel steps (k_chol_dstep / k_chol_step) + the one-wave backward substitution: 9, 18,
+# 30, 33, 60, 63.  Above: the persistent tile kernel (k_chol_tiles, 64 x 64 tiles: 2 to 21 tile rows here, ragged last tiles: 65, 66,
+# 96, 129, 130, 162) + the multi-workgroup backward substitution; 1300: more than 1024 unknowns (one-workgroup backward substitution).
 @pytest.mark.parametrize("n_cam,n_p", [(3, 3), (13, 5), (60, 5), (200, 5), (150, 6), (64, 3), (32, 3), (43, 3), (11, 6), (26, 5), (54, 3), (260, 5),
-                                       (6, 5), (11, 3), (12, 5), (21, 3)])
-def test_dense_cholesky_solve(gpu, monkeypatch, n_cam, n_p, mode):
-    """The reduced-system solver alone: plant a random SPD system in the exchange payload and solve it."""
-    monkeypatch.setenv("SATBA_CHOL", mode)  # read when the problem handle is created
+                                       (6, 5), (11, 3), (12, 5), (21, 3), (22, 3), (199, 5)])
+def test_dense_cholesky_solve(gpu, n_cam, n_p):
+    """The reduced-system solver alone: plant a random SPD system in the exchange payload and solve it (twice: the tile kernel's flags
+    carry launch epochs and are never cleared)."""
     rng = np.random.default_rng(n_cam)
     model = "perspective" if n_p == 6 else "affine"
     corr = ["R"] if n_p == 3 else ["R", "T"]
@@ -307,11 +303,14 @@ def test_dense_cholesky_solve(gpu, monkeypatch, n_cam, n_p, mode):
     rhs = rng.normal(size=n)
     eng.set_exchange(eng.hdr, np.tril(S).T.ravel())  # column-major lower triangle; the strict upper is ignored
     eng.set_exchange(eng.hdr + n * n, rhs)
-    eng.solve()
-    h = eng.read_header()
-    assert h[trf.CHOL_FAIL] == 0
-    dc = eng.get_vector("gn_h")[:n] / eng.get_vector("scale_inv")[:n]
-    assert rel(dc, np.linalg.solve(S, rhs)) < 1e-10
+    for _ in range(2):
+        eng.set_exchange(eng.hdr, np.tril(S).T.ravel())
+        eng.set_exchange(eng.hdr + n * n, rhs)
+        eng.solve()
+        h = eng.read_header()
+        assert h[trf.CHOL_FAIL] == 0
+        dc = eng.get_vector("gn_h")[:n] / eng.get_vector("scale_inv")[:n]
+        assert rel(dc, np.linalg.solve(S, rhs)) < 1e-10
     # a matrix that is not positive definite must raise the flag instead of producing NaNs silently
     S[0, 0] = -1.0
     eng.set_exchange(eng.hdr, np.tril(S).T.ravel())
@@ -790,11 +789,9 @@ ALT_PATHS = [
     {"SATBA_RPC_GLOBAL": "1"},       # RPC tables gathered from global memory (more than ~90 RPC cameras)
     {"SATBA_CAM_SUMS": "1"},         # camera sums by the camera-major pass (accumulator table larger than the LDS)
     {"SATBA_DETERMINISTIC": "1"},    # the same pass, selected by the repeatability option
-    {"SATBA_CHOL": "2"},             # single panel steps only (k_chol_step; default: double steps, k_chol_dstep)
     {"SATBA_SCHUR_CHUNKS": "3"},     # pair lists cut into point-range chunks + partial reduce
     {"SATBA_SCHUR_CHUNKS": "1"},     # ... and as one chunk (direct store)
     {"SATBA_CM_CHUNKS": "5"},        # chunking of the camera-major passes
-    {"SATBA_SCHUR_ORDER": "chunk"},  # chunk-major item order of round 1
 ]
 
 

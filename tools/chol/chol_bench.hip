@@ -1,8 +1,9 @@
 // Stand-alone check + timing of the dense solve (csrc/satba_chol*.h) without the Python side:
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -munsafe-fp-atomics -I ../../sat-bundleadjust_amd/csrc chol_bench.hip -o chol_bench
 //   ./chol_bench [reps] n1 n2 ...        (SATBA_STAMPS=1: per-step time stamps of the persistent kernel)
-// For every n: a random SPD system, the host's Cholesky as the reference, then factor / forward substitution / solution of the
-// persistent tile kernel against it, and the time per solve (HIP events around the launches only).
+// For every n: a random SPD system, the host's Cholesky as the reference, then factor / forward substitution / L^T / block inverses /
+// solution of the persistent tile kernel against it ("tiles": the tile kernel at every size; "driver": cholesky_solve as the library
+// calls it, panel steps up to 64 unknowns), the not-SPD flag, and the time per solve (HIP events around the launches only).
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cmath>
@@ -78,8 +79,14 @@ int main(int argc, char** argv) {
                 CK(hipMemcpyAsync(db, db0, sizeof(double) * n, hipMemcpyDeviceToDevice, st));
                 CK(hipMemsetAsync(dfail, 0, sizeof(int) * (1 + CH_MAX_STEPS), st));
                 CK(hipEventRecord(e0, st));
-                if (which == 0) cholesky_solve_tiles(dA, n, db, dfail, dfail + 1, st, w, dinv, nullptr, dts);
-                else cholesky_solve(dA, n, db, dfail, dfail + 1, 0, st, nullptr, dinv, true, nullptr);
+                if (which == 0) {   // the tile kernel at every size (the library's driver switches to panel steps up to 64 unknowns)
+                    cholesky_init();
+                    const bool mw = n > CH_SMALL && n <= 1024;
+                    cholesky_tiles(dA, n, db, dfail, st, w, mw ? dinv : nullptr, mw, nullptr, dts);
+                    if (n <= CH_SMALL) hipLaunchKernelGGL(k_trsv_back_small, dim3(1), dim3(64), 0, st, dA, n, db, (const int*)nullptr);
+                    else if (mw) hipLaunchKernelGGL(k_trsv_back_mw, dim3((n + CH_SB - 1) / CH_SB), dim3(512), 0, st, dA, dinv, n, db, dfail + 1 + CH_TRSV_FLAGS, (const int*)nullptr);
+                    else hipLaunchKernelGGL(k_trsv_back, dim3(1), dim3(1024), sizeof(double) * n, st, dA, n, db);
+                } else cholesky_solve(dA, n, db, dfail, dfail + 1, st, w, dinv, true, nullptr);
                 CK(hipEventRecord(e1, st));
                 CK(hipEventSynchronize(e1));
                 float ms = 0.f;
@@ -91,7 +98,7 @@ int main(int argc, char** argv) {
             CK(hipMemcpyAsync(dA, dA0, sizeof(double) * n * n, hipMemcpyDeviceToDevice, st));
             CK(hipMemcpyAsync(db, db0, sizeof(double) * n, hipMemcpyDeviceToDevice, st));
             CK(hipMemsetAsync(dfail, 0, sizeof(int) * (1 + CH_MAX_STEPS), st));
-            chol_tiles_init();
+            cholesky_init();
             C3Args g;
             g.A = dA; g.n = n; g.b = db; g.fail = dfail; g.flags = w.flags; g.epoch = ++w.epoch; g.Linv = w.Linv; g.Cc = w.Cc; g.ctr = w.ctr;
             g.dinv = dinv; g.ts = nullptr; g.mirror = getenv("SATBA_NO_MIRROR") ? 0 : 1;
@@ -137,7 +144,7 @@ int main(int argc, char** argv) {
             if (!(eL <= 1e-11 * nL) || !(ez <= 1e-10 * nz) || fail) worst = 1;
             std::sort(times.begin(), times.end());
             printf("n %5d %s  fail %d  |dL|/|L| %.2e (worst at %d,%d)  |dz|/|z| %.2e   solve us: min %.1f median %.1f max %.1f\n", n,
-                   which == 0 ? "tiles " : "dsteps", fail, eL / nL, wr, wc, ez / nz, times.front() * 1e3, times[times.size() / 2] * 1e3, times.back() * 1e3);
+                   which == 0 ? "tiles " : "driver", fail, eL / nL, wr, wc, ez / nz, times.front() * 1e3, times[times.size() / 2] * 1e3, times.back() * 1e3);
             if (which == 0 && stamps) {
                 std::vector<long long> ts((size_t)C3_TS * T);
                 CK(hipMemcpy(ts.data(), dts, sizeof(long long) * C3_TS * T, hipMemcpyDeviceToHost));
@@ -169,7 +176,7 @@ int main(int argc, char** argv) {
             CK(hipMemcpy(dA, A2.data(), sizeof(double) * n * n, hipMemcpyHostToDevice));
             CK(hipMemcpy(db, b.data(), sizeof(double) * n, hipMemcpyHostToDevice));
             CK(hipMemsetAsync(dfail, 0, sizeof(int) * (1 + CH_MAX_STEPS), st));
-            cholesky_solve_tiles(dA, n, db, dfail, dfail + 1, st, w, dinv, nullptr, nullptr);
+            cholesky_solve(dA, n, db, dfail, dfail + 1, st, w, dinv, true, nullptr);
             CK(hipStreamSynchronize(st));
             int fail = 0;
             CK(hipMemcpy(&fail, dfail, sizeof(int), hipMemcpyDeviceToHost));
