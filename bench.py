@@ -63,22 +63,56 @@ def compulsory_bytes(K, N, model, n_params, loss, unit_weights, fused_prepare):
     return float(per_obs) * K + (96.0 + (96.0 if fused_prepare else 0.0)) * N
 
 
-def lm_step(eng, comm, st, trf):
-    """One fixed-work LM iteration (see module docstring).  `st` carries cost, Delta between steps."""
+class PhaseProfile:
+    """Per-phase device time of the multi-rank iteration (torch events on the stream the phases and the collectives are queued on)
+    and the host's blocking header reads (wall clock): what `phase_ms` of the bench line is made of."""
+
+    def __init__(self, torch):
+        self.torch, self.ev, self.host = torch, [], {}
+
+    def dev(self, name, fn):
+        a, b = self.torch.cuda.Event(enable_timing=True), self.torch.cuda.Event(enable_timing=True)
+        a.record()
+        out = fn()
+        b.record()
+        self.ev.append((name, a, b))
+        return out
+
+    def wait(self, name, fn):
+        t0 = time.perf_counter()
+        out = fn()
+        self.host[name] = self.host.get(name, 0.0) + 1e3 * (time.perf_counter() - t0)
+        return out
+
+    def result(self, iterations):
+        self.torch.cuda.synchronize()
+        tot = {}
+        for name, a, b in self.ev:
+            tot[name] = tot.get(name, 0.0) + a.elapsed_time(b)
+        out = {k: v / iterations for k, v in tot.items()}
+        out.update({k: v / iterations for k, v in self.host.items()})
+        return out
+
+
+def lm_step(eng, comm, st, trf, prof=None):
+    """One fixed-work LM iteration (see module docstring).  `st` carries cost, Delta between steps.  prof: a PhaseProfile (a separate,
+    untimed pass of the bench: the events serialise nothing, but they are not part of the timed region)."""
     hdr = eng.hdr
+    dev = prof.dev if prof else (lambda name, fn: fn())
+    wait = prof.wait if prof else (lambda name, fn: fn())
 
     def exchange(n):
-        comm.allreduce(eng, n)
-        return eng.read_header()
+        dev("allreduce", lambda: comm.allreduce(eng, n))
+        return wait("host_wait", eng.read_header)
 
     # linearize -> prepare -> damped Gauss-Newton step, queued without a host round trip (satba/trf.py: front)
-    eng.linearize()
-    comm.allreduce(eng, eng.len_lin)
-    eng.prepare(st["first"])
-    comm.allreduce(eng, hdr)
-    eng.schur_auto(-1.0 if st["first"] else st["Delta"], 1e-14)
-    comm.allreduce_schur(eng)
-    eng.solve()
+    dev("linearize", eng.linearize)
+    dev("allreduce", lambda: comm.allreduce(eng, eng.len_lin))
+    dev("prepare", lambda: eng.prepare(st["first"]))
+    dev("allreduce", lambda: comm.allreduce(eng, hdr))
+    dev("schur", lambda: eng.schur_auto(-1.0 if st["first"] else st["Delta"], 1e-14))
+    dev("allreduce_schur", lambda: comm.allreduce_schur(eng))
+    dev("dense_solve", eng.solve)
     h = exchange(hdr)
     st["first"] = False
     cost, Delta, reg, jg_sq = h[trf.K_COST], h[trf.K_DELTA], h[trf.K_LAM], h[trf.K_JG_SQ]
@@ -87,14 +121,14 @@ def lm_step(eng, comm, st, trf):
     p_S, newton = trf.solve_trust_region_2d(B_S, g_S, Delta)
     st["interior"] = st.get("interior", 0) + int(newton)
     predicted = -(0.5 * p_S @ B_S @ p_S + g_S @ p_S)
-    eng.trial_gn(*coeffs(p_S))
+    dev("trial", lambda: eng.trial_gn(*coeffs(p_S)))
     h = exchange(hdr)
     cost_new = h[trf.COST_NEW]
     step_h_norm = np.linalg.norm(p_S)
     actual = cost - cost_new if np.isfinite(cost_new) else -1.0
     st["Delta"], _ = trf.update_tr_radius(Delta, actual, predicted, step_h_norm, step_h_norm > 0.95 * Delta)
     if actual > 0:
-        eng.accept()
+        dev("accept", eng.accept)
         st["accepted"] += 1
     st["cost"] = cost_new if actual > 0 else cost
 
@@ -342,10 +376,31 @@ def main():
             raise SystemExit("the device-resident loop stopped for the host (reason {}): use --driver native-sync".format(int(ls["host_reason"])))
         assert int(ls["iterations"]) == args.steps, ls
         st.update(accepted=int(ls["accepted"]), interior=int(ls["newton"]), cost=ls["cost_new"] if ls["actual"] > 0 else ls["cost"])
+    phase_ms = None
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        # where an iteration's time goes with several ranks: a second pass over the same iterations, every
+        # phase and every collective between torch events on the stream they are queued on, the blocking header reads on the
+        # host's clock; rank 0's figures, ms per iteration.  ("dense_solve" includes the scaling of the reduced system and the
+        # back-substitution of the points; the all-reduce of S is `allreduce_schur`, pack and unpack included.)
+        if restart:
+            eng.snapshot_x(True)
+            st["first"] = True
+        n_step[0] = 0
+        keep2 = dict(st)
+        prof = PhaseProfile(torch)
+        n_prof = min(args.steps, 20)
+        for _ in range(n_prof):
+            if restart and n_step[0] and n_step[0] % restart == 0:
+                eng.snapshot_x(True)
+                st["first"] = True
+            lm_step(eng, comm, st, trf, prof)
+            n_step[0] += 1
+        phase_ms = prof.result(n_prof)
+        st.clear()
+        st.update(keep2)
 
     # dominant kernels, HIP events on the launch stream (rank-local shard)
     eng.linearize()
@@ -401,6 +456,7 @@ def main():
                          "algorithmic_bytes_per_launch": alg_bytes, "ms_per_launch": 1e3 * t_lin, "launches_timed": n_lin,
                          "ms_per_launch_back_to_back": kern["linearize"]},
             "kernel_ms": kern,
+            "phase_ms": phase_ms,  # several ranks: device time per phase and collective, host time in blocking header reads (per iteration)
             "accepted_steps": st["accepted"], "interior_2d_steps": st.get("interior", 0), "final_cost": st["cost"], "scene_gen_s": t_gen,
             "launch_patterns_executed": int(ls["ticks"]) if ls else None,  # > steps when a factorisation had to be repeated with more damping
         }

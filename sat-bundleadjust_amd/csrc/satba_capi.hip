@@ -28,6 +28,34 @@
 #include "satba_rpcfit.h"
 #include "satba_schur.h"
 
+#include <dlfcn.h>
+
+// Range markers around the phases of an LM iteration (tracing): `rocprofv3 --marker-trace` shows the iteration
+// structure -- linearize | prepare | schur | solve | trial | accept.  The marker library (ROCm's roctx) is looked up at run time, once:
+// no link-time dependency, and a plain function-pointer test when it is absent.
+namespace {
+struct Roctx {
+    int (*push)(const char*) = nullptr;
+    int (*pop)() = nullptr;
+    Roctx() {
+        for (const char* name : {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so", "libroctx64.so.4"}) {
+            if (void* h = dlopen(name, RTLD_LAZY | RTLD_GLOBAL)) {
+                push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
+                pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+                if (push && pop) return;
+                push = nullptr; pop = nullptr;
+            }
+        }
+    }
+};
+inline const Roctx& roctx() { static const Roctx r; return r; }
+struct Range {  // a phase's launches are queued between push and pop: the range covers the host side, the kernels follow on the stream
+    bool on;
+    explicit Range(const char* name) : on(roctx().push != nullptr) { if (on) roctx().push(name); }
+    ~Range() { if (on) roctx().pop(); }
+};
+}  // namespace
+
 using namespace satba;
 
 static thread_local std::string g_err;
@@ -710,6 +738,7 @@ const char* satba_last_error(void) { return g_err.c_str(); }
 int satba_version(void) { return 3; }
 
 int satba_problem_create(const satba_problem_desc* d, satba_problem** out) {
+    Range range_("satba:problem_create");
     if (!d || !out) return fail(SATBA_E_ARG, "null argument");
     *out = nullptr;
     if (d->cam_model < 0 || d->cam_model > 2) return fail(SATBA_E_ARG, "cam_model must be 0, 1 or 2");
@@ -1000,6 +1029,7 @@ int satba_get_x(satba_problem* p, double* host_x) {
 }
 
 int satba_residuals(satba_problem* p, double* host_r, double* host_cost) {
+    Range range_("satba:residuals");
     if (!p) return fail(SATBA_E_ARG, "null handle");
     HIP_TRY(hipSetDevice(p->device));
     // the cost goes through a private scalar so the exchange header of a running solve is left alone; the residual pairs go
@@ -1021,6 +1051,7 @@ int satba_residuals(satba_problem* p, double* host_r, double* host_cost) {
 }
 
 int satba_linearize(satba_problem* p) {
+    Range range_("satba:linearize");
     if (!p) return fail(SATBA_E_ARG, "null handle");
     HIP_TRY(hipSetDevice(p->device));
     const size_t nU = (size_t)p->M * p->NP * p->NP;
@@ -1059,6 +1090,7 @@ int satba_linearize(satba_problem* p) {
 }
 
 int satba_prepare(satba_problem* p, int32_t first) {
+    Range range_("satba:prepare");
     if (!p) return fail(SATBA_E_ARG, "null handle");
     if (!p->linearized) return fail(SATBA_E_STATE, "prepare before linearize");
     HIP_TRY(hipSetDevice(p->device));
@@ -1079,6 +1111,7 @@ int satba_prepare(satba_problem* p, int32_t first) {
 
 // automatic: the damping comes from the prepare header and the trust radius Delta (satba_schur_auto)
 static int schur_impl(satba_problem* p, double lam, bool automatic, double Delta, double lam_floor) {
+    Range range_("satba:schur");
     const size_t nS = (size_t)p->n_c * p->n_c + p->n_c;
     const bool pairs_run = p->L.n_pairs > 0 && p->L.E > 0;
     const double* lam_dev = automatic ? p->d_keep + 5 : nullptr;
@@ -1125,6 +1158,7 @@ int satba_schur_auto(satba_problem* p, double Delta, double lam_floor) {
 }
 
 int satba_solve(satba_problem* p) {
+    Range range_("satba:solve");
     if (!p) return fail(SATBA_E_ARG, "null handle");
     HIP_TRY(hipSetDevice(p->device));
     double* S = p->payload();
@@ -1143,6 +1177,7 @@ int satba_solve(satba_problem* p) {
 }
 
 int satba_subspace(satba_problem* p, double alpha, double inv_norm_g) {
+    Range range_("satba:subspace");
     if (!p) return fail(SATBA_E_ARG, "null handle");
     if (!p->have_step) return fail(SATBA_E_STATE, "subspace before solve");
     HIP_TRY(hipSetDevice(p->device));
@@ -1154,6 +1189,7 @@ int satba_subspace(satba_problem* p, double alpha, double inv_norm_g) {
 }
 
 int satba_subspace_products(satba_problem* p) {
+    Range range_("satba:subspace_products");
     if (!p) return fail(SATBA_E_ARG, "null handle");
     if (!p->have_step) return fail(SATBA_E_STATE, "subspace_products before solve");
     HIP_TRY(hipSetDevice(p->device));
@@ -1168,6 +1204,7 @@ static int trial_impl(satba_problem* p, double c0, double c1, const double* v0, 
 }
 
 int satba_trial(satba_problem* p, double p0, double p1) {
+    Range range_("satba:trial");
     if (!p) return fail(SATBA_E_ARG, "null handle");
     if (!p->have_step) return fail(SATBA_E_STATE, "trial before solve");
     HIP_TRY(hipSetDevice(p->device));
@@ -1175,6 +1212,7 @@ int satba_trial(satba_problem* p, double p0, double p1) {
 }
 
 int satba_trial_gn(satba_problem* p, double ca, double cb) {
+    Range range_("satba:trial");
     if (!p) return fail(SATBA_E_ARG, "null handle");
     if (!p->have_step) return fail(SATBA_E_STATE, "trial before solve");
     HIP_TRY(hipSetDevice(p->device));
@@ -1182,6 +1220,7 @@ int satba_trial_gn(satba_problem* p, double ca, double cb) {
 }
 
 int satba_accept(satba_problem* p) {
+    Range range_("satba:accept");
     if (!p) return fail(SATBA_E_ARG, "null handle");
     std::swap(p->d_x, p->d_xnew);
     std::swap(p->d_camc, p->d_camc_new);
@@ -1566,6 +1605,7 @@ static int lm_host_loop(satba_problem* p, const satba_lm_opts* o, satba_lm_stats
 }
 
 int satba_solve_lm(satba_problem* p, const satba_lm_opts* o, satba_lm_stats* out) {
+    Range range_("satba:solve_lm");
     if (!p || !o || !out) return fail(SATBA_E_ARG, "null argument");
     if (p->world != 1) return fail(SATBA_E_ARG, "satba_solve_lm drives a single-rank handle (world = %d): use the phase entry points", p->world);
     memset(out, 0, sizeof *out);

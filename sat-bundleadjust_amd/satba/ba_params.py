@@ -169,7 +169,9 @@ class BundleAdjustmentParameters:
             if "T" in self.cam_params_to_optimize:
                 self.n_params += _N_T[self.cam_model]
         else:
-            raise Error('correction_params must contain "R"')
+            # the reference builds `cam_params_opt = []` here and fails on `cam_params_opt.ravel()` (AttributeError,
+            # ref:bundle_adjust/ba_params.py:152-170): there is no behaviour to reproduce, only a clearer message
+            raise Error('correction_params must contain "R" (the reference raises AttributeError without it)')
         cam_params_opt = self.cam_params[:, : self.n_params]
         self.params_opt = np.hstack((cam_params_opt.ravel(), self.pts3d.ravel()))
 

@@ -25,7 +25,12 @@ SOLVE_CASES = {
     # every camera sees every point (the two shipped RPCs alternate: same-parity-only points have no parallax)
     "rpc_small_R": ("rpc", 4, 300, 4, 5, {"correction_params": ["R"], "n_cam_fix": 1}, ["linear", "soft_l1"]),
     "persp_small_RT": ("perspective", 5, 300, 4, 4, {"correction_params": ["R", "T"], "n_cam_fix": 1}, ["linear"]),
+    # round 4 (tools/gen_golden.py solves4): the correction mode bench.py times on a BASELINE shape, and a gauge-free problem (no frozen
+    # camera).  Both have flat directions: only gauge-invariant outputs are compared (cost, residual vector, errors)
+    "affine_C2_RT": ("affine", 10, 5000, 6, 1, {"correction_params": ["R", "T"], "n_cam_fix": 1}, ["linear"]),
+    "affine_small_free": ("affine", 6, 400, 4, 2, {"correction_params": ["R"], "n_cam_fix": 0}, ["linear"]),
 }
+FLAT_CASES = ("affine_small_RT", "affine_C2_RT", "affine_small_free")  # parameters are not compared
 SCENE_KW = {"rpc_small_R": {"sigma_theta": 5e-6}}
 
 

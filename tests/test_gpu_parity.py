@@ -358,9 +358,9 @@ def test_tight_solve_matches_tight_scipy_reference(gpu, monkeypatch, name, route
         # north star: residual vector to 1e-6 relative.  Met wherever the reference's finite differences resolve it
         # (measured: C2 1.7e-7 / 8.4e-7, perspective 6e-7 .. 1e-6, rpc vs 3-point 1e-7); the two 6 x 400 affine toys sit
         # on their own finite-difference floor (1.5e-6 / 5e-7 measured) and keep 5e-6
-        r_tol = 5e-6 if name in ("affine_small_R", "affine_small_RT", "persp_small_R") else 1e-6
+        r_tol = 5e-6 if name in ("affine_small_R", "affine_small_RT", "persp_small_R", "affine_small_free") else 1e-6
         assert np.linalg.norm(res.fun - ft) < r_tol * np.linalg.norm(ft), np.linalg.norm(res.fun - ft) / np.linalg.norm(ft)
-        if name != "affine_small_RT":  # R+T on affine cameras with one frozen camera is a flat valley
+        if name not in cases.FLAT_CASES:  # R+T on affine cameras with one frozen camera is a flat valley, no frozen camera a gauge freedom
             # rpc: the angles are ~1e-5 rad and scipy's xtol test (|dx| < xtol |x|, |x| ~ 1e8 m) stops at steps of 1e-7:
             # 1e-5 relative = 1e-10 rad is what the reference run itself resolves (measured 2.7e-6)
             p_tol = 1e-5 if rpc else 1e-6
@@ -381,7 +381,12 @@ def test_default_tolerances_behave_like_reference(gpu, name):
         assert np.allclose(err_init, g["ship_err_init_" + loss], rtol=0, atol=1e-8)
         assert abs(err_ba.mean() - g["ship_err_" + loss].mean()) < 1e-2
         assert abs(np.median(err_ba) - np.median(g["ship_err_" + loss])) < 1e-2
-        assert iters <= 2 * int(g["ship_iters_" + loss]) + 10
+        ref_iters = int(g["ship_iters_" + loss])
+        if loss == "linear":
+            # the exact damped step should not need more evaluations than scipy's LSMR steps do: within 25 % (at least +- 2)
+            assert abs(iters - ref_iters) <= max(2, 0.25 * ref_iters), (iters, ref_iters)
+        else:
+            assert iters <= 2 * ref_iters + 10
 
 
 def test_max_iter_one_only_evaluates(gpu):
@@ -695,6 +700,11 @@ def test_queued_front_matches_host_driven_phases(gpu, name, Delta):
         e.close()
 
 
+def _c3_params():
+    scene = synth.make_affine_scene(50, 100000, 10, seed=1, sigma_theta=2e-6)
+    return synth.make_params(scene, {"correction_params": ["R"], "n_cam_fix": 1})
+
+
 def _two_rank_worker(rank, world, port, name, loss, out_dir, backend="gloo"):
     import sys
 
@@ -715,12 +725,17 @@ def _two_rank_worker(rank, world, port, name, loss, out_dir, backend="gloo"):
     from satba import sharding as sh, trf as tr
     from satba.engine_hip import HipEngine as Eng
 
-    _, make_p, _, _ = cs.solve_case(name)
-    p = make_p()
+    if name == "C3":  # BASELINE shape 50 x 100 k x 1 M (rotations only, one frozen camera: a well-determined minimum)
+        p = _c3_params()
+        tol = dict(ftol=1e-12, xtol=1e-12, gtol=1e-12, max_nfev=40)
+    else:
+        _, make_p, _, _ = cs.solve_case(name)
+        p = make_p()
+        tol = dict(ftol=1e-15, xtol=1e-15, gtol=1e-15, max_nfev=300)
     comm = tr.TorchComm()
     shard = sh.make_shard(p, comm.rank, comm.world)
     eng = Eng(p, shard)
-    res = tr.trf_solve(eng, comm, ftol=1e-15, xtol=1e-15, gtol=1e-15, max_nfev=300, loss=loss)
+    res = tr.trf_solve(eng, comm, loss=loss, **tol)
     x = sh.assemble_x(p, shard, eng.get_x(), comm)
     r = sh.assemble_residuals(p, shard, eng.residuals(), comm)
     np.savez(os.path.join(out_dir, "rank{}.npz".format(rank)), x=x, r=r, cost=res.cost, nfev=res.nfev, status=res.status)
@@ -753,6 +768,35 @@ def test_two_ranks_on_one_gpu(gpu, tmp_path, name, loss):
     assert np.linalg.norm(outs[0]["r"] - g["tight_fun_" + loss]) < 5e-6 * np.linalg.norm(g["tight_fun_" + loss])
     st = g["tight_stats_" + loss]
     assert abs(float(outs[0]["cost"]) - st[0]) < 1e-9 * st[0]
+
+
+def test_sharded_solve_at_C3_matches_single_rank(gpu, tmp_path):
+    """
+    The N > 1 product path at a BASELINE size: 50 x 100 k x 1 M sharded over two ranks (two processes on this GPU, gloo) against the
+    single-rank solve of the same problem -- same evaluations, cost to 1e-12, parameters and residual vector to 1e-9 (the shards sum
+    the camera blocks in another order).
+    """
+    import torch.multiprocessing as mp
+
+    p = _c3_params()
+    eng = HipEngine(p)
+    res = trf.trf_solve(eng, None, loss="linear", ftol=1e-12, xtol=1e-12, gtol=1e-12, max_nfev=40)
+    x1, r1 = eng.get_x(), eng.residuals()
+    eng.close()
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_two_rank_worker, args=(2, port, "C3", "linear", str(tmp_path)), nprocs=2, join=True)
+    outs = [np.load(os.path.join(str(tmp_path), "rank{}.npz".format(r))) for r in range(2)]
+    assert np.array_equal(outs[0]["x"], outs[1]["x"])
+    # (which of ftol / xtol trips first at 1e-12 is a matter of the last bits: 3 on two ranks, 4 on one)
+    assert int(outs[0]["nfev"]) == res.nfev and int(outs[0]["status"]) in (2, 3, 4) and res.status in (2, 3, 4)
+    assert abs(float(outs[0]["cost"]) - res.cost) < 1e-12 * res.cost
+    n_c = p.n_cam * p.n_params
+    assert np.abs(outs[0]["x"][:n_c] - x1[:n_c]).max() < 1e-9 * np.abs(x1[:n_c]).max()
+    assert np.abs(outs[0]["x"][n_c:] - x1[n_c:]).max() < 1e-9 * np.abs(x1[n_c:]).max()
+    assert np.linalg.norm(outs[0]["r"] - r1) < 1e-9 * np.linalg.norm(r1)
 
 
 def test_two_ranks_over_rccl(gpu, tmp_path):

@@ -258,6 +258,19 @@ def test_projection_matrix_json_writer(tmp_path):
     assert np.allclose(P2, P / P[2, 3], rtol=0, atol=0) and off2 == off
 
 
+def test_correction_params_the_reference_cannot_build_raise_error():
+    """`correction_params` without "R" (the reference dies with AttributeError on `[].ravel()`, ref:bundle_adjust/ba_params.py:152-170)
+    and with "K" (it slices the T columns a second time, :163) have no behaviour to reproduce: ba_params.Error, not a silent guess."""
+    from satba import ba_params
+
+    scene = synth.make_affine_scene(4, 30, 3, seed=1)
+    for cp in ([], ["T"], ["R", "T", "K"], ["R", "T", "K", "COMMON_K"]):
+        with pytest.raises(ba_params.Error):
+            synth.make_params(scene, {"correction_params": cp})
+    p = synth.make_params(scene, {"correction_params": ["R", "T"]})
+    assert p.n_params == 5 and p.params_opt.size == 4 * 5 + 3 * 30
+
+
 def test_track_filter_counts_only_pairs_written_i_lt_j():
     """
     satba.ba_outliers._tracks_with_a_listed_pair against a literal restatement of

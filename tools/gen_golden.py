@@ -222,6 +222,26 @@ def golden_solves():
     save("solve_rpc_config1", x_softl1=v1, x_l2=v2, err_init=e0, err_softl1=e1, err_l2=e2, iters=np.array([it1, it2]))
 
 
+def golden_solves_round4():
+    """Round 4: the tight protocol at the correction mode bench.py times (R+T) on a BASELINE shape, and a gauge-free case
+    (no frozen camera).  Both have flat directions: only gauge-invariant outputs are compared (cost, residual vector, errors)."""
+    specs = [
+        ("affine_C2_RT", "affine", 10, 5000, 6, 1, {"correction_params": ["R", "T"], "n_cam_fix": 1}, ["linear"]),
+        ("affine_small_free", "affine", 6, 400, 4, 2, {"correction_params": ["R"], "n_cam_fix": 0}, ["linear"]),
+    ]
+    for name, model, M, N, opp, seed, d, losses in specs:
+        scene = synth.make_scene(model, M, N, opp, seed=seed)
+        out = dict(n_obs=scene.n_obs)
+        for loss in losses:
+            p = ref_params(scene, dict(d, reduce=False))
+            res = tight_solve(p, loss=loss, max_nfev=300)
+            print(name, loss, "tight: status", res.status, "nfev", res.nfev, "cost %.10f" % res.cost, "optimality %.3e" % res.optimality)
+            out.update({"tight_x_" + loss: res.x, "tight_fun_" + loss: res.fun,
+                        "tight_stats_" + loss: np.array([res.cost, res.nfev, res.status, res.optimality])})
+        save("solve_" + name, **out)
+
+
+
 def rpc_fun_f64(p):
     """The reference's rpc residual chain with the float32 store of ba_core.py:150 left out."""
     def f64(v):
@@ -448,13 +468,15 @@ def golden_rpcfit():
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["fun", "params", "solves", "tight2", "outliers", "init_pts3d", "rpcfit"]
+    which = sys.argv[1:] or ["fun", "params", "solves", "solves4", "tight2", "outliers", "init_pts3d", "rpcfit"]
     if "fun" in which:
         golden_fun_and_jac()
     if "params" in which:
         golden_params()
     if "solves" in which:
         golden_solves()
+    if "solves4" in which:
+        golden_solves_round4()
     if "tight2" in which:
         golden_tight_rpc_persp()
     if "outliers" in which:
