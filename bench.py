@@ -227,9 +227,9 @@ def main():
                          "(20000 points took 45 s there)")
     ap.add_argument("--kernel-reps", type=int, default=20)
     ap.add_argument("--loss", default="linear", help="linear (headline) | soft_l1 | huber | cauchy | arctan")
-    ap.add_argument("--driver", default="auto", help="host side of an LM iteration: native (device-resident loop, satba_lm_ticks; one rank) | "
+    ap.add_argument("--driver", default="auto", help="host side of an LM iteration: native (device-resident loop, satba_lm_ticks; one rank) | device (the same for several ranks: tick parts + queued all-reduces) | "
                     "native-sync (C++ host loop, satba_lm_step: two header reads per iteration) | python (phase entry points + all-reduces) | "
-                    "auto (native for one rank)")
+                    "auto (native for one rank, device for several)")
     ap.add_argument("--cpu-c3", action="store_true", help="also run the measured C3 CPU baseline (max_nfev=3, ~10 min)")
     ap.add_argument("--camera-major", action="store_true", help="form the per-camera sums with the camera-major float64 pass from the "
                     "start (SATBA_FLAG_CAMERA_MAJOR_SUMS: the route the fixed-point sums fall back to)")
@@ -281,9 +281,15 @@ def main():
 
     # single rank: the host side of an iteration is the library's C++ (satba_lm_step, the loop body of satba_solve_lm, which is
     # what ba_core's solve runs); several ranks: the Python phases with the all-reduces between them
-    driver = args.driver if args.driver != "auto" else ("native" if world == 1 else "python")
+    # several ranks: "device" = the device-resident loop in parts with the all-reduces queued between them (trf.drive_device_loop: no
+    # host wait inside an iteration), "python" = the host loop with two blocking header reads per iteration (rounds 1-3)
+    driver = args.driver if args.driver != "auto" else ("native" if world == 1 else ("python" if os.environ.get("SATBA_HOST_LOOP") else "device"))
     if driver.startswith("native") and world > 1:
         raise SystemExit("--driver native drives one rank")
+    if driver == "device" and world == 1:
+        raise SystemExit("--driver device is the several-rank form of --driver native")
+    if world > 1:
+        eng.use_torch_stream()
     step = (lambda: lm_step_native(eng, st)) if driver.startswith("native") else (lambda: lm_step(eng, comm, st, trf))
     st = {"first": True, "accepted": 0, "fail": 0, "cost": None}
     # Every timed step is an iteration a real solve performs.  The solve from x0 under the shipped tolerances (ftol 1e-4, xtol 1e-10,
@@ -341,6 +347,10 @@ def main():
         """n iterations, the point going back to x0 every `restart` of them"""
         if ticks:
             return eng.lm_run(n, cycle_len=restart, lam_floor=1e-14)
+        if driver == "device":
+            eng.lm_begin(loss=args.loss, f_scale=1.0, never_stop=True, max_iterations=n, cycle_len=restart)
+            trf.drive_device_loop(eng, comm, 1e-14, max_patterns=24 * n + 1000)
+            return eng.lm_state()
         for _ in range(n):
             step()
         return None
@@ -371,7 +381,7 @@ def main():
     eng.profile_linearize(False)
     st.clear()
     st.update(keep)
-    if ticks:
+    if ticks or driver == "device":
         if int(ls["phase"]) == 2:
             raise SystemExit("the device-resident loop stopped for the host (reason {}): use --driver native-sync".format(int(ls["host_reason"])))
         assert int(ls["iterations"]) == args.steps, ls

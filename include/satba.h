@@ -219,6 +219,19 @@ typedef struct satba_lm_stats {
 } satba_lm_stats;
 int satba_solve_lm(satba_problem *p, const satba_lm_opts *opts, satba_lm_stats *stats);
 
+/* The device-resident loop for several ranks (replaces the host side of scipy:optimize/_lsq/trf.py:450-551 when the points are sharded,
+ * north_star: "LM outer loop on device ... points shard across the 8 GPUs").  A tick is queued in parts with the caller's all-reduces
+ * of the exchange buffer between them (torch.distributed on the handle's stream; satba/trf.py: trf_solve_sharded):
+ *     0 | linearize payload | 1 | header | 2 | reduced system | 3 | header | 4 | header | 5
+ * and the degenerate-subspace pattern  6 | header | 7 | header | 8 | header | 9.  Nothing waits for the device; the decisions are taken
+ * by one-thread kernels on all-reduced scalars, identically on every rank.  satba_lm_begin: reset the loop (o: tolerances, loss;
+ * never_stop / max_iterations / cycle_len as satba_lm_run).  satba_lm_poll (no wait): out[0] patterns executed, [1] phase (0 running,
+ * 1 done, 2 needs the host, 3 paused for the subspace pattern), [2] pauses so far, [3] tick of the latest pause, [4] tick at which the
+ * loop left the running phase (0: not yet).  Every rank must queue exactly out[4] + 3 patterns.  satba_lm_state returns the scalars. */
+int satba_lm_begin(satba_problem* p, const satba_lm_opts* o, int32_t never_stop, int64_t max_iterations, int32_t cycle_len);
+int satba_lm_part(satba_problem* p, int32_t part, double lam_floor);
+int satba_lm_poll(satba_problem* p, int64_t* out, int32_t n);
+
 /* ---- outlier rejection between the two solves of the pipeline (ba_outliers.py:14-58, 112-155): per-camera elbow threshold
  * on the reprojection errors of the current x and the observations above it.
  * err (host, K, caller's observation order, may be NULL: computed from the residuals at the current x as

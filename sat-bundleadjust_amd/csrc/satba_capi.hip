@@ -1352,7 +1352,7 @@ static int lm_reset(satba_problem* p, const satba_lm_opts* o, bool never_stop, b
     init.max_iterations = max_iterations; init.cycle_len = cycle_len;
     if (watch) {  // the host is going to poll the summary: nothing of an earlier run may still post to it
         HIP_TRY(hipStreamSynchronize(p->stream));
-        p->h_lm->word = (unsigned long long)LM_RUN; p->h_lm->sub_requests = 0;
+        p->h_lm->word = (unsigned long long)LM_RUN; p->h_lm->sub_requests = 0; p->h_lm->sub_tick = 0; p->h_lm->end_tick = 0;
     }
     hipLaunchKernelGGL(k_lm_reset, dim3(1), dim3(1), 0, p->stream, p->d_lm, init, keep_counters ? 1 : 0);
     HIP_TRY(hipGetLastError());
@@ -1485,6 +1485,70 @@ int satba_lm_run(satba_problem* p, int64_t n_iterations, int32_t cycle_len, doub
     return 0;
 }
 
+// ---- the device-resident loop for SEVERAL ranks.  The exchange buffer has to be all-reduced five times inside a tick (DESIGN.md
+// section 5) and the collectives are the caller's (torch.distributed on the handle's stream), so the tick comes in parts; the caller
+// queues   part 0 | all-reduce(linearize payload) | 1 | all-reduce(header) | 2 | all-reduce(S, rhs) | 3 | all-reduce(header) | 4 |
+// all-reduce(header) | 5   without waiting for anything: the decisions between the parts are the same one-thread kernels as for one
+// rank, on all-reduced scalars -- every rank decides the same.  The degenerate-subspace pattern: parts 6 | all-reduce(header) | 7 |
+// all-reduce(header) | 8 | all-reduce(header) | 9.  A switched-off part leaves the buffer alone; its all-reduce is still issued (the
+// ranks' collectives must match) and moves stale numbers nobody reads.  satba_lm_poll: the device's progress report (pinned memory,
+// no wait): [0] patterns executed, [1] phase, [2] pauses for the subspace pattern so far, [3] tick of the latest pause, [4] tick at
+// which the loop left LM_RUN (0: still running).  The caller must queue exactly out[4] + LM_RUN_AHEAD patterns (satba/trf.py).
+int satba_lm_begin(satba_problem* p, const satba_lm_opts* o, int32_t never_stop, int64_t max_iterations, int32_t cycle_len) {
+    if (!p || !o || max_iterations < 0 || cycle_len < 0) return fail(SATBA_E_ARG, "bad argument");
+    if (p->n_c > 1024) return fail(SATBA_E_ARG, "the device-resident loop needs a reduced system of at most 1024 unknowns");
+    if (cycle_len > 0 && !p->d_x0) return fail(SATBA_E_STATE, "cycles need a kept point (satba_snapshot_x)");
+    HIP_TRY(hipSetDevice(p->device));
+    p->loss = o->loss; p->f_scale = o->f_scale;
+    return lm_reset(p, o, never_stop != 0, true, false, max_iterations, cycle_len);
+}
+
+int satba_lm_part(satba_problem* p, int32_t part, double lam_floor) {
+    if (!p || part < 0 || part > 9) return fail(SATBA_E_ARG, "bad argument");
+    HIP_TRY(hipSetDevice(p->device));
+    LmDev* st = p->d_lm;
+    LmArgsScope scope(p);
+    switch (part) {
+        case 0: p->gate = &st->run_lin; return satba_linearize(p);
+        case 1: p->gate = &st->run_lin; return satba_prepare(p, 0);
+        case 2: p->gate = &st->run_solve; return satba_schur_auto(p, -1.0, lam_floor);
+        case 3: p->gate = &st->run_solve; return satba_solve(p);
+        case 4:
+            hipLaunchKernelGGL(k_lm_decide1a, dim3(1), dim3(1), 0, p->stream, st, p->d_xb);
+            p->gate = &st->run_trial;
+            return satba_trial_gn(p, 0.0, 0.0);
+        case 6: p->gate = &st->run_sub; return satba_subspace(p, 0.0, 0.0);
+        case 7:
+            hipLaunchKernelGGL(k_lm_decide1b, dim3(1), dim3(1), 0, p->stream, st, p->d_xb);
+            p->gate = &st->run_prod;
+            return satba_subspace_products(p);
+        case 8:
+            hipLaunchKernelGGL(k_lm_decide1c, dim3(1), dim3(1), 0, p->stream, st, p->d_xb);
+            p->gate = &st->run_trial;
+            return satba_trial_gn(p, 0.0, 0.0);
+        default: break;  // 5, 9: decision, accepted point into place
+    }
+    hipLaunchKernelGGL(k_lm_decide2, dim3(1), dim3(1), 0, p->stream, st, p->d_xb, p->h_lm_dev);
+    const double* x0 = p->d_x0;
+    hipLaunchKernelGGL(k_lm_accept, dim3(grid_for(p->n / 2 + 1, 256, 1024)), dim3(256), 0, p->stream, st, (long long)p->n, p->d_x, p->d_xnew,
+                       p->M * CAMC, p->d_camc, p->d_camc_new, p->d_fxcost, p->d_fxcost_new, x0, x0 ? x0 + p->n + 6 : nullptr, p->d_fxcost0, p->d_bbox);
+    HIP_TRY(hipGetLastError());
+    p->linearized = true; p->prepared = false; p->have_step = true;
+    p->fxcost_valid = true; p->fxcost_new_valid = false;
+    ++p->lm_ticks_queued;
+    return 0;
+}
+
+int satba_lm_poll(satba_problem* p, int64_t* out, int32_t n) {
+    if (!p || !out || n < 5) return fail(SATBA_E_ARG, "bad argument");
+    const unsigned long long w = __atomic_load_n(&p->h_lm->word, __ATOMIC_ACQUIRE);
+    out[0] = lm_summary_tick(w); out[1] = lm_summary_phase(w);
+    out[2] = __atomic_load_n(&p->h_lm->sub_requests, __ATOMIC_ACQUIRE);
+    out[3] = __atomic_load_n(&p->h_lm->sub_tick, __ATOMIC_ACQUIRE);
+    out[4] = __atomic_load_n(&p->h_lm->end_tick, __ATOMIC_ACQUIRE);
+    return 0;
+}
+
 int satba_lm_state(satba_problem* p, double* out, int32_t n) {
     if (!p || !out || n < 16) return fail(SATBA_E_ARG, "bad argument");
     HIP_TRY(hipSetDevice(p->device));
@@ -1494,6 +1558,7 @@ int satba_lm_state(satba_problem* p, double* out, int32_t n) {
     out[0] = st.cost; out[1] = st.cost_new; out[2] = st.Delta; out[3] = st.accepted_total; out[4] = st.interior_total;
     out[5] = st.predicted; out[6] = st.actual; out[7] = st.reg; out[8] = st.phase; out[9] = st.status; out[10] = (double)st.nfev;
     out[11] = (double)st.njev; out[12] = (double)st.iterations; out[13] = (double)st.tick; out[14] = st.host_reason; out[15] = st.g_norm;
+    if (n > 16) out[16] = st.initial_cost;
     return 0;
 }
 

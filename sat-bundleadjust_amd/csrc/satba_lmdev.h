@@ -49,6 +49,7 @@ struct LmDev {
     long long nfev, njev, iterations, max_nfev, tick;
     long long max_iterations;  // fixed-work runs (never_stop): stop after this many iterations (0: never)
     long long sub_requests;
+    long long sub_tick, end_tick;  // the tick (1-based) of the latest pause for the subspace pattern / at which the loop left LM_RUN (0: not yet)
     // trust region and the scalars of scipy's loop
     double Delta, cost, g_norm, initial_cost, step_norm, actual;
     // quadratic model on the orthonormal basis of span{g_h, gn_h} (kept across rejected trials)
@@ -68,6 +69,9 @@ struct LmDev {
 struct LmSummary {
     unsigned long long word;
     long long sub_requests;
+    // for several ranks (satba_lm_part): every rank must queue the SAME number of patterns, so the host does not act on "the latest
+    // report" but on these two tick numbers, which are functions of all-reduced scalars only
+    long long sub_tick, end_tick;
 };
 __host__ __device__ inline long long lm_summary_tick(unsigned long long w) { return (long long)(w >> 8); }
 __host__ __device__ inline int lm_summary_phase(unsigned long long w) { return (int)(w & 0xff); }
@@ -171,6 +175,7 @@ __global__ void k_lm_decide1a(LmDev* __restrict__ gst, const double* __restrict_
         st->run_sub = 1;
         st->phase = LM_NEED_SUB;
         st->sub_requests += 1;
+        st->sub_tick = st->tick + 1;
     }
 }
 
@@ -264,6 +269,9 @@ __global__ void k_lm_decide2(LmDev* __restrict__ gst, const double* __restrict__
     }
     st->run_trial = 0;
     st->tick += 1;
+    if (st->end_tick == 0 && st->phase != LM_RUN && st->phase != LM_NEED_SUB) st->end_tick = st->tick;
+    __hip_atomic_store(&sum->sub_tick, st->sub_tick, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&sum->end_tick, st->end_tick, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __hip_atomic_store(&sum->sub_requests, st->sub_requests, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __hip_atomic_store(&sum->word, ((unsigned long long)st->tick << 8) | (unsigned long long)st->phase, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }

@@ -30,7 +30,7 @@ SYMBOLS = [
     "satba_accept", "satba_camera_sums_fallback", "satba_read_header", "satba_get_blocks", "satba_get_jacobian", "satba_get_exchange",
     "satba_set_exchange", "satba_get_vector", "satba_time_kernel",
     "satba_packed_schur_len", "satba_pack_schur", "satba_unpack_schur",
-    "satba_solve_lm", "satba_lm_step", "satba_lm_run", "satba_lm_state", "satba_profile_linearize", "satba_profile_read", "satba_outliers", "satba_layout_len", "satba_get_layout", "satba_get_info",
+    "satba_solve_lm", "satba_lm_step", "satba_lm_run", "satba_lm_state", "satba_lm_begin", "satba_lm_part", "satba_lm_poll", "satba_profile_linearize", "satba_profile_read", "satba_outliers", "satba_layout_len", "satba_get_layout", "satba_get_info",
     "satba_triangulate_pairwise", "satba_init_pts3d", "satba_snapshot_x",
     "satba_rpc_fit", "satba_rpc_localization", "satba_rpc_refit",
 ]
@@ -118,6 +118,9 @@ def load_library(path=None):
     lib.satba_solve_lm.argtypes = [h, C.POINTER(LmOpts), C.POINTER(LmStats)]
     lib.satba_lm_step.argtypes = [h, C.c_int32, C.c_double, C.c_double, C.POINTER(C.c_double)]
     lib.satba_lm_run.argtypes = [h, C.c_int64, C.c_int32, C.c_double, C.POINTER(C.c_double), C.c_int32]
+    lib.satba_lm_begin.argtypes = [h, C.POINTER(LmOpts), C.c_int32, C.c_int64, C.c_int32]
+    lib.satba_lm_part.argtypes = [h, C.c_int32, C.c_double]
+    lib.satba_lm_poll.argtypes = [h, C.POINTER(C.c_int64), C.c_int32]
     lib.satba_lm_state.argtypes = [h, C.POINTER(C.c_double), C.c_int32]
     lib.satba_profile_linearize.argtypes = [h, C.c_int32]
     lib.satba_profile_read.argtypes = [h, C.POINTER(C.c_int64), C.POINTER(C.c_double)]
@@ -220,6 +223,7 @@ class HipEngine:
                 # several ranks: the kernels must order with the collectives torch.distributed queues on torch's current stream
                 self.use_stream(torch.cuda.current_stream(self.device))
         self._hdr_host = np.zeros(self.hdr)
+        self._poll = np.zeros(5, dtype=np.int64)
         self.xp = None  # packed Schur payload (header | lower triangle of S | rhs), allocated on first use
         self.len_schur_packed = int(self.lib.satba_packed_schur_len(self._h))
         self.set_x(sh.local_x(p, np.asarray(p.params_opt, dtype=np.float64)))
@@ -351,7 +355,7 @@ class HipEngine:
         return dict(zip(keys, out))
 
     LM_KEYS = ["cost", "cost_new", "Delta", "accepted", "newton", "predicted", "actual", "lam", "phase", "status", "nfev", "njev",
-               "iterations", "ticks", "host_reason", "g_norm"]
+               "iterations", "ticks", "host_reason", "g_norm", "initial_cost"]
 
     def lm_run(self, n_iterations, cycle_len=0, lam_floor=0.0):
         """
@@ -363,10 +367,26 @@ class HipEngine:
         _check(self.lib, self.lib.satba_lm_run(self._h, int(n_iterations), int(cycle_len), float(lam_floor), _ptr(out), 16))
         return dict(zip(self.LM_KEYS, out))
 
+    def lm_begin(self, ftol=1e-8, xtol=1e-8, gtol=1e-8, max_nfev=None, loss="linear", f_scale=1.0, never_stop=False, max_iterations=0,
+                 cycle_len=0):
+        """satba_lm_begin: reset the device-resident loop (several ranks: the parts of a tick are queued with lm_part)."""
+        o = LmOpts(ftol=ftol, xtol=xtol, gtol=gtol, f_scale=f_scale, max_nfev=-1 if max_nfev is None else int(max_nfev),
+                   loss=LOSSES[loss], verbose=0)
+        _check(self.lib, self.lib.satba_lm_begin(self._h, C.byref(o), 1 if never_stop else 0, int(max_iterations), int(cycle_len)))
+
+    def lm_part(self, part, lam_floor=0.0):
+        _check(self.lib, self.lib.satba_lm_part(self._h, int(part), float(lam_floor)))
+
+    def lm_poll(self):
+        """satba_lm_poll (no wait): (patterns executed, phase, pauses for the subspace pattern, tick of the latest pause, tick at which
+        the loop left the running phase or 0)."""
+        _check(self.lib, self.lib.satba_lm_poll(self._h, self._poll.ctypes.data_as(C.POINTER(C.c_int64)), 5))
+        return tuple(int(v) for v in self._poll)
+
     def lm_state(self):
         """satba_lm_state: wait for the stream and return the scalars of the device-resident loop as a dict."""
-        out = np.zeros(16)
-        _check(self.lib, self.lib.satba_lm_state(self._h, _ptr(out), 16))
+        out = np.zeros(17)
+        _check(self.lib, self.lib.satba_lm_state(self._h, _ptr(out), 17))
         return dict(zip(self.LM_KEYS, out))
 
     def solve_lm(self, ftol=1e-8, xtol=1e-8, gtol=1e-8, max_nfev=None, loss="linear", f_scale=1.0, verbose=0):

@@ -310,6 +310,85 @@ def subspace_model(engine, exchange, ga, gb, gc, jg_sq, reg):
     return B_S, np.array([sa, ghw / nw]), lambda p_S: (p_S[0] / sa - p_S[1] * alpha / nw, p_S[1] / nw)
 
 
+# ----------------------------------------------------------------------------- the loop on the device, several ranks
+
+LM_RUN, LM_DONE, LM_NEED_HOST, LM_NEED_SUB = 0, 1, 2, 3
+LM_RUN_AHEAD = 3  # csrc/satba_lmdev.h
+
+
+def drive_device_loop(engine, comm, lam_floor=0.0, max_patterns=None, watchdog_s=60.0):
+    """
+    Queue the launch patterns of the device-resident loop (csrc/satba_lmdev.h) for a sharded problem: the parts of a tick
+    (engine.lm_part) with the all-reduces of the exchange buffer between them, all on one stream, nothing waits for the device --
+    the decisions between the parts are one-thread kernels on all-reduced scalars, the same on every rank.
+
+    Every rank must issue the SAME sequence of collectives, so the host does not act on "the latest report it happens to see":
+    pattern i is queued once the device has reported pattern i - 1 - LM_RUN_AHEAD, and what pattern i is -- a tick, the
+    degenerate-subspace pattern, or nothing because the loop has ended -- follows from two tick numbers in that report which are
+    functions of all-reduced scalars only: the tick of the latest pause (the subspace pattern is pattern number pause +
+    LM_RUN_AHEAD + 1) and the tick at which the loop left the running phase (end + LM_RUN_AHEAD patterns are queued in all).
+    Returns the number of patterns queued.  Call engine.lm_begin first; engine.lm_state() afterwards waits for the stream.
+    """
+    import time
+
+    hdr = engine.hdr
+    queued, served = 0, 0
+
+    def tick():
+        engine.lm_part(0, lam_floor)
+        comm.allreduce(engine, engine.len_lin)
+        engine.lm_part(1)
+        comm.allreduce(engine, hdr)
+        engine.lm_part(2, lam_floor)
+        comm.allreduce_schur(engine)
+        engine.lm_part(3)
+        comm.allreduce(engine, hdr)
+        engine.lm_part(4)
+        comm.allreduce(engine, hdr)
+        engine.lm_part(5)
+
+    def sub_pattern():
+        for part in (6, 7, 8):
+            engine.lm_part(part)
+            comm.allreduce(engine, hdr)
+        engine.lm_part(9)
+
+    while True:
+        t0 = time.perf_counter()
+        while True:
+            done, phase, subreq, sub_tick, end_tick = engine.lm_poll()
+            if done >= queued - LM_RUN_AHEAD:
+                break
+            if time.perf_counter() - t0 > watchdog_s:
+                raise RuntimeError("device-resident loop: no progress report from the device for {} s".format(watchdog_s))
+        if end_tick and queued >= end_tick + LM_RUN_AHEAD:
+            return queued
+        if max_patterns is not None and queued > max_patterns:
+            raise RuntimeError("device-resident loop: {} launch patterns queued without reaching the end".format(queued))
+        if subreq > served and queued == sub_tick + LM_RUN_AHEAD:
+            sub_pattern()
+            served = subreq
+        else:
+            tick()
+        queued += 1
+
+
+def trf_solve_sharded(engine, comm, ftol, xtol, gtol, max_nfev, loss, f_scale):
+    """The loop for several ranks with its decisions on the device (drive_device_loop).  Returns a Result, or None when the device
+    handed over to the host (overflow of the fixed-point camera sums, a factorisation that failed ten times, non-finite residuals):
+    the caller continues with the host loop from the point the device stopped at."""
+    engine.lm_begin(ftol=ftol, xtol=xtol, gtol=gtol, max_nfev=max_nfev, loss=loss, f_scale=f_scale)
+    nmax = max_nfev if max_nfev is not None else engine.n_total * 100
+    drive_device_loop(engine, comm, 0.0, max_patterns=24 * nmax + 1000)
+    st = engine.lm_state()
+    if int(st["phase"]) != LM_DONE:
+        return None
+    status = int(st["status"]) if int(st["status"]) >= 0 else 0
+    return Result(cost=st["cost"], optimality=st["g_norm"], nfev=int(st["nfev"]), njev=int(st["njev"]), status=status,
+                  success=status > 0, message=TERMINATION_MESSAGES[status], iterations=int(st["iterations"]),
+                  initial_cost=st["initial_cost"])
+
+
 # ----------------------------------------------------------------------------- the loop
 
 def trf_solve(engine, comm=None, ftol=1e-8, xtol=1e-8, gtol=1e-8, max_nfev=None, loss="linear", f_scale=1.0,
@@ -338,6 +417,20 @@ def trf_solve(engine, comm=None, ftol=1e-8, xtol=1e-8, gtol=1e-8, max_nfev=None,
         return res
     if isinstance(comm, TorchComm) and (comm.world > 1 or comm.always) and hasattr(engine, "use_torch_stream"):
         engine.use_torch_stream()  # the all-reduces are queued on torch's stream: the phases must order with them
+        # several ranks: the decisions of the loop on the device, the host only queues (no header read inside an iteration);
+        # SATBA_HOST_LOOP=1 or an iteration table (verbose 2) keep the host loop below, and so does a hand-over by the device
+        if (hasattr(engine, "lm_part") and verbose < 2 and timers is None and not os.environ.get("SATBA_HOST_LOOP")
+                and engine.n_c <= 1024):
+            engine.configure(loss, f_scale)
+            res = trf_solve_sharded(engine, comm, ftol, xtol, gtol, max_nfev, loss, f_scale)
+            if res is not None:
+                if verbose >= 1:
+                    print(res.message)
+                    print("Function evaluations {}, initial cost {:.4e}, final cost {:.4e}, first-order optimality {:.2e}."
+                          .format(res.nfev, res.initial_cost, res.cost, res.optimality))
+                return res
+            if getattr(engine, "camera_sums_fallback", None):
+                engine.camera_sums_fallback()  # (all ranks stop for the same reason: the flag travels in an all-reduced header)
     hdr = engine.hdr
     slots = slice(engine.HDR_FIXED, engine.HDR_FIXED + comm.world)
     if max_nfev is None:
@@ -365,8 +458,11 @@ def trf_solve(engine, comm=None, ftol=1e-8, xtol=1e-8, gtol=1e-8, max_nfev=None,
             h = exchange(hdr)
             # K_FX_BAD (summed over the ranks): a term of some shard's fixed-point camera sums left its range -- every rank
             # switches to the camera-major sums and repeats the iteration (include/satba.h, SATBA_HDR_FX_BAD)
-            if h[K_FX_BAD] == 0 or not getattr(engine, "camera_sums_fallback", None) or not engine.camera_sums_fallback():
+            # (the decision depends on the all-reduced flag only: every rank switches and repeats together, whatever route its own
+            # handle was on -- a rank that returned here while the others loop again would leave their collectives unmatched)
+            if h[K_FX_BAD] == 0 or not getattr(engine, "camera_sums_fallback", None):
                 return h
+            engine.camera_sums_fallback()
 
     engine.configure(loss, f_scale)
     h = front(None)
