@@ -231,6 +231,8 @@ def main():
                     "native-sync (C++ host loop, satba_lm_step: two header reads per iteration) | python (phase entry points + all-reduces) | "
                     "auto (native for one rank, device for several)")
     ap.add_argument("--cpu-c3", action="store_true", help="also run the measured C3 CPU baseline (max_nfev=3, ~10 min)")
+    ap.add_argument("--backend", default="nccl", help="collective backend for several ranks: nccl (= RCCL; what the scaling runs use) | gloo (tests)")
+    ap.add_argument("--share-gpu", action="store_true", help="tests: all ranks on GPU 0 (a one-GPU box; needs --backend gloo)")
     ap.add_argument("--camera-major", action="store_true", help="form the per-camera sums with the camera-major float64 pass from the "
                     "start (SATBA_FLAG_CAMERA_MAJOR_SUMS: the route the fixed-point sums fall back to)")
     args = ap.parse_args()
@@ -258,9 +260,14 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("--gpus {} but {} rank(s) were launched".format(args.gpus, world))
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend)
 
     from satba import sharding, synth, trf
     from satba.engine_hip import HipEngine

@@ -396,3 +396,33 @@ def test_bench_line_contract(gpu, driver):
     assert d["deterministic"] is True and d["camera_sums"] == "fixed_point_lds" and d["fixed_point_fallbacks"] == 0
     assert r["launches_timed"] == 8 and d["restart_every"] >= 1 and d["host_driver"] == driver
     assert d["accepted_steps"] >= 4  # restarts keep the timed steps productive
+
+
+@pytest.mark.parametrize("driver", ["device", "python"])
+def test_bench_line_two_ranks(gpu, driver):
+    """bench.py --gpus 2 the way the scaling runs launch it (torch.distributed.run, one process per rank), on this one GPU over gloo
+    (--backend gloo --share-gpu: test switches): the line of rank 0, whole-job value, the per-phase breakdown, both host drivers."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
+           str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--shape", "C2", "--steps", "8", "--warmup", "2", "--cpu-sample-pts", "0",
+           "--backend", "gloo", "--share-gpu", "--driver", driver]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 8 and d["host_driver"] == driver and d["scaling"] == "strong"
+    assert abs(d["value"] - 1000.0 / d["ms_per_step"]) < 1e-6 * d["value"]
+    ph = d["phase_ms"]
+    for k in ("linearize", "prepare", "schur", "dense_solve", "trial", "allreduce", "allreduce_schur", "host_wait"):
+        assert k in ph and ph[k] >= 0.0, k
+    assert d["accepted_steps"] >= 4 and d["config"]["obs_per_rank0"] < 29981  # a shard, not the whole scene
