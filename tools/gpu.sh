@@ -7,6 +7,7 @@
 #   tools/gpu.sh TAG pmc SHAPE LOSS REGEX        PMC passes (separate runs, counters only) over tools/kernel_times.py -> pmc_summary.txt
 #   tools/gpu.sh TAG pmc_loop SHAPE LOSS         FETCH_SIZE / WRITE_SIZE of the kernels inside LM iterations -> pmc_summary.txt
 #   tools/gpu.sh TAG chol N...                   tools/chol/chol_bench (dense solve harness) at the given sizes
+#   tools/gpu.sh TAG calib                       tools/ubench/fetch_calib.bin: FETCH_SIZE / request counters against known byte counts
 # (rounds 1-3 had one script per experiment: tools/gpu_*.sh, 21 of them)
 tag=$1; cmd=$2; shift 2
 out=$GRAFT_REPO_ROOT/gpurun_out/$tag
@@ -61,5 +62,14 @@ pmc|pmc_loop)
   find $out -name "*.csv" -size +1M -delete; find $out -name "*.db" -size +8M -delete ;;
 chol)
   cd tools/chol && timeout 300 ./chol_bench 10 "$@" > $out/chol.log 2>&1; grep "tiles\|driver\|ok\|FAIL" $out/chol.log | cut -c1-175 ;;
+calib)
+  cd /tmp && export TMPDIR=/tmp
+  $GRAFT_REPO_ROOT/tools/ubench/fetch_calib.bin > $out/plain.txt 2>&1
+  i=0
+  for set in "FETCH_SIZE" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "TCC_HIT_sum TCC_MISS_sum" "TCP_TCC_READ_REQ_sum"; do
+    i=$((i+1))
+    timeout 300 rocprofv3 --pmc $set --kernel-trace -d $out/c$i -o c -- $GRAFT_REPO_ROOT/tools/ubench/fetch_calib.bin > $out/c$i.log 2>&1
+  done
+  python3 $GRAFT_REPO_ROOT/tools/ubench/calib_summary.py $out > $out/summary.txt; cat $out/summary.txt ;;
 *) echo "unknown sub-command $cmd"; exit 2 ;;
 esac
