@@ -786,7 +786,7 @@ int satba_problem_create(const satba_problem_desc* d, satba_problem** out) {
             ++p->lin_rep_shift;
         if (const char* rs = getenv("SATBA_LIN_REP")) p->lin_rep_shift = std::min(4, std::max(0, atoi(rs)));  // experiments
         const size_t acc_b = cam_sum_bytes(p->NP, (size_t)(p->M << p->lin_rep_shift));
-        p->cam_sums_lds = (acc_b <= budget && !p->deterministic && !getenv("SATBA_CAM_SUMS") && p->n_max_cam <= (double)(1 << 28)) ? 1 : 0;
+        p->cam_sums_lds = (acc_b <= budget && !p->deterministic && !getenv("SATBA_CAM_SUMS") && p->n_max_cam <= (double)FX_MAX_OBS_PER_CAM) ? 1 : 0;
         size_t used = p->cam_sums_lds ? acc_b : 0;
         p->camc_lds = (camc_b <= 48 * 1024 && used + camc_b <= budget && !getenv("SATBA_CAMC_GLOBAL")) ? 1 : 0;
         used += p->camc_lds ? camc_b : 0;

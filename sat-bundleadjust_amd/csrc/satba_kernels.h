@@ -34,6 +34,10 @@ __host__ __device__ constexpr int cam_acc_stride(int np) { return cam_acc_len(np
 __host__ __device__ constexpr int cam_sum_len(int np) { return 3 * np; }
 __host__ __device__ constexpr int cam_sum_stride(int np) { return (3 * np) | 1; }
 constexpr int FX_LO_SHIFT = 40;  // the low limb of a g_c term holds its remainder below the high limb's unit, scaled by 2^40
+// The high limbs are scaled per problem for the camera with the most observations (k_lin_scales: Q = 62 - log2 n_max) and range-checked
+// per term; the low limb is not: a term is at most 2^(FX_LO_SHIFT - 1) there, so its sum stays inside 63 bits for fewer than
+// 2^(63 - 39) = 2^24 observations of one camera.  Problems above this bound (with a factor 2 to spare) take the camera-major sums.
+constexpr long long FX_MAX_OBS_PER_CAM = 1ll << 23;
 __host__ __device__ constexpr size_t cam_sum_bytes(int np, size_t rows) { return rows * cam_sum_stride(np) * 8; }
 
 constexpr int RPCS = 91;  // row stride of the LDS copy of the RPC tables (90 used, odd)

@@ -103,6 +103,13 @@ __device__ inline void lm_trial_step(LmDev* st) {
     st->run_trial = 1;
 }
 
+// Hand-over to the host loop: every gate goes down with the phase, so that the ticks already queued behind this one (up to
+// LM_RUN_AHEAD) pass through empty instead of repeating the front at the same x (the host loop starts from x, not from the gates)
+__device__ inline void lm_to_host(LmDev* st, int reason) {
+    st->phase = LM_NEED_HOST; st->host_reason = reason;
+    st->run_lin = 0; st->run_solve = 0;
+}
+
 // After the front (the parts of it that ran): bookkeeping of a new linearisation and scipy's top-of-loop tests, the damping
 // escalation after a failed factorisation, the quadratic model from the normal equations -- or the request for the explicit
 // subspace vectors when the two directions are parallel to 1e-6 (satba/trf.py: subspace_model).  h: the solve header.
@@ -121,11 +128,11 @@ __global__ void k_lm_decide1a(LmDev* __restrict__ gst, const double* __restrict_
         return;
     }
     // fixed-point overflow of the camera sums: the host switches the summation route and repeats (nothing is booked)
-    if (h[LMH_FX_BAD] != 0.0) { st->phase = LM_NEED_HOST; st->host_reason = LM_HOST_FX; return; }
+    if (h[LMH_FX_BAD] != 0.0) { lm_to_host(st, LM_HOST_FX); return; }
     if (st->run_lin) {
         // bookkeeping of the new linearisation (scipy trf.py:536-546 after an accepted step; :405-426 before the loop)
         const double cost = h[LMH_K_COST];
-        if (st->first && !isfinite(cost)) { st->phase = LM_NEED_HOST; st->host_reason = LM_HOST_NONFINITE; return; }
+        if (st->first && !isfinite(cost)) { lm_to_host(st, LM_HOST_NONFINITE); return; }
         st->cost = cost;
         st->g_norm = h[LMH_K_GINF];
         if (st->first) {
@@ -148,7 +155,7 @@ __global__ void k_lm_decide1a(LmDev* __restrict__ gst, const double* __restrict_
     }
     // a Cholesky needs a floor where LSMR copes with a numerically singular system: escalate the damping and factorise again
     if (!(h[LMH_CHOL_FAIL] == 0.0) || !isfinite(h[LMH_GRAM_C])) {
-        if (++st->attempts > 10) { st->phase = LM_NEED_HOST; st->host_reason = LM_HOST_CHOL; return; }
+        if (++st->attempts > 10) { lm_to_host(st, LM_HOST_CHOL); return; }
         st->reg = fmax(st->reg, 1e-16) * 100.0;
         st->lam_force = st->reg;
         return;  // run_solve stays up: the next tick forms the Schur complement with the forced damping and solves again

@@ -292,10 +292,8 @@ __global__ __launch_bounds__(256) void k_refit_grid(int n, const RefitCam* __res
 __global__ __launch_bounds__(256) void k_refit_check(int n, const RefitCam* __restrict__ cams, const double* __restrict__ tables,
                                                      const double* __restrict__ grid, const double* __restrict__ locs, const double* __restrict__ target,
                                                      double* __restrict__ err, int* __restrict__ covered) {
-    constexpr int MAXP = REFIT_MAX_N * REFIT_MAX_N * REFIT_MAX_N;
     __shared__ double s_tab[TRI_RPC_STRIDE];
-    __shared__ double2 s_p[MAXP];
-    __shared__ double s_key[256];
+    extern __shared__ double2 s_p[];  // n^3 re-projected nodes (dynamic: 16 KB at the reference's n = 10, 64 KB at REFIT_MAX_N)
     __shared__ int s_idx[256];
     __shared__ int s_bad;
     const int cam = blockIdx.x, tid = threadIdx.x, n3 = n * n * n;
@@ -362,7 +360,6 @@ __global__ __launch_bounds__(256) void k_refit_check(int n, const RefitCam* __re
     }
     __syncthreads();
     if (tid == 0) covered[c.slot] = s_bad ? 0 : 1;
-    (void)s_key;
 }
 
 }  // namespace satba
