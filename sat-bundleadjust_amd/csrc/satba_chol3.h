@@ -228,7 +228,8 @@ struct C3Lds {
     int* tb_cnt;            // += 1 per wave of the next diagonal tile (two) and step: its blocks are in Tb
     int* pub_cnt;           // += 1 per storing wave of L_kk^-1, y_k and step (4 + 1)
     int* pubR_cnt;          // += 1 per storing wave of R and step (4)
-    int* mir_cnt;           // += 1 per wave of the identity and step: its rows of L^T (diagonal tile and R) are written
+    int* mir_cnt;           // += 4 per step: the diagonal tile's micro-panels have been read for L^T (16 rows at a time)
+    int* mirR_cnt;          // ... and R's
     int* prod_cnt;          // += 1 per wave of R and step: its share of the next input is formed (R's rows in LDS may go)
     int* b_rdy;             // = step + 1 when bcur[step & 1] is ready
     int* inv_flag;          // [8]: inv8[p] is ready (value: step + 1)
@@ -242,7 +243,7 @@ __device__ __forceinline__ C3Lds c3_carve(double* lds) {
     l.bcur = l.yv + 64;
     l.inv8 = l.bcur + 128;
     int* li = reinterpret_cast<int*>(l.inv8 + 512);
-    l.lf = li; l.tb_cnt = li + 24; l.pub_cnt = li + 25; l.b_rdy = li + 26; l.pubR_cnt = li + 27; l.prod_cnt = li + 28; l.mir_cnt = li + 29; l.inv_flag = li + 32;
+    l.lf = li; l.tb_cnt = li + 24; l.pub_cnt = li + 25; l.b_rdy = li + 26; l.pubR_cnt = li + 27; l.prod_cnt = li + 28; l.mir_cnt = li + 29; l.mirR_cnt = li + 30; l.inv_flag = li + 32;
     return l;
 }
 
@@ -252,21 +253,26 @@ __device__ __forceinline__ C3Lds c3_carve(double* lds) {
 // counted: the next step may reuse the blocks while the stores go out.  (History: as 8-byte stores scattered over 64 lines by the
 // waves that hold the tiles, in front of their drains: +25 us per factorisation; in the riders' function, an LDS address reloaded from
 // scratch per row, whose s_waitcnt vmcnt(0) waited for the previous store: 11 us per step.)
-__device__ __forceinline__ void c3_mirror_rows(double* A, int n, int r0, int w, int has_r, int* done_cnt) {
+__device__ __forceinline__ void c3_mirror_part(double* A, int n, int r0, int w, int set, int* done_cnt) {
     extern __shared__ __attribute__((aligned(16))) double c3_lds[];
     const int lane = threadIdx.x & 63;
-    const double* src = c3_lds + (lane >> 3) * C3_BLK + (lane & 7);  // column `lane` of a row: micro-panel lane / 8, entry lane % 8
-    double vd[16], vr[16];
+    const double* src = c3_lds + set * 8 * C3_BLK + (lane >> 3) * C3_BLK + (lane & 7);  // column `lane` of a row: micro-panel lane / 8, entry lane % 8
+    double v[16];
 #pragma unroll
-    for (int rr = 0; rr < 16; ++rr) { vd[rr] = src[(16 * w + rr) * C3_RS]; vr[rr] = src[8 * C3_BLK + (16 * w + rr) * C3_RS]; }
-    C3_PIN4(vd[15], vr[15], vd[14], vr[14]);
+    for (int rr = 0; rr < 16; ++rr) v[rr] = src[(16 * w + rr) * C3_RS];
+    C3_PIN4(v[15], v[14], v[13], v[12]);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (lane == 0) c3_lds_inc(done_cnt);  // the rows are in registers: the micro-panel blocks may be reused while the stores go out
+    // (the address arithmetic must stay here: hoisted out of the step loop it put the wave's registers into scratch, and a reload
+    // from scratch waits for every store in front of it)
+    asm volatile("" : "+v"(n), "+v"(A), "+v"(r0));
+    const int c0 = r0 + 64 * set + 16 * w;  // first of my 16 columns of the upper triangle
+    double* dst = A + (size_t)(r0 + lane) + (size_t)c0 * n;
 #pragma unroll
     for (int rr = 0; rr < 16; ++rr) {
-        const int r = 16 * w + rr;
-        if (r0 + r < n && lane < r && r0 + lane < n) c3_gst(A + (size_t)(r0 + lane) + (size_t)(r0 + r) * n, vd[rr]);
-        if (has_r && r0 + 64 + r < n) c3_gst(A + (size_t)(r0 + lane) + (size_t)(r0 + 64 + r) * n, vr[rr]);
+        const bool ok = (set == 0) ? (c0 + rr < n && lane < 16 * w + rr) : (c0 + rr < n);
+        if (ok) c3_gst(dst, v[rr]);
+        dst += n;
     }
 }
 
@@ -336,7 +342,7 @@ __device__ __noinline__ void c3_chain_diag(int q, double* A, int n, int T, int* 
         const bool has_r = k + 1 < T;
         // the identity's riders still read the micro-panels of the previous step (R's are done: the hand-over buffer is complete)
         if (k > 0 && !c3_wait_lds(l.lf + 16 + 7, 4 * k, fail)) return;
-        if (mirror && k > 0 && !c3_wait_lds(l.mir_cnt, 4 * k, fail)) return;  // ... and have written L^T of the previous step from LDS
+        if (mirror && k > 0 && !c3_wait_lds(l.mir_cnt, 4 * k, fail)) return;  // ... and the inverter's wave has read them for L^T
         C3_STAMP(ts, k * C3_TS + 0, tid == 0);
         const bool bad = c3_panel(a, q, lane, l.pan, l.pinv, l.lf, step1, fail, ts ? ts + k * C3_TS + 8 : nullptr);
         if (bad && lane == 0) atomicOr(fail, 1);
@@ -409,7 +415,7 @@ __device__ __noinline__ void c3_chain_rider(int set, int w, double* A, int n, in
             // the right-hand side's wave is done with this set's rows of the previous step, and so are the products of R's four waves
             if (k > 0 && !c3_wait_lds(l.b_rdy, step1, fail)) return;
             if (isR && k > 0 && !c3_wait_lds(l.prod_cnt, 4 * k, fail)) return;
-            if (isR && mirror && k > 0 && !c3_wait_lds(l.mir_cnt, 4 * k, fail)) return;
+            if (isR && mirror && k > 0 && !c3_wait_lds(l.mirR_cnt, 4 * k, fail)) return;
 #pragma unroll
             for (int p = 0; p < 8; ++p) {
                 const int cb = p >> 1, h = p & 1;
@@ -418,10 +424,13 @@ __device__ __noinline__ void c3_chain_rider(int set, int w, double* A, int n, in
                 const double i0 = (e16 < 8) ? l.inv8[p * 64 + e16 * 8 + g4] : 0.0;
                 const double i1 = (e16 < 8) ? l.inv8[p * 64 + e16 * 8 + 4 + g4] : 0.0;
                 chol_d4 x = chol_d4{0.0, 0.0, 0.0, 0.0};
-#ifndef C3_EXP_NO_RIDER_MFMA
-                x = __builtin_amdgcn_mfma_f64_16x16x4f64(i0, acc[cb][2 * h], x, 0, 0, 0);
-                x = __builtin_amdgcn_mfma_f64_16x16x4f64(i1, acc[cb][2 * h + 1], x, 0, 0, 0);
-#endif
+                // (row r of I L_kk^-T is column r of L_kk^-1: zero left of column r -- rows 16 w .. stay zero in the column blocks
+                // before w, which are the ones with the most blocks to their right: more than half of the identity's MFMAs)
+                const bool zero = !isR && cb < w;
+                if (!zero) {
+                    x = __builtin_amdgcn_mfma_f64_16x16x4f64(i0, acc[cb][2 * h], x, 0, 0, 0);
+                    x = __builtin_amdgcn_mfma_f64_16x16x4f64(i1, acc[cb][2 * h + 1], x, 0, 0, 0);
+                }
                 acc[cb][2 * h] = x[0]; acc[cb][2 * h + 1] = x[1];
                 panS[p * C3_BLK + (16 * w + e16) * C3_RS + g4] = x[0];
                 panS[p * C3_BLK + (16 * w + e16) * C3_RS + 4 + g4] = x[1];
@@ -432,16 +441,12 @@ __device__ __noinline__ void c3_chain_rider(int set, int w, double* A, int n, in
                 // ---- trailing update of the columns to the right (h == 0: the second half of this block, too)
 #pragma unroll
                 for (int cb2 = 0; cb2 < 4; ++cb2) {
-                    if (cb2 > cb || (cb2 == cb && h == 0)) {
+                    if ((cb2 > cb || (cb2 == cb && h == 0)) && !zero) {
                         double v0 = l.pan[p * C3_BLK + (16 * cb2 + e16) * C3_RS + g4];
                         double v1 = l.pan[p * C3_BLK + (16 * cb2 + e16) * C3_RS + 4 + g4];
                         if (cb2 == cb && e16 < 8) { v0 = 0.0; v1 = 0.0; }  // the solved columns stay
-#ifndef C3_EXP_NO_RIDER_MFMA
                         acc[cb2] = __builtin_amdgcn_mfma_f64_16x16x4f64(v0, xn0, acc[cb2], 0, 0, 0);
                         acc[cb2] = __builtin_amdgcn_mfma_f64_16x16x4f64(v1, xn1, acc[cb2], 0, 0, 0);
-#else
-                        acc[cb2][0] += v0 * xn0; acc[cb2][1] += v1 * xn1;
-#endif
                     }
                 }
             }
@@ -537,19 +542,65 @@ __device__ __noinline__ void c3_chain_dnext(double* A, int n, int T, int* fail, 
         if (has_r) {
             if (!c3_dnext_blocks<Q>(l, A, n, T, k, fail, flags, want1, lane)) return;
             C3_STAMP(ts, k * C3_TS + 4, lane == 0 && Q == 1);
-        } else if (mirror && !c3_wait_lds(l.lf + 7, k + 1, fail)) return;  // last step: the diagonal tile is complete
-        // L^T of this step's tiles for the back-substitution kernel (32 rows per wave): the rows are read from LDS first and counted,
-        // then stored -- the next step may reuse the micro-panel blocks meanwhile
-        if (mirror) {
-            c3_mirror_rows(A, n, 64 * k, 2 * Q, has_r ? 1 : 0, l.mir_cnt);
-            c3_mirror_rows(A, n, 64 * k, 2 * Q + 1, has_r ? 1 : 0, l.mir_cnt);
         }
     }
 }
 
-// the other four waves of the chain workgroup: 0 inverts the 8 x 8 diagonal blocks of the micro-panels for the riders, 1 carries the
-// right-hand side and publishes the step, 2 and 3 form the next diagonal tile (c3_dnext_blocks)
-__device__ __noinline__ void c3_chain_aux(int q, double* A, int n, int T, int* fail, int* flags, int want1, int want2, double* b, const double* Cc, long long* ts) {
+// The other four waves of the chain workgroup, each in a function of its own (compiled together their registers went to scratch):
+// the inverter (the 8 x 8 diagonal blocks of the micro-panels for the riders, then L^T of the step's tiles), the right-hand side's
+// wave, which also publishes the step, and the two that form the next diagonal tile (c3_chain_dnext).
+__device__ __noinline__ void c3_chain_inv(double* A, int n, int T, int* fail, int mirror, long long* ts) {
+    extern __shared__ __attribute__((aligned(16))) double c3_lds[];
+    const int lane = threadIdx.x & 63;
+    const C3Lds l = c3_carve(c3_lds);
+    for (int k = 0; k < T; ++k) {
+        const int step1 = k + 1;
+        const int r0 = 64 * k;
+        const bool has_r = k + 1 < T;
+        // ---- X = L_pp^-1, lane c (< 8) solves column c by forward substitution; the L entries come as LDS broadcasts
+        // (inv8[p] of the previous step has been read by every rider: D's micro-panel p of this step exists)
+        const int c = lane & 7;
+        for (int p = 0; p < 8; ++p) {
+            if (!c3_wait_lds(l.lf + p, step1, fail)) return;
+            const double* Lp = l.pan + p * C3_BLK + 8 * p * C3_RS;
+            double x[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                double s0 = (r == c) ? 1.0 : 0.0, s1 = 0.0;
+#pragma unroll
+                for (int m = 0; m < r; ++m) {
+                    if (m & 1) s1 = fma(-Lp[r * C3_RS + m], x[m], s1);
+                    else s0 = fma(-Lp[r * C3_RS + m], x[m], s0);
+                }
+                x[r] = (s0 + s1) * l.pinv[8 * p + r];
+            }
+            if (lane < 8) {
+#pragma unroll
+                for (int r = 0; r < 8; ++r) l.inv8[p * 64 + r * 8 + c] = x[r];
+            }
+            asm volatile("" ::: "memory");
+            if (lane == 0) c3_lds_set(l.inv_flag + p, step1);
+        }
+        // ---- L^T of this step's two tiles for the back-substitution kernel, from the micro-panels in LDS (plain stores, read by
+        // the next kernel): this wave is idle from the diagonal tile's last micro-panel to the next step's first, and its function
+        // has nothing in scratch -- a reload from scratch waits for every store in front of it.  (The two waves that form the next
+        // diagonal tile did it after that tile at first: the next step, which reuses the blocks, started 3.6 us after the tile was
+        // there; the diagonal tile's own waves: 5.6 us.)
+        if (mirror) {
+#pragma unroll 1
+            for (int w = 0; w < 4; ++w) c3_mirror_part(A, n, r0, w, 0, l.mir_cnt);
+            C3_STAMP(ts, k * C3_TS + 7, lane == 0);
+            if (has_r) {
+                if (!c3_wait_lds(l.lf + 8 + 7, 4 * step1, fail)) return;  // every row of R is in LDS
+#pragma unroll 1
+                for (int w = 0; w < 4; ++w) c3_mirror_part(A, n, r0, w, 1, l.mirR_cnt);
+            }
+        }
+    }
+}
+
+// the right-hand side's wave (also publishes the step)
+__device__ __noinline__ void c3_chain_aux(double* A, int n, int T, int* fail, int* flags, int want1, int want2, double* b, const double* Cc, long long* ts) {
     extern __shared__ __attribute__((aligned(16))) double c3_lds[];
     const int lane = threadIdx.x & 63;
     const C3Lds l = c3_carve(c3_lds);
@@ -558,89 +609,62 @@ __device__ __noinline__ void c3_chain_aux(int q, double* A, int n, int T, int* f
         const int step1 = k + 1;
         const int r0 = 64 * k;
         const bool has_r = k + 1 < T;
-        if (q == 0) {
-            // ---- X = L_pp^-1, lane c (< 8) solves column c by forward substitution; the L entries come as LDS broadcasts
-            // (inv8[p] of the previous step has been read by every rider: D's micro-panel p of this step exists)
-            const int c = lane & 7;
-            for (int p = 0; p < 8; ++p) {
-                if (!c3_wait_lds(l.lf + p, step1, fail)) return;
-                const double* Lp = l.pan + p * C3_BLK + 8 * p * C3_RS;
-                double x[8];
+        // ---- right-hand side: y_k = L_kk^-1 b'_k (lane = row: sum_c (L^-T)[c][r] b'[c]), then b'_{k+1}
+        if (!c3_wait_lds(l.lf + 16 + 7, 4 * step1, fail)) return;
+        const double* panI = l.pan + 16 * C3_BLK + (lane >> 3) * C3_BLK + (lane & 7);
+        const double* bk = l.bcur + 64 * (k & 1);
+        double y0 = 0.0, y1 = 0.0;
 #pragma unroll
-                for (int r = 0; r < 8; ++r) {
-                    double s0 = (r == c) ? 1.0 : 0.0, s1 = 0.0;
-#pragma unroll
-                    for (int m = 0; m < r; ++m) {
-                        if (m & 1) s1 = fma(-Lp[r * C3_RS + m], x[m], s1);
-                        else s0 = fma(-Lp[r * C3_RS + m], x[m], s0);
-                    }
-                    x[r] = (s0 + s1) * l.pinv[8 * p + r];
-                }
-                if (lane < 8) {
-#pragma unroll
-                    for (int r = 0; r < 8; ++r) l.inv8[p * 64 + r * 8 + c] = x[r];
-                }
-                asm volatile("" ::: "memory");
-                if (lane == 0) c3_lds_set(l.inv_flag + p, step1);
-            }
-        } else {
-            // ---- right-hand side: y_k = L_kk^-1 b'_k (lane = row: sum_c (L^-T)[c][r] b'[c]), then b'_{k+1}
-            if (!c3_wait_lds(l.lf + 16 + 7, 4 * step1, fail)) return;
-            const double* panI = l.pan + 16 * C3_BLK + (lane >> 3) * C3_BLK + (lane & 7);
-            const double* bk = l.bcur + 64 * (k & 1);
-            double y0 = 0.0, y1 = 0.0;
-#pragma unroll
-            for (int c = 0; c < 64; c += 2) {
-                y0 = fma(panI[c * C3_RS], bk[c], y0);
-                y1 = fma(panI[(c + 1) * C3_RS], bk[c + 1], y1);
-                if ((c & 14) == 14) C3_PIN2(y0, y1);  // sixteen entries' operands in flight
-            }
-            const double y = y0 + y1;
-            l.yv[lane] = y;
-            if (r0 + lane < n) c3_st(b + r0 + lane, y);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (lane == 0) c3_lds_inc(l.pub_cnt);
-            // ---- publish L_kk^-1 and y_k as soon as their five storing waves have drained: the panel solves of the tiles below
-            // start while R is still on its way
-            if (!c3_wait_lds(l.pub_cnt, 5 * step1, fail)) return;
-            if (lane == 0) c3_st_flag(flags + k * T + k, want2);
-            if (has_r) {
-                // ---- publish R = L(k+1, k) as soon as its four storing waves have drained
-                if (!c3_wait_lds(l.pubR_cnt, 4 * step1, fail)) return;
-                if (lane == 0) c3_st_flag(flags + (k + 1) * T + k, want2);
-                // ---- b'_{k+1} = b_{k+1} - sum_{m < k} L(k+1, m) y_m - R y_k, in this fixed order
-                // (R's input was read behind the S1 flag of tile (k+1, k): every L(k+1, m), m < k, and its share of b are published)
-                const int row = r0 + 64 + lane;
-                double bn = (row < n) ? c3_gld(b + row) : 0.0;
-                for (int m0 = 0; m0 < k; m0 += 8) {  // eight loads in flight
-                    double cv[8];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        const double cc_ = c3_ld(Cc + ((size_t)(k + 1) * T + (m0 + u < k ? m0 + u : k - 1)) * 64 + lane);
-                        cv[u] = (m0 + u < k) ? cc_ : 0.0;
-                    }
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) bn -= cv[u];
-                }
-                double s0 = 0.0, s1 = 0.0;
-#pragma unroll
-                for (int p = 0; p < 8; ++p) {
-                    const double2* row_ = reinterpret_cast<const double2*>(l.pan + 8 * C3_BLK + p * C3_BLK + lane * C3_RS);
-#pragma unroll
-                    for (int m = 0; m < 4; ++m) {
-                        const double2 t = row_[m];
-                        s0 = fma(t.x, l.yv[8 * p + 2 * m], s0);
-                        s1 = fma(t.y, l.yv[8 * p + 2 * m + 1], s1);
-                    }
-                    if (p & 1) C3_PIN2(s0, s1);
-                }
-                bn -= s0 + s1;
-                l.bcur[64 * ((k + 1) & 1) + lane] = bn;
-                asm volatile("" ::: "memory");
-                if (lane == 0) c3_lds_set(l.b_rdy, step1 + 1);  // also: this wave is done with the riders' rows of this step
-            }
-            C3_STAMP(ts, k * C3_TS + 5, lane == 0);
+        for (int c = 0; c < 64; c += 2) {
+            y0 = fma(panI[c * C3_RS], bk[c], y0);
+            y1 = fma(panI[(c + 1) * C3_RS], bk[c + 1], y1);
+            if ((c & 14) == 14) C3_PIN2(y0, y1);  // sixteen entries' operands in flight
         }
+        const double y = y0 + y1;
+        l.yv[lane] = y;
+        if (r0 + lane < n) c3_st(b + r0 + lane, y);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) c3_lds_inc(l.pub_cnt);
+        // ---- publish L_kk^-1 and y_k as soon as their five storing waves have drained: the panel solves of the tiles below
+        // start while R is still on its way
+        if (!c3_wait_lds(l.pub_cnt, 5 * step1, fail)) return;
+        if (lane == 0) c3_st_flag(flags + k * T + k, want2);
+        if (has_r) {
+            // ---- publish R = L(k+1, k) as soon as its four storing waves have drained
+            if (!c3_wait_lds(l.pubR_cnt, 4 * step1, fail)) return;
+            if (lane == 0) c3_st_flag(flags + (k + 1) * T + k, want2);
+            // ---- b'_{k+1} = b_{k+1} - sum_{m < k} L(k+1, m) y_m - R y_k, in this fixed order
+            // (R's input was read behind the S1 flag of tile (k+1, k): every L(k+1, m), m < k, and its share of b are published)
+            const int row = r0 + 64 + lane;
+            double bn = (row < n) ? c3_gld(b + row) : 0.0;
+            for (int m0 = 0; m0 < k; m0 += 8) {  // eight loads in flight
+                double cv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const double cc_ = c3_ld(Cc + ((size_t)(k + 1) * T + (m0 + u < k ? m0 + u : k - 1)) * 64 + lane);
+                    cv[u] = (m0 + u < k) ? cc_ : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) bn -= cv[u];
+            }
+            double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                const double2* row_ = reinterpret_cast<const double2*>(l.pan + 8 * C3_BLK + p * C3_BLK + lane * C3_RS);
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const double2 t = row_[m];
+                    s0 = fma(t.x, l.yv[8 * p + 2 * m], s0);
+                    s1 = fma(t.y, l.yv[8 * p + 2 * m + 1], s1);
+                }
+                if (p & 1) C3_PIN2(s0, s1);
+            }
+            bn -= s0 + s1;
+            l.bcur[64 * ((k + 1) & 1) + lane] = bn;
+            asm volatile("" ::: "memory");
+            if (lane == 0) c3_lds_set(l.b_rdy, step1 + 1);  // also: this wave is done with the riders' rows of this step
+        }
+        C3_STAMP(ts, k * C3_TS + 5, lane == 0);
     }
 }
 
@@ -662,7 +686,8 @@ __device__ __forceinline__ void c3_chain(const C3Args& g, int T) {
     else if (oth < 8) c3_chain_rider(1 + (oth >> 2), oth & 3, g.A, g.n, T, g.fail, g.flags, want1, g.Linv, g.dinv, g.mirror, g.ts);
     else if (oth == 10) c3_chain_dnext<0>(g.A, g.n, T, g.fail, g.flags, want1, g.mirror, g.ts);
     else if (oth == 11) c3_chain_dnext<1>(g.A, g.n, T, g.fail, g.flags, want1, g.mirror, g.ts);
-    else c3_chain_aux(oth - 8, g.A, g.n, T, g.fail, g.flags, want1, want2, g.b, g.Cc, g.ts);
+    else if (oth == 8) c3_chain_inv(g.A, g.n, T, g.fail, g.mirror, g.ts);
+    else c3_chain_aux(g.A, g.n, T, g.fail, g.flags, want1, want2, g.b, g.Cc, g.ts);
 }
 
 // ---------------------------------------------------------------------------------------------------------------- owners
