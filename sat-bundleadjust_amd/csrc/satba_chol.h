@@ -556,7 +556,7 @@ inline void cholesky_tiles(double* A, int n, double* b, int* fail, hipStream_t s
     C3Args g;
     g.A = A; g.n = n; g.b = b; g.fail = fail; g.flags = w.flags; g.epoch = ++w.epoch; g.Linv = w.Linv; g.Cc = w.Cc; g.ctr = w.ctr;
     g.dinv = dinv; g.ts = ts; g.mirror = mirror ? 1 : 0;
-    hipLaunchKernelGGL(k_chol_tiles, dim3(chol_tiles_grid(n)), dim3(1024), c3_lds_bytes(), stream, g, gate);
+    hipLaunchKernelGGL(k_chol_tiles, dim3(chol_tiles_grid(n, g.mirror)), dim3(1024), c3_lds_bytes(), stream, g, gate);
 }
 
 // Factorise A (n x n, column-major lower, in place) and solve A z = b in place.  *fail != 0 if A was not SPD (or a wait inside the

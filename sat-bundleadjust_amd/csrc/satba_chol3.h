@@ -226,10 +226,9 @@ struct C3Lds {
     int* lf;                // [0..7] micro-panel p of D published (value: step + 1); [8..15], [16..23]: waves of R / the identity
                             // that have published micro-panel p (4 per step)
     int* tb_cnt;            // += 1 per wave of the next diagonal tile (two) and step: its blocks are in Tb
-    int* pub_cnt;           // += 1 per storing wave of L_kk^-1, y_k and step (4 + 1)
+    int* pub_cnt;           // += 1 per storing wave of L_kk, L_kk^-1, y_k and step (4 + 4 + 1)
     int* pubR_cnt;          // += 1 per storing wave of R and step (4)
-    int* mir_cnt;           // += 4 per step: the diagonal tile's micro-panels have been read for L^T (16 rows at a time)
-    int* mirR_cnt;          // ... and R's
+    int* y_done;            // = step + 1 when y of the step is formed (the identity's rows have been read by its wave)
     int* prod_cnt;          // += 1 per wave of R and step: its share of the next input is formed (R's rows in LDS may go)
     int* b_rdy;             // = step + 1 when bcur[step & 1] is ready
     int* inv_flag;          // [8]: inv8[p] is ready (value: step + 1)
@@ -243,7 +242,7 @@ __device__ __forceinline__ C3Lds c3_carve(double* lds) {
     l.bcur = l.yv + 64;
     l.inv8 = l.bcur + 128;
     int* li = reinterpret_cast<int*>(l.inv8 + 512);
-    l.lf = li; l.tb_cnt = li + 24; l.pub_cnt = li + 25; l.b_rdy = li + 26; l.pubR_cnt = li + 27; l.prod_cnt = li + 28; l.mir_cnt = li + 29; l.mirR_cnt = li + 30; l.inv_flag = li + 32;
+    l.lf = li; l.tb_cnt = li + 24; l.pub_cnt = li + 25; l.b_rdy = li + 26; l.pubR_cnt = li + 27; l.prod_cnt = li + 28; l.y_done = li + 29; l.inv_flag = li + 32;
     return l;
 }
 
@@ -253,29 +252,6 @@ __device__ __forceinline__ C3Lds c3_carve(double* lds) {
 // counted: the next step may reuse the blocks while the stores go out.  (History: as 8-byte stores scattered over 64 lines by the
 // waves that hold the tiles, in front of their drains: +25 us per factorisation; in the riders' function, an LDS address reloaded from
 // scratch per row, whose s_waitcnt vmcnt(0) waited for the previous store: 11 us per step.)
-__device__ __forceinline__ void c3_mirror_part(double* A, int n, int r0, int w, int set, int* done_cnt) {
-    extern __shared__ __attribute__((aligned(16))) double c3_lds[];
-    const int lane = threadIdx.x & 63;
-    const double* src = c3_lds + set * 8 * C3_BLK + (lane >> 3) * C3_BLK + (lane & 7);  // column `lane` of a row: micro-panel lane / 8, entry lane % 8
-    double v[16];
-#pragma unroll
-    for (int rr = 0; rr < 16; ++rr) v[rr] = src[(16 * w + rr) * C3_RS];
-    C3_PIN4(v[15], v[14], v[13], v[12]);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if (lane == 0) c3_lds_inc(done_cnt);  // the rows are in registers: the micro-panel blocks may be reused while the stores go out
-    // (the address arithmetic must stay here: hoisted out of the step loop it put the wave's registers into scratch, and a reload
-    // from scratch waits for every store in front of it)
-    asm volatile("" : "+v"(n), "+v"(A), "+v"(r0));
-    const int c0 = r0 + 64 * set + 16 * w;  // first of my 16 columns of the upper triangle
-    double* dst = A + (size_t)(r0 + lane) + (size_t)c0 * n;
-#pragma unroll
-    for (int rr = 0; rr < 16; ++rr) {
-        const bool ok = (set == 0) ? (c0 + rr < n && lane < 16 * w + rr) : (c0 + rr < n);
-        if (ok) c3_gst(dst, v[rr]);
-        dst += n;
-    }
-}
-
 // Next diagonal tile, A'(k+1,k+1) - R R^T: its ten lower 16 x 16 blocks by two of the helper waves, five blocks each, as rank-8
 // updates (two MFMAs per block) when a micro-panel of R appears in LDS -- ten MFMAs per micro-panel and wave, well inside the 1.6 us
 // a micro-panel takes, so that after R's last micro-panel only ten more are left.  The accumulators start from the base -- the tile
@@ -342,19 +318,21 @@ __device__ __noinline__ void c3_chain_diag(int q, double* A, int n, int T, int* 
         const bool has_r = k + 1 < T;
         // the identity's riders still read the micro-panels of the previous step (R's are done: the hand-over buffer is complete)
         if (k > 0 && !c3_wait_lds(l.lf + 16 + 7, 4 * k, fail)) return;
-        if (mirror && k > 0 && !c3_wait_lds(l.mir_cnt, 4 * k, fail)) return;  // ... and the inverter's wave has read them for L^T
         C3_STAMP(ts, k * C3_TS + 0, tid == 0);
         const bool bad = c3_panel(a, q, lane, l.pan, l.pinv, l.lf, step1, fail, ts ? ts + k * C3_TS + 8 : nullptr);
         if (bad && lane == 0) atomicOr(fail, 1);
         C3_STAMP(ts, k * C3_TS + 1, lane == 0 && q == 3);
-        // ---- my 16 columns of L_kk: plain stores -- nothing in this launch reads L_kk (the tiles below are multiplied by L_kk^-1),
-        // so no write-through, no drain, no flag; L^T for the back-substitution is written by the identity's waves from LDS
+        // ---- my 16 columns of L_kk, write-through and counted for the step's publication: the only reader in this launch is the
+        // workgroup that writes L^T of the step's tiles for the back-substitution kernel (c3_mirror_task); the drain falls into the
+        // wait for the next diagonal tile
         asm volatile("" : "+v"(n), "+v"(A));  // (keeps the address arithmetic of the stores out of the registers of the factorisation)
 #pragma unroll
         for (int c = 0; c < 16; ++c) {
             const int row = r0 + lane, col = r0 + 16 * q + c;
-            if (row < n && col <= row) c3_gst(A + (size_t)row + (size_t)col * n, a[c]);
+            if (row < n && col <= row) c3_st(A + (size_t)row + (size_t)col * n, a[c]);
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) c3_lds_inc(l.pub_cnt);
         // ---- the next diagonal tile, formed by two of the helper waves (c3_dnext_blocks), from LDS, one row per lane
         if (has_r) {
             if (!c3_wait_lds(l.tb_cnt, 2 * step1, fail)) return;
@@ -413,9 +391,8 @@ __device__ __noinline__ void c3_chain_rider(int set, int w, double* A, int n, in
         }
         if (!isR || has_r) {
             // the right-hand side's wave is done with this set's rows of the previous step, and so are the products of R's four waves
-            if (k > 0 && !c3_wait_lds(l.b_rdy, step1, fail)) return;
+            if (k > 0 && !c3_wait_lds(isR ? l.b_rdy : l.y_done, isR ? step1 : k, fail)) return;
             if (isR && k > 0 && !c3_wait_lds(l.prod_cnt, 4 * k, fail)) return;
-            if (isR && mirror && k > 0 && !c3_wait_lds(l.mirR_cnt, 4 * k, fail)) return;
 #pragma unroll
             for (int p = 0; p < 8; ++p) {
                 const int cb = p >> 1, h = p & 1;
@@ -547,9 +524,9 @@ __device__ __noinline__ void c3_chain_dnext(double* A, int n, int T, int* fail, 
 }
 
 // The other four waves of the chain workgroup, each in a function of its own (compiled together their registers went to scratch):
-// the inverter (the 8 x 8 diagonal blocks of the micro-panels for the riders, then L^T of the step's tiles), the right-hand side's
-// wave, which also publishes the step, and the two that form the next diagonal tile (c3_chain_dnext).
-__device__ __noinline__ void c3_chain_inv(double* A, int n, int T, int* fail, int mirror, long long* ts) {
+// the inverter (the 8 x 8 diagonal blocks of the micro-panels for the riders), the right-hand side's wave, which also publishes
+// the step, and the two that form the next diagonal tile (c3_chain_dnext).
+__device__ __noinline__ void c3_chain_inv(int T, int* fail) {
     extern __shared__ __attribute__((aligned(16))) double c3_lds[];
     const int lane = threadIdx.x & 63;
     const C3Lds l = c3_carve(c3_lds);
@@ -581,21 +558,6 @@ __device__ __noinline__ void c3_chain_inv(double* A, int n, int T, int* fail, in
             asm volatile("" ::: "memory");
             if (lane == 0) c3_lds_set(l.inv_flag + p, step1);
         }
-        // ---- L^T of this step's two tiles for the back-substitution kernel, from the micro-panels in LDS (plain stores, read by
-        // the next kernel): this wave is idle from the diagonal tile's last micro-panel to the next step's first, and its function
-        // has nothing in scratch -- a reload from scratch waits for every store in front of it.  (The two waves that form the next
-        // diagonal tile did it after that tile at first: the next step, which reuses the blocks, started 3.6 us after the tile was
-        // there; the diagonal tile's own waves: 5.6 us.)
-        if (mirror) {
-#pragma unroll 1
-            for (int w = 0; w < 4; ++w) c3_mirror_part(A, n, r0, w, 0, l.mir_cnt);
-            C3_STAMP(ts, k * C3_TS + 7, lane == 0);
-            if (has_r) {
-                if (!c3_wait_lds(l.lf + 8 + 7, 4 * step1, fail)) return;  // every row of R is in LDS
-#pragma unroll 1
-                for (int w = 0; w < 4; ++w) c3_mirror_part(A, n, r0, w, 1, l.mirR_cnt);
-            }
-        }
     }
 }
 
@@ -609,6 +571,26 @@ __device__ __noinline__ void c3_chain_aux(double* A, int n, int T, int* fail, in
         const int step1 = k + 1;
         const int r0 = 64 * k;
         const bool has_r = k + 1 < T;
+        // ---- b_{k+1} - sum_{m < k} L(k+1, m) y_m first, in this fixed order: everything in it is at least a step old (the last
+        // term comes with tile (k+1, k-1), whose owner had L_(k-1)(k-1)^-1 a step ago; R's waves of the last step waited for that
+        // tile, but not necessarily before this point), and fetched behind R it cost 4 - 5 us of latency at the end of the step,
+        // which the riders of the next step waited for
+        double bn = 0.0;
+        if (has_r) {
+            if (k >= 1 && !c3_wait(flags + (k + 1) * T + (k - 1), want2, fail)) return;
+            const int row = r0 + 64 + lane;
+            bn = (row < n) ? c3_gld(b + row) : 0.0;
+            for (int m0 = 0; m0 < k; m0 += 8) {  // eight loads in flight
+                double cv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const double cc_ = c3_ld(Cc + ((size_t)(k + 1) * T + (m0 + u < k ? m0 + u : k - 1)) * 64 + lane);
+                    cv[u] = (m0 + u < k) ? cc_ : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) bn -= cv[u];
+            }
+        }
         // ---- right-hand side: y_k = L_kk^-1 b'_k (lane = row: sum_c (L^-T)[c][r] b'[c]), then b'_{k+1}
         if (!c3_wait_lds(l.lf + 16 + 7, 4 * step1, fail)) return;
         const double* panI = l.pan + 16 * C3_BLK + (lane >> 3) * C3_BLK + (lane & 7);
@@ -622,31 +604,20 @@ __device__ __noinline__ void c3_chain_aux(double* A, int n, int T, int* fail, in
         }
         const double y = y0 + y1;
         l.yv[lane] = y;
+        asm volatile("" ::: "memory");
+        if (lane == 0) c3_lds_set(l.y_done, step1);  // the identity's rows of this step have been read
         if (r0 + lane < n) c3_st(b + r0 + lane, y);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (lane == 0) c3_lds_inc(l.pub_cnt);
-        // ---- publish L_kk^-1 and y_k as soon as their five storing waves have drained: the panel solves of the tiles below
-        // start while R is still on its way
-        if (!c3_wait_lds(l.pub_cnt, 5 * step1, fail)) return;
+        // ---- publish L_kk, L_kk^-1 and y_k as soon as their nine storing waves have drained: the panel solves of the tiles
+        // below start while R is still on its way
+        if (!c3_wait_lds(l.pub_cnt, 9 * step1, fail)) return;
         if (lane == 0) c3_st_flag(flags + k * T + k, want2);
         if (has_r) {
             // ---- publish R = L(k+1, k) as soon as its four storing waves have drained
             if (!c3_wait_lds(l.pubR_cnt, 4 * step1, fail)) return;
             if (lane == 0) c3_st_flag(flags + (k + 1) * T + k, want2);
-            // ---- b'_{k+1} = b_{k+1} - sum_{m < k} L(k+1, m) y_m - R y_k, in this fixed order
-            // (R's input was read behind the S1 flag of tile (k+1, k): every L(k+1, m), m < k, and its share of b are published)
-            const int row = r0 + 64 + lane;
-            double bn = (row < n) ? c3_gld(b + row) : 0.0;
-            for (int m0 = 0; m0 < k; m0 += 8) {  // eight loads in flight
-                double cv[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const double cc_ = c3_ld(Cc + ((size_t)(k + 1) * T + (m0 + u < k ? m0 + u : k - 1)) * 64 + lane);
-                    cv[u] = (m0 + u < k) ? cc_ : 0.0;
-                }
-#pragma unroll
-                for (int u = 0; u < 8; ++u) bn -= cv[u];
-            }
+            // ---- b'_{k+1} = (b_{k+1} - sum_{m < k} L(k+1, m) y_m) - R y_k
             double s0 = 0.0, s1 = 0.0;
 #pragma unroll
             for (int p = 0; p < 8; ++p) {
@@ -686,7 +657,7 @@ __device__ __forceinline__ void c3_chain(const C3Args& g, int T) {
     else if (oth < 8) c3_chain_rider(1 + (oth >> 2), oth & 3, g.A, g.n, T, g.fail, g.flags, want1, g.Linv, g.dinv, g.mirror, g.ts);
     else if (oth == 10) c3_chain_dnext<0>(g.A, g.n, T, g.fail, g.flags, want1, g.mirror, g.ts);
     else if (oth == 11) c3_chain_dnext<1>(g.A, g.n, T, g.fail, g.flags, want1, g.mirror, g.ts);
-    else if (oth == 8) c3_chain_inv(g.A, g.n, T, g.fail, g.mirror, g.ts);
+    else if (oth == 8) c3_chain_inv(T, g.fail);
     else c3_chain_aux(g.A, g.n, T, g.fail, g.flags, want1, want2, g.b, g.Cc, g.ts);
 }
 
@@ -698,16 +669,19 @@ __device__ __forceinline__ void c3_chain(const C3Args& g, int T) {
 // (Round 4 on the way here: (j+1, j) with all panels applied by its owner -- 13 us from the chain's publication to its next
 // input, through four hand-overs; one workgroup for (j+2, j) and (j+2, j+1) -- 10 us.)
 // kind: 0 diagonal, 1 below the diagonal, 2 ordinary
-__host__ __device__ inline int c3_task_count(int T) {
+// kind 3 (mirror != 0): L^T of the chain's tiles of step j -- (j, j) and (j+1, j) -- into the strict upper triangle, behind column j's
+// other tasks (it waits for the step's publication only: every ticket it depends on is lower)
+__host__ __device__ inline int c3_task_count(int T, int mirror) {
     int cnt = 1;
     for (int j = 0; j < T; ++j) {
         if (j >= 2) ++cnt;
         if (j >= 2 && j + 1 <= T - 1) ++cnt;
         if (T - 1 >= j + 2) cnt += T - 1 - (j + 2) + 1;
+        if (mirror) ++cnt;
     }
     return cnt;
 }
-__device__ inline void c3_task(int T, int idx, int& i, int& j, int& kind) {  // idx >= 1
+__device__ inline void c3_task(int T, int mirror, int idx, int& i, int& j, int& kind) {  // idx >= 1
     --idx;
     for (j = 0; j < T; ++j) {
         if (j >= 2) { if (idx == 0) { i = j; kind = 0; return; } --idx; }
@@ -715,8 +689,43 @@ __device__ inline void c3_task(int T, int idx, int& i, int& j, int& kind) {  // 
         const int cnt = T - 1 >= j + 2 ? T - 1 - (j + 2) + 1 : 0;
         if (idx < cnt) { i = j + 2 + idx; kind = 2; return; }
         idx -= cnt;
+        if (mirror) { if (idx == 0) { i = j; kind = 3; return; } --idx; }
     }
     i = j = 0; kind = -1;
+}
+
+// L^T of the chain's two tiles of step k for the back-substitution kernel: through LDS ([column][row], stride 65), so that a wave
+// stores 64 consecutive addresses.  (Inside the chain's workgroup -- by the waves that form the next diagonal tile, by the diagonal
+// tile's own, by the inverter's -- it sat in front of the next step, which reuses the micro-panel blocks it was read from: 2 - 5 us
+// per step; a wave there gets an issue slot every ~13 cycles beside the MFMAs.)
+__device__ __noinline__ void c3_mirror_task(C3Args g, int T, int k) {
+    extern __shared__ __attribute__((aligned(16))) double c3_lds[];
+    double* Xt = c3_lds;
+    int* s_ok = reinterpret_cast<int*>(c3_lds + 3 * 8 * C3_BLK + 64 * C3_TBS + 64 + 64 + 128 + 512) + 61;
+    const int tid = threadIdx.x, n = g.n, r0 = 64 * k;
+    const int want2 = 4 * g.epoch + C3_S2;
+    double* A = g.A;
+    const int n_tiles = (k + 1 < T) ? 2 : 1;
+    for (int t2 = 0; t2 < n_tiles; ++t2) {
+        if (tid == 0) c3_lds_set(s_ok, c3_wait(g.flags + (k + t2) * T + k, want2, g.fail) ? 1 : 0);
+        __syncthreads();  // also: the stores of the first tile have read Xt
+        if (!c3_lds_get(s_ok)) return;
+        const int rt = r0 + 64 * t2;  // first row of the tile
+        double v[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int idx = tid + 1024 * t, r = idx & 63, c = idx >> 6;
+            v[t] = c3_ld_at(A, n, rt + r, r0 + c, rt + r < n && r0 + c < n && (t2 == 1 || c < r));
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { const int idx = tid + 1024 * t, r = idx & 63, c = idx >> 6; Xt[c * 65 + r] = v[t]; }
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int idx = tid + 1024 * t, c = idx & 63, r = idx >> 6;
+            if (rt + r < n && r0 + c < n && (t2 == 1 || c < r)) c3_gst(A + (size_t)(r0 + c) + (size_t)(rt + r) * n, Xt[c * 65 + r]);
+        }
+    }
 }
 
 __device__ __noinline__ void c3_owner(C3Args g, int T, int i, int j, int kind) {
@@ -849,7 +858,7 @@ __global__ __launch_bounds__(1024) void k_chol_tiles(C3Args g, const int* gate) 
     extern __shared__ __attribute__((aligned(16))) double c3_lds[];
     int* s_task = reinterpret_cast<int*>(c3_lds + 3 * 8 * C3_BLK + 64 * C3_TBS + 64 + 64 + 128 + 512) + 60;  // (all LDS in the dynamic region: 16-byte aligned base)
     const int T = (g.n + 63) / 64;
-    const int n_tasks = c3_task_count(T);
+    const int n_tasks = c3_task_count(T, g.mirror);
     for (;;) {
         __syncthreads();
         if (threadIdx.x == 0) c3_lds_set(s_task, atomicAdd(g.ctr, 1));
@@ -860,8 +869,9 @@ __global__ __launch_bounds__(1024) void k_chol_tiles(C3Args g, const int* gate) 
             c3_chain(g, T);
         } else {
             int i, j, kind;
-            c3_task(T, task, i, j, kind);
-            c3_owner(g, T, i, j, kind);
+            c3_task(T, g.mirror, task, i, j, kind);
+            if (kind == 3) c3_mirror_task(g, T, j);
+            else c3_owner(g, T, i, j, kind);
         }
     }
     __syncthreads();
@@ -871,8 +881,8 @@ __global__ __launch_bounds__(1024) void k_chol_tiles(C3Args g, const int* gate) 
     }
 }
 
-inline int chol_tiles_grid(int n) {
-    const int n_tasks = c3_task_count((n + 63) / 64);
+inline int chol_tiles_grid(int n, int mirror) {
+    const int n_tasks = c3_task_count((n + 63) / 64, mirror);
     return n_tasks < 256 ? n_tasks : 256;
 }
 

@@ -102,7 +102,7 @@ int main(int argc, char** argv) {
             C3Args g;
             g.A = dA; g.n = n; g.b = db; g.fail = dfail; g.flags = w.flags; g.epoch = ++w.epoch; g.Linv = w.Linv; g.Cc = w.Cc; g.ctr = w.ctr;
             g.dinv = dinv; g.ts = nullptr; g.mirror = getenv("SATBA_NO_MIRROR") ? 0 : 1;
-            hipLaunchKernelGGL(k_chol_tiles, dim3(chol_tiles_grid(n)), dim3(1024), c3_lds_bytes(), st, g, (const int*)nullptr);
+            hipLaunchKernelGGL(k_chol_tiles, dim3(chol_tiles_grid(n, g.mirror)), dim3(1024), c3_lds_bytes(), st, g, (const int*)nullptr);
             CK(hipStreamSynchronize(st));
             std::vector<double> Lg((size_t)n * n), yg(n), dg((size_t)((n + 31) / 32) * 1024);
             CK(hipMemcpy(Lg.data(), dA, sizeof(double) * n * n, hipMemcpyDeviceToHost));
