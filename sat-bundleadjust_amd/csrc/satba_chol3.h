@@ -532,8 +532,6 @@ __device__ __noinline__ void c3_chain_inv(int T, int* fail) {
     const C3Lds l = c3_carve(c3_lds);
     for (int k = 0; k < T; ++k) {
         const int step1 = k + 1;
-        const int r0 = 64 * k;
-        const bool has_r = k + 1 < T;
         // ---- X = L_pp^-1, lane c (< 8) solves column c by forward substitution; the L entries come as LDS broadcasts
         // (inv8[p] of the previous step has been read by every rider: D's micro-panel p of this step exists)
         const int c = lane & 7;
