@@ -376,7 +376,7 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     # the roofline kernel inside LM iterations: a second pass over the same iterations with HIP events around every k_linearize
-    # launch, on its launch stream (the timed pass replays a captured graph per iteration: no events inside it)
+    # launch, on its launch stream (the timed pass itself carries no events)
     if restart:
         eng.snapshot_x(True)
         st["first"] = True

@@ -107,8 +107,7 @@ void satba_problem_destroy(satba_problem *p);
 
 /* A handle launches everything on a stream of its own (created non-blocking with the handle).  satba_set_stream moves it to
  * `hip_stream` (a hipStream_t; NULL = the legacy default stream) -- e.g. the stream torch.distributed queues its collectives on --
- * or, with use_own != 0, back to its own.  The device-resident loop replays a captured hipGraph per iteration where the stream
- * can be captured (not the legacy default stream: direct launches there). */
+ * or, with use_own != 0, back to its own. */
 int satba_set_stream(satba_problem *p, void *hip_stream, int32_t use_own);
 
 /* Length in doubles of the exchange buffer: header + max(M n_p^2 + M n_p, (M n_p)^2 + M n_p). */
