@@ -162,7 +162,9 @@ __device__ __forceinline__ bool c3_panel(double (&a)[16], int q, int lane, doubl
             }
         }
     }
-    // ---- my own two micro-panels
+    // ---- my own two micro-panels: the pivot chain.  The other three waves of the tile share this SIMD and are busy with the updates
+    // of their own columns; with a higher priority the chain's dependent operations are issued as soon as they are ready
+    __builtin_amdgcn_s_setprio(3);
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         const int p = 2 * q + h;
@@ -212,6 +214,7 @@ __device__ __forceinline__ bool c3_panel(double (&a)[16], int q, int lane, doubl
             }
         }
     }
+    __builtin_amdgcn_s_setprio(0);
     return bad;
 }
 
