@@ -80,18 +80,40 @@ class SingleComm:
 class TorchComm:
     """Sum all-reduce over torch.distributed (backend nccl == RCCL on ROCm, gloo in the CPU tests)."""
 
-    def __init__(self, group=None, always=False):
+    def __init__(self, group=None, always=False, ordered=False):
         import torch.distributed as dist
 
         self.dist, self.group = dist, group
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
         self.always = always  # issue the collectives even for a single rank (plumbing tests)
         self.pack = not os.environ.get("SATBA_NO_PACK")  # packed lower triangle for the Schur all-reduce
+        # SATBA_ORDERED_REDUCE=1: sums in RANK ORDER, ((r0 + r1) + r2) + ..., formed by every rank from an all-gather -- the same
+        # bits whatever algorithm, topology or channel count the collective library picks (SURVEY 8e: a rank-ordered reduction
+        # option).  world x the bytes of the all-reduce it replaces: 32 MB per rank for the packed Schur payload at 8 ranks.
+        self.ordered = ordered or bool(os.environ.get("SATBA_ORDERED_REDUCE"))
+        self._gather = {}
+
+    def _sum(self, t):
+        """In-place sum of tensor t over the ranks (stream ordered like the collective itself)."""
+        if not self.ordered:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+            return
+        import torch
+
+        key = (t.numel(), t.device, t.dtype)
+        buf = self._gather.get(key)
+        if buf is None:
+            buf = self._gather[key] = torch.empty((self.world, t.numel()), dtype=t.dtype, device=t.device)
+        self.dist.all_gather(list(buf.unbind(0)), t.reshape(-1), group=self.group)
+        flat = t.reshape(-1)
+        flat.copy_(buf[0])
+        for r in range(1, self.world):
+            flat.add_(buf[r])
 
     def allreduce(self, engine, n):
         """Sum the first n doubles of the engine's exchange buffer over all ranks, in place."""
         if self.world > 1 or self.always:
-            self.dist.all_reduce(engine.xb[:n], op=self.dist.ReduceOp.SUM, group=self.group)
+            self._sum(engine.xb[:n])
 
     def allreduce_schur(self, engine):
         """
@@ -103,7 +125,7 @@ class TorchComm:
             return
         if getattr(engine, "pack_schur", None) is not None and getattr(engine, "xb", None) is not None and self.pack:
             xp = engine.pack_schur()
-            self.dist.all_reduce(xp, op=self.dist.ReduceOp.SUM, group=self.group)
+            self._sum(xp)
             engine.unpack_schur()
         else:
             self.allreduce(engine, engine.len_schur)
@@ -116,7 +138,7 @@ class TorchComm:
             return a
         dev = "cuda" if self.dist.get_backend(self.group) == "nccl" else "cpu"
         t = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(dev)
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+        self._sum(t)
         return t.cpu().numpy()
 
     def gather_array(self, a):

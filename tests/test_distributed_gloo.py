@@ -85,3 +85,52 @@ def test_two_rank_solve_equals_single_rank_and_reference(tmp_path, name, loss):
     xt = g["tight_x_" + loss]
     assert np.abs(x2[:n_c] - xt[:n_c]).max() < 1e-6 * np.abs(xt[:n_c]).max()  # and the reference's tight scipy run
     assert np.linalg.norm(outs[0]["r"] - g["tight_fun_" + loss]) < 5e-6 * np.linalg.norm(g["tight_fun_" + loss])
+
+
+def _ordered_worker(rank, world, port, out_dir):
+    import sys
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    root = os.path.dirname(here)
+    sys.path[:0] = [os.path.join(root, "sat-bundleadjust_amd"), root, here]
+    import torch
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from satba import trf
+
+    class Eng:  # the exchange buffer is all the communicator touches
+        pass
+
+    n = 4099
+    out = {}
+    for ordered in (False, True):
+        e = Eng()
+        # magnitudes spread over 30 decades: the sum depends on the order of the additions in the last bits
+        rng = np.random.default_rng(100 + rank)
+        e.xb = torch.from_numpy(rng.standard_normal(n) * 10.0 ** rng.uniform(-15, 15, n))
+        trf.TorchComm(ordered=ordered).allreduce(e, n - 3)  # a prefix, like the phases' headers
+        out["ordered" if ordered else "plain"] = e.xb.numpy().copy()
+    np.savez(os.path.join(out_dir, "rank{}.npz".format(rank)), **out)
+    dist.destroy_process_group()
+
+
+def test_rank_ordered_reduction_is_the_sum_in_rank_order(tmp_path):
+    """SATBA_ORDERED_REDUCE / TorchComm(ordered=True): every rank forms ((r0 + r1) + r2) itself -- the bits do not depend on the
+    collective's algorithm; three ranks, because with two every order gives the same sum."""
+    import torch.multiprocessing as mp
+
+    world, port, n = 3, _free_port(), 4099
+    mp.spawn(_ordered_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    outs = [np.load(os.path.join(str(tmp_path), "rank{}.npz".format(r))) for r in range(world)]
+    parts = []
+    for r in range(world):
+        rng = np.random.default_rng(100 + r)
+        parts.append(rng.standard_normal(n) * 10.0 ** rng.uniform(-15, 15, n))
+    want = (parts[0] + parts[1]) + parts[2]
+    for r in range(world):
+        got = outs[r]["ordered"]
+        assert np.array_equal(got[: n - 3], want[: n - 3])      # bit for bit, on every rank
+        assert np.array_equal(got[n - 3:], parts[r][n - 3:])     # beyond the prefix: untouched
+        assert np.allclose(outs[r]["plain"][: n - 3], want[: n - 3], rtol=1e-12, atol=0)

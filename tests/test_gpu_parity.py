@@ -746,7 +746,7 @@ def _two_rank_worker(rank, world, port, name, loss, out_dir, backend="gloo", env
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("loop", ["device", "host"])
+@pytest.mark.parametrize("loop", ["device", "host", "device-ordered"])
 @pytest.mark.parametrize("name,loss", [("affine_small_RT", "linear"), ("affine_small_R", "soft_l1")])
 def test_two_ranks_on_one_gpu(gpu, tmp_path, name, loss, loop):
     """
@@ -754,7 +754,8 @@ def test_two_ranks_on_one_gpu(gpu, tmp_path, name, loss, loop):
     the exchange buffers (device tensors) are all-reduced over gloo.  RCCL itself is covered by the single-rank
     plumbing test; here the sharded device arithmetic, the rank-0-only terms and the queued front are under test.
     loop: "device" -- the decisions of the loop on the device, the host only queues tick parts and all-reduces
-    (trf.drive_device_loop: what several ranks run); "host" -- the Python loop with two header reads per iteration (SATBA_HOST_LOOP).
+    (trf.drive_device_loop: what several ranks run); "host" -- the Python loop with two header reads per iteration (SATBA_HOST_LOOP);
+    "device-ordered" -- the device loop with the rank-ordered sums (SATBA_ORDERED_REDUCE: all-gather + additions on the stream).
     """
     import torch.multiprocessing as mp
 
@@ -762,12 +763,12 @@ def test_two_ranks_on_one_gpu(gpu, tmp_path, name, loss, loop):
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    env = {"SATBA_HOST_LOOP": "1"} if loop == "host" else {}
+    env = {"SATBA_HOST_LOOP": "1"} if loop == "host" else ({"SATBA_ORDERED_REDUCE": "1"} if loop == "device-ordered" else {})
     mp.spawn(_two_rank_worker, args=(2, port, name, loss, str(tmp_path), "gloo", env), nprocs=2, join=True)
     outs = [np.load(os.path.join(str(tmp_path), "rank{}.npz".format(r))) for r in range(2)]
     assert np.array_equal(outs[0]["x"], outs[1]["x"]) and int(outs[0]["nfev"]) == int(outs[1]["nfev"])
     # the device loop ran (one launch pattern per evaluation at least) / did not run
-    assert (int(outs[0]["ticks"]) >= int(outs[0]["nfev"]) - 1) if loop == "device" else int(outs[0]["ticks"]) == 0
+    assert (int(outs[0]["ticks"]) >= int(outs[0]["nfev"]) - 1) if loop != "host" else int(outs[0]["ticks"]) == 0
     _, make_p, g, _ = cases.solve_case(name)
     p = make_p()
     n_c = p.n_cam * p.n_params
