@@ -264,6 +264,13 @@ int satba_triangulate_pairwise(int32_t cam_model, const double *cam_i, const dou
 int satba_init_pts3d(int32_t cam_model, int32_t n_cam, int64_t n_pts, const int64_t *pt_ofs, const int32_t *cam_ind,
                      const double *obs, const double *cameras, int32_t n_pairs, const int32_t *pairs, float *pts3d,
                      int32_t *n_tri, int32_t device, int32_t reps, float *kernel_ms);
+/* The same on a problem handle's RESIDENT observations -- what ba_outliers.py:89-93 does right after the outlier rejection: the
+ * tracks are not uploaded again.  remove (host, n_obs bytes in the caller's observation order, e.g. satba_outliers' mask; may be
+ * NULL): observations to treat as absent.  cameras: host, n_cam x (12 | SATBA_RPC_TABLE_LEN) -- the caller's choice (the
+ * reference passes p.cameras).  pts3d (host, n_pts x 3 float32) and n_tri (host, n_pts, may be NULL) in the caller's point order;
+ * a track with n_tri = 0 is one ft_utils.filter_C_using_pairs_to_triangulate would drop.  Single-rank handles only. */
+int satba_init_pts3d_resident(satba_problem *p, const uint8_t *remove, const double *cameras, int32_t n_pairs,
+                              const int32_t *pairs, float *pts3d, int32_t *n_tri, float *kernel_ms);
 
 /* ---- RPC re-fit after the solve, the step behind the path.  Stand-alone: no problem handle.
  * satba_rpc_fit replaces ba_rpcfit.weighted_lsq (ba_rpcfit.py:88-153, with initialize_rpc / scaling_params :156-198), batched over

@@ -255,7 +255,16 @@ struct TriArgs {
     int2* entries;          // per triangulation, track-major and in list order within a track: the two observations
     float* res;             // per triangulation: the point, rounded to float32
     float* out;             // N x 3
+    // a problem handle's resident layout instead of track-major lists (satba_init_pts3d_resident): observation k of track q sits at
+    // slice_base[q / 64] + 64 k + q % 64 of cam_ind / obs (sliced ELL, satba_layout.h), pt_ofs only gives the track lengths, tracks
+    // are the handle's internal points and results go to the caller's point order through perm
+    const int* slice_base = nullptr;
+    const unsigned char* removed = nullptr;  // per observation position: 1 = treat as absent (outlier mask), or null
+    const int* perm = nullptr;               // output row of track q (null: q)
+    int* n_tri_out = nullptr;                // triangulations per track in the caller's order (null: not wanted)
 };
+__device__ inline int tri_pos(const TriArgs& a, int q, int o0, int k) { return a.slice_base ? a.slice_base[q >> 6] + 64 * k + (q & 63) : o0 + k; }
+__device__ inline int tri_cam(const TriArgs& a, int pos) { return (a.removed && a.removed[pos]) ? -1 : a.cam_ind[pos]; }
 
 // Four passes.  (1) k_tri_count: triangulations per track = listed ordered pairs among its cameras; a prefix sum gives every track
 // its slice of the work list.  (2) k_tri_list: the track writes its triangulations into the slice in the order the reference's pair
@@ -267,10 +276,13 @@ __global__ __launch_bounds__(256) void k_tri_count(const TriArgs a) {
     const int o0 = a.pt_ofs[q], k = a.pt_ofs[q + 1] - o0;
     int total = 0;
     for (int ia = 0; ia < k; ++ia) {
-        const int ca = a.cam_ind[o0 + ia];
+        const int ca = tri_cam(a, tri_pos(a, q, o0, ia));
+        if (ca < 0) continue;
         for (int ib = a.ordered ? ia + 1 : 0; ib < k; ++ib) {
             if (ib == ia) continue;
-            for (int id = a.pair_first[(size_t)ca * a.M + a.cam_ind[o0 + ib]]; id >= 0; id = a.pair_next[id]) ++total;
+            const int cb = tri_cam(a, tri_pos(a, q, o0, ib));
+            if (cb < 0) continue;
+            for (int id = a.pair_first[(size_t)ca * a.M + cb]; id >= 0; id = a.pair_next[id]) ++total;
         }
     }
     a.n_tri[q] = total;
@@ -283,9 +295,12 @@ __global__ __launch_bounds__(256) void k_tri_list_ordered(const TriArgs a) {
     int w = a.tri_ofs[q];
     if (a.tri_ofs[q + 1] == w) return;
     for (int ia = 0; ia < k; ++ia) {
-        const int ca = a.cam_ind[o0 + ia];
-        for (int ib = ia + 1; ib < k; ++ib)
-            if (a.pair_first[(size_t)ca * a.M + a.cam_ind[o0 + ib]] >= 0) a.entries[w++] = make_int2(o0 + ia, o0 + ib);
+        const int pa = tri_pos(a, q, o0, ia), ca = tri_cam(a, pa);
+        if (ca < 0) continue;
+        for (int ib = ia + 1; ib < k; ++ib) {
+            const int pb = tri_pos(a, q, o0, ib), cb = tri_cam(a, pb);
+            if (cb >= 0 && a.pair_first[(size_t)ca * a.M + cb] >= 0) a.entries[w++] = make_int2(pa, pb);
+        }
     }
 }
 
@@ -301,10 +316,12 @@ __global__ __launch_bounds__(TRI_THREADS) void k_tri_list(const TriArgs a) {
         // the TRI_BUF smallest list indices above `last` among the ordered camera pairs of the track, ascending
         int nb = 0;
         for (int ia = 0; ia < k; ++ia) {
-            const int ca = a.cam_ind[o0 + ia];
+            const int ca = tri_cam(a, tri_pos(a, q, o0, ia));
+            if (ca < 0) continue;
             for (int ib = 0; ib < k; ++ib) {
                 if (ib == ia) continue;
-                const int cb = a.cam_ind[o0 + ib];
+                const int cb = tri_cam(a, tri_pos(a, q, o0, ib));
+                if (cb < 0) continue;
                 for (int id = a.pair_first[(size_t)ca * a.M + cb]; id >= 0; id = a.pair_next[id]) {
                     if (id <= last) continue;
                     if (nb == TRI_BUF && id >= s_buf[TRI_BUF - 1][tid]) continue;
@@ -319,11 +336,11 @@ __global__ __launch_bounds__(TRI_THREADS) void k_tri_list(const TriArgs a) {
             const int ci = a.pairs[2 * id], cj = a.pairs[2 * id + 1];
             int ia = 0, ib = 0;
             for (int t = 0; t < k; ++t) {
-                const int c = a.cam_ind[o0 + t];
+                const int c = tri_cam(a, tri_pos(a, q, o0, t));
                 if (c == ci) ia = t;
                 if (c == cj) ib = t;
             }
-            a.entries[w++] = make_int2(o0 + ia, o0 + ib);
+            a.entries[w++] = make_int2(tri_pos(a, q, o0, ia), tri_pos(a, q, o0, ib));
         }
         if (nb < TRI_BUF) break;
         last = s_buf[nb - 1][tid];
@@ -364,7 +381,14 @@ __global__ __launch_bounds__(256) void k_tri_mean(const TriArgs a) {
 #pragma unroll
         for (int d = 0; d < 3; ++d) avg[d] = tri_mean_update(avg[d], cm1, a.res[3 * (size_t)e + d], cnt);
     }
-    a.out[3 * (size_t)q] = avg[0]; a.out[3 * (size_t)q + 1] = avg[1]; a.out[3 * (size_t)q + 2] = avg[2];
+    const size_t row = a.perm ? (size_t)a.perm[q] : (size_t)q;
+    a.out[3 * row] = avg[0]; a.out[3 * row + 1] = avg[1]; a.out[3 * row + 2] = avg[2];
+    if (a.n_tri_out) a.n_tri_out[row] = a.tri_ofs[q + 1] - a.tri_ofs[q];
+}
+// outlier mask in the caller's observation order -> the handle's observation positions
+__global__ void k_tri_mask_ell(long long K, const int* __restrict__ obs_pos, const unsigned char* __restrict__ rm, unsigned char* __restrict__ rm_ell) {
+    const long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (o < K) rm_ell[obs_pos[o]] = rm[o];
 }
 
 }  // namespace satba

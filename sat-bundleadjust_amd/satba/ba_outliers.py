@@ -10,6 +10,8 @@ parameters the way ref:bundle_adjust/ba_outliers.py:61-109, 158-185 do: the surv
 observations left (satba.ft_triangulate, on the device) unless the caller hands over coordinates to carry on with (`pts3d=`), and
 `rm_outliers` returns `p` itself when nothing was detected.
 """
+import os
+
 import numpy as np
 
 
@@ -151,9 +153,17 @@ def rm_outliers(err, p, predef_thr=None, min_thr=1.0, verbose=False, pts3d=None)
         pairs = list(p.pairs_to_triangulate)
         canonical = all(0 <= a < b < p.n_cam for a, b in pairs)
         pts = None
-        if pts3d is None and canonical:
-            # one device call gives both the re-triangulated points and, per track, how many listed pairs apply to it: a track
-            # survives iff that count is positive (pairs written i < j, as filter_C_using_pairs_to_triangulate requires)
+        if pts3d is None and canonical and not os.environ.get("SATBA_TRI_UPLOAD"):
+            # one device call on the handle's RESIDENT observations (the mask goes up, the tracks do not go up again) gives both the
+            # re-triangulated points and, per track, how many listed pairs apply to it: a track survives iff that count is positive
+            # (pairs written i < j, as filter_C_using_pairs_to_triangulate requires)
+            from .ft_triangulate import init_pts3d_resident
+
+            pts_all, info = init_pts3d_resident(p, pairs, remove=remove, return_info=True)
+            ok = info["n_tri"] > 0
+            pts = pts_all[ok]
+        elif pts3d is None and canonical:
+            # (SATBA_TRI_UPLOAD=1: the same through the stand-alone entry point, which uploads the surviving tracks -- tests)
             from .ft_triangulate import init_pts3d_from_observations
 
             cand = np.nonzero(two)[0]

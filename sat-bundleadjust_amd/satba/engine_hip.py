@@ -31,7 +31,7 @@ SYMBOLS = [
     "satba_set_exchange", "satba_get_vector", "satba_time_kernel",
     "satba_packed_schur_len", "satba_pack_schur", "satba_unpack_schur",
     "satba_solve_lm", "satba_lm_step", "satba_lm_run", "satba_lm_state", "satba_lm_begin", "satba_lm_part", "satba_lm_poll", "satba_profile_linearize", "satba_profile_read", "satba_outliers", "satba_layout_len", "satba_get_layout", "satba_get_info",
-    "satba_triangulate_pairwise", "satba_init_pts3d", "satba_snapshot_x",
+    "satba_triangulate_pairwise", "satba_init_pts3d", "satba_init_pts3d_resident", "satba_snapshot_x",
     "satba_rpc_fit", "satba_rpc_localization", "satba_rpc_refit",
 ]
 
@@ -137,6 +137,7 @@ def load_library(path=None):
     lib.satba_triangulate_pairwise.argtypes = [C.c_int32, _dp, _dp, C.c_int64, _dp, _dp, _dp, _fp, C.c_int32, _fp]
     lib.satba_init_pts3d.argtypes = [C.c_int32, C.c_int32, C.c_int64, C.POINTER(C.c_int64), _ip, _dp, _dp, C.c_int32, _ip, _fp, _ip,
                                      C.c_int32, C.c_int32, _fp]
+    lib.satba_init_pts3d_resident.argtypes = [C.c_void_p, C.POINTER(C.c_uint8), _dp, C.c_int32, _ip, _fp, _ip, _fp]
     if path == LIB_PATH:
         _LIB = lib
     return lib
@@ -414,6 +415,30 @@ class HipEngine:
         _check(self.lib, self.lib.satba_outliers(self._h, _ptr(e) if e is not None else None, -1.0 if predef_thr is None else float(predef_thr),
                                                  float(min_thr), _ptr(thr), rm.ctypes.data_as(C.POINTER(C.c_uint8)), C.byref(n)))
         return thr, rm[: self.n_obs].astype(bool), int(n.value)
+
+    def init_pts3d(self, camera_table, pairs, remove=None):
+        """
+        ft_triangulate.init_pts3d on the handle's RESIDENT observations (ref:bundle_adjust/ba_outliers.py:89-93 re-triangulates right
+        after the outlier rejection; the tracks are not uploaded again).  camera_table: (n_cam, 12 | 90) float64 (ft_triangulate's
+        table of projection matrices / RPC records), pairs: (n_pairs, 2), remove: (K,) bool in the caller's observation order or None.
+        Returns (pts3d (N, 3) float32, n_tri (N,) int32, kernel_ms).
+        """
+        tab = np.ascontiguousarray(camera_table, dtype=np.float64)
+        if tab.shape[0] != self.n_cam:
+            raise ValueError("camera table has {} rows, expected {}".format(tab.shape[0], self.n_cam))
+        pr = np.ascontiguousarray(np.asarray(pairs, dtype=np.int32).reshape(-1, 2))
+        rm = None
+        if remove is not None:
+            rm = np.ascontiguousarray(remove, dtype=np.uint8)
+            if rm.size != self.n_obs:
+                raise ValueError("remove has {} entries, expected {}".format(rm.size, self.n_obs))
+        out = np.zeros((self.n_pts, 3), dtype=np.float32)
+        n_tri = np.zeros(max(self.n_pts, 1), dtype=np.int32)
+        ms = C.c_float(0.0)
+        _check(self.lib, self.lib.satba_init_pts3d_resident(self._h, rm.ctypes.data_as(C.POINTER(C.c_uint8)) if rm is not None else None,
+                                                            _ptr(tab), pr.shape[0], _ptr(pr, _ip), out.ctypes.data_as(C.POINTER(C.c_float)),
+                                                            _ptr(n_tri, _ip), C.byref(ms)))
+        return out, n_tri[: self.n_pts], ms.value
 
     # -- inspection (parity tests)
     def get_layout(self, name):

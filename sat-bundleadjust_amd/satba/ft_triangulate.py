@@ -105,6 +105,25 @@ def init_pts3d_from_observations(pts_ind, cam_ind, pts2d, n_pts, cameras, cam_mo
     return out
 
 
+def init_pts3d_resident(p, pairs_to_triangulate=None, cameras=None, remove=None, return_info=False):
+    """
+    init_pts3d for the tracks of a BundleAdjustmentParameters object whose observations are already on the device (an engine exists or
+    is created for it: ba_core.get_engine) -- what ref:bundle_adjust/ba_outliers.py:89-93 needs right after the outlier rejection.
+    remove: (K,) bool, observations to treat as absent (compute_obs_mask's mask).  cameras / pairs default to p's.
+    Returns avg_pts3d (p.n_pts, 3) float32 (zero rows where no listed pair applies); with return_info also {"kernel_ms", "n_tri"}.
+    """
+    from . import ba_core
+
+    eng = ba_core.get_engine(p)
+    cams = p.cameras if cameras is None else cameras
+    pairs = p.pairs_to_triangulate if pairs_to_triangulate is None else pairs_to_triangulate
+    tab = _camera_table(list(cams)[: p.n_cam], p.cam_model)
+    out, n_tri, ms = eng.init_pts3d(tab, np.asarray(list(pairs), dtype=np.int32).reshape(-1, 2), remove)
+    if return_info:
+        return out, {"kernel_ms": ms, "n_tri": n_tri}
+    return out
+
+
 def init_pts3d(C_mat, cameras, cam_model, pairs_to_triangulate, verbose=False):
     """
     ref:bundle_adjust/feature_tracks/ft_triangulate.py:57-127: the 3-D point of every feature track = float32 running mean of

@@ -142,3 +142,48 @@ def test_edge_cases(gpu):
     pts = FT.init_pts3d(C, scene.cameras, "affine", [(0, 1)])
     both = ~np.isnan(C[0]) & ~np.isnan(C[2])
     assert np.all(pts[~both] == 0.0) and np.all(np.abs(pts[both]).max(axis=1) > 1e5)
+
+
+@pytest.mark.parametrize("general", [False, True])
+@pytest.mark.parametrize("model,M,N,opp", [("affine", 12, 3000, 5), ("perspective", 9, 2000, 4), ("rpc", 12, 1500, 8)])
+def test_resident_triangulation_is_the_upload_path_bit_for_bit(gpu, model, M, N, opp, general, monkeypatch):
+    """satba_init_pts3d_resident (the tracks of a problem handle, not uploaded again: what ref:bundle_adjust/ba_outliers.py:89-93 needs
+    after the outlier rejection) against satba_init_pts3d on the same observations: without a mask, and with a third of the
+    observations marked as removed (tracks shrink, some lose every listed pair: n_tri = 0 and a zero row, like the reference)."""
+    scene = synth.make_scene(model, M, N, opp, seed=13)
+    p = synth.make_params(scene, {"correction_params": ["R"], "n_cam_fix": 1})
+    ok = (lambda i, j: (i + j) % 2 == 1) if model == "rpc" else (lambda i, j: (i * 5 + j) % 7 != 0)
+    pairs = [(i, j) for i in range(M) for j in range(i + 1, M) if ok(i, j)]
+    if general:  # out of order, with a duplicate and a reversed pair: the sorted-buffer pass
+        rng = np.random.default_rng(3)
+        rng.shuffle(pairs)
+        pairs = [tuple(int(v) for v in pr) for pr in pairs]
+        pairs += [pairs[1], (pairs[3][1], pairs[3][0])]
+    up, info_u = FT.init_pts3d_from_observations(p.pts_ind, p.cam_ind, p.pts2d, p.n_pts, p.cameras, model, pairs, return_info=True)
+    res, info_r = FT.init_pts3d_resident(p, pairs, return_info=True)
+    assert np.array_equal(res, up) and np.array_equal(info_r["n_tri"], info_u["n_tri"]) and info_u["n_tri"].sum() > N
+    remove = np.random.default_rng(5).random(p.n_obs) < 0.33
+    keep = ~remove
+    up, info_u = FT.init_pts3d_from_observations(p.pts_ind[keep], p.cam_ind[keep], p.pts2d[keep], p.n_pts, p.cameras, model, pairs, return_info=True)
+    res, info_r = FT.init_pts3d_resident(p, pairs, remove=remove, return_info=True)
+    assert np.array_equal(res, up) and np.array_equal(info_r["n_tri"], info_u["n_tri"])
+    assert (info_u["n_tri"] == 0).any() and not res[info_u["n_tri"] == 0].any()
+
+
+def test_rm_outliers_retriangulates_on_the_resident_tracks(gpu, monkeypatch):
+    """rm_outliers on an object without a dense C: the re-triangulation of the surviving tracks through the handle's resident
+    observations gives the object the upload path (SATBA_TRI_UPLOAD) gives."""
+    from satba import ba_core, ba_outliers
+
+    scene = synth.make_scene("affine", 8, 4000, 5, seed=21, noise_px=0.4)
+    outl = np.random.default_rng(2).random(scene.pts2d.shape[0]) < 0.01
+    scene.pts2d[outl] += 40.0
+    p = synth.make_params(scene, {"correction_params": ["R"], "n_cam_fix": 1})
+    err = ba_core.compute_reprojection_error(ba_core.fun(p.params_opt, p), p.pts2d_w)
+    new_r = ba_outliers.rm_outliers(err, p)
+    monkeypatch.setenv("SATBA_TRI_UPLOAD", "1")
+    new_u = ba_outliers.rm_outliers(err, p)
+    assert new_r is not p and new_r.n_pts == new_u.n_pts < p.n_pts + 1 and new_r.n_obs == new_u.n_obs < p.n_obs
+    assert np.array_equal(np.asarray(new_r.pts3d), np.asarray(new_u.pts3d))
+    assert np.array_equal(new_r.pts_ind, new_u.pts_ind) and np.array_equal(new_r.cam_ind, new_u.cam_ind)
+    assert np.array_equal(new_r.pts_prev_indices, new_u.pts_prev_indices)

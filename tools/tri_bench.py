@@ -2,7 +2,7 @@
 Runs ON the GPU box: initial triangulation (satba_init_pts3d) at the sizes of the bench shapes, kernel time from HIP events, and the
 CPU baseline beside it -- the reference's own C (oracle/_ref/disp_to_h.so, `kind: reference`) for the RPC method when the snapshot
 carries it, else the numpy oracle (`kind: port`); the numpy oracle for the linear method.  One JSON line per shape.
-    usage: python tools/tri_bench.py [C5|C3|C2 ...]
+    usage: python tools/tri_bench.py [C5|C3|C2 ...] [--resident]
 """
 import ctypes
 import json
@@ -73,7 +73,7 @@ def cpu_baseline(scene, C, pairs, n_target):
     return t_sum / max(done, 1), done, kind
 
 
-for name in sys.argv[1:] or ["C5", "C3"]:
+for name in [a for a in sys.argv[1:] if not a.startswith("--")] or ["C5", "C3"]:
     model, M, N, opp = SHAPES[name]
     scene = synth.make_scene(model, M, N, opp, seed=1)
     ok = (lambda i, j: (i + j) % 2 == 1) if model == "rpc" else (lambda i, j: True)  # the rpc scene alternates two real models
@@ -94,6 +94,24 @@ for name in sys.argv[1:] or ["C5", "C3"]:
             "triangulations": n_tri, "kernel_ms": round(info["kernel_ms"], 4), "triangulations_per_s": round(n_tri / (info["kernel_ms"] * 1e-3)),
             "call_s_with_transfers": round((wall5 - 4 * info["kernel_ms"] * 1e-3), 4), "first_call_s": round(wall_first, 3),
             "median_distance_to_truth_m": round(float(np.median(d[info["n_tri"] > 0])), 3)}
+    if "--resident" in sys.argv:
+        # the same on a problem handle's resident tracks (satba_init_pts3d_resident: what follows the outlier rejection), wall time
+        # of the call with a one-percent mask going up and the points coming back
+        p = synth.make_params(scene, {"correction_params": ["R"], "n_cam_fix": 1})
+        from satba import ba_core
+        ba_core.get_engine(p)  # (the handle exists after the first solve)
+        rm = np.random.default_rng(1).random(p.n_obs) < 0.01
+        FT.init_pts3d_resident(p, pairs, remove=rm)
+        t0 = time.perf_counter()
+        for _ in range(5):
+            pr, ir = FT.init_pts3d_resident(p, pairs, remove=rm, return_info=True)
+        line["resident_call_s"] = round((time.perf_counter() - t0) / 5, 4)
+        line["resident_kernel_ms"] = round(ir["kernel_ms"], 4)
+        keep = ~rm
+        t0 = time.perf_counter()
+        for _ in range(5):
+            FT.init_pts3d_from_observations(p.pts_ind[keep], p.cam_ind[keep], p.pts2d[keep], p.n_pts, p.cameras, model, pairs)
+        line["upload_call_s_same_mask"] = round((time.perf_counter() - t0) / 5, 4)
     if Cs is not None:
         line["cpu_baseline"] = {"value": round(1.0 / spt), "unit": "triangulations/s", "cores": 1, "kind": kind,
                                 "sample": "%d correspondences, pairs in list order" % n_cpu,
