@@ -424,11 +424,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((MODEL == A
             struct Coop { double2 c0, c1, c2, c3, c4, c5, c6; };  // (named members: an array here ends up in scratch)
             int rsrc[NPC];
             const double2* psrc[NPC];
+            unsigned pcv[NPC];  // piece of the record (unit weights: a 32-bit offset from the uniform base instead of five 64-bit pointers)
             int kind[NPC];  // LDS slot of the index that addresses the piece: 64 x (0 record, 1 / 2 scale of observation i / j) + source lane
 #pragma unroll
             for (int t = 0; t < NPC; ++t) {
                 const int g = 64 * t + lane, pc = g % NPC;
                 rsrc[t] = g / NPC;
+                pcv[t] = (unsigned)pc;
                 kind[t] = 64 * (pc < 5 ? 0 : pc - 4) + g / NPC;
                 psrc[t] = pc < 5 ? s.PV + pc : reinterpret_cast<const double2*>(a.sc);
             }
@@ -448,7 +450,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((MODEL == A
                     o.c0 = psrc[0][o0]; o.c1 = psrc[1][o1]; o.c2 = psrc[2][o2]; o.c3 = psrc[3][o3]; o.c4 = psrc[4][o4];
                     o.c5 = psrc[NPC - 2][o5]; o.c6 = psrc[NPC - 1][o6];
                 } else {
-#define SATBA_CL(t) psrc[t][(PV_STRIDE / 2) * (size_t)__shfl(p, rsrc[t])]
+#define SATBA_CL(t) s.PV[(unsigned)(PV_STRIDE / 2) * (unsigned)__shfl(p, rsrc[t]) + pcv[t]]
                     o.c0 = SATBA_CL(0); o.c1 = SATBA_CL(1); o.c2 = SATBA_CL(2); o.c3 = SATBA_CL(3); o.c4 = SATBA_CL(4);
 #undef SATBA_CL
                 }
