@@ -458,7 +458,10 @@ __device__ __noinline__ void c3_chain_rider(int set, int w, double* A, int n, in
         }
         C3_STAMPI(ts, k * C3_TS + 8 + 8, !isR && lane == 0 && w == 3);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // my stores are acknowledged
-        if (lane == 0) c3_lds_inc(isR ? l.pubR_cnt : l.pub_cnt);
+        // (R's waves count only the steps in which they store: in the last step they have nothing to do, and a wave that ran ahead
+        // into it would count twice before a slower one has drained the step before -- the last R would be flagged too early, which
+        // its only reader, the workgroup that writes its transpose, showed as one wrong solve in a hundred at three tile rows)
+        if (lane == 0 && (!isR || has_r)) c3_lds_inc(isR ? l.pubR_cnt : l.pub_cnt);
         C3_STAMPI(ts, k * C3_TS + 8 + 9, !isR && lane == 0 && w == 3);
         if (!isR) {
             // ---- plain stores for the back-substitution kernel: the 32 x 32 block inverses
@@ -881,6 +884,77 @@ __global__ __launch_bounds__(1024) void k_chol_tiles(C3Args g, const int* gate) 
         if (done == (int)gridDim.x - 1) { g.ctr[0] = 0; g.ctr[1] = 0; }  // the last workgroup leaves the counters clean
     }
 }
+
+// ---------------------------------------------------------------------------------------------------------------- small systems
+// n <= 63 unknowns (the reference's usual case: a dozen cameras): the whole solve phase in ONE launch of one workgroup -- scaling of
+// the reduced system, factorisation, forward and backward substitution, the step back in unscaled variables and the header of the
+// phase (k_scale_system, k_chol_dstep, k_trsv_back_small, k_unscale before: 35 us of a 150 us iteration at 10 cameras x 5).  The
+// diagonal-tile code of the chain above (c3_panel: four waves, lane = row, 8-column micro-panels) factorises the tile
+//     [ S'   .  ]      S' = D S D (D = 1 / scale_inv), identity padding to 63,
+//     [ b'^T big ]     b' = D rhs in row 63
+// whose last row comes out as y^T = (L^-1 b')^T: the forward substitution rides along as a row.  Then one wave substitutes backwards
+// from the micro-panels in LDS.  hdr: the solve phase's header as k_unscale writes it.
+__global__ __launch_bounds__(256) void k_solve_small(int n, const double* __restrict__ scale_inv, const double* __restrict__ S, const double* __restrict__ rhs,
+                                                     double* __restrict__ dch, double* __restrict__ dc, int* __restrict__ fail, int n_clear, int hdr_len,
+                                                     double* __restrict__ hdr, double lead, const double* __restrict__ keep, int keep_at, int keep_len,
+                                                     const int* gate) {
+    SATBA_GATE(gate);
+    __shared__ __attribute__((aligned(16))) double s_pan[8 * C3_BLK];
+    __shared__ __attribute__((aligned(16))) double s_pinv[64];
+    __shared__ int s_lf[8];
+    __shared__ int s_bad;
+    const int tid = threadIdx.x, lane = tid & 63, q = tid >> 6;
+    for (int i = tid; i < n_clear; i += 256) fail[i] = 0;  // the dense solver's status word and the flag words behind it
+    if (tid < 8) s_lf[tid] = 0;
+    if (tid == 0) s_bad = 0;
+    const double si_row = scale_inv[lane < n ? lane : 0];
+    double a[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        const int col = 16 * q + c;
+        double v = (col == lane) ? 1.0 : 0.0;  // identity padding
+        if (col < n) {
+            const double si_col = scale_inv[col];
+            if (lane < n && col <= lane) v = S[(size_t)lane + (size_t)col * n] / (si_row * si_col);  // (k_scale_system's arithmetic)
+            else if (lane == 63) v = rhs[col] / si_col;
+        } else if (lane == 63 && col == 63) {
+            v = 1e200;  // any value above |y|^2: the last pivot is not used
+        }
+        a[c] = v;
+    }
+    __syncthreads();
+    const bool bad = c3_panel(a, q, lane, s_pan, s_pinv, s_lf, 1, fail, nullptr);
+    if (bad && lane == 0) atomicOr(&s_bad, 1);
+    __syncthreads();  // every micro-panel is in LDS
+    if (q == 0) {
+        // z = L^-T y: lane = column c of L (k_trsv_back_small's loop, the factor read from the micro-panel blocks: entry (k, c) at
+        // [c / 8][k][c % 8])
+        const int c = lane, cc = min(c, n - 1);
+        const double* colp = s_pan + (cc >> 3) * C3_BLK + (cc & 7);
+        double t[63];
+#pragma unroll
+        for (int k = 0; k < 63; ++k) t[k] = (k < n && k > c) ? colp[k * C3_RS] : 0.0;
+        const double inv = s_pinv[cc];
+        double y = (c < n) ? colp[63 * C3_RS] : 0.0;
+#pragma unroll
+        for (int k = 62; k >= 0; --k) {
+            if (k < n) {  // (uniform)
+                const double zk = readlane_f64(y * inv, k);
+                y = (c == k) ? zk : fma(-t[k], zk, y);  // t[k] is zero at and behind the diagonal (lanes >= k)
+            }
+        }
+        if (c < n) { dch[c] = y; dc[c] = y / scale_inv[c]; }
+    }
+    const int failed = s_bad;
+    if (tid == 0 && failed) fail[0] = 1;
+    for (int i = tid; i < hdr_len; i += 256) {
+        double v = 0.0;
+        if (i == 4) v = failed ? lead : 0.0;
+        if (i >= keep_at && i < keep_at + keep_len) v = lead * keep[i - keep_at];
+        hdr[i] = v;
+    }
+}
+constexpr int CH_ONE_LAUNCH = 63;  // largest system k_solve_small takes
 
 inline int chol_tiles_grid(int n, int mirror) {
     const int n_tasks = c3_task_count((n + 63) / 64, mirror);

@@ -24,6 +24,7 @@ int main(int argc, char** argv) {
     for (int i = 2; i < argc; ++i) sizes.push_back(atoi(argv[i]));
     if (sizes.empty()) sizes = {1000};
     const bool stamps = getenv("SATBA_STAMPS") != nullptr;
+    const bool check_all = getenv("SATBA_CHECK_ALL") != nullptr;
     hipStream_t st;
     CK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
     int worst = 0;
@@ -73,6 +74,7 @@ int main(int argc, char** argv) {
         if (stamps) { CK(hipMalloc(&dts, sizeof(long long) * C3_TS * T)); CK(hipMemset(dts, 0, sizeof(long long) * C3_TS * T)); }
         hipEvent_t e0, e1;
         CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+        int bad_reps = 0;
         auto run = [&](int which, std::vector<float>& times) {
             for (int r = 0; r < reps; ++r) {
                 CK(hipMemcpyAsync(dA, dA0, sizeof(double) * n * n, hipMemcpyDeviceToDevice, st));
@@ -92,6 +94,45 @@ int main(int argc, char** argv) {
                 float ms = 0.f;
                 CK(hipEventElapsedTime(&ms, e0, e1));
                 times.push_back(ms);
+                if (check_all) {  // every repetition's solution, not only the last one's (a rare hand-over race shows as one bad solve in many)
+                    std::vector<double> zr(n);
+                    CK(hipMemcpy(zr.data(), db, sizeof(double) * n, hipMemcpyDeviceToHost));
+                    double ez = 0.0, nz = 0.0; int wi = -1;
+                    for (int i = 0; i < n; ++i) { const double d = std::fabs(zr[i] - z[i]); if (!(d <= ez)) { ez = d; wi = i; } nz = std::max(nz, std::fabs(z[i])); }
+                    if (!(ez <= 1e-10 * nz)) {
+                        ++bad_reps; worst = 1;
+                        if (bad_reps <= 5) {
+                            printf("   n %d %s rep %d: |dz|/|z| %.2e worst row %d; per 64-row block:", n, which ? "driver" : "tiles", r, ez / nz, wi);
+                            for (int b0 = 0; b0 < n; b0 += 64) { double e = 0.0; for (int i = b0; i < std::min(n, b0 + 64); ++i) e = std::max(e, std::fabs(zr[i] - z[i])); printf(" %.1e", e / nz); }
+                            // which of the factor's parts is off: L (lower), L^T (upper), the 32 x 32 inverses
+                            std::vector<double> Lr((size_t)n * n);
+                            CK(hipMemcpy(Lr.data(), dA, sizeof(double) * n * n, hipMemcpyDeviceToHost));
+                            for (int tj = 0; tj * 64 < n; ++tj) for (int ti = 0; ti * 64 < n; ++ti) {
+                                double e = 0.0;
+                                for (int c = 64 * tj; c < std::min(n, 64 * tj + 64); ++c) for (int rr = 64 * ti; rr < std::min(n, 64 * ti + 64); ++rr) {
+                                    if (rr == c) continue;
+                                    const double want = rr > c ? L[(size_t)rr + (size_t)c * n] : L[(size_t)c + (size_t)rr * n];  // upper = L^T
+                                    e = std::max(e, std::fabs(Lr[(size_t)rr + (size_t)c * n] - want));
+                                }
+                                if (e > 1e-9) {
+                                    printf(" tile(%d,%d) off by %.1e", ti, tj, e);
+                                    int nbad = 0, shown = 0;
+                                    for (int c = 64 * tj; c < std::min(n, 64 * tj + 64); ++c) for (int rr = 64 * ti; rr < std::min(n, 64 * ti + 64); ++rr) {
+                                        if (rr == c) continue;
+                                        const double want = rr > c ? L[(size_t)rr + (size_t)c * n] : L[(size_t)c + (size_t)rr * n];
+                                        const double got = Lr[(size_t)rr + (size_t)c * n];
+                                        if (std::fabs(got - want) > 1e-9) {
+                                            ++nbad;
+                                            if (shown < 3) { ++shown; printf(" [(%d,%d) got %.6f want %.6f input(lower twin) %.6f]", rr, c, got, want, A[(size_t)c + (size_t)rr * n]); }
+                                        }
+                                    }
+                                    printf(" %d entries", nbad);
+                                }
+                            }
+                            printf("\n");
+                        }
+                    }
+                }
             }
         };
         {   // the tile kernel alone: forward-substituted right-hand side, mirror and 32 x 32 block inverses against the host
