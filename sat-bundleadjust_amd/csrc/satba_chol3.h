@@ -229,7 +229,9 @@ struct C3Lds {
     int* lf;                // [0..7] micro-panel p of D published (value: step + 1); [8..15], [16..23]: waves of R / the identity
                             // that have published micro-panel p (4 per step)
     int* tb_cnt;            // += 1 per wave of the next diagonal tile (two) and step: its blocks are in Tb
-    int* pub_cnt;           // += 1 per storing wave of L_kk, L_kk^-1, y_k and step (4 + 4 + 1)
+    int* pub_cnt;           // += 1 per storing wave of L_kk^-1, y_k and step (4 + 1)
+    int* pubD_cnt;          // += 1 per storing wave of L_kk and step (4): a counter of its own -- waves of different roles reach a step's
+                            // publication at different times, and a count shared between roles could be completed by the early ones of the next step
     int* pubR_cnt;          // += 1 per storing wave of R and step (4)
     int* y_done;            // = step + 1 when y of the step is formed (the identity's rows have been read by its wave)
     int* prod_cnt;          // += 1 per wave of R and step: its share of the next input is formed (R's rows in LDS may go)
@@ -245,7 +247,7 @@ __device__ __forceinline__ C3Lds c3_carve(double* lds) {
     l.bcur = l.yv + 64;
     l.inv8 = l.bcur + 128;
     int* li = reinterpret_cast<int*>(l.inv8 + 512);
-    l.lf = li; l.tb_cnt = li + 24; l.pub_cnt = li + 25; l.b_rdy = li + 26; l.pubR_cnt = li + 27; l.prod_cnt = li + 28; l.y_done = li + 29; l.inv_flag = li + 32;
+    l.lf = li; l.tb_cnt = li + 24; l.pub_cnt = li + 25; l.b_rdy = li + 26; l.pubR_cnt = li + 27; l.prod_cnt = li + 28; l.y_done = li + 29; l.pubD_cnt = li + 30; l.inv_flag = li + 32;
     return l;
 }
 
@@ -335,7 +337,7 @@ __device__ __noinline__ void c3_chain_diag(int q, double* A, int n, int T, int* 
             if (row < n && col <= row) c3_st(A + (size_t)row + (size_t)col * n, a[c]);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0) c3_lds_inc(l.pub_cnt);
+        if (lane == 0) c3_lds_inc(l.pubD_cnt);
         // ---- the next diagonal tile, formed by two of the helper waves (c3_dnext_blocks), from LDS, one row per lane
         if (has_r) {
             if (!c3_wait_lds(l.tb_cnt, 2 * step1, fail)) return;
@@ -613,9 +615,9 @@ __device__ __noinline__ void c3_chain_aux(double* A, int n, int T, int* fail, in
         if (r0 + lane < n) c3_st(b + r0 + lane, y);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (lane == 0) c3_lds_inc(l.pub_cnt);
-        // ---- publish L_kk, L_kk^-1 and y_k as soon as their nine storing waves have drained: the panel solves of the tiles
+        // ---- publish L_kk, L_kk^-1 and y_k as soon as their nine storing waves (4 + 4 + 1, counted per role) have drained: the panel solves of the tiles
         // below start while R is still on its way
-        if (!c3_wait_lds(l.pub_cnt, 9 * step1, fail)) return;
+        if (!c3_wait_lds(l.pub_cnt, 5 * step1, fail) || !c3_wait_lds(l.pubD_cnt, 4 * step1, fail)) return;
         if (lane == 0) c3_st_flag(flags + k * T + k, want2);
         if (has_r) {
             // ---- publish R = L(k+1, k) as soon as its four storing waves have drained
