@@ -320,7 +320,7 @@ def test_dense_cholesky_solve(gpu, n_cam, n_p):
     eng.close()
 
 
-@pytest.mark.parametrize("n_cam,n_p", [(64, 3), (85, 3), (64, 5), (43, 3)])
+@pytest.mark.parametrize("n_cam,n_p", [(64, 3), (85, 3), (64, 5), (43, 3), (12, 5), (21, 3), (3, 3)])
 def test_dense_solve_many_times_without_one_bad_solve(gpu, n_cam, n_p):
     """The tile kernel's hand-overs are races when they are wrong: one bad solve in a hundred (round 4: the last tile below the
     diagonal flagged before all of its rows were stored, seen by the workgroup that writes its transpose -- at three tile rows only).
