@@ -135,8 +135,10 @@ __device__ __forceinline__ bool c3_wait_lds(const int* f, int want, int* fail) {
 // Tried and dropped: the wave's 16 columns factorised entirely in registers (column j's multipliers by v_readlane applied to all
 // 15 - j later columns, the last foreign micro-panel's share of columns 8 .. 15 issued inside the factorisation): the registers
 // ran out, five spills per column sat on the chain -- 7.6 us per pair of micro-panels against 3.7.
-__device__ __forceinline__ bool c3_panel(double (&a)[16], int q, int lane, double* pan, double* pinv, int* lf, int step1, int* fail, long long* tsp) {
+// n_mp: micro-panels to factorise (8: the whole tile; k_solve_small: only those that hold columns of the system)
+__device__ __forceinline__ bool c3_panel(double (&a)[16], int q, int lane, double* pan, double* pinv, int* lf, int step1, int* fail, long long* tsp, int n_mp = 8) {
     bool bad = false;
+    if (2 * q >= n_mp) return false;
     for (int pp = 0; pp < q; ++pp) {
         // ---- the two micro-panels of the waves to my left: rank-8 updates of my 16 columns, as they appear
 #pragma unroll
@@ -168,6 +170,7 @@ __device__ __forceinline__ bool c3_panel(double (&a)[16], int q, int lane, doubl
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         const int p = 2 * q + h;
+        if (p >= n_mp) break;
         double inv_[8];  // 1 / L_jj (wave-uniform; written once per micro-panel: a store under `lane == 0` per column cost the chain 60 %)
         double d = readlane_f64(a[8 * h], 8 * p);
         bad |= !(d > 1e-300) || !(d < 1e300);
@@ -198,7 +201,7 @@ __device__ __forceinline__ bool c3_panel(double (&a)[16], int q, int lane, doubl
         asm volatile("" ::: "memory");
         if (lane == 0) c3_lds_set(lf + p, step1);  // the LDS unit executes a wave's operations in order: the data are in place before the flag
         C3_STAMP(tsp, p, lane == 0);
-        if (h == 0) {  // the micro-panel's share of my columns 8 .. 15
+        if (h == 0 && p + 1 < n_mp) {  // the micro-panel's share of my columns 8 .. 15
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
                 const double2* lc = reinterpret_cast<const double2*>(pan + p * C3_BLK + (16 * q + 8 + c) * C3_RS);
@@ -925,7 +928,7 @@ __global__ __launch_bounds__(256) void k_solve_small(int n, const double* __rest
         a[c] = v;
     }
     __syncthreads();
-    const bool bad = c3_panel(a, q, lane, s_pan, s_pinv, s_lf, 1, fail, nullptr);
+    const bool bad = c3_panel(a, q, lane, s_pan, s_pinv, s_lf, 1, fail, nullptr, (n + 7) >> 3);  // (padding columns and the corner are not factorised)
     if (bad && lane == 0) atomicOr(&s_bad, 1);
     __syncthreads();  // every micro-panel is in LDS
     if (q == 0) {
