@@ -187,3 +187,16 @@ def test_rm_outliers_retriangulates_on_the_resident_tracks(gpu, monkeypatch):
     assert np.array_equal(np.asarray(new_r.pts3d), np.asarray(new_u.pts3d))
     assert np.array_equal(new_r.pts_ind, new_u.pts_ind) and np.array_equal(new_r.cam_ind, new_u.cam_ind)
     assert np.array_equal(new_r.pts_prev_indices, new_u.pts_prev_indices)
+
+
+def test_resident_triangulation_edge_cases(gpu):
+    """No pairs at all, a pair list that names only missing cameras, every observation removed: zero rows and zero counts, no error."""
+    scene = synth.make_scene("affine", 5, 300, 3, seed=2)
+    p = synth.make_params(scene, {"correction_params": ["R"], "n_cam_fix": 1})
+    for pairs in ([], [(7, 9), (5, 6)]):
+        pts, info = FT.init_pts3d_resident(p, pairs, return_info=True)
+        assert pts.shape == (p.n_pts, 3) and not pts.any() and not info["n_tri"].any()
+    pts, info = FT.init_pts3d_resident(p, [(0, 1), (1, 2)], remove=np.ones(p.n_obs, dtype=bool), return_info=True)
+    assert not pts.any() and not info["n_tri"].any()
+    with pytest.raises(ValueError):
+        FT.init_pts3d_resident(p, [(0, 1)], remove=np.zeros(p.n_obs + 1, dtype=bool))
