@@ -93,6 +93,7 @@ struct satba_problem {
     double *d_fx = nullptr, *d_bbox = nullptr, *d_fxcost = nullptr, *d_fxcost_new = nullptr, *d_fxcost0 = nullptr;
     int *d_fxflag = nullptr, *d_fxe = nullptr;
     bool fxcost_valid = false, fxcost_new_valid = false, fxcost0_valid = false;
+    bool decide_fused = false;  // device-resident loop: the next launch_trial carries k_lm_decide1a in its first launch
     double w_max = 1.0, n_max_cam = 1.0, fx_shrink = 1.0;
     int fx_fallbacks = 0;
     // device-resident LM loop (satba_lmdev.h): while a tick is being queued, `gate` points at the word of the loop's state that
@@ -289,6 +290,11 @@ static int launch_residual(satba_problem* p, bool at_new, double2* f, double* co
 
 // trial point + cost there + |step|^2, |x|^2 in one pass over the observations (k_residual<..., TRIAL>)
 static int launch_trial(satba_problem* p, double c0, double c1, const double* v0, const double* v1) {
+    if (p->decide_fused) {  // device-resident loop: the decision kernel in front of the trial rides in this launch
+        p->decide_fused = false;
+        hipLaunchKernelGGL(k_lm_decide1a_trial_cams, dim3(1), dim3(256), 0, p->stream, p->d_lm, p->d_xb, p->model, p->M, p->NP, p->c_p, p->d_x, v0, v1,
+                           p->d_scale_inv, p->d_cam_static, p->d_xnew, p->d_camc_new, p->d_xb, (int)p->hdr);
+    } else
     hipLaunchKernelGGL(k_trial_cams, dim3((std::max(p->M, (int)p->hdr) + 63) / 64), dim3(64), 0, p->stream, p->model, p->M, p->NP, p->c_p, p->d_x, v0, v1,
                        p->d_scale_inv, c0, c1, p->d_cam_static, p->d_xnew, p->d_camc_new, p->d_xb, (int)p->hdr, p->coef_dev, p->gate);
     HIP_TRY(hipGetLastError());
@@ -1402,7 +1408,7 @@ static int lm_launch_tick(satba_problem* p, double lam_floor) {
     TRY(satba_prepare(p, 0));
     p->gate = &st->run_solve;
     TRY(front_schur_solve(p, true, 0.0, -1.0, lam_floor));
-    hipLaunchKernelGGL(k_lm_decide1a, dim3(1), dim3(1), 0, p->stream, st, p->d_xb);
+    p->decide_fused = true;  // k_lm_decide1a rides in the trial's first launch (launch_trial)
     return lm_launch_tail(p);
 }
 
@@ -1523,7 +1529,7 @@ int satba_lm_part(satba_problem* p, int32_t part, double lam_floor) {
         case 2: p->gate = &st->run_solve; return satba_schur_auto(p, -1.0, lam_floor);
         case 3: p->gate = &st->run_solve; return satba_solve(p);
         case 4:
-            hipLaunchKernelGGL(k_lm_decide1a, dim3(1), dim3(1), 0, p->stream, st, p->d_xb);
+            p->decide_fused = true;  // k_lm_decide1a rides in the trial's first launch (launch_trial)
             p->gate = &st->run_trial;
             return satba_trial_gn(p, 0.0, 0.0);
         case 6: p->gate = &st->run_sub; return satba_subspace(p, 0.0, 0.0);

@@ -113,9 +113,8 @@ __device__ inline void lm_to_host(LmDev* st, int reason) {
 // After the front (the parts of it that ran): bookkeeping of a new linearisation and scipy's top-of-loop tests, the damping
 // escalation after a failed factorisation, the quadratic model from the normal equations -- or the request for the explicit
 // subspace vectors when the two directions are parallel to 1e-6 (satba/trf.py: subspace_model).  h: the solve header.
-__global__ void k_lm_decide1a(LmDev* __restrict__ gst, const double* __restrict__ h) {
+__device__ inline void lm_decide1a(LmDev* __restrict__ gst, const double* __restrict__ h) {
 #pragma clang fp contract(off)
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
     if (gst->phase != LM_RUN) return;  // finished, or paused for the subspace pattern (whose gates must stay as they are)
     // the state is read in one sweep, worked on in registers and written back in one sweep (field-by-field accesses through the
     // pointer serialise on each other's latency: 6 us for this one-thread kernel instead of 3)
@@ -183,6 +182,43 @@ __global__ void k_lm_decide1a(LmDev* __restrict__ gst, const double* __restrict_
         st->phase = LM_NEED_SUB;
         st->sub_requests += 1;
         st->sub_tick = st->tick + 1;
+    }
+}
+
+__global__ void k_lm_decide1a(LmDev* __restrict__ gst, const double* __restrict__ h) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    lm_decide1a(gst, h);
+}
+
+// The same decision and, in the same launch, what follows it in the normal pattern: the trial point of the cameras and their
+// constants there (k_trial_cams; one workgroup: a few hundred cameras at most per thread loop), the exchange header cleared for the
+// residual kernel behind.  One launch less per tick -- a tick of a 10-camera problem is 21 launches of 4 - 23 us.
+__global__ __launch_bounds__(256) void k_lm_decide1a_trial_cams(LmDev* __restrict__ gst, const double* h, int model, int M, int n_p, int c_p,
+                                                                const double* __restrict__ x, const double* __restrict__ v0,
+                                                                const double* __restrict__ v1, const double* __restrict__ scale_inv,
+                                                                const double* __restrict__ cam_static, double* __restrict__ x_new,
+                                                                double* __restrict__ camc_new, double* xb, int hdr_len) {
+    if (threadIdx.x == 0) {
+        lm_decide1a(gst, h);
+        __threadfence();  // the state is in memory before the other waves of the workgroup look at it
+    }
+    __syncthreads();  // (also: thread 0 is done with the header that is cleared below)
+    if (__hip_atomic_load(&gst->run_trial, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;  // k_trial_cams' gate
+    const double c0 = __hip_atomic_load(&gst->coef[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const double c1 = __hip_atomic_load(&gst->coef[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int top = M > hdr_len ? M : hdr_len;
+    for (int c = threadIdx.x; c < top; c += blockDim.x) {
+        if (c < hdr_len) xb[c] = 0.0;
+        if (c >= M) continue;
+        double full[11];
+        for (int i = 0; i < c_p; ++i) full[i] = cam_static[(size_t)c * c_p + i];
+        for (int i = 0; i < n_p; ++i) {
+            const size_t k = (size_t)c * n_p + i;
+            const double v = x[k] + (c0 * v0[k] + c1 * v1[k]) / scale_inv[k];
+            x_new[k] = v;
+            full[i] = v;
+        }
+        cam_constants(model, full, camc_new + (size_t)c * CAMC);
     }
 }
 
