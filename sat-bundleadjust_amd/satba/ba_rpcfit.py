@@ -13,7 +13,6 @@ The coverage test of the reference (`check_correspondences_are_good`: the convex
 image rectangle, via shapely there) is done with scipy.spatial.ConvexHull here: a convex hull contains a rectangle exactly when it
 contains its four corners.
 """
-import ctypes as C
 import os
 
 import numpy as np

@@ -84,7 +84,6 @@ class RPCModel:
     def localization(self, col, row, alt):
         """(col, row [px], alt [m]) -> (lon, lat) degrees by inverting the projection on the device (satba_rpc_localization); same
         signature as rpcm.RPCModel.localization for a model without inverse coefficients (call sites ref:bundle_adjust/ba_rpcfit.py:245,323)."""
-        import ctypes as C
 
         from . import engine_hip as E
 

@@ -12,7 +12,6 @@ import numpy as np
 import pytest
 
 import cases
-from oracle import ba_oracle as O
 from satba import ba_core, ba_outliers, synth, trf
 from satba.engine_hip import HipEngine
 

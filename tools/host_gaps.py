@@ -5,7 +5,6 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [os.path.join(ROOT, "sat-bundleadjust_amd"), ROOT]
-import numpy as np
 import torch
 import bench
 from satba import sharding, synth, trf
