@@ -143,6 +143,11 @@ struct satba_problem {
     int* d_fail = nullptr;
     double* d_dinv = nullptr;  // inverted 32 x 32 diagonal blocks of the factor (backward substitution)
     CholWork chol;             // scratch of the tile factorisation (satba_chol3.h)
+    // the factorisation beside the pair kernel (front_schur_solve): its stream, fork / join events, the producers' counters
+    hipStream_t chol_stream = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    int* d_arrive = nullptr;   // (M + 1) x SCHUR_ARRIVE_STRIDE ints, zero between launches
+    int arrive_epoch = 0;      // != 0 while a front with the factorisation beside it is being queued (launch_schur)
     double* d_scal = nullptr;  // 8 private scalars (costs of satba_residuals, timing sinks)
     double* d_keep = nullptr;  // SATBA_KEEP_LEN scalars of the running iteration that outlive the per-phase headers
     bool prepared = false;
@@ -426,6 +431,11 @@ static int launch_schur(satba_problem* p, const ObsArgs& a, double* S, double* r
     const int dchunks = (a.sc && MODEL != RPC) ? p->cm_chunks_w : p->cm_chunks;
     s.diag_xcd = (dchunks % 8 == 0 && !getenv("SATBA_NO_DIAG_XCD")) ? 1 : 0;
     hipLaunchKernelGGL((k_schur_diag<MODEL, NP>), dim3(p->M, dchunks), dim3(LINC_THREADS), 0, p->stream, a, cm, s, p->d_part3);
+    const int total = p->M * cam_acc_len(NP);
+    if (p->arrive_epoch) {  // the factorisation waits beside this stream: diagonal blocks and right-hand side first, the pair kernel counts its items in
+        hipLaunchKernelGGL(k_schur_diag_finish, dim3((8 * total + 255) / 256), dim3(256), 0, p->stream, p->M, NP, p->n_c, dchunks, p->d_part3, S, rhs, p->gate);
+        s.arrive = p->d_arrive; s.arrive_epoch = p->arrive_epoch;
+    }
     if (n_pairs > 0 && p->L.E > 0) {
         const bool merged = a.unit && p->d_item_desc_merged;  // one item per pair: straight into S, no partials
         if (merged) { s.desc = p->d_item_desc_merged; s.items = p->d_items_merged; s.n_chunks = 1; }
@@ -439,8 +449,8 @@ static int launch_schur(satba_problem* p, const ObsArgs& a, double* S, double* r
                                p->L.pair_ij, p->d_pair_part, S, p->gate, 0ll, n_pairs);
         }
     }
-    const int total = p->M * cam_acc_len(NP);
-    hipLaunchKernelGGL(k_schur_diag_finish, dim3((8 * total + 255) / 256), dim3(256), 0, p->stream, p->M, NP, p->n_c, dchunks, p->d_part3, S, rhs, p->gate);
+    if (!p->arrive_epoch)
+        hipLaunchKernelGGL(k_schur_diag_finish, dim3((8 * total + 255) / 256), dim3(256), 0, p->stream, p->M, NP, p->n_c, dchunks, p->d_part3, S, rhs, p->gate);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -896,6 +906,9 @@ void satba_problem_destroy(satba_problem* p) {
     if (p->h_pin) (void)hipHostFree(p->h_pin);
     if (p->h_lm) (void)hipHostFree(p->h_lm);
     if (p->own_stream) (void)hipStreamDestroy(p->own_stream);
+    if (p->chol_stream) (void)hipStreamDestroy(p->chol_stream);
+    if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
+    if (p->ev_join) (void)hipEventDestroy(p->ev_join);
     delete p;
 }
 
@@ -1142,10 +1155,63 @@ static int schur_impl(satba_problem* p, double lam, bool automatic, double Delta
 }
 
 // schur (+ auto damping) and solve of a front
+// One rank, unit weights, more than two tile columns: the tile factorisation is launched FIRST, on a stream of its own, and works
+// beside the pair kernel -- the rows of the pair triangle are finished in ascending order (schur_item_table), i.e. the columns of S
+// from the left, and every tile of the factorisation waits for the producers of its columns (C3Args::arrive).  The workgroups of
+// the factorisation (SATBA_CHOL_BESIDE_WGS, 1024 threads each: a CU of their own) are resident before the Schur kernels fill the chip.
+static bool chol_beside_ok(const satba_problem* p) {
+    const char* env = getenv("SATBA_CHOL_BESIDE");  // (read at every front: the tests switch it inside one process)
+    if (env && atoi(env) == 0) return false;
+    return p->world == 1 && p->loss == 0 && p->unit_weights && (p->d_item_desc_merged || p->L.C == 1) && p->L.n_pairs > 0 && p->L.E > 0 && p->n_c == p->M * p->NP &&
+           p->n_c > 128 && p->n_c <= 1024 && p->N > 0;
+}
 static int front_schur_solve(satba_problem* p, bool automatic, double lam, double Delta, double lam_floor) {
-    if (automatic) TRY(satba_schur_auto(p, Delta, lam_floor));
-    else TRY(satba_schur(p, lam));
-    return satba_solve(p);
+    if (!chol_beside_ok(p)) {
+        if (automatic) TRY(satba_schur_auto(p, Delta, lam_floor));
+        else TRY(satba_schur(p, lam));
+        return satba_solve(p);
+    }
+    HIP_TRY(hipSetDevice(p->device));
+    if (!p->chol_stream) {
+        HIP_TRY(hipStreamCreateWithFlags(&p->chol_stream, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming));
+        TRY(dev_alloc(p, &p->d_arrive, (size_t)(p->M + 1) * SCHUR_ARRIVE_STRIDE));
+        HIP_TRY(hipMemsetAsync(p->d_arrive, 0, sizeof(int) * (size_t)(p->M + 1) * SCHUR_ARRIVE_STRIDE, p->stream));
+    }
+    const char* env_wgs = getenv("SATBA_CHOL_BESIDE_WGS");
+    const int wgs = (env_wgs && atoi(env_wgs) > 0) ? atoi(env_wgs) : 32;
+    double* S = p->payload();
+    double* rhs = S + (size_t)p->n_c * p->n_c;
+    const int n = p->n_c;
+    {
+        Range range_("satba:solve");
+        HIP_TRY(hipEventRecord(p->ev_fork, p->stream));
+        HIP_TRY(hipStreamWaitEvent(p->chol_stream, p->ev_fork, 0));
+        HIP_TRY(hipMemsetAsync(p->d_fail, 0, sizeof(int) * (1 + CH_MAX_STEPS), p->chol_stream));
+        cholesky_init();
+        C3Args g;
+        g.A = S; g.n = n; g.b = p->d_dch; g.fail = p->d_fail; g.flags = p->chol.flags; g.epoch = ++p->chol.epoch; g.Linv = p->chol.Linv; g.Cc = p->chol.Cc;
+        g.ctr = p->chol.ctr; g.dinv = p->d_dinv; g.ts = nullptr; g.mirror = 1;
+        g.arrive = p->d_arrive; g.arr_M = p->M; g.np = p->NP; g.arr_epoch = g.epoch; g.si = p->d_scale_inv; g.rhs = rhs;
+        hipLaunchKernelGGL(k_chol_tiles, dim3(std::min(chol_tiles_grid(n, 1), wgs)), dim3(1024), c3_lds_bytes(), p->chol_stream, g, p->gate);
+        hipLaunchKernelGGL(k_trsv_back_mw, dim3((n + CH_SB - 1) / CH_SB), dim3(512), 0, p->chol_stream, S, p->d_dinv, n, p->d_dch,
+                           p->d_fail + 1 + CH_TRSV_FLAGS, p->gate);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(p->ev_join, p->chol_stream));
+        p->arrive_epoch = g.epoch;
+    }
+    const int rc = automatic ? satba_schur_auto(p, Delta, lam_floor) : satba_schur(p, lam);
+    p->arrive_epoch = 0;
+    HIP_TRY(hipStreamWaitEvent(p->stream, p->ev_join, 0));  // (also after a failed queueing: the other stream's work is bounded by its time-out)
+    TRY(rc);
+    const int nu = std::max(p->n_c, (int)p->hdr);
+    hipLaunchKernelGGL(k_unscale, dim3((nu + 255) / 256), dim3(256), 0, p->stream, p->n_c, p->d_scale_inv, p->d_dch, p->d_dc, (int)p->hdr,
+                       p->d_xb, p->d_fail, p->lead, p->d_keep, SATBA_HDR_KEEP, SATBA_KEEP_LEN, p->gate);
+    HIP_TRY(hipGetLastError());
+    TRY(launch_backsub_kernel(p));
+    p->have_step = true;
+    return 0;
 }
 
 int satba_schur(satba_problem* p, double lam) {

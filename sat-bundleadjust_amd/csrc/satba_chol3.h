@@ -48,7 +48,20 @@ struct C3Args {
     double* dinv;     // 32 x 32 inverses of the diagonal blocks, [blk][r][c], for k_trsv_back_mw (or null)
     long long* ts;    // tools: C3_TS wall-clock stamps per step (or null)
     int mirror;       // also store L^T into the strict upper triangle (k_trsv_back_mw reads it)
+    // The launch runs BESIDE the kernel that produces the matrix (k_schur_pairs, SchurArgs::arrive) when `arrive` is set: a tile is
+    // read only when the producers of its columns have counted themselves in -- word SCHUR_ARRIVE_STRIDE * c of `arrive` reaches
+    // arr_M - 1 - c for every camera c (np unknowns each) with a column in the tile, word SCHUR_ARRIVE_STRIDE * arr_M holds
+    // arr_epoch -- and is scaled as it is read, A[r][c] / (si[r] si[c]), b = rhs / si (k_scale_system's arithmetic); the last
+    // workgroup leaves the counters at zero.  Producers publish with write-through stores; everything that is input is read with
+    // agent-scope loads.
+    int* arrive = nullptr;
+    int arr_M = 0, np = 1, arr_epoch = 0;
+    const double* si = nullptr;
+    const double* rhs = nullptr;
 };
+constexpr int C3_ARRIVE_STRIDE = 32;  // (= SCHUR_ARRIVE_STRIDE)
+
+struct C3Arrive { const int* arrive; int M, np, epoch; };
 
 constexpr size_t c3_lds_bytes() {
     return sizeof(double) * (3 * 8 * C3_BLK + 64 * C3_TBS + 64 + 64 + 128 + 512) + sizeof(int) * 64;
@@ -125,6 +138,27 @@ __device__ __forceinline__ bool c3_wait_lds(const int* f, int want, int* fail) {
     }
     asm volatile("" ::: "memory");
     return true;
+}
+
+// one wave (all 64 lanes call): until the producers of columns col_lo .. col_hi of the matrix have all counted themselves in
+__device__ __forceinline__ bool c3_wait_arrive(const C3Arrive& r, int col_lo, int col_hi, int* fail) {
+    const int lane = threadIdx.x & 63;
+    const int c_lo = col_lo / r.np, c_hi = col_hi / r.np;
+    int spins = 0;
+    for (;;) {
+        bool ok = true;
+        // lane 0: the word behind the last camera; lanes 1 ..: one camera each (64-column tiles: at most 22 with 3 unknowns per camera)
+        for (int c = c_lo + lane - 1; c <= c_hi; c += 63) {
+            if (lane == 0) { ok = (int)(c3_ld_flag(r.arrive + (size_t)C3_ARRIVE_STRIDE * r.M) - r.epoch) >= 0; break; }
+            if (c3_ld_flag(r.arrive + (size_t)C3_ARRIVE_STRIDE * c) < r.M - 1 - c) ok = false;
+        }
+        if (__all(ok)) return true;
+        __builtin_amdgcn_s_sleep(20);
+        if ((++spins & 255) == 0) {
+            if (spins > C3_SPIN_LIMIT) { if (lane == 0) atomicOr(fail, 2); return false; }
+            if (c3_ld_flag(fail) & 2) return false;
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------- chain
@@ -317,7 +351,7 @@ __device__ __noinline__ void c3_chain_diag(int q, double* A, int n, int T, int* 
     for (int c = 0; c < 16; ++c) {
         const int col = 16 * q + c;
         double v = (col == lane) ? 1.0 : 0.0;
-        if (lane < n && col <= lane) v = c3_gld(A + (size_t)lane + (size_t)col * n);
+        if (lane < n && col <= lane) v = c3_ld(A + (size_t)lane + (size_t)col * n);
         a[c] = v;
     }
     for (int k = 0; k < T; ++k) {
@@ -382,7 +416,7 @@ __device__ __noinline__ void c3_chain_rider(int set, int w, double* A, int n, in
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
                 const int cc = 16 * cb + g4 + 4 * reg, row = 64 + 16 * w + e16;
-                acc[cb][reg] = (row < n) ? c3_gld(A + (size_t)row + (size_t)cc * n) : 0.0;
+                acc[cb][reg] = (row < n) ? c3_ld(A + (size_t)row + (size_t)cc * n) : 0.0;
             }
     }
     for (int k = 0; k < T; ++k) {
@@ -588,7 +622,7 @@ __device__ __noinline__ void c3_chain_aux(double* A, int n, int T, int* fail, in
         if (has_r) {
             if (k >= 1 && !c3_wait(flags + (k + 1) * T + (k - 1), want2, fail)) return;
             const int row = r0 + 64 + lane;
-            bn = (row < n) ? c3_gld(b + row) : 0.0;
+            bn = (row < n) ? c3_ld(b + row) : 0.0;
             for (int m0 = 0; m0 < k; m0 += 8) {  // eight loads in flight
                 double cv[8];
 #pragma unroll
@@ -653,7 +687,31 @@ __device__ __forceinline__ void c3_chain(const C3Args& g, int T) {
     const int tid = threadIdx.x;
     const C3Lds l = c3_carve(c3_lds);
     if (tid < 60) l.lf[tid] = 0;
-    if (tid < 64) l.bcur[tid] = (tid < g.n) ? c3_gld(g.b + tid) : 0.0;
+    if (g.arrive) {
+        // the chain's own input -- tiles (0,0), (1,0), (1,1), (2,1) and the right-hand side -- scaled in place once the producers of
+        // the first two tile columns are done
+        int* s_ok = l.lf + 61;
+        const int n = g.n;
+        if (tid < 64) {
+            const C3Arrive r{g.arrive, g.arr_M, g.np, g.arr_epoch};
+            const bool ok = c3_wait_arrive(r, 0, (n < 128 ? n : 128) - 1, g.fail);
+            if (tid == 0) c3_lds_set(s_ok, ok ? 1 : 0);
+        }
+        __syncthreads();
+        if (!c3_lds_get(s_ok)) return;
+        const int rows = n < 192 ? n : 192, cols = n < 128 ? n : 128;
+        for (int idx = tid; idx < rows * cols; idx += 1024) {
+            const int row = idx % rows, col = idx / rows;
+            if (row >= col && (col >= 64 || row < 128)) {  // (tile (2,0) has an owner)
+                double* pa = g.A + (size_t)row + (size_t)col * n;
+                c3_st(pa, c3_ld(pa) / (g.si[row] * g.si[col]));
+            }
+        }
+        for (int i = tid; i < n; i += 1024) c3_st(g.b + i, c3_ld(g.rhs + i) / g.si[i]);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    if (tid < 64) l.bcur[tid] = (tid < g.n) ? c3_ld(g.b + tid) : 0.0;
     __syncthreads();
     if (tid == 0) c3_lds_set(l.b_rdy, 1);
     const int want2 = 4 * g.epoch + C3_S2, want1 = 4 * g.epoch + C3_S1;
@@ -754,13 +812,32 @@ __device__ __noinline__ void c3_owner(C3Args g, int T, int i, int j, int kind) {
     const bool diag = kind == 0;
     const int rr = 16 * rb + e16;
     chol_d4 old, acc = chol_d4{0.0, 0.0, 0.0, 0.0};
+    if (g.arrive) {
+        if (wave == 0) {
+            const C3Arrive r{g.arrive, g.arr_M, g.np, g.arr_epoch};
+            const bool ok = c3_wait_arrive(r, c0, (c0 + 63 < n ? c0 + 63 : n - 1), g.fail);
+            if (tid == 0) c3_lds_set(s_ok, ok ? 1 : 0);
+        }
+        __syncthreads();
+        if (!c3_lds_get(s_ok)) return;
+        const double si_r = g.si[r0 + rr < n ? r0 + rr : n - 1];
 #pragma unroll
-    for (int reg = 0; reg < 4; ++reg) {
-        const int cc = 16 * cb + g4 + 4 * reg;
-        const int row = r0 + rr, col = c0 + cc;
-        double v = 0.0;
-        if (row < n && col < n && (!diag || cc <= rr)) v = c3_gld(A + (size_t)row + (size_t)col * n);
-        old[reg] = v;
+        for (int reg = 0; reg < 4; ++reg) {
+            const int cc = 16 * cb + g4 + 4 * reg;
+            const int row = r0 + rr, col = c0 + cc;
+            const double v = c3_ld_at(A, n, row, col, row < n && col < n && (!diag || cc <= rr));
+            old[reg] = v / (si_r * g.si[col < n ? col : n - 1]);
+        }
+        __syncthreads();  // (s_ok is used again)
+    } else {
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int cc = 16 * cb + g4 + 4 * reg;
+            const int row = r0 + rr, col = c0 + cc;
+            double v = 0.0;
+            if (row < n && col < n && (!diag || cc <= rr)) v = c3_gld(A + (size_t)row + (size_t)col * n);
+            old[reg] = v;
+        }
     }
     const int n_upd = kind == 2 ? j : j - 1;
     for (int m = 0; m < n_upd; ++m) {
@@ -887,6 +964,12 @@ __global__ __launch_bounds__(1024) void k_chol_tiles(C3Args g, const int* gate) 
     if (threadIdx.x == 0) {
         const int done = atomicAdd(g.ctr + 1, 1);
         if (done == (int)gridDim.x - 1) { g.ctr[0] = 0; g.ctr[1] = 0; }  // the last workgroup leaves the counters clean
+        if (g.arrive) c3_lds_set(s_task, done == (int)gridDim.x - 1 ? 1 : 0);
+    }
+    if (g.arrive) {
+        __syncthreads();
+        if (c3_lds_get(s_task))
+            for (int c = threadIdx.x; c < g.arr_M; c += 1024) g.arrive[(size_t)C3_ARRIVE_STRIDE * c] = 0;
     }
 }
 

@@ -167,7 +167,13 @@ struct SchurArgs {
     const struct SchurItem* __restrict__ desc;  // the same items with everything a wave needs to start (k_schur_item_desc)
     int n_chunks;
     int diag_xcd = 0;                        // k_schur_diag: chunks dealt to the XCDs (see there)
+    // factorisation running beside the pair kernel (satba_chol3.h, C3Args::arrive): every item publishes its block (write-through
+    // stores, drain) and counts itself in the word of its camera row i; word M = arrive_epoch once the kernels in front of this one
+    // (diagonal blocks, right-hand side) are complete.  Words SCHUR_ARRIVE_STRIDE ints apart (one per 128-byte line); null: off
+    int* arrive = nullptr;
+    int arrive_epoch = 0;
 };
+constexpr int SCHUR_ARRIVE_STRIDE = 32;
 
 // Wave "reduce-scatter": N (power of two) values per lane are summed over the 64 lanes with N - 1 + (6 - log2 N)
 // shuffles instead of 6 N: at every step a lane keeps one half of its values and trades the other half with its
@@ -239,6 +245,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((MODEL == A
     const long long n_pairs = (long long)a.M * (a.M - 1) / 2;
     const SchurItem* dp = s.desc + (blockIdx.x * 4u + (unsigned)wave);
     const int i = __builtin_amdgcn_readfirstlane(dp->i);  // wave-uniform by construction: lets the camera constants use scalar loads
+    if (s.arrive && blockIdx.x == 0 && threadIdx.x == 0)
+        __hip_atomic_store(s.arrive + (size_t)SCHUR_ARRIVE_STRIDE * a.M, s.arrive_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (i < 0) return;
     const int j = __builtin_amdgcn_readfirstlane(dp->j);
     const int chunk = __builtin_amdgcn_readfirstlane(dp->chunk);
@@ -558,7 +566,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((MODEL == A
     if (writer) {
         const int r = e / NP, q = e % NP;
         if (s.n_chunks > 1) s.pair_part[((size_t)chunk * n_pairs + pair) * NB2 + e] = total;
-        else S[(size_t)(j * NP + q) + (size_t)(i * NP + r) * a.n_c] = total;  // S[(j,q), (i,r)] = (W_i Vinv W_j^T)[r][q]
+        else if (!s.arrive) S[(size_t)(j * NP + q) + (size_t)(i * NP + r) * a.n_c] = total;  // S[(j,q), (i,r)] = (W_i Vinv W_j^T)[r][q]
+        else __hip_atomic_store(S + (size_t)(j * NP + q) + (size_t)(i * NP + r) * a.n_c, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (s.arrive && s.n_chunks == 1) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_fetch_add(s.arrive + (size_t)SCHUR_ARRIVE_STRIDE * i, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 

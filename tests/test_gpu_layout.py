@@ -198,6 +198,32 @@ def test_device_resident_solve_matches_host_loop(gpu, monkeypatch, name, loss, t
     assert outs[0][0] == outs[1][0] and np.array_equal(outs[0][1], outs[1][1])
 
 
+@pytest.mark.parametrize("model,M,N,opp,corr", [("affine", 40, 4000, 6, ["R", "T"]), ("affine", 70, 5000, 5, ["R"]),
+                                                ("affine", 200, 20000, 8, ["R", "T"]), ("perspective", 30, 3000, 5, ["R", "T"]),
+                                                ("affine", 27, 2000, 6, ["R", "T"])])
+@pytest.mark.parametrize("loop", ["host", "device"])
+def test_factorisation_beside_the_pair_kernel_is_the_sequential_solve(gpu, monkeypatch, model, M, N, opp, corr, loop):
+    """
+    One rank, unit weights, more than two tile columns: the tile Cholesky runs on its own stream beside k_schur_pairs and takes every
+    tile when the producers of its columns have counted themselves in (front_schur_solve, C3Args::arrive).  Same arithmetic in the
+    same order as scale -> factorise -> substitute one after the other (SATBA_CHOL_BESIDE=0): identical to the last bit, for the
+    loop with the decisions on the host and for the device-resident one.
+    """
+    scene = synth.make_scene(model, M, N, opp, seed=11)
+    if loop == "host":
+        monkeypatch.setenv("SATBA_HOST_LOOP", "1")
+    outs = []
+    for beside in ("1", "0", "1"):
+        monkeypatch.setenv("SATBA_CHOL_BESIDE", beside)
+        eng = HipEngine(synth.make_params(scene, {"correction_params": corr, "n_cam_fix": 1}))
+        st = eng.solve_lm(max_nfev=30, loss="linear", ftol=1e-12, xtol=1e-12, gtol=1e-12)
+        outs.append(((st.cost, st.nfev, st.njev, st.iterations, st.status, st.optimality, st.initial_cost), eng.get_x()))
+        eng.close()
+    assert outs[0][0] == outs[1][0] == outs[2][0]
+    assert np.array_equal(outs[0][1], outs[1][1]) and np.array_equal(outs[0][1], outs[2][1])
+    assert outs[0][0][0] < 0.5 * outs[0][0][6]  # (the solve went somewhere)
+
+
 def test_snapshot_restores_the_point_and_the_solve_repeats(gpu):
     """satba_snapshot_x (what bench.py restarts its solve with): the point comes back bit for bit, and the solve that follows
     repeats the first one exactly (default path: fixed-point camera sums)."""
