@@ -148,6 +148,8 @@ struct satba_problem {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int* d_arrive = nullptr;   // (M + 1) x SCHUR_ARRIVE_STRIDE ints, zero between launches
     int arrive_epoch = 0;      // != 0 while a front with the factorisation beside it is being queued (launch_schur)
+    bool beside_last = false;  // the last front ran that way
+    bool beside_off = false;   // ... and timed out waiting for the pair kernel (kernels serialised by a tool): never again on this handle
     double* d_scal = nullptr;  // 8 private scalars (costs of satba_residuals, timing sinks)
     double* d_keep = nullptr;  // SATBA_KEEP_LEN scalars of the running iteration that outlive the per-phase headers
     bool prepared = false;
@@ -1163,10 +1165,22 @@ static bool chol_beside_ok(const satba_problem* p) {
     const char* env = getenv("SATBA_CHOL_BESIDE");  // (read at every front: the tests switch it inside one process)
     if (env && atoi(env) == 0) return false;
     return p->world == 1 && p->loss == 0 && p->unit_weights && (p->d_item_desc_merged || p->L.C == 1) && p->L.n_pairs > 0 && p->L.E > 0 && p->n_c == p->M * p->NP &&
-           p->n_c > 128 && p->n_c <= 1024 && p->N > 0;
+           p->n_c > 128 && p->n_c <= 1024 && p->N > 0 && !p->beside_off;
+}
+static int front_schur_solve(satba_problem* p, bool automatic, double lam, double Delta, double lam_floor);
+// header slot 4 of the solve phase = lead x status word of the factorisation: bit 1 = a wait timed out.  Beside the pair kernel that
+// means the two kernels did not run at the same time (a profiler collecting counters serialises the launches): the handle goes back
+// to one kernel after the other and the caller repeats the front with the same damping.
+static bool beside_timed_out(satba_problem* p, const double* h) {
+    if (!p->beside_last || !(h[4] >= 2.0)) return false;
+    p->beside_off = true;
+    (void)hipStreamSynchronize(p->chol_stream);
+    (void)hipMemsetAsync(p->d_arrive, 0, sizeof(int) * (size_t)(p->M + 1) * SCHUR_ARRIVE_STRIDE, p->stream);
+    return true;
 }
 static int front_schur_solve(satba_problem* p, bool automatic, double lam, double Delta, double lam_floor) {
-    if (!chol_beside_ok(p)) {
+    p->beside_last = chol_beside_ok(p);
+    if (!p->beside_last) {
         if (automatic) TRY(satba_schur_auto(p, Delta, lam_floor));
         else TRY(satba_schur(p, lam));
         return satba_solve(p);
@@ -1395,7 +1409,7 @@ int satba_lm_step(satba_problem* p, int32_t first, double Delta, double lam_floo
     double reg = h[K_LAM];
     for (int attempt = 0; attempt < 10; ++attempt) {  // a failed factorisation is repeated with more damping, as satba_solve_lm does
         if (h[4] == 0 && std::isfinite(h[3])) break;
-        reg = std::fmax(reg, 1e-16) * 100.0;
+        if (!beside_timed_out(p, h)) reg = std::fmax(reg, 1e-16) * 100.0;
         TRY(front_schur_solve(p, false, reg, 0.0, 0.0));
         TRY(satba_read_header(p, h));
     }
@@ -1702,7 +1716,7 @@ static int lm_host_loop(satba_problem* p, const satba_lm_opts* o, satba_lm_stats
         int attempt = 0;
         for (; attempt < 10; ++attempt) {  // a Cholesky needs a floor where LSMR copes with a numerically singular system
             if (h[CHOL_FAIL] == 0 && std::isfinite(h[GRAM_C])) break;
-            reg = std::fmax(reg, 1e-16) * 100.0;
+            if (!beside_timed_out(p, h)) reg = std::fmax(reg, 1e-16) * 100.0;
             TRY(front_schur_solve(p, false, reg, 0.0, 0.0));
             TRY(satba_read_header(p, h));
         }
@@ -1945,6 +1959,7 @@ int satba_get_info(const satba_problem* p, double* out, int32_t n) {
     out[5] = p->L.P; out[6] = (double)p->L.E; out[7] = p->L.C; out[8] = p->unit_weights; out[9] = p->camc_lds; out[10] = p->rpc_lds;
     out[11] = p->cam_sums_lds; out[12] = p->deterministic; out[13] = p->cm_chunks; out[14] = p->lin_grid; out[15] = p->fx_fallbacks;
     if (n > 16) out[16] = (lm_device_loop_ok(p) && lm_device_loop_pays(p)) ? 1.0 : 0.0;
+    if (n > 17) out[17] = p->beside_off ? -1.0 : (p->beside_last ? 1.0 : 0.0);
     return 0;
 }
 

@@ -33,6 +33,7 @@ constexpr int C3_TBS = 65;                 // column stride of the hand-over buf
 constexpr int C3_LD = 80;                  // row stride of an owner's operand tiles [k][r] (MFMA operand loads: disjoint bank ranges)
 constexpr int C3_S1 = 1, C3_S2 = 2;        // stages of a tile flag: 1 = A' (all panels but the chain's) published, 2 = L published
 constexpr int C3_SPIN_LIMIT = 1 << 22;
+constexpr int C3_ARRIVE_SPIN_LIMIT = 1 << 19;  // looks at the producers' counters before giving up (~0.3 s: they are not running beside this kernel)
 constexpr int C3_TS = 32;                  // time stamps per step (tools): 0..5 phases, 8 + 8 set + p: micro-panel p of a row set flagged
 
 struct C3Args {
@@ -55,13 +56,13 @@ struct C3Args {
     // workgroup leaves the counters at zero.  Producers publish with write-through stores; everything that is input is read with
     // agent-scope loads.
     int* arrive = nullptr;
-    int arr_M = 0, np = 1, arr_epoch = 0;
+    int arr_M = 0, np = 1, arr_epoch = 0, nap = 1;  // nap: length of a pause between two looks at the counters, in units of ~0.5 us
     const double* si = nullptr;
     const double* rhs = nullptr;
 };
 constexpr int C3_ARRIVE_STRIDE = 32;  // (= SCHUR_ARRIVE_STRIDE)
 
-struct C3Arrive { const int* arrive; int M, np, epoch; };
+struct C3Arrive { const int* arrive; int M, np, epoch, nap; };
 
 constexpr size_t c3_lds_bytes() {
     return sizeof(double) * (3 * 8 * C3_BLK + 64 * C3_TBS + 64 + 64 + 128 + 512) + sizeof(int) * 64;
@@ -153,9 +154,9 @@ __device__ __forceinline__ bool c3_wait_arrive(const C3Arrive& r, int col_lo, in
             if (c3_ld_flag(r.arrive + (size_t)C3_ARRIVE_STRIDE * c) < r.M - 1 - c) ok = false;
         }
         if (__all(ok)) return true;
-        __builtin_amdgcn_s_sleep(20);
+        for (int t = 0; t < r.nap; ++t) __builtin_amdgcn_s_sleep(20);
         if ((++spins & 255) == 0) {
-            if (spins > C3_SPIN_LIMIT) { if (lane == 0) atomicOr(fail, 2); return false; }
+            if (spins > C3_ARRIVE_SPIN_LIMIT) { if (lane == 0) atomicOr(fail, 2); return false; }
             if (c3_ld_flag(fail) & 2) return false;
         }
     }
@@ -693,7 +694,7 @@ __device__ __forceinline__ void c3_chain(const C3Args& g, int T) {
         int* s_ok = l.lf + 61;
         const int n = g.n;
         if (tid < 64) {
-            const C3Arrive r{g.arrive, g.arr_M, g.np, g.arr_epoch};
+            const C3Arrive r{g.arrive, g.arr_M, g.np, g.arr_epoch, g.nap};
             const bool ok = c3_wait_arrive(r, 0, (n < 128 ? n : 128) - 1, g.fail);
             if (tid == 0) c3_lds_set(s_ok, ok ? 1 : 0);
         }
@@ -814,7 +815,7 @@ __device__ __noinline__ void c3_owner(C3Args g, int T, int i, int j, int kind) {
     chol_d4 old, acc = chol_d4{0.0, 0.0, 0.0, 0.0};
     if (g.arrive) {
         if (wave == 0) {
-            const C3Arrive r{g.arrive, g.arr_M, g.np, g.arr_epoch};
+            const C3Arrive r{g.arrive, g.arr_M, g.np, g.arr_epoch, g.nap};
             const bool ok = c3_wait_arrive(r, c0, (c0 + 63 < n ? c0 + 63 : n - 1), g.fail);
             if (tid == 0) c3_lds_set(s_ok, ok ? 1 : 0);
         }

@@ -1178,7 +1178,7 @@ __global__ void k_unscale(int n_c, const double* __restrict__ scale_inv, const d
     if (i < n_c) dc[i] = dch[i] / scale_inv[i];
     if (i < hdr_len) {
         double v = 0.0;
-        if (i == 4) v = (*fail_flag != 0) ? lead : 0.0;
+        if (i == 4) v = lead * (double)*fail_flag;  // (0: factorised; bit 0 not positive definite, bit 1 a wait timed out)
         if (i >= keep_at && i < keep_at + keep_len) v = lead * keep[i - keep_at];
         hdr[i] = v;
     }

@@ -245,7 +245,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((MODEL == A
     const long long n_pairs = (long long)a.M * (a.M - 1) / 2;
     const SchurItem* dp = s.desc + (blockIdx.x * 4u + (unsigned)wave);
     const int i = __builtin_amdgcn_readfirstlane(dp->i);  // wave-uniform by construction: lets the camera constants use scalar loads
-    if (s.arrive && blockIdx.x == 0 && threadIdx.x == 0)
+    if (UNITW && s.arrive && blockIdx.x == 0 && threadIdx.x == 0)  // (the weighted / robust kernel leaves partial blocks: never beside the factorisation)
         __hip_atomic_store(s.arrive + (size_t)SCHUR_ARRIVE_STRIDE * a.M, s.arrive_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (i < 0) return;
     const int j = __builtin_amdgcn_readfirstlane(dp->j);
@@ -566,10 +566,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((MODEL == A
     if (writer) {
         const int r = e / NP, q = e % NP;
         if (s.n_chunks > 1) s.pair_part[((size_t)chunk * n_pairs + pair) * NB2 + e] = total;
-        else if (!s.arrive) S[(size_t)(j * NP + q) + (size_t)(i * NP + r) * a.n_c] = total;  // S[(j,q), (i,r)] = (W_i Vinv W_j^T)[r][q]
+        else if (!UNITW || !s.arrive) S[(size_t)(j * NP + q) + (size_t)(i * NP + r) * a.n_c] = total;  // S[(j,q), (i,r)] = (W_i Vinv W_j^T)[r][q]
         else __hip_atomic_store(S + (size_t)(j * NP + q) + (size_t)(i * NP + r) * a.n_c, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (s.arrive && s.n_chunks == 1) {
+    if (UNITW && s.arrive && s.n_chunks == 1) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (lane == 0) __hip_atomic_fetch_add(s.arrive + (size_t)SCHUR_ARRIVE_STRIDE * i, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }

@@ -22,7 +22,9 @@ SHAPES = {"C2": (10, 5000, 6), "C3": (50, 100000, 10), "C4": (200, 1000000, 10)}
 # BASELINE.json configs by name: (camera model, correction_params, n_cam, n_pts, obs_per_pt)
 CONFIGS = {"C2": ("affine", ["R", "T"], 10, 5000, 6), "C3": ("affine", ["R", "T"], 50, 100000, 10),
            "C4": ("affine", ["R", "T"], 200, 1000000, 10), "C5": ("rpc", ["R"], 50, 100000, 10),
-           "P3": ("perspective", ["R", "T"], 50, 100000, 10)}
+           "P3": ("perspective", ["R", "T"], 50, 100000, 10),
+           # between C3 and C4 (tuning of thresholds that depend on the number of cameras; not bench lines)
+           "M100": ("affine", ["R", "T"], 100, 300000, 10), "M150": ("affine", ["R", "T"], 150, 600000, 10)}
 
 
 class Scene:

@@ -212,16 +212,47 @@ def test_factorisation_beside_the_pair_kernel_is_the_sequential_solve(gpu, monke
     scene = synth.make_scene(model, M, N, opp, seed=11)
     if loop == "host":
         monkeypatch.setenv("SATBA_HOST_LOOP", "1")
+    monkeypatch.setenv("SATBA_SCHUR_MERGE", "1")  # one item per camera pair for the few cameras of a test, too (the default from 8 192 pairs on)
     outs = []
     for beside in ("1", "0", "1"):
         monkeypatch.setenv("SATBA_CHOL_BESIDE", beside)
         eng = HipEngine(synth.make_params(scene, {"correction_params": corr, "n_cam_fix": 1}))
         st = eng.solve_lm(max_nfev=30, loss="linear", ftol=1e-12, xtol=1e-12, gtol=1e-12)
         outs.append(((st.cost, st.nfev, st.njev, st.iterations, st.status, st.optimality, st.initial_cost), eng.get_x()))
+        assert int(eng.info()["chol_beside"]) == int(beside)
         eng.close()
     assert outs[0][0] == outs[1][0] == outs[2][0]
     assert np.array_equal(outs[0][1], outs[1][1]) and np.array_equal(outs[0][1], outs[2][1])
     assert outs[0][0][0] < 0.5 * outs[0][0][6]  # (the solve went somewhere)
+
+
+def test_factorisation_beside_the_pair_kernel_falls_back_when_launches_are_serialised(gpu):
+    """
+    A tool that runs one kernel at a time (counter collection; here AMD_SERIALIZE_KERNEL=3) leaves the factorisation waiting for a
+    pair kernel that has not been started: its waits time out (status bit 1), the handle goes back to one kernel after the other and
+    the front is repeated with the same damping -- the solve is the sequential one, bit for bit.
+    """
+    import os
+    import subprocess
+    import sys
+
+    code = (
+        "import sys, hashlib; sys.path.insert(0, %r)\n"
+        "from satba import synth\nfrom satba.engine_hip import HipEngine\n"
+        "scene = synth.make_scene('affine', 40, 3000, 6, seed=11)\n"
+        "eng = HipEngine(synth.make_params(scene, {'correction_params': ['R', 'T'], 'n_cam_fix': 1}))\n"
+        "st = eng.solve_lm(max_nfev=6, loss='linear', ftol=1e-12, xtol=1e-12, gtol=1e-12)\n"
+        "print('RESULT', repr(st.cost), st.nfev, st.status, hashlib.sha1(eng.get_x().tobytes()).hexdigest())\n"
+        "print('BESIDE', int(eng.info()['chol_beside']))\n"
+    ) % os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "sat-bundleadjust_amd")
+    outs = []
+    for env_add in ({"SATBA_CHOL_BESIDE": "0"}, {"AMD_SERIALIZE_KERNEL": "3"}):
+        env = dict(os.environ, SATBA_SCHUR_MERGE="1", SATBA_HOST_LOOP="1", **env_add)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=240)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append([ln for ln in r.stdout.splitlines() if ln.startswith("RESULT")][-1])
+        assert "BESIDE %d" % (-1 if "AMD_SERIALIZE_KERNEL" in env_add else 0) in r.stdout, r.stdout
+    assert outs[0] == outs[1], outs
 
 
 def test_snapshot_restores_the_point_and_the_solve_repeats(gpu):

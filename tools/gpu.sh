@@ -40,9 +40,11 @@ stats)
   cd /tmp && export TMPDIR=/tmp
   timeout 600 rocprofv3 --kernel-trace --stats -d $out/prof -o stats -- python3 $GRAFT_REPO_ROOT/bench.py --cpu-sample-pts 0 "$@" > $out/bench_profiled.json 2> $out/prof.log
   python3 $GRAFT_REPO_ROOT/tools/rocpd_stats.py $out/prof/stats_results.db > $out/kernel_stats.txt
-  head -34 $out/kernel_stats.txt
+  python3 $GRAFT_REPO_ROOT/tools/rocpd_timeline.py $out/prof/stats_results.db > $out/timeline.txt 2>&1
+  head -${HEAD_LINES:-34} $out/kernel_stats.txt; cat $out/timeline.txt
   find $out -name "*.db" -size +2M -delete ;;
 pmc|pmc_loop)
+  export SATBA_CHOL_BESIDE=0  # (counter collection runs one kernel at a time: the factorisation beside the pair kernel would only time out)
   shape=${1:-C4}; loss=${2:-linear}; pat=${3:-k_linearize}
   cd /tmp && export TMPDIR=/tmp
   if [ $cmd = pmc ]; then
