@@ -147,6 +147,7 @@ struct satba_problem {
     hipStream_t chol_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int* d_arrive = nullptr;   // (M + 1) x SCHUR_ARRIVE_STRIDE ints, zero between launches
+    long long* d_ts = nullptr; // (tools, -DC3_STAMPS: time stamps of the last factorisation beside the pair kernel, printed when the handle goes)
     int arrive_epoch = 0;      // != 0 while a front with the factorisation beside it is being queued (launch_schur)
     bool beside_last = false;  // the last front ran that way
     bool beside_off = false;   // ... and timed out waiting for the pair kernel (kernels serialised by a tool): never again on this handle
@@ -903,6 +904,22 @@ void satba_problem_destroy(satba_problem* p) {
     if (!p) return;
     (void)hipSetDevice(p->device);
     (void)hipDeviceSynchronize();
+#ifdef C3_STAMPS
+    if (p->d_ts) {
+        std::vector<long long> ts((size_t)20 * C3_TS);
+        (void)hipMemcpy(ts.data(), p->d_ts, sizeof(long long) * ts.size(), hipMemcpyDeviceToHost);
+        const int T = (p->n_c + 63) / 64;
+        const long long t0 = ts[(size_t)T * C3_TS + 0];
+        fprintf(stderr, "C3TS wait_begin 0 chain_start %.2f\n", (ts[(size_t)T * C3_TS + 1] - t0) * 0.01);
+        for (int k = 0; k < T; ++k) {
+            fprintf(stderr, "C3TS step %2d start %8.2f D_done %8.2f R %8.2f I %8.2f dnext %8.2f aux %8.2f nextD %8.2f | col arrived %8.2f handed %8.2f\n", k,
+                    (ts[(size_t)k * C3_TS + 0] - t0) * 0.01, (ts[(size_t)k * C3_TS + 1] - t0) * 0.01, (ts[(size_t)k * C3_TS + 2] - t0) * 0.01,
+                    (ts[(size_t)k * C3_TS + 3] - t0) * 0.01, (ts[(size_t)k * C3_TS + 4] - t0) * 0.01, (ts[(size_t)k * C3_TS + 5] - t0) * 0.01,
+                    (ts[(size_t)k * C3_TS + 6] - t0) * 0.01, k >= 2 ? (ts[(size_t)T * C3_TS + k] - t0) * 0.01 : 0.0,
+                    k >= 2 ? (ts[(size_t)(T + 1) * C3_TS + k] - t0) * 0.01 : 0.0);
+        }
+    }
+#endif
     for (void* q : p->allocs) (void)hipFree(q);
     for (hipEvent_t e : p->prof_ev) (void)hipEventDestroy(e);
     if (p->h_pin) (void)hipHostFree(p->h_pin);
@@ -1207,6 +1224,11 @@ static int front_schur_solve(satba_problem* p, bool automatic, double lam, doubl
         C3Args g;
         g.A = S; g.n = n; g.b = p->d_dch; g.fail = p->d_fail; g.flags = p->chol.flags; g.epoch = ++p->chol.epoch; g.Linv = p->chol.Linv; g.Cc = p->chol.Cc;
         g.ctr = p->chol.ctr; g.dinv = p->d_dinv; g.ts = nullptr; g.mirror = 1;
+#ifdef C3_STAMPS
+        if (!p->d_ts) { TRY(dev_alloc(p, &p->d_ts, (size_t)20 * C3_TS)); }
+        HIP_TRY(hipMemsetAsync(p->d_ts, 0, sizeof(long long) * 20 * C3_TS, p->chol_stream));
+        g.ts = p->d_ts;
+#endif
         g.arrive = p->d_arrive; g.arr_M = p->M; g.np = p->NP; g.arr_epoch = g.epoch; g.si = p->d_scale_inv; g.rhs = rhs;
         hipLaunchKernelGGL(k_chol_tiles, dim3(std::min(chol_tiles_grid(n, 1), wgs)), dim3(1024), c3_lds_bytes(), p->chol_stream, g, p->gate);
         hipLaunchKernelGGL(k_trsv_back_mw, dim3((n + CH_SB - 1) / CH_SB), dim3(512), 0, p->chol_stream, S, p->d_dinv, n, p->d_dch,

@@ -695,7 +695,9 @@ __device__ __forceinline__ void c3_chain(const C3Args& g, int T) {
         const int n = g.n;
         if (tid < 64) {
             const C3Arrive r{g.arrive, g.arr_M, g.np, g.arr_epoch, g.nap};
+            C3_STAMP(g.ts, T * C3_TS + 0, tid == 0);
             const bool ok = c3_wait_arrive(r, 0, (n < 128 ? n : 128) - 1, g.fail);
+            C3_STAMP(g.ts, T * C3_TS + 1, tid == 0);
             if (tid == 0) c3_lds_set(s_ok, ok ? 1 : 0);
         }
         __syncthreads();
@@ -812,25 +814,35 @@ __device__ __noinline__ void c3_owner(C3Args g, int T, int i, int j, int kind) {
     const int r0 = 64 * i, c0 = 64 * j;
     const bool diag = kind == 0;
     const int rr = 16 * rb + e16;
-    chol_d4 old, acc = chol_d4{0.0, 0.0, 0.0, 0.0};
+    chol_d4 old = chol_d4{0.0, 0.0, 0.0, 0.0}, acc = chol_d4{0.0, 0.0, 0.0, 0.0};
+    // beside the producing kernel the tile itself is read LAST: the sum of the panel products does not need it, and the late tile
+    // columns arrive long after their first panels (read first, the diagonal tiles reached the chain 20 - 30 us after they had arrived)
+    double sprod[4] = {1.0, 1.0, 1.0, 1.0};  // scale_inv[row] scale_inv[col] of the thread's four entries
     if (g.arrive) {
+        const double si_r = g.si[r0 + rr < n ? r0 + rr : n - 1];
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) { const int col = c0 + 16 * cb + g4 + 4 * reg; sprod[reg] = si_r * g.si[col < n ? col : n - 1]; }
+    }
+    auto load_arrived = [&]() -> bool {
         if (wave == 0) {
             const C3Arrive r{g.arrive, g.arr_M, g.np, g.arr_epoch, g.nap};
             const bool ok = c3_wait_arrive(r, c0, (c0 + 63 < n ? c0 + 63 : n - 1), g.fail);
             if (tid == 0) c3_lds_set(s_ok, ok ? 1 : 0);
         }
         __syncthreads();
-        if (!c3_lds_get(s_ok)) return;
-        const double si_r = g.si[r0 + rr < n ? r0 + rr : n - 1];
+        if (!c3_lds_get(s_ok)) return false;
+        C3_STAMP(g.ts, T * C3_TS + j, tid == 0 && kind == 0);
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
             const int cc = 16 * cb + g4 + 4 * reg;
             const int row = r0 + rr, col = c0 + cc;
             const double v = c3_ld_at(A, n, row, col, row < n && col < n && (!diag || cc <= rr));
-            old[reg] = v / (si_r * g.si[col < n ? col : n - 1]);
+            old[reg] = v / sprod[reg];
         }
         __syncthreads();  // (s_ok is used again)
-    } else {
+        return true;
+    };
+    if (!g.arrive) {
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
             const int cc = 16 * cb + g4 + 4 * reg;
@@ -873,6 +885,7 @@ __device__ __noinline__ void c3_owner(C3Args g, int T, int i, int j, int kind) {
             }
         }
     }
+    if (g.arrive && !load_arrived()) return;
     if (kind != 2) {
         // ---- hand the tile to the chain: all panels but the last applied
 #pragma unroll
@@ -884,6 +897,7 @@ __device__ __noinline__ void c3_owner(C3Args g, int T, int i, int j, int kind) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) c3_st_flag(g.flags + i * T + j, want1);
+        C3_STAMP(g.ts, (T + 1) * C3_TS + j, tid == 0 && kind == 0);
         return;
     }
     // ---- panel solve as a product: L(i,j) = A' L_jj^-T, X[r][c] = sum_m A'[r][m] Linv[c][m]
