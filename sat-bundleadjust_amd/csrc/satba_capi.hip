@@ -1192,7 +1192,7 @@ static bool beside_timed_out(satba_problem* p, const double* h) {
     if (!p->beside_last || !(h[4] >= 2.0)) return false;
     p->beside_off = true;
     (void)hipStreamSynchronize(p->chol_stream);
-    (void)hipMemsetAsync(p->d_arrive, 0, sizeof(int) * (size_t)(p->M + 1) * SCHUR_ARRIVE_STRIDE, p->stream);
+    (void)hipMemsetAsync(p->d_arrive, 0, sizeof(int) * (size_t)(p->M + 2) * SCHUR_ARRIVE_STRIDE, p->stream);
     return true;
 }
 static int front_schur_solve(satba_problem* p, bool automatic, double lam, double Delta, double lam_floor) {
@@ -1207,8 +1207,8 @@ static int front_schur_solve(satba_problem* p, bool automatic, double lam, doubl
         HIP_TRY(hipStreamCreateWithFlags(&p->chol_stream, hipStreamNonBlocking));
         HIP_TRY(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming));
-        TRY(dev_alloc(p, &p->d_arrive, (size_t)(p->M + 1) * SCHUR_ARRIVE_STRIDE));
-        HIP_TRY(hipMemsetAsync(p->d_arrive, 0, sizeof(int) * (size_t)(p->M + 1) * SCHUR_ARRIVE_STRIDE, p->stream));
+        TRY(dev_alloc(p, &p->d_arrive, (size_t)(p->M + 2) * SCHUR_ARRIVE_STRIDE));  // (+ k_schur_pairs' start word, + the solve's done word)
+        HIP_TRY(hipMemsetAsync(p->d_arrive, 0, sizeof(int) * (size_t)(p->M + 2) * SCHUR_ARRIVE_STRIDE, p->stream));
     }
     const char* env_wgs = getenv("SATBA_CHOL_BESIDE_WGS");
     const int wgs = (env_wgs && atoi(env_wgs) > 0) ? atoi(env_wgs) : 32;
@@ -1232,20 +1232,26 @@ static int front_schur_solve(satba_problem* p, bool automatic, double lam, doubl
         g.arrive = p->d_arrive; g.arr_M = p->M; g.np = p->NP; g.arr_epoch = g.epoch; g.si = p->d_scale_inv; g.rhs = rhs;
         hipLaunchKernelGGL(k_chol_tiles, dim3(std::min(chol_tiles_grid(n, 1), wgs)), dim3(1024), c3_lds_bytes(), p->chol_stream, g, p->gate);
         hipLaunchKernelGGL(k_trsv_back_mw, dim3((n + CH_SB - 1) / CH_SB), dim3(512), 0, p->chol_stream, S, p->d_dinv, n, p->d_dch,
-                           p->d_fail + 1 + CH_TRSV_FLAGS, p->gate);
+                           p->d_fail + 1 + CH_TRSV_FLAGS, p->gate, p->d_arrive + (size_t)SCHUR_ARRIVE_STRIDE * (p->M + 1), g.epoch);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(p->ev_join, p->chol_stream));
         p->arrive_epoch = g.epoch;
     }
+    const int epoch = p->arrive_epoch;
     const int rc = automatic ? satba_schur_auto(p, Delta, lam_floor) : satba_schur(p, lam);
     p->arrive_epoch = 0;
-    HIP_TRY(hipStreamWaitEvent(p->stream, p->ev_join, 0));  // (also after a failed queueing: the other stream's work is bounded by its time-out)
-    TRY(rc);
+    if (rc) {
+        HIP_TRY(hipStreamWaitEvent(p->stream, p->ev_join, 0));  // (the other stream's work is bounded by its time-out)
+        return rc;
+    }
+    // k_unscale waits for the word the backward substitution posts on the other stream; the event only orders what follows
     const int nu = std::max(p->n_c, (int)p->hdr);
     hipLaunchKernelGGL(k_unscale, dim3((nu + 255) / 256), dim3(256), 0, p->stream, p->n_c, p->d_scale_inv, p->d_dch, p->d_dc, (int)p->hdr,
-                       p->d_xb, p->d_fail, p->lead, p->d_keep, SATBA_HDR_KEEP, SATBA_KEEP_LEN, p->gate);
+                       p->d_xb, p->d_fail, p->lead, p->d_keep, SATBA_HDR_KEEP, SATBA_KEEP_LEN, p->gate,
+                       p->d_arrive + (size_t)SCHUR_ARRIVE_STRIDE * (p->M + 1), epoch);
     HIP_TRY(hipGetLastError());
     TRY(launch_backsub_kernel(p));
+    HIP_TRY(hipStreamWaitEvent(p->stream, p->ev_join, 0));
     p->have_step = true;
     return 0;
 }

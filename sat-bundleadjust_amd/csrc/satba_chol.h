@@ -401,8 +401,9 @@ __global__ __launch_bounds__(1024) void k_trsv_back(const double* __restrict__ L
 // block.  L^T is read from the strict upper triangle (written by k_chol_tiles): consecutive columns are consecutive addresses.
 // flag: one int per superblock, zero on entry.  All workgroups are resident (at most 8 of them).
 constexpr int CH_SB = 128;
+// done (or null): = done_epoch when z is complete -- a kernel on another stream may spin on it instead of waiting for an event (k_unscale)
 __global__ __launch_bounds__(512) void k_trsv_back_mw(const double* __restrict__ L, const double* __restrict__ dinv, int n, double* __restrict__ b,
-                                                      int* __restrict__ flag, const int* gate) {
+                                                      int* __restrict__ flag, const int* gate, int* __restrict__ done = nullptr, int done_epoch = 0) {
     SATBA_GATE(gate);
     __shared__ double ys[CH_SB], zs[CH_SB], part[4][CH_SB];
     __shared__ double Dk[4][CH_NB][CH_NB + 1];  // Dk[blk][r][c] = (D_blk^-1)[r][c] of my four diagonal blocks
@@ -477,7 +478,10 @@ __global__ __launch_bounds__(512) void k_trsv_back_mw(const double* __restrict__
     if (tid < CH_SB && k0 + tid < n) __hip_atomic_store(b + k0 + tid, ys[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __builtin_amdgcn_s_waitcnt(0);
     __syncthreads();
-    if (tid == 0) __hip_atomic_store(flag + k, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) {
+        __hip_atomic_store(flag + k, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (k == 0 && done) __hip_atomic_store(done, done_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (superblock 0 is the last one)
+    }
 }
 
 // L^T z = y for n <= 64, one wave, straight from the factor's lower triangle (no mirror, no block inverses): lane c holds column c

@@ -1170,15 +1170,28 @@ __global__ __launch_bounds__(256) void k_scale_system(int n_c, const double* __r
 // dc = dc_h / scale_inv (unscaled camera step for the back-substitution).  The same launch prepares the header of the
 // solve phase (nothing touches it between here and k_backsub): zero, Cholesky status in slot 4, the scalars
 // kept from the earlier phases of this iteration in slots SATBA_HDR_KEEP.. (rank 0 only: headers are summed over ranks)
+// done (or null): the dense solve runs on ANOTHER stream (front_schur_solve, beside the pair kernel) and posts done_epoch there when
+// dc_h is complete (k_trsv_back_mw) -- every workgroup waits for the word instead of the stream for an event (13 us from the end of
+// the substitution to the start of this kernel, measured), and reads what that stream wrote with agent-scope loads
 __global__ void k_unscale(int n_c, const double* __restrict__ scale_inv, const double* __restrict__ dch, double* __restrict__ dc,
                           int hdr_len, double* __restrict__ hdr, const int* __restrict__ fail_flag, double lead,
-                          const double* __restrict__ keep, int keep_at, int keep_len, const int* gate) {
+                          const double* __restrict__ keep, int keep_at, int keep_len, const int* gate, const int* __restrict__ done = nullptr,
+                          int done_epoch = 0) {
     SATBA_GATE(gate);
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n_c) dc[i] = dch[i] / scale_inv[i];
+    int timed_out = 0;
+    if (done) {
+        int spins = 0;
+        while ((int)(__hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - done_epoch) < 0) {
+            __builtin_amdgcn_s_sleep(8);
+            if (++spins > (1 << 22)) { timed_out = 2; break; }  // (~1 s: the other stream's kernels bound their own waits)
+        }
+    }
+    if (i < n_c) dc[i] = (done ? __hip_atomic_load(dch + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : dch[i]) / scale_inv[i];
     if (i < hdr_len) {
         double v = 0.0;
-        if (i == 4) v = lead * (double)*fail_flag;  // (0: factorised; bit 0 not positive definite, bit 1 a wait timed out)
+        // (0: factorised; bit 0 not positive definite, bit 1 a wait timed out)
+        if (i == 4) v = lead * (double)((done ? __hip_atomic_load(fail_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *fail_flag) | timed_out);
         if (i >= keep_at && i < keep_at + keep_len) v = lead * keep[i - keep_at];
         hdr[i] = v;
     }
