@@ -143,6 +143,8 @@ struct satba_problem {
     int* d_fail = nullptr;
     double* d_dinv = nullptr;  // inverted 32 x 32 diagonal blocks of the factor (backward substitution)
     CholWork chol;             // scratch of the tile factorisation (satba_chol3.h)
+    double schur_lam = 0.0;    // damping of the Schur phase being queued (k_schur_finish): value, or where k_vinv left it on the device
+    const double* schur_lam_dev = nullptr;
     // the factorisation beside the pair kernel (front_schur_solve): its stream, fork / join events, the producers' counters
     hipStream_t chol_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -435,10 +437,19 @@ static int launch_schur(satba_problem* p, const ObsArgs& a, double* S, double* r
     s.diag_xcd = (dchunks % 8 == 0 && !getenv("SATBA_NO_DIAG_XCD")) ? 1 : 0;
     hipLaunchKernelGGL((k_schur_diag<MODEL, NP>), dim3(p->M, dchunks), dim3(LINC_THREADS), 0, p->stream, a, cm, s, p->d_part3);
     const int total = p->M * cam_acc_len(NP);
+    const int nb_diag = (int)((std::max<long long>(8ll * total, p->hdr) + 255) / 256);
+    // end of the phase: diagonal blocks, right-hand side, header (and the pairs' chunk partials, red_chunks > 1) in one launch
+    auto finish = [&](int red_chunks) {
+        const long long outs = red_chunks > 1 ? n_pairs * NP * NP : 0;
+        hipLaunchKernelGGL(k_schur_finish, dim3((unsigned)(nb_diag + (outs + 255) / 256)), dim3(256), 0, p->stream, p->M, NP, p->n_c, dchunks, p->d_part3,
+                           p->schur_lam, p->schur_lam_dev, p->lead, p->d_gc, p->d_scale_inv, S, rhs, p->d_xb, (int)p->hdr, nb_diag, red_chunks,
+                           p->L.pair_ij, p->d_pair_part, p->gate);
+    };
     if (p->arrive_epoch) {  // the factorisation waits beside this stream: diagonal blocks and right-hand side first, the pair kernel counts its items in
-        hipLaunchKernelGGL(k_schur_diag_finish, dim3((8 * total + 255) / 256), dim3(256), 0, p->stream, p->M, NP, p->n_c, dchunks, p->d_part3, S, rhs, p->gate);
+        finish(1);
         s.arrive = p->d_arrive; s.arrive_epoch = p->arrive_epoch;
     }
+    int red_chunks = 1;
     if (n_pairs > 0 && p->L.E > 0) {
         const bool merged = a.unit && p->d_item_desc_merged;  // one item per pair: straight into S, no partials
         if (merged) { s.desc = p->d_item_desc_merged; s.items = p->d_items_merged; s.n_chunks = 1; }
@@ -446,14 +457,9 @@ static int launch_schur(satba_problem* p, const ObsArgs& a, double* S, double* r
         if (a.unit) hipLaunchKernelGGL((k_schur_pairs<MODEL, NP, true>), igrid, dim3(256), 0, p->stream, a, s, S);
         else hipLaunchKernelGGL((k_schur_pairs<MODEL, NP, false>), igrid, dim3(256), 0, p->stream, a, s, S);
         HIP_TRY(hipGetLastError());
-        if (p->L.C > 1 && !merged) {
-            const long long outs = n_pairs * NP * NP;
-            hipLaunchKernelGGL(k_schur_pairs_reduce, dim3((unsigned)((outs + 255) / 256)), dim3(256), 0, p->stream, p->M, NP, p->n_c, p->L.C,
-                               p->L.pair_ij, p->d_pair_part, S, p->gate, 0ll, n_pairs);
-        }
+        if (p->L.C > 1 && !merged) red_chunks = p->L.C;
     }
-    if (!p->arrive_epoch)
-        hipLaunchKernelGGL(k_schur_diag_finish, dim3((8 * total + 255) / 256), dim3(256), 0, p->stream, p->M, NP, p->n_c, dchunks, p->d_part3, S, rhs, p->gate);
+    if (!p->arrive_epoch) finish(red_chunks);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -1134,6 +1140,14 @@ int satba_prepare(satba_problem* p, int32_t first) {
     HIP_TRY(hipSetDevice(p->device));
     const size_t nU = (size_t)p->M * p->NP * p->NP;
     if (p->hdr > 1024) return fail(SATBA_E_ARG, "header too long");
+    if (p->prep_fused && p->n_c <= 1024) {  // the point entries are done (k_linearize): stash and camera entries in one launch
+        hipLaunchKernelGGL(k_prepare_cams, dim3(1), dim3(1024), 0, p->stream, (int)nU, p->n_c, p->NP, p->world, SATBA_HDR_FIXED, (int)p->hdr, first, p->lead,
+                           p->d_xb, p->d_U, p->d_gc, p->d_keep, p->d_x, p->d_g, p->d_scale_inv, p->d_gh, p->d_q1, p->first_dev, p->gate);
+        HIP_TRY(hipGetLastError());
+        TRY(launch_jvp(p, 1, p->d_q1, p->d_q1, p->d_xb + 2, true));  // d_q1 is free until the subspace phase
+        p->prepared = true;
+        return 0;
+    }
     hipLaunchKernelGGL(k_prepare_stash, dim3(1), dim3(1024), 0, p->stream, (int)nU, p->n_c, p->world, SATBA_HDR_FIXED, (int)p->hdr, p->d_xb, p->d_U,
                        p->d_gc, p->d_keep, p->gate);
     HIP_TRY(hipGetLastError());
@@ -1161,14 +1175,11 @@ static int schur_impl(satba_problem* p, double lam, bool automatic, double Delta
         hipLaunchKernelGGL(k_lambda, dim3(1), dim3(1), 0, p->stream, p->d_xb, Delta, lam_floor, p->d_keep, p->Delta_dev, p->lam_force_dev, p->gate);
     }
     HIP_TRY(hipGetLastError());
-    // The header is cleared by k_schur_init (behind k_vinv, which reads it).  S and rhs are only cleared when no pair kernel will
-    // run: every block of the lower triangle is otherwise written by the kernels below (k_schur_init the diagonal blocks and rhs,
-    // the pair kernels every off-diagonal block).
+    // The header is cleared by k_schur_finish (k_vinv reads it).  S and rhs are only cleared when no pair kernel will run: every block
+    // of the lower triangle is otherwise written by the kernels below (k_schur_finish the diagonal blocks and rhs, the pair kernel or
+    // k_schur_finish every off-diagonal block).
     if (!pairs_run) HIP_TRY(hipMemsetAsync(p->d_xb + p->hdr, 0, sizeof(double) * nS, p->stream));
-    double* S = p->payload();
-    hipLaunchKernelGGL(k_schur_init, dim3((std::max<long long>((long long)p->n_c * p->NP, p->hdr) + 255) / 256), dim3(256), 0, p->stream, p->M, p->NP,
-                       lam, lam_dev, p->lead, p->d_gc, p->d_scale_inv, S, S + (size_t)p->n_c * p->n_c, p->d_xb, (int)p->hdr, p->gate);
-    HIP_TRY(hipGetLastError());
+    p->schur_lam = lam; p->schur_lam_dev = lam_dev;
     TRY(launch_schur_kernel(p));
     return 0;
 }

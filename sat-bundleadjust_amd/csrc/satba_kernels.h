@@ -1219,6 +1219,65 @@ __global__ __launch_bounds__(1024) void k_prepare_stash(int nU, int n_c, int wor
     if ((int)threadIdx.x < hdr_len) xb[threadIdx.x] = 0.0;
 }
 
+// k_prepare_stash and the camera entries of k_prepare_vec in ONE launch of one workgroup: what the prepare phase is when k_linearize
+// has done its point part (ObsArgs::prep_*, the loops of satba_capi.hip) and there are at most 1 024 camera unknowns -- one launch
+// less in front of every iteration (4.4 us of 140 at 10 cameras).  Same values as the two kernels; the two sums are formed by this
+// workgroup alone (fixed order), the point part's sums (header slots SATBA_HDR_PREP_GH / _XS) added last.
+__global__ __launch_bounds__(1024) void k_prepare_cams(int nU, int n_c, int NP, int world, int hdr_fixed, int hdr_len, int first, double lead,
+                                                       double* __restrict__ xb, double* __restrict__ U, double* __restrict__ gc,
+                                                       double* __restrict__ keep, const double* __restrict__ x, double* __restrict__ g,
+                                                       double* __restrict__ scale_inv, double* __restrict__ gh, double* __restrict__ ghs,
+                                                       const int* __restrict__ first_dev, const int* gate) {
+    SATBA_GATE(gate);
+    __shared__ double s_k[3], s_red[3][16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const double* payload = xb + hdr_len;
+    for (int i = tid; i < nU + n_c; i += 1024) {
+        if (i < nU) U[i] = payload[i];
+        else gc[i - nU] = payload[i];
+    }
+    if (tid == 0) {
+        double m = 0.0;
+        for (int r = 0; r < world; ++r) m = fmax(m, xb[hdr_fixed + r]);
+        keep[0] = xb[0];
+        keep[1] = m;
+        s_k[0] = xb[SATBA_HDR_PREP_GH]; s_k[1] = xb[SATBA_HDR_PREP_XS]; s_k[2] = xb[SATBA_HDR_FX];
+        keep[2] = s_k[0]; keep[4] = s_k[1];  // (replaced by the totals in the Schur phase)
+        keep[SATBA_K_FX] = s_k[2];
+    }
+    __syncthreads();
+    if (tid < hdr_len) xb[tid] = 0.0;
+    if (s_k[2] != 0.0) return;  // the fixed-point camera sums overflowed: the caller repeats the linearisation (k_prepare_vec)
+    if (first_dev) first = *first_dev;
+    double s_gh = 0.0, s_xs = 0.0, m_gc = 0.0;
+    for (int i = tid; i < n_c; i += 1024) {
+        const int cam = i / NP, k = i % NP;
+        const double diag = payload[(size_t)cam * NP * NP + k * NP + k], gi = payload[nU + i];
+        g[i] = gi;
+        m_gc = fmax(m_gc, fabs(gi));
+        double si = sqrt(diag);
+        if (first) si = (si == 0.0) ? 1.0 : si;
+        else si = fmax(si, scale_inv[i]);
+        scale_inv[i] = si;
+        const double h = gi / si;
+        gh[i] = h;
+        ghs[i] = h / si;
+        s_gh += lead * h * h;
+        const double xs = x[i] * si;
+        s_xs += lead * xs * xs;
+    }
+    s_gh = wave_sum(s_gh); s_xs = wave_sum(s_xs); m_gc = wave_max(m_gc);
+    if (lane == 0) { s_red[0][wave] = s_gh; s_red[1][wave] = s_xs; s_red[2][wave] = m_gc; }
+    __syncthreads();  // (also: the header is cleared)
+    if (tid == 0) {
+        double a = 0.0, b = 0.0, m = 0.0;
+        for (int w = 0; w < 16; ++w) { a += s_red[0][w]; b += s_red[1][w]; m = fmax(m, s_red[2][w]); }
+        xb[1] = a + s_k[0];
+        xb[3] = b + s_k[1];
+        xb[4] = lead * m;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ K5 back-substitution
 // t_p = sum_obs Jp^T (Jc dc[cam]) per point in the lane's registers, then the point part of the Gauss-Newton step in scaled
 // variables, gn_h = scale_inv_p * Vinv (g_p - t), and the Gram matrix of (g_h, gn_h): hdr[1..3] = a, b, c.  The camera part

@@ -7,7 +7,7 @@
 // (satba_layout.h; a coalesced 12-byte stream: point, the ELL positions of its two observations), gathers the packed
 // 128-byte point record (X, Vinv) of every hit, evaluates both Jacobians -- both cameras are wave-uniform, their constants
 // sit in scalar registers -- and accumulates the NP x NP block in registers; one wave reduce-scatter per item, the chunk
-// partials are added by k_schur_pairs_reduce.  The diagonal blocks (including the full J_c^T J_c) and the right-hand side
+// partials are added by k_schur_finish.  The diagonal blocks (including the full J_c^T J_c) and the right-hand side
 // come from a camera-major pass (k_schur_diag) that also accumulates in registers.
 // History (round 1): global float64 atomics 72.5 ms, LDS column panels 6.2 ms, visibility-bitmap intersection 1.8-3.0 ms,
 // static pair lists 0.90 ms, chunked dispatch + 128-byte records 0.59 ms at 200 x 1M x 10M.
@@ -121,32 +121,6 @@ __global__ __launch_bounds__(VINV_THREADS) void k_vinv(int N, double lam, const 
             if (q < 6 && r < n_here) out[g] = v;  // the two pad pieces of a record are never read
         }
     }
-}
-
-// Diagonal blocks of S <- (lead) * lam Dc^2 on the diagonal and zero elsewhere, rhs <- (lead) * g_c; S column-major n_c x n_c.
-// The J_c^T J_c blocks are added by k_schur_diag_finish.  Every block of the lower triangle is written by a kernel of the Schur
-// phase (the off-diagonal ones by k_schur_pairs / k_schur_pairs_reduce, also for pairs without a common point), so S is not
-// cleared first (an 8 MB fill per iteration at 200 cameras x 5); the strict upper triangle is never read.
-// lam_dev (optional): the damping is read from device memory (keep[5], written by k_vinv) instead of the argument.
-// The same launch clears the exchange header (hdr_len doubles at xb), which the phases after this one accumulate into.
-__global__ void k_schur_init(int M, int NP, double lam, const double* __restrict__ lam_dev, double lead,
-                             const double* __restrict__ gc, const double* __restrict__ scale_inv,
-                             double* __restrict__ S, double* __restrict__ rhs, double* __restrict__ xb, int hdr_len, const int* gate) {
-    SATBA_GATE(gate);
-    if (lam_dev) lam = *lam_dev;
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx < hdr_len) xb[idx] = 0.0;
-    const int n_c = M * NP;
-    if (idx >= n_c * NP) return;
-    const int col = idx / NP, q = idx % NP;  // column col = cam * NP + r of S, row cam * NP + q
-    const int cam = col / NP, r = col % NP;
-    double v = 0.0;
-    if (q == r) {
-        const double s = scale_inv[col];
-        v = lead * lam * s * s;
-        rhs[col] = lead * gc[col];
-    }
-    S[(size_t)(cam * NP + q) + (size_t)col * n_c] = v;
 }
 
 // one work item of k_schur_pairs, flattened: without it a wave starts with three dependent loads (item -> pair_ij, pair_ofs)
@@ -576,25 +550,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((MODEL == A
 }
 
 
-// several point-range chunks: S block of each pair = sum of its chunk partials (chunk order: repeatable)
-__global__ __launch_bounds__(256) void k_schur_pairs_reduce(int M, int NP, int n_c, int n_chunks, const int2* __restrict__ pair_ij,
-                                                            const double* __restrict__ part, double* __restrict__ S, const int* gate,
-                                                            long long pair_lo, long long pair_cnt) {
-    // pair_lo, pair_cnt: the pairs of a range of camera rows (their indices are contiguous)
-    SATBA_GATE(gate);
-    const long long n_pairs = (long long)M * (M - 1) / 2;
-    const int NB2 = NP * NP;
-    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= pair_cnt * NB2) return;
-    const long long pair = pair_lo + idx / NB2;
-    const int e = (int)(idx % NB2);
-    double t = 0.0;
-    for (int ch = 0; ch < n_chunks; ++ch) t += part[((size_t)ch * n_pairs + pair) * NB2 + e];
-    const int2 ij = pair_ij[pair];
-    const int r = e / NP, q = e % NP;
-    S[(size_t)(ij.y * NP + q) + (size_t)(ij.x * NP + r) * n_c] = t;
-}
-
 // Diagonal blocks and right-hand side: camera-major pass, registers only.
 //   S_ii += sum_p (Jc^T Jc - W_ip Vinv W_ip^T),   rhs_i -= sum_p W_ip Vinv g_p.   grid (M, chunks); part [M][chunks][CU]
 // The J_c^T J_c term is the U_c block, which the linearize kernel therefore does not have to accumulate.
@@ -815,13 +770,48 @@ __global__ __launch_bounds__(LINC_THREADS) void k_schur_diag(ObsArgs a, CamMajor
     }
 }
 
-// S_ii (lower incl. diagonal, both triangles of the block are written) and rhs_i += chunk partials.  Eight threads per output, each
-// over every eighth chunk, combined in a fixed order (up to 64 chunks: a single thread's dependent loads were 18 us with 32 chunks)
-__global__ void k_schur_diag_finish(int M, int NP, int n_c, int n_chunks, const double* __restrict__ part,
-                                    double* __restrict__ S, double* __restrict__ rhs, const int* gate) {
+// End of the Schur phase, one launch (three in rounds 1-3: k_schur_init in front of the phase, k_schur_pairs_reduce and k_schur_diag_finish
+// behind it -- 9 us of a 140 us iteration at 10 cameras):
+//   workgroups < nb_diag   S_ii = (lead) lam Dc^2 on the diagonal + the chunk partials of k_schur_diag (both triangles of the block are
+//                          written), rhs_i = (lead) g_c + partials: eight threads per output, each over every eighth chunk, combined in a
+//                          fixed order (up to 64 chunks: a single thread's dependent loads were 18 us with 32 chunks); the exchange header
+//                          (hdr_len doubles at xb), which the phases after this one accumulate into, is cleared here (k_vinv, in front
+//                          of the phase, still reads it)
+//   workgroups >= nb_diag  (red_chunks > 1: the pair kernel left point-range partials) S block of each pair = sum of its chunk partials,
+//                          chunk order: repeatable
+// Every block of the lower triangle is written by a kernel of the Schur phase (the off-diagonal ones here or by k_schur_pairs, also for
+// pairs without a common point), so S is not cleared first (an 8 MB fill per iteration at 200 cameras x 5); the strict upper triangle is
+// never read.  lam_dev (optional): the damping is read from device memory (keep[5], written by k_vinv) instead of the argument.
+__global__ __launch_bounds__(256) void k_schur_finish(int M, int NP, int n_c, int n_chunks, const double* __restrict__ part, double lam,
+                                                      const double* __restrict__ lam_dev, double lead, const double* __restrict__ gc,
+                                                      const double* __restrict__ scale_inv, double* __restrict__ S, double* __restrict__ rhs,
+                                                      double* __restrict__ xb, int hdr_len, int nb_diag, int red_chunks,
+                                                      const int2* __restrict__ pair_ij, const double* __restrict__ pair_part, const int* gate) {
     SATBA_GATE(gate);
+    if ((int)blockIdx.x >= nb_diag) {
+        const long long n_pairs = (long long)M * (M - 1) / 2;
+        const int NB2 = NP * NP;
+        const long long idx = (long long)(blockIdx.x - nb_diag) * blockDim.x + threadIdx.x;
+        if (idx >= n_pairs * NB2) return;
+        const long long pair = idx / NB2;
+        const int e = (int)(idx % NB2);
+        double t = 0.0;
+        int ch = 0;
+        for (; ch + 4 <= red_chunks; ch += 4) {  // (four loads in flight; the additions stay in chunk order)
+            const double p0 = pair_part[((size_t)ch * n_pairs + pair) * NB2 + e], p1 = pair_part[((size_t)(ch + 1) * n_pairs + pair) * NB2 + e];
+            const double p2 = pair_part[((size_t)(ch + 2) * n_pairs + pair) * NB2 + e], p3 = pair_part[((size_t)(ch + 3) * n_pairs + pair) * NB2 + e];
+            t += p0; t += p1; t += p2; t += p3;
+        }
+        for (; ch < red_chunks; ++ch) t += pair_part[((size_t)ch * n_pairs + pair) * NB2 + e];
+        const int2 ij = pair_ij[pair];
+        const int r = e / NP, q = e % NP;
+        S[(size_t)(ij.y * NP + q) + (size_t)(ij.x * NP + r) * n_c] = t;
+        return;
+    }
+    if (lam_dev) lam = *lam_dev;
     const int CU = cam_acc_len(NP);
     const int gid = blockIdx.x * blockDim.x + threadIdx.x, idx = gid >> 3, sub = gid & 7;
+    if (gid < hdr_len) xb[gid] = 0.0;
     const bool live = idx < M * CU;
     const int cam = live ? idx / CU : 0, k = live ? idx % CU : 0;
     double t = 0.0;
@@ -833,14 +823,20 @@ __global__ void k_schur_diag_finish(int M, int NP, int n_c, int n_chunks, const 
     if (!live || sub != 0) return;
     const int ntri = NP * (NP + 1) / 2;
     if (k >= ntri) {
-        rhs[cam * NP + (k - ntri)] += t;
+        const int col = cam * NP + (k - ntri);
+        rhs[col] = lead * gc[col] + t;
         return;
     }
     int r = 0, rem = k;
     while (rem >= NP - r) { rem -= NP - r; ++r; }
     const int q = r + rem;
-    S[(size_t)(cam * NP + q) + (size_t)(cam * NP + r) * n_c] += t;
-    if (q != r) S[(size_t)(cam * NP + r) + (size_t)(cam * NP + q) * n_c] += t;
+    double v = 0.0;
+    if (q == r) {
+        const double si = scale_inv[cam * NP + r];
+        v = lead * lam * si * si;
+    }
+    S[(size_t)(cam * NP + q) + (size_t)(cam * NP + r) * n_c] = v + t;
+    if (q != r) S[(size_t)(cam * NP + r) + (size_t)(cam * NP + q) * n_c] = v + t;
 }
 
 }  // namespace satba

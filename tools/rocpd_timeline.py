@@ -18,7 +18,7 @@ def main(path, out=sys.stdout):
     rows = c.execute("select s.{n}, d.{s}, d.{e} from {d} d join {y} s on d.kernel_id = s.id order by d.{s}".format(
         n=name_col, s=start, e=end, d=disp, y=sym)).fetchall()
     rows = [(re.sub(r"\(.*", "", n), a, b) for n, a, b in rows]
-    names = ["k_vinv", "k_schur_init", "k_schur_diag<", "k_schur_diag_finish", "k_schur_pairs<", "k_chol_tiles", "k_trsv_back_mw", "k_unscale",
+    names = ["k_vinv", "k_schur_diag<", "k_schur_finish", "k_schur_pairs<", "k_chol_tiles", "k_trsv_back_mw", "k_unscale",
              "k_backsub"]
     phases = []
     for idx, (n, a, b) in enumerate(rows):
