@@ -541,6 +541,48 @@ FULL_SIZE = [("C3", "linear", 2e-5), ("C3", "soft_l1", 2e-6), ("C4", "linear", 2
              ("C5", "linear", 1e-6), ("C5", "soft_l1", 1e-6)]
 
 
+def _beside_vs_sequential(monkeypatch, scene, corr, n_iter, restart_every):
+    """Two handles on the same problem, one with the tile Cholesky beside the pair kernel and one with it behind: LM iterations
+    (bench.py's native step) in lock-step, the point and the loop's scalars compared bit for bit after every one of them."""
+    import bench
+
+    engs = []
+    for beside in ("1", "0"):
+        monkeypatch.setenv("SATBA_CHOL_BESIDE", beside)  # (read at every front)
+        eng = HipEngine(synth.make_params(scene, {"correction_params": corr, "n_cam_fix": 1}))
+        eng.configure("linear", 1.0)
+        eng.snapshot_x(False)
+        engs.append((beside, eng, {"first": True, "accepted": 0, "fail": 0, "cost": None}))
+    for it in range(n_iter):
+        outs = []
+        for beside, eng, st in engs:
+            monkeypatch.setenv("SATBA_CHOL_BESIDE", beside)
+            if it and it % restart_every == 0:
+                eng.snapshot_x(True)
+                st["first"] = True
+            bench.lm_step_native(eng, st)
+            outs.append((st["cost"], st["Delta"], st["accepted"], eng.get_x()))
+        assert outs[0][:3] == outs[1][:3], (it, outs[0][:3], outs[1][:3])
+        assert np.array_equal(outs[0][3], outs[1][3]), it
+    assert int(engs[0][1].info()["chol_beside"]) == 1 and int(engs[1][1].info()["chol_beside"]) == 0
+    for _, eng, _ in engs:
+        eng.close()
+
+
+@pytest.mark.parametrize("n_cam,corr", [(200, ["R", "T"]), (180, ["R"]), (131, ["R", "T"])])
+def test_factorisation_beside_the_pair_kernel_many_iterations(gpu, monkeypatch, n_cam, corr):
+    """A wrong hand-over between the two kernels is a race and shows once in many launches: 400 iterations at 16 / 9 / 11 tile
+    columns (the last one partial), every one compared with the sequential front."""
+    scene = synth.make_scene("affine", n_cam, 20000, 8, seed=5)
+    _beside_vs_sequential(monkeypatch, scene, corr, 400, 5)
+
+
+def test_factorisation_beside_the_pair_kernel_at_the_headline_size(gpu, monkeypatch):
+    """... and at 200 x 1 M x 10 M, where the pair kernel runs for 0.45 ms beside it (40 iterations)."""
+    model, corr, n_cam, n_pts, opp = synth.CONFIGS["C4"]
+    _beside_vs_sequential(monkeypatch, _full_size_scene("C4", 2e-5), corr, 40, 4)
+
+
 @pytest.mark.parametrize("shape,loss,sigma_theta", FULL_SIZE, ids=["-".join(map(str, c[:2])) for c in FULL_SIZE])
 def test_full_size_properties(gpu, shape, loss, sigma_theta):
     """

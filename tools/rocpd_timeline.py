@@ -31,6 +31,9 @@ def main(path, out=sys.stdout):
                     ph[key] = ((a2 - a) / 1e3, (b2 - a) / 1e3)
         if all(k in ph for k in names):
             phases.append(ph)
+    if not phases:
+        out.write("no Schur / solve phase with the tile Cholesky in this trace\n")
+        return
     out.write("{} phases\n{:<22s} {:>9s} {:>9s} {:>9s}\n".format(len(phases), "kernel", "start", "end", "length"))
     for k in names:
         s = statistics.median(p[k][0] for p in phases)
