@@ -148,7 +148,8 @@ struct satba_problem {
     // the factorisation beside the pair kernel (front_schur_solve): its stream, fork / join events, the producers' counters
     hipStream_t chol_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    int* d_arrive = nullptr;   // (M + 1) x SCHUR_ARRIVE_STRIDE ints, zero between launches
+    int* d_arrive = nullptr;   // (M + 2) x SCHUR_ARRIVE_STRIDE ints, zero between launches
+    int* d_pair_cnt = nullptr; // weighted / robust runs: chunk items finished per camera pair (SchurArgs::pair_cnt), zero between launches
     long long* d_ts = nullptr; // (tools, -DC3_STAMPS: time stamps of the last factorisation beside the pair kernel, printed when the handle goes)
     int arrive_epoch = 0;      // != 0 while a front with the factorisation beside it is being queued (launch_schur)
     bool beside_last = false;  // the last front ran that way
@@ -447,7 +448,7 @@ static int launch_schur(satba_problem* p, const ObsArgs& a, double* S, double* r
     };
     if (p->arrive_epoch) {  // the factorisation waits beside this stream: diagonal blocks and right-hand side first, the pair kernel counts its items in
         finish(1);
-        s.arrive = p->d_arrive; s.arrive_epoch = p->arrive_epoch;
+        s.arrive = p->d_arrive; s.arrive_epoch = p->arrive_epoch; s.pair_cnt = p->d_pair_cnt; s.fail = p->d_fail;
     }
     int red_chunks = 1;
     if (n_pairs > 0 && p->L.E > 0) {
@@ -458,6 +459,7 @@ static int launch_schur(satba_problem* p, const ObsArgs& a, double* S, double* r
         else hipLaunchKernelGGL((k_schur_pairs<MODEL, NP, false>), igrid, dim3(256), 0, p->stream, a, s, S);
         HIP_TRY(hipGetLastError());
         if (p->L.C > 1 && !merged) red_chunks = p->L.C;
+        if (p->arrive_epoch && (a.unit ? red_chunks > 1 : false)) return fail(SATBA_E_STATE, "factorisation beside a unit-weight pair kernel with chunk partials");
     }
     if (!p->arrive_epoch) finish(red_chunks);
     HIP_TRY(hipGetLastError());
@@ -1192,8 +1194,14 @@ static int schur_impl(satba_problem* p, double lam, bool automatic, double Delta
 static bool chol_beside_ok(const satba_problem* p) {
     const char* env = getenv("SATBA_CHOL_BESIDE");  // (read at every front: the tests switch it inside one process)
     if (env && atoi(env) == 0) return false;
-    return p->world == 1 && p->loss == 0 && p->unit_weights && (p->d_item_desc_merged || p->L.C == 1) && p->L.n_pairs > 0 && p->L.E > 0 && p->n_c == p->M * p->NP &&
-           p->n_c > 128 && p->n_c <= 1024 && p->N > 0 && !p->beside_off;
+    // unit weights: one item per pair (the table exists from 8 192 pairs on, or SATBA_SCHUR_MERGE); weighted / robust: the chunk items, the
+    // last one of a pair adds the partials (SchurArgs::pair_cnt) -- affine and perspective cameras (the RPC kernel keeps its reduce pass)
+    const bool unit = p->loss == 0 && p->unit_weights;
+    const char* mg = getenv("SATBA_SCHUR_MERGE");
+    const bool enough = p->L.n_pairs >= 8192 || (mg && atoi(mg) != 0);
+    const bool items_ok = unit ? (p->d_item_desc_merged || p->L.C == 1) : (enough && p->model != RPC);
+    return p->world == 1 && items_ok && p->L.n_pairs > 0 && p->L.E > 0 && p->n_c == p->M * p->NP && p->n_c > 128 && p->n_c <= 1024 && p->N > 0 &&
+           !p->beside_off;
 }
 static int front_schur_solve(satba_problem* p, bool automatic, double lam, double Delta, double lam_floor);
 // header slot 4 of the solve phase = lead x status word of the factorisation: bit 1 = a wait timed out.  Beside the pair kernel that
@@ -1204,6 +1212,7 @@ static bool beside_timed_out(satba_problem* p, const double* h) {
     p->beside_off = true;
     (void)hipStreamSynchronize(p->chol_stream);
     (void)hipMemsetAsync(p->d_arrive, 0, sizeof(int) * (size_t)(p->M + 2) * SCHUR_ARRIVE_STRIDE, p->stream);
+    (void)hipMemsetAsync(p->d_pair_cnt, 0, sizeof(int) * (size_t)std::max<long long>(p->L.n_pairs, 1), p->stream);
     return true;
 }
 static int front_schur_solve(satba_problem* p, bool automatic, double lam, double Delta, double lam_floor) {
@@ -1215,11 +1224,19 @@ static int front_schur_solve(satba_problem* p, bool automatic, double lam, doubl
     }
     HIP_TRY(hipSetDevice(p->device));
     if (!p->chol_stream) {
-        HIP_TRY(hipStreamCreateWithFlags(&p->chol_stream, hipStreamNonBlocking));
+        // A priority of its own: streams of one priority share a small pool of hardware queues, and two streams on ONE queue run in
+        // submission order -- the factorisation, queued first, would wait for a pair kernel stuck behind it until its waits time out
+        // (seen once in a long test process, where the pool had been handed round many times).
+        int least = 0, greatest = 0, mine = 0;
+        HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        HIP_TRY(hipStreamGetPriority(p->stream, &mine));
+        HIP_TRY(hipStreamCreateWithPriority(&p->chol_stream, hipStreamNonBlocking, mine != greatest ? greatest : least));
         HIP_TRY(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming));
         TRY(dev_alloc(p, &p->d_arrive, (size_t)(p->M + 2) * SCHUR_ARRIVE_STRIDE));  // (+ k_schur_pairs' start word, + the solve's done word)
         HIP_TRY(hipMemsetAsync(p->d_arrive, 0, sizeof(int) * (size_t)(p->M + 2) * SCHUR_ARRIVE_STRIDE, p->stream));
+        TRY(dev_alloc(p, &p->d_pair_cnt, (size_t)std::max<long long>(p->L.n_pairs, 1)));
+        HIP_TRY(hipMemsetAsync(p->d_pair_cnt, 0, sizeof(int) * (size_t)std::max<long long>(p->L.n_pairs, 1), p->stream));
     }
     const char* env_wgs = getenv("SATBA_CHOL_BESIDE_WGS");
     const int wgs = (env_wgs && atoi(env_wgs) > 0) ? atoi(env_wgs) : 32;

@@ -146,6 +146,12 @@ struct SchurArgs {
     // (diagonal blocks, right-hand side) are complete.  Words SCHUR_ARRIVE_STRIDE ints apart (one per 128-byte line); null: off
     int* arrive = nullptr;
     int arrive_epoch = 0;
+    // ... with point-range chunks (weighted / robust runs): every (pair, chunk) item publishes its partial block and counts itself in
+    // pair_cnt[pair] (n_pairs ints, zero between launches); the item of the LAST chunk -- the last of its pair in dispatch order: every
+    // other one has been started before it -- waits for that count, adds the partials in chunk order (k_schur_finish's arithmetic),
+    // publishes the block and counts the pair in `arrive`.  fail: the factorisation's status word (bit 1: a wait timed out)
+    int* pair_cnt = nullptr;
+    int* fail = nullptr;
 };
 constexpr int SCHUR_ARRIVE_STRIDE = 32;
 
@@ -197,6 +203,36 @@ __global__ void k_schur_item_desc(long long n_items, const int2* __restrict__ it
     desc[e] = d;
 }
 
+// End of a (pair, chunk) item beside the factorisation (SchurArgs::pair_cnt).
+// mine: the item's entry of its partial block; stride: doubles between the chunks' partial blocks
+__device__ __forceinline__ void schur_pair_publish(double* mine, size_t stride, int n_chunks, int chunk, int* cnt, int* arrive_row, int* fail,
+                                                double* s_out, double total, bool writer) {
+    const int lane = threadIdx.x & 63;
+    if (writer) __hip_atomic_store(mine, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (chunk + 1 < n_chunks) {
+        if (lane == 0) __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    if (lane == 0) {  // the last chunk's item: every other item of the pair has been started before this one
+        int spins = 0;
+        while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < n_chunks - 1) {
+            __builtin_amdgcn_s_sleep(4);
+            if (++spins > (1 << 22)) { atomicOr(fail, 2); break; }
+        }
+        __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (writer) {
+        const double* first = mine - (size_t)chunk * stride;
+        double t = 0.0;
+        for (int ch = 0; ch < n_chunks; ++ch) t += __hip_atomic_load(first + (size_t)ch * stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(s_out, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) __hip_atomic_fetch_add(arrive_row, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // 1-D grid, 4 waves per workgroup, one (pair, chunk) item each, taken from an item table in DISPATCH order that is built
 // for the chip's topology (satba_capi.hip: schur_item_table): workgroup b runs on XCD b % 8 (observed placement; only speed
 // depends on it), and every XCD works through the pairs (i, j) of ONE camera i and ONE point-range chunk at a time.  All those
@@ -219,8 +255,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((MODEL == A
     const long long n_pairs = (long long)a.M * (a.M - 1) / 2;
     const SchurItem* dp = s.desc + (blockIdx.x * 4u + (unsigned)wave);
     const int i = __builtin_amdgcn_readfirstlane(dp->i);  // wave-uniform by construction: lets the camera constants use scalar loads
-    if (UNITW && s.arrive && blockIdx.x == 0 && threadIdx.x == 0)  // (the weighted / robust kernel leaves partial blocks: never beside the factorisation)
-        __hip_atomic_store(s.arrive + (size_t)SCHUR_ARRIVE_STRIDE * a.M, s.arrive_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (i < 0) return;
     const int j = __builtin_amdgcn_readfirstlane(dp->j);
     const int chunk = __builtin_amdgcn_readfirstlane(dp->chunk);
@@ -537,15 +571,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((MODEL == A
     const double total = cam_mask * wave_reduce_scatter<NPAD>(flat, lane, 32);
     const int e = rs_index<NPAD>(lane);
     const bool writer = (lane & (64 / NPAD - 1)) == 0 && e < NB2;  // one lane per total (NPAD = 64: every lane)
-    if (writer) {
-        const int r = e / NP, q = e % NP;
-        if (s.n_chunks > 1) s.pair_part[((size_t)chunk * n_pairs + pair) * NB2 + e] = total;
-        else if (!UNITW || !s.arrive) S[(size_t)(j * NP + q) + (size_t)(i * NP + r) * a.n_c] = total;  // S[(j,q), (i,r)] = (W_i Vinv W_j^T)[r][q]
-        else __hip_atomic_store(S + (size_t)(j * NP + q) + (size_t)(i * NP + r) * a.n_c, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // (the epilogue's address arithmetic starts here: without the fences it was hoisted above the hit loop -- 191 registers instead of
+    // 152 in the weighted kernel, two waves per SIMD)
+    int e_ = e, i_ = i, j_ = j, chunk_ = chunk;
+    long long pair_ = pair;
+    asm volatile("" : "+v"(e_), "+s"(i_), "+s"(j_), "+s"(chunk_), "+s"(pair_));
+    // the first item tells the factorisation that this kernel runs: everything in front of it on the stream (diagonal blocks, right-hand side) is complete
+    if (s.arrive && blockIdx.x == 0 && threadIdx.x == 0)
+        __hip_atomic_store(s.arrive + (size_t)SCHUR_ARRIVE_STRIDE * a.M, s.arrive_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    double* const s_out = S + (size_t)(j_ * NP + e_ % NP) + (size_t)(i_ * NP + e_ / NP) * a.n_c;  // S[(j,q), (i,r)] = (W_i Vinv W_j^T)[r][q], e = r NP + q
+    if constexpr (!UNITW) {
+        if (s.arrive && s.n_chunks > 1) {  // beside the factorisation, chunk partials (SchurArgs::pair_cnt)
+            schur_pair_publish(s.pair_part + ((size_t)chunk_ * n_pairs + pair_) * NB2 + e_, (size_t)n_pairs * NB2, s.n_chunks, chunk_, s.pair_cnt + pair_,
+                               s.arrive + (size_t)SCHUR_ARRIVE_STRIDE * i_, s.fail, s_out, total, writer);
+            return;
+        }
     }
-    if (UNITW && s.arrive && s.n_chunks == 1) {
+    if (writer) {
+        if (s.n_chunks > 1) s.pair_part[((size_t)chunk_ * n_pairs + pair_) * NB2 + e_] = total;
+        else if (!s.arrive) *s_out = total;
+        else __hip_atomic_store(s_out, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (s.arrive && s.n_chunks == 1) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0) __hip_atomic_fetch_add(s.arrive + (size_t)SCHUR_ARRIVE_STRIDE * i, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0) __hip_atomic_fetch_add(s.arrive + (size_t)SCHUR_ARRIVE_STRIDE * i_, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 

@@ -201,13 +201,14 @@ def test_device_resident_solve_matches_host_loop(gpu, monkeypatch, name, loss, t
 @pytest.mark.parametrize("model,M,N,opp,corr", [("affine", 40, 4000, 6, ["R", "T"]), ("affine", 70, 5000, 5, ["R"]),
                                                 ("affine", 200, 20000, 8, ["R", "T"]), ("perspective", 30, 3000, 5, ["R", "T"]),
                                                 ("affine", 27, 2000, 6, ["R", "T"])])
-@pytest.mark.parametrize("loop", ["host", "device"])
-def test_factorisation_beside_the_pair_kernel_is_the_sequential_solve(gpu, monkeypatch, model, M, N, opp, corr, loop):
+@pytest.mark.parametrize("loop,loss", [("host", "linear"), ("device", "linear"), ("host", "soft_l1")])
+def test_factorisation_beside_the_pair_kernel_is_the_sequential_solve(gpu, monkeypatch, model, M, N, opp, corr, loop, loss):
     """
     One rank, unit weights, more than two tile columns: the tile Cholesky runs on its own stream beside k_schur_pairs and takes every
     tile when the producers of its columns have counted themselves in (front_schur_solve, C3Args::arrive).  Same arithmetic in the
     same order as scale -> factorise -> substitute one after the other (SATBA_CHOL_BESIDE=0): identical to the last bit, for the
-    loop with the decisions on the host and for the device-resident one.
+    loop with the decisions on the host and for the device-resident one.  soft_l1: the pair kernel works on point-range chunks, the
+    last chunk's item of a pair adds the partials (SchurArgs::pair_cnt) in the order of the reduce pass it replaces.
     """
     scene = synth.make_scene(model, M, N, opp, seed=11)
     if loop == "host":
@@ -217,7 +218,7 @@ def test_factorisation_beside_the_pair_kernel_is_the_sequential_solve(gpu, monke
     for beside in ("1", "0", "1"):
         monkeypatch.setenv("SATBA_CHOL_BESIDE", beside)
         eng = HipEngine(synth.make_params(scene, {"correction_params": corr, "n_cam_fix": 1}))
-        st = eng.solve_lm(max_nfev=30, loss="linear", ftol=1e-12, xtol=1e-12, gtol=1e-12)
+        st = eng.solve_lm(max_nfev=30, loss=loss, ftol=1e-12, xtol=1e-12, gtol=1e-12)
         outs.append(((st.cost, st.nfev, st.njev, st.iterations, st.status, st.optimality, st.initial_cost), eng.get_x()))
         assert int(eng.info()["chol_beside"]) == int(beside)
         eng.close()
