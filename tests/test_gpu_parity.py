@@ -541,7 +541,7 @@ FULL_SIZE = [("C3", "linear", 2e-5), ("C3", "soft_l1", 2e-6), ("C4", "linear", 2
              ("C5", "linear", 1e-6), ("C5", "soft_l1", 1e-6)]
 
 
-def _beside_vs_sequential(monkeypatch, scene, corr, n_iter, restart_every):
+def _beside_vs_sequential(monkeypatch, scene, corr, n_iter, restart_every, loss="linear"):
     """Two handles on the same problem, one with the tile Cholesky beside the pair kernel and one with it behind: LM iterations
     (bench.py's native step) in lock-step, the point and the loop's scalars compared bit for bit after every one of them."""
     import bench
@@ -550,7 +550,7 @@ def _beside_vs_sequential(monkeypatch, scene, corr, n_iter, restart_every):
     for beside in ("1", "0"):
         monkeypatch.setenv("SATBA_CHOL_BESIDE", beside)  # (read at every front)
         eng = HipEngine(synth.make_params(scene, {"correction_params": corr, "n_cam_fix": 1}))
-        eng.configure("linear", 1.0)
+        eng.configure(loss, 1.0)
         eng.snapshot_x(False)
         engs.append((beside, eng, {"first": True, "accepted": 0, "fail": 0, "cost": None}))
     for it in range(n_iter):
@@ -570,18 +570,21 @@ def _beside_vs_sequential(monkeypatch, scene, corr, n_iter, restart_every):
         eng.close()
 
 
-@pytest.mark.parametrize("n_cam,corr", [(200, ["R", "T"]), (180, ["R"]), (131, ["R", "T"])])
-def test_factorisation_beside_the_pair_kernel_many_iterations(gpu, monkeypatch, n_cam, corr):
+@pytest.mark.parametrize("n_cam,corr,loss", [(200, ["R", "T"], "linear"), (180, ["R"], "linear"), (131, ["R", "T"], "linear"),
+                                             (200, ["R", "T"], "soft_l1"), (150, ["R"], "soft_l1")])
+def test_factorisation_beside_the_pair_kernel_many_iterations(gpu, monkeypatch, n_cam, corr, loss):
     """A wrong hand-over between the two kernels is a race and shows once in many launches: 400 iterations at 16 / 9 / 11 tile
-    columns (the last one partial), every one compared with the sequential front."""
+    columns (the last one partial), every one compared with the sequential front; soft_l1: the pair kernel's chunk items and the
+    partial sums by the last item of a pair."""
     scene = synth.make_scene("affine", n_cam, 20000, 8, seed=5)
-    _beside_vs_sequential(monkeypatch, scene, corr, 400, 5)
+    _beside_vs_sequential(monkeypatch, scene, corr, 400, 5, loss)
 
 
 def test_factorisation_beside_the_pair_kernel_at_the_headline_size(gpu, monkeypatch):
     """... and at 200 x 1 M x 10 M, where the pair kernel runs for 0.45 ms beside it (40 iterations)."""
     model, corr, n_cam, n_pts, opp = synth.CONFIGS["C4"]
     _beside_vs_sequential(monkeypatch, _full_size_scene("C4", 2e-5), corr, 40, 4)
+    _beside_vs_sequential(monkeypatch, _full_size_scene("C4", 2e-5), corr, 20, 4, "soft_l1")
 
 
 @pytest.mark.parametrize("shape,loss,sigma_theta", FULL_SIZE, ids=["-".join(map(str, c[:2])) for c in FULL_SIZE])
