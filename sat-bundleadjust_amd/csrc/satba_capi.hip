@@ -379,7 +379,7 @@ static int raise_lin_limits(satba_problem* p) {
     const size_t t = std::max(table_bytes(p), dir_table_bytes(p));
     TRY(raise_lds_limit(k_jvp<MODEL, NP, 1, CL, RL, true>, t));
     TRY(raise_lds_limit(k_jvp<MODEL, NP, 1, CL, RL, false>, t));
-    TRY(raise_lds_limit(k_jvp<MODEL, NP, 2, CL, RL, false>, t));
+    TRY(raise_lds_limit(k_jvp<MODEL, NP, 2, CL, RL, false>, std::max(t, 2 * dir_table_bytes(p))));
     TRY(raise_lds_limit(k_backsub<MODEL, NP, CL, RL>, t));
     return 0;
 }
@@ -498,7 +498,8 @@ static int launch_jvp(satba_problem* p, int nv, const double* q1, const double* 
         SATBA_DISPATCH(p, hipLaunchKernelGGL((k_jvp<MODEL, NP, 1, CL, RL, false>), dim3(grid), dim3(JVP_THREADS), table_bytes(p), p->stream, a, q1, q2,
                                              p->d_scale_inv, rb, out));
     } else {
-        SATBA_DISPATCH(p, hipLaunchKernelGGL((k_jvp<MODEL, NP, 2, CL, RL, false>), dim3(grid), dim3(JVP_THREADS), table_bytes(p), p->stream, a, q1, q2,
+        const size_t lds = p->model == AFFINE ? std::max(table_bytes(p), 2 * dir_table_bytes(p)) : table_bytes(p);  // affine: two direction tables
+        SATBA_DISPATCH(p, hipLaunchKernelGGL((k_jvp<MODEL, NP, 2, CL, RL, false>), dim3(grid), dim3(JVP_THREADS), lds, p->stream, a, q1, q2,
                                              p->d_scale_inv, rb, out));
     }
     HIP_TRY(hipGetLastError());
