@@ -507,8 +507,14 @@ static int launch_jvp(satba_problem* p, int nv, const double* q1, const double* 
 }
 
 // S z = rhs for the reduced system (S column-major lower, destroyed; b in place)
-static int dense_solve(satba_problem* p, double* S, double* b, bool cleared = false) {
-    cholesky_solve(S, p->n_c, b, p->d_fail, p->d_fail + 1, p->stream, p->chol, p->d_dinv, cleared, p->gate);  // clears d_fail and the flags unless the caller has
+// unscaled (or null): set to whether the step in unscaled variables and the phase's header were written as well (k_unscale's work)
+static int dense_solve(satba_problem* p, double* S, double* b, bool cleared = false, bool* unscaled = nullptr) {
+    TrsvTail tail;
+    tail.dc = p->d_dc; tail.scale_inv = p->d_scale_inv; tail.hdr = p->d_xb; tail.hdr_len = (int)p->hdr; tail.fail = p->d_fail; tail.lead = p->lead;
+    tail.keep = p->d_keep; tail.keep_at = SATBA_HDR_KEEP; tail.keep_len = SATBA_KEEP_LEN;
+    const bool done = cholesky_solve(S, p->n_c, b, p->d_fail, p->d_fail + 1, p->stream, p->chol, p->d_dinv, cleared, p->gate, nullptr,
+                                     unscaled ? &tail : nullptr);  // clears d_fail and the flags unless the caller has
+    if (unscaled) *unscaled = done;
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -1318,11 +1324,14 @@ int satba_solve(satba_problem* p) {
     hipLaunchKernelGGL(k_scale_system, dim3(grid_for((long long)p->n_c * p->n_c, 256, 2048)), dim3(256), 0, p->stream, p->n_c,
                        p->d_scale_inv, S, rhs, p->d_dch, p->d_fail, 1 + CH_MAX_STEPS, p->gate, 0, p->n_c);
     HIP_TRY(hipGetLastError());
-    TRY(dense_solve(p, S, p->d_dch, true));  // the not-SPD flag and the step flags were cleared by the scaling kernel
-    const int nu = std::max(p->n_c, (int)p->hdr);
-    hipLaunchKernelGGL(k_unscale, dim3((nu + 255) / 256), dim3(256), 0, p->stream, p->n_c, p->d_scale_inv, p->d_dch, p->d_dc, (int)p->hdr,
-                       p->d_xb, p->d_fail, p->lead, p->d_keep, SATBA_HDR_KEEP, SATBA_KEEP_LEN, p->gate);
-    HIP_TRY(hipGetLastError());
+    bool unscaled = false;
+    TRY(dense_solve(p, S, p->d_dch, true, &unscaled));  // the not-SPD flag and the step flags were cleared by the scaling kernel
+    if (!unscaled) {
+        const int nu = std::max(p->n_c, (int)p->hdr);
+        hipLaunchKernelGGL(k_unscale, dim3((nu + 255) / 256), dim3(256), 0, p->stream, p->n_c, p->d_scale_inv, p->d_dch, p->d_dc, (int)p->hdr,
+                           p->d_xb, p->d_fail, p->lead, p->d_keep, SATBA_HDR_KEEP, SATBA_KEEP_LEN, p->gate);
+        HIP_TRY(hipGetLastError());
+    }
     TRY(launch_backsub_kernel(p));
     p->have_step = true;
     return 0;

@@ -401,9 +401,23 @@ __global__ __launch_bounds__(1024) void k_trsv_back(const double* __restrict__ L
 // block.  L^T is read from the strict upper triangle (written by k_chol_tiles): consecutive columns are consecutive addresses.
 // flag: one int per superblock, zero on entry.  All workgroups are resident (at most 8 of them).
 constexpr int CH_SB = 128;
+// What follows the substitution in the solve phase (k_unscale), done by the last workgroup of k_trsv_back_mw when dc is set: the step in
+// unscaled variables dc = z / scale_inv and the header of the phase (zero; slot 4 = lead x status word; the kept scalars) -- one
+// launch less per iteration when the kernels run one after the other (4.8 us of 322 at 50 cameras).
+struct TrsvTail {
+    double* dc = nullptr;
+    const double* scale_inv = nullptr;
+    double* hdr = nullptr;
+    int hdr_len = 0;
+    const int* fail = nullptr;
+    double lead = 1.0;
+    const double* keep = nullptr;
+    int keep_at = 0, keep_len = 0;
+};
 // done (or null): = done_epoch when z is complete -- a kernel on another stream may spin on it instead of waiting for an event (k_unscale)
 __global__ __launch_bounds__(512) void k_trsv_back_mw(const double* __restrict__ L, const double* __restrict__ dinv, int n, double* __restrict__ b,
-                                                      int* __restrict__ flag, const int* gate, int* __restrict__ done = nullptr, int done_epoch = 0) {
+                                                      int* __restrict__ flag, const int* gate, int* __restrict__ done = nullptr, int done_epoch = 0,
+                                                      TrsvTail tail = TrsvTail()) {
     SATBA_GATE(gate);
     __shared__ double ys[CH_SB], zs[CH_SB], part[4][CH_SB];
     __shared__ double Dk[4][CH_NB][CH_NB + 1];  // Dk[blk][r][c] = (D_blk^-1)[r][c] of my four diagonal blocks
@@ -481,6 +495,15 @@ __global__ __launch_bounds__(512) void k_trsv_back_mw(const double* __restrict__
     if (tid == 0) {
         __hip_atomic_store(flag + k, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (k == 0 && done) __hip_atomic_store(done, done_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (superblock 0 is the last one)
+    }
+    if (k == 0 && tail.dc) {  // every z is published (the other superblocks' behind their flags, this one's drained above)
+        for (int i = tid; i < n; i += 512) tail.dc[i] = __hip_atomic_load(b + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) / tail.scale_inv[i];
+        for (int i = tid; i < tail.hdr_len; i += 512) {
+            double v = 0.0;
+            if (i == 4) v = tail.lead * (double)*tail.fail;
+            if (i >= tail.keep_at && i < tail.keep_at + tail.keep_len) v = tail.lead * tail.keep[i - tail.keep_at];
+            tail.hdr[i] = v;
+        }
     }
 }
 
@@ -567,8 +590,9 @@ inline void cholesky_tiles(double* A, int n, double* b, int* fail, hipStream_t s
 // tile kernel timed out: bit 1).  flags: CH_MAX_STEPS ints of scratch directly behind *fail (flags == fail + 1); both are cleared here
 // unless `cleared` (satba_solve does it in its scaling kernel).  dinv: (n / 32 rounded up) x 1024 doubles of scratch.
 // ts (tools): C3_TS time stamps per step of the tile kernel (a build with -DC3_STAMPS).
-inline void cholesky_solve(double* A, int n, double* b, int* fail, int* flags, hipStream_t stream, CholWork& w, double* dinv, bool cleared = false,
-                           const int* gate = nullptr, long long* ts = nullptr) {
+// tail (or null): what k_unscale does, by the backward substitution's last workgroup where that kernel runs (returns true), else left to the caller
+inline bool cholesky_solve(double* A, int n, double* b, int* fail, int* flags, hipStream_t stream, CholWork& w, double* dinv, bool cleared = false,
+                           const int* gate = nullptr, long long* ts = nullptr, const TrsvTail* tail = nullptr) {
     cholesky_init();
     if (!cleared) (void)hipMemsetAsync(fail, 0, sizeof(int) * (1 + CH_MAX_STEPS), stream);  // flags == fail + 1: one fill for both
     if (n <= CH_SMALL) {
@@ -587,12 +611,17 @@ inline void cholesky_solve(double* A, int n, double* b, int* fail, int* flags, h
                 hipLaunchKernelGGL(k_chol_step<false>, dim3(T * (T + 1) / 2), dim3(256), 0, stream, A, n, npend, k0, fail, fl, b, (long long*)nullptr, gate);
         }
         hipLaunchKernelGGL(k_trsv_back_small, dim3(1), dim3(64), 0, stream, A, n, b, gate);
-        return;
+        return false;
     }
     const bool mw = n <= 1024;  // the multi-workgroup backward substitution reads L^T from the upper triangle and the 32 x 32 inverses
     cholesky_tiles(A, n, b, fail, stream, w, mw ? dinv : nullptr, mw, gate, ts);
-    if (mw) hipLaunchKernelGGL(k_trsv_back_mw, dim3((n + CH_SB - 1) / CH_SB), dim3(512), 0, stream, A, dinv, n, b, flags + CH_TRSV_FLAGS, gate);
-    else hipLaunchKernelGGL(k_trsv_back, dim3(1), dim3(1024), sizeof(double) * n, stream, A, n, b);
+    if (mw) {
+        hipLaunchKernelGGL(k_trsv_back_mw, dim3((n + CH_SB - 1) / CH_SB), dim3(512), 0, stream, A, dinv, n, b, flags + CH_TRSV_FLAGS, gate, (int*)nullptr, 0,
+                           tail ? *tail : TrsvTail());
+        return tail != nullptr;
+    }
+    hipLaunchKernelGGL(k_trsv_back, dim3(1), dim3(1024), sizeof(double) * n, stream, A, n, b);
+    return false;
 }
 
 }  // namespace satba
