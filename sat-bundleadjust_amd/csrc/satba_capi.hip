@@ -143,6 +143,8 @@ struct satba_problem {
     int* d_fail = nullptr;
     double* d_dinv = nullptr;  // inverted 32 x 32 diagonal blocks of the factor (backward substitution)
     CholWork chol;             // scratch of the tile factorisation (satba_chol3.h)
+    bool scale_in_finish = false;  // front_schur_solve, one rank: k_schur_finish may hand the system over in scaled variables ...
+    bool s_scaled = false;         // ... and has (satba_solve skips k_scale_system)
     double schur_lam = 0.0;    // damping of the Schur phase being queued (k_schur_finish): value, or where k_vinv left it on the device
     const double* schur_lam_dev = nullptr;
     // the factorisation beside the pair kernel (front_schur_solve): its stream, fork / join events, the producers' counters
@@ -440,14 +442,17 @@ static int launch_schur(satba_problem* p, const ObsArgs& a, double* S, double* r
     const int total = p->M * cam_acc_len(NP);
     const int nb_diag = (int)((std::max<long long>(8ll * total, p->hdr) + 255) / 256);
     // end of the phase: diagonal blocks, right-hand side, header (and the pairs' chunk partials, red_chunks > 1) in one launch
-    auto finish = [&](int red_chunks) {
+    auto finish = [&](int red_chunks, bool direct) {  // direct: the pair kernel writes (has written) blocks of S itself
         const long long outs = red_chunks > 1 ? n_pairs * NP * NP : 0;
+        const bool scale = p->scale_in_finish && !direct && 1 + CH_MAX_STEPS <= nb_diag * 256;
         hipLaunchKernelGGL(k_schur_finish, dim3((unsigned)(nb_diag + (outs + 255) / 256)), dim3(256), 0, p->stream, p->M, NP, p->n_c, dchunks, p->d_part3,
                            p->schur_lam, p->schur_lam_dev, p->lead, p->d_gc, p->d_scale_inv, S, rhs, p->d_xb, (int)p->hdr, nb_diag, red_chunks,
-                           p->L.pair_ij, p->d_pair_part, p->gate);
+                           p->L.pair_ij, p->d_pair_part, p->gate, scale ? p->d_dch : (double*)nullptr, scale ? p->d_fail : (int*)nullptr,
+                           scale ? 1 + CH_MAX_STEPS : 0);
+        p->s_scaled = scale;
     };
     if (p->arrive_epoch) {  // the factorisation waits beside this stream: diagonal blocks and right-hand side first, the pair kernel counts its items in
-        finish(1);
+        finish(1, true);
         s.arrive = p->d_arrive; s.arrive_epoch = p->arrive_epoch; s.pair_cnt = p->d_pair_cnt; s.fail = p->d_fail;
     }
     int red_chunks = 1;
@@ -461,7 +466,7 @@ static int launch_schur(satba_problem* p, const ObsArgs& a, double* S, double* r
         if (p->L.C > 1 && !merged) red_chunks = p->L.C;
         if (p->arrive_epoch && (a.unit ? red_chunks > 1 : false)) return fail(SATBA_E_STATE, "factorisation beside a unit-weight pair kernel with chunk partials");
     }
-    if (!p->arrive_epoch) finish(red_chunks);
+    if (!p->arrive_epoch) finish(red_chunks, n_pairs > 0 && p->L.E > 0 && red_chunks == 1);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -1225,8 +1230,10 @@ static bool beside_timed_out(satba_problem* p, const double* h) {
 static int front_schur_solve(satba_problem* p, bool automatic, double lam, double Delta, double lam_floor) {
     p->beside_last = chol_beside_ok(p);
     if (!p->beside_last) {
-        if (automatic) TRY(satba_schur_auto(p, Delta, lam_floor));
-        else TRY(satba_schur(p, lam));
+        p->scale_in_finish = p->world == 1 && p->n_c > CH_ONE_LAUNCH;  // (the solve follows at once: nobody looks at S in between)
+        const int rc = automatic ? satba_schur_auto(p, Delta, lam_floor) : satba_schur(p, lam);
+        p->scale_in_finish = false;
+        if (rc) { p->s_scaled = false; return rc; }
         return satba_solve(p);
     }
     HIP_TRY(hipSetDevice(p->device));
@@ -1321,8 +1328,9 @@ int satba_solve(satba_problem* p) {
         p->have_step = true;
         return 0;
     }
-    hipLaunchKernelGGL(k_scale_system, dim3(grid_for((long long)p->n_c * p->n_c, 256, 2048)), dim3(256), 0, p->stream, p->n_c,
-                       p->d_scale_inv, S, rhs, p->d_dch, p->d_fail, 1 + CH_MAX_STEPS, p->gate, 0, p->n_c);
+    if (p->s_scaled) p->s_scaled = false;  // k_schur_finish has scaled the system and cleared the solver's status words
+    else hipLaunchKernelGGL(k_scale_system, dim3(grid_for((long long)p->n_c * p->n_c, 256, 2048)), dim3(256), 0, p->stream, p->n_c,
+                            p->d_scale_inv, S, rhs, p->d_dch, p->d_fail, 1 + CH_MAX_STEPS, p->gate, 0, p->n_c);
     HIP_TRY(hipGetLastError());
     bool unscaled = false;
     TRY(dense_solve(p, S, p->d_dch, true, &unscaled));  // the not-SPD flag and the step flags were cleared by the scaling kernel

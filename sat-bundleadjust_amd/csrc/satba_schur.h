@@ -831,11 +831,15 @@ __global__ __launch_bounds__(LINC_THREADS) void k_schur_diag(ObsArgs a, CamMajor
 // Every block of the lower triangle is written by a kernel of the Schur phase (the off-diagonal ones here or by k_schur_pairs, also for
 // pairs without a common point), so S is not cleared first (an 8 MB fill per iteration at 200 cameras x 5); the strict upper triangle is
 // never read.  lam_dev (optional): the damping is read from device memory (keep[5], written by k_vinv) instead of the argument.
+// rhs_scaled (or null): every entry of S passes through this launch and the dense solve follows at once (one rank): the system goes out in
+// scaled variables -- S / (scale_inv_r scale_inv_c), rhs_scaled = rhs / scale_inv, k_scale_system's arithmetic -- and the solver's
+// status word and flags (n_clear ints at clear) are cleared: that launch is gone, too.
 __global__ __launch_bounds__(256) void k_schur_finish(int M, int NP, int n_c, int n_chunks, const double* __restrict__ part, double lam,
                                                       const double* __restrict__ lam_dev, double lead, const double* __restrict__ gc,
                                                       const double* __restrict__ scale_inv, double* __restrict__ S, double* __restrict__ rhs,
                                                       double* __restrict__ xb, int hdr_len, int nb_diag, int red_chunks,
-                                                      const int2* __restrict__ pair_ij, const double* __restrict__ pair_part, const int* gate) {
+                                                      const int2* __restrict__ pair_ij, const double* __restrict__ pair_part, const int* gate,
+                                                      double* __restrict__ rhs_scaled = nullptr, int* __restrict__ clear = nullptr, int n_clear = 0) {
     SATBA_GATE(gate);
     if ((int)blockIdx.x >= nb_diag) {
         const long long n_pairs = (long long)M * (M - 1) / 2;
@@ -854,6 +858,7 @@ __global__ __launch_bounds__(256) void k_schur_finish(int M, int NP, int n_c, in
         for (; ch < red_chunks; ++ch) t += pair_part[((size_t)ch * n_pairs + pair) * NB2 + e];
         const int2 ij = pair_ij[pair];
         const int r = e / NP, q = e % NP;
+        if (rhs_scaled) t /= scale_inv[ij.y * NP + q] * scale_inv[ij.x * NP + r];
         S[(size_t)(ij.y * NP + q) + (size_t)(ij.x * NP + r) * n_c] = t;
         return;
     }
@@ -861,6 +866,7 @@ __global__ __launch_bounds__(256) void k_schur_finish(int M, int NP, int n_c, in
     const int CU = cam_acc_len(NP);
     const int gid = blockIdx.x * blockDim.x + threadIdx.x, idx = gid >> 3, sub = gid & 7;
     if (gid < hdr_len) xb[gid] = 0.0;
+    if (gid < n_clear) clear[gid] = 0;
     const bool live = idx < M * CU;
     const int cam = live ? idx / CU : 0, k = live ? idx % CU : 0;
     double t = 0.0;
@@ -873,7 +879,9 @@ __global__ __launch_bounds__(256) void k_schur_finish(int M, int NP, int n_c, in
     const int ntri = NP * (NP + 1) / 2;
     if (k >= ntri) {
         const int col = cam * NP + (k - ntri);
-        rhs[col] = lead * gc[col] + t;
+        const double v = lead * gc[col] + t;
+        rhs[col] = v;
+        if (rhs_scaled) rhs_scaled[col] = v / scale_inv[col];
         return;
     }
     int r = 0, rem = k;
@@ -884,8 +892,10 @@ __global__ __launch_bounds__(256) void k_schur_finish(int M, int NP, int n_c, in
         const double si = scale_inv[cam * NP + r];
         v = lead * lam * si * si;
     }
-    S[(size_t)(cam * NP + q) + (size_t)(cam * NP + r) * n_c] = v + t;
-    if (q != r) S[(size_t)(cam * NP + r) + (size_t)(cam * NP + q) * n_c] = v + t;
+    double out = v + t;
+    if (rhs_scaled) out /= scale_inv[cam * NP + q] * scale_inv[cam * NP + r];
+    S[(size_t)(cam * NP + q) + (size_t)(cam * NP + r) * n_c] = out;
+    if (q != r) S[(size_t)(cam * NP + r) + (size_t)(cam * NP + q) * n_c] = out;
 }
 
 }  // namespace satba
