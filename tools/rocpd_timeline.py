@@ -29,13 +29,15 @@ def main(path, out=sys.stdout):
             for key in names[1:]:
                 if key in n2 and key not in ph and b2 > a:
                     ph[key] = ((a2 - a) / 1e3, (b2 - a) / 1e3)
-        if all(k in ph for k in names):
+        if all(k in ph for k in names if k != "k_unscale"):
             phases.append(ph)
     if not phases:
         out.write("no Schur / solve phase with the tile Cholesky in this trace\n")
         return
     out.write("{} phases\n{:<22s} {:>9s} {:>9s} {:>9s}\n".format(len(phases), "kernel", "start", "end", "length"))
     for k in names:
+        if not all(k in p for p in phases):
+            continue
         s = statistics.median(p[k][0] for p in phases)
         e = statistics.median(p[k][1] for p in phases)
         out.write("{:<22s} {:>9.1f} {:>9.1f} {:>9.1f}\n".format(k.rstrip("<"), s, e, statistics.median(p[k][1] - p[k][0] for p in phases)))
