@@ -1319,8 +1319,7 @@ int satba_solve(satba_problem* p) {
     HIP_TRY(hipSetDevice(p->device));
     double* S = p->payload();
     double* rhs = S + (size_t)p->n_c * p->n_c;
-    static const bool split_small = getenv("SATBA_SOLVE_SPLIT") != nullptr;  // tests: the four-launch path for small systems, too
-    if (p->n_c <= CH_ONE_LAUNCH && !split_small) {
+    if (p->n_c <= CH_ONE_LAUNCH) {
         hipLaunchKernelGGL(k_solve_small, dim3(1), dim3(256), 0, p->stream, p->n_c, p->d_scale_inv, S, rhs, p->d_dch, p->d_dc, p->d_fail, 1 + CH_MAX_STEPS,
                            (int)p->hdr, p->d_xb, p->lead, p->d_keep, SATBA_HDR_KEEP, SATBA_KEEP_LEN, p->gate);
         HIP_TRY(hipGetLastError());

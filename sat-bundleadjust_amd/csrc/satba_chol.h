@@ -4,11 +4,10 @@
 // block pairs (a, b) with a <= b, which land in the column-major lower triangle).  This replaces the LSMR
 // iteration of scipy:optimize/_lsq/trf.py:479-480 by an exact factorisation.
 //
-// More than 64 unknowns: ONE persistent launch factorises the matrix in 64 x 64 tiles and carries the right-hand side along
-// (k_chol_tiles, satba_chol3.h), then the multi-workgroup backward substitution (k_trsv_back_mw).  Up to 64 unknowns (one tile; the
-// reference's usual 2 .. 20 images x 3 parameters): the panel steps of rounds 1 - 2 below -- k_chol_dstep (two 32-column panels per
-// launch, satba_chol2.h) or k_chol_step (one) -- and a one-wave backward substitution; there the tile kernel's fixed cost
-// (31 us against 16 - 27) does not pay.
+// More than 63 unknowns: ONE persistent launch factorises the matrix in 64 x 64 tiles and carries the right-hand side along
+// (k_chol_tiles, satba_chol3.h), then the multi-workgroup backward substitution (k_trsv_back_mw).  Up to 63 unknowns (the
+// reference's usual 2 .. 20 images x 3 parameters): the whole solve phase is one workgroup (k_solve_small, satba_chol3.h) and never
+// comes here; n_c = (cameras) x (3, 5 or 6) is never 64.  The panel-step kernels of rounds 1 - 2 were removed in round 5.
 // fp64 MFMA runs at the vector rate on gfx950 and the matrix is tiny: the solve is bound by the latency of the
 // dependent pivot chain (tools/ubench/dp_latency.hip: 92 ns per column at best), not by flops; see DESIGN.md.
 #pragma once
@@ -42,290 +41,7 @@ __device__ inline double half_rsqrt(double d) {
     return fma(h, r, h);
 }
 
-constexpr int CH_LD = 80;  // row stride (doubles) of the LDS panel copies: 160 dwords = 32 mod 64 banks, so the four k-rows an
-                           // MFMA operand load touches (16 consecutive doubles each) fall into disjoint bank ranges
 typedef double chol_d4 __attribute__((ext_vector_type(4)));
-// acc[rb] += sum_k Pc[k][16 w + i] Pr[k][16 rb + j] for the 64 x 16 strip of a 64 x 64 tile that wave w owns, K = CH_NB, with
-// v_mfma_f64_16x16x4 (A[i][k]: lane i + 16 k, B[k][j]: lane j + 16 k, D[i][j]: lane j + 16 (i & 3), register i >> 2):
-// on return acc[rb][reg] of a lane is the update of tile row 16 rb + (lane & 15), tile column 16 w + (lane >> 4) + 4 reg.
-// fp64 MFMA runs at the vector rate: what it saves is LDS operand traffic (40 instead of 256 reads per wave and panel) -- with
-// one wave per SIMD the register-tiled form was bound by LDS latency (4.3 us per panel against ~1 us of arithmetic).
-__device__ __forceinline__ void chol_mfma_update(const double (*Pr)[CH_LD], const double (*Pc)[CH_LD], int wave, int lane, chol_d4 (&acc)[4]) {
-    const int kq = lane >> 4, e = lane & 15;
-#pragma unroll
-    for (int ks = 0; ks < CH_NB / 4; ++ks) {
-        const double a = Pc[4 * ks + kq][16 * wave + e];
-#pragma unroll
-        for (int rb = 0; rb < 4; ++rb) {
-            const double bb = Pr[4 * ks + kq][16 * rb + e];
-            acc[rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bb, acc[rb], 0, 0, 0);
-        }
-    }
-}
-
-// Diagonal block in registers: lanes 0..31 hold the rows of the block (a[c], zero above the diagonal), lanes 32..63
-// ride along (rows below the block: they end up holding L21).  Returns true if a pivot was not positive and finite.
-//
-// Micro-panels of 8 columns.  Inside a micro-panel everything stays in registers: the serial chain per column is
-// l = a_j * rsqrt(d) -> pivot of column j + 1 from the lane's own value (a[j+1] - l * l) -> readlane -> rsqrt; the other
-// columns of the micro-panel get L[c][j] by v_readlane (an SGPR operand of the multiply-add).  After a micro-panel its
-// 8 values per row go to LDS once and the remaining columns receive a rank-8 update from LDS broadcasts.
-// Round 1 broadcast every column through LDS: the LDS write -> read round trip (~60 ns) sat on the chain of the next
-// pivot 32 times per block (6.5 us per block; tools/chol_times.py); here it is paid 3 times.
-// pan: 64 x 8 doubles of LDS private to the wave.
-constexpr int CH_MP = 8;
-// pub(c, v): called for every column c of a finished micro-panel with the lane's final value -- the callers publish the block
-// with write-through stores there, so that all but the last micro-panel's stores are acknowledged while the factorisation is
-// still running (they used to be issued at the end: ~1.5 us of store latency on the chain of every panel).
-template <class PUB>
-__device__ __forceinline__ bool chol_diag_block(double (&a)[CH_NB], int lane, double (*pan)[CH_MP], PUB&& pub) {
-    bool bad = false;
-    double d = readlane_f64(a[0], 0);
-    bad |= !(d > 1e-300) || !(d < 1e300);
-    double h = half_rsqrt(d);
-#pragma unroll
-    for (int p = 0; p < CH_NB / CH_MP; ++p) {
-#pragma unroll
-        for (int jj = 0; jj < CH_MP; ++jj) {
-            const int j = CH_MP * p + jj;
-            const double a2 = a[j] + a[j];
-            const double l = a2 * h;  // lane j: 2 d h = sqrt(d)
-            a[j] = l;
-            if (j + 1 < CH_NB) {
-                const double piv = fma(-l, l, a[j + 1]);  // lane j + 1: its own l is L[j+1][j]
-                if (jj + 1 < CH_MP) {  // next pivot inside the micro-panel: complete after this column
-                    d = readlane_f64(piv, j + 1);
-                    bad |= !(d > 1e-300) || !(d < 1e300);
-                    h = half_rsqrt(d);
-                }
-#pragma unroll
-                for (int c = j + 1; c < CH_MP * (p + 1); ++c) a[c] = fma(-l, readlane_f64(l, c), a[c]);
-            }
-        }
-#pragma unroll
-        for (int jj = 0; jj < CH_MP; ++jj) pub(CH_MP * p + jj, a[CH_MP * p + jj]);
-        if (p + 1 < CH_NB / CH_MP) {
-            // rank-8 update of the columns behind the micro-panel
-            double2* row = reinterpret_cast<double2*>(&pan[lane][0]);
-#pragma unroll
-            for (int m = 0; m < CH_MP / 2; ++m) row[m] = make_double2(a[CH_MP * p + 2 * m], a[CH_MP * p + 2 * m + 1]);
-            __builtin_amdgcn_wave_barrier();  // single wave: its LDS operations execute in order
-#pragma unroll
-            for (int c = CH_MP * (p + 1); c < CH_NB; ++c) {
-                const double2* lc = reinterpret_cast<const double2*>(&pan[c][0]);  // row c of the panel: the same address for every lane
-                double s0 = 0.0, s1 = 0.0;
-#pragma unroll
-                for (int m = 0; m < CH_MP / 2; ++m) {
-                    const double2 t = lc[m];
-                    s0 = fma(a[CH_MP * p + 2 * m], t.x, s0);
-                    s1 = fma(a[CH_MP * p + 2 * m + 1], t.y, s1);
-                }
-                a[c] -= s0 + s1;
-                if (c == CH_MP * (p + 1)) {  // the next pivot: start its chain as early as possible
-                    d = readlane_f64(a[c], c);
-                    bad |= !(d > 1e-300) || !(d < 1e300);
-                    h = half_rsqrt(d);
-                }
-            }
-            __builtin_amdgcn_wave_barrier();
-            asm volatile("" ::: "memory");
-        }
-    }
-    return bad;
-}
-
-// One panel step in one launch.  kp: first column of the previous panel (applied to the trailing matrix here; < 0:
-// none), k0: first column of the panel that is factorised (k0 = kp + CH_NB or 0).  1-D grid over the lower 64x64
-// tiles of A[k0:, k0:], tile column 0 first.  flag: one int per launch, zero on entry.
-//
-// Column broadcasts go through LDS (every lane reads the same address: one ds_read, no bank conflicts); the
-// v_readlane version of the same loops took ~2x as long (two readlanes + hazard nops per multiply-add, measured with
-// tools/chol_times.py).
-// FULL: the panel has all CH_NB columns (every step but possibly the last).
-template <bool FULL>
-__global__ __launch_bounds__(256) void k_chol_step(double* __restrict__ A, int n, int npend, int k0, int* __restrict__ fail,
-                                                   int* __restrict__ flag, double* __restrict__ b, long long* __restrict__ ts, const int* gate) {
-    SATBA_GATE(gate);
-    // npend: number of 32-column panels directly before k0 whose trailing update is still pending (1 after a single step, 2
-    // after a double step, k_chol_dstep); they are applied one after the other in the same pass over the tile
-    // ts (tools only, normally null): 8 wall-clock stamps of this step -- 0 start of tile (0,0), 1 its update done,
-    // 2 diagonal block factorised (flag raised), 3 its wave done; 4..7 the same for tile (1, 0): start, update done, flag seen, end
-    __shared__ double Pi[CH_NB][CH_LD], Pj[CH_NB][CH_LD];  // Pj doubles as the stash X[c][r] of the tile's first 32 columns
-    __shared__ double Lb[CH_NB][CH_NB];              // L_kk, Lb[c][r] = L[r][c] (column-major like A)
-    __shared__ double lcol[2][64];
-    __shared__ double pan[64][CH_MP];
-    __shared__ double brow[64];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int T = (n - k0 + 63) / 64;
-    int bi, bj;
-    if ((int)blockIdx.x < T) { bi = blockIdx.x; bj = 0; }
-    else {  // tiles (bi >= bj >= 1), row by row
-        int idx = blockIdx.x - T;
-        bi = 1;
-        while (idx >= bi) { idx -= bi; ++bi; }
-        bj = idx + 1;
-    }
-    const int r0 = k0 + bi * 64, c0 = k0 + bj * 64;
-    const bool stamp = ts && bj == 0 && bi < 2 && tid == 0;
-    if (stamp) ts[bi * 4 + 0] = wall_clock64();
-
-    if (npend > 0) {
-        // ---- trailing update with the previous panel(s): A[r0.., c0..] -= P_i P_j^T, b[r0..] -= P_i y_prev
-        // v_mfma_f64_16x16x4 (chol_mfma_update): wave w owns tile columns 16 w .. 16 w + 15; a lane holds rows 16 rb + (lane & 15),
-        // columns 16 w + (lane >> 4) + 4 reg
-        const int e16 = lane & 15, g4 = lane >> 4;
-        chol_d4 old[4];  // the tile itself: in flight together with the panel loads
-#pragma unroll
-        for (int rb = 0; rb < 4; ++rb)
-#pragma unroll
-            for (int reg = 0; reg < 4; ++reg) {
-                const int r = r0 + 16 * rb + e16, cc = c0 + 16 * wave + g4 + 4 * reg;
-                old[rb][reg] = (r < n && cc < n && r >= cc) ? A[(size_t)r + (size_t)cc * n] : 0.0;
-            }
-        if (bj == 0 && tid < 64) brow[tid] = (r0 + tid < n) ? b[r0 + tid] : 0.0;
-        chol_d4 acc[4];
-#pragma unroll
-        for (int rb = 0; rb < 4; ++rb) acc[rb] = chol_d4{0.0, 0.0, 0.0, 0.0};
-        for (int pass = 0; pass < npend; ++pass) {
-            const int kq = k0 - CH_NB * (npend - pass);
-            if (pass > 0) __syncthreads();  // the previous pass is done with Pi, Pj, lcol
-            for (int idx = tid; idx < CH_NB * 64; idx += 256) {
-                const int r = idx & 63, k = idx >> 6;
-                Pi[k][r] = (r0 + r < n) ? A[(size_t)(r0 + r) + (size_t)(kq + k) * n] : 0.0;
-                Pj[k][r] = (c0 + r < n) ? A[(size_t)(c0 + r) + (size_t)(kq + k) * n] : 0.0;
-            }
-            if (bj == 0 && tid >= 64 && tid < 64 + CH_NB) lcol[0][tid - 64] = b[kq + tid - 64];  // y of that panel
-            __syncthreads();
-            if (bj == 0 && tid < 64) {
-                double s = 0.0;
-#pragma unroll 8
-                for (int k = 0; k < CH_NB; ++k) s += Pi[k][tid] * lcol[0][k];
-                brow[tid] -= s;  // only this thread touches brow[tid] until the barrier below
-            }
-            chol_mfma_update(Pi, Pj, wave, lane, acc);
-        }
-        if (bj == 0 && tid < 64 && bi > 0 && r0 + tid < n) b[r0 + tid] = brow[tid];  // tile (0, 0): solved and stored below
-        if (bj == 0) __syncthreads();  // everyone is done reading Pj before it becomes the stash
-#pragma unroll
-        for (int rb = 0; rb < 4; ++rb)
-#pragma unroll
-            for (int reg = 0; reg < 4; ++reg) {
-                const int row = 16 * rb + e16, col = 16 * wave + g4 + 4 * reg;
-                const int r = r0 + row, cc = c0 + col;
-                const double v = old[rb][reg] - acc[rb][reg];
-                if (bj == 0 && col < CH_NB) Pj[col][row] = v;  // panel columns are stored after the solve
-                else if (r < n && cc < n && r >= cc) A[(size_t)r + (size_t)cc * n] = v;
-            }
-    } else {
-        for (int idx = tid; idx < CH_NB * 64; idx += 256) {
-            const int r = idx & 63, k = idx >> 6;
-            Pj[k][r] = (r0 + r < n && k0 + k < n && r0 + r >= k0 + k) ? A[(size_t)(r0 + r) + (size_t)(k0 + k) * n] : 0.0;
-        }
-        if (tid < 64) brow[tid] = (r0 + tid < n) ? b[r0 + tid] : 0.0;
-    }
-    if (bj != 0) return;
-    __syncthreads();
-    if (stamp) ts[bi * 4 + 1] = wall_clock64();
-    const int nb = FULL ? CH_NB : min(CH_NB, n - k0);
-
-    if (bi == 0) {
-        // ---- tile (0, 0): lanes 0..31 = rows of the diagonal block, lanes 32..63 = the first 32 panel rows
-        if (wave == 0) {
-            double a[CH_NB];
-#pragma unroll
-            for (int c = 0; c < CH_NB; ++c) {
-                double v = Pj[c][lane];
-                if (lane < CH_NB && (c > lane || lane >= nb || c >= nb)) v = (c == lane) ? 1.0 : 0.0;  // identity padding
-                if (c >= nb && lane >= CH_NB) v = 0.0;
-                a[c] = v;
-            }
-            // publish L_kk as it is formed: agent-scope stores (write through to the coherence point) + flag, no release fence --
-            // a fence writes back the whole L2 of this XCD (~2.5 us measured) while the other tiles are still storing.
-            // A failed factorisation only raises the flag: the caller discards it.
-            const bool bad = chol_diag_block(a, lane, pan, [&](int c, double v) {
-                if (lane < nb && c <= lane) __hip_atomic_store(A + (size_t)(k0 + lane) + (size_t)(k0 + c) * n, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            });
-            __builtin_amdgcn_s_waitcnt(0);  // the stores above are acknowledged
-            if (lane == 0) __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (stamp) ts[2] = wall_clock64();
-            if (bad && lane == 0) atomicOr(fail, 1);
-            const int r = k0 + lane;
-            if (lane >= CH_NB && r < n) {
-#pragma unroll
-                for (int c = 0; c < CH_NB; ++c)
-                    if (c < nb) A[(size_t)r + (size_t)(k0 + c) * n] = a[c];
-            }
-            if (lane < CH_NB) {
-#pragma unroll
-                for (int c = 0; c < CH_NB; ++c) Lb[c][lane] = a[c];
-            }
-            if (stamp) ts[3] = wall_clock64();
-        }
-        __syncthreads();
-        if (wave == 1) {  // right-hand side: y_k = L_kk^-1 b_k, lane = entry
-            double v = (lane < nb) ? brow[lane] : 0.0;
-            const int cl = min(lane, CH_NB - 1);
-            for (int m = 0; m < nb; ++m) {
-                const double ym = __shfl(v, m) / Lb[m][m];
-                if (lane == m) v = ym;
-                else if (lane > m && lane < nb) v -= Lb[m][cl] * ym;
-            }
-            if (lane < nb) b[k0 + lane] = v;
-            else if (k0 + lane < n) b[k0 + lane] = brow[lane];
-        }
-        return;
-    }
-    // ---- tiles (i > 0, 0): 64 panel rows, x L_kk^T = p  (a partial panel is the last one: it has no rows below)
-    if (!FULL || wave != 0) return;
-    double x[CH_NB];
-#pragma unroll
-    for (int c = 0; c < CH_NB; ++c) x[c] = Pj[c][lane];  // columns >= nb of the stash are zero
-    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(1);
-    if (stamp) ts[6] = wall_clock64();
-    {   // L_kk: 16 coalesced loads per lane in flight, then into LDS (identity padding)
-        double v[CH_NB * CH_NB / 64];
-#pragma unroll
-        for (int t = 0; t < CH_NB * CH_NB / 64; ++t) {
-            const int idx = t * 64 + lane, r = idx % CH_NB, c = idx / CH_NB;
-            v[t] = (r < nb && c <= r) ? __hip_atomic_load(A + (size_t)(k0 + r) + (size_t)(k0 + c) * n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                                      : ((r == c) ? 1.0 : 0.0);
-        }
-#pragma unroll
-        for (int t = 0; t < CH_NB * CH_NB / 64; ++t) (&Lb[0][0])[t * 64 + lane] = v[t];
-    }
-    __builtin_amdgcn_wave_barrier();
-    if (lane < CH_NB) lcol[0][lane] = 1.0 / Lb[lane][lane];
-    __builtin_amdgcn_wave_barrier();
-    const int r = r0 + lane;
-    if (r >= n) return;  // before the arithmetic: stores under a condition would let the compiler sink all of it below
-                         // the LDS reads (2.5 KB of spills)
-    // row m + 1 of L^T is read from LDS while step m is computed; the barriers keep the compiler from hoisting all
-    // 528 reads (spills) or sinking the arithmetic below them
-    double cur[CH_NB], nxt[CH_NB];
-#pragma unroll
-    for (int c = 1; c < CH_NB; ++c) cur[c] = Lb[0][c];
-    cur[0] = lcol[0][0];
-#pragma unroll
-    for (int m = 0; m < CH_NB; ++m) {
-        if (m + 1 < CH_NB) {
-#pragma unroll
-            for (int c = m + 2; c < CH_NB; ++c) nxt[c] = Lb[m + 1][c];
-            nxt[m + 1] = lcol[0][m + 1];
-        }
-        const double xm = x[m] * cur[m];  // cur[m] = 1 / L[m][m]
-        x[m] = xm;
-#pragma unroll
-        for (int c = m + 1; c < CH_NB; ++c) x[c] -= xm * cur[c];  // L[c][m]
-        asm volatile("" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int c = m + 1; c < CH_NB; ++c) cur[c] = nxt[c];
-    }
-#pragma unroll
-    for (int c = 0; c < CH_NB; ++c)
-        if (FULL || c < nb) A[(size_t)r + (size_t)(k0 + c) * n] = x[c];
-    if (stamp) ts[7] = wall_clock64();
-}
 
 // L^T z = y in place in b (b holds y on entry), left-looking, one workgroup of 1024 threads:
 // z_k = L_kk^-T (y_k - L[tail, k-block]^T z_tail).  The right-hand side lives in LDS; each wave takes two columns of
@@ -507,49 +223,14 @@ __global__ __launch_bounds__(512) void k_trsv_back_mw(const double* __restrict__
     }
 }
 
-// L^T z = y for n <= 64, one wave, straight from the factor's lower triangle (no mirror, no block inverses): lane c holds column c
-// of L below the diagonal in registers (= row c of L^T) and its running right-hand side; step k (bottom up) broadcasts z_k and
-// every lane in front of it takes its term off.  Few cameras are the common case of the reference's pipelines (2 .. 20 images x 3
-// parameters); at 10 x 5 the mirror + inverses kernel and the multi-workgroup back-substitution were 19 us of a 165 us iteration,
-// this is 5.  (Tried with it: the factorisation in the same single wave, lane = row -- 38 us against 21 + 5 for k_chol_dstep's
-// four-wave diagonal blocks plus this kernel: dropped.)
-constexpr int CH_SMALL = 64;
-__global__ __launch_bounds__(64) void k_trsv_back_small(const double* __restrict__ L, int n, double* __restrict__ b, const int* gate) {
-    SATBA_GATE(gate);
-    const int c = threadIdx.x;
-    const int cc = min(c, n - 1);
-    double t[CH_SMALL];
-#pragma unroll
-    for (int k = 0; k < CH_SMALL; ++k) t[k] = (k < n && k > c) ? L[(size_t)k + (size_t)cc * n] : 0.0;
-    const double inv = 1.0 / L[(size_t)cc + (size_t)cc * n];
-    double y = (c < n) ? b[c] : 0.0;
-#pragma unroll
-    for (int k = CH_SMALL - 1; k >= 0; --k) {
-        if (k < n) {  // (uniform)
-            const double zk = readlane_f64(y * inv, k);
-            y = (c == k) ? zk : fma(-t[k], zk, y);  // t[k] is zero at and behind the diagonal (lanes >= k)
-        }
-    }
-    if (c < n) b[c] = y;
-}
-
 }  // namespace satba
-#include "satba_chol2.h"
 #include "satba_chol3.h"
 namespace satba {
 
-constexpr int CH_MAX_STEPS = 256;  // flag words behind the not-SPD flag (the small path's panel flags, then the backward substitution's)
+constexpr int CH_MAX_STEPS = 256;  // flag words behind the not-SPD flag (the backward substitution's sit at CH_TRSV_FLAGS)
 constexpr int CH_TRSV_FLAGS = 64;  // k_trsv_back_mw's flags
 
-// k_chol_dstep's tile column + scratch exceed the 64 KB a kernel gets without asking (called once per process)
-inline void cholesky_init() {
-    static const bool once = [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chol_dstep), hipFuncAttributeMaxDynamicSharedMemorySize, (int)chol_dstep_lds());
-        return true;
-    }();
-    (void)once;
-    chol_tiles_init();
-}
+inline void cholesky_init() { chol_tiles_init(); }
 
 // Scratch of the tile kernel (per handle): tile flags (zeroed once: they carry epochs), the inverted 64 x 64 diagonal blocks,
 // the tiles' shares of the forward substitution, the ticket counters (zero between launches).
@@ -595,24 +276,6 @@ inline bool cholesky_solve(double* A, int n, double* b, int* fail, int* flags, h
                            const int* gate = nullptr, long long* ts = nullptr, const TrsvTail* tail = nullptr) {
     cholesky_init();
     if (!cleared) (void)hipMemsetAsync(fail, 0, sizeof(int) * (1 + CH_MAX_STEPS), stream);  // flags == fail + 1: one fill for both
-    if (n <= CH_SMALL) {
-        // one tile: panel steps (two panels per launch while more than 32 columns remain, then one) + the one-wave backward substitution
-        int k0 = 0, npend = 0;
-        int* fl = flags;
-        for (; n - k0 > CH_NB; k0 += 2 * CH_NB, fl += 2, npend = 2) {  // (the second panel may be partial)
-            const int T = (n - k0 + 63) / 64;
-            hipLaunchKernelGGL(k_chol_dstep, dim3(T * (T + 1) / 2), dim3(256), chol_dstep_lds(), stream, A, n, npend, k0, fail, fl, b, (long long*)nullptr, gate);
-        }
-        for (; k0 < n; k0 += CH_NB, ++fl, npend = 1) {
-            const int T = (n - k0 + 63) / 64;
-            if (n - k0 >= CH_NB)
-                hipLaunchKernelGGL(k_chol_step<true>, dim3(T * (T + 1) / 2), dim3(256), 0, stream, A, n, npend, k0, fail, fl, b, (long long*)nullptr, gate);
-            else
-                hipLaunchKernelGGL(k_chol_step<false>, dim3(T * (T + 1) / 2), dim3(256), 0, stream, A, n, npend, k0, fail, fl, b, (long long*)nullptr, gate);
-        }
-        hipLaunchKernelGGL(k_trsv_back_small, dim3(1), dim3(64), 0, stream, A, n, b, gate);
-        return false;
-    }
     const bool mw = n <= 1024;  // the multi-workgroup backward substitution reads L^T from the upper triangle and the 32 x 32 inverses
     cholesky_tiles(A, n, b, fail, stream, w, mw ? dinv : nullptr, mw, gate, ts);
     if (mw) {

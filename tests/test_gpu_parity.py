@@ -279,7 +279,7 @@ def test_schur_matrix_and_rhs(gpu, monkeypatch, chunks):
     dev.close()
 
 
-# n_c = 9 ... 1300 unknowns.  Up to 64 (one tile): panel steps (k_chol_dstep / k_chol_step) + the one-wave backward substitution: 9, 18,
+# n_c = 9 ... 1300 unknowns.  Up to 63: the one-workgroup solve phase (k_solve_small): 9, 18,
 # 30, 33, 60, 63.  Above: the persistent tile kernel (k_chol_tiles, 64 x 64 tiles: 2 to 21 tile rows here, ragged last tiles: 65, 66,
 # 96, 129, 130, 162) + the multi-workgroup backward substitution; 1300: more than 1024 unknowns (one-workgroup backward substitution).
 @pytest.mark.parametrize("n_cam,n_p", [(3, 3), (13, 5), (60, 5), (200, 5), (150, 6), (64, 3), (32, 3), (43, 3), (11, 6), (26, 5), (54, 3), (260, 5),

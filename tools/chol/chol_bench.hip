@@ -81,12 +81,11 @@ int main(int argc, char** argv) {
                 CK(hipMemcpyAsync(db, db0, sizeof(double) * n, hipMemcpyDeviceToDevice, st));
                 CK(hipMemsetAsync(dfail, 0, sizeof(int) * (1 + CH_MAX_STEPS), st));
                 CK(hipEventRecord(e0, st));
-                if (which == 0) {   // the tile kernel at every size (the library's driver switches to panel steps up to 64 unknowns)
+                if (which == 0) {   // the tile kernel and the backward substitution, launched by hand (time stamps)
                     cholesky_init();
-                    const bool mw = n > CH_SMALL && n <= 1024;
+                    const bool mw = n <= 1024;
                     cholesky_tiles(dA, n, db, dfail, st, w, mw ? dinv : nullptr, mw, nullptr, dts);
-                    if (n <= CH_SMALL) hipLaunchKernelGGL(k_trsv_back_small, dim3(1), dim3(64), 0, st, dA, n, db, (const int*)nullptr);
-                    else if (mw) hipLaunchKernelGGL(k_trsv_back_mw, dim3((n + CH_SB - 1) / CH_SB), dim3(512), 0, st, dA, dinv, n, db, dfail + 1 + CH_TRSV_FLAGS, (const int*)nullptr);
+                    if (mw) hipLaunchKernelGGL(k_trsv_back_mw, dim3((n + CH_SB - 1) / CH_SB), dim3(512), 0, st, dA, dinv, n, db, dfail + 1 + CH_TRSV_FLAGS, (const int*)nullptr);
                     else hipLaunchKernelGGL(k_trsv_back, dim3(1), dim3(1024), sizeof(double) * n, st, dA, n, db);
                 } else cholesky_solve(dA, n, db, dfail, dfail + 1, st, w, dinv, true, nullptr);
                 CK(hipEventRecord(e1, st));
