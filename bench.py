@@ -473,7 +473,10 @@ def main():
                          "algorithmic_bytes_per_launch": alg_bytes, "ms_per_launch": 1e3 * t_lin, "launches_timed": n_lin,
                          "ms_per_launch_back_to_back": kern["linearize"]},
             "kernel_ms": kern,
-            "phase_ms": phase_ms,  # several ranks: device time per phase and collective, host time in blocking header reads (per iteration)
+            # several ranks: device time per phase and collective, host time in blocking header reads (per iteration).  Taken in a separate
+            # pass with the PYTHON host loop (lm_step: torch events around every phase, two blocking header reads per iteration) -- the
+            # timed figure above comes from `host_driver`, which for "device" has no host wait at all: host_wait below is that pass's
+            "phase_ms": phase_ms, "phase_ms_driver": "python" if phase_ms is not None else None,
             "accepted_steps": st["accepted"], "interior_2d_steps": st.get("interior", 0), "final_cost": st["cost"], "scene_gen_s": t_gen,
             "launch_patterns_executed": int(ls["ticks"]) if ls else None,  # > steps when a factorisation had to be repeated with more damping
         }

@@ -309,7 +309,8 @@ int satba_get_layout(satba_problem *p, int32_t which, int64_t n, void *host_out)
  * [11] camera sums by (fixed-point) LDS atomics, [12] camera-major sums requested, [13] chunks of the camera-major passes,
  * [14] workgroups of k_linearize, [15] fall-backs from the fixed-point sums so far, [16] satba_solve_lm runs on the
  * device-resident loop (n >= 17), [17] the last Schur + solve front had the factorisation running beside the pair
- * kernel (1), not (0), or that mode was switched off on this handle after a wait timed out (-1) (n >= 18) */
+ * kernel (1), not (0), or that mode is switched off on this handle after a wait timed out (-1; it is tried again
+ * after 128, 256, ... sequential fronts) (n >= 18), [18] such time-outs so far (n >= 19)                        */
 int satba_get_info(const satba_problem *p, double *out, int32_t n);
 /* normal-equation blocks of the last linearize: U (M n_p n_p), g_c (M n_p) as written to the exchange
  * payload, V (N x 6: xx xy xz yy yz zz), g_p (N x 3), points in the caller's order. Any pointer may be NULL.

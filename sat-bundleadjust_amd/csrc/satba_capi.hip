@@ -155,7 +155,10 @@ struct satba_problem {
     long long* d_ts = nullptr; // (tools, -DC3_STAMPS: time stamps of the last factorisation beside the pair kernel, printed when the handle goes)
     int arrive_epoch = 0;      // != 0 while a front with the factorisation beside it is being queued (launch_schur)
     bool beside_last = false;  // the last front ran that way
-    bool beside_off = false;   // ... and timed out waiting for the pair kernel (kernels serialised by a tool): never again on this handle
+    bool beside_off = false;   // ... and timed out waiting for the pair kernel (kernels serialised by a tool, one hardware queue for both streams)
+    int beside_clean = 0;      // sequential fronts since the time-out; the concurrent front is tried again after beside_retry_after of
+    int beside_retry_after = 64;  // them, and the interval doubles with every further time-out (a profiler costs a handful of stalls, not one per front)
+    int beside_timeouts = 0;
     double* d_scal = nullptr;  // 8 private scalars (costs of satba_residuals, timing sinks)
     double* d_keep = nullptr;  // SATBA_KEEP_LEN scalars of the running iteration that outlive the per-phase headers
     bool prepared = false;
@@ -1219,15 +1222,20 @@ static int front_schur_solve(satba_problem* p, bool automatic, double lam, doubl
 // header slot 4 of the solve phase = lead x status word of the factorisation: bit 1 = a wait timed out.  Beside the pair kernel that
 // means the two kernels did not run at the same time (a profiler collecting counters serialises the launches): the handle goes back
 // to one kernel after the other and the caller repeats the front with the same damping.
-static bool beside_timed_out(satba_problem* p, const double* h) {
-    if (!p->beside_last || !(h[4] >= 2.0)) return false;
-    p->beside_off = true;
+static void beside_disable(satba_problem* p) {
+    p->beside_off = true; p->beside_clean = 0; ++p->beside_timeouts;
+    p->beside_retry_after = std::min(p->beside_retry_after * 2, 1 << 20);
     (void)hipStreamSynchronize(p->chol_stream);
     (void)hipMemsetAsync(p->d_arrive, 0, sizeof(int) * (size_t)(p->M + 2) * SCHUR_ARRIVE_STRIDE, p->stream);
     (void)hipMemsetAsync(p->d_pair_cnt, 0, sizeof(int) * (size_t)std::max<long long>(p->L.n_pairs, 1), p->stream);
+}
+static bool beside_timed_out(satba_problem* p, const double* h) {
+    if (!p->beside_last || !(h[4] >= 2.0)) return false;
+    beside_disable(p);
     return true;
 }
 static int front_schur_solve(satba_problem* p, bool automatic, double lam, double Delta, double lam_floor) {
+    if (p->beside_off && ++p->beside_clean > p->beside_retry_after) p->beside_off = false;  // (chol_beside_ok decides whether it applies at all)
     p->beside_last = chol_beside_ok(p);
     if (!p->beside_last) {
         p->scale_in_finish = p->world == 1 && p->n_c > CH_ONE_LAUNCH;  // (the solve follows at once: nobody looks at S in between)
@@ -1272,6 +1280,8 @@ static int front_schur_solve(satba_problem* p, bool automatic, double lam, doubl
         g.ts = p->d_ts;
 #endif
         g.arrive = p->d_arrive; g.arr_M = p->M; g.np = p->NP; g.arr_epoch = g.epoch; g.si = p->d_scale_inv; g.rhs = rhs;
+        // 5 ms + ~10 x what the kernels in front of a tile's last producer take at HBM speed (hit lists and records: ~100 bytes per hit)
+        g.arr_timeout = 500000 + (long long)((double)p->L.E * 100.0 / 6e12 * 1e8 * 10.0) + (long long)((double)p->K * 200.0 / 6e12 * 1e8 * 10.0);
         hipLaunchKernelGGL(k_chol_tiles, dim3(std::min(chol_tiles_grid(n, 1), wgs)), dim3(1024), c3_lds_bytes(), p->chol_stream, g, p->gate);
         hipLaunchKernelGGL(k_trsv_back_mw, dim3((n + CH_SB - 1) / CH_SB), dim3(512), 0, p->chol_stream, S, p->d_dinv, n, p->d_dch,
                            p->d_fail + 1 + CH_TRSV_FLAGS, p->gate, p->d_arrive + (size_t)SCHUR_ARRIVE_STRIDE * (p->M + 1), g.epoch);
@@ -1521,6 +1531,7 @@ static int lm_reset(satba_problem* p, const satba_lm_opts* o, bool never_stop, b
     if (watch) {  // the host is going to poll the summary: nothing of an earlier run may still post to it
         HIP_TRY(hipStreamSynchronize(p->stream));
         p->h_lm->word = (unsigned long long)LM_RUN; p->h_lm->sub_requests = 0; p->h_lm->sub_tick = 0; p->h_lm->end_tick = 0;
+        __atomic_thread_fence(__ATOMIC_SEQ_CST);
     }
     hipLaunchKernelGGL(k_lm_reset, dim3(1), dim3(1), 0, p->stream, p->d_lm, init, keep_counters ? 1 : 0);
     HIP_TRY(hipGetLastError());
@@ -1615,7 +1626,7 @@ static int lm_drive(satba_problem* p, double lam_floor, long long max_ticks) {
     long long sub_served = 0;
     for (;;) {
         // every evaluation and every repeated factorisation is one pattern: a loop that queues many more has lost track of the device
-        if (p->lm_ticks_queued > max_ticks) return fail(SATBA_E_STATE, "device-resident loop: %lld launch patterns queued without reaching the end", p->lm_ticks_queued);
+        if (p->lm_ticks_queued > max_ticks || p->lm_ticks_queued >= LM_MAX_TICKS) return fail(SATBA_E_STATE, "device-resident loop: %lld launch patterns queued without reaching the end", p->lm_ticks_queued);
         TRY(lm_queue_tick(p, lam_floor));
         // watchdog: a tick is milliseconds of device work; a minute without a report means the device is stuck
         auto t_wait = std::chrono::steady_clock::now();
@@ -1628,11 +1639,24 @@ static int lm_drive(satba_problem* p, double lam_floor, long long max_ticks) {
             if (ms_since(t_wait) > 60000.0) return fail(SATBA_E_HIP, "device-resident loop: no progress report from the device for 60 s");
         }
         const int phase = lm_summary_phase(w);
-        const long long req = __atomic_load_n(&p->h_lm->sub_requests, __ATOMIC_ACQUIRE);
+        const long long req = lm_stamp_value(__atomic_load_n(&p->h_lm->sub_requests, __ATOMIC_ACQUIRE));
         if (req > sub_served) {  // the loop has paused for the degenerate-subspace pattern (the ticks queued behind the pause are switched off)
             sub_served = req;
             TRY(lm_launch_sub_pattern(p));
             ++p->lm_ticks_queued;
+            continue;
+        }
+        if (phase == LM_NEED_HOST) {
+            // the factorisation beside the pair kernel timed out (the two kernels did not run at the same time): sequential fronts from
+            // here on, and the loop carries on at the front that was lost -- nothing of it was booked (lm_decide1a)
+            LmDev st;
+            TRY(lm_read_state(p, &st));  // (waits for the stream: every queued tick has passed)
+            if (st.host_reason != LM_HOST_BESIDE || !p->beside_last) return 0;
+            beside_disable(p);
+            hipLaunchKernelGGL(k_lm_resume_front, dim3(1), dim3(1), 0, p->stream, p->d_lm);
+            HIP_TRY(hipGetLastError());
+            __atomic_store_n(&p->h_lm->word, ((unsigned long long)st.tick << 8) | (unsigned long long)LM_RUN, __ATOMIC_RELEASE);
+            p->lm_ticks_queued = st.tick;
             continue;
         }
         if (phase != LM_RUN && phase != LM_NEED_SUB) return 0;
@@ -1709,12 +1733,24 @@ int satba_lm_part(satba_problem* p, int32_t part, double lam_floor) {
 
 int satba_lm_poll(satba_problem* p, int64_t* out, int32_t n) {
     if (!p || !out || n < 5) return fail(SATBA_E_ARG, "bad argument");
-    const unsigned long long w = __atomic_load_n(&p->h_lm->word, __ATOMIC_ACQUIRE);
-    out[0] = lm_summary_tick(w); out[1] = lm_summary_phase(w);
-    out[2] = __atomic_load_n(&p->h_lm->sub_requests, __ATOMIC_ACQUIRE);
-    out[3] = __atomic_load_n(&p->h_lm->sub_tick, __ATOMIC_ACQUIRE);
-    out[4] = __atomic_load_n(&p->h_lm->end_tick, __ATOMIC_ACQUIRE);
-    return 0;
+    // the four words are stored one by one without a fence (LmSummary): a snapshot is consistent when none of the three stamped
+    // words is older than the tick in `word` -- every rank then acts on values at least as new as the tick it acts on
+    for (int tries = 0;; ++tries) {
+        const unsigned long long w = __atomic_load_n(&p->h_lm->word, __ATOMIC_ACQUIRE);
+        const unsigned long long sr = __atomic_load_n(&p->h_lm->sub_requests, __ATOMIC_ACQUIRE);
+        const unsigned long long stk = __atomic_load_n(&p->h_lm->sub_tick, __ATOMIC_ACQUIRE);
+        const unsigned long long etk = __atomic_load_n(&p->h_lm->end_tick, __ATOMIC_ACQUIRE);
+        const long long t = lm_summary_tick(w);
+        if (lm_stamp_tick(sr) >= t && lm_stamp_tick(stk) >= t && lm_stamp_tick(etk) >= t) {
+            out[0] = t; out[1] = lm_summary_phase(w);
+            out[2] = lm_stamp_value(sr); out[3] = lm_stamp_value(stk); out[4] = lm_stamp_value(etk);
+            return 0;
+        }
+        if (tries > 1000000) return fail(SATBA_E_HIP, "device-resident loop: the progress report stays inconsistent");
+#if defined(__x86_64__)
+        __builtin_ia32_pause();
+#endif
+    }
 }
 
 int satba_lm_state(satba_problem* p, double* out, int32_t n) {
@@ -2033,6 +2069,7 @@ int satba_get_info(const satba_problem* p, double* out, int32_t n) {
     out[11] = p->cam_sums_lds; out[12] = p->deterministic; out[13] = p->cm_chunks; out[14] = p->lin_grid; out[15] = p->fx_fallbacks;
     if (n > 16) out[16] = (lm_device_loop_ok(p) && lm_device_loop_pays(p)) ? 1.0 : 0.0;
     if (n > 17) out[17] = p->beside_off ? -1.0 : (p->beside_last ? 1.0 : 0.0);
+    if (n > 18) out[18] = p->beside_timeouts;
     return 0;
 }
 

@@ -33,7 +33,7 @@ constexpr int C3_TBS = 65;                 // column stride of the hand-over buf
 constexpr int C3_LD = 80;                  // row stride of an owner's operand tiles [k][r] (MFMA operand loads: disjoint bank ranges)
 constexpr int C3_S1 = 1, C3_S2 = 2;        // stages of a tile flag: 1 = A' (all panels but the chain's) published, 2 = L published
 constexpr int C3_SPIN_LIMIT = 1 << 22;
-constexpr int C3_ARRIVE_SPIN_LIMIT = 1 << 19;  // looks at the producers' counters before giving up (~0.3 s: they are not running beside this kernel)
+constexpr long long C3_ARRIVE_TIMEOUT = 1000000;  // default wait for the producers' counters, in ticks of the 100 MHz wall clock (10 ms; C3Args::arr_timeout)
 constexpr int C3_TS = 32;                  // time stamps per step (tools): 0..5 phases, 8 + 8 set + p: micro-panel p of a row set flagged
 
 struct C3Args {
@@ -57,12 +57,16 @@ struct C3Args {
     // agent-scope loads.
     int* arrive = nullptr;
     int arr_M = 0, np = 1, arr_epoch = 0, nap = 1;  // nap: length of a pause between two looks at the counters, in units of ~0.5 us
+    // how long a tile waits for its producers before it gives up (fail |= 2: the two kernels are not running at the same time), in
+    // ticks of the 100 MHz wall clock.  Round 4 counted spins (~0.3 - 1 s); the caller now passes a few milliseconds plus a
+    // multiple of the pair kernel's expected duration, so that a fall-back to the sequential front costs ~10 ms
+    long long arr_timeout = C3_ARRIVE_TIMEOUT;
     const double* si = nullptr;
     const double* rhs = nullptr;
 };
 constexpr int C3_ARRIVE_STRIDE = 32;  // (= SCHUR_ARRIVE_STRIDE)
 
-struct C3Arrive { const int* arrive; int M, np, epoch, nap; };
+struct C3Arrive { const int* arrive; int M, np, epoch, nap; long long timeout; };
 
 constexpr size_t c3_lds_bytes() {
     return sizeof(double) * (3 * 8 * C3_BLK + 64 * C3_TBS + 64 + 64 + 128 + 512) + sizeof(int) * 64;
@@ -146,6 +150,7 @@ __device__ __forceinline__ bool c3_wait_arrive(const C3Arrive& r, int col_lo, in
     const int lane = threadIdx.x & 63;
     const int c_lo = col_lo / r.np, c_hi = col_hi / r.np;
     int spins = 0;
+    const long long t0 = wall_clock64();
     for (;;) {
         bool ok = true;
         // lane 0: the word behind the last camera; lanes 1 ..: one camera each (64-column tiles: at most 22 with 3 unknowns per camera)
@@ -155,8 +160,8 @@ __device__ __forceinline__ bool c3_wait_arrive(const C3Arrive& r, int col_lo, in
         }
         if (__all(ok)) return true;
         for (int t = 0; t < r.nap; ++t) __builtin_amdgcn_s_sleep(20);
-        if ((++spins & 255) == 0) {
-            if (spins > C3_ARRIVE_SPIN_LIMIT) { if (lane == 0) atomicOr(fail, 2); return false; }
+        if ((++spins & 31) == 0) {
+            if (wall_clock64() - t0 > r.timeout) { if (lane == 0) atomicOr(fail, 2); return false; }
             if (c3_ld_flag(fail) & 2) return false;
         }
     }
@@ -694,7 +699,7 @@ __device__ __forceinline__ void c3_chain(const C3Args& g, int T) {
         int* s_ok = l.lf + 61;
         const int n = g.n;
         if (tid < 64) {
-            const C3Arrive r{g.arrive, g.arr_M, g.np, g.arr_epoch, g.nap};
+            const C3Arrive r{g.arrive, g.arr_M, g.np, g.arr_epoch, g.nap, g.arr_timeout};
             C3_STAMP(g.ts, T * C3_TS + 0, tid == 0);
             const bool ok = c3_wait_arrive(r, 0, (n < 128 ? n : 128) - 1, g.fail);
             C3_STAMP(g.ts, T * C3_TS + 1, tid == 0);
@@ -825,7 +830,7 @@ __device__ __noinline__ void c3_owner(C3Args g, int T, int i, int j, int kind) {
     }
     auto load_arrived = [&]() -> bool {
         if (wave == 0) {
-            const C3Arrive r{g.arrive, g.arr_M, g.np, g.arr_epoch, g.nap};
+            const C3Arrive r{g.arrive, g.arr_M, g.np, g.arr_epoch, g.nap, g.arr_timeout};
             const bool ok = c3_wait_arrive(r, c0, (c0 + 63 < n ? c0 + 63 : n - 1), g.fail);
             if (tid == 0) c3_lds_set(s_ok, ok ? 1 : 0);
         }

@@ -38,13 +38,14 @@
 namespace satba {
 
 enum { LM_RUN = 0, LM_DONE = 1, LM_NEED_HOST = 2, LM_NEED_SUB = 3 };
-enum { LM_HOST_NONE = 0, LM_HOST_FX = 1, LM_HOST_CHOL = 2, LM_HOST_NONFINITE = 3 };
+enum { LM_HOST_NONE = 0, LM_HOST_FX = 1, LM_HOST_CHOL = 2, LM_HOST_NONFINITE = 3, LM_HOST_BESIDE = 4 };
 constexpr int LM_RUN_AHEAD = 3;  // ticks the host may queue beyond the last one the device has reported
 
 struct LmDev {
     // gates (SATBA_GATE) and control
     int run_lin, run_solve, run_sub, run_prod, run_trial, accept, restore;
     int phase, status, first, one_dim, have_actual, host_reason, never_stop, attempts;
+    int resume_lin;  // LM_HOST_BESIDE: run_lin at the hand-over (the linearisation of the repeated front is not booked yet iff 1)
     int accepted_total, interior_total, cycle_len, cycle_it;
     long long nfev, njev, iterations, max_nfev, tick;
     long long max_iterations;  // fixed-work runs (never_stop): stop after this many iterations (0: never)
@@ -62,17 +63,22 @@ struct LmDev {
     double coef[2], predicted, step_h_norm, cost_new;
 };
 
-// what the host polls, in pinned host memory: written by k_lm_decide2 with two relaxed system-scope stores (uncached, straight
-// over PCIe).  No release fence: at system scope it writes the whole L2 back (tens of microseconds per tick, measured); the two
-// words are self-contained instead -- `word` = executed patterns << 8 | phase, `sub_requests` = how often the loop has paused for
-// the subspace pattern (a host that sees the pause before the count simply polls again).
+// what the host polls, in pinned host memory: written by k_lm_decide2 with relaxed system-scope stores (uncached, straight over
+// PCIe).  No release fence: at system scope it writes the whole L2 back (tens of microseconds per tick, measured).  Every word is
+// self-contained instead: `word` = executed patterns << 8 | phase, and each of the other three carries the tick it was written at
+// in its upper half (stamp << 32 | value).  A reader that finds a stamp older than the tick in `word` has caught the stores half
+// way and polls again (satba_lm_poll, lm_summary_read): with several ranks every rank must act on values at least as new as the
+// tick it acts on, or the ranks queue different patterns and their collectives no longer match (round-4 advisor finding).
 struct LmSummary {
     unsigned long long word;
-    long long sub_requests;
+    unsigned long long sub_requests;  // how often the loop has paused for the subspace pattern
     // for several ranks (satba_lm_part): every rank must queue the SAME number of patterns, so the host does not act on "the latest
     // report" but on these two tick numbers, which are functions of all-reduced scalars only
-    long long sub_tick, end_tick;
+    unsigned long long sub_tick, end_tick;
 };
+constexpr long long LM_MAX_TICKS = (1ll << 31) - 8;  // ticks travel in 32 bits of the stamped words
+__host__ __device__ inline long long lm_stamp_tick(unsigned long long w) { return (long long)(w >> 32); }
+__host__ __device__ inline long long lm_stamp_value(unsigned long long w) { return (long long)(w & 0xffffffffull); }
 __host__ __device__ inline long long lm_summary_tick(unsigned long long w) { return (long long)(w >> 8); }
 __host__ __device__ inline int lm_summary_phase(unsigned long long w) { return (int)(w & 0xff); }
 
@@ -128,6 +134,10 @@ __device__ inline void lm_decide1a(LmDev* __restrict__ gst, const double* __rest
     }
     // fixed-point overflow of the camera sums: the host switches the summation route and repeats (nothing is booked)
     if (h[LMH_FX_BAD] != 0.0) { lm_to_host(st, LM_HOST_FX); return; }
+    // the factorisation beside the pair kernel timed out waiting for it (status bit 1: the two kernels did not run at the same time --
+    // launches serialised by a tool, two streams on one hardware queue): not a failed factorisation.  Nothing is booked, the damping
+    // stays; the host switches the handle to one kernel after the other and resumes the loop at this front (lm_drive)
+    if (h[LMH_CHOL_FAIL] >= 2.0) { st->resume_lin = st->run_lin; lm_to_host(st, LM_HOST_BESIDE); return; }
     if (st->run_lin) {
         // bookkeeping of the new linearisation (scipy trf.py:536-546 after an accepted step; :405-426 before the loop)
         const double cost = h[LMH_K_COST];
@@ -313,10 +323,19 @@ __global__ void k_lm_decide2(LmDev* __restrict__ gst, const double* __restrict__
     st->run_trial = 0;
     st->tick += 1;
     if (st->end_tick == 0 && st->phase != LM_RUN && st->phase != LM_NEED_SUB) st->end_tick = st->tick;
-    __hip_atomic_store(&sum->sub_tick, st->sub_tick, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __hip_atomic_store(&sum->end_tick, st->end_tick, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __hip_atomic_store(&sum->sub_requests, st->sub_requests, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    const unsigned long long stamp = (unsigned long long)st->tick << 32;
+    __hip_atomic_store(&sum->sub_tick, stamp | ((unsigned long long)st->sub_tick & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&sum->end_tick, stamp | ((unsigned long long)st->end_tick & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&sum->sub_requests, stamp | ((unsigned long long)st->sub_requests & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __hip_atomic_store(&sum->word, ((unsigned long long)st->tick << 8) | (unsigned long long)st->phase, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// After LM_HOST_BESIDE the host has switched the handle to sequential fronts (and waited for the stream: nothing else touches the
+// state): the loop carries on at the front that timed out.
+__global__ void k_lm_resume_front(LmDev* __restrict__ st) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    st->phase = LM_RUN; st->host_reason = LM_HOST_NONE; st->end_tick = 0;
+    st->run_lin = st->resume_lin; st->run_solve = 1; st->resume_lin = 0;
 }
 
 // x <- x_new (and the camera constants, and the cost that bounds the fixed-point camera sums) after an accepted trial; or, at the

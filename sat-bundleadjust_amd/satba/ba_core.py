@@ -115,6 +115,17 @@ def get_engine(p, comm=None, rpc_f32=True):
     return cache[key]
 
 
+def cached_engine(p, world=1, rpc_f32=None):
+    """The engine get_engine has already built for p's current state with `world` ranks (rank 0), or None -- for callers that can
+    use a resident whole-problem handle but should not build (and upload) one just for themselves."""
+    cache = p.__dict__.get(_ENGINE_ATTR, {})
+    fp = _fingerprint(p)
+    for (rank, w, f32), key_fp in cache:
+        if key_fp == fp and rank == 0 and w == world and (rpc_f32 is None or f32 == bool(rpc_f32)):
+            return cache[((rank, w, f32), key_fp)]
+    return None
+
+
 def _frozen_vars(v, p):
     """
     Variable vector with frozen cameras / points restored to their initial values, as

@@ -153,7 +153,9 @@ def rm_outliers(err, p, predef_thr=None, min_thr=1.0, verbose=False, pts3d=None)
         pairs = list(p.pairs_to_triangulate)
         canonical = all(0 <= a < b < p.n_cam for a, b in pairs)
         pts = None
-        if pts3d is None and canonical and not os.environ.get("SATBA_TRI_UPLOAD"):
+        from . import ba_core
+
+        if pts3d is None and canonical and not os.environ.get("SATBA_TRI_UPLOAD") and ba_core.cached_engine(p) is not None:
             # one device call on the handle's RESIDENT observations (the mask goes up, the tracks do not go up again) gives both the
             # re-triangulated points and, per track, how many listed pairs apply to it: a track survives iff that count is positive
             # (pairs written i < j, as filter_C_using_pairs_to_triangulate requires)
@@ -163,7 +165,8 @@ def rm_outliers(err, p, predef_thr=None, min_thr=1.0, verbose=False, pts3d=None)
             ok = info["n_tri"] > 0
             pts = pts_all[ok]
         elif pts3d is None and canonical:
-            # (SATBA_TRI_UPLOAD=1: the same through the stand-alone entry point, which uploads the surviving tracks -- tests)
+            # no single-rank engine holds p's tracks (a sharded run caches only its (rank, world) engines; or nothing has run on p
+            # yet), or SATBA_TRI_UPLOAD=1 (tests): the same through the stand-alone entry point, which uploads the surviving tracks
             from .ft_triangulate import init_pts3d_from_observations
 
             cand = np.nonzero(two)[0]

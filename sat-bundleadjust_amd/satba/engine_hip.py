@@ -450,10 +450,10 @@ class HipEngine:
         return out
 
     def info(self):
-        v = np.zeros(18)
-        _check(self.lib, self.lib.satba_get_info(self._h, _ptr(v), 18))
+        v = np.zeros(19)
+        _check(self.lib, self.lib.satba_get_info(self._h, _ptr(v), 19))
         keys = ["ms_uploads", "ms_sizes", "ms_ell", "ms_pairs", "ms_create", "ell_len", "pair_entries", "pair_chunks", "unit_weights",
-                "camc_lds", "rpc_lds", "cam_sums_lds", "deterministic", "cm_chunks", "lin_grid", "fx_fallbacks", "device_loop", "chol_beside"]
+                "camc_lds", "rpc_lds", "cam_sums_lds", "deterministic", "cm_chunks", "lin_grid", "fx_fallbacks", "device_loop", "chol_beside", "chol_beside_timeouts"]
         return dict(zip(keys, v[: len(keys)]))
 
     def get_blocks(self):

@@ -107,14 +107,16 @@ def init_pts3d_from_observations(pts_ind, cam_ind, pts2d, n_pts, cameras, cam_mo
 
 def init_pts3d_resident(p, pairs_to_triangulate=None, cameras=None, remove=None, return_info=False):
     """
-    init_pts3d for the tracks of a BundleAdjustmentParameters object whose observations are already on the device (an engine exists or
-    is created for it: ba_core.get_engine) -- what ref:bundle_adjust/ba_outliers.py:89-93 needs right after the outlier rejection.
+    init_pts3d for the tracks of a BundleAdjustmentParameters object whose observations are already on the device (a single-rank
+    engine exists for it, ba_core.cached_engine; one is built when there is none -- callers that should not pay for that check
+    first, as ba_outliers.rm_outliers does: in a sharded run only the (rank, world) engines exist and a whole-problem upload per rank
+    would be the opposite of "resident") -- what ref:bundle_adjust/ba_outliers.py:89-93 needs right after the outlier rejection.
     remove: (K,) bool, observations to treat as absent (compute_obs_mask's mask).  cameras / pairs default to p's.
     Returns avg_pts3d (p.n_pts, 3) float32 (zero rows where no listed pair applies); with return_info also {"kernel_ms", "n_tri"}.
     """
     from . import ba_core
 
-    eng = ba_core.get_engine(p)
+    eng = ba_core.cached_engine(p) or ba_core.get_engine(p)
     cams = p.cameras if cameras is None else cameras
     pairs = p.pairs_to_triangulate if pairs_to_triangulate is None else pairs_to_triangulate
     tab = _camera_table(list(cams)[: p.n_cam], p.cam_model)

@@ -335,6 +335,7 @@ def subspace_model(engine, exchange, ga, gb, gc, jg_sq, reg):
 # ----------------------------------------------------------------------------- the loop on the device, several ranks
 
 LM_RUN, LM_DONE, LM_NEED_HOST, LM_NEED_SUB = 0, 1, 2, 3
+LM_HOST_FX, LM_HOST_CHOL, LM_HOST_NONFINITE = 1, 2, 3  # LmDev::host_reason (csrc/satba_lmdev.h)
 LM_RUN_AHEAD = 3  # csrc/satba_lmdev.h
 
 
@@ -396,19 +397,20 @@ def drive_device_loop(engine, comm, lam_floor=0.0, max_patterns=None, watchdog_s
 
 
 def trf_solve_sharded(engine, comm, ftol, xtol, gtol, max_nfev, loss, f_scale):
-    """The loop for several ranks with its decisions on the device (drive_device_loop).  Returns a Result, or None when the device
-    handed over to the host (overflow of the fixed-point camera sums, a factorisation that failed ten times, non-finite residuals):
-    the caller continues with the host loop from the point the device stopped at."""
+    """The loop for several ranks with its decisions on the device (drive_device_loop).  Returns (Result, state); the Result is None
+    when the device handed over to the host -- state["host_reason"]: overflow of the fixed-point camera sums (the caller switches
+    the summation route and continues with the host loop from the point the device stopped at, carrying state's counters), a
+    factorisation that failed ten times, non-finite residuals in the initial point (errors, as in the host loop)."""
     engine.lm_begin(ftol=ftol, xtol=xtol, gtol=gtol, max_nfev=max_nfev, loss=loss, f_scale=f_scale)
     nmax = max_nfev if max_nfev is not None else engine.n_total * 100
     drive_device_loop(engine, comm, 0.0, max_patterns=24 * nmax + 1000)
     st = engine.lm_state()
     if int(st["phase"]) != LM_DONE:
-        return None
+        return None, st
     status = int(st["status"]) if int(st["status"]) >= 0 else 0
     return Result(cost=st["cost"], optimality=st["g_norm"], nfev=int(st["nfev"]), njev=int(st["njev"]), status=status,
                   success=status > 0, message=TERMINATION_MESSAGES[status], iterations=int(st["iterations"]),
-                  initial_cost=st["initial_cost"])
+                  initial_cost=st["initial_cost"]), st
 
 
 # ----------------------------------------------------------------------------- the loop
@@ -424,6 +426,7 @@ def trf_solve(engine, comm=None, ftol=1e-8, xtol=1e-8, gtol=1e-8, max_nfev=None,
     all-reduces between the phases are issued from here.
     """
     comm = comm or SingleComm()
+    resume = None
     if native is None:
         # (the per-phase counts of `timers` only exist in this Python loop)
         native = comm.world == 1 and not getattr(comm, "always", False) and verbose < 2 and hasattr(engine, "solve_lm") and timers is None
@@ -444,15 +447,23 @@ def trf_solve(engine, comm=None, ftol=1e-8, xtol=1e-8, gtol=1e-8, max_nfev=None,
         if (hasattr(engine, "lm_part") and verbose < 2 and timers is None and not os.environ.get("SATBA_HOST_LOOP")
                 and engine.n_c <= 1024):
             engine.configure(loss, f_scale)
-            res = trf_solve_sharded(engine, comm, ftol, xtol, gtol, max_nfev, loss, f_scale)
+            res, dev_state = trf_solve_sharded(engine, comm, ftol, xtol, gtol, max_nfev, loss, f_scale)
             if res is not None:
                 if verbose >= 1:
                     print(res.message)
                     print("Function evaluations {}, initial cost {:.4e}, final cost {:.4e}, first-order optimality {:.2e}."
                           .format(res.nfev, res.initial_cost, res.cost, res.optimality))
                 return res
-            if getattr(engine, "camera_sums_fallback", None):
-                engine.camera_sums_fallback()  # (all ranks stop for the same reason: the flag travels in an all-reduced header)
+            # the device handed over (all ranks stop for the same reason: it follows from all-reduced headers)
+            reason = int(dev_state["host_reason"])
+            if reason == LM_HOST_NONFINITE:
+                raise ValueError("Residuals are not finite in the initial point.")
+            if reason == LM_HOST_CHOL:
+                raise RuntimeError("reduced camera system could not be factorised")
+            if reason == LM_HOST_FX and getattr(engine, "camera_sums_fallback", None):
+                engine.camera_sums_fallback()  # only this reason changes the summation route
+            if int(dev_state["nfev"]) > 0:
+                resume = dev_state  # the work done on the device counts: evaluations, trust radius, initial cost
     hdr = engine.hdr
     slots = slice(engine.HDR_FIXED, engine.HDR_FIXED + comm.world)
     if max_nfev is None:
@@ -487,15 +498,23 @@ def trf_solve(engine, comm=None, ftol=1e-8, xtol=1e-8, gtol=1e-8, max_nfev=None,
             engine.camera_sums_fallback()
 
     engine.configure(loss, f_scale)
-    h = front(None)
-    cost, g_norm, Delta = h[K_COST], h[K_GINF], h[K_DELTA]
-    if not np.isfinite(cost):
-        raise ValueError("Residuals are not finite in the initial point.")
-    nfev = njev = 1
-    initial_cost = cost
+    if resume is None:
+        h = front(None)
+        cost, g_norm, Delta = h[K_COST], h[K_GINF], h[K_DELTA]
+        if not np.isfinite(cost):
+            raise ValueError("Residuals are not finite in the initial point.")
+        nfev = njev = 1
+        initial_cost = cost
+    else:
+        # continue where the device-resident loop stopped: the linearisation it could not book (at the device's current x) is
+        # repeated here with the device's trust radius; x_scale's running maximum lives on the device and carries over by itself
+        Delta = float(resume["Delta"])
+        h = front(Delta)
+        cost, g_norm = h[K_COST], h[K_GINF]
+        nfev, njev, initial_cost = int(resume["nfev"]), int(resume["njev"]) + 1, float(resume["initial_cost"])
 
     status, iteration, step_norm, actual_reduction = None, 0, None, None
-    lm_iterations = 0
+    lm_iterations = 0 if resume is None else int(resume["iterations"])
     if verbose == 2:
         _print_header()
 

@@ -180,6 +180,7 @@ def test_rm_outliers_retriangulates_on_the_resident_tracks(gpu, monkeypatch):
     scene.pts2d[outl] += 40.0
     p = synth.make_params(scene, {"correction_params": ["R"], "n_cam_fix": 1})
     err = ba_core.compute_reprojection_error(ba_core.fun(p.params_opt, p), p.pts2d_w)
+    assert ba_core.cached_engine(p) is not None  # (fun built it: the resident path is the one that runs)
     new_r = ba_outliers.rm_outliers(err, p)
     monkeypatch.setenv("SATBA_TRI_UPLOAD", "1")
     new_u = ba_outliers.rm_outliers(err, p)

@@ -98,6 +98,37 @@ def test_oracle_scipy_driver_reproduces_tight_rpc_and_perspective(name):
     assert np.abs(e.get_x()[:n_c] - xt[:n_c]).max() < (1e-5 if p.cam_model == "rpc" else 1e-6) * np.abs(xt[:n_c]).max()
 
 
+@pytest.mark.parametrize("name,loss", [("affine_small_R", "linear"), ("affine_small_RT", "linear"), ("persp_small_R", "linear"),
+                                       ("affine_small_free", "linear")])
+def test_reference_forward_differences_displace_its_own_minimum(name, loss):
+    """
+    Round 5: why the parity tests hold the solver to the reference's 3-point run (tests/golden/solve_tight3.npz) and not to its default
+    forward-difference run.  (1) The reference's OWN two tight runs -- same `fun`, same scipy, jac="2-point" against jac="3-point" --
+    sit 5e-7 .. 3e-6 of |f| apart: that is the bias of a forward-difference Jacobian (relative step 1.5e-8), not of the solver
+    compared with it.  (2) The exact-Jacobian LM of this repository (host loop of satba/trf.py over the CPU oracle's engine: the
+    loop the device kernels are held bit-identical to) lands on the 3-point run to better than 1e-7 -- twenty times closer than the
+    reference is to itself.
+    """
+    from satba import trf
+
+    _, make_p, g, _ = cases.solve_case(name)
+    g3 = cases.golden("solve_tight3")
+    f2, f3 = g["tight_fun_" + loss], g3["fun_{}_{}".format(name, loss)]
+    own = np.linalg.norm(f2 - f3) / np.linalg.norm(f3)
+    assert 3e-7 < own < 5e-6, own
+    p = make_p()
+    eng = L.OracleEngine(p)
+    res = trf.trf_solve(eng, ftol=1e-15, xtol=1e-15, gtol=1e-15, max_nfev=300, loss=loss)
+    f = eng.residuals()
+    mine = np.linalg.norm(f - f3) / np.linalg.norm(f3)
+    assert mine < 1e-7 and mine < 0.05 * own, (mine, own)
+    assert abs(res.cost - g3["stats_{}_{}".format(name, loss)][0]) < 1e-9 * res.cost
+    if name not in cases.FLAT_CASES:
+        n_c = p.n_cam * p.n_params
+        x3 = g3["x_{}_{}".format(name, loss)]
+        assert np.abs(eng.get_x()[:n_c] - x3[:n_c]).max() < 1e-8 * np.abs(x3[:n_c]).max()
+
+
 def test_rpc_projection_against_reference_c():
     """oracle.rpc_projection and satba.RPCModel.projection vs the reference's own C evaluator (ref:c/rpc.c:442-452)."""
     lib_path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "librpc.so")

@@ -300,8 +300,8 @@ def golden_tight_rpc_persp():
 
 def golden_tight3():
     """
-    Round 5: the tight protocol with scipy's own jac="3-point" option for EVERY solve case that is not rpc (rpc has had these vectors
-    since round 2).  scipy's default forward differences (relative step 1.5e-8) put the stationary point of J_fd^T f = 0 a little
+    Round 5: the tight protocol with scipy's own jac="3-point" option for EVERY solve case (rpc had such vectors since round 2, in
+    solve_rpc_small_R.npz; the ones written here are converged further, see below).  scipy's default forward differences (relative step 1.5e-8) put the stationary point of J_fd^T f = 0 a little
     away from the minimiser of the reference's own `fun`; central differences (relative step 6e-6, error O(h^2) x third
     derivative) remove that bias, so these vectors say where the reference's cost function has its minimum -- which is what an
     exact-Jacobian solver must reproduce to 1e-6.  Separate file: the 2-point vectors of rounds 1-4 stay byte for byte.
@@ -313,15 +313,24 @@ def golden_tight3():
 
     out = {}
     for name, (model, M, N, opp, seed, d, losses) in cases.SOLVE_CASES.items():
-        if model == "rpc":
-            continue
         scene = synth.make_scene(model, M, N, opp, seed=seed, **cases.SCENE_KW.get(name, {}))
         for loss in losses:
             p = ref_params(scene, dict(d, reduce=False))
             A = ref.ba_core.build_jacobian_sparsity(p)
-            res3 = least_squares(ref.ba_core.fun, p.params_opt.copy(), jac="3-point", jac_sparsity=A, x_scale="jac", method="trf",
-                                 loss=loss, f_scale=1.0, ftol=1e-15, xtol=1e-15, gtol=1e-15, max_nfev=600,
-                                 tr_options={"atol": 1e-12, "btol": 1e-12}, args=(p,))
+            kw = dict(jac="3-point", jac_sparsity=A, x_scale="jac", method="trf", loss=loss, f_scale=1.0,
+                      tr_options={"atol": 1e-12, "btol": 1e-12})
+            if model == "rpc":
+                # rpc (the reference chain in float64, rpc_fun_f64): scipy's xtol test compares |dx| with xtol |x|, and |x| is
+                # dominated by ECEF coordinates (1e7 m) while the unknown angles are 1e-5 rad -- the tight run of round 2 stops with
+                # the angles 2e-10 rad (2.7e-6 relative) short of the minimum (its gradient there is 100 x the one at the point an
+                # exact LM reaches, and its cost higher: tools/tight_metrics.py).  Here the step and cost tests are switched off
+                # (None) and the same solver runs a fixed number of evaluations: the reference's cost function minimised as far as
+                # its own solver takes it.
+                res3 = least_squares(rpc_fun_f64(p), p.params_opt.copy(), ftol=None, xtol=None, gtol=1e-15,
+                                     max_nfev=60 if loss == "linear" else 200, **kw)
+            else:
+                res3 = least_squares(ref.ba_core.fun, p.params_opt.copy(), ftol=1e-15, xtol=1e-15, gtol=1e-15, max_nfev=600,
+                                     args=(p,), **kw)
             print(name, loss, "tight, 3-point FD: status", res3.status, "nfev", res3.nfev, "cost %.12f" % res3.cost,
                   "optimality %.3e" % res3.optimality, flush=True)
             key = name + "_" + loss
