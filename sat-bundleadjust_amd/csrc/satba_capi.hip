@@ -895,7 +895,7 @@ int satba_problem_create(const satba_problem_desc* d, satba_problem** out) {
             }
             if (const char* dc = getenv("SATBA_CM_CHUNKS")) chunks_w = chunks = std::max(1, std::min(256, atoi(dc)));  // experiments, tests
             p->cm_chunks = chunks; p->cm_chunks_w = chunks_w;
-            TRY(dev_alloc(p, &p->d_part3, (size_t)p->M * std::max(chunks, chunks_w) * cam_acc_len(p->NP)));
+            TRY(dev_alloc(p, &p->d_part3, (size_t)p->M * std::max(chunks, chunks_w) * (cam_acc_len(p->NP) + p->NP)));  // (+ NP: k_cam_sums' error words)
         }
         if (p->L.C > 1) TRY(dev_alloc(p, &p->d_pair_part, (size_t)p->L.C * std::max<long long>(p->L.n_pairs, 1) * p->NP * p->NP));
         TRY(schur_item_table(p));

@@ -856,10 +856,30 @@ struct CamMajor {
 };
 constexpr int LINC_THREADS = 256;
 
+// error-free addition (Knuth): hi + t = s + e exactly; the error is collected in lo
+__device__ __forceinline__ void two_sum_acc(double& hi, double& lo, double t) {
+    const double s = hi + t, bb = s - hi;
+    lo += (hi - (s - bb)) + (t - bb);
+    hi = s;
+}
+__device__ __forceinline__ void wave_sum2(double& hi, double& lo) {  // lane 0 ends up with the wave's (hi, lo)
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        const double oh = __shfl_down(hi, d), ol = __shfl_down(lo, d);
+        two_sum_acc(hi, lo, oh);
+        lo += ol;
+    }
+}
+
 // Full U_c = J_c^T J_c (upper triangle) and g_c = J_c^T f of the linearisation k_linearize has just stored (f, row scales,
 // RPC blocks), by a camera-major pass: grid (M, chunks), every thread accumulates cam_acc_len(NP) sums of its camera in
 // registers over a strided slice of the camera's list; fixed summation order.  Used (a) for the parity tests' view of the
 // full blocks, (b) SATBA_DETERMINISTIC runs, (c) camera counts whose accumulator table does not fit the LDS.
+// g_c is summed with compensation (round 5): every addition is error free (two_sum_acc), the errors travel in a second word through
+// the lanes, the waves and the chunk partials (part: cam_acc_len(NP) + NP doubles per (camera, chunk)) and are added once at the
+// end.  The gradient cancels to ~1e-9 of its terms at the solution; plain float64 sums left the tight affine_C2_R / soft_l1 solve
+// 1.3e-6 of |f| short of the minimiser the fixed-point sums of k_linearize (exact) reach to 6e-9 (the CPU oracle, plain sums, stops
+// at the same 1.3e-6).
 template <int MODEL, int NP>
 __global__ __launch_bounds__(LINC_THREADS) void k_cam_sums(ObsArgs a, CamMajor c, const double2* __restrict__ f, double* __restrict__ part) {
     SATBA_GATE(a.gate);
@@ -870,9 +890,11 @@ __global__ __launch_bounds__(LINC_THREADS) void k_cam_sums(ObsArgs a, CamMajor c
     const int lo = b + (int)(len * chunk / n_chunks), hi = b + (int)(len * (chunk + 1) / n_chunks);
     const double* cc = a.camc + (size_t)cam * CAMC;
     const double mc = (cam >= a.n_cam_fix) ? 1.0 : 0.0;
-    double acc[CU];
+    double acc[CU], glo[NP];
 #pragma unroll
     for (int k = 0; k < CU; ++k) acc[k] = 0.0;
+#pragma unroll
+    for (int k = 0; k < NP; ++k) glo[k] = 0.0;
     for (int i = lo + threadIdx.x; i < hi; i += LINC_THREADS) {
         const int pos = c.pos[i], q = c.pt[i], io = c.io[i];
         double2 ff;
@@ -907,20 +929,32 @@ __global__ __launch_bounds__(LINC_THREADS) void k_cam_sums(ObsArgs a, CamMajor c
 #pragma unroll
             for (int s = r; s < NP; ++s) acc[k++] += Jc[0][r] * Jc[0][s] + Jc[1][r] * Jc[1][s];
 #pragma unroll
-        for (int r = 0; r < NP; ++r) acc[k++] += Jc[0][r] * fs0 + Jc[1][r] * fs1;
+        for (int r = 0; r < NP; ++r, ++k) two_sum_acc(acc[k], glo[r], Jc[0][r] * fs0 + Jc[1][r] * fs1);
     }
-    __shared__ double s_red[LINC_THREADS / 64][CU];
+    constexpr int NTRI = NP * (NP + 1) / 2;
+    __shared__ double s_red[LINC_THREADS / 64][CU + NP];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
-    for (int k = 0; k < CU; ++k) {
+    for (int k = 0; k < NTRI; ++k) {
         const double t = wave_sum(acc[k]);
         if (lane == 0) s_red[wave][k] = t;
     }
+#pragma unroll
+    for (int r = 0; r < NP; ++r) {
+        wave_sum2(acc[NTRI + r], glo[r]);
+        if (lane == 0) { s_red[wave][NTRI + r] = acc[NTRI + r]; s_red[wave][CU + r] = glo[r]; }
+    }
     __syncthreads();
     if (threadIdx.x < CU) {
-        double t = 0.0;
-        for (int wv = 0; wv < LINC_THREADS / 64; ++wv) t += s_red[wv][threadIdx.x];
-        part[((size_t)cam * n_chunks + chunk) * CU + threadIdx.x] = t;
+        double* out = part + ((size_t)cam * n_chunks + chunk) * (CU + NP);
+        double t = 0.0, tl = 0.0;
+        if (threadIdx.x < NTRI) {
+            for (int wv = 0; wv < LINC_THREADS / 64; ++wv) t += s_red[wv][threadIdx.x];
+        } else {
+            for (int wv = 0; wv < LINC_THREADS / 64; ++wv) { two_sum_acc(t, tl, s_red[wv][threadIdx.x]); tl += s_red[wv][CU + threadIdx.x - NTRI]; }
+            out[CU + threadIdx.x - NTRI] = tl;
+        }
+        out[threadIdx.x] = t;
     }
 }
 
@@ -932,10 +966,19 @@ __global__ void k_cam_sums_finish(int M, int NP, int n_chunks, const double* __r
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= M * CU) return;
     const int cam = idx / CU, k = idx % CU;
+    const int ntri = NP * (NP + 1) / 2, W = CU + NP;  // k_cam_sums: cam_acc_len sums, then the error words of the g_c entries
+    if (k >= ntri) {
+        double t = 0.0, tl = 0.0;
+        for (int ch = 0; ch < n_chunks; ++ch) {
+            const double* row = part + ((size_t)cam * n_chunks + ch) * W;
+            two_sum_acc(t, tl, row[k]);
+            tl += row[CU + k - ntri];
+        }
+        gc[cam * NP + (k - ntri)] = t + tl;
+        return;
+    }
     double t = 0.0;
-    for (int ch = 0; ch < n_chunks; ++ch) t += part[((size_t)cam * n_chunks + ch) * CU + k];
-    const int ntri = NP * (NP + 1) / 2;
-    if (k >= ntri) { gc[cam * NP + (k - ntri)] = t; return; }
+    for (int ch = 0; ch < n_chunks; ++ch) t += part[((size_t)cam * n_chunks + ch) * W + k];
     int r = 0, rem = k;
     while (rem >= NP - r) { rem -= NP - r; ++r; }
     const int s = r + rem;
