@@ -131,6 +131,12 @@ struct satba_problem {
     double *d_part = nullptr, *d_part3 = nullptr, *d_pair_part = nullptr;
     int2* d_items = nullptr;  // (pair, chunk) work items of the Schur pair kernel in dispatch order
     SchurItem* d_item_desc = nullptr;
+    // weighted / robust runs of the affine and perspective models (Layout::w_fix, built on first use by ensure_wlayout): the merged
+    // records W and the item table with the diagonal items in front of every (camera row, chunk) group
+    double2* d_W = nullptr;
+    int2* d_items_w = nullptr;
+    SchurItem* d_item_desc_w = nullptr;
+    int n_item_blocks_w = 0;
     int2* d_items_merged = nullptr;           // one item per pair (all chunks), for the unit-weight kernels
     SchurItem* d_item_desc_merged = nullptr;
     int n_item_blocks_merged = 0;
@@ -152,6 +158,7 @@ struct satba_problem {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int* d_arrive = nullptr;   // (M + 2) x SCHUR_ARRIVE_STRIDE ints, zero between launches
     int* d_pair_cnt = nullptr; // weighted / robust runs: chunk items finished per camera pair (SchurArgs::pair_cnt), zero between launches
+    int* d_dg_cnt = nullptr;   // ... and diagonal items finished per camera (SchurArgs::dg_cnt)
     long long* d_ts = nullptr; // (tools, -DC3_STAMPS: time stamps of the last factorisation beside the pair kernel, printed when the handle goes)
     int arrive_epoch = 0;      // != 0 while a front with the factorisation beside it is being queued (launch_schur)
     bool beside_last = false;  // the last front ran that way
@@ -219,6 +226,9 @@ static int dev_alloc(satba_problem* p, T** out, size_t count) {
         }                                                                                                         \
     } while (0)
 
+// weighted / robust runs with recomputed Jacobians (affine, perspective): row scales and point records share the merged records W
+static bool wmode(const satba_problem* p) { return p->model != RPC && !(p->loss == 0 && p->unit_weights); }
+
 static ObsArgs obs_args(const satba_problem* p, bool at_new) {
     ObsArgs a;
     const Layout& L = p->L;
@@ -229,6 +239,10 @@ static ObsArgs obs_args(const satba_problem* p, bool at_new) {
     a.rpc = p->d_rpc;
     a.Jpm = at_new ? nullptr : p->d_Jpm;  // stored Jacobian blocks belong to the linearisation at x
     a.sc = (at_new || (p->loss == 0 && p->unit_weights)) ? nullptr : p->d_sc;
+    if (wmode(p)) {  // the scales live in W: sc_ofs[q] + k instead of ipt_ofs[q] + k (null until the first linearisation has built the layout)
+        a.sc = (at_new || !L.wl_ready) ? nullptr : p->d_W;
+        if (L.wl_ready) a.ipt_ofs = L.sc_ofs;
+    }
     a.K = p->K; a.P = L.P; a.n_slices = L.n_slices; a.M = p->M; a.N = p->N; a.n_c = p->n_c;
     a.n_cam_fix = p->n_cam_fix; a.n_pts_fix = p->n_pts_fix; a.loss = p->loss; a.f32 = p->f32;
     a.f_scale = p->f_scale;
@@ -239,7 +253,9 @@ static ObsArgs obs_args(const satba_problem* p, bool at_new) {
     a.sh = 0;  // lanes per point: set by the launchers of the kernels that support it
     return a;
 }
-static CamMajor cam_major(const satba_problem* p) { return CamMajor{p->L.cam_ofs, p->L.cm_pt, p->L.cm_pos, p->L.cm_io}; }
+static CamMajor cam_major(const satba_problem* p) {
+    return CamMajor{p->L.cam_ofs, p->L.cm_pt, p->L.cm_pos, (wmode(p) && p->L.wl_ready) ? p->L.cm_sc : p->L.cm_io};
+}
 
 static int grid_for(long long work, int block, int cap) {
     long long g = (work + block - 1) / block;
@@ -430,6 +446,11 @@ static SchurArgs schur_args(const satba_problem* p) {
     s.PV = reinterpret_cast<const double2*>(p->d_PV);
     s.pair_ofs = p->L.pair_ofs; s.pair_pts = p->L.pair_pts; s.pair_pi = p->L.pair_pi; s.pair_pj = p->L.pair_pj;
     s.pair_ij = p->L.pair_ij; s.pair_part = p->d_pair_part; s.n_chunks = p->L.C; s.items = p->d_items; s.desc = p->d_item_desc;
+    if (wmode(p) && p->L.wl_ready) {
+        s.PV = p->d_W; s.wmode = 1; s.zero_fix = p->L.zero_fix; s.n_dg = p->L.n_dg;
+        s.pair_rec = p->L.pair_rec; s.pair_kk = p->L.pair_kk; s.cm_rec = p->L.cm_rec; s.cm_sc = p->L.cm_sc; s.dg_part = p->d_part3;
+        s.items = p->d_items_w; s.desc = p->d_item_desc_w;
+    }
     return s;
 }
 
@@ -438,10 +459,17 @@ static int launch_schur(satba_problem* p, const ObsArgs& a, double* S, double* r
     CamMajor cm = cam_major(p);
     SchurArgs s = schur_args(p);
     const long long n_pairs = p->L.n_pairs;
-    // diagonal blocks (with J_c^T J_c) and right-hand side
-    const int dchunks = (a.sc && MODEL != RPC) ? p->cm_chunks_w : p->cm_chunks;
-    s.diag_xcd = (dchunks % 8 == 0 && !getenv("SATBA_NO_DIAG_XCD")) ? 1 : 0;
-    hipLaunchKernelGGL((k_schur_diag<MODEL, NP>), dim3(p->M, dchunks), dim3(LINC_THREADS), 0, p->stream, a, cm, s, p->d_part3);
+    // diagonal blocks (with J_c^T J_c) and right-hand side: a camera-major pass of its own -- or, weighted / robust runs on the merged
+    // records, items of the pair kernel in front of every (camera row, chunk) group, whose pair items then find the records in L2
+    const bool pairs_run = n_pairs > 0 && p->L.E > 0;
+    const bool dg_in_pairs = s.wmode && MODEL != RPC && pairs_run;
+    int dchunks = (a.sc && MODEL != RPC) ? p->cm_chunks_w : p->cm_chunks;
+    if (dg_in_pairs) dchunks = p->L.n_dg;
+    else {
+        if (s.wmode) cm.pt = p->L.cm_rec;  // (k_schur_diag on the merged records: piece offsets instead of point indices)
+        s.diag_xcd = (dchunks % 8 == 0 && !getenv("SATBA_NO_DIAG_XCD")) ? 1 : 0;
+        hipLaunchKernelGGL((k_schur_diag<MODEL, NP>), dim3(p->M, dchunks), dim3(LINC_THREADS), 0, p->stream, a, cm, s, p->d_part3);
+    }
     const int total = p->M * cam_acc_len(NP);
     const int nb_diag = (int)((std::max<long long>(8ll * total, p->hdr) + 255) / 256);
     // end of the phase: diagonal blocks, right-hand side, header (and the pairs' chunk partials, red_chunks > 1) in one launch
@@ -455,14 +483,21 @@ static int launch_schur(satba_problem* p, const ObsArgs& a, double* S, double* r
         p->s_scaled = scale;
     };
     if (p->arrive_epoch) {  // the factorisation waits beside this stream: diagonal blocks and right-hand side first, the pair kernel counts its items in
-        finish(1, true);
+        if (dg_in_pairs) {  // ... or they come out of the pair kernel as well (SchurArgs::dg_cnt): only the header is cleared here
+            const int keep = dchunks;
+            dchunks = 0;
+            finish(1, true);
+            dchunks = keep;
+            s.dg_cnt = p->d_dg_cnt; s.dg_lam = p->schur_lam; s.dg_lam_dev = p->schur_lam_dev; s.dg_lead = p->lead; s.dg_gc = p->d_gc;
+            s.dg_scale_inv = p->d_scale_inv; s.dg_rhs = rhs;
+        } else finish(1, true);
         s.arrive = p->d_arrive; s.arrive_epoch = p->arrive_epoch; s.pair_cnt = p->d_pair_cnt; s.fail = p->d_fail;
     }
     int red_chunks = 1;
     if (n_pairs > 0 && p->L.E > 0) {
         const bool merged = a.unit && p->d_item_desc_merged;  // one item per pair: straight into S, no partials
         if (merged) { s.desc = p->d_item_desc_merged; s.items = p->d_items_merged; s.n_chunks = 1; }
-        const dim3 igrid((unsigned)(merged ? p->n_item_blocks_merged : p->n_item_blocks));
+        const dim3 igrid((unsigned)(merged ? p->n_item_blocks_merged : (s.wmode ? p->n_item_blocks_w : p->n_item_blocks)));
         if (a.unit) hipLaunchKernelGGL((k_schur_pairs<MODEL, NP, true>), igrid, dim3(256), 0, p->stream, a, s, S);
         else hipLaunchKernelGGL((k_schur_pairs<MODEL, NP, false>), igrid, dim3(256), 0, p->stream, a, s, S);
         HIP_TRY(hipGetLastError());
@@ -587,6 +622,101 @@ static int schur_item_table(satba_problem* p) {
     // ... where the pairs alone fill the chip: with few cameras the chunks are what provides the parallelism (50 cameras: 1 225 pairs)
     const bool enough = p->L.n_pairs >= 8192 || (mg && atoi(mg) != 0);
     if (p->L.C > 1 && enough && !(mg && atoi(mg) == 0)) TRY(schur_item_table_build(p, true, &p->d_items_merged, &p->d_item_desc_merged, &p->n_item_blocks_merged));
+    return 0;
+}
+
+// Item table of the weighted / robust pair kernel on the merged records: as above (chunked items, rows dealt to the XCDs), with the
+// diagonal items of (camera i, chunk) -- dg_spc of them, one wave each over an equal share of the camera's entries in the chunk -- in
+// FRONT of the pair items (i, j > i) of that chunk: they pull the chunk's records of camera i into the XCD's L2, where the pair items
+// then find them.  The last camera has no pair items: its diagonal items form groups of their own.
+static int schur_item_table_w(satba_problem* p) {
+    const int M = p->M, C = p->L.C, X = 8, spc = p->L.dg_spc;
+    std::vector<std::vector<int2>> per(X);
+    std::vector<long long> load(X, 0);
+    const long long dg_weight = std::max<long long>(1, p->L.n_pairs > 0 && p->L.E > 0 ? (long long)((double)p->K / M / ((double)p->L.E / p->L.n_pairs)) : 1);
+    for (int i = 0; i < M; ++i) {
+        int x = 0;
+        for (int k = 1; k < X; ++k) if (load[k] < load[x]) x = k;
+        load[x] += (M - 1 - i) + dg_weight;
+        for (int ch = 0; ch < C; ++ch) {
+            for (int sub = 0; sub < spc; ++sub) per[x].push_back(make_int2(-2 - i, ch * spc + sub));
+            for (int j = i + 1; j < M; ++j) per[x].push_back(make_int2((int)pair_index(M, i, j), ch));
+            while (per[x].size() % 4) per[x].push_back(make_int2(-1, 0));
+        }
+    }
+    size_t slots = 0;
+    for (int x = 0; x < X; ++x) slots = std::max(slots, per[x].size() / 4);
+    std::vector<int2> table(std::max<size_t>(slots, 1) * X * 4, make_int2(-1, 0));
+    for (int x = 0; x < X; ++x)
+        for (size_t sl = 0; sl < per[x].size() / 4; ++sl)
+            for (int w = 0; w < 4; ++w) table[(sl * X + x) * 4 + w] = per[x][sl * 4 + w];
+    p->n_item_blocks_w = (int)(table.size() / 4);
+    TRY(dev_alloc(p, &p->d_items_w, table.size()));
+    HIP_TRY(hipMemcpyAsync(p->d_items_w, table.data(), sizeof(int2) * table.size(), hipMemcpyHostToDevice, p->stream));
+    HIP_TRY(hipStreamSynchronize(p->stream));  // (the host vector goes away)
+    TRY(dev_alloc(p, &p->d_item_desc_w, table.size()));
+    hipLaunchKernelGGL(k_schur_item_desc, dim3((unsigned)((table.size() + 255) / 256)), dim3(256), 0, p->stream, (long long)table.size(), p->d_items_w,
+                       p->L.pair_ij, p->L.pair_ofs, p->L.C, p->d_item_desc_w, p->L.dg_ofs, p->L.n_dg);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// The merged record layout of the weighted / robust runs (Layout::w_fix), built when the first such linearisation is queued: record
+// offsets from the track lengths (one scan), the pair and camera-major lists re-expressed as piece offsets, the diagonal items.
+static int ensure_wlayout(satba_problem* p) {
+    Layout& L = p->L;
+    if (L.wl_ready || !wmode(p)) return 0;
+    const int N = p->N, M = p->M;
+    hipStream_t st = p->stream;
+    const size_t Nz = (size_t)N + 1;
+    int *sz = nullptr, *wb = nullptr;
+    char* cub = nullptr;
+    size_t need = 0;
+    HIP_TRY(hipMalloc((void**)&sz, sizeof(int) * (Nz + 1)));
+    HIP_TRY(hipMalloc((void**)&wb, sizeof(int) * (Nz + 1)));
+    int rc = [&]() -> int {
+        TRY(dev_alloc(p, &L.w_fix, Nz)); TRY(dev_alloc(p, &L.sc_ofs, Nz));
+        HIP_TRY(hipMemsetAsync(sz, 0, sizeof(int) * (Nz + 1), st));
+        hipLaunchKernelGGL(k_lay_wsize, dim3((unsigned)((Nz + 255) / 256)), dim3(256), 0, st, N, L.pt_cnt, sz);
+        HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, need, sz, wb, (int)(Nz + 1), st));
+        HIP_TRY(hipMalloc((void**)&cub, need + 16));
+        HIP_TRY(hipcub::DeviceScan::ExclusiveSum(cub, need, sz, wb, (int)(Nz + 1), st));
+        hipLaunchKernelGGL(k_lay_wfix, dim3((unsigned)((Nz + 255) / 256)), dim3(256), 0, st, N, L.pt_cnt, sz, wb, L.w_fix, L.sc_ofs);
+        int h_len = 0, h_zero = 0;
+        HIP_TRY(hipMemcpyAsync(&h_len, wb + Nz, sizeof(int), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(&h_zero, L.w_fix + N, sizeof(int), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        // (32-bit piece offsets: 2^31 pieces are 32 GB of records; a shard has fewer than 2^31 observations)
+        if (h_len <= 0) return fail(SATBA_E_ARG, "the merged records of this shard exceed 2^31 pieces");
+        L.W_len = h_len; L.zero_fix = h_zero;
+        TRY(dev_alloc(p, &p->d_W, (size_t)L.W_len + 8));
+        HIP_TRY(hipMemsetAsync(p->d_W, 0, sizeof(double2) * ((size_t)L.W_len + 8), st));  // pads, the zero record; scales are 0 until a linearisation
+        const size_t Ez = (size_t)std::max<long long>(L.E, 1), Kz = (size_t)std::max<long long>(p->K, 1);
+        TRY(dev_alloc(p, &L.pair_rec, Ez)); TRY(dev_alloc(p, &L.pair_kk, Ez)); TRY(dev_alloc(p, &L.cm_rec, Kz)); TRY(dev_alloc(p, &L.cm_sc, Kz));
+        if (L.E > 0)
+            hipLaunchKernelGGL(k_lay_pair_w, dim3(grid_for(L.E, 256, 8192)), dim3(256), 0, st, L.E, L.pair_pts, L.pair_pi, L.pair_pj, L.ipt_ofs, L.pt_cnt,
+                               L.w_fix, L.pair_rec, L.pair_kk);
+        if (p->K > 0)
+            hipLaunchKernelGGL(k_lay_cm_w, dim3(grid_for(p->K, 256, 8192)), dim3(256), 0, st, p->K, L.cm_pt, L.cm_io, L.ipt_ofs, L.pt_cnt, L.w_fix,
+                               L.cm_rec, L.cm_sc);
+        // diagonal items: about 768 entries each (a dozen iterations of a wave; the pair items of the headline shape run five), at most 64
+        // per camera (k_schur_finish adds a camera's partials with eight threads)
+        const int C = L.C;
+        const long long per_group = p->K / std::max(1, M) / std::max(1, C);
+        int spc = (int)std::max<long long>(1, std::min<long long>((per_group + 767) / 768, std::max(1, 64 / C)));
+        if (const char* e = getenv("SATBA_DIAG_SPC")) spc = std::max(1, std::min(atoi(e), std::max(1, 64 / C)));  // experiments
+        L.dg_spc = spc; L.n_dg = C * spc;
+        TRY(dev_alloc(p, &L.dg_ofs, (size_t)M * L.n_dg + 1));
+        hipLaunchKernelGGL(k_lay_diag_items, dim3((unsigned)((M * C + 1 + 255) / 256)), dim3(256), 0, st, M, C, spc, std::max(N, 1), L.cam_ofs, L.cm_pt, L.dg_ofs);
+        HIP_TRY(hipGetLastError());
+        TRY(schur_item_table_w(p));
+        HIP_TRY(hipStreamSynchronize(st));
+        return 0;
+    }();
+    (void)hipFree(sz); (void)hipFree(wb);
+    if (cub) (void)hipFree(cub);
+    if (rc) return rc;
+    L.wl_ready = true;
     return 0;
 }
 
@@ -849,7 +979,8 @@ int satba_problem_create(const satba_problem_desc* d, satba_problem** out) {
         HIP_TRY(hipMemset(p->d_PV + (size_t)PV_STRIDE * p->N, 0, sizeof(double) * PV_STRIDE));
         TRY(dev_alloc(p, &p->d_dc, p->n_c)); TRY(dev_alloc(p, &p->d_dch, p->n_c));
         const size_t Kz = (size_t)std::max<long long>(K, 1) + 64;
-        TRY(dev_alloc(p, &p->d_f, Pz)); TRY(dev_alloc(p, &p->d_ftmp, Pz)); TRY(dev_alloc(p, &p->d_sc, Kz));
+        TRY(dev_alloc(p, &p->d_f, Pz)); TRY(dev_alloc(p, &p->d_ftmp, Pz));
+        if (p->model == RPC) TRY(dev_alloc(p, &p->d_sc, Kz));  // (affine / perspective: the scales live in the merged records W, ensure_wlayout)
         if (p->model == RPC) TRY(dev_alloc(p, &p->d_Jpm, Kz * jrow_stride(p->NP)));
         TRY(dev_alloc(p, &p->d_fail, 1 + CH_MAX_STEPS));  // [0] not-SPD flag, then the panel-step flags
         TRY(dev_alloc(p, &p->d_dinv, (size_t)((p->n_c + CH_NB - 1) / CH_NB) * CH_NB * CH_NB));
@@ -895,7 +1026,8 @@ int satba_problem_create(const satba_problem_desc* d, satba_problem** out) {
             }
             if (const char* dc = getenv("SATBA_CM_CHUNKS")) chunks_w = chunks = std::max(1, std::min(256, atoi(dc)));  // experiments, tests
             p->cm_chunks = chunks; p->cm_chunks_w = chunks_w;
-            TRY(dev_alloc(p, &p->d_part3, (size_t)p->M * std::max(chunks, chunks_w) * (cam_acc_len(p->NP) + p->NP)));  // (+ NP: k_cam_sums' error words)
+            // (+ NP: k_cam_sums' error words; 64: the diagonal items of the weighted / robust pair kernel, Layout::n_dg)
+            TRY(dev_alloc(p, &p->d_part3, (size_t)p->M * std::max(64, std::max(chunks, chunks_w)) * (cam_acc_len(p->NP) + p->NP)));
         }
         if (p->L.C > 1) TRY(dev_alloc(p, &p->d_pair_part, (size_t)p->L.C * std::max<long long>(p->L.n_pairs, 1) * p->NP * p->NP));
         TRY(schur_item_table(p));
@@ -1115,6 +1247,7 @@ int satba_linearize(satba_problem* p) {
     Range range_("satba:linearize");
     if (!p) return fail(SATBA_E_ARG, "null handle");
     HIP_TRY(hipSetDevice(p->device));
+    TRY(ensure_wlayout(p));
     const size_t nU = (size_t)p->M * p->NP * p->NP;
     const int n_clear = (int)(p->hdr + nU + p->n_c);  // header, U (only its diagonal is written), g_c
     if (p->cam_sums_lds) {
@@ -1185,9 +1318,11 @@ static int schur_impl(satba_problem* p, double lam, bool automatic, double Delta
     const bool pairs_run = p->L.n_pairs > 0 && p->L.E > 0;
     const double* lam_dev = automatic ? p->d_keep + 5 : nullptr;
     if (p->N > 0) {
+        const bool w = wmode(p) && p->L.wl_ready;  // the records go into the merged records W, behind the row scales k_linearize left there
         hipLaunchKernelGGL(k_vinv, dim3((p->N + VINV_THREADS - 1) / VINV_THREADS), dim3(VINV_THREADS), 0, p->stream, p->N, lam, automatic ? p->d_xb : nullptr, Delta, lam_floor,
-                           p->d_keep, p->d_V, p->d_scale_inv + p->n_c, p->d_Vinv, p->d_x + p->n_c, p->d_g + p->n_c, p->d_PV, p->L.perm, p->n_pts_fix,
-                           automatic ? p->Delta_dev : nullptr, automatic ? p->lam_force_dev : nullptr, p->gate);
+                           p->d_keep, p->d_V, p->d_scale_inv + p->n_c, p->d_Vinv, p->d_x + p->n_c, p->d_g + p->n_c, w ? reinterpret_cast<double*>(p->d_W) : p->d_PV,
+                           p->L.perm, p->n_pts_fix, automatic ? p->Delta_dev : nullptr, automatic ? p->lam_force_dev : nullptr, p->gate,
+                           w ? p->L.w_fix : (const int*)nullptr);
     } else if (automatic) {
         hipLaunchKernelGGL(k_lambda, dim3(1), dim3(1), 0, p->stream, p->d_xb, Delta, lam_floor, p->d_keep, p->Delta_dev, p->lam_force_dev, p->gate);
     }
@@ -1214,6 +1349,8 @@ static bool chol_beside_ok(const satba_problem* p) {
     const bool unit = p->loss == 0 && p->unit_weights;
     const char* mg = getenv("SATBA_SCHUR_MERGE");
     const bool enough = p->L.n_pairs >= 8192 || (mg && atoi(mg) != 0);
+    // weighted / robust (round 5): the pair kernel also carries the diagonal blocks and the right-hand side as items of its own, and
+    // their last one per camera adds them up (SchurArgs::dg_cnt)
     const bool items_ok = unit ? (p->d_item_desc_merged || p->L.C == 1) : (enough && p->model != RPC);
     return p->world == 1 && items_ok && p->L.n_pairs > 0 && p->L.E > 0 && p->n_c == p->M * p->NP && p->n_c > 128 && p->n_c <= 1024 && p->N > 0 &&
            !p->beside_off;
@@ -1228,6 +1365,7 @@ static void beside_disable(satba_problem* p) {
     (void)hipStreamSynchronize(p->chol_stream);
     (void)hipMemsetAsync(p->d_arrive, 0, sizeof(int) * (size_t)(p->M + 2) * SCHUR_ARRIVE_STRIDE, p->stream);
     (void)hipMemsetAsync(p->d_pair_cnt, 0, sizeof(int) * (size_t)std::max<long long>(p->L.n_pairs, 1), p->stream);
+    (void)hipMemsetAsync(p->d_dg_cnt, 0, sizeof(int) * (size_t)p->M, p->stream);
 }
 static bool beside_timed_out(satba_problem* p, const double* h) {
     if (!p->beside_last || !(h[4] >= 2.0)) return false;
@@ -1259,6 +1397,8 @@ static int front_schur_solve(satba_problem* p, bool automatic, double lam, doubl
         HIP_TRY(hipMemsetAsync(p->d_arrive, 0, sizeof(int) * (size_t)(p->M + 2) * SCHUR_ARRIVE_STRIDE, p->stream));
         TRY(dev_alloc(p, &p->d_pair_cnt, (size_t)std::max<long long>(p->L.n_pairs, 1)));
         HIP_TRY(hipMemsetAsync(p->d_pair_cnt, 0, sizeof(int) * (size_t)std::max<long long>(p->L.n_pairs, 1), p->stream));
+        TRY(dev_alloc(p, &p->d_dg_cnt, (size_t)p->M));
+        HIP_TRY(hipMemsetAsync(p->d_dg_cnt, 0, sizeof(int) * (size_t)p->M, p->stream));
     }
     const char* env_wgs = getenv("SATBA_CHOL_BESIDE_WGS");
     const int wgs = (env_wgs && atoi(env_wgs) > 0) ? atoi(env_wgs) : 32;
@@ -1280,6 +1420,7 @@ static int front_schur_solve(satba_problem* p, bool automatic, double lam, doubl
         g.ts = p->d_ts;
 #endif
         g.arrive = p->d_arrive; g.arr_M = p->M; g.np = p->NP; g.arr_epoch = g.epoch; g.si = p->d_scale_inv; g.rhs = rhs;
+        g.arr_extra = (wmode(p) && p->L.wl_ready) ? 1 : 0;  // (the pair kernel writes the diagonal blocks and the right-hand side, too: launch_schur)
         // 5 ms + ~10 x what the kernels in front of a tile's last producer take at HBM speed (hit lists and records: ~100 bytes per hit)
         g.arr_timeout = 500000 + (long long)((double)p->L.E * 100.0 / 6e12 * 1e8 * 10.0) + (long long)((double)p->K * 200.0 / 6e12 * 1e8 * 10.0);
         hipLaunchKernelGGL(k_chol_tiles, dim3(std::min(chol_tiles_grid(n, 1), wgs)), dim3(1024), c3_lds_bytes(), p->chol_stream, g, p->gate);

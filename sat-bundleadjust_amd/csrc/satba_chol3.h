@@ -61,12 +61,16 @@ struct C3Args {
     // ticks of the 100 MHz wall clock.  Round 4 counted spins (~0.3 - 1 s); the caller now passes a few milliseconds plus a
     // multiple of the pair kernel's expected duration, so that a fall-back to the sequential front costs ~10 ms
     long long arr_timeout = C3_ARRIVE_TIMEOUT;
+    // arr_extra = 1: the producer also writes the DIAGONAL block of camera c and its entries of the right-hand side, and counts that in
+    // (M - c counts for camera c instead of M - 1 - c): the right-hand side of a tile row is complete when the producers of the
+    // tile's own columns have counted in, and the chain takes it tile by tile (c3_chain_aux) instead of all at once at its start
+    int arr_extra = 0;
     const double* si = nullptr;
     const double* rhs = nullptr;
 };
 constexpr int C3_ARRIVE_STRIDE = 32;  // (= SCHUR_ARRIVE_STRIDE)
 
-struct C3Arrive { const int* arrive; int M, np, epoch, nap; long long timeout; };
+struct C3Arrive { const int* arrive; int M, np, epoch, nap; long long timeout; int extra; };
 
 constexpr size_t c3_lds_bytes() {
     return sizeof(double) * (3 * 8 * C3_BLK + 64 * C3_TBS + 64 + 64 + 128 + 512) + sizeof(int) * 64;
@@ -156,7 +160,7 @@ __device__ __forceinline__ bool c3_wait_arrive(const C3Arrive& r, int col_lo, in
         // lane 0: the word behind the last camera; lanes 1 ..: one camera each (64-column tiles: at most 22 with 3 unknowns per camera)
         for (int c = c_lo + lane - 1; c <= c_hi; c += 63) {
             if (lane == 0) { ok = (int)(c3_ld_flag(r.arrive + (size_t)C3_ARRIVE_STRIDE * r.M) - r.epoch) >= 0; break; }
-            if (c3_ld_flag(r.arrive + (size_t)C3_ARRIVE_STRIDE * c) < r.M - 1 - c) ok = false;
+            if (c3_ld_flag(r.arrive + (size_t)C3_ARRIVE_STRIDE * c) < r.M - 1 - c + r.extra) ok = false;
         }
         if (__all(ok)) return true;
         for (int t = 0; t < r.nap; ++t) __builtin_amdgcn_s_sleep(20);
@@ -611,7 +615,10 @@ __device__ __noinline__ void c3_chain_inv(int T, int* fail) {
 }
 
 // the right-hand side's wave (also publishes the step)
-__device__ __noinline__ void c3_chain_aux(double* A, int n, int T, int* fail, int* flags, int want1, int want2, double* b, const double* Cc, long long* ts) {
+// arr (arr->arrive != null and arr->extra): the right-hand side of tile row k + 1 >= 2 is read from rhs, scaled by si, once the producers
+// of that tile's columns have counted in (C3Args::arr_extra)
+__device__ __noinline__ void c3_chain_aux(double* A, int n, int T, int* fail, int* flags, int want1, int want2, double* b, const double* Cc, long long* ts,
+                                          const C3Arrive* arr, const double* rhs, const double* si) {
     extern __shared__ __attribute__((aligned(16))) double c3_lds[];
     const int lane = threadIdx.x & 63;
     const C3Lds l = c3_carve(c3_lds);
@@ -628,6 +635,12 @@ __device__ __noinline__ void c3_chain_aux(double* A, int n, int T, int* fail, in
         if (has_r) {
             if (k >= 1 && !c3_wait(flags + (k + 1) * T + (k - 1), want2, fail)) return;
             const int row = r0 + 64 + lane;
+            if (arr && arr->arrive && arr->extra && k >= 1) {
+                if (!c3_wait_arrive(*arr, r0 + 64, (r0 + 127 < n ? r0 + 127 : n - 1), fail)) return;
+                const int rc = row < n ? row : n - 1;
+                const double v = c3_ld(rhs + rc) / si[rc];
+                bn = (row < n) ? v : 0.0;
+            } else
             bn = (row < n) ? c3_ld(b + row) : 0.0;
             for (int m0 = 0; m0 < k; m0 += 8) {  // eight loads in flight
                 double cv[8];
@@ -699,7 +712,7 @@ __device__ __forceinline__ void c3_chain(const C3Args& g, int T) {
         int* s_ok = l.lf + 61;
         const int n = g.n;
         if (tid < 64) {
-            const C3Arrive r{g.arrive, g.arr_M, g.np, g.arr_epoch, g.nap, g.arr_timeout};
+            const C3Arrive r{g.arrive, g.arr_M, g.np, g.arr_epoch, g.nap, g.arr_timeout, g.arr_extra};
             C3_STAMP(g.ts, T * C3_TS + 0, tid == 0);
             const bool ok = c3_wait_arrive(r, 0, (n < 128 ? n : 128) - 1, g.fail);
             C3_STAMP(g.ts, T * C3_TS + 1, tid == 0);
@@ -715,7 +728,8 @@ __device__ __forceinline__ void c3_chain(const C3Args& g, int T) {
                 c3_st(pa, c3_ld(pa) / (g.si[row] * g.si[col]));
             }
         }
-        for (int i = tid; i < n; i += 1024) c3_st(g.b + i, c3_ld(g.rhs + i) / g.si[i]);
+        // (arr_extra: the entries of the later tile rows are not there yet -- c3_chain_aux takes them when their producers have counted in)
+        for (int i = tid; i < (g.arr_extra ? (n < 128 ? n : 128) : n); i += 1024) c3_st(g.b + i, c3_ld(g.rhs + i) / g.si[i]);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
@@ -733,7 +747,10 @@ __device__ __forceinline__ void c3_chain(const C3Args& g, int T) {
     else if (oth == 10) c3_chain_dnext<0>(g.A, g.n, T, g.fail, g.flags, want1, g.mirror, g.ts);
     else if (oth == 11) c3_chain_dnext<1>(g.A, g.n, T, g.fail, g.flags, want1, g.mirror, g.ts);
     else if (oth == 8) c3_chain_inv(T, g.fail);
-    else c3_chain_aux(g.A, g.n, T, g.fail, g.flags, want1, want2, g.b, g.Cc, g.ts);
+    else {
+        const C3Arrive arr{g.arrive, g.arr_M, g.np, g.arr_epoch, g.nap, g.arr_timeout, g.arr_extra};
+        c3_chain_aux(g.A, g.n, T, g.fail, g.flags, want1, want2, g.b, g.Cc, g.ts, &arr, g.rhs, g.si);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------- owners
@@ -830,7 +847,7 @@ __device__ __noinline__ void c3_owner(C3Args g, int T, int i, int j, int kind) {
     }
     auto load_arrived = [&]() -> bool {
         if (wave == 0) {
-            const C3Arrive r{g.arrive, g.arr_M, g.np, g.arr_epoch, g.nap, g.arr_timeout};
+            const C3Arrive r{g.arrive, g.arr_M, g.np, g.arr_epoch, g.nap, g.arr_timeout, g.arr_extra};
             const bool ok = c3_wait_arrive(r, c0, (c0 + 63 < n ? c0 + 63 : n - 1), g.fail);
             if (tid == 0) c3_lds_set(s_ok, ok ? 1 : 0);
         }

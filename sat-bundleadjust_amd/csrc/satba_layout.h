@@ -44,6 +44,21 @@ struct Layout {
     int2* pair_ij = nullptr;
     int *pair_pts = nullptr, *pair_pi = nullptr, *pair_pj = nullptr;
     long long* hit_ofs = nullptr;  // N + 1: running count of the k (k - 1) / 2 pair entries of the points before q
+    // Weighted / robust runs of the affine and perspective models (round 5, built on first use: wl_ready).  The point record of the
+    // Schur kernels and the Jacobian row scales of the point's observations share ONE variable-length record in the buffer W of
+    // 16-byte pieces, ending on a 128-byte line:
+    //     [ pad | s_0 s_1 .. s_{c-1} | X0 X1 | X2 v00 | v01 v02 | v11 v12 | v22 g0 | g1 g2 ]       c = track length
+    // so that a visit of camera (track position k) reads one contiguous run s_k .. g: ceil((c - k + 6) / 8) lines, 1.9 on
+    // average at ten observations per point, where the separate record (1 line) and io-ordered scale array (1.7) made 2.7.
+    // w_fix[q]: piece of X0 (w_fix[N]: an all-zero record); sc_ofs[q] = w_fix[q] - c: piece of s_0 (replaces ipt_ofs in the
+    // kernels that walk a point's observations); pair_rec / pair_kk: per pair-list entry w_fix of the point and the distances
+    // (c - k_i) | (c - k_j) << 16 of its two scales in front of it; cm_rec / cm_sc: per camera-major entry w_fix of the point and
+    // the piece of the observation's scale; dg_ofs: the camera-major lists cut into the diagonal items of k_schur_pairs,
+    // [(camera n_dg + chunk dg_spc + sub)], n_dg = C dg_spc per camera.
+    bool wl_ready = false;
+    long long W_len = 0;     // pieces, the zero record included
+    int zero_fix = 0, dg_spc = 1, n_dg = 1;
+    int *w_fix = nullptr, *sc_ofs = nullptr, *pair_rec = nullptr, *pair_kk = nullptr, *cm_rec = nullptr, *cm_sc = nullptr, *dg_ofs = nullptr;
 };
 
 // error word: 0 ok; otherwise (code << 32 | index of the first offender + 1 is not tracked: code only)
@@ -167,6 +182,55 @@ __global__ void k_lay_hits(int N, int M, const int* __restrict__ cnt, const int*
             ++at;
         }
     }
+}
+
+// ---- the merged record layout of the weighted / robust runs (Layout::w_fix ...)
+__global__ void k_lay_wsize(int N, const int* __restrict__ cnt, int* __restrict__ sz) {  // pieces of record q; entry N: the zero record
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q <= N) sz[q] = q < N ? ((cnt[q] + 6 + 7) & ~7) : 8;
+}
+__global__ void k_lay_wfix(int N, const int* __restrict__ cnt, const int* __restrict__ sz, const int* __restrict__ wb, int* __restrict__ w_fix,
+                           int* __restrict__ sc_ofs) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q > N) return;
+    const int f = wb[q] + sz[q] - 6;
+    w_fix[q] = f;
+    sc_ofs[q] = f - (q < N ? cnt[q] : 0);
+}
+__global__ void k_lay_pair_w(long long E, const int* __restrict__ pts, const int* __restrict__ pi, const int* __restrict__ pj,
+                             const int* __restrict__ ipt_ofs, const int* __restrict__ cnt, const int* __restrict__ w_fix,
+                             int* __restrict__ rec, int* __restrict__ kk) {
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < E; e += (long long)gridDim.x * blockDim.x) {
+        const int q = pts[e], io0 = ipt_ofs[q], c = cnt[q];
+        rec[e] = w_fix[q];
+        kk[e] = (c - (pi[e] - io0)) | ((c - (pj[e] - io0)) << 16);
+    }
+}
+__global__ void k_lay_cm_w(long long K, const int* __restrict__ cm_pt, const int* __restrict__ cm_io, const int* __restrict__ ipt_ofs,
+                           const int* __restrict__ cnt, const int* __restrict__ w_fix, int* __restrict__ cm_rec, int* __restrict__ cm_sc) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < K; i += (long long)gridDim.x * blockDim.x) {
+        const int q = cm_pt[i], f = w_fix[q];
+        cm_rec[i] = f;
+        cm_sc[i] = f - cnt[q] + (cm_io[i] - ipt_ofs[q]);
+    }
+}
+// dg_ofs[(cam C + ch) spc + s]: first camera-major entry of diagonal item (cam, ch, s): the entries of camera cam whose point lies in
+// point-range chunk ch (the chunks of the pair lists: chunk(q) = q C / N), cut into spc equal parts; one thread per (cam, ch)
+__global__ void k_lay_diag_items(int M, int C, int spc, int N, const int* __restrict__ cam_ofs, const int* __restrict__ cm_pt, int* __restrict__ dg_ofs) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t > M * C) return;
+    if (t == M * C) { dg_ofs[(size_t)M * C * spc] = cam_ofs[M]; return; }
+    const int cam = t / C, ch = t % C;
+    auto first_in = [&](int chunk) {  // first entry of the camera whose point's chunk is >= chunk
+        int lo = cam_ofs[cam], hi = cam_ofs[cam + 1];
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if ((int)((long long)cm_pt[mid] * C / N) < chunk) lo = mid + 1; else hi = mid;
+        }
+        return lo;
+    };
+    const int b = first_in(ch), e = first_in(ch + 1);
+    for (int s = 0; s < spc; ++s) dg_ofs[(size_t)t * spc + s] = b + (int)((long long)(e - b) * s / spc);
 }
 
 __global__ void k_lay_pair_ij(int M, int2* __restrict__ ij) {

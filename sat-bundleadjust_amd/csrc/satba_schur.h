@@ -62,7 +62,7 @@ __global__ __launch_bounds__(VINV_THREADS) void k_vinv(int N, double lam, const 
                                                        const double* __restrict__ scale_inv_p, double* __restrict__ Vinv,
                                                        const double* __restrict__ xp, const double* __restrict__ gp, double* __restrict__ PV,
                                                        const int* __restrict__ perm, int n_pts_fix, const double* __restrict__ Delta_dev,
-                                                       const double* __restrict__ lam_force, const int* gate) {
+                                                       const double* __restrict__ lam_force, const int* gate, const int* __restrict__ w_fix = nullptr) {
     SATBA_GATE(gate);
     if (Delta_dev) Delta = *Delta_dev;  // device-resident loop: the trust radius lives in the loop's state (<= 0: first iteration)
     if (lam_force && *lam_force > 0.0) {  // ... and so does the escalated damping after a failed factorisation (the prepare header is gone then)
@@ -112,6 +112,17 @@ __global__ __launch_bounds__(VINV_THREADS) void k_vinv(int N, double lam, const 
     row[3] = make_double2(mp * o3, mp * o4); row[4] = make_double2(mp * o5, g0); row[5] = make_double2(g1, g2);
     asm volatile("" ::: "memory");
     __builtin_amdgcn_wave_barrier();
+    if (w_fix) {  // merged records (Layout::w_fix): PV is the buffer W, record p's six pieces start at piece w_fix[p] -- 96 contiguous bytes per record
+        double2* out = reinterpret_cast<double2*>(PV);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int g = 64 * k + lane, r = g >> 3, q = g & 7;
+            const double2 v = t[9 * r + (q < 6 ? q : 0)];
+            const int at = w_fix[min(p0 + r, N - 1)];
+            if (q < 6 && r < n_here) out[(size_t)at + q] = v;
+        }
+        return;
+    }
     {
         double2* out = reinterpret_cast<double2*>(PV + PV_STRIDE * (size_t)p0);
 #pragma unroll
@@ -141,6 +152,28 @@ struct SchurArgs {
     const struct SchurItem* __restrict__ desc;  // the same items with everything a wave needs to start (k_schur_item_desc)
     int n_chunks;
     int diag_xcd = 0;                        // k_schur_diag: chunks dealt to the XCDs (see there)
+    // weighted / robust runs, affine and perspective cameras (Layout::w_fix): PV points at the merged records W (piece offsets instead
+    // of point indices), the pair lists are pair_rec (piece of X0 of the hit's record) and pair_kk (distances of its two scales in
+    // front of it, (c - k_i) | (c - k_j) << 16); zero_fix: an all-zero record.  The diagonal blocks and the right-hand side are items
+    // of k_schur_pairs then (item.i == item.j: the camera; lo .. hi: its entries in cm_rec / cm_sc; chunk: its slot among the
+    // camera's n_dg partials dg_part, which k_schur_finish adds up like k_schur_diag's)
+    int wmode = 0, zero_fix = 0, n_dg = 1;
+    const int* __restrict__ pair_rec = nullptr;
+    const int* __restrict__ pair_kk = nullptr;
+    const int* __restrict__ cm_rec = nullptr;
+    const int* __restrict__ cm_sc = nullptr;
+    double* __restrict__ dg_part = nullptr;
+    // ... beside the factorisation (arrive != null): the diagonal items publish their partials and count themselves in dg_cnt[camera] (M
+    // ints, zero between launches); the camera's LAST item in dispatch order (slot n_dg - 1: every other one has been started before
+    // it) waits for that count, adds the partials up the way k_schur_finish does (schur_diag_total / schur_diag_store: the same
+    // arithmetic in the same order), writes the diagonal block and the camera's entries of the right-hand side and counts the camera
+    // in `arrive` -- the factorisation expects M - c counts of camera c then (C3Args::arr_extra) and takes the right-hand side tile by tile
+    int* dg_cnt = nullptr;
+    double dg_lam = 0.0, dg_lead = 1.0;
+    const double* dg_lam_dev = nullptr;
+    const double* __restrict__ dg_gc = nullptr;
+    const double* __restrict__ dg_scale_inv = nullptr;
+    double* __restrict__ dg_rhs = nullptr;
     // factorisation running beside the pair kernel (satba_chol3.h, C3Args::arrive): every item publishes its block (write-through
     // stores, drain) and counts itself in the word of its camera row i; word M = arrive_epoch once the kernels in front of this one
     // (diagonal blocks, right-hand side) are complete.  Words SCHUR_ARRIVE_STRIDE ints apart (one per 128-byte line); null: off
@@ -187,13 +220,19 @@ __device__ inline int rs_index(int lane) {
 }
 
 __global__ void k_schur_item_desc(long long n_items, const int2* __restrict__ items, const int2* __restrict__ pair_ij,
-                                  const long long* __restrict__ pair_ofs, int n_chunks, SchurItem* __restrict__ desc) {
+                                  const long long* __restrict__ pair_ofs, int n_chunks, SchurItem* __restrict__ desc,
+                                  const int* __restrict__ dg_ofs = nullptr, int n_dg = 1) {
     const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n_items) return;
     const int2 it = items[e];
     SchurItem d;
-    if (it.x < 0) { d.lo = d.hi = 0; d.i = d.j = -1; d.pair = -1; d.chunk = 0; }
-    else {
+    if (it.x == -1) { d.lo = d.hi = 0; d.i = d.j = -1; d.pair = -1; d.chunk = 0; }
+    else if (it.x < -1) {  // diagonal item of camera -2 - it.x, slot it.y among its n_dg partials
+        const int cam = -2 - it.x;
+        d.lo = dg_ofs[(size_t)cam * n_dg + it.y];
+        d.hi = dg_ofs[(size_t)cam * n_dg + it.y + 1];
+        d.i = d.j = cam; d.pair = -1; d.chunk = it.y;
+    } else {
         const int2 ij = pair_ij[it.x];
         const int c0 = it.y < 0 ? 0 : it.y, c1 = it.y < 0 ? n_chunks : it.y + 1;  // chunk < 0: the whole list of the pair
         d.lo = pair_ofs[(long long)it.x * (n_chunks + 1) + c0];
@@ -233,6 +272,57 @@ __device__ __forceinline__ void schur_pair_publish(double* mine, size_t stride, 
     if (lane == 0) __hip_atomic_fetch_add(arrive_row, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// The sum of a camera's n_chunks partials of output k (k_schur_diag's, or the diagonal items' of k_schur_pairs), by eight neighbouring
+// lanes: lane `sub` adds every eighth partial, the eight sums are combined by an xor tree -- one fixed order, wherever it runs.
+// ATOMIC: the partials were published by other workgroups of the SAME launch (agent-scope loads).
+template <bool ATOMIC>
+__device__ __forceinline__ double schur_diag_total(const double* __restrict__ part, int cam, int n_chunks, int CU, int k, int sub, bool live) {
+    double t = 0.0;
+    if (live)
+        for (int ch = sub; ch < n_chunks; ch += 8) {
+            const double* q = part + ((size_t)cam * n_chunks + ch) * CU + k;
+            t += ATOMIC ? __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *q;
+        }
+    t += __shfl_xor(t, 1);
+    t += __shfl_xor(t, 2);
+    t += __shfl_xor(t, 4);
+    return t;
+}
+// ... and where it goes: output k < NP (NP + 1) / 2 is entry (r, q >= r) of the diagonal block (+ (lead) lam Dc^2 on the diagonal; both
+// triangles of the block are written), the others are the camera's entries of the right-hand side (+ (lead) g_c).  rhs_scaled (or null):
+// the system goes out in scaled variables (k_schur_finish)
+template <bool ATOMIC>
+__device__ __forceinline__ void schur_diag_store(int cam, int k, double t, int NP, int n_c, double lam, double lead, const double* __restrict__ gc,
+                                                 const double* __restrict__ scale_inv, double* __restrict__ S, double* __restrict__ rhs,
+                                                 double* __restrict__ rhs_scaled) {
+    auto st = [](double* q, double v) { if (ATOMIC) __hip_atomic_store(q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *q = v; };
+    const int ntri = NP * (NP + 1) / 2;
+    if (k >= ntri) {
+        const int col = cam * NP + (k - ntri);
+        const double v = lead * gc[col] + t;
+        st(rhs + col, v);
+        if (rhs_scaled) rhs_scaled[col] = v / scale_inv[col];
+        return;
+    }
+    int r = 0, rem = k;
+    while (rem >= NP - r) { rem -= NP - r; ++r; }
+    const int q = r + rem;
+    double v = 0.0;
+    if (q == r) {
+        const double si = scale_inv[cam * NP + r];
+        v = lead * lam * si * si;
+    }
+    double out = v + t;
+    if (rhs_scaled) out /= scale_inv[cam * NP + q] * scale_inv[cam * NP + r];
+    st(S + (size_t)(cam * NP + q) + (size_t)(cam * NP + r) * n_c, out);
+    if (q != r) st(S + (size_t)(cam * NP + r) + (size_t)(cam * NP + q) * n_c, out);
+}
+
+template <int MODEL, int NP, int THREADS>
+__device__ __forceinline__ void schur_diag_walk(const ObsArgs& a, const double2* __restrict__ base, const int* __restrict__ lst_rec,
+                                                const int* __restrict__ lst_sc, int rmul, int zero_rec, int cam, int lo, int hi, int tid,
+                                                double2* my, double (&acc)[cam_acc_len(NP)]);
+
 // 1-D grid, 4 waves per workgroup, one (pair, chunk) item each, taken from an item table in DISPATCH order that is built
 // for the chip's topology (satba_capi.hip: schur_item_table): workgroup b runs on XCD b % 8 (observed placement; only speed
 // depends on it), and every XCD works through the pairs (i, j) of ONE camera i and ONE point-range chunk at a time.  All those
@@ -247,7 +337,7 @@ __device__ __forceinline__ void schur_pair_publish(double* mine, size_t stride, 
 #define SATBA_PAIRS_OCC_U 3
 #endif
 template <int MODEL, int NP, bool UNITW>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((MODEL == AFFINE && UNITW) ? SATBA_PAIRS_OCC_U : 1, (MODEL == AFFINE && UNITW) ? SATBA_PAIRS_OCC_U : 3))) void k_schur_pairs(ObsArgs a, SchurArgs s, double* __restrict__ S) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((MODEL == AFFINE) ? SATBA_PAIRS_OCC_U : 1, (MODEL == AFFINE) ? SATBA_PAIRS_OCC_U : 3))) void k_schur_pairs(ObsArgs a, SchurArgs s, double* __restrict__ S) {
     SATBA_GATE(a.gate);
     __shared__ double2 s_coop[4 * 64 * 7];  // per wave: 64 records x 80 (112: with the scales) bytes, or 64 Jacobian rows x 112 (the cooperative gathers are transposed here)
     __shared__ unsigned s_idx[4][3 * 64];   // weighted / robust: the three gather indices of a wave's 64 hits
@@ -259,6 +349,57 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((MODEL == A
     const int j = __builtin_amdgcn_readfirstlane(dp->j);
     const int chunk = __builtin_amdgcn_readfirstlane(dp->chunk);
     const long long pair = __builtin_amdgcn_readfirstlane(dp->pair);
+    if constexpr (!UNITW && MODEL != RPC) {
+        if (i == j) {  // a diagonal item (SchurArgs::wmode): partial diagonal block and right-hand side of camera i over the entries lo .. hi of its list
+            constexpr int CU = cam_acc_len(NP), CPAD = CU <= 16 ? 16 : 32;
+            double dacc[CU];
+#pragma unroll
+            for (int k = 0; k < CU; ++k) dacc[k] = 0.0;
+            schur_diag_walk<MODEL, NP, 64>(a, s.PV, s.cm_rec, s.cm_sc, 1, s.zero_fix, i, (int)dp->lo, (int)dp->hi, lane,
+                                           reinterpret_cast<double2*>(reinterpret_cast<char*>(s_coop) + wave * (64 * 112)), dacc);
+            double flat[CPAD];
+            const double cam_mask = i < a.n_cam_fix ? 0.0 : 1.0;
+#pragma unroll
+            for (int e = 0; e < CPAD; ++e) flat[e] = (e < CU) ? dacc[e] : 0.0;
+            const double total = cam_mask * wave_reduce_scatter<CPAD>(flat, lane, 32);
+            const int e = rs_index<CPAD>(lane);
+            double* const mine = s.dg_part + ((size_t)i * s.n_dg + chunk) * CU + e;
+            const bool writer = (lane & (64 / CPAD - 1)) == 0 && e < CU;
+            if (!s.arrive) {  // k_schur_finish adds the partials up
+                if (writer) *mine = total;
+                return;
+            }
+            if (writer) __hip_atomic_store(mine, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (blockIdx.x == 0 && threadIdx.x == 0)  // (the first item of the launch: everything in front of this kernel on the stream is complete)
+                __hip_atomic_store(s.arrive + (size_t)SCHUR_ARRIVE_STRIDE * a.M, s.arrive_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int* cnt = s.dg_cnt + i;
+            if (chunk + 1 < s.n_dg) {
+                if (lane == 0) __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return;
+            }
+            if (lane == 0) {  // the camera's last item: every other one has been started before this one
+                const long long t0 = wall_clock64();
+                while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < s.n_dg - 1) {
+                    __builtin_amdgcn_s_sleep(4);
+                    if (wall_clock64() - t0 > 100000000ll) { atomicOr(s.fail, 2); break; }  // (1 s: a workgroup of this launch never ran)
+                }
+                __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            __builtin_amdgcn_wave_barrier();
+            const double lam = s.dg_lam_dev ? *s.dg_lam_dev : s.dg_lam;
+#pragma unroll 1
+            for (int o0 = 0; o0 < CU; o0 += 8) {  // eight outputs a pass, eight lanes an output (k_schur_finish's arrangement)
+                const int k = o0 + (lane >> 3), sub = lane & 7;
+                const bool live = k < CU;
+                const double t = schur_diag_total<true>(s.dg_part, i, s.n_dg, CU, live ? k : 0, sub, live);
+                if (live && sub == 0) schur_diag_store<true>(i, k, t, NP, a.n_c, lam, s.dg_lead, s.dg_gc, s.dg_scale_inv, S, s.dg_rhs, nullptr);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) __hip_atomic_fetch_add(s.arrive + (size_t)SCHUR_ARRIVE_STRIDE * i, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
+    }
     const double* cci = a.camc + (size_t)i * CAMC;
     const double* ccj = a.camc + (size_t)j * CAMC;
 
@@ -430,10 +571,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((MODEL == A
             const long long last = hi - 1;
             // the lists are streamed once: non-temporal loads keep them from displacing the point records in L2
             auto ld = [&](const int* arr, long long k) { return __builtin_nontemporal_load(arr + (k < last ? k : last)); };
-            auto ldp = [&](long long k) { const int v = ld(s.pair_pts, k); return (k < hi) ? v : a.N; };
+            // weighted / robust (SCL): the merged records (SchurArgs::wmode) -- `p` is the piece offset of the hit's record, `pi` the packed
+            // distances of its two scales in front of it
+            auto ldp = [&](long long k) { const int v = ld(SCL ? s.pair_rec : s.pair_pts, k); return (k < hi) ? v : (SCL ? s.zero_fix : a.N); };
+            auto ldk = [&](long long k) { const int v = ld(s.pair_kk, k); return (k < hi) ? v : 0x00010001; };
             // piece g = 64 t + lane of the 64 NPC pieces (64 records x NPC) in load t: record g / NPC, piece g % NPC.
             // Weighted / robust (SCL): NPC = 7 -- pieces 5 and 6 of a "record" are the row scales of the hit's two observations
-            // (a.sc, io order: a track's scales are contiguous, so the two usually share a line).  Gathered with lane = hit they were
+            // (round 5: they sit in the SAME variable-length record, in front of X0, Layout::w_fix; before that in a separate array in io order).  Gathered with lane = hit they were
             // two more instructions of 64 lines each per iteration; dealt to the lanes with the record pieces an instruction
             // touches ~9 records x 2 lines.
             constexpr int NPC = SCL ? 7 : 5;
@@ -456,7 +600,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((MODEL == A
                 if constexpr (SCL) {
                     // the three indices of every hit go through LDS (one bpermute per piece would need all three per source lane)
                     asm volatile("" ::: "memory");
-                    sidx[lane] = (unsigned)p * (unsigned)(PV_STRIDE / 2); sidx[64 + lane] = (unsigned)pi; sidx[128 + lane] = (unsigned)pj;
+                    sidx[lane] = (unsigned)p; sidx[64 + lane] = (unsigned)p - ((unsigned)pi & 0xffffu); sidx[128 + lane] = (unsigned)p - ((unsigned)pi >> 16);
                     asm volatile("" ::: "memory");
                     __builtin_amdgcn_wave_barrier();
                     const unsigned o0 = sidx[kind[0]], o1 = sidx[kind[1]], o2 = sidx[kind[2]], o3 = sidx[kind[3]], o4 = sidx[kind[4]],
@@ -529,7 +673,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((MODEL == A
             long long idx = lo + lane;
             int p_nxt = ldp(idx + 64);
             int pi_cur = 0, pj_cur = 0, pi_nxt = 0, pj_nxt = 0;
-            if constexpr (POS) {
+            if constexpr (SCL) {
+                pi_cur = ldk(idx); pi_nxt = ldk(idx + 64);
+            } else if constexpr (POS) {
                 pi_cur = ld(s.pair_pi, idx); pj_cur = ld(s.pair_pj, idx);
                 pi_nxt = ld(s.pair_pi, idx + 64); pj_nxt = ld(s.pair_pj, idx + 64);
             }
@@ -543,7 +689,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((MODEL == A
                 // indices run two iterations ahead, records one: neither latency is on the critical path
                 const int p_nn = ldp(idx + 128);
                 int pi_nn = 0, pj_nn = 0;
-                if constexpr (POS) { pi_nn = ld(s.pair_pi, idx + 128); pj_nn = ld(s.pair_pj, idx + 128); }
+                if constexpr (SCL) pi_nn = ldk(idx + 128);
+                else if constexpr (POS) { pi_nn = ld(s.pair_pi, idx + 128); pj_nn = ld(s.pair_pj, idx + 128); }
                 const Coop c_nxt = coop_load(p_nxt, pi_nxt, pj_nxt);
                 JCoop ji_nxt, jj_nxt;
                 if constexpr (JROWS) { ji_nxt = jcoop_load(pi_nxt); jj_nxt = jcoop_load(pj_nxt); }
@@ -600,56 +747,43 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((MODEL == A
 
 
 // Diagonal blocks and right-hand side: camera-major pass, registers only.
-//   S_ii += sum_p (Jc^T Jc - W_ip Vinv W_ip^T),   rhs_i -= sum_p W_ip Vinv g_p.   grid (M, chunks); part [M][chunks][CU]
+//   S_ii += sum_p (Jc^T Jc - W_ip Vinv W_ip^T),   rhs_i -= sum_p W_ip Vinv g_p.
 // The J_c^T J_c term is the U_c block, which the linearize kernel therefore does not have to accumulate.
-// grid (M, chunks): the workgroups of one chunk (the same slice of every camera's point-sorted list, i.e. about the same
-// point range) are dispatched together and share their point records in L2.
-template <int MODEL, int NP>
-__global__ __launch_bounds__(LINC_THREADS) void k_schur_diag(ObsArgs a, CamMajor c, SchurArgs s, double* __restrict__ part) {
-    SATBA_GATE(a.gate);
-    constexpr int CU = cam_acc_len(NP);
-    // s.diag_xcd (chunk count a multiple of 8): workgroup L = y M + x of the launch runs on XCD L % 8 (observed placement); XCD x takes
-    // the chunks = x (mod 8), every camera's slice of one chunk in a row, so that the records (and, weighted runs, the scale lines)
-    // of a point range are fetched by ONE XCD instead of by the ~6 that hold one of the point's cameras
-    int cam = blockIdx.x, chunk = blockIdx.y;
-    const int n_chunks = gridDim.y;
-    if (s.diag_xcd) {
-        const int L = blockIdx.y * gridDim.x + blockIdx.x, x = L & 7, q = L >> 3, M = gridDim.x;
-        cam = q % M; chunk = (q / M) * 8 + x;
-    }
-    const int b = c.cam_ofs[cam], e = c.cam_ofs[cam + 1];
-    const long long len = e - b;
-    const int lo = b + (int)(len * chunk / n_chunks), hi = b + (int)(len * (chunk + 1) / n_chunks);
+// schur_diag_walk: the entries lo .. hi - 1 of camera cam's list, THREADS threads (tid) striding over them, every thread
+// accumulating cam_acc_len(NP) sums in registers; shared by k_schur_diag (a workgroup per (camera, chunk)) and by the diagonal items
+// of k_schur_pairs (one wave).  base: the records (PV, or the merged records W of the weighted / robust runs, Layout::w_fix);
+// lst_rec: per entry the point (rmul = 8: fixed-stride records) or the record's piece offset (rmul = 1); lst_sc: per entry the index of
+// its row scales in a.sc (RPC: of its stored Jacobian rows); zero_rec: piece offset of an all-zero record; my: 64 x 7 double2 of LDS
+// per wave.
+template <int MODEL, int NP, int THREADS>
+__device__ __forceinline__ void schur_diag_walk(const ObsArgs& a, const double2* __restrict__ base, const int* __restrict__ lst_rec,
+                                                const int* __restrict__ lst_sc, int rmul, int zero_rec, int cam, int lo, int hi, int tid,
+                                                double2* my, double (&acc)[cam_acc_len(NP)]) {
     const double* cc = a.camc + (size_t)cam * CAMC;
-    double acc[CU];
-#pragma unroll
-    for (int k = 0; k < CU; ++k) acc[k] = 0.0;
     // Software pipeline: point indices run two iterations ahead, the point records one.  The records are gathered cooperatively
     // (see k_schur_pairs): the 384 16-byte pieces of a wave's 64 records are dealt to the lanes in order (load t, lane l: piece
     // (64 t + l) % 6 of record (64 t + l) / 6), so a gather instruction touches 11 lines instead of 64, and transposed through
     // LDS (record stride 7 pieces = 112 bytes: the 16 lanes of a ds_read_b128 phase fall into disjoint banks).  All threads run
     // the same number of iterations; threads past the end of the list are pointed at record N (zeros) and masked.
     struct Rec { double2 r0, r1, r2, r3, r4, r5; };
-    __shared__ double2 s_coop[(LINC_THREADS / 64) * 64 * 7];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    double2* my = s_coop + wave * (64 * 7);
+    const int lane = tid & 63;
     int rsrc[6];
     const double2* psrc[6];
     double2* wdst[6];
 #pragma unroll
     for (int t = 0; t < 6; ++t) {
         const int g = 64 * t + lane;
-        rsrc[t] = g / 6; psrc[t] = s.PV + g % 6; wdst[t] = my + (g / 6) * 7 + g % 6;
+        rsrc[t] = g / 6; psrc[t] = base + g % 6; wdst[t] = my + (g / 6) * 7 + g % 6;
     }
     struct Coop { double2 c0, c1, c2, c3, c4, c5; };
     auto coop_load = [&](int p) {
         Coop o;
-        o.c0 = psrc[0][(PV_STRIDE / 2) * (size_t)__shfl(p, rsrc[0])];
-        o.c1 = psrc[1][(PV_STRIDE / 2) * (size_t)__shfl(p, rsrc[1])];
-        o.c2 = psrc[2][(PV_STRIDE / 2) * (size_t)__shfl(p, rsrc[2])];
-        o.c3 = psrc[3][(PV_STRIDE / 2) * (size_t)__shfl(p, rsrc[3])];
-        o.c4 = psrc[4][(PV_STRIDE / 2) * (size_t)__shfl(p, rsrc[4])];
-        o.c5 = psrc[5][(PV_STRIDE / 2) * (size_t)__shfl(p, rsrc[5])];
+        o.c0 = psrc[0][(size_t)__shfl(p, rsrc[0])];
+        o.c1 = psrc[1][(size_t)__shfl(p, rsrc[1])];
+        o.c2 = psrc[2][(size_t)__shfl(p, rsrc[2])];
+        o.c3 = psrc[3][(size_t)__shfl(p, rsrc[3])];
+        o.c4 = psrc[4][(size_t)__shfl(p, rsrc[4])];
+        o.c5 = psrc[5][(size_t)__shfl(p, rsrc[5])];
         return o;
     };
     const double2* mine = my + lane * 7;
@@ -674,23 +808,24 @@ __global__ __launch_bounds__(LINC_THREADS) void k_schur_diag(ObsArgs a, CamMajor
 #pragma unroll
         for (int k = 0; k < 6; ++k) tr[k] = cc[k];
     }
-    const int n_it = (hi - lo + LINC_THREADS - 1) / LINC_THREADS;
+    const int n_it = (hi - lo + THREADS - 1) / THREADS;
     if (n_it > 0) {
-        auto ldp = [&](int q) { const int v = c.pt[q < hi ? q : hi - 1]; return q < hi ? v : a.N; };
-        int pos = lo + threadIdx.x;
-        int p_nxt = ldp(pos + LINC_THREADS);
+        // (a record is addressed by its first 16-byte piece: rmul = 8 for the fixed-stride records PV, 1 when the list holds piece offsets)
+        auto ldp = [&](int q) { const int v = lst_rec[q < hi ? q : hi - 1]; return q < hi ? rmul * v : zero_rec; };
+        int pos = lo + tid;
+        int p_nxt = ldp(pos + THREADS);
         Coop cur = coop_load(ldp(pos));
         // weighted / robust runs (affine, perspective): the row scales of the observation, io order.  Indices two iterations ahead,
         // scales one, like the records (round 2 loaded them where they were used: a dependent index -> scale chain in every
         // iteration, 0.28 ms against 0.13 for the unit-weight kernel)
         const bool scl = MODEL != RPC && a.sc != nullptr;
-        auto ldio = [&](int q) { return c.io[q < hi ? q : hi - 1]; };
-        int io_nxt = scl ? ldio(pos + LINC_THREADS) : 0;
+        auto ldio = [&](int q) { return lst_sc[q < hi ? q : hi - 1]; };
+        int io_nxt = scl ? ldio(pos + THREADS) : 0;
         double2 sc_cur = scl ? a.sc[ldio(pos)] : make_double2(1.0, 1.0);
-        for (int it = 0; it < n_it; ++it, pos += LINC_THREADS) {
+        for (int it = 0; it < n_it; ++it, pos += THREADS) {
             const Rec rc = transpose(cur);  // first: its wait covers only loads of the previous iteration
-            const int p_nn = ldp(pos + 2 * LINC_THREADS);
-            const int io_nn = scl ? ldio(pos + 2 * LINC_THREADS) : 0;
+            const int p_nn = ldp(pos + 2 * THREADS);
+            const int io_nn = scl ? ldio(pos + 2 * THREADS) : 0;
             const double2 sc_nxt = scl ? a.sc[io_nxt] : make_double2(1.0, 1.0);
             const Coop nxt = coop_load(p_nxt);
             __builtin_amdgcn_sched_barrier(0);
@@ -756,7 +891,7 @@ __global__ __launch_bounds__(LINC_THREADS) void k_schur_diag(ObsArgs a, CamMajor
                 double Jc[2][NP], Jp[2][3];
                 if constexpr (MODEL == RPC) {  // the blocks the linearize kernel stored (scales and masks included)
                     ObsEval<MODEL, NP, true> e2;
-                    e2.load_jac(a, c.io[posc]);
+                    e2.load_jac(a, lst_sc[posc]);
 #pragma unroll
                     for (int k = 0; k < NP; ++k) { Jc[0][k] = vm * e2.Jc[0][k]; Jc[1][k] = vm * e2.Jc[1][k]; }
 #pragma unroll
@@ -801,6 +936,33 @@ __global__ __launch_bounds__(LINC_THREADS) void k_schur_diag(ObsArgs a, CamMajor
             __builtin_amdgcn_sched_barrier(0);
         }
     }
+}
+
+// grid (M, chunks): the workgroups of one chunk (the same slice of every camera's point-sorted list, i.e. about the same
+// point range) are dispatched together and share their point records in L2.  part [M][chunks][CU]
+template <int MODEL, int NP>
+__global__ __launch_bounds__(LINC_THREADS) void k_schur_diag(ObsArgs a, CamMajor c, SchurArgs s, double* __restrict__ part) {
+    SATBA_GATE(a.gate);
+    constexpr int CU = cam_acc_len(NP);
+    // s.diag_xcd (chunk count a multiple of 8): workgroup L = y M + x of the launch runs on XCD L % 8 (observed placement); XCD x takes
+    // the chunks = x (mod 8), every camera's slice of one chunk in a row, so that the records (and, weighted runs, the scale lines)
+    // of a point range are fetched by ONE XCD instead of by the ~6 that hold one of the point's cameras
+    int cam = blockIdx.x, chunk = blockIdx.y;
+    const int n_chunks = gridDim.y;
+    if (s.diag_xcd) {
+        const int L = blockIdx.y * gridDim.x + blockIdx.x, x = L & 7, q = L >> 3, M = gridDim.x;
+        cam = q % M; chunk = (q / M) * 8 + x;
+    }
+    const int b = c.cam_ofs[cam], e = c.cam_ofs[cam + 1];
+    const long long len = e - b;
+    const int lo = b + (int)(len * chunk / n_chunks), hi = b + (int)(len * (chunk + 1) / n_chunks);
+    __shared__ double2 s_coop[(LINC_THREADS / 64) * 64 * 7];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double acc[CU];
+#pragma unroll
+    for (int k = 0; k < CU; ++k) acc[k] = 0.0;
+    schur_diag_walk<MODEL, NP, LINC_THREADS>(a, s.PV, c.pt, c.io, s.wmode ? 1 : PV_STRIDE / 2, s.wmode ? s.zero_fix : (PV_STRIDE / 2) * a.N, cam, lo, hi,
+                                             (int)threadIdx.x, s_coop + wave * (64 * 7), acc);
     if (MODEL != RPC && cam < a.n_cam_fix) {  // fixed camera (block-uniform); RPC: the stored blocks carry the mask
 #pragma unroll
         for (int k = 0; k < CU; ++k) acc[k] = 0.0;
@@ -867,35 +1029,12 @@ __global__ __launch_bounds__(256) void k_schur_finish(int M, int NP, int n_c, in
     const int gid = blockIdx.x * blockDim.x + threadIdx.x, idx = gid >> 3, sub = gid & 7;
     if (gid < hdr_len) xb[gid] = 0.0;
     if (gid < n_clear) clear[gid] = 0;
+    if (n_chunks <= 0) return;  // the diagonal blocks and the right-hand side are written by the pair kernel itself (SchurArgs::dg_cnt)
     const bool live = idx < M * CU;
     const int cam = live ? idx / CU : 0, k = live ? idx % CU : 0;
-    double t = 0.0;
-    if (live)
-        for (int ch = sub; ch < n_chunks; ch += 8) t += part[((size_t)cam * n_chunks + ch) * CU + k];
-    t += __shfl_xor(t, 1);
-    t += __shfl_xor(t, 2);
-    t += __shfl_xor(t, 4);
+    const double t = schur_diag_total<false>(part, cam, n_chunks, CU, k, sub, live);
     if (!live || sub != 0) return;
-    const int ntri = NP * (NP + 1) / 2;
-    if (k >= ntri) {
-        const int col = cam * NP + (k - ntri);
-        const double v = lead * gc[col] + t;
-        rhs[col] = v;
-        if (rhs_scaled) rhs_scaled[col] = v / scale_inv[col];
-        return;
-    }
-    int r = 0, rem = k;
-    while (rem >= NP - r) { rem -= NP - r; ++r; }
-    const int q = r + rem;
-    double v = 0.0;
-    if (q == r) {
-        const double si = scale_inv[cam * NP + r];
-        v = lead * lam * si * si;
-    }
-    double out = v + t;
-    if (rhs_scaled) out /= scale_inv[cam * NP + q] * scale_inv[cam * NP + r];
-    S[(size_t)(cam * NP + q) + (size_t)(cam * NP + r) * n_c] = out;
-    if (q != r) S[(size_t)(cam * NP + r) + (size_t)(cam * NP + q) * n_c] = out;
+    schur_diag_store<false>(cam, k, t, NP, n_c, lam, lead, gc, scale_inv, S, rhs, rhs_scaled);
 }
 
 }  // namespace satba

@@ -184,7 +184,8 @@ def run_ba_optimization(p, ls_params=None, verbose=False, plots=True):
     Solve the bundle adjustment problem on the GPU (ref:bundle_adjust/ba_core.py:244-332).
 
     Returns (vars_init, vars_ba, err_init, err_ba, iterations) where, as in the reference, `iterations` is the
-    number of residual evaluations (`nfev`).  `plots` is accepted and ignored.
+    number of residual evaluations (`nfev`).  `plots` (the reference's default: True) draws the reference's three panels
+    (plot_residuals_and_errors) and calls plt.show(), which returns at once on a non-interactive backend.
     """
     extra = ls_params or {}
     cfg = init_optimization_config(ls_params)
@@ -192,13 +193,20 @@ def run_ba_optimization(p, ls_params=None, verbose=False, plots=True):
         print("\nRunning bundle adjustment...")
         display_dict(cfg)
 
+    # ls_params["timings"] (a dict, optional): filled with the wall-clock seconds of the parts of this call -- what bench.py reports
+    # as `e2e`: the reference times the same region at ref:bundle_adjust/ba_core.py:283-299
+    tm = extra.get("timings")
+    clock = time.perf_counter
+    t_call = clock()
     comm = _distributed()
     eng = get_engine(p, comm, rpc_f32=extra.get("rpc_store_f32", True))
+    t_eng = clock()
     vars_init = p.params_opt.copy()
     x0 = _frozen_vars(np.array(vars_init, dtype=np.float64), p)
     eng.configure("linear", 1.0)
     eng.set_x(eng.shard.local_x(p, x0))
     residuals_init = sharding.assemble_residuals(p, eng.shard, eng.residuals(), comm)
+    t_init = clock()
     if verbose:
         flush_print("Shape of Jacobian sparsity: {}x{}".format(2 * p.n_obs, p.n_cam * p.n_params + 3 * p.n_pts))
 
@@ -206,14 +214,19 @@ def run_ba_optimization(p, ls_params=None, verbose=False, plots=True):
     res = trf.trf_solve(eng, comm, ftol=cfg["ftol"], xtol=cfg["xtol"], gtol=extra.get("gtol", 1e-8),
                         max_nfev=cfg["max_iter"], loss=cfg["loss"], f_scale=cfg["f_scale"],
                         verbose=cfg["verbose"] if comm.rank == 0 else 0)
+    t_solve = clock()
     vars_ba = sharding.assemble_x(p, eng.shard, eng.get_x(), comm)
     residuals_ba = sharding.assemble_residuals(p, eng.shard, eng.residuals(), comm)
+    t_back = clock()
     if verbose:
         flush_print("Optimization took {:.2f} seconds\n".format(time.time() - t0))
 
     iterations = res.nfev
     err_init = compute_reprojection_error(residuals_init, p.pts2d_w)
     err_ba = compute_reprojection_error(residuals_ba, p.pts2d_w)
+    if tm is not None:
+        tm.update(engine_s=t_eng - t_call, initial_residuals_s=t_init - t_eng, solve_s=t_solve - t_init, read_back_s=t_back - t_solve,
+                  host_errors_s=clock() - t_back, nfev=int(res.nfev))
     if verbose:
         flush_print("Reprojection error before BA (mean / median): {:.2f} / {:.2f}".format(
             np.mean(err_init), np.median(err_init)))
@@ -226,6 +239,11 @@ def run_ba_optimization(p, ls_params=None, verbose=False, plots=True):
             flush_print("    - cam {:3} - {:5} obs - (mean before / mean after): {:.2f} / {:.2f}".format(
                 c, n_per_cam[c], mean_init[c], mean_ba[c]))
         print("\n")
+
+    if plots and comm.rank == 0:
+        plot_residuals_and_errors(residuals_init, residuals_ba, err_init, err_ba)
+    if tm is not None:
+        tm["total_s"] = clock() - t_call
 
     if extra.get("return_result", False):
         res["x"], res["fun"] = vars_ba, residuals_ba
@@ -260,6 +278,30 @@ def _pyplot():
     import matplotlib.pyplot as plt
 
     return plt
+
+
+def plot_residuals_and_errors(residuals_init, residuals_ba, err_init, err_ba, show=True, max_points=2000000):
+    """
+    The figure at the end of the reference's run_ba_optimization (ref:bundle_adjust/ba_core.py:321-330): residual vectors before and
+    after, and the two histograms of the reprojection error (40 bins; the second on the range of the first).  Beyond max_points
+    residuals the first panel draws every n-th one (the reference draws all of them -- 20 million line segments at the headline
+    size); the histograms always see every observation.  Returns the figure.
+    """
+    plt = _pyplot()
+    residuals_init, residuals_ba = np.asarray(residuals_init), np.asarray(residuals_ba)
+    step = max(1, int(np.ceil(residuals_init.size / max_points)))
+    fig, f = plt.subplots(1, 3, figsize=(15, 3))
+    f[0].plot(residuals_init[::step])
+    f[0].plot(residuals_ba[::step])
+    f[0].title.set_text("Residuals before and after BA")
+    f[1].hist(err_init, bins=40)
+    f[1].title.set_text("Reprojection error before BA")
+    f[2].hist(err_ba, bins=40, range=(err_init.min(), err_init.max()) if np.size(err_init) else None)
+    f[2].title.set_text("Reprojection error after BA")
+    if show:
+        plt.show()
+        plt.close(fig)  # (a pipeline calls this once per solve)
+    return fig
 
 
 def save_histogram_of_errors(img_path, err_init, err_ba, plot=False):

@@ -324,3 +324,25 @@ def test_asan_build_of_the_abi_shim_raises_no_report():
         pytest.skip("ASan build absent (make -C sat-bundleadjust_amd/csrc asan_check)")
     out = subprocess.run([drv], capture_output=True, text=True, timeout=120, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0"))
     assert out.returncode == 0 and "abi_driver ok" in out.stdout and "AddressSanitizer" not in out.stderr, out.stderr[-2000:]
+
+
+def test_plots_of_run_ba_optimization_are_the_reference_panels(monkeypatch):
+    """ref:bundle_adjust/ba_core.py:321-330 (`plots=True`, the reference's default): three panels -- residuals before / after, the two
+    histograms of the reprojection error with 40 bins, the second on the range of the first."""
+    import matplotlib
+
+    matplotlib.use("Agg")
+    from satba import ba_core
+
+    rng = np.random.default_rng(0)
+    r0, r1 = rng.normal(size=400), 0.1 * rng.normal(size=400)
+    e0, e1 = np.abs(rng.normal(size=200)), 0.1 * np.abs(rng.normal(size=200))
+    fig = ba_core.plot_residuals_and_errors(r0, r1, e0, e1, show=False)
+    ax = fig.axes
+    assert [a.get_title() for a in ax] == ["Residuals before and after BA", "Reprojection error before BA", "Reprojection error after BA"]
+    assert len(ax[0].lines) == 2 and np.array_equal(ax[0].lines[0].get_ydata(), r0) and np.array_equal(ax[0].lines[1].get_ydata(), r1)
+    assert len(ax[1].patches) == 40 and len(ax[2].patches) == 40
+    assert abs(ax[2].patches[0].get_x() - e0.min()) < 1e-12 and abs(ax[2].patches[-1].get_x() + ax[2].patches[-1].get_width() - e0.max()) < 1e-12
+    import matplotlib.pyplot as plt
+
+    plt.close(fig)

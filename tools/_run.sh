@@ -1,5 +1,7 @@
 set -x
-mkdir -p gpurun_out/r5b
-timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -q -x --timeout 300 -k "tight or cam_sums or blocks or repeat" > gpurun_out/r5b/pytest.log 2>&1; tail -5 gpurun_out/r5b/pytest.log
-timeout 600 python -m pytest tests/test_gpu_layout.py -m gpu -q --timeout 300 -k "serialised or beside" > gpurun_out/r5b/pytest2.log 2>&1; tail -8 gpurun_out/r5b/pytest2.log
-SATBA_DETERMINISTIC=1 python tools/tight_metrics.py > gpurun_out/r5b/tight_cm.txt 2>&1; tail -12 gpurun_out/r5b/tight_cm.txt
+mkdir -p gpurun_out/r5f
+timeout 1200 python -m pytest tests/test_gpu_layout.py tests/test_gpu_parity.py -m gpu -q --timeout 300 -k "beside or tight or many_times or cholesky" > gpurun_out/r5f/pytest.log 2>&1; tail -15 gpurun_out/r5f/pytest.log
+tools/gpu.sh r5f_soft bench --cpu-sample-pts 0 --loss soft_l1
+SATBA_DEVICE_LOOP=1 tools/gpu.sh r5f_soft_dev bench --cpu-sample-pts 0 --loss soft_l1
+SATBA_CHOL_BESIDE=0 tools/gpu.sh r5f_soft_seq bench --cpu-sample-pts 0 --loss soft_l1
+tools/gpu.sh r5f_lin bench --cpu-sample-pts 0
