@@ -233,6 +233,7 @@ def main():
     ap.add_argument("--cpu-c3", action="store_true", help="also run the measured C3 CPU baseline (max_nfev=3, ~10 min)")
     ap.add_argument("--backend", default="nccl", help="collective backend for several ranks: nccl (= RCCL; what the scaling runs use) | gloo (tests)")
     ap.add_argument("--share-gpu", action="store_true", help="tests: all ranks on GPU 0 (a one-GPU box; needs --backend gloo)")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the wall clock of the drop-in call (ba_core.run_ba_optimization) after the timed loop")
     ap.add_argument("--camera-major", action="store_true", help="form the per-camera sums with the camera-major float64 pass from the "
                     "start (SATBA_FLAG_CAMERA_MAJOR_SUMS: the route the fixed-point sums fall back to)")
     args = ap.parse_args()
@@ -456,7 +457,16 @@ def main():
             # every reduction has a fixed order or is integer arithmetic: repeated runs give the same bits on both routes
             "deterministic": True, "camera_sums": "fixed_point_lds" if info["cam_sums_lds"] else "camera_major_pass",
             "fixed_point_fallbacks": int(info["fx_fallbacks"]),
-            "host_driver": driver, "restart_every": restart, "solve_shipped_tolerances": solve_stats,
+            "host_driver": driver,
+            "host_driver_reason": ("device-resident loop (satba_lm_run): the library's default for this shape and loss" if ticks else
+                                   "several ranks: tick parts with the all-reduces queued between them" if driver == "device" else
+                                   "host loop: the library's default for a robust loss from 4 M observations on (three iterations in ten pause "
+                                   "for the degenerate-subspace pattern, which the host queues: 411-420 it/s on the device against 427-438), "
+                                   "or forced by --driver / SATBA_HOST_LOOP / SATBA_DEVICE_LOOP"),
+            # the factorisation beside the pair kernel in the last front: 1 ran that way, 0 not applicable (several ranks, few cameras,
+            # switched off), -1 a wait timed out and the handle fell back to one kernel after the other (`value` is then ~10 % lower)
+            "chol_beside": int(info["chol_beside"]), "chol_beside_timeouts": int(info["chol_beside_timeouts"]),
+            "restart_every": restart, "solve_shipped_tolerances": solve_stats,
             "config": {"workload": "{}: {} cams x {} pts x {} obs, {}, correction {}, 1 fixed camera, seed 1"
                        .format(args.shape, n_cam, n_pts, p.n_obs, model, "+".join(corr)),
                        "sharding": "points over {} rank(s)".format(world),
@@ -464,11 +474,12 @@ def main():
             "obs_per_sec_residual_jacobian": world * K_loc / t_lin,
             # achieved / frac: SURVEY 8d's algorithmic bytes (48 K + 96 N: a throughput-equivalent, the kernel no longer moves all
             # of them); *_as_built: the bytes this kernel has to move; achieved_counter: the bytes the PMC counters saw it move
-            "roofline": {"bound": bound, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            # (bound and the as-built fraction first: `frac` is the throughput equivalent and must not be read without them)
+            "roofline": {"bound": bound, "frac_as_built": rate_as_built / HBM_PEAK_GBPS,
+                         "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "achieved_counter": rate_counter,
                          "compulsory_bytes_as_built": comp_bytes, "achieved_as_built": rate_as_built,
-                         "frac_as_built": rate_as_built / HBM_PEAK_GBPS,
                          "kernel": "k_linearize",
                          "algorithmic_bytes_per_launch": alg_bytes, "ms_per_launch": 1e3 * t_lin, "launches_timed": n_lin,
                          "ms_per_launch_back_to_back": kern["linearize"]},
@@ -480,6 +491,23 @@ def main():
             "accepted_steps": st["accepted"], "interior_2d_steps": st.get("interior", 0), "final_cost": st["cost"], "scene_gen_s": t_gen,
             "launch_patterns_executed": int(ls["ticks"]) if ls else None,  # > steps when a factorisation had to be repeated with more damping
         }
+        if world == 1 and not args.no_e2e:
+            # The drop-in call a user of the reference makes: ba_core.run_ba_optimization(p, ls_params) (ref:bundle_adjust/ba_core.py:244-332;
+            # the reference times the solve inside it at :283-299).  Wall clock of the first call -- engine creation: upload of the four
+            # observation arrays, layout construction on the device -- and of a warm one (cached engine), split into its parts; the
+            # solve is the one under the shipped tolerances from x0 (nfev evaluations), not the fixed-work loop timed above.
+            from satba import ba_core
+
+            eng.close()  # (the benchmark's own handle: the call below builds the one a caller would get)
+            e2e = {"call": "ba_core.run_ba_optimization(p, {loss, verbose: 0}, False, False)"}
+            for which in ("first", "warm"):
+                tm = {}
+                t0 = time.perf_counter()
+                ba_core.run_ba_optimization(p, {"loss": args.loss, "verbose": 0, "timings": tm}, False, False)
+                tm["wall_s"] = time.perf_counter() - t0
+                tm["host_overhead_frac"] = 1.0 - tm["solve_s"] / tm["wall_s"]
+                e2e[which] = tm
+            out["e2e"] = e2e
         if args.cpu_sample_pts > 0 and world == 1:
             out["cpu_baseline"] = cpu_baseline(scene, min(args.cpu_sample_pts, n_pts), corr, full_c3=args.cpu_c3)
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]

@@ -239,6 +239,12 @@ int satba_lm_poll(satba_problem* p, int64_t* out, int32_t n);
 int satba_outliers(satba_problem *p, const double *err, double predef_thr, double min_thr, double *cam_thr, uint8_t *remove,
                    int64_t *n_removed);
 
+/* ba_core.compute_reprojection_error(ba_core.fun(x, p), p.pts2d_w) (ref:bundle_adjust/ba_core.py:335-349 on :157-183) at the current
+ * x without the residual vector crossing the bus: host_err (K doubles, caller's observation order) = || f_k / w_k ||_2, the
+ * reference's operations with their roundings (bit-identical to the host formula); host_cost (optional): 0.5 |f|^2.  What
+ * ref:bundle_adjust/ba_core.py:277,303-304 computes before and after the solve.                                                  */
+int satba_reprojection_errors(satba_problem *p, double *host_err, double *host_cost);
+
 /* device-side copy of the current point (no host transfer): restore == 0 keeps x, restore != 0 returns to the kept x, as
  * satba_set_x with the same vector would.  bench.py restarts its solve with it; a caller can use it to retry a solve. */
 int satba_snapshot_x(satba_problem *p, int32_t restore);

@@ -1752,12 +1752,14 @@ static bool lm_device_loop_ok(const satba_problem* p) {
     const bool off = getenv("SATBA_HOST_LOOP") != nullptr;  // A/B runs and the tests' comparison of the two loops (read per call)
     return !off && p->world == 1 && p->n_c <= 1024;
 }
-// ... and whether it pays: its three extra launches per iteration (two decisions, the copy of the accepted point) cost what the two
-// header reads of the host loop cost at ~1.4 ms per iteration (200 x 1 M x 10 M: 681 against 696 it/s; soft_l1 353 / 372), and
-// much less below (50 x 100 k x 1 M: 2 580 / 2 500; 10 x 5 k x 30 k: 6 320 / 5 380).  SATBA_DEVICE_LOOP=1 / 0 forces the choice.
+// ... and whether it pays.  Round 5, 200 x 1 M x 10 M: linear loss 846 it/s on the device against 837 with the host's two header reads
+// per iteration (the factorisation beside the pair kernel took the dense solve off the critical path, and with it the slack that hid
+// the reads); soft_l1 411 - 420 against 427 - 438: three iterations in ten pause for the degenerate-subspace pattern there, which the
+// host has to notice and queue (LM_NEED_SUB: the ticks queued behind the pause pass empty).  Below 4 M observations the device loop
+// wins for every loss (50 x 100 k x 1 M: 2 580 / 2 500; 10 x 5 k x 30 k: 6 320 / 5 380, round 3).  SATBA_DEVICE_LOOP=1 / 0 forces the choice.
 static bool lm_device_loop_pays(const satba_problem* p) {
     if (const char* e = getenv("SATBA_DEVICE_LOOP")) return atoi(e) != 0;
-    return p->K < 4000000;
+    return p->loss == 0 || p->K < 4000000;
 }
 
 int satba_lm_state(satba_problem* p, double* out, int32_t n);

@@ -407,6 +407,10 @@ __global__ void k_gather_obs(long long K, const int* __restrict__ obs_pos, const
     for (long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x; o < K; o += (long long)gridDim.x * blockDim.x) out[o] = f[obs_pos[o]];
 }
 
+__global__ void k_gather_obs1(long long K, const int* __restrict__ obs_pos, const double* __restrict__ v, double* __restrict__ out) {
+    for (long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x; o < K; o += (long long)gridDim.x * blockDim.x) out[o] = v[obs_pos[o]];
+}
+
 // ------------------------------------------------------------------------------------------------ K1 residuals
 // ba_core.fun (ref:bundle_adjust/ba_core.py:157-183).  *cost = 0.5 * sum rho.  f (ELL order) may be null (cost only).
 // UNITW: every weight is 1 and the loss is linear (the weight array is not read: 8 of 28 streamed bytes per observation)

@@ -15,10 +15,14 @@ namespace satba {
 // err[pos] = | |f / w| |_2 of the residual pair (ref:bundle_adjust/ba_core.py:335-349), ELL order
 __global__ void k_out_err_ell(int P, const int* __restrict__ e_cam, const double2* __restrict__ f, const double* __restrict__ w,
                               double* __restrict__ err) {
+    // no contraction: HIP's __dmul_rn / __dadd_rn are plain operators, and a * a + b * b fused into fma(a, a, b * b) differs from
+    // numpy's two products and one sum in the last bit (round 5: the errors are returned to the caller in place of the host formula)
+#pragma clang fp contract(off)
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < P; i += gridDim.x * blockDim.x) {
         if (e_cam[i] < 0) continue;
         const double a = fabs(__ddiv_rn(f[i].x, w[i])), b = fabs(__ddiv_rn(f[i].y, w[i]));
-        err[i] = __dsqrt_rn(__dadd_rn(__dmul_rn(a, a), __dmul_rn(b, b)));
+        const double aa = a * a, bb = b * b;
+        err[i] = __dsqrt_rn(aa + bb);
     }
 }
 // camera-major copy of the errors: from ELL order (src_is_ell) or from the caller's observation order through obs_pos^-1

@@ -418,6 +418,34 @@ def test_tight_solve_matches_tight_scipy_reference(gpu, monkeypatch, name, route
             assert rel(vars_ba[:n_c], xt[:n_c]) < (5e-3 if rpc else 1e-6)
 
 
+@pytest.mark.parametrize("name", ["affine_R_fix", "persp_RT", "rpc_RT"])
+def test_device_reprojection_errors_are_the_host_formula_bit_for_bit(gpu, name):
+    """satba_reprojection_errors (what run_ba_optimization returns as err_init / err_ba when no residual vector is asked for): the
+    reference's compute_reprojection_error on the reference's fun, operation for operation -- equal to the host formula on the
+    downloaded residuals in every bit, weights (ref_cam_weight 2.5 in affine_R_fix) and the float32 store of the rpc chain included."""
+    _, p, g = cases.fun_case(name)
+    eng = ba_core.get_engine(p)
+    v = ba_core._frozen_vars(g["v"][1].copy(), p)
+    eng.configure("soft_l1", 1.0)  # (the errors are those of the plain residuals whatever the handle is configured for)
+    eng.set_x(v)
+    e_dev = eng.reprojection_errors()
+    e_host = ba_core.compute_reprojection_error(eng.residuals(), p.pts2d_w)
+    assert e_dev.shape == e_host.shape and np.array_equal(e_dev, e_host)
+    assert np.array_equal(e_host, ba_core.compute_reprojection_error(ba_core.fun(v, p), p.pts2d_w))
+
+
+def test_run_ba_optimization_errors_do_not_depend_on_the_residual_download(gpu):
+    """The five return values with and without the residual vectors on the host (return_result / plots ask for them)."""
+    _, make_p, _, _ = cases.solve_case("affine_small_R")
+    a = ba_core.run_ba_optimization(make_p(), {"verbose": 0}, False, False)
+    tm = {}
+    b = ba_core.run_ba_optimization(make_p(), {"verbose": 0, "return_result": True, "timings": tm}, False, False)
+    for x, y in zip(a, b[:5]):
+        assert np.array_equal(x, y)
+    assert np.array_equal(b[3], ba_core.compute_reprojection_error(b[5].fun, make_p().pts2d_w))
+    assert {"engine_s", "initial_residuals_s", "solve_s", "read_back_s", "host_errors_s", "total_s"} <= set(tm)
+
+
 @pytest.mark.parametrize("name", ["affine_small_R", "persp_small_R", "affine_C2_R"])
 def test_default_tolerances_behave_like_reference(gpu, name):
     """As shipped (ftol 1e-4): both solvers stop early and path-dependently; compare statistics, not parameters."""

@@ -1,7 +1,9 @@
-set -x
-mkdir -p gpurun_out/r5f
-timeout 1200 python -m pytest tests/test_gpu_layout.py tests/test_gpu_parity.py -m gpu -q --timeout 300 -k "beside or tight or many_times or cholesky" > gpurun_out/r5f/pytest.log 2>&1; tail -15 gpurun_out/r5f/pytest.log
-tools/gpu.sh r5f_soft bench --cpu-sample-pts 0 --loss soft_l1
-SATBA_DEVICE_LOOP=1 tools/gpu.sh r5f_soft_dev bench --cpu-sample-pts 0 --loss soft_l1
-SATBA_CHOL_BESIDE=0 tools/gpu.sh r5f_soft_seq bench --cpu-sample-pts 0 --loss soft_l1
-tools/gpu.sh r5f_lin bench --cpu-sample-pts 0
+tools/gpu.sh r5h tests
+grep -E "^FAILED|^ERROR" gpurun_out/r5h/pytest_gpu.log | head -30
+tools/gpu.sh r5h_lin bench --cpu-sample-pts 0
+python - <<'PY'
+import json
+d=json.loads(open('gpurun_out/r5h_lin/bench.json').read().strip().splitlines()[-1])
+print({k:d[k] for k in ('host_driver','chol_beside','value')}); print(json.dumps(d['e2e'])[:1200])
+PY
+tools/gpu.sh r5h_soft bench --cpu-sample-pts 0 --loss soft_l1
