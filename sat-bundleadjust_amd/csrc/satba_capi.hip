@@ -126,7 +126,6 @@ struct satba_problem {
     bool prof_lin = false;                      // satba_profile_linearize: event pairs around k_linearize
     std::vector<hipEvent_t> prof_ev;            // start, stop, start, stop, ...
     size_t prof_used = 0;
-    double2* d_sc = nullptr;                  // Jacobian row scales of the current linearisation, io order
     double* d_Jpm = nullptr;                  // RPC: Jacobian blocks of the current linearisation, io order
     double *d_part = nullptr, *d_part3 = nullptr, *d_pair_part = nullptr;
     int2* d_items = nullptr;  // (pair, chunk) work items of the Schur pair kernel in dispatch order
@@ -238,7 +237,7 @@ static ObsArgs obs_args(const satba_problem* p, bool at_new) {
     a.camc = at_new ? p->d_camc_new : p->d_camc;
     a.rpc = p->d_rpc;
     a.Jpm = at_new ? nullptr : p->d_Jpm;  // stored Jacobian blocks belong to the linearisation at x
-    a.sc = (at_new || (p->loss == 0 && p->unit_weights)) ? nullptr : p->d_sc;
+    a.sc = nullptr;  // (RPC: the row scales ride in the stored D', ObsEval::store_jac)
     if (wmode(p)) {  // the scales live in W: sc_ofs[q] + k instead of ipt_ofs[q] + k (null until the first linearisation has built the layout)
         a.sc = (at_new || !L.wl_ready) ? nullptr : p->d_W;
         if (L.wl_ready) a.ipt_ofs = L.sc_ofs;
@@ -345,11 +344,11 @@ static int launch_trial(satba_problem* p, double c0, double c1, const double* v0
     return 0;
 }
 
-// which instantiation of k_linearize a run takes: 0 unit weights + linear loss (not RPC: its Jacobian store carries the
-// masks), 1 linear loss, 2 soft_l1 specialised (not RPC: registers), 3 generic robust
+// which instantiation of k_linearize a run takes: 0 unit weights + linear loss (not RPC), 1 linear loss, 2 soft_l1 specialised at compile
+// time, 3 generic robust
 static int lin_variant(const satba_problem* p) {
     if (p->loss == 0) return (p->unit_weights && p->model != RPC) ? 0 : 1;
-    return (p->loss == SATBA_LOSS_SOFT_L1 && p->model != RPC) ? 2 : 3;
+    return p->loss == SATBA_LOSS_SOFT_L1 ? 2 : 3;  // (RPC: the compile-time soft_l1 keeps the GENERIC formulas, robust(..., fast_soft = false): same bits, fewer registers)
 }
 
 template <int MODEL, int NP, bool CL, bool RL>
@@ -367,12 +366,12 @@ static int launch_lin(satba_problem* p, const ObsArgs& a) {
     if (p->cam_sums_lds) {
         if (v == 0) { if constexpr (MODEL != RPC) SATBA_LIN_LAUNCH(false, false, true, true, false); }
         else if (v == 1) SATBA_LIN_LAUNCH(false, false, false, true, BIGL);
-        else if (v == 2) { if constexpr (MODEL != RPC) SATBA_LIN_LAUNCH(true, true, false, true, false); }
+        else if (v == 2) SATBA_LIN_LAUNCH(true, true, false, true, BIGL);
         else SATBA_LIN_LAUNCH(true, false, false, true, true);
     } else {
         if (v == 0) { if constexpr (MODEL != RPC) SATBA_LIN_LAUNCH(false, false, true, false, false); }
         else if (v == 1) SATBA_LIN_LAUNCH(false, false, false, false, BIGL);
-        else if (v == 2) { if constexpr (MODEL != RPC) SATBA_LIN_LAUNCH(true, true, false, false, false); }
+        else if (v == 2) SATBA_LIN_LAUNCH(true, true, false, false, BIGL);
         else SATBA_LIN_LAUNCH(true, false, false, false, true);
     }
 #undef SATBA_LIN_LAUNCH
@@ -387,11 +386,11 @@ static int raise_lin_limits(satba_problem* p) {
     TRY(raise_lds_limit(k_linearize<MODEL, NP, false, CL, RL, false, false, false>, lds));
     TRY(raise_lds_limit(k_linearize<MODEL, NP, true, CL, RL, false, false, true>, lds));
     TRY(raise_lds_limit(k_linearize<MODEL, NP, true, CL, RL, false, false, false>, lds));
+    TRY(raise_lds_limit(k_linearize<MODEL, NP, true, CL, RL, true, false, true>, lds));
+    TRY(raise_lds_limit(k_linearize<MODEL, NP, true, CL, RL, true, false, false>, lds));
     if constexpr (MODEL != RPC) {
         TRY(raise_lds_limit(k_linearize<MODEL, NP, false, CL, RL, false, true, true>, lds));
         TRY(raise_lds_limit(k_linearize<MODEL, NP, false, CL, RL, false, true, false>, lds));
-        TRY(raise_lds_limit(k_linearize<MODEL, NP, true, CL, RL, true, false, true>, lds));
-        TRY(raise_lds_limit(k_linearize<MODEL, NP, true, CL, RL, true, false, false>, lds));
     }
     TRY(raise_lds_limit(k_residual<MODEL, NP, CL, RL, true, false>, table_bytes(p)));
     TRY(raise_lds_limit(k_residual<MODEL, NP, CL, RL, false, false>, table_bytes(p)));
@@ -980,7 +979,6 @@ int satba_problem_create(const satba_problem_desc* d, satba_problem** out) {
         TRY(dev_alloc(p, &p->d_dc, p->n_c)); TRY(dev_alloc(p, &p->d_dch, p->n_c));
         const size_t Kz = (size_t)std::max<long long>(K, 1) + 64;
         TRY(dev_alloc(p, &p->d_f, Pz)); TRY(dev_alloc(p, &p->d_ftmp, Pz));
-        if (p->model == RPC) TRY(dev_alloc(p, &p->d_sc, Kz));  // (affine / perspective: the scales live in the merged records W, ensure_wlayout)
         if (p->model == RPC) TRY(dev_alloc(p, &p->d_Jpm, Kz * jrow_stride(p->NP)));
         TRY(dev_alloc(p, &p->d_fail, 1 + CH_MAX_STEPS));  // [0] not-SPD flag, then the panel-step flags
         TRY(dev_alloc(p, &p->d_dinv, (size_t)((p->n_c + CH_NB - 1) / CH_NB) * CH_NB * CH_NB));

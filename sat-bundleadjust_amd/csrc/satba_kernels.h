@@ -47,10 +47,11 @@ constexpr int SATBA_HDR_FX = 5;  // linearize header: a term of the fixed-point 
 constexpr int SATBA_K_FX = 7;    // ... and its place among the kept scalars (header slot SATBA_HDR_KEEP + 7 after satba_solve)
 constexpr double FX_MAGIC = 6755399441055744.0;
 constexpr unsigned long long FX_MAGIC_BITS = 0x4338000000000000ull;
-// row stride (doubles) of the stored Jacobian blocks (RPC): 2 np + 6 used.  np = 3: 12 doubles in a 128-byte row -- one line per
-// gathered row instead of 1.75 with 96-byte rows (k_schur_pairs<RPC> sits on the L1-miss path); np = 6: 18 doubles in 192 bytes
-// (always two lines instead of up to three)
-__host__ __device__ constexpr int jrow_stride(int np) { return 2 * np + 6 <= 16 ? 16 : 24; }
+// RPC: what a linearisation stores per observation for the passes behind it (io order): D' = diag(row scales) d(col,row)/dX', 2 x 3 =
+// six doubles in a 64-byte row (half a line; never straddles one).  The passes rebuild Jc = mc D' dR(X - T - C), Jp = mp D' R from it
+// (rpc_jac_from_d: ~45 multiply-adds).  Rounds 1 - 4 stored the blocks Jc | Jp themselves, 128 bytes (3 parameters) or 192 bytes (6) per
+// observation: the pair kernel gathered two such rows per hit.
+__host__ __device__ constexpr int jrow_stride(int) { return 8; }
 
 // Device-resident LM loop (satba_lmdev.h): the host queues a fixed pattern of kernels per iteration without knowing whether the
 // previous trial step was accepted; every kernel of the pattern starts by reading its gate -- a word of the loop's state in device
@@ -70,7 +71,7 @@ struct ObsArgs {
     const double* __restrict__ x;        // variable vector [cameras | internal points] whose POINT part is used
     const double* __restrict__ camc;     // M x CAMC camera constants built from the same vector
     const double* __restrict__ rpc;      // M x 90 or null
-    double* __restrict__ Jpm;            // RPC only (else null): K x (2 NP + 6) Jacobian blocks Jc | Jp of the current
+    double* __restrict__ Jpm;            // RPC only (else null): K x jrow_stride: D' = row-scaled d(col,row)/dX' of the current
                                          // linearisation, io order; written by the linearize kernel and read by every later
                                          // pass (the RPC chain costs 2-3 kflop per evaluation)
     double2* __restrict__ sc;            // weighted / robust runs (else null): K Jacobian row scales (w js0, w js1) of the
@@ -116,13 +117,18 @@ struct ObsEval {
     double Jc[2][NP];
     double Jp[2][3];
     double sw[2];     // Jacobian row scales w * js (before the fixed-camera / fixed-point masks)
+    double Dr[2][3];  // RPC with JAC: d(col,row)/dX' (eval: unscaled; store_jac scales it)
 
     // cc: the camera's constant record, tab: its RPC table (global memory or LDS copies); mp: 0 for a fixed point
     __device__ inline void eval(const ObsArgs& a, int cam, double mp, const double* cc, const double* tab, const double2 ob,
                                 const double w, const double X, const double Y, const double Z) {
         double u, v;
-        project<MODEL, NP, JAC>(cc, tab, X, Y, Z, a.f32 != 0, u, v, Jc, Jp);
+        // RPC: the chain leaves D; the blocks are formed from it BEHIND the loss function below (with them alive across the generic
+        // loss code the robust variants spilled 880 bytes per thread)
+        if constexpr (MODEL == RPC) project_rpc_d<NP, JAC, false>(cc, tab, X, Y, Z, a.f32 != 0, u, v, Jc, Jp, Dr);
+        else project<MODEL, NP, JAC>(cc, tab, X, Y, Z, a.f32 != 0, u, v, Jc, Jp);
         if constexpr (UNITW && !ROBUST) {
+            if constexpr (MODEL == RPC && JAC) rpc_jac_from_d<NP>(cc, X, Y, Z, Dr, Jc, Jp);
             ftrue[0] = u - ob.x; ftrue[1] = v - ob.y;
             fs[0] = ftrue[0]; fs[1] = ftrue[1];
             rho = ftrue[0] * ftrue[0] + ftrue[1] * ftrue[1];
@@ -142,6 +148,7 @@ struct ObsEval {
         }
         rho = r0 + r1;
         if (JAC) {
+            if constexpr (MODEL == RPC) rpc_jac_from_d<NP>(cc, X, Y, Z, Dr, Jc, Jp);
             const double mc = (cam >= a.n_cam_fix) ? 1.0 : 0.0;
             const double s0 = w * js0, s1 = w * js1;
             sw[0] = s0; sw[1] = s1;
@@ -152,26 +159,17 @@ struct ObsEval {
         }
     }
 
-    // the blocks of the current linearisation, stored / reloaded (RPC): 2 NP + 6 doubles = NP + 3 16-byte words
+    // RPC: D' of the current linearisation, stored (after eval) / reloaded: three 16-byte words
     __device__ inline void store_jac(const ObsArgs& a, int io) const {
-        double t[2 * NP + 6];
-#pragma unroll
-        for (int k = 0; k < NP; ++k) { t[k] = Jc[0][k]; t[NP + k] = Jc[1][k]; }
-#pragma unroll
-        for (int k = 0; k < 3; ++k) { t[2 * NP + k] = Jp[0][k]; t[2 * NP + 3 + k] = Jp[1][k]; }
         double2* q = reinterpret_cast<double2*>(a.Jpm + (size_t)io * jrow_stride(NP));
-#pragma unroll
-        for (int k = 0; k < NP + 3; ++k) q[k] = make_double2(t[2 * k], t[2 * k + 1]);
+        q[0] = make_double2(sw[0] * Dr[0][0], sw[0] * Dr[0][1]);
+        q[1] = make_double2(sw[0] * Dr[0][2], sw[1] * Dr[1][0]);
+        q[2] = make_double2(sw[1] * Dr[1][1], sw[1] * Dr[1][2]);
     }
-    __device__ inline void load_jac(const ObsArgs& a, int io) {
+    __device__ inline void load_d(const ObsArgs& a, int io) {
         const double2* q = reinterpret_cast<const double2*>(a.Jpm + (size_t)io * jrow_stride(NP));
-        double t[2 * NP + 6];
-#pragma unroll
-        for (int k = 0; k < NP + 3; ++k) { const double2 v = q[k]; t[2 * k] = v.x; t[2 * k + 1] = v.y; }
-#pragma unroll
-        for (int k = 0; k < NP; ++k) { Jc[0][k] = t[k]; Jc[1][k] = t[NP + k]; }
-#pragma unroll
-        for (int k = 0; k < 3; ++k) { Jp[0][k] = t[2 * NP + k]; Jp[1][k] = t[2 * NP + 3 + k]; }
+        const double2 q0 = q[0], q1 = q[1], q2 = q[2];
+        Dr[0][0] = q0.x; Dr[0][1] = q0.y; Dr[0][2] = q1.x; Dr[1][0] = q1.y; Dr[1][1] = q2.x; Dr[1][2] = q2.y;
     }
     // Jacobian blocks only, for the passes that follow a linearisation at the same x: from the store when there is one
     // (RPC); otherwise the unit-weight, linear-loss Jacobian times the row scales the linearize kernel stored (a.sc;
@@ -179,8 +177,14 @@ struct ObsEval {
     // loss function is not evaluated.
     __device__ inline void jac(const ObsArgs& a, int io, int cam, double mp, const double* cc, const double* tab,
                                const double X, const double Y, const double Z) {
-        if constexpr (MODEL == RPC) {  // always stored for RPC cameras
-            load_jac(a, io);
+        if constexpr (MODEL == RPC) {  // always stored for RPC cameras: the blocks from D' (it carries the row scales), masks applied here
+            load_d(a, io);
+            rpc_jac_from_d<NP>(cc, X, Y, Z, Dr, Jc, Jp);
+            const double mc = (cam >= a.n_cam_fix) ? 1.0 : 0.0;
+#pragma unroll
+            for (int i = 0; i < NP; ++i) { Jc[0][i] *= mc; Jc[1][i] *= mc; }
+#pragma unroll
+            for (int j = 0; j < 3; ++j) { Jp[0][j] *= mp; Jp[1][j] *= mp; }
             return;
         }
         double u, v;
@@ -783,14 +787,15 @@ __global__ __launch_bounds__(256) void k_lin_scales(int M, const double* __restr
     }
 #pragma unroll
     for (int i = 0; i < NP; ++i) m[i] = 0.0;
-    for (int cam = threadIdx.x; cam < M; cam += 256) {
-        for (int corner = 0; corner < 8; ++corner) {
-            const double X = c[0] + ((corner & 1) ? h[0] : -h[0]), Y = c[1] + ((corner & 2) ? h[1] : -h[1]), Z = c[2] + ((corner & 4) ? h[2] : -h[2]);
-            double u, v, Jc[2][NP], Jp[2][3];
-            project<MODEL, NP, true>(camc + (size_t)cam * CAMC, MODEL == RPC ? rpc + (size_t)cam * 90 : nullptr, X, Y, Z, false, u, v, Jc, Jp);
+    // one thread per (camera, corner) (round 5: a thread per camera walked its eight corners one after the other -- eight RPC chains in a
+    // row were 17 us of a 0.67 ms iteration at 50 cameras; a maximum does not depend on the order)
+    for (int idx = threadIdx.x; idx < 8 * M; idx += 256) {
+        const int cam = idx >> 3, corner = idx & 7;
+        const double X = c[0] + ((corner & 1) ? h[0] : -h[0]), Y = c[1] + ((corner & 2) ? h[1] : -h[1]), Z = c[2] + ((corner & 4) ? h[2] : -h[2]);
+        double u, v, Jc[2][NP], Jp[2][3];
+        project<MODEL, NP, true>(camc + (size_t)cam * CAMC, MODEL == RPC ? rpc + (size_t)cam * 90 : nullptr, X, Y, Z, false, u, v, Jc, Jp);
 #pragma unroll
-            for (int i = 0; i < NP; ++i) m[i] = fmax(m[i], fmax(fabs(Jc[0][i]), fabs(Jc[1][i])));
-        }
+        for (int i = 0; i < NP; ++i) m[i] = fmax(m[i], fmax(fabs(Jc[0][i]), fabs(Jc[1][i])));
     }
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
@@ -903,10 +908,11 @@ __global__ __launch_bounds__(LINC_THREADS) void k_cam_sums(ObsArgs a, CamMajor c
         const int pos = c.pos[i], q = c.pt[i], io = c.io[i];
         double2 ff;
         double Jc[2][NP], Jp[2][3];
-        if constexpr (MODEL == RPC) {  // the blocks and residuals k_linearize stored (scales and masks included)
+        if constexpr (MODEL == RPC) {  // the residuals and D' k_linearize stored (row scales included)
             ff = f[pos];
             ObsEval<MODEL, NP, true> e2;
-            e2.load_jac(a, io);
+            const double* px = a.x + a.n_c + 3 * (size_t)q;
+            e2.jac(a, io, cam, 1.0, cc, nullptr, px[0], px[1], px[2]);
 #pragma unroll
             for (int k = 0; k < NP; ++k) { Jc[0][k] = e2.Jc[0][k]; Jc[1][k] = e2.Jc[1][k]; }
         } else {  // the projection is evaluated for the Jacobian anyway: the residual comes with it (no 16 B / observation store)

@@ -182,6 +182,69 @@ __device__ inline void rpc_project(const double* __restrict__ tab, double x, dou
     }
 }
 
+// RPC: Jc and Jp of one observation from D = d(col,row)/dX' (2 x 3), the camera's rotation and the point -- the tail of the chain
+// (ref:bundle_adjust/ba_core.py:126-130 differentiated): Jc[:, i] = D dR/dtheta_i (X - T - C), Jp = D R, d/dT = -D R.  Every pass behind
+// a linearisation recomputes the blocks from the stored D (round 5: 64 bytes per observation instead of the 128 / 192-byte rows Jc | Jp).
+template <int NP>
+__device__ inline void rpc_jac_from_d(const double* __restrict__ cc, double X, double Y, double Z, const double (&D)[2][3], double Jc[2][NP],
+                                      double Jp[2][3]) {
+    Rot r;
+    rotate<true>(cc, X - cc[15] - cc[18], Y - cc[16] - cc[19], Z - cc[17] - cc[20], r);
+    const double* d[3] = {r.da, r.db, r.dg};
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        Jc[0][i] = D[0][0] * d[i][0] + D[0][1] * d[i][1] + D[0][2] * d[i][2];
+        Jc[1][i] = D[1][0] * d[i][0] + D[1][1] * d[i][1] + D[1][2] * d[i][2];
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        Jp[0][j] = D[0][0] * cc[6 + j] + D[0][1] * cc[9 + j] + D[0][2] * cc[12 + j];
+        Jp[1][j] = D[1][0] * cc[6 + j] + D[1][1] * cc[9 + j] + D[1][2] * cc[12 + j];
+    }
+    if constexpr (NP == 6) {  // d/dT = -D R
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            Jc[0][3 + j] = -Jp[0][j];
+            Jc[1][3 + j] = -Jp[1][j];
+        }
+    }
+}
+
+// RPC projection of one observation; if JAC also D = d(col,row)/dX' and (BLOCKS) the blocks Jc, Jp formed from it
+template <int NP, bool JAC, bool BLOCKS = true>
+__device__ inline void project_rpc_d(const double* __restrict__ cc, const double* __restrict__ rpc_tab, double X, double Y, double Z, bool f32,
+                                     double& u, double& v, double Jc[2][NP], double Jp[2][3], double (&D)[2][3]) {
+    // X' = R (X - T - C) + C   (ref:bundle_adjust/ba_core.py:126-130)
+    const double C0 = cc[18], C1 = cc[19], C2 = cc[20];
+    Rot r;
+    rotate<JAC && BLOCKS>(cc, X - cc[15] - C0, Y - cc[16] - C1, Z - cc[17] - C2, r);
+    rpc_project<JAC>(rpc_tab, r.y3[0] + C0, r.y3[1] + C1, r.y3[2] + C2, u, v, D);
+    if (f32) {  // ref:bundle_adjust/ba_core.py:150 stores the projections in a float32 array
+        u = (double)(float)u;
+        v = (double)(float)v;
+    }
+    if (JAC && BLOCKS) {
+        const double* d[3] = {r.da, r.db, r.dg};
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            Jc[0][i] = D[0][0] * d[i][0] + D[0][1] * d[i][1] + D[0][2] * d[i][2];
+            Jc[1][i] = D[1][0] * d[i][0] + D[1][1] * d[i][1] + D[1][2] * d[i][2];
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            Jp[0][j] = D[0][0] * cc[6 + j] + D[0][1] * cc[9 + j] + D[0][2] * cc[12 + j];
+            Jp[1][j] = D[1][0] * cc[6 + j] + D[1][1] * cc[9 + j] + D[1][2] * cc[12 + j];
+        }
+        if constexpr (NP == 6) {  // d/dT = -D R
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                Jc[0][3 + j] = -Jp[0][j];
+                Jc[1][3 + j] = -Jp[1][j];
+            }
+        }
+    }
+}
+
 // One observation: projection (u, v) and, if JAC, Jc (2 x NP) w.r.t. [angles(3), T(NP-3)] and Jp (2 x 3).
 template <int MODEL, int NP, bool JAC>
 __device__ inline void project(const double* __restrict__ cc, const double* __restrict__ rpc_tab, double X, double Y,
@@ -246,35 +309,8 @@ __device__ inline void project(const double* __restrict__ cc, const double* __re
             }
         }
     } else {
-        // X' = R (X - T - C) + C   (ref:bundle_adjust/ba_core.py:126-130)
-        const double C0 = cc[18], C1 = cc[19], C2 = cc[20];
-        rotate<JAC>(cc, X - cc[15] - C0, Y - cc[16] - C1, Z - cc[17] - C2, r);
         double D[2][3];
-        rpc_project<JAC>(rpc_tab, r.y3[0] + C0, r.y3[1] + C1, r.y3[2] + C2, u, v, D);
-        if (f32) {  // ref:bundle_adjust/ba_core.py:150 stores the projections in a float32 array
-            u = (double)(float)u;
-            v = (double)(float)v;
-        }
-        if (JAC) {
-            const double* d[3] = {r.da, r.db, r.dg};
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                Jc[0][i] = D[0][0] * d[i][0] + D[0][1] * d[i][1] + D[0][2] * d[i][2];
-                Jc[1][i] = D[1][0] * d[i][0] + D[1][1] * d[i][1] + D[1][2] * d[i][2];
-            }
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                Jp[0][j] = D[0][0] * cc[6 + j] + D[0][1] * cc[9 + j] + D[0][2] * cc[12 + j];
-                Jp[1][j] = D[1][0] * cc[6 + j] + D[1][1] * cc[9 + j] + D[1][2] * cc[12 + j];
-            }
-            if constexpr (NP == 6) {  // d/dT = -D R
-#pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    Jc[0][3 + j] = -Jp[0][j];
-                    Jc[1][3 + j] = -Jp[1][j];
-                }
-            }
-        }
+        project_rpc_d<NP, JAC>(cc, rpc_tab, X, Y, Z, f32, u, v, Jc, Jp, D);
     }
 }
 

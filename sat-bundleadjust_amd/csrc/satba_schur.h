@@ -451,9 +451,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((MODEL == A
         d[0][1] = cg * y2z;           d[1][1] = sg * y2z;
         d[0][2] = -(sg * y2x + cg * y1y); d[1][2] = cg * y2x - sg * y1y;
     };
-    // JROWS: the stored Jacobian rows of both observations come in ti / tj (RPC, gathered cooperatively by the caller)
-    constexpr bool JROWS = MODEL == RPC && NP == 3;
-    constexpr int JLEN = 2 * NP + 6;
+    // JROWS (RPC): D' = row-scaled d(col,row)/dX' of both observations comes in ti / tj (six doubles each, gathered cooperatively by the
+    // caller); the blocks are rebuilt from it, the point and the two cameras' rotations (rpc_jac_from_d)
+    constexpr bool JROWS = MODEL == RPC;
+    constexpr int JLEN = 6;
     auto compute = [&](const Rec& rc, int pi, int pj, const double2& scl_i, const double2& scl_j, const double* tip, const double* tjp) {
         const double X = rc.r0.x, Y = rc.r0.y, Z = rc.r1.x;
         const double v00 = rc.r1.y, v01 = rc.r2.x, v02 = rc.r2.y, v11 = rc.r3.x, v12 = rc.r3.y, v22 = rc.r4;
@@ -504,26 +505,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((MODEL == A
         }
         double Jci[2][NP], Jpi[2][3], Jcj[2][NP], Jpj[2][3];
         if constexpr (MODEL == RPC) {
-            double ti[JLEN], tj[JLEN];
-            if constexpr (JROWS) {
-#pragma unroll
-                for (int k = 0; k < JLEN; ++k) { ti[k] = tip[k]; tj[k] = tjp[k]; }
-            } else {
-                const double2* qi = reinterpret_cast<const double2*>(a.Jpm + (size_t)pi * jrow_stride(NP));
-                const double2* qj = reinterpret_cast<const double2*>(a.Jpm + (size_t)pj * jrow_stride(NP));
-#pragma unroll
-                for (int k = 0; k < NP + 3; ++k) {
-                    const double2 vi = qi[k], vj = qj[k];
-                    ti[2 * k] = vi.x; ti[2 * k + 1] = vi.y; tj[2 * k] = vj.x; tj[2 * k + 1] = vj.y;
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < NP; ++k) { Jci[0][k] = ti[k]; Jci[1][k] = ti[NP + k]; Jcj[0][k] = tj[k]; Jcj[1][k] = tj[NP + k]; }
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                Jpi[0][k] = ti[2 * NP + k]; Jpi[1][k] = ti[2 * NP + 3 + k];
-                Jpj[0][k] = tj[2 * NP + k]; Jpj[1][k] = tj[2 * NP + 3 + k];
-            }
+            const double Di[2][3] = {{tip[0], tip[1], tip[2]}, {tip[3], tip[4], tip[5]}};
+            const double Dj[2][3] = {{tjp[0], tjp[1], tjp[2]}, {tjp[3], tjp[4], tjp[5]}};
+            rpc_jac_from_d<NP>(cci, X, Y, Z, Di, Jci, Jpi);
+            rpc_jac_from_d<NP>(ccj, X, Y, Z, Dj, Jcj, Jpj);
         } else {
             double u, v;
             project<MODEL, NP, true>(cci, nullptr, X, Y, Z, false, u, v, Jci, Jpi);
@@ -636,18 +621,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((MODEL == A
                 __builtin_amdgcn_wave_barrier();
                 return r;
             };
-            // RPC, rotation only: the stored Jacobian rows (12 doubles = 6 pieces per observation in a 128-byte row, io order) of both observations are
-            // gathered the same way (piece 64 t + lane: row (64 t + lane) / 6, piece (64 t + lane) % 6; 11 lines per instruction
-            // instead of 64, twelve instructions per iteration) and transposed through the same LDS buffer, row stride 7 pieces
-            struct JCoop { double2 c0, c1, c2, c3, c4, c5; };
+            // RPC: the stored D' (six doubles = 3 pieces per observation in a 64-byte row, io order) of both observations is gathered the
+            // same way (piece 64 t + lane: row (64 t + lane) / 3, piece (64 t + lane) % 3: 22 half-lines per instruction instead of 64
+            // lines, six instructions per iteration; rounds 2 - 4: twelve, on 128-byte rows of Jc | Jp) and transposed through the same
+            // LDS buffer, row stride 3 pieces (odd: conflict-free 16-byte reads)
+            struct JCoop { double2 c0, c1, c2; };
             struct JRow { double v[JLEN]; };
-            int jsrc[6];
-            const double2* jp[6];
-            double2* jw[6];
+            int jsrc[3];
+            const double2* jp[3];
+            double2* jw[3];
 #pragma unroll
-            for (int t = 0; t < 6; ++t) {
+            for (int t = 0; t < 3; ++t) {
                 const int g = 64 * t + lane;
-                jsrc[t] = g / 6; jp[t] = reinterpret_cast<const double2*>(a.Jpm) + g % 6; jw[t] = reinterpret_cast<double2*>(my) + (g / 6) * 7 + g % 6;
+                jsrc[t] = g / 3; jp[t] = reinterpret_cast<const double2*>(a.Jpm) + g % 3; jw[t] = reinterpret_cast<double2*>(my) + g;
             }
             auto jcoop_load = [&](int io) {
                 JCoop o;
@@ -655,20 +641,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((MODEL == A
                 o.c0 = jp[0][RS * (size_t)__shfl(io, jsrc[0])];
                 o.c1 = jp[1][RS * (size_t)__shfl(io, jsrc[1])];
                 o.c2 = jp[2][RS * (size_t)__shfl(io, jsrc[2])];
-                o.c3 = jp[3][RS * (size_t)__shfl(io, jsrc[3])];
-                o.c4 = jp[4][RS * (size_t)__shfl(io, jsrc[4])];
-                o.c5 = jp[5][RS * (size_t)__shfl(io, jsrc[5])];
                 return o;
             };
-            const double2* jmine = reinterpret_cast<const double2*>(my) + lane * 7;
+            const double2* jmine = reinterpret_cast<const double2*>(my) + lane * 3;
             auto jtranspose = [&](const JCoop& o) {
                 JRow r;
                 asm volatile("" ::: "memory");
-                *jw[0] = o.c0; *jw[1] = o.c1; *jw[2] = o.c2; *jw[3] = o.c3; *jw[4] = o.c4; *jw[5] = o.c5;
+                *jw[0] = o.c0; *jw[1] = o.c1; *jw[2] = o.c2;
                 asm volatile("" ::: "memory");
                 __builtin_amdgcn_wave_barrier();
 #pragma unroll
-                for (int k = 0; k < 6; ++k) { const double2 t = jmine[k]; r.v[2 * k] = t.x; r.v[2 * k + 1] = t.y; }
+                for (int k = 0; k < 3; ++k) { const double2 t = jmine[k]; r.v[2 * k] = t.x; r.v[2 * k + 1] = t.y; }
                 asm volatile("" ::: "memory");
                 __builtin_amdgcn_wave_barrier();
                 return r;
@@ -716,8 +699,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((MODEL == A
     double flat[NPAD];
 #pragma unroll
     for (int e = 0; e < NPAD; ++e) flat[e] = (e < NB2) ? acc[e / NP][e % NP] : 0.0;
-    // fixed-camera masks (RPC: the stored blocks carry them)
-    const double cam_mask = (MODEL != RPC && (i < a.n_cam_fix || j < a.n_cam_fix)) ? 0.0 : 1.0;
+    // fixed-camera masks
+    const double cam_mask = (i < a.n_cam_fix || j < a.n_cam_fix) ? 0.0 : 1.0;
     const double total = cam_mask * wave_reduce_scatter<NPAD>(flat, lane, 32);
     const int e = rs_index<NPAD>(lane);
     const bool writer = (lane & (64 / NPAD - 1)) == 0 && e < NB2;  // one lane per total (NPAD = 64: every lane)
@@ -892,13 +875,12 @@ __device__ __forceinline__ void schur_diag_walk(const ObsArgs& a, const double2*
                 if constexpr (NP == 5) { acc[k++] -= b0; acc[k++] -= b1; }
             } else {
                 double Jc[2][NP], Jp[2][3];
-                if constexpr (MODEL == RPC) {  // the blocks the linearize kernel stored (scales and masks included)
+                if constexpr (MODEL == RPC) {  // from D' the linearize kernel stored (the row scales ride in it; the fixed-point mask in the record's Vinv)
                     ObsEval<MODEL, NP, true> e2;
-                    e2.load_jac(a, lst_sc[posc]);
+                    e2.load_d(a, lst_sc[posc]);
+                    rpc_jac_from_d<NP>(cc, r0.x, r0.y, r1.x, e2.Dr, Jc, Jp);
 #pragma unroll
-                    for (int k = 0; k < NP; ++k) { Jc[0][k] = vm * e2.Jc[0][k]; Jc[1][k] = vm * e2.Jc[1][k]; }
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) { Jp[0][k] = e2.Jp[0][k]; Jp[1][k] = e2.Jp[1][k]; }
+                    for (int k = 0; k < NP; ++k) { Jc[0][k] *= vm; Jc[1][k] *= vm; }
                     ux = uy = sx = sy = 1.0;
                 } else {
                     double u, v;
@@ -966,7 +948,7 @@ __global__ __launch_bounds__(LINC_THREADS) void k_schur_diag(ObsArgs a, CamMajor
     for (int k = 0; k < CU; ++k) acc[k] = 0.0;
     schur_diag_walk<MODEL, NP, LINC_THREADS>(a, s.PV, c.pt, c.io, s.wmode ? 1 : PV_STRIDE / 2, s.wmode ? s.zero_fix : (PV_STRIDE / 2) * a.N, cam, lo, hi,
                                              (int)threadIdx.x, s_coop + wave * (64 * 7), acc);
-    if (MODEL != RPC && cam < a.n_cam_fix) {  // fixed camera (block-uniform); RPC: the stored blocks carry the mask
+    if (cam < a.n_cam_fix) {  // fixed camera (block-uniform)
 #pragma unroll
         for (int k = 0; k < CU; ++k) acc[k] = 0.0;
     }
