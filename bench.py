@@ -35,12 +35,12 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 
-# HBM bytes per k_linearize launch from rocprofv3 PMC passes of this same command (profiles/r4_pmc_hbm_traffic.json, from the
+# HBM bytes per k_linearize launch from rocprofv3 PMC passes of this same command (profiles/r5_pmc_hbm_traffic.json, from the
 # summaries of tools/pmc_summary.py): 2 x FETCH_SIZE (gfx950 counts 128-B requests as 64 B, MI355X_MICROARCH.md section HBM) + WRITE_SIZE.
 # PMC counters cannot be read from inside an unprofiled run, so the committed measurement is quoted for the (shape, loss) --
 # i.e. the kernel instantiation -- it was taken on (one GPU), and the field is null otherwise.
 def profiled_traffic(shape, loss, world):
-    path = os.path.join(ROOT, "profiles", "r4_pmc_hbm_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r5_pmc_hbm_traffic.json")
     if world != 1 or not os.path.exists(path):
         return None
     with open(path) as fh:

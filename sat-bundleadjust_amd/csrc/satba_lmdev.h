@@ -311,7 +311,10 @@ __global__ void k_lm_decide2(LmDev* __restrict__ gst, const double* __restrict__
             if (st->never_stop) {
                 // fixed-work runs (bench.py): stop after max_iterations; every cycle_len iterations the solve starts again from the
                 // kept point x0 (satba_snapshot_x), the way bench.py restarts the solve that the shipped tolerances end there
-                if (st->max_iterations > 0 && st->iterations >= st->max_iterations) st->phase = LM_DONE;
+                if (st->max_iterations > 0 && st->iterations >= st->max_iterations) {
+                    st->phase = LM_DONE;
+                    st->run_lin = 0; st->run_solve = 0;  // (the ticks queued behind the end pass empty: they ran up to three more fronts before round 5)
+                }
                 else if (st->cycle_len > 0 && ++st->cycle_it >= st->cycle_len) {
                     st->cycle_it = 0;
                     st->restore = 1; st->accept = 0;
