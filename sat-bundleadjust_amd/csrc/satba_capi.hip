@@ -171,6 +171,8 @@ struct satba_problem {
     double *d_xb_own = nullptr, *d_xb = nullptr;
     long long xb_len = 0;
     double* h_pin = nullptr;  // pinned staging for header reads
+    void* h_stage = nullptr;  // pinned staging of the transfers between the caller's arrays and the device (copy_to_host)
+    size_t h_stage_len = 0;
     double* d_x0 = nullptr;   // satba_snapshot_x
     bool linearized = false, have_step = false;
     double create_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -1076,6 +1078,7 @@ void satba_problem_destroy(satba_problem* p) {
     for (void* q : p->allocs) (void)hipFree(q);
     for (hipEvent_t e : p->prof_ev) (void)hipEventDestroy(e);
     if (p->h_pin) (void)hipHostFree(p->h_pin);
+    if (p->h_stage) (void)hipHostFree(p->h_stage);
     if (p->h_lm) (void)hipHostFree(p->h_lm);
     if (p->own_stream) (void)hipStreamDestroy(p->own_stream);
     if (p->chol_stream) (void)hipStreamDestroy(p->chol_stream);
@@ -1154,11 +1157,48 @@ int satba_configure(satba_problem* p, int32_t loss, double f_scale) {
     return 0;
 }
 
+// Copies between the caller's (pageable) arrays and the device.  The runtime's first copy to or from a host range it has not seen
+// costs 20 - 30 ms whatever its size (measured at 1 M observations, profiles/r5_e2e_C3.json: 28 ms for the 8 MB of errors, twice per
+// call, where the transfer itself is 0.5 ms) -- and a caller's result arrays are new ranges every time.  Up to 32 MB the bytes go
+// through a pinned buffer of the handle and one memcpy; larger transfers go direct (at 80 MB the direct copy runs at 15 GB/s and
+// the extra memcpy would cost more than it saves).  Both wait for the stream.
+constexpr size_t SATBA_STAGE_MAX = 32u << 20;
+static int host_stage(satba_problem* p, size_t bytes) {
+    if (p->h_stage_len >= bytes) return 0;
+    if (p->h_stage) (void)hipHostFree(p->h_stage);
+    p->h_stage = nullptr; p->h_stage_len = 0;
+    HIP_TRY(hipHostMalloc((void**)&p->h_stage, bytes));
+    p->h_stage_len = bytes;
+    return 0;
+}
+static int copy_to_host(satba_problem* p, void* host, const void* dev, size_t bytes) {
+    if (bytes == 0) { HIP_TRY(hipStreamSynchronize(p->stream)); return 0; }
+    if (bytes > SATBA_STAGE_MAX) {
+        HIP_TRY(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, p->stream));
+        HIP_TRY(hipStreamSynchronize(p->stream));
+        return 0;
+    }
+    TRY(host_stage(p, bytes));
+    HIP_TRY(hipMemcpyAsync(p->h_stage, dev, bytes, hipMemcpyDeviceToHost, p->stream));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    memcpy(host, p->h_stage, bytes);
+    return 0;
+}
+static int copy_to_device_async(satba_problem* p, void* dev, const void* host, size_t bytes) {
+    if (bytes == 0) return 0;
+    if (bytes > SATBA_STAGE_MAX) { HIP_TRY(hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, p->stream)); return 0; }
+    HIP_TRY(hipStreamSynchronize(p->stream));  // (an earlier copy out of the pinned buffer may still be queued)
+    TRY(host_stage(p, bytes));
+    memcpy(p->h_stage, host, bytes);
+    HIP_TRY(hipMemcpyAsync(dev, p->h_stage, bytes, hipMemcpyHostToDevice, p->stream));
+    return 0;
+}
+
 // host vector in the caller's point order -> device vector in internal order (and back); dim doubles per point
 static int upload_permuted(satba_problem* p, const double* host, double* dev, int n_c, int dim) {
     const size_t len = (size_t)n_c + (size_t)p->N * dim;
     if (len > p->stage_len) return fail(SATBA_E_ARG, "staging buffer too small");
-    HIP_TRY(hipMemcpyAsync(p->d_stage, host, sizeof(double) * len, hipMemcpyHostToDevice, p->stream));
+    TRY(copy_to_device_async(p, p->d_stage, host, sizeof(double) * len));
     hipLaunchKernelGGL(k_permute_vec, dim3(grid_for((long long)len, 256, 2048)), dim3(256), 0, p->stream, n_c, p->N, dim, p->L.perm, p->d_stage, dev, 0);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(p->stream));
@@ -1169,9 +1209,7 @@ static int download_permuted(satba_problem* p, const double* dev, double* host, 
     if (len > p->stage_len) return fail(SATBA_E_ARG, "staging buffer too small");
     hipLaunchKernelGGL(k_permute_vec, dim3(grid_for((long long)len, 256, 2048)), dim3(256), 0, p->stream, n_c, p->N, dim, p->L.perm, dev, p->d_stage, 1);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(host, p->d_stage, sizeof(double) * len, hipMemcpyDeviceToHost, p->stream));
-    HIP_TRY(hipStreamSynchronize(p->stream));
-    return 0;
+    return copy_to_host(p, host, p->d_stage, sizeof(double) * len);
 }
 
 int satba_set_x(satba_problem* p, const double* host_x) {
@@ -1234,7 +1272,7 @@ int satba_residuals(satba_problem* p, double* host_r, double* host_cost) {
     if (want) {
         hipLaunchKernelGGL(k_gather_obs, dim3(grid_for(p->K, 256, 4096)), dim3(256), 0, p->stream, p->K, p->L.obs_pos, p->d_ftmp, f_obs);
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(host_r, f_obs, sizeof(double) * 2 * p->K, hipMemcpyDeviceToHost, p->stream));
+        TRY(copy_to_host(p, host_r, f_obs, sizeof(double) * 2 * p->K));
     }
     HIP_TRY(hipStreamSynchronize(p->stream));
     if (host_cost) *host_cost = p->h_pin[0];

@@ -144,19 +144,6 @@ def load_library(path=None):
     return lib
 
 
-def _host_out(n):
-    """
-    Host array a device-to-host copy lands in.  A copy into pageable memory that has never been touched takes the driver's page-fault
-    path: 28 ms for the 8 MB of errors at 1 M observations (round 5, profiles/r5_e2e_C3.json) where the copy itself is 0.5 ms.  Up to
-    32 MB the pages are touched first (glibc hands such blocks out fresh until its mmap threshold has adapted); larger blocks are
-    backed by huge pages and copy at full speed untouched.
-    """
-    a = np.empty(n)
-    if a.nbytes <= (32 << 20):
-        a.fill(0.0)
-    return a
-
-
 def _ptr(a, typ=_dp):
     return a.ctypes.data_as(typ)
 
@@ -292,19 +279,19 @@ class HipEngine:
         _check(self.lib, self.lib.satba_set_x(self._h, _ptr(x)))
 
     def get_x(self):
-        x = _host_out(self.n)
+        x = np.empty(self.n)
         _check(self.lib, self.lib.satba_get_x(self._h, _ptr(x)))
         return x
 
     def residuals(self, with_cost=False):
-        r = _host_out(2 * self.n_obs)
+        r = np.empty(2 * self.n_obs)
         cost = C.c_double()
         _check(self.lib, self.lib.satba_residuals(self._h, _ptr(r), C.byref(cost)))
         return (r, cost.value) if with_cost else r
 
     def reprojection_errors(self):
         """satba_reprojection_errors: compute_reprojection_error(fun(x)) on the device, (n_obs,) float64 in the caller's order."""
-        e = _host_out(self.n_obs)
+        e = np.empty(self.n_obs)
         _check(self.lib, self.lib.satba_reprojection_errors(self._h, _ptr(e), None))
         return e
 
