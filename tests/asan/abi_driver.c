@@ -43,6 +43,9 @@ int main(void) {
         CHECK(satba_set_x(p, x) == SATBA_OK);
         CHECK(satba_set_x(p, NULL) == SATBA_E_ARG);
         CHECK(satba_prepare(p, 1) == SATBA_E_STATE);
+        double err[4], cost = -1.0;
+        CHECK(satba_reprojection_errors(p, NULL, NULL) == SATBA_E_ARG);
+        CHECK(satba_reprojection_errors(p, err, &cost) == SATBA_OK && cost >= 0.0);
         CHECK(satba_configure(p, 9, 1.0) == SATBA_E_ARG && satba_configure(p, 1, -1.0) == SATBA_E_ARG);
         double out[16];
         CHECK(satba_get_info(p, out, 4) == SATBA_E_ARG && satba_get_info(p, out, 16) == SATBA_OK);
@@ -54,6 +57,7 @@ int main(void) {
     CHECK(satba_set_x(NULL, NULL) == SATBA_E_ARG && satba_linearize(NULL) == SATBA_E_ARG && satba_accept(NULL) == SATBA_E_ARG);
     CHECK(satba_header_len(NULL) == 0 && satba_exchange_len(NULL) == 0 && satba_layout_len(NULL, 0) == -1);
     CHECK(satba_lm_run(NULL, 1, 0, 0.0, NULL, 0) == SATBA_E_ARG && satba_lm_state(NULL, NULL, 0) == SATBA_E_ARG);
+    CHECK(satba_reprojection_errors(NULL, NULL, NULL) == SATBA_E_ARG);
     CHECK(satba_rpc_fit(-1, 0, NULL, NULL, 1e-3, 1e-2, 20, NULL, NULL, NULL, 0) == SATBA_E_ARG);
     CHECK(satba_rpc_refit(1, NULL, NULL, NULL, NULL, NULL, 10, 1e-3, 1e-2, 20, NULL, NULL, NULL, NULL, NULL, 0) == SATBA_E_ARG);
     CHECK(satba_rpc_localization(NULL, 3, NULL, NULL, NULL, NULL, NULL, 0) == SATBA_E_ARG);
