@@ -1800,7 +1800,16 @@ static bool lm_device_loop_pays(const satba_problem* p) {
 
 int satba_lm_state(satba_problem* p, double* out, int32_t n);
 
-// queue ticks until the device reports that the loop has left LM_RUN, LM_RUN_AHEAD beyond its last report
+// One rank: how many ticks the host queues beyond the device's last report.  Every tick queued behind the end of the loop passes
+// empty, but its ~15 launches still cost ~40 us -- with the three of the several-rank protocol (LM_RUN_AHEAD) a fifth of a C2-sized
+// solve.  The host queues a tick in ~45 us, so ONE tick of lead keeps the device busy (measured, round 5: C2 8 030 it/s with 1, 8 064
+// with 3, 7 625 with 0; C3 3 195 / 3 188 / 3 147; a 4-evaluation C2 solve 0.637 ms against 0.685).  SATBA_RUN_AHEAD overrides.
+static int lm_run_ahead_single() {
+    static const int v = getenv("SATBA_RUN_AHEAD") ? std::max(0, std::min(8, atoi(getenv("SATBA_RUN_AHEAD")))) : 1;
+    return v;
+}
+
+// queue ticks until the device reports that the loop has left LM_RUN, lm_run_ahead_single() beyond its last report
 static int lm_drive(satba_problem* p, double lam_floor, long long max_ticks) {
     long long sub_served = 0;
     for (;;) {
@@ -1811,7 +1820,7 @@ static int lm_drive(satba_problem* p, double lam_floor, long long max_ticks) {
         auto t_wait = std::chrono::steady_clock::now();
         // (a profiled run -- HIP events around every k_linearize launch -- does not run ahead: no switched-off launch is timed)
         unsigned long long w;
-        while (lm_summary_tick(w = __atomic_load_n(&p->h_lm->word, __ATOMIC_ACQUIRE)) + (p->prof_lin ? 0 : LM_RUN_AHEAD) < p->lm_ticks_queued) {
+        while (lm_summary_tick(w = __atomic_load_n(&p->h_lm->word, __ATOMIC_ACQUIRE)) + (p->prof_lin ? 0 : lm_run_ahead_single()) < p->lm_ticks_queued) {
 #if defined(__x86_64__)
             __builtin_ia32_pause();
 #endif
