@@ -510,6 +510,40 @@ def test_points_with_more_than_64_observations(gpu):
     dev.close()
 
 
+@pytest.mark.parametrize("n_cam,n_pts,opp", [(2, 60, 1), (3, 40, 1), (90, 40, 80), (5, 300, 2)])
+def test_weighted_record_layout_at_its_edges(gpu, n_cam, n_pts, opp):
+    """
+    The merged records of the weighted / robust runs (csrc/satba_layout.h: Layout::w_fix) where their special cases live: tracks of
+    length one (no camera pair shares a point, E = 0: no pair kernel, the diagonal blocks come from k_schur_diag on the merged
+    records), tracks longer than a wavefront (records of 88 pieces, scale distances up to 80), tracks of length two (records of
+    one line).  soft_l1 and weighted-linear against the CPU oracle, phase by phase, and the Schur matrix itself.
+    """
+    scene = synth.make_affine_scene(n_cam, n_pts, opp, seed=13)
+    for loss, ref_w in (("soft_l1", 1.0), ("linear", 2.5)):
+        p = synth.make_params(scene, {"correction_params": ["R", "T"], "n_cam_fix": 1 if n_cam > 1 else 0, "ref_cam_weight": ref_w, "reduce": False})
+        v = p.params_opt.copy()
+        dev, ora = HipEngine(p), L.OracleEngine(p)
+        for e in (dev, ora):
+            e.configure(loss, 1.0)
+            e.set_x(v)
+            e.linearize(); e.prepare(True); e.schur(0.37)
+        n_c = dev.n_c
+        S = dev.get_exchange(dev.hdr, n_c * n_c).reshape(n_c, n_c).T
+        rhs = dev.get_exchange(dev.hdr + n_c * n_c, n_c)
+        S_o = ora._xb[ora.hdr: ora.hdr + n_c * n_c].reshape(n_c, n_c)
+        rhs_o = ora._xb[ora.hdr + n_c * n_c: ora.len_schur]
+        low = np.tril_indices(n_c)
+        tol = 1e-9 if opp > 64 else 1e-10  # (80 terms per point block: the summation orders differ in the last bits)
+        assert rel(S[low], S_o[low]) < tol and rel(rhs, rhs_o) < tol, (loss, rel(S[low], S_o[low]), rel(rhs, rhs_o))
+        for e in (dev, ora):
+            e.solve()
+        assert rel(dev.get_vector("gn_h"), ora.gn_h) < 1e-6
+        ha, hb = dev.read_header(), ora.read_header()
+        for s_ in (trf.GRAM_A, trf.GRAM_B, trf.GRAM_C):
+            assert abs(ha[s_] - hb[s_]) <= 1e-7 * abs(hb[s_]) + 1e-300
+        dev.close()
+
+
 def test_ragged_and_tiny_problems(gpu):
     """2 cameras x 3 points, every point seen twice; and a problem whose tiles end exactly on 64 observations."""
     scene = synth.make_affine_scene(2, 3, 2, seed=9)
