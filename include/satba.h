@@ -306,7 +306,12 @@ int satba_rpc_refit(int32_t n_cam, const double *tables_in, const double *rt, co
 /* ---- inspection entry points (parity tests; not used by the solver loop) */
 /* index structures built by satba_problem_create, as int32 arrays (SATBA_LAY_PAIR_OFS: int64): n must equal satba_layout_len */
 enum { SATBA_LAY_PERM = 0, SATBA_LAY_RANK, SATBA_LAY_PT_CNT, SATBA_LAY_SLICE_BASE, SATBA_LAY_E_CAM, SATBA_LAY_OBS_POS, SATBA_LAY_CAM_OFS,
-       SATBA_LAY_CM_PT, SATBA_LAY_CM_POS, SATBA_LAY_PAIR_OFS, SATBA_LAY_PAIR_PTS, SATBA_LAY_PAIR_PI, SATBA_LAY_PAIR_PJ, SATBA_LAY_PAIR_IJ, SATBA_LAY_CM_IO, SATBA_LAY_IPT_OFS };
+       SATBA_LAY_CM_PT, SATBA_LAY_CM_POS, SATBA_LAY_PAIR_OFS, SATBA_LAY_PAIR_PTS, SATBA_LAY_PAIR_PI, SATBA_LAY_PAIR_PJ, SATBA_LAY_PAIR_IJ, SATBA_LAY_CM_IO, SATBA_LAY_IPT_OFS,
+       /* the merged records of the weighted / robust runs (affine, perspective; built by the first such linearisation, length -1 before):
+        * piece offsets of the records' fixed parts (n_pts + 1: the last one is the all-zero record), of every point's first row scale,
+        * the pair lists as (record, distances of the two scales in front of it), the camera-major lists as (record, scale piece), the
+        * first camera-major entry of every diagonal item (+ 1 sentinel) */
+       SATBA_LAY_W_FIX, SATBA_LAY_SC_OFS, SATBA_LAY_PAIR_REC, SATBA_LAY_PAIR_KK, SATBA_LAY_CM_REC, SATBA_LAY_CM_SC, SATBA_LAY_DG_OFS };
 int64_t satba_layout_len(const satba_problem *p, int32_t which);
 int satba_get_layout(satba_problem *p, int32_t which, int64_t n, void *host_out);
 /* n >= 16 doubles: [0..4] milliseconds since the start of satba_problem_create when the uploads were queued, the layout sizes were
@@ -316,7 +321,8 @@ int satba_get_layout(satba_problem *p, int32_t which, int64_t n, void *host_out)
  * [14] workgroups of k_linearize, [15] fall-backs from the fixed-point sums so far, [16] satba_solve_lm runs on the
  * device-resident loop (n >= 17), [17] the last Schur + solve front had the factorisation running beside the pair
  * kernel (1), not (0), or that mode is switched off on this handle after a wait timed out (-1; it is tried again
- * after 128, 256, ... sequential fronts) (n >= 18), [18] such time-outs so far (n >= 19)                        */
+ * after 128, 256, ... sequential fronts) (n >= 18), [18] such time-outs so far (n >= 19), [19] diagonal items per (camera,
+ * chunk) of the weighted / robust pair kernel, 0 before the merged records exist (n >= 20)                               */
 int satba_get_info(const satba_problem *p, double *out, int32_t n);
 /* normal-equation blocks of the last linearize: U (M n_p n_p), g_c (M n_p) as written to the exchange
  * payload, V (N x 6: xx xy xz yy yz zz), g_p (N x 3), points in the caller's order. Any pointer may be NULL.

@@ -2213,6 +2213,10 @@ int64_t satba_layout_len(const satba_problem* p, int32_t which) {
         case SATBA_LAY_PAIR_OFS: return L.n_pairs * (L.C + 1) + 1;
         case SATBA_LAY_PAIR_PTS: case SATBA_LAY_PAIR_PI: case SATBA_LAY_PAIR_PJ: return L.E;
         case SATBA_LAY_PAIR_IJ: return 2 * L.n_pairs;
+        case SATBA_LAY_W_FIX: case SATBA_LAY_SC_OFS: return L.wl_ready ? L.N + 1 : -1;
+        case SATBA_LAY_PAIR_REC: case SATBA_LAY_PAIR_KK: return L.wl_ready ? L.E : -1;
+        case SATBA_LAY_CM_REC: case SATBA_LAY_CM_SC: return L.wl_ready ? L.K : -1;
+        case SATBA_LAY_DG_OFS: return L.wl_ready ? (long long)L.M * L.n_dg + 1 : -1;
         default: return -1;
     }
 }
@@ -2241,6 +2245,13 @@ int satba_get_layout(satba_problem* p, int32_t which, int64_t n, void* host_out)
         case SATBA_LAY_PAIR_PI: src = L.pair_pi; break;
         case SATBA_LAY_PAIR_PJ: src = L.pair_pj; break;
         case SATBA_LAY_PAIR_IJ: src = L.pair_ij; break;
+        case SATBA_LAY_W_FIX: src = L.w_fix; break;
+        case SATBA_LAY_SC_OFS: src = L.sc_ofs; break;
+        case SATBA_LAY_PAIR_REC: src = L.pair_rec; break;
+        case SATBA_LAY_PAIR_KK: src = L.pair_kk; break;
+        case SATBA_LAY_CM_REC: src = L.cm_rec; break;
+        case SATBA_LAY_CM_SC: src = L.cm_sc; break;
+        case SATBA_LAY_DG_OFS: src = L.dg_ofs; break;
         default: return fail(SATBA_E_ARG, "unknown layout array %d", which);
     }
     HIP_TRY(hipSetDevice(p->device));
@@ -2258,6 +2269,7 @@ int satba_get_info(const satba_problem* p, double* out, int32_t n) {
     if (n > 16) out[16] = (lm_device_loop_ok(p) && lm_device_loop_pays(p)) ? 1.0 : 0.0;
     if (n > 17) out[17] = p->beside_off ? -1.0 : (p->beside_last ? 1.0 : 0.0);
     if (n > 18) out[18] = p->beside_timeouts;
+    if (n > 19) out[19] = p->L.wl_ready ? p->L.dg_spc : 0;
     return 0;
 }
 

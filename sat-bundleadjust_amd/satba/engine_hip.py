@@ -37,7 +37,9 @@ SYMBOLS = [
 
 FLAG_DETERMINISTIC = 1
 LAYOUT = {"perm": 0, "rank": 1, "pt_cnt": 2, "slice_base": 3, "e_cam": 4, "obs_pos": 5, "cam_ofs": 6, "cm_pt": 7, "cm_pos": 8,
-          "pair_ofs": 9, "pair_pts": 10, "pair_pi": 11, "pair_pj": 12, "pair_ij": 13, "cm_io": 14, "ipt_ofs": 15}
+          "pair_ofs": 9, "pair_pts": 10, "pair_pi": 11, "pair_pj": 12, "pair_ij": 13, "cm_io": 14, "ipt_ofs": 15,
+          # the merged records of the weighted / robust runs (exist after the first such linearisation)
+          "w_fix": 16, "sc_ofs": 17, "pair_rec": 18, "pair_kk": 19, "cm_rec": 20, "cm_sc": 21, "dg_ofs": 22}
 
 
 class LmOpts(C.Structure):
@@ -452,15 +454,17 @@ class HipEngine:
         """One of the index structures satba_problem_create built on the device (csrc/satba_layout.h), as a numpy array."""
         which = LAYOUT[name]
         n = int(self.lib.satba_layout_len(self._h, which))
+        if n < 0:
+            raise ValueError("layout array {} does not exist (yet)".format(name))
         out = np.empty(n, dtype=np.int64 if name == "pair_ofs" else np.int32)
         _check(self.lib, self.lib.satba_get_layout(self._h, which, n, out.ctypes.data_as(C.c_void_p)))
         return out
 
     def info(self):
-        v = np.zeros(19)
-        _check(self.lib, self.lib.satba_get_info(self._h, _ptr(v), 19))
+        v = np.zeros(20)
+        _check(self.lib, self.lib.satba_get_info(self._h, _ptr(v), 20))
         keys = ["ms_uploads", "ms_sizes", "ms_ell", "ms_pairs", "ms_create", "ell_len", "pair_entries", "pair_chunks", "unit_weights",
-                "camc_lds", "rpc_lds", "cam_sums_lds", "deterministic", "cm_chunks", "lin_grid", "fx_fallbacks", "device_loop", "chol_beside", "chol_beside_timeouts"]
+                "camc_lds", "rpc_lds", "cam_sums_lds", "deterministic", "cm_chunks", "lin_grid", "fx_fallbacks", "device_loop", "chol_beside", "chol_beside_timeouts", "diag_items_per_chunk"]
         return dict(zip(keys, v[: len(keys)]))
 
     def get_blocks(self):

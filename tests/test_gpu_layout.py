@@ -78,6 +78,58 @@ def test_device_layout_is_bit_exact(gpu, model, M, N, opp, seed):
     eng.close()
 
 
+def numpy_merged_records(lay, M, N, C, spc):
+    """The merged records of the weighted / robust runs (csrc/satba_layout.h: Layout::w_fix ...) restated with numpy from the base layout."""
+    cnt, ipt_ofs = lay["pt_cnt"], lay["ipt_ofs"]
+    size = np.concatenate((((cnt + 6 + 7) // 8) * 8, [8]))               # pieces per record (a multiple of 8: it ends on a line); + the zero record
+    begin = np.concatenate(([0], np.cumsum(size)))[:-1]
+    w_fix = begin + size - 6                                             # piece of X0: six pieces in front of the end
+    sc_ofs = w_fix - np.concatenate((cnt, [0]))                          # piece of the first row scale
+    q = lay["pair_pts"]
+    di = cnt[q] - (lay["pair_pi"] - ipt_ofs[q])
+    dj = cnt[q] - (lay["pair_pj"] - ipt_ofs[q])
+    cq = lay["cm_pt"]
+    out = dict(w_fix=w_fix, sc_ofs=sc_ofs, pair_rec=w_fix[q], pair_kk=di | (dj << 16), cm_rec=w_fix[cq],
+               cm_sc=w_fix[cq] - cnt[cq] + (lay["cm_io"] - ipt_ofs[cq]))
+    dg = []
+    for cam in range(M):
+        b0, e0 = lay["cam_ofs"][cam], lay["cam_ofs"][cam + 1]
+        chunk = cq[b0:e0] * C // max(N, 1)
+        for ch in range(C):
+            b, e = b0 + np.searchsorted(chunk, ch), b0 + np.searchsorted(chunk, ch + 1)
+            dg.extend(b + (e - b) * s // spc for s in range(spc))
+    out["dg_ofs"] = np.array(dg + [lay["cam_ofs"][M]], dtype=np.int64)
+    return out
+
+
+@pytest.mark.parametrize("model,M,N,opp,seed", [("affine", 9, 3000, 4, 3), ("affine", 70, 200, 68, 5), ("perspective", 5, 64, 3, 1),
+                                                ("affine", 2, 1, 2, 2)])
+def test_merged_record_layout_is_bit_exact(gpu, model, M, N, opp, seed):
+    """The index structures of the weighted / robust runs (round 5), built on the device by the first such linearisation: every array
+    against the numpy restatement; before that linearisation they do not exist."""
+    scene = synth.make_scene(model, M, N, opp, seed=seed)
+    p = synth.make_params(scene, {"correction_params": ["R"], "n_cam_fix": 1})
+    eng = HipEngine(p)
+    with pytest.raises(ValueError):
+        eng.get_layout("w_fix")
+    eng.configure("linear", 1.0)
+    eng.linearize()                      # unit weights, linear loss: the merged records are not built
+    with pytest.raises(ValueError):
+        eng.get_layout("w_fix")
+    eng.configure("soft_l1", 1.0)
+    eng.linearize()
+    info = eng.info()
+    C, spc = int(info["pair_chunks"]), int(info["diag_items_per_chunk"])
+    assert spc >= 1
+    lay = {k: eng.get_layout(k).astype(np.int64) for k in ("pt_cnt", "ipt_ofs", "pair_pts", "pair_pi", "pair_pj", "cm_pt", "cm_io", "cam_ofs")}
+    want = numpy_merged_records(lay, M, p.n_pts, C, spc)
+    for name, ref in want.items():
+        got = eng.get_layout(name)
+        assert got.shape == ref.shape and np.array_equal(got, ref), name
+    assert np.all(want["w_fix"] % 8 == 2)  # every record ends on a 128-byte line
+    eng.close()
+
+
 def test_layout_rejects_unsorted_cameras(gpu):
     scene = synth.make_affine_scene(4, 30, 3, seed=1)
     p = synth.make_params(scene, {"correction_params": ["R"]})
