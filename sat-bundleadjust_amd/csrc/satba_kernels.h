@@ -74,10 +74,11 @@ struct ObsArgs {
     double* __restrict__ Jpm;            // RPC only (else null): K x jrow_stride: D' = row-scaled d(col,row)/dX' of the current
                                          // linearisation, io order; written by the linearize kernel and read by every later
                                          // pass (the RPC chain costs 2-3 kflop per evaluation)
-    double2* __restrict__ sc;            // weighted / robust runs (else null): K Jacobian row scales (w js0, w js1) of the
-                                         // current linearisation, io order; written by the linearize kernel.  io order: a
-                                         // lane streams through its point's entries, and the Schur pair kernel finds the two
-                                         // scales of a hit in neighbouring lines (in ELL order they are 1 KB apart)
+    double2* __restrict__ sc;            // weighted / robust runs of the affine and perspective models (else null): the Jacobian row scales
+                                         // (w js0, w js1) of the current linearisation, written by the linearize kernel INTO the
+                                         // merged point records (Layout::w_fix): observation k of internal point q at piece
+                                         // ipt_ofs[q] + k, where `ipt_ofs` is then Layout::sc_ofs (rounds 1 - 4: an array of its own
+                                         // in io order).  RPC: null -- the scales ride in the stored D'
     long long K;
     int P, n_slices, M, N, n_c, n_cam_fix, n_pts_fix, loss, f32;
     int unit;                            // every weight is 1 and the loss is linear
@@ -605,8 +606,8 @@ __global__ __launch_bounds__(LinCfg<(ROBUST && !SOFT) || MODEL == RPC>::THREADS)
                 e.eval(a, cam, mp, T.cc(cam), T.tab(cam), r[0].ob, r[0].w, X, Y, Z);
                 if constexpr (MODEL == RPC) e.store_jac(a, io0 + k);
                 // (this strided 16-byte store is 68 us of the weighted / robust kernel's 250 at 200 x 1M x 10M -- measured by leaving it
-                // out; non-temporal: 439 us; whole 32-byte sectors from two buffered slots: 243 us.  The io order is what the Schur
-                // kernels' gathers need, section 3 of DESIGN.md)
+                // out; non-temporal: 439 us; whole 32-byte sectors from two buffered slots: 243 us.  Its place -- inside the point's
+                // merged record -- is what the Schur kernels' gathers need, section 3 of DESIGN.md)
                 if (a.sc) a.sc[io0 + k] = make_double2(e.sw[0], e.sw[1]);
                 if (f) f[pos] = make_double2(e.ftrue[0], e.ftrue[1]);  // only the camera-major pass reads it (k_cam_sums)
                 cost += e.rho;

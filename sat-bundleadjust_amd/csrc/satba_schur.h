@@ -337,7 +337,7 @@ __device__ __forceinline__ void schur_diag_walk(const ObsArgs& a, const double2*
 #define SATBA_PAIRS_OCC_U 3
 #endif
 #ifndef SATBA_PAIRS_OCC_W
-#define SATBA_PAIRS_OCC_W 3  // weighted / robust affine kernel (round 5 experiments: 2 waves per SIMD, no spills: see DESIGN.md)
+#define SATBA_PAIRS_OCC_W 3  // weighted / robust affine kernel (round 5: with 2 waves per SIMD and no spills the Schur phase is 1.21 instead of 1.09 ms)
 #endif
 template <int MODEL, int NP, bool UNITW>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((MODEL == AFFINE) ? (UNITW ? SATBA_PAIRS_OCC_U : SATBA_PAIRS_OCC_W) : 1, (MODEL == AFFINE) ? (UNITW ? SATBA_PAIRS_OCC_U : SATBA_PAIRS_OCC_W) : 3))) void k_schur_pairs(ObsArgs a, SchurArgs s, double* __restrict__ S) {
