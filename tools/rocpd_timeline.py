@@ -29,7 +29,8 @@ def main(path, out=sys.stdout):
             for key in names[1:]:
                 if key in n2 and key not in ph and b2 > a:
                     ph[key] = ((a2 - a) / 1e3, (b2 - a) / 1e3)
-        if all(k in ph for k in names if k != "k_unscale"):
+        # (the weighted Schur complement has no k_schur_diag launch: its diagonal items run inside the pair kernel)
+        if all(k in ph for k in names if k not in ("k_unscale", "k_schur_diag<")):
             phases.append(ph)
     if not phases:
         out.write("no Schur / solve phase with the tile Cholesky in this trace\n")
