@@ -458,11 +458,9 @@ def main():
             "deterministic": True, "camera_sums": "fixed_point_lds" if info["cam_sums_lds"] else "camera_major_pass",
             "fixed_point_fallbacks": int(info["fx_fallbacks"]),
             "host_driver": driver,
-            "host_driver_reason": ("device-resident loop (satba_lm_run): the library's default for this shape and loss" if ticks else
+            "host_driver_reason": ("device-resident loop (satba_lm_run): the library's default on one rank" if ticks else
                                    "several ranks: tick parts with the all-reduces queued between them" if driver == "device" else
-                                   "host loop: the library's default for a robust loss from 4 M observations on (three iterations in ten pause "
-                                   "for the degenerate-subspace pattern, which the host queues: 411-420 it/s on the device against 427-438), "
-                                   "or forced by --driver / SATBA_HOST_LOOP / SATBA_DEVICE_LOOP"),
+                                   "host loop: forced by --driver / SATBA_HOST_LOOP / SATBA_DEVICE_LOOP=0 (or more than 1 024 camera unknowns)"),
             # the factorisation beside the pair kernel in the last front: 1 ran that way, 0 not applicable (several ranks, few cameras,
             # switched off), -1 a wait timed out and the handle fell back to one kernel after the other (`value` is then ~10 % lower)
             "chol_beside": int(info["chol_beside"]), "chol_beside_timeouts": int(info["chol_beside_timeouts"]),

@@ -852,10 +852,12 @@ static int build_layout(satba_problem* p, const satba_problem_desc* d) {
             if (L.n_pairs > 0 && L.E > 0) {
                 C = (int)std::max<long long>(1, ((long long)N * 8 * PV_STRIDE + (32ll << 20) - 1) / (32ll << 20));
                 // weighted / robust runs: an XCD works on one (camera, chunk) group at a time and gathers the records AND the row
-                // scales of the camera's points in the chunk (~384 bytes of lines per point); that set should sit in the XCD's
-                // 4 MB L2 with room to spare (200 x 1M x 10M: 4 chunks 1.24 ms, 8 chunks 1.02 ms, 12 chunks 1.04 ms; the
-                // unit-weight kernels use one item per pair and do not look at the chunks)
-                C = (int)std::max<long long>(C, (K / std::max(M, 1) * 384 + 2400000 - 1) / 2400000);
+                // scales of the camera's points in the chunk -- one merged record per point since round 5, ~256 bytes of lines (rounds 3-4:
+                // record and scales apart, ~384); that set should sit in the XCD's 4 MB L2 with room to spare.  200 x 1M x 10M, LM it/s
+                // of the soft_l1 loop with the merged records: 4 chunks 465, 5: 467, 6: 462, 7: 458, 8: 452, 10: 437, 12: 425, 16: 399
+                // (round 4, separate arrays, pair kernel alone: 4 chunks 1.24 ms, 8: 1.02, 12: 1.04).  The unit-weight kernels use one
+                // item per pair and do not look at the chunks
+                C = (int)std::max<long long>(C, (K / std::max(M, 1) * 256 + 2800000 - 1) / 2800000);
                 C = (int)std::max<long long>(1, std::min<long long>(C, L.E / L.n_pairs / 256));
                 C = (int)std::max<long long>(C, std::min<long long>((8192 + L.n_pairs - 1) / L.n_pairs, std::max<long long>(1, L.E / L.n_pairs / 64)));
                 if (const char* cs = getenv("SATBA_SCHUR_CHUNKS")) C = std::max(1, atoi(cs));
@@ -1011,16 +1013,20 @@ int satba_problem_create(const satba_problem_desc* d, satba_problem** out) {
         // one workgroup per CU for the linearize kernel (its LDS table is flushed once per workgroup)
         p->lin_grid = grid_for((long long)p->L.n_slices << slice_split(p), LinCfg<false>::WAVES, 256 * (1024 / LinCfg<false>::THREADS));
         TRY(dev_alloc(p, &p->d_part, (size_t)512 * p->M * cam_sum_len(p->NP)));
-        {   // chunking of the camera-major passes (k_schur_diag, k_cam_sums)
-            int chunks = (2048 + p->M - 1) / p->M;
-            if (chunks > 64) chunks = 64;
-            while (chunks > 1 && K / ((long long)p->M * chunks) < 512) --chunks;  // keep >= ~2 obs per thread
-            // From 8 chunks on they are dealt to the XCDs (k_schur_diag: s.diag_xcd), in multiples of 8; the weighted / robust pass, which
-            // is bound by its memory traffic (record + scale line per entry), takes twice as many (200 x 1M x 10M: unit weights 134 us
-            // with 11 chunks, 125 with 16 dealt; soft_l1 288 with 11, 239 / 217 / 210 / 252 with 16 / 32 / 40 / 64 dealt)
+        {   // chunking of the camera-major passes (k_schur_diag, k_cam_sums): (camera, chunk) workgroups
+            // Eight chunks, dealt to the eight XCDs (k_schur_diag: s.diag_xcd, a multiple of 8) -- more only where few cameras hold many
+            // observations (>= 512 workgroups, >= 4 096 observations each), fewer where a workgroup would get less than 256 observations.
+            // Round 5, LM it/s by chunk count (rounds 2-4 aimed at 2 048 workgroups of >= 512 observations: 40 chunks at 50 cameras, 16 at 200):
+            //   50 x 100 k x 1 M    2: 3 123   4: 3 269   5: 3 295   8: 3 309   10: 3 300   12: 3 278   16: 3 265   40: 3 180
+            //   perspective, same   4: 2 277   8: 2 333   12: 2 274   16: 2 281   40: 2 211
+            //   200 x 1 M x 10 M    4: 831   6: 840   8: 840-847   10: 848   12: 841   16: 840-846   24: 833   32: 822   64: 776
+            //   10 x 5 k x 30 k     1: 7 586   2: 7 758   3: 7 888   5: 7 958   8: 8 035
+            // The weighted / robust pass (two lines per entry; only where the diagonal blocks are not items of the pair kernel) takes twice as many
+            int chunks = 8;
+            while (chunks < 64 && (long long)p->M * chunks < 512 && K / ((long long)p->M * (chunks + 8)) >= 4096) chunks += 8;
+            while (chunks > 1 && K / ((long long)p->M * chunks) < 256) --chunks;
             int chunks_w = chunks;
             if (chunks >= 8) {
-                chunks = (chunks + 7) / 8 * 8;
                 chunks_w = std::min(64, 2 * chunks);
                 while (chunks_w > chunks && K / ((long long)p->M * chunks_w) < 512) chunks_w -= 8;
             }
@@ -1437,7 +1443,12 @@ static int front_schur_solve(satba_problem* p, bool automatic, double lam, doubl
         HIP_TRY(hipMemsetAsync(p->d_dg_cnt, 0, sizeof(int) * (size_t)p->M, p->stream));
     }
     const char* env_wgs = getenv("SATBA_CHOL_BESIDE_WGS");
-    const int wgs = (env_wgs && atoi(env_wgs) > 0) ? atoi(env_wgs) : 32;
+    // workgroups (= CUs) lent to the factorisation, a multiple of the eight XCDs.  Measured at 200 cameras x 5 (round 5, LM it/s): beside the
+    // unit-weight pair kernel (0.43 ms) 16: 777, 24: 819, 28: 820, 32: 841, 36: 793, 40: 788, 48: 783, 64: 802; beside the weighted one
+    // (1.3 ms: the factorisation has three times as long, the pair kernel misses every CU longer) 8: 439, 12: 456, 16: 460, 20: 454,
+    // 24: 436, 32: 433 (the sequential front: 433)
+    const bool weighted_front = wmode(p) && p->L.wl_ready;
+    const int wgs = (env_wgs && atoi(env_wgs) > 0) ? atoi(env_wgs) : (weighted_front ? 16 : 32);
     double* S = p->payload();
     double* rhs = S + (size_t)p->n_c * p->n_c;
     const int n = p->n_c;
@@ -1456,7 +1467,7 @@ static int front_schur_solve(satba_problem* p, bool automatic, double lam, doubl
         g.ts = p->d_ts;
 #endif
         g.arrive = p->d_arrive; g.arr_M = p->M; g.np = p->NP; g.arr_epoch = g.epoch; g.si = p->d_scale_inv; g.rhs = rhs;
-        g.arr_extra = (wmode(p) && p->L.wl_ready) ? 1 : 0;  // (the pair kernel writes the diagonal blocks and the right-hand side, too: launch_schur)
+        g.arr_extra = weighted_front ? 1 : 0;  // (the pair kernel writes the diagonal blocks and the right-hand side, too: launch_schur)
         // 5 ms + ~10 x what the kernels in front of a tile's last producer take at HBM speed (hit lists and records: ~100 bytes per hit)
         g.arr_timeout = 500000 + (long long)((double)p->L.E * 100.0 / 6e12 * 1e8 * 10.0) + (long long)((double)p->K * 200.0 / 6e12 * 1e8 * 10.0);
         hipLaunchKernelGGL(k_chol_tiles, dim3(std::min(chol_tiles_grid(n, 1), wgs)), dim3(1024), c3_lds_bytes(), p->chol_stream, g, p->gate);
@@ -1788,14 +1799,16 @@ static bool lm_device_loop_ok(const satba_problem* p) {
     const bool off = getenv("SATBA_HOST_LOOP") != nullptr;  // A/B runs and the tests' comparison of the two loops (read per call)
     return !off && p->world == 1 && p->n_c <= 1024;
 }
-// ... and whether it pays.  Round 5, 200 x 1 M x 10 M: linear loss 846 it/s on the device against 837 with the host's two header reads
-// per iteration (the factorisation beside the pair kernel took the dense solve off the critical path, and with it the slack that hid
-// the reads); soft_l1 411 - 420 against 427 - 438: three iterations in ten pause for the degenerate-subspace pattern there, which the
-// host has to notice and queue (LM_NEED_SUB: the ticks queued behind the pause pass empty).  Below 4 M observations the device loop
-// wins for every loss (50 x 100 k x 1 M: 2 580 / 2 500; 10 x 5 k x 30 k: 6 320 / 5 380, round 3).  SATBA_DEVICE_LOOP=1 / 0 forces the choice.
-static bool lm_device_loop_pays(const satba_problem* p) {
+// ... and whether it is the default: everywhere it can run (round 5).  200 x 1 M x 10 M: linear loss 846 it/s on the device against 837
+// with the host's two header reads per iteration (the factorisation beside the pair kernel took the dense solve off the critical
+// path, and with it the slack that hid the reads); soft_l1 463 / 463 / 463 against 465 / 463 / 464 -- three iterations in ten pause
+// there for the degenerate-subspace pattern, which the host has to notice and queue (LM_NEED_SUB: the ticks queued behind the pause
+// pass empty); with round 4's Schur phase that cost 411 - 420 against 427 - 438 and the host loop was the default for robust losses
+// from 4 M observations on.  Smaller problems: 50 x 100 k x 1 M 2 580 / 2 500, 10 x 5 k x 30 k 6 320 / 5 380 (round 3).
+// SATBA_DEVICE_LOOP=0 (or SATBA_HOST_LOOP) selects the host loop.
+static bool lm_device_loop_pays(const satba_problem*) {
     if (const char* e = getenv("SATBA_DEVICE_LOOP")) return atoi(e) != 0;
-    return p->loss == 0 || p->K < 4000000;
+    return true;
 }
 
 int satba_lm_state(satba_problem* p, double* out, int32_t n);
