@@ -300,6 +300,10 @@ static int slice_split(const satba_problem* p) {
     if (p->deterministic) return 0;  // the repeatability option keeps the summation order of the plain walk (goldens were made with it)
     int sh = 0;
     while (sh < 3 && ((long long)p->L.n_slices << sh) < 3000) ++sh;  // measured: 2 lanes per point at 100 k points, 8 at 5 k
+    // weighted / robust runs: at least two lanes per point at every size (their linearize kernel keeps one record in flight instead of
+    // two and sits at its register limit).  200 x 1M x 10M, soft_l1, LM it/s: 1 lane 455 / 455 / 455, 2 lanes 467 / 468 / 468, 4 lanes 459;
+    // unit weights + linear loss: 841 / 822
+    if (!(p->loss == 0 && p->unit_weights)) sh = std::max(sh, 1);
     return sh;
 }
 static int slice_grid(const satba_problem* p, int waves_per_block, int per_cu, int sh = 0) {
