@@ -419,7 +419,10 @@ __global__ void k_gather_obs1(long long K, const int* __restrict__ obs_pos, cons
 // ------------------------------------------------------------------------------------------------ K1 residuals
 // ba_core.fun (ref:bundle_adjust/ba_core.py:157-183).  *cost = 0.5 * sum rho.  f (ELL order) may be null (cost only).
 // UNITW: every weight is 1 and the loss is linear (the weight array is not read: 8 of 28 streamed bytes per observation)
-constexpr int RES_THREADS = 512;
+#ifndef SATBA_RES_THREADS
+#define SATBA_RES_THREADS 512
+#endif
+constexpr int RES_THREADS = SATBA_RES_THREADS;
 // TRIAL: the kernel forms the trial point itself -- x_new = x + (c0 v0 + c1 v1) / scale_inv for the points (the camera entries and
 // the camera constants at x_new come from k_trial_cams, launched in front) -- and returns |step|^2 and |x|^2 beside the cost: a
 // separate vector kernel moved 120 MB for this at 1 M points (27 us) and cost a launch.  a.x is not read then.
@@ -864,7 +867,10 @@ struct CamMajor {
     const int* __restrict__ pos;      // K: its ELL position (residuals)
     const int* __restrict__ io;       // K: its io index (row scales, stored RPC blocks)
 };
-constexpr int LINC_THREADS = 256;
+#ifndef SATBA_LINC_THREADS
+#define SATBA_LINC_THREADS 256
+#endif
+constexpr int LINC_THREADS = SATBA_LINC_THREADS;
 
 // error-free addition (Knuth): hi + t = s + e exactly; the error is collected in lo
 __device__ __forceinline__ void two_sum_acc(double& hi, double& lo, double t) {
@@ -1051,7 +1057,10 @@ __global__ __launch_bounds__(256) void k_prepare_vec(int n, int n_c, int NP, int
 
 // ------------------------------------------------------------------------------------------------ Jacobian-vector products
 constexpr int JVP_ROW = 15;  // per-camera constants of the affine form of k_jvp / k_backsub: B (6) | b (2) | A (6), odd stride
-constexpr int JVP_THREADS = 512;
+#ifndef SATBA_JVP_THREADS
+#define SATBA_JVP_THREADS 512
+#endif
+constexpr int JVP_THREADS = SATBA_JVP_THREADS;
 
 // affine cameras: J_c v_c = B_c X + b_c with B_c = sum_i v_ci D_ci, b_c = K-columns . v_cT, and J_p = A_c.  Every workgroup
 // derives the 14 constants of each camera once (three evaluations of the projector's Jacobian at the unit vectors) into an
@@ -1393,7 +1402,10 @@ __global__ __launch_bounds__(1024) void k_prepare_cams(int nU, int n_c, int NP, 
 // t_p = sum_obs Jp^T (Jc dc[cam]) per point in the lane's registers, then the point part of the Gauss-Newton step in scaled
 // variables, gn_h = scale_inv_p * Vinv (g_p - t), and the Gram matrix of (g_h, gn_h): hdr[1..3] = a, b, c.  The camera part
 // gn_h[0 .. n_c) = dc_h is copied by workgroup 0.  (Round 1 needed a staging buffer and a second kernel for the per-point sums.)
-constexpr int BS_THREADS = 512;
+#ifndef SATBA_BS_THREADS
+#define SATBA_BS_THREADS 512
+#endif
+constexpr int BS_THREADS = SATBA_BS_THREADS;
 template <int MODEL, int NP, bool CL, bool RL>
 __global__ __launch_bounds__(BS_THREADS) void k_backsub(ObsArgs a, const double* __restrict__ dc, const double* __restrict__ dch,
                                                         double lead, const double* __restrict__ Vinv, const double* __restrict__ g,

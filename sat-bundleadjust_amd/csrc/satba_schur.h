@@ -56,7 +56,10 @@ __device__ inline double schur_lambda(const double* __restrict__ hdr, double Del
 // texture path handles one line per cycle); the wave's 64 rows / records are contiguous in memory, so they are transposed through
 // LDS (row strides 48 and 144 bytes: the 16 lanes of a ds_write_b128 phase fall into disjoint banks) and written as three / eight
 // fully coalesced 16-byte stores per lane.  Workgroups of 256 threads, N need not be a multiple of 64.
-constexpr int VINV_THREADS = 256;
+#ifndef SATBA_VINV_THREADS
+#define SATBA_VINV_THREADS 256
+#endif
+constexpr int VINV_THREADS = SATBA_VINV_THREADS;
 __global__ __launch_bounds__(VINV_THREADS) void k_vinv(int N, double lam, const double* __restrict__ hdr_auto, double Delta, double lam_floor,
                                                        double* __restrict__ keep, const double* __restrict__ V,
                                                        const double* __restrict__ scale_inv_p, double* __restrict__ Vinv,
