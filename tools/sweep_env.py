@@ -1,4 +1,5 @@
-"""scratch: bench.py over values of one environment variable.  usage: _sweep.py TAG VAR v1,v2,... [bench args...]"""
+"""bench.py (no CPU leg, no e2e) over the values of one environment variable, one line per run: how the launch parameters in
+csrc/satba_capi.hip were chosen (ten runs fit one GPU call).  usage: sweep_env.py TAG VAR v1,v2,... [bench args...]   ("-": variable unset)"""
 import json, os, subprocess, sys
 tag, var, vals = sys.argv[1], sys.argv[2], sys.argv[3].split(",")
 args = sys.argv[4:]
