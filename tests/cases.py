@@ -60,3 +60,23 @@ def tri_case(name):
     g = np.load(os.path.join(GOLDEN, "init_pts3d.npz"))
     sub = {k[len(name) + 1:]: g[k] for k in g.files if k.startswith(name + "_")}
     return scene, sub["C"], [tuple(int(v) for v in pr) for pr in sub["pairs"]], sub
+
+
+def random_case(seed):
+    """A small random problem (tools/fuzz_solve.py, test_random_problems_end_where_the_oracle_ends): camera model, sizes, track
+    length, correction mode, loss, frozen cameras / points and the reference camera's weight drawn from `seed`.
+    Returns (tag, params, loss)."""
+    rng = np.random.default_rng(1000 + seed)
+    model = ["affine", "perspective", "rpc"][rng.integers(0, 3)]
+    n_cam = int(rng.integers(2, 70)) if model != "rpc" else int(rng.integers(2, 12))
+    n_pts = int(rng.integers(40, 2500)) if model != "rpc" else int(rng.integers(40, 600))
+    opp = int(rng.integers(2, min(n_cam, 12) + 1))
+    corr = [["R"], ["R", "T"]][rng.integers(0, 2)]
+    loss = ["linear", "soft_l1", "huber", "cauchy"][rng.integers(0, 4)]
+    d = {"correction_params": corr, "n_cam_fix": int(rng.integers(0, min(3, n_cam))), "n_pts_fix": int(rng.integers(0, 2)) * 5,
+         "ref_cam_weight": [1.0, 3.0][rng.integers(0, 2)]}
+    scene = synth.make_scene(model, n_cam, n_pts, opp, seed=seed, sigma_theta=2e-6 if model != "rpc" else 1e-6)
+    p = synth.make_params(scene, d)
+    tag = "{} M{} N{} K{} opp{} {} {} fix{}/{} w{}".format(model, p.n_cam, p.n_pts, p.n_obs, opp, "".join(corr), loss, d["n_cam_fix"],
+                                                          d["n_pts_fix"], d["ref_cam_weight"])
+    return tag, p, loss
