@@ -171,6 +171,8 @@ struct satba_problem {
     double *d_xb_own = nullptr, *d_xb = nullptr;
     long long xb_len = 0;
     double* h_pin = nullptr;  // pinned staging for header reads
+    bool dir_global = false;       // affine cameras whose direction tables (k_jvp, k_backsub) do not fit the LDS: d_dir_tab, built per launch
+    double* d_dir_tab = nullptr;   // 2 x M x JVP_ROW
     void* h_stage = nullptr;  // pinned staging of the transfers between the caller's arrays and the device (copy_to_host)
     size_t h_stage_len = 0;
     double* d_x0 = nullptr;   // satba_snapshot_x
@@ -251,6 +253,7 @@ static ObsArgs obs_args(const satba_problem* p, bool at_new) {
     a.rep_shift = p->lin_rep_shift;
     a.fxe = p->d_fxe; a.fx_flag = p->d_fxflag; a.gate = p->gate;
     a.prep_scale = nullptr; a.prep_gh = nullptr; a.prep_ghs = nullptr; a.prep_first_dev = nullptr; a.prep_first = 0;
+    a.dir_tab = p->d_dir_tab;
     a.sh = 0;  // lanes per point: set by the launchers of the kernels that support it
     return a;
 }
@@ -402,10 +405,11 @@ static int raise_lin_limits(satba_problem* p) {
     TRY(raise_lds_limit(k_residual<MODEL, NP, CL, RL, false, false>, table_bytes(p)));
     TRY(raise_lds_limit(k_residual<MODEL, NP, CL, RL, true, true>, table_bytes(p)));
     TRY(raise_lds_limit(k_residual<MODEL, NP, CL, RL, false, true>, table_bytes(p)));
-    const size_t t = std::max(table_bytes(p), dir_table_bytes(p));
+    const size_t dirb = p->dir_global ? 0 : dir_table_bytes(p);  // (global direction tables: those instantiations take no dynamic LDS)
+    const size_t t = std::max(table_bytes(p), dirb);
     TRY(raise_lds_limit(k_jvp<MODEL, NP, 1, CL, RL, true>, t));
     TRY(raise_lds_limit(k_jvp<MODEL, NP, 1, CL, RL, false>, t));
-    TRY(raise_lds_limit(k_jvp<MODEL, NP, 2, CL, RL, false>, std::max(t, 2 * dir_table_bytes(p))));
+    TRY(raise_lds_limit(k_jvp<MODEL, NP, 2, CL, RL, false>, std::max(t, 2 * dirb)));
     TRY(raise_lds_limit(k_backsub<MODEL, NP, CL, RL>, t));
     return 0;
 }
@@ -527,6 +531,13 @@ static int launch_backsub_kernel(satba_problem* p) {
     a.sh = slice_split(p);
     const int grid = slice_grid(p, BS_THREADS / 64, 2, a.sh);
     const size_t lds = p->model == AFFINE ? dir_table_bytes(p) : table_bytes(p);
+    if (p->dir_global) {
+        SATBA_DISPATCH(p, if constexpr (MODEL == AFFINE) {
+            hipLaunchKernelGGL((k_affine_dir_tab<NP>), dim3(1), dim3(1024), 0, p->stream, a, p->d_dc, (const double*)nullptr, (const double*)nullptr);
+            hipLaunchKernelGGL((k_backsub<MODEL, NP, CL, RL, true>), dim3(grid), dim3(BS_THREADS), 0, p->stream, a, p->d_dc, p->d_dch, p->lead,
+                               p->d_Vinv, p->d_g, p->d_scale_inv, p->d_gh, p->d_gn, p->red(RB_BS), p->d_xb);
+        });
+    } else
     SATBA_DISPATCH(p, hipLaunchKernelGGL((k_backsub<MODEL, NP, CL, RL>), dim3(grid), dim3(BS_THREADS), lds, p->stream, a, p->d_dc, p->d_dch, p->lead,
                                          p->d_Vinv, p->d_g, p->d_scale_inv, p->d_gh, p->d_gn, p->red(RB_BS), p->d_xb));
     HIP_TRY(hipGetLastError());
@@ -539,7 +550,13 @@ static int launch_jvp(satba_problem* p, int nv, const double* q1, const double* 
     a.sh = slice_split(p);
     const int grid = slice_grid(p, JVP_THREADS / 64, 2, a.sh);
     const RedBuf rb = p->red(RB_JVP);
-    if (nv == 1 && pre) {
+    if (p->dir_global && (nv == 2 || pre)) {  // (affine) direction tables from global memory, built here
+        SATBA_DISPATCH(p, if constexpr (MODEL == AFFINE) {
+            hipLaunchKernelGGL((k_affine_dir_tab<NP>), dim3(1), dim3(1024), 0, p->stream, a, q1, nv == 2 ? q2 : nullptr, nv == 2 ? p->d_scale_inv : nullptr);
+            if (nv == 1) hipLaunchKernelGGL((k_jvp<MODEL, NP, 1, CL, RL, true, true>), dim3(grid), dim3(JVP_THREADS), 0, p->stream, a, q1, q2, p->d_scale_inv, rb, out);
+            else hipLaunchKernelGGL((k_jvp<MODEL, NP, 2, CL, RL, false, true>), dim3(grid), dim3(JVP_THREADS), 0, p->stream, a, q1, q2, p->d_scale_inv, rb, out);
+        });
+    } else if (nv == 1 && pre) {
         const size_t lds = p->model == AFFINE ? dir_table_bytes(p) : table_bytes(p);
         SATBA_DISPATCH(p, hipLaunchKernelGGL((k_jvp<MODEL, NP, 1, CL, RL, true>), dim3(grid), dim3(JVP_THREADS), lds, p->stream, a, q1, q2, p->d_scale_inv, rb, out));
     } else if (nv == 1) {
@@ -970,7 +987,10 @@ int satba_problem_create(const satba_problem_desc* d, satba_problem** out) {
         p->camc_lds = (camc_b <= 48 * 1024 && used + camc_b <= budget && !getenv("SATBA_CAMC_GLOBAL")) ? 1 : 0;
         used += p->camc_lds ? camc_b : 0;
         p->rpc_lds = (p->model == RPC && rpc_b <= 64 * 1024 && used + rpc_b <= budget && !getenv("SATBA_RPC_GLOBAL")) ? 1 : 0;
-        if (dir_table_bytes(p) > budget) return fail(SATBA_E_ARG, "n_cam = %d exceeds the LDS budget of the per-camera tables", p->M);
+        // affine cameras: the direction tables of k_jvp (two for the explicit-products pattern) and k_backsub live in the LDS up to ~640
+        // cameras, beyond that in global memory (k_affine_dir_tab in front of every such launch)
+        p->dir_global = p->model == AFFINE && (2 * dir_table_bytes(p) > budget || getenv("SATBA_DIR_GLOBAL"));  // (the switch: tests)
+        if (p->dir_global) TRY(dev_alloc(p, &p->d_dir_tab, (size_t)2 * p->M * JVP_ROW));
         SATBA_DISPATCH(p, TRY((raise_lin_limits<MODEL, NP, CL, RL>(p))));
 
         const size_t n = p->n, Pz = (size_t)std::max(p->L.P, 1) + 64;

@@ -89,6 +89,8 @@ struct ObsArgs {
                                          // the two constants of the range check
     int* __restrict__ fx_flag;           // set when a term leaves its range (the sums are then formed by k_cam_sums instead)
     const int* gate;                     // SATBA_GATE
+    double* dir_tab;                     // affine cameras beyond the LDS (k_jvp / k_backsub with DG): their direction tables in global
+                                         // memory (2 x M x JVP_ROW), filled by k_affine_dir_tab in front of the kernel
     // k_linearize, single-rank loops: the point part of the prepare phase (x_scale="jac" update, g_h, g_h / scale_inv, and the point
     // sums of |g_h|^2 and |x_h|^2) is done in the lane that has just formed the point's blocks -- the vector kernel of the prepare
     // phase then only visits the camera entries (it read V, g, x, scale_inv of 3 N entries again: 43 us at 1 M points).  Null: not fused.
@@ -1096,10 +1098,20 @@ __device__ inline void affine_dir_table(const ObsArgs& a, const double* __restri
     __syncthreads();
 }
 
+// The same tables in global memory (a.dir_tab), one launch of one workgroup in front of k_jvp / k_backsub<..., DG = true>: camera counts
+// whose tables do not fit the LDS (two tables of 120 bytes per camera: from ~640 cameras on).  v2 (or null): a second direction
+template <int NP>
+__global__ __launch_bounds__(1024) void k_affine_dir_tab(ObsArgs a, const double* __restrict__ v1, const double* __restrict__ v2, const double* __restrict__ vs) {
+    SATBA_GATE(a.gate);
+    affine_dir_table<NP>(a, v1, a.dir_tab, 1024, vs);
+    if (v2) affine_dir_table<NP>(a, v2, a.dir_tab + (size_t)a.M * JVP_ROW, 1024, vs);
+}
+
 // For NV vectors given in scaled variables (v = q / scale_inv): sums of (J v_a) . (J v_b) over the observations.
 // NV = 1: out[0] = |J v1|^2.   NV = 2: out[0] = |J v1|^2, out[1] = (J v1).(J v2), out[2] = |J v2|^2.
 // PRE (NV = 1): q1 is already divided by scale_inv (k_prepare_vec)
-template <int MODEL, int NP, int NV, bool CL, bool RL, bool PRE>
+// DG (affine cameras): the direction tables are read from a.dir_tab (k_affine_dir_tab) instead of being built in the LDS
+template <int MODEL, int NP, int NV, bool CL, bool RL, bool PRE, bool DG = false>
 __global__ __launch_bounds__(JVP_THREADS) void k_jvp(ObsArgs a, const double* __restrict__ q1, const double* __restrict__ q2,
                                                      const double* __restrict__ scale_inv, RedBuf rb, double* __restrict__ out) {
     SATBA_GATE(a.gate);
@@ -1108,8 +1120,8 @@ __global__ __launch_bounds__(JVP_THREADS) void k_jvp(ObsArgs a, const double* __
     constexpr int WAVES = JVP_THREADS / 64;
     double s11 = 0.0, s12 = 0.0, s22 = 0.0;
     if constexpr (MODEL == AFFINE && PRE && NV == 1) {
-        double* tab = s_dyn_jvp;  // M x JVP_ROW
-        affine_dir_table<NP>(a, q1, tab, JVP_THREADS);
+        const double* tab = DG ? a.dir_tab : s_dyn_jvp;  // M x JVP_ROW
+        if constexpr (!DG) affine_dir_table<NP>(a, q1, s_dyn_jvp, JVP_THREADS);
         for_each_slice(a.n_slices << a.sh, WAVES, [&](const int u) {
             const SliceUnit su(a, u, lane);
             const int q = su.q;
@@ -1146,10 +1158,12 @@ __global__ __launch_bounds__(JVP_THREADS) void k_jvp(ObsArgs a, const double* __
     } else if constexpr (MODEL == AFFINE && !PRE && NV == 2) {
         // the two directions of the explicit-products pattern (g_h and gn_h parallel: 30 % of the soft_l1 iterations at 200 cameras):
         // two direction tables instead of a Jacobian evaluation per observation (208 -> ~110 us at 10 M observations)
-        double* tab1 = s_dyn_jvp;
-        double* tab2 = s_dyn_jvp + (size_t)a.M * JVP_ROW;
-        affine_dir_table<NP>(a, q1, tab1, JVP_THREADS, scale_inv);
-        affine_dir_table<NP>(a, q2, tab2, JVP_THREADS, scale_inv);
+        const double* tab1 = DG ? a.dir_tab : s_dyn_jvp;
+        const double* tab2 = tab1 + (size_t)a.M * JVP_ROW;
+        if constexpr (!DG) {
+            affine_dir_table<NP>(a, q1, s_dyn_jvp, JVP_THREADS, scale_inv);
+            affine_dir_table<NP>(a, q2, s_dyn_jvp + (size_t)a.M * JVP_ROW, JVP_THREADS, scale_inv);
+        }
         for_each_slice(a.n_slices << a.sh, WAVES, [&](const int u) {
             const SliceUnit su(a, u, lane);
             const int q = su.q;
@@ -1406,7 +1420,7 @@ __global__ __launch_bounds__(1024) void k_prepare_cams(int nU, int n_c, int NP, 
 #define SATBA_BS_THREADS 512
 #endif
 constexpr int BS_THREADS = SATBA_BS_THREADS;
-template <int MODEL, int NP, bool CL, bool RL>
+template <int MODEL, int NP, bool CL, bool RL, bool DG = false>
 __global__ __launch_bounds__(BS_THREADS) void k_backsub(ObsArgs a, const double* __restrict__ dc, const double* __restrict__ dch,
                                                         double lead, const double* __restrict__ Vinv, const double* __restrict__ g,
                                                         const double* __restrict__ scale_inv, const double* __restrict__ gh,
@@ -1424,8 +1438,8 @@ __global__ __launch_bounds__(BS_THREADS) void k_backsub(ObsArgs a, const double*
         }
     }
     CamTables<CL, RL> T;
-    double* tab = s_dyn_bs;
-    if constexpr (MODEL == AFFINE) affine_dir_table<NP>(a, dc, tab, BS_THREADS);
+    const double* tab = DG ? a.dir_tab : s_dyn_bs;  // (DG: built by k_affine_dir_tab in front)
+    if constexpr (MODEL == AFFINE) { if constexpr (!DG) affine_dir_table<NP>(a, dc, s_dyn_bs, BS_THREADS); }
     else T.stage(a, s_dyn_bs, BS_THREADS);
     for_each_slice(a.n_slices << a.sh, WAVES, [&](const int u) {
         const SliceUnit su(a, u, lane);

@@ -562,6 +562,24 @@ def test_random_problems_end_where_the_oracle_ends(gpu, seed):
     assert abs(rd.cost - ro.cost) <= 1e-8 * ro.cost, (tag, rd.cost, ro.cost)
 
 
+@pytest.mark.parametrize("loss", ["linear", "soft_l1"])
+def test_more_cameras_than_the_lds_tables_hold(gpu, monkeypatch, loss):
+    """700 affine cameras (2 100 camera unknowns): the direction tables of k_jvp / k_backsub come from global memory, the camera
+    constants too, the loop runs on the host (more than 1 024 camera unknowns) -- round 5: the handle could not be created from
+    667 cameras on.  The solve must end where the same problem with the tables forced out of the LDS at a size that fits ends is
+    checked by test_alternative_kernel_paths; here: it converges to the noise level of the scene (0.3 px)."""
+    scene = synth.make_scene("affine", 700, 20000, 6, seed=2, sigma_theta=2e-6)
+    p = synth.make_params(scene, {"correction_params": ["R"], "n_cam_fix": 1})
+    e = HipEngine(p)
+    e.configure(loss, 1.0)
+    e.set_x(p.params_opt.copy())
+    st = e.solve_lm(ftol=1e-8, xtol=1e-10, gtol=1e-8, max_nfev=100, loss=loss, f_scale=1.0)
+    assert st.status > 0 and st.cost < 2e-2 * st.initial_cost, (st.status, st.cost, st.initial_cost)
+    # 0.3 px noise on both coordinates: 0.5 * 2 * 0.09 per observation before the degrees of freedom are taken off
+    assert 0.03 < st.cost / p.n_obs < 0.09, st.cost / p.n_obs
+    e.close()
+
+
 def test_ragged_and_tiny_problems(gpu):
     """2 cameras x 3 points, every point seen twice; and a problem whose tiles end exactly on 64 observations."""
     scene = synth.make_affine_scene(2, 3, 2, seed=9)
@@ -1039,6 +1057,7 @@ ALT_PATHS = [
     {"SATBA_SCHUR_CHUNKS": "3"},     # pair lists cut into point-range chunks + partial reduce
     {"SATBA_SCHUR_CHUNKS": "1"},     # ... and as one chunk (direct store)
     {"SATBA_CM_CHUNKS": "5"},        # chunking of the camera-major passes
+    {"SATBA_DIR_GLOBAL": "1"},       # affine cameras: direction tables of k_jvp / k_backsub in global memory (more than ~640 cameras)
 ]
 
 
