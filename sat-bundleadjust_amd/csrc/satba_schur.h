@@ -342,8 +342,12 @@ __device__ __forceinline__ void schur_diag_walk(const ObsArgs& a, const double2*
 #ifndef SATBA_PAIRS_OCC_W
 #define SATBA_PAIRS_OCC_W 3  // weighted / robust affine kernel (round 5: with 2 waves per SIMD and no spills the Schur phase is 1.21 instead of 1.09 ms)
 #endif
+#ifndef SATBA_PAIRS_OCC_MIN_O
+#define SATBA_PAIRS_OCC_MIN_O 1  // perspective / RPC kernels: least waves per SIMD the register allocator must leave room for (218 - 252 registers: two
+                                 // waves.  Round 5, forced to 3 -- 168 registers, 88 - 340 bytes of scratch in the hit loop: C5 1 419 against 1 699 it/s, P3 1 209 / 2 324)
+#endif
 template <int MODEL, int NP, bool UNITW>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((MODEL == AFFINE) ? (UNITW ? SATBA_PAIRS_OCC_U : SATBA_PAIRS_OCC_W) : 1, (MODEL == AFFINE) ? (UNITW ? SATBA_PAIRS_OCC_U : SATBA_PAIRS_OCC_W) : 3))) void k_schur_pairs(ObsArgs a, SchurArgs s, double* __restrict__ S) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((MODEL == AFFINE) ? (UNITW ? SATBA_PAIRS_OCC_U : SATBA_PAIRS_OCC_W) : SATBA_PAIRS_OCC_MIN_O, (MODEL == AFFINE) ? (UNITW ? SATBA_PAIRS_OCC_U : SATBA_PAIRS_OCC_W) : 3))) void k_schur_pairs(ObsArgs a, SchurArgs s, double* __restrict__ S) {
     SATBA_GATE(a.gate);
     __shared__ double2 s_coop[4 * 64 * 7];  // per wave: 64 records x 80 (112: with the scales) bytes, or 64 Jacobian rows x 112 (the cooperative gathers are transposed here)
     __shared__ unsigned s_idx[4][3 * 64];   // weighted / robust: the three gather indices of a wave's 64 hits
