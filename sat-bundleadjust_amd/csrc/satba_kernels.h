@@ -1063,6 +1063,13 @@ constexpr int JVP_ROW = 15;  // per-camera constants of the affine form of k_jvp
 #define SATBA_JVP_THREADS 512
 #endif
 constexpr int JVP_THREADS = SATBA_JVP_THREADS;
+// slots of a point whose camera index (and row scales) are in flight ahead of the one being worked on, in the table forms of k_jvp and
+// k_backsub.  Not what bounds them: depths 2 / 4 / 8 give 49.9 / 50.0 / 49.9 us (k_jvp) and 55.4 / 54.9 / 55.6 us (k_backsub) at
+// 200 x 1M x 10M (round 5).  Their time is the LDS: 14 eight-byte reads per observation from the table row of a random camera -- 64 lanes on
+// ~50 different rows, a measured ~3.5 passes per read -- i.e. ~197 cycles per wave and iteration and CU, which is what 50 us are
+#ifndef SATBA_CAM_PF
+#define SATBA_CAM_PF 2
+#endif
 
 // affine cameras: J_c v_c = B_c X + b_c with B_c = sum_i v_ci D_ci, b_c = K-columns . v_cT, and J_p = A_c.  Every workgroup
 // derives the 14 constants of each camera once (three evaluations of the projector's Jacobian at the unit vectors) into an
@@ -1137,22 +1144,32 @@ __global__ __launch_bounds__(JVP_THREADS) void k_jvp(ObsArgs a, const double* __
             int pos = su.pos;
             const int io0 = has ? a.ipt_ofs[q] : 0;
             // cameras (and row scales) of the next two slots in flight
-            const int k1 = su.slot(1);
-            int c0 = (su.g < cnt) ? a.e_cam[pos] : 0, c1 = (k1 < cnt) ? a.e_cam[pos + su.step] : 0;
-            double2 s0 = (su.g < cnt && a.sc) ? a.sc[io0 + su.g] : make_double2(1.0, 1.0), s1 = (k1 < cnt && a.sc) ? a.sc[io0 + k1] : make_double2(1.0, 1.0);
+            constexpr int D = SATBA_CAM_PF;
+            int cq[D];
+            double2 sq[D];
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                const int kd = su.slot(d);
+                cq[d] = 0; sq[d] = make_double2(1.0, 1.0);
+                if (kd < cnt) { cq[d] = a.e_cam[pos + d * su.step]; if (a.sc) sq[d] = a.sc[io0 + kd]; }
+            }
             for (int tt = 0; tt < su.nt; ++tt, pos += su.step) {
-                const int k = su.slot(tt), k2 = su.slot(tt + 2);
-                int c2 = 0;
-                double2 s2 = make_double2(1.0, 1.0);
-                if (k2 < cnt) { c2 = a.e_cam[pos + 2 * su.step]; if (a.sc) s2 = a.sc[io0 + k2]; }
+                const int k = su.slot(tt), kn = su.slot(tt + D);
+                int cn = 0;
+                double2 sn = make_double2(1.0, 1.0);
+                if (kn < cnt) { cn = a.e_cam[pos + D * su.step]; if (a.sc) sn = a.sc[io0 + kn]; }
                 __builtin_amdgcn_sched_barrier(0);
+                const int c0 = cq[0];
+                const double2 s0 = sq[0];
                 if (k < cnt) {
                     const double* row = tab + (size_t)c0 * JVP_ROW;
                     const double j0 = s0.x * (row[0] * X + row[1] * Y + row[2] * Z + row[6] + row[8] * v0 + row[9] * v1 + row[10] * v2);
                     const double j1 = s0.y * (row[3] * X + row[4] * Y + row[5] * Z + row[7] + row[11] * v0 + row[12] * v1 + row[13] * v2);
                     s11 += j0 * j0 + j1 * j1;
                 }
-                c0 = c1; c1 = c2; s0 = s1; s1 = s2;
+#pragma unroll
+                for (int d = 0; d + 1 < D; ++d) { cq[d] = cq[d + 1]; sq[d] = sq[d + 1]; }
+                cq[D - 1] = cn; sq[D - 1] = sn;
             }
         });
     } else if constexpr (MODEL == AFFINE && !PRE && NV == 2) {
@@ -1183,15 +1200,23 @@ __global__ __launch_bounds__(JVP_THREADS) void k_jvp(ObsArgs a, const double* __
             }
             int pos = su.pos;
             const int io0 = has ? a.ipt_ofs[q] : 0;
-            const int k1 = su.slot(1);
-            int c0 = (su.g < cnt) ? a.e_cam[pos] : 0, c1 = (k1 < cnt) ? a.e_cam[pos + su.step] : 0;
-            double2 s0 = (su.g < cnt && a.sc) ? a.sc[io0 + su.g] : make_double2(1.0, 1.0), s1 = (k1 < cnt && a.sc) ? a.sc[io0 + k1] : make_double2(1.0, 1.0);
+            constexpr int D = SATBA_CAM_PF;
+            int cq[D];
+            double2 sq[D];
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                const int kd = su.slot(d);
+                cq[d] = 0; sq[d] = make_double2(1.0, 1.0);
+                if (kd < cnt) { cq[d] = a.e_cam[pos + d * su.step]; if (a.sc) sq[d] = a.sc[io0 + kd]; }
+            }
             for (int tt = 0; tt < su.nt; ++tt, pos += su.step) {
-                const int k = su.slot(tt), k2 = su.slot(tt + 2);
-                int c2 = 0;
-                double2 s2 = make_double2(1.0, 1.0);
-                if (k2 < cnt) { c2 = a.e_cam[pos + 2 * su.step]; if (a.sc) s2 = a.sc[io0 + k2]; }
+                const int k = su.slot(tt), kn = su.slot(tt + D);
+                int cn = 0;
+                double2 sn = make_double2(1.0, 1.0);
+                if (kn < cnt) { cn = a.e_cam[pos + D * su.step]; if (a.sc) sn = a.sc[io0 + kn]; }
                 __builtin_amdgcn_sched_barrier(0);
+                const int c0 = cq[0];
+                const double2 s0 = sq[0];
                 if (k < cnt) {
                     const double* r1 = tab1 + (size_t)c0 * JVP_ROW;
                     const double* r2 = tab2 + (size_t)c0 * JVP_ROW;
@@ -1204,7 +1229,9 @@ __global__ __launch_bounds__(JVP_THREADS) void k_jvp(ObsArgs a, const double* __
                     s12 += u0 * w0 + u1 * w1;
                     s22 += w0 * w0 + w1 * w1;
                 }
-                c0 = c1; c1 = c2; s0 = s1; s1 = s2;
+#pragma unroll
+                for (int d = 0; d + 1 < D; ++d) { cq[d] = cq[d + 1]; sq[d] = sq[d + 1]; }
+                cq[D - 1] = cn; sq[D - 1] = sn;
             }
         });
     } else {
@@ -1456,18 +1483,26 @@ __global__ __launch_bounds__(BS_THREADS) void k_backsub(ObsArgs a, const double*
         int pos = su.pos;
         const int io0 = has ? a.ipt_ofs[q] : 0;
         if constexpr (MODEL == AFFINE) {
-            const int k1 = su.slot(1);
-            int c0 = (su.g < cnt) ? a.e_cam[pos] : 0, c1 = (k1 < cnt) ? a.e_cam[pos + su.step] : 0;
-            double2 w0 = (su.g < cnt && a.sc) ? a.sc[io0 + su.g] : make_double2(1.0, 1.0), w1 = (k1 < cnt && a.sc) ? a.sc[io0 + k1] : make_double2(1.0, 1.0);
+            constexpr int D = SATBA_CAM_PF;
+            int cq[D];
+            double2 sq[D];
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                const int kd = su.slot(d);
+                cq[d] = 0; sq[d] = make_double2(1.0, 1.0);
+                if (kd < cnt) { cq[d] = a.e_cam[pos + d * su.step]; if (a.sc) sq[d] = a.sc[io0 + kd]; }
+            }
             for (int tt = 0; tt < su.nt; ++tt, pos += su.step) {
-                const int k = su.slot(tt), k2 = su.slot(tt + 2);
-                int c2 = 0;
-                double2 w2 = make_double2(1.0, 1.0);
-                if (k2 < cnt) { c2 = a.e_cam[pos + 2 * su.step]; if (a.sc) w2 = a.sc[io0 + k2]; }
+                const int k = su.slot(tt), kn = su.slot(tt + D);
+                int cn = 0;
+                double2 sn = make_double2(1.0, 1.0);
+                if (kn < cnt) { cn = a.e_cam[pos + D * su.step]; if (a.sc) sn = a.sc[io0 + kn]; }
                 __builtin_amdgcn_sched_barrier(0);
-                const int cam = c0;
-                const double2 s2 = w0;
-                c0 = c1; c1 = c2; w0 = w1; w1 = w2;
+                const int cam = cq[0];
+                const double2 s2 = sq[0];
+#pragma unroll
+                for (int d = 0; d + 1 < D; ++d) { cq[d] = cq[d + 1]; sq[d] = sq[d + 1]; }
+                cq[D - 1] = cn; sq[D - 1] = sn;
                 if (k < cnt) {
                     const double* row = tab + (size_t)cam * JVP_ROW;
                     // both blocks of an observation carry its row scale
