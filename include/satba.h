@@ -244,6 +244,12 @@ int satba_outliers(satba_problem *p, const double *err, double predef_thr, doubl
  * reference's operations with their roundings (bit-identical to the host formula); host_cost (optional): 0.5 |f|^2.  What
  * ref:bundle_adjust/ba_core.py:277,303-304 computes before and after the solve.                                                  */
 int satba_reprojection_errors(satba_problem *p, double *host_err, double *host_cost);
+/* The same in two steps (round 6): _begin queues the error kernels at the current x into a device buffer of the handle and returns
+ * without waiting; _fetch moves the K errors to host_err and may be called from ANOTHER host thread while this handle runs the solve
+ * that follows -- the download of ref:bundle_adjust/ba_core.py:277's initial errors then overlaps the region :283-299 times.  One
+ * _fetch per _begin; the values are those of the x at _begin whatever the handle has done since.                                  */
+int satba_reprojection_errors_begin(satba_problem *p);
+int satba_reprojection_errors_fetch(satba_problem *p, double *host_err);
 
 /* device-side copy of the current point (no host transfer): restore == 0 keeps x, restore != 0 returns to the kept x, as
  * satba_set_x with the same vector would.  bench.py restarts its solve with it; a caller can use it to retry a solve. */

@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
@@ -15,6 +16,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/satba.h"
@@ -162,7 +164,8 @@ struct satba_problem {
     int arrive_epoch = 0;      // != 0 while a front with the factorisation beside it is being queued (launch_schur)
     bool beside_last = false;  // the last front ran that way
     bool beside_off = false;   // ... and timed out waiting for the pair kernel (kernels serialised by a tool, one hardware queue for both streams)
-    int beside_clean = 0;      // sequential fronts since the time-out; the concurrent front is tried again after beside_retry_after of
+    int beside_clean = 0;      // sequential fronts QUEUED since the time-out (the device-resident loop also queues fronts that pass gated off:
+                               // an upper bound of the ones that ran); the concurrent front is tried again after beside_retry_after of
     int beside_retry_after = 64;  // them, and the interval doubles with every further time-out (a profiler costs a handful of stalls, not one per front)
     int beside_timeouts = 0;
     double* d_scal = nullptr;  // 8 private scalars (costs of satba_residuals, timing sinks)
@@ -175,6 +178,12 @@ struct satba_problem {
     double* d_dir_tab = nullptr;   // 2 x M x JVP_ROW
     void* h_stage = nullptr;  // pinned staging of the transfers between the caller's arrays and the device (copy_to_host)
     size_t h_stage_len = 0;
+    // large transfers (round 6): COPY_LANES slices, each with a stream, a thread and two pinned chunks of its own (copy_big)
+    struct CopyLane { hipStream_t st = nullptr; char* pin = nullptr; };
+    CopyLane lanes[8];
+    bool lanes_ready = false;
+    double* d_err_keep = nullptr;      // K per-observation errors kept for satba_reprojection_errors_fetch (caller's order)
+    hipEvent_t ev_err = nullptr;       // ... complete on the device
     double* d_x0 = nullptr;   // satba_snapshot_x
     bool linearized = false, have_step = false;
     double create_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -308,6 +317,12 @@ static int slice_split(const satba_problem* p) {
     // unit weights + linear loss: 841 / 822
     if (!(p->loss == 0 && p->unit_weights)) sh = std::max(sh, 1);
     return sh;
+}
+// grid of k_linearize: one workgroup per CU (its LDS table is flushed once per workgroup; d_part holds 512 partial tables).  Depends on
+// the lanes per point, i.e. on the configured loss: recomputed by satba_configure (round-5 advisor: a unit-weight handle later
+// configured for a robust loss kept the grid of one lane per point -- half the workgroups on small problems)
+static int lin_grid_for(const satba_problem* p) {
+    return std::min(512, grid_for((long long)p->L.n_slices << slice_split(p), LinCfg<false>::WAVES, 256 * (1024 / LinCfg<false>::THREADS)));
 }
 static int slice_grid(const satba_problem* p, int waves_per_block, int per_cu, int sh = 0) {
     static const int env = getenv("SATBA_BPC") ? atoi(getenv("SATBA_BPC")) : 0;
@@ -694,9 +709,14 @@ static int ensure_wlayout(satba_problem* p) {
     int *sz = nullptr, *wb = nullptr;
     char* cub = nullptr;
     size_t need = 0;
-    HIP_TRY(hipMalloc((void**)&sz, sizeof(int) * (Nz + 1)));
-    HIP_TRY(hipMalloc((void**)&wb, sizeof(int) * (Nz + 1)));
+    // (round-5 advisor) the piece offsets are 32-bit: a record has at most track length + 13 pieces, so K + 13 N + 8 bounds the total
+    // without waiting for the scan (whose int32 total could wrap to a positive value); pair_kk packs two track positions into 16 bits
+    // each -- a track is at most M observations long (cameras strictly ascending inside a point)
+    if ((long long)p->K + 13LL * N + 8 >= (1LL << 31)) return fail(SATBA_E_ARG, "the merged records of this shard exceed 2^31 pieces");
+    if (M >= 65536) return fail(SATBA_E_ARG, "the merged record layout holds track positions in 16 bits: fewer than 65 536 cameras");
     int rc = [&]() -> int {
+        HIP_TRY(hipMalloc((void**)&sz, sizeof(int) * (Nz + 1)));  // (freed below whatever fails from here on)
+        HIP_TRY(hipMalloc((void**)&wb, sizeof(int) * (Nz + 1)));
         TRY(dev_alloc(p, &L.w_fix, Nz)); TRY(dev_alloc(p, &L.sc_ofs, Nz));
         HIP_TRY(hipMemsetAsync(sz, 0, sizeof(int) * (Nz + 1), st));
         hipLaunchKernelGGL(k_lay_wsize, dim3((unsigned)((Nz + 255) / 256)), dim3(256), 0, st, N, L.pt_cnt, sz);
@@ -735,7 +755,8 @@ static int ensure_wlayout(satba_problem* p) {
         HIP_TRY(hipStreamSynchronize(st));
         return 0;
     }();
-    (void)hipFree(sz); (void)hipFree(wb);
+    if (sz) (void)hipFree(sz);
+    if (wb) (void)hipFree(wb);
     if (cub) (void)hipFree(cub);
     if (rc) return rc;
     L.wl_ready = true;
@@ -1035,7 +1056,7 @@ int satba_problem_create(const satba_problem_desc* d, satba_problem** out) {
         TRY(dev_alloc(p, &p->d_red_cnt, RED_SLOTS));
         HIP_TRY(hipMemset(p->d_red_cnt, 0, sizeof(unsigned) * RED_SLOTS));
         // one workgroup per CU for the linearize kernel (its LDS table is flushed once per workgroup)
-        p->lin_grid = grid_for((long long)p->L.n_slices << slice_split(p), LinCfg<false>::WAVES, 256 * (1024 / LinCfg<false>::THREADS));
+        p->lin_grid = lin_grid_for(p);
         TRY(dev_alloc(p, &p->d_part, (size_t)512 * p->M * cam_sum_len(p->NP)));
         {   // chunking of the camera-major passes (k_schur_diag, k_cam_sums): (camera, chunk) workgroups
             // Eight chunks, dealt to the eight XCDs (k_schur_diag: s.diag_xcd, a multiple of 8) -- more only where few cameras hold many
@@ -1109,6 +1130,8 @@ void satba_problem_destroy(satba_problem* p) {
     for (hipEvent_t e : p->prof_ev) (void)hipEventDestroy(e);
     if (p->h_pin) (void)hipHostFree(p->h_pin);
     if (p->h_stage) (void)hipHostFree(p->h_stage);
+    for (auto& l : p->lanes) { if (l.st) (void)hipStreamDestroy(l.st); if (l.pin) (void)hipHostFree(l.pin); }
+    if (p->ev_err) (void)hipEventDestroy(p->ev_err);
     if (p->h_lm) (void)hipHostFree(p->h_lm);
     if (p->own_stream) (void)hipStreamDestroy(p->own_stream);
     if (p->chol_stream) (void)hipStreamDestroy(p->chol_stream);
@@ -1184,6 +1207,7 @@ int satba_configure(satba_problem* p, int32_t loss, double f_scale) {
         p->fxcost_valid = false; p->fxcost_new_valid = false; p->fxcost0_valid = false;  // the kept costs belong to the old loss
     }
     p->loss = loss; p->f_scale = f_scale;
+    p->lin_grid = lin_grid_for(p);
     return 0;
 }
 
@@ -1201,8 +1225,66 @@ static int host_stage(satba_problem* p, size_t bytes) {
     p->h_stage_len = bytes;
     return 0;
 }
+// Large transfers (round 6; the drop-in call at 200 x 1M x 10M moves 208 MB: x up, x and two error vectors down).  A direct copy to or
+// from a pageable array runs at ~15 GB/s -- the runtime's one staging thread: DMA into a bounce buffer, memcpy into pages that are
+// touched for the first time -- and the bus does three times that.  COPY_LANES slices of the range move at the same time, each on a
+// stream and a host thread of its own through two pinned chunks (the DMA of chunk i + 1 under the memcpy of chunk i).  `after`: an
+// event the device-side data are complete at (else the caller has synchronised).  Does not touch p->stream or the staging buffer:
+// safe beside a solve that another host thread drives on this handle (satba_reprojection_errors_fetch).
+constexpr size_t COPY_CHUNK = 4u << 20, COPY_BIG_MIN = 8u << 20;
+constexpr int COPY_LANES = 4;
+static int copy_lanes_init(satba_problem* p) {
+    if (p->lanes_ready) return 0;
+    for (int t = 0; t < COPY_LANES; ++t) {
+        HIP_TRY(hipStreamCreateWithFlags(&p->lanes[t].st, hipStreamNonBlocking));
+        HIP_TRY(hipHostMalloc((void**)&p->lanes[t].pin, 2 * COPY_CHUNK));
+    }
+    p->lanes_ready = true;
+    return 0;
+}
+static int copy_big(satba_problem* p, char* host, char* dev, size_t bytes, bool to_host, hipEvent_t after) {
+    TRY(copy_lanes_init(p));
+    std::atomic<int> err{0};
+    const size_t per = (((bytes + COPY_LANES - 1) / COPY_LANES) + 4095) & ~(size_t)4095;
+    auto work = [&](int t) {
+        if (hipSetDevice(p->device) != hipSuccess) { err = 1; return; }
+        const size_t lo = std::min(bytes, per * t), hi = std::min(bytes, lo + per);
+        auto& L = p->lanes[t];
+        if (after && hipStreamWaitEvent(L.st, after, 0) != hipSuccess) { err = 1; return; }
+        size_t off = lo, prev_off = 0, prev_len = 0;
+        for (int i = 0; off < hi || prev_len; ++i) {
+            const size_t len = off < hi ? std::min(COPY_CHUNK, hi - off) : 0;
+            char* cur = L.pin + (size_t)(i & 1) * COPY_CHUNK;
+            char* prv = L.pin + (size_t)((i + 1) & 1) * COPY_CHUNK;
+            if (to_host) {
+                if (len && hipMemcpyAsync(cur, dev + off, len, hipMemcpyDeviceToHost, L.st) != hipSuccess) err = 1;
+                if (prev_len) memcpy(host + prev_off, prv, prev_len);
+                if (len && hipStreamSynchronize(L.st) != hipSuccess) err = 1;
+            } else {
+                // chunk i is copied into its pinned half while the DMA of chunk i - 1 (other half) runs; the half is free again when the
+                // DMA of chunk i - 2 has finished: the synchronise at the end of the previous round
+                if (len) memcpy(cur, host + off, len);
+                if (prev_len && hipStreamSynchronize(L.st) != hipSuccess) err = 1;
+                if (len && hipMemcpyAsync(dev + off, cur, len, hipMemcpyHostToDevice, L.st) != hipSuccess) err = 1;
+            }
+            prev_off = off; prev_len = len; off += len;
+            if (err) return;
+        }
+        if (!to_host && hipStreamSynchronize(L.st) != hipSuccess) err = 1;
+    };
+    std::thread th[COPY_LANES - 1];
+    for (int t = 1; t < COPY_LANES; ++t) th[t - 1] = std::thread(work, t);
+    work(0);
+    for (auto& t : th) t.join();
+    if (err) return fail(SATBA_E_HIP, "a slice of a large host transfer failed");
+    return 0;
+}
 static int copy_to_host(satba_problem* p, void* host, const void* dev, size_t bytes) {
     if (bytes == 0) { HIP_TRY(hipStreamSynchronize(p->stream)); return 0; }
+    if (bytes >= COPY_BIG_MIN && !getenv("SATBA_COPY_DIRECT")) {
+        HIP_TRY(hipStreamSynchronize(p->stream));
+        return copy_big(p, static_cast<char*>(host), static_cast<char*>(const_cast<void*>(dev)), bytes, true, nullptr);
+    }
     if (bytes > SATBA_STAGE_MAX) {
         HIP_TRY(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, p->stream));
         HIP_TRY(hipStreamSynchronize(p->stream));
@@ -1216,6 +1298,10 @@ static int copy_to_host(satba_problem* p, void* host, const void* dev, size_t by
 }
 static int copy_to_device_async(satba_problem* p, void* dev, const void* host, size_t bytes) {
     if (bytes == 0) return 0;
+    if (bytes >= COPY_BIG_MIN && !getenv("SATBA_COPY_DIRECT")) {
+        HIP_TRY(hipStreamSynchronize(p->stream));  // (whatever still reads the destination has passed; the lanes' streams are not ordered with it)
+        return copy_big(p, static_cast<char*>(const_cast<void*>(host)), static_cast<char*>(dev), bytes, false, nullptr);  // complete on return
+    }
     if (bytes > SATBA_STAGE_MAX) { HIP_TRY(hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, p->stream)); return 0; }
     HIP_TRY(hipStreamSynchronize(p->stream));  // (an earlier copy out of the pinned buffer may still be queued)
     TRY(host_stage(p, bytes));
@@ -1426,15 +1512,16 @@ static int front_schur_solve(satba_problem* p, bool automatic, double lam, doubl
 // means the two kernels did not run at the same time (a profiler collecting counters serialises the launches): the handle goes back
 // to one kernel after the other and the caller repeats the front with the same damping.
 static void beside_disable(satba_problem* p) {
+    // (the interval in force is doubled AFTER it has been used: the first one is 64 sequential fronts, as the field says)
+    if (p->beside_timeouts > 0) p->beside_retry_after = std::min(p->beside_retry_after * 2, 1 << 20);
     p->beside_off = true; p->beside_clean = 0; ++p->beside_timeouts;
-    p->beside_retry_after = std::min(p->beside_retry_after * 2, 1 << 20);
     (void)hipStreamSynchronize(p->chol_stream);
     (void)hipMemsetAsync(p->d_arrive, 0, sizeof(int) * (size_t)(p->M + 2) * SCHUR_ARRIVE_STRIDE, p->stream);
     (void)hipMemsetAsync(p->d_pair_cnt, 0, sizeof(int) * (size_t)std::max<long long>(p->L.n_pairs, 1), p->stream);
     (void)hipMemsetAsync(p->d_dg_cnt, 0, sizeof(int) * (size_t)p->M, p->stream);
 }
 static bool beside_timed_out(satba_problem* p, const double* h) {
-    if (!p->beside_last || !(h[4] >= 2.0)) return false;
+    if (!p->beside_last || !(h[4] >= 4.0)) return false;  // (bit 2: a wait between the two kernels)
     beside_disable(p);
     return true;
 }
@@ -1916,7 +2003,7 @@ int satba_lm_begin(satba_problem* p, const satba_lm_opts* o, int32_t never_stop,
     if (p->n_c > 1024) return fail(SATBA_E_ARG, "the device-resident loop needs a reduced system of at most 1024 unknowns");
     if (cycle_len > 0 && !p->d_x0) return fail(SATBA_E_STATE, "cycles need a kept point (satba_snapshot_x)");
     HIP_TRY(hipSetDevice(p->device));
-    p->loss = o->loss; p->f_scale = o->f_scale;
+    p->loss = o->loss; p->f_scale = o->f_scale; p->lin_grid = lin_grid_for(p);
     return lm_reset(p, o, never_stop != 0, true, false, max_iterations, cycle_len);
 }
 
@@ -2122,8 +2209,12 @@ int satba_solve_lm(satba_problem* p, const satba_lm_opts* o, satba_lm_stats* out
             return fail(SATBA_E_NONFINITE, "Residuals are not finite in the initial point.");
         } else if (st.host_reason == LM_HOST_CHOL) {
             return fail(SATBA_E_STATE, "reduced camera system could not be factorised");
+        } else if (st.host_reason == LM_HOST_BESIDE) {
+            // lm_drive resumes a handed-back concurrent front itself; it only returns with this reason when the front it handed back was
+            // NOT concurrent (p->beside_last false) -- which lm_decide1a no longer raises (status bit 2): an inconsistency, not a route change
+            return fail(SATBA_E_STATE, "device-resident loop handed back a front that did not run beside the pair kernel");
         } else {
-            TRY(lm_host_loop(p, o, out, &st));  // fixed-point overflow of the camera sums: the host switches the route and carries on
+            TRY(lm_host_loop(p, o, out, &st));  // LM_HOST_FX, fixed-point overflow of the camera sums: the host switches the route and carries on
             done = true;
         }
     }

@@ -40,7 +40,7 @@ struct C3Args {
     double* A;        // n x n, column-major, lower triangle valid; L in place on return (and L^T in the strict upper triangle if mirror)
     int n;
     double* b;        // right-hand side; y = L^-1 b on return
-    int* fail;        // |= 1 not positive definite, |= 2 a wait timed out
+    int* fail;        // |= 1 not positive definite, |= 2 a wait timed out, |= 4 (with 2) it was a wait for the kernel that produces the matrix (c3_wait_arrive)
     int* flags;       // T x T tile flags (never cleared: epochs)
     int epoch;        // > 0, larger at every launch
     double* Linv;     // T x 64 x 64: column-major inverses of the diagonal blocks
@@ -165,7 +165,7 @@ __device__ __forceinline__ bool c3_wait_arrive(const C3Arrive& r, int col_lo, in
         if (__all(ok)) return true;
         for (int t = 0; t < r.nap; ++t) __builtin_amdgcn_s_sleep(20);
         if ((++spins & 31) == 0) {
-            if (wall_clock64() - t0 > r.timeout) { if (lane == 0) atomicOr(fail, 2); return false; }
+            if (wall_clock64() - t0 > r.timeout) { if (lane == 0) atomicOr(fail, 2 | 4); return false; }  // bit 2: the wait was for the PRODUCING kernel
             if (c3_ld_flag(fail) & 2) return false;
         }
     }

@@ -534,6 +534,15 @@ __host__ __device__ constexpr bool lin_const_t(int model, int np, bool robust, b
     return model == AFFINE && np == 5 && !robust && unit;
 }
 
+// Experiment switch (make OUT=... EXTRA=-DSATBA_ABLATE_CAM_ATOMICS, profiles/r6_linearize_floor.txt): the floor of k_linearize without
+// its LDS atomics.  The fixed-point conversion, the range check and the address arithmetic stay -- every term is folded into a
+// register that reaches memory at the end --, only the ds_add_u64 go.  The camera sums are wrong in such a build: timing only.
+#ifdef SATBA_ABLATE_CAM_ATOMICS
+#define SATBA_CAM_ADD(ptr, val) (abl ^= (val) + (unsigned long long)(unsigned)row)
+#else
+#define SATBA_CAM_ADD(ptr, val) atomicAdd((ptr), (val))
+#endif
+
 template <bool BIG>
 struct LinCfg {
 #ifndef SATBA_LIN_THREADS
@@ -563,6 +572,7 @@ __global__ __launch_bounds__(LinCfg<(ROBUST && !SOFT) || MODEL == RPC>::THREADS)
     // adds the replicas up.
     const int n_rows = a.M << a.rep_shift;
     unsigned long long bad = 0ull;  // wave mask of the lanes that saw a term outside the fixed-point range (SALU: s_or_b64)
+    [[maybe_unused]] unsigned long long abl = 0ull;  // (SATBA_ABLATE_CAM_ATOMICS)
     int fea[NP], feb = 0, fc1 = 0, fc2 = 0;
     if constexpr (CAMSUMS) {
         for (int i = threadIdx.x; i < n_rows * CUS; i += THREADS) s_acc[i] = 0ull;
@@ -637,7 +647,7 @@ __global__ __launch_bounds__(LinCfg<(ROBUST && !SOFT) || MODEL == RPC>::THREADS)
                         if (!(const_t && i >= 3)) {
                             const double y = ldexp(e.Jc[0][i] * e.Jc[0][i] + e.Jc[1][i] * e.Jc[1][i], 2 * fea[i]) + FX_MAGIC;
                             umax = max(umax, (unsigned)(__double2hiint(y) + fc1));
-                            atomicAdd(acc + i, (unsigned long long)__double_as_longlong(y));
+                            SATBA_CAM_ADD(acc + i, (unsigned long long)__double_as_longlong(y));
                         }
 #pragma unroll
                     for (int i = 0; i < NP; ++i) {
@@ -649,8 +659,8 @@ __global__ __launch_bounds__(LinCfg<(ROBUST && !SOFT) || MODEL == RPC>::THREADS)
                         const double y = ts + FX_MAGIC;
                         umax = max(umax, (unsigned)(__double2hiint(y) + fc1));
                         const double y2 = ldexp(ts - (y - FX_MAGIC), FX_LO_SHIFT) + FX_MAGIC;
-                        atomicAdd(acc + NP + i, (unsigned long long)__double_as_longlong(y));
-                        atomicAdd(acc + 2 * NP + i, (unsigned long long)__double_as_longlong(y2));
+                        SATBA_CAM_ADD(acc + NP + i, (unsigned long long)__double_as_longlong(y));
+                        SATBA_CAM_ADD(acc + 2 * NP + i, (unsigned long long)__double_as_longlong(y2));
                     }
                     bad |= __ballot(umax >= (unsigned)fc2);
                 }
@@ -696,6 +706,9 @@ __global__ __launch_bounds__(LinCfg<(ROBUST && !SOFT) || MODEL == RPC>::THREADS)
     if (lane == 0 && gmax > 0.0) atomic_max_pos(hdr_gpmax, gmax);
     if constexpr (CAMSUMS) {
         if (bad != 0ull && lane == 0) atomicOr(a.fx_flag, 1);
+#ifdef SATBA_ABLATE_CAM_ATOMICS
+        if (abl == 0x5a5a5a5a5a5a5a5aull) atomicOr(a.fx_flag, 4);
+#endif
         __syncthreads();
         unsigned long long* out = reinterpret_cast<unsigned long long*>(part) + (size_t)blockIdx.x * a.M * 3 * NP;
         for (int i = threadIdx.x; i < a.M * 3 * NP; i += THREADS) {
@@ -1345,13 +1358,14 @@ __global__ void k_unscale(int n_c, const double* __restrict__ scale_inv, const d
         int spins = 0;
         while ((int)(__hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - done_epoch) < 0) {
             __builtin_amdgcn_s_sleep(8);
-            if (++spins > (1 << 22)) { timed_out = 2; break; }  // (~1 s: the other stream's kernels bound their own waits)
+            if (++spins > (1 << 22)) { timed_out = 2 | 4; break; }  // (~1 s: the other stream's kernels bound their own waits; bit 2: a wait between the two streams)
         }
     }
     if (i < n_c) dc[i] = (done ? __hip_atomic_load(dch + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : dch[i]) / scale_inv[i];
     if (i < hdr_len) {
         double v = 0.0;
-        // (0: factorised; bit 0 not positive definite, bit 1 a wait timed out)
+        // (0: factorised; bit 0 not positive definite, bit 1 a wait timed out, bit 2: it was a wait of the concurrent front -- for the kernel
+        // on the other stream)
         if (i == 4) v = lead * (double)((done ? __hip_atomic_load(fail_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *fail_flag) | timed_out);
         if (i >= keep_at && i < keep_at + keep_len) v = lead * keep[i - keep_at];
         hdr[i] = v;

@@ -137,7 +137,9 @@ __device__ inline void lm_decide1a(LmDev* __restrict__ gst, const double* __rest
     // the factorisation beside the pair kernel timed out waiting for it (status bit 1: the two kernels did not run at the same time --
     // launches serialised by a tool, two streams on one hardware queue): not a failed factorisation.  Nothing is booked, the damping
     // stays; the host switches the handle to one kernel after the other and resumes the loop at this front (lm_drive)
-    if (h[LMH_CHOL_FAIL] >= 2.0) { st->resume_lin = st->run_lin; lm_to_host(st, LM_HOST_BESIDE); return; }
+    // (round-5 advisor: only a wait BETWEEN the two kernels -- status bit 2, raised by c3_wait_arrive and k_unscale's spin -- is handed back; a
+    // time-out inside a sequential front, or with several ranks, is a factorisation that did not finish: the escalation branch below)
+    if (h[LMH_CHOL_FAIL] >= 4.0) { st->resume_lin = st->run_lin; lm_to_host(st, LM_HOST_BESIDE); return; }
     if (st->run_lin) {
         // bookkeeping of the new linearisation (scipy trf.py:536-546 after an accepted step; :405-426 before the loop)
         const double cost = h[LMH_K_COST];

@@ -22,6 +22,7 @@ Differences from the reference, all deliberate:
     satba/geo_utils.py and footprint masks from matplotlib paths instead of pyproj / utm / shapely; `plots=True` of
     `run_ba_optimization` is accepted and ignored (the reference opens an interactive window there).
 """
+import os
 import time
 
 import numpy as np
@@ -83,10 +84,31 @@ def project_rpc(pts3d, rpcs, cam_params, pts_ind, cam_ind):
 
 # ----------------------------------------------------------------------------- device plumbing
 
+_SUM_POOL = None
+_SUM_CHUNK = 1 << 20  # elements
+
+
+def _content_sum(a):
+    """Sum of a contiguous array's entries, over fixed 8 MB chunks on a few threads (numpy releases the GIL inside a sum): the
+    content part of the cache key below.  At 200 x 1M x 10M the three sums over 240 MB were 9 ms of a 45 ms call (round 5); the
+    chunking is fixed, so the value is a function of the content alone."""
+    global _SUM_POOL
+    a = np.asarray(a)
+    if a.size < 4 * _SUM_CHUNK or not a.flags.c_contiguous:
+        return float(a.sum())
+    if _SUM_POOL is None:
+        from concurrent.futures import ThreadPoolExecutor
+
+        _SUM_POOL = ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1), thread_name_prefix="satba-sum")
+    flat = a.reshape(-1)
+    parts = list(_SUM_POOL.map(lambda i: float(flat[i:i + _SUM_CHUNK].sum()), range(0, flat.size, _SUM_CHUNK)))
+    return float(np.sum(parts))
+
+
 def _fingerprint(p):
     return (p.cam_model, p.n_cam, p.n_pts, p.n_obs, p.n_params, int(p.n_cam_fix), int(p.n_pts_fix),
             id(p.pts_ind), id(p.cam_ind), id(p.pts2d), id(p.pts2d_w), id(p.cam_params),
-            float(p.pts2d_w.sum()), float(p.pts2d.sum()), float(p.cam_params.sum()), float(np.sum(p.pts3d[: int(p.n_pts_fix)])))
+            _content_sum(p.pts2d_w), _content_sum(p.pts2d), float(p.cam_params.sum()), float(np.sum(p.pts3d[: int(p.n_pts_fix)])))
 
 
 def _distributed():
@@ -210,16 +232,44 @@ def run_ba_optimization(p, ls_params=None, verbose=False, plots=True):
     # (satba_reprojection_errors): half the bytes over the bus and no numpy passes over 2 K doubles (C4: 0.2 -> 0.05 s per call)
     need_r = bool(plots) or bool(extra.get("return_result", False)) or not hasattr(eng, "reprojection_errors")
     residuals_init = sharding.assemble_residuals(p, eng.shard, eng.residuals(), comm) if need_r else None
-    err_init = None if need_r else sharding.assemble_residuals(p, eng.shard, eng.reprojection_errors(), comm)
+    # Nothing on the device needs the initial errors again: from 8 MB on (1 M observations) their download runs in a second thread
+    # beside the solve (engine_hip.reprojection_errors_begin / _fetch; at 200 x 1M x 10M 80 MB over the bus under a 7 ms solve).
+    # SATBA_ERR_OVERLAP=0 keeps the one-step call.
+    err_pending = None
+    if (not need_r and hasattr(eng, "reprojection_errors_fetch") and eng.n_obs >= (1 << 20)
+            and os.environ.get("SATBA_ERR_OVERLAP", "1") != "0"):
+        import threading
+
+        eng.reprojection_errors_begin()
+        box = {}
+
+        def _fetch():
+            try:
+                box["err"] = eng.reprojection_errors_fetch()
+            except BaseException as e:  # noqa: B902  (re-raised in the calling thread below)
+                box["exc"] = e
+        err_pending = threading.Thread(target=_fetch, name="satba-err-init")
+        err_pending.start()
+        err_init = None
+    else:
+        err_init = None if need_r else sharding.assemble_residuals(p, eng.shard, eng.reprojection_errors(), comm)
     t_init = clock()
     if verbose:
         flush_print("Shape of Jacobian sparsity: {}x{}".format(2 * p.n_obs, p.n_cam * p.n_params + 3 * p.n_pts))
 
     t0 = time.time()
-    res = trf.trf_solve(eng, comm, ftol=cfg["ftol"], xtol=cfg["xtol"], gtol=extra.get("gtol", 1e-8),
-                        max_nfev=cfg["max_iter"], loss=cfg["loss"], f_scale=cfg["f_scale"],
-                        verbose=cfg["verbose"] if comm.rank == 0 else 0)
+    try:
+        res = trf.trf_solve(eng, comm, ftol=cfg["ftol"], xtol=cfg["xtol"], gtol=extra.get("gtol", 1e-8),
+                            max_nfev=cfg["max_iter"], loss=cfg["loss"], f_scale=cfg["f_scale"],
+                            verbose=cfg["verbose"] if comm.rank == 0 else 0)
+    finally:
+        if err_pending is not None:
+            err_pending.join()  # (before the next transfer of this handle: the copy lanes are shared)
     t_solve = clock()
+    if err_pending is not None:
+        if "exc" in box:
+            raise box["exc"]
+        err_init = sharding.assemble_residuals(p, eng.shard, box["err"], comm)
     vars_ba = sharding.assemble_x(p, eng.shard, eng.get_x(), comm)
     residuals_ba = sharding.assemble_residuals(p, eng.shard, eng.residuals(), comm) if need_r else None
     err_ba = None if need_r else sharding.assemble_residuals(p, eng.shard, eng.reprojection_errors(), comm)

@@ -26,7 +26,7 @@ HDR_FIXED = 16
 SYMBOLS = [
     "satba_last_error", "satba_version", "satba_problem_create", "satba_problem_destroy", "satba_set_stream",
     "satba_exchange_len", "satba_header_len", "satba_bind_exchange", "satba_configure", "satba_set_x", "satba_get_x",
-    "satba_residuals", "satba_reprojection_errors", "satba_linearize", "satba_prepare", "satba_schur", "satba_schur_auto", "satba_solve", "satba_subspace", "satba_subspace_products", "satba_trial", "satba_trial_gn",
+    "satba_residuals", "satba_reprojection_errors", "satba_reprojection_errors_begin", "satba_reprojection_errors_fetch", "satba_linearize", "satba_prepare", "satba_schur", "satba_schur_auto", "satba_solve", "satba_subspace", "satba_subspace_products", "satba_trial", "satba_trial_gn",
     "satba_accept", "satba_camera_sums_fallback", "satba_read_header", "satba_get_blocks", "satba_get_jacobian", "satba_get_exchange",
     "satba_set_exchange", "satba_get_vector", "satba_time_kernel",
     "satba_packed_schur_len", "satba_pack_schur", "satba_unpack_schur",
@@ -99,6 +99,8 @@ def load_library(path=None):
     lib.satba_get_x.argtypes = [h, _dp]
     lib.satba_residuals.argtypes = [h, _dp, _dp]
     lib.satba_reprojection_errors.argtypes = [h, _dp, _dp]
+    lib.satba_reprojection_errors_begin.argtypes = [h]
+    lib.satba_reprojection_errors_fetch.argtypes = [h, _dp]
     for name in ("satba_linearize", "satba_solve", "satba_accept", "satba_subspace_products", "satba_camera_sums_fallback"):
         getattr(lib, name).argtypes = [h]
     lib.satba_prepare.argtypes = [h, C.c_int32]
@@ -295,6 +297,17 @@ class HipEngine:
         """satba_reprojection_errors: compute_reprojection_error(fun(x)) on the device, (n_obs,) float64 in the caller's order."""
         e = np.empty(self.n_obs)
         _check(self.lib, self.lib.satba_reprojection_errors(self._h, _ptr(e), None))
+        return e
+
+    def reprojection_errors_begin(self):
+        """Queue the error kernels at the current x (satba_reprojection_errors_begin); reprojection_errors_fetch brings them over."""
+        _check(self.lib, self.lib.satba_reprojection_errors_begin(self._h))
+
+    def reprojection_errors_fetch(self):
+        """The errors of the x at reprojection_errors_begin.  May run in another thread while this engine solves (ctypes releases the
+        GIL; the transfer uses streams and pinned buffers of its own)."""
+        e = np.empty(self.n_obs)
+        _check(self.lib, self.lib.satba_reprojection_errors_fetch(self._h, _ptr(e)))
         return e
 
     def read_header(self):

@@ -335,7 +335,7 @@ def subspace_model(engine, exchange, ga, gb, gc, jg_sq, reg):
 # ----------------------------------------------------------------------------- the loop on the device, several ranks
 
 LM_RUN, LM_DONE, LM_NEED_HOST, LM_NEED_SUB = 0, 1, 2, 3
-LM_HOST_FX, LM_HOST_CHOL, LM_HOST_NONFINITE = 1, 2, 3  # LmDev::host_reason (csrc/satba_lmdev.h)
+LM_HOST_FX, LM_HOST_CHOL, LM_HOST_NONFINITE, LM_HOST_BESIDE = 1, 2, 3, 4  # LmDev::host_reason (csrc/satba_lmdev.h)
 LM_RUN_AHEAD = 3  # csrc/satba_lmdev.h
 
 
@@ -460,6 +460,10 @@ def trf_solve(engine, comm=None, ftol=1e-8, xtol=1e-8, gtol=1e-8, max_nfev=None,
                 raise ValueError("Residuals are not finite in the initial point.")
             if reason == LM_HOST_CHOL:
                 raise RuntimeError("reduced camera system could not be factorised")
+            if reason == LM_HOST_BESIDE:
+                # a front is only handed back when a wait BETWEEN the factorisation and the pair kernel running beside it timed out
+                # (status bit 2, csrc/satba_lmdev.h: lm_decide1a); sharded fronts run one kernel after the other
+                raise RuntimeError("device loop handed back a concurrent front on a sharded run")
             if reason == LM_HOST_FX and getattr(engine, "camera_sums_fallback", None):
                 engine.camera_sums_fallback()  # only this reason changes the summation route
             if int(dev_state["nfev"]) > 0:

@@ -46,6 +46,10 @@ int main(void) {
         double err[4], cost = -1.0;
         CHECK(satba_reprojection_errors(p, NULL, NULL) == SATBA_E_ARG);
         CHECK(satba_reprojection_errors(p, err, &cost) == SATBA_OK && cost >= 0.0);
+        double err2[4] = {-1.0, -1.0, -1.0, -1.0};
+        CHECK(satba_reprojection_errors_fetch(p, err2) == SATBA_E_STATE);  /* no _begin yet */
+        CHECK(satba_reprojection_errors_begin(p) == SATBA_OK && satba_reprojection_errors_fetch(p, NULL) == SATBA_E_ARG);
+        CHECK(satba_reprojection_errors_fetch(p, err2) == SATBA_OK && memcmp(err, err2, sizeof err) == 0);
         CHECK(satba_configure(p, 9, 1.0) == SATBA_E_ARG && satba_configure(p, 1, -1.0) == SATBA_E_ARG);
         double out[16];
         CHECK(satba_get_info(p, out, 4) == SATBA_E_ARG && satba_get_info(p, out, 16) == SATBA_OK);
@@ -58,6 +62,7 @@ int main(void) {
     CHECK(satba_header_len(NULL) == 0 && satba_exchange_len(NULL) == 0 && satba_layout_len(NULL, 0) == -1);
     CHECK(satba_lm_run(NULL, 1, 0, 0.0, NULL, 0) == SATBA_E_ARG && satba_lm_state(NULL, NULL, 0) == SATBA_E_ARG);
     CHECK(satba_reprojection_errors(NULL, NULL, NULL) == SATBA_E_ARG);
+    CHECK(satba_reprojection_errors_begin(NULL) == SATBA_E_ARG && satba_reprojection_errors_fetch(NULL, NULL) == SATBA_E_ARG);
     CHECK(satba_rpc_fit(-1, 0, NULL, NULL, 1e-3, 1e-2, 20, NULL, NULL, NULL, 0) == SATBA_E_ARG);
     CHECK(satba_rpc_refit(1, NULL, NULL, NULL, NULL, NULL, 10, 1e-3, 1e-2, 20, NULL, NULL, NULL, NULL, NULL, 0) == SATBA_E_ARG);
     CHECK(satba_rpc_localization(NULL, 3, NULL, NULL, NULL, NULL, NULL, 0) == SATBA_E_ARG);

@@ -446,6 +446,39 @@ def test_run_ba_optimization_errors_do_not_depend_on_the_residual_download(gpu):
     assert {"engine_s", "initial_residuals_s", "solve_s", "read_back_s", "host_errors_s", "total_s"} <= set(tm)
 
 
+def test_initial_errors_downloaded_beside_the_solve_are_the_one_step_errors(gpu, monkeypatch):
+    """Round 6: from 1 M observations on run_ba_optimization fetches err_init in a second thread while the solve runs
+    (satba_reprojection_errors_begin / _fetch over the copy lanes: four slices of the range, each through pinned chunks on a stream of
+    its own -- which also carry every transfer from 8 MB on: x up and down, err_ba).  Same five return values, bit for bit, as with
+    the one-step call and direct copies; and the two-step errors taken by hand beside a running solve equal the one-step errors."""
+    import threading
+
+    scene = synth.make_scene("affine", 12, 140000, 8, seed=5)
+    make_p = lambda: synth.make_params(scene, {"correction_params": ["R", "T"], "n_cam_fix": 1})  # noqa: E731
+    p = make_p()
+    assert p.n_obs >= (1 << 20)
+    a = ba_core.run_ba_optimization(p, {"verbose": 0}, False, False)
+    monkeypatch.setenv("SATBA_ERR_OVERLAP", "0")
+    monkeypatch.setenv("SATBA_COPY_DIRECT", "1")
+    b = ba_core.run_ba_optimization(make_p(), {"verbose": 0}, False, False)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+    monkeypatch.delenv("SATBA_COPY_DIRECT")
+    eng = ba_core.get_engine(p)
+    eng.configure("linear", 1.0)
+    eng.set_x(ba_core._frozen_vars(p.params_opt.copy(), p))
+    e1 = eng.reprojection_errors()
+    assert np.array_equal(e1, a[2])
+    eng.reprojection_errors_begin()
+    box = {}
+    t = threading.Thread(target=lambda: box.update(e=eng.reprojection_errors_fetch()))
+    t.start()
+    res = trf.trf_solve(eng, ftol=1e-4, xtol=1e-10, gtol=1e-8, max_nfev=50)  # moves x while the errors of the old x come over
+    t.join()
+    assert res.nfev > 1 and np.array_equal(box["e"], e1)
+    assert not np.array_equal(eng.reprojection_errors(), e1)
+
+
 @pytest.mark.parametrize("name", ["affine_small_R", "persp_small_R", "affine_C2_R"])
 def test_default_tolerances_behave_like_reference(gpu, name):
     """As shipped (ftol 1e-4): both solvers stop early and path-dependently; compare statistics, not parameters."""

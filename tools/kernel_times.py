@@ -35,9 +35,14 @@ if "--loop" in sys.argv:
         eng.lm_step(i % 3 == 0, 1.0, 1e-14)
     print(json.dumps({"loop_iterations": reps}))
     sys.exit(0)
-for name in ("linearize", "residual", "jvp", "backsub", "schur", "cholesky"):
-    eng.linearize(); eng.prepare(False); eng.schur(1e-6)
+names = ("linearize", "residual", "jvp", "backsub", "schur", "cholesky")
+if "--only" in sys.argv:  # (an ablation build's sums are wrong: only the kernel in question is run)
+    names = (sys.argv[sys.argv.index("--only") + 1],)
+for name in names:
+    eng.linearize()
+    if len(names) > 1:
+        eng.prepare(False); eng.schur(1e-6)
     out[name] = round(eng.time_kernel(name, reps if name not in ("schur", "cholesky") else max(2, reps // 4)), 5)
-print(json.dumps({k: out[k] for k in ("linearize", "residual", "jvp", "backsub", "schur", "cholesky")}), json.dumps(out["env"]), flush=True)
+print(json.dumps({k: out[k] for k in names}), json.dumps(out["env"]), flush=True)
 if "-v" in sys.argv:
     print(json.dumps(out))
