@@ -179,8 +179,9 @@ struct satba_problem {
     void* h_stage = nullptr;  // pinned staging of the transfers between the caller's arrays and the device (copy_to_host)
     size_t h_stage_len = 0;
     // large transfers (round 6): COPY_LANES slices, each with a stream, a thread and two pinned chunks of its own (copy_big)
-    struct CopyLane { hipStream_t st = nullptr; char* pin = nullptr; };
+    struct CopyLane { char* pin = nullptr; hipEvent_t ev[2] = {nullptr, nullptr}; };
     CopyLane lanes[8];
+    hipStream_t copy_stream = nullptr;
     bool lanes_ready = false;
     double* d_err_keep = nullptr;      // K per-observation errors kept for satba_reprojection_errors_fetch (caller's order)
     hipEvent_t ev_err = nullptr;       // ... complete on the device
@@ -1034,7 +1035,7 @@ int satba_problem_create(const satba_problem_desc* d, satba_problem** out) {
         {   // scratch of the tile factorisation: tile flags (zeroed once: they carry epochs), inverted 64 x 64 diagonal blocks, the tiles'
             // shares of the forward substitution, ticket counters
             const size_t T = (size_t)(p->n_c + 63) / 64;
-            TRY(dev_alloc(p, &p->chol.flags, T * T + 1)); TRY(dev_alloc(p, &p->chol.Linv, T * 4096 + 1)); TRY(dev_alloc(p, &p->chol.Cc, T * T * 64 + 1));
+            TRY(dev_alloc(p, &p->chol.flags, T * T + 1)); TRY(dev_alloc(p, &p->chol.Linv, 2 * T * 4096 + 1)); TRY(dev_alloc(p, &p->chol.Cc, T * T * 64 + 1));
             TRY(dev_alloc(p, &p->chol.ctr, 4));
             HIP_TRY(hipMemset(p->chol.flags, 0, sizeof(int) * (T * T + 1)));
             HIP_TRY(hipMemset(p->chol.ctr, 0, sizeof(int) * 4));
@@ -1130,7 +1131,8 @@ void satba_problem_destroy(satba_problem* p) {
     for (hipEvent_t e : p->prof_ev) (void)hipEventDestroy(e);
     if (p->h_pin) (void)hipHostFree(p->h_pin);
     if (p->h_stage) (void)hipHostFree(p->h_stage);
-    for (auto& l : p->lanes) { if (l.st) (void)hipStreamDestroy(l.st); if (l.pin) (void)hipHostFree(l.pin); }
+    for (auto& l : p->lanes) { if (l.pin) (void)hipHostFree(l.pin); for (hipEvent_t e : l.ev) if (e) (void)hipEventDestroy(e); }
+    if (p->copy_stream) (void)hipStreamDestroy(p->copy_stream);
     if (p->ev_err) (void)hipEventDestroy(p->ev_err);
     if (p->h_lm) (void)hipHostFree(p->h_lm);
     if (p->own_stream) (void)hipStreamDestroy(p->own_stream);
@@ -1227,56 +1229,69 @@ static int host_stage(satba_problem* p, size_t bytes) {
 }
 // Large transfers (round 6; the drop-in call at 200 x 1M x 10M moves 208 MB: x up, x and two error vectors down).  A direct copy to or
 // from a pageable array runs at ~15 GB/s -- the runtime's one staging thread: DMA into a bounce buffer, memcpy into pages that are
-// touched for the first time -- and the bus does three times that.  COPY_LANES slices of the range move at the same time, each on a
-// stream and a host thread of its own through two pinned chunks (the DMA of chunk i + 1 under the memcpy of chunk i).  `after`: an
-// event the device-side data are complete at (else the caller has synchronised).  Does not touch p->stream or the staging buffer:
-// safe beside a solve that another host thread drives on this handle (satba_reprojection_errors_fetch).
+// touched for the first time -- and the bus does three times that.  Here copy_lanes() host threads share the memcpy side: thread t
+// moves every copy_lanes()-th 4 MB chunk through two pinned halves of its own, the DMA of its next chunk under the memcpy of the
+// current one.  ALL DMAs go through ONE extra stream (events tell a thread when its chunk has landed): the first version gave every
+// thread a stream of its own, and with three or more streams alive beside the handle's the kernels of the LM loop ran 30 - 45 % slower
+// for the rest of the process (200 x 1M x 10M: 594 against 859 it/s, a 5-evaluation solve 11.5 - 15 ms against 8.2; with one extra
+// stream 8.1 - 8.3 -- profiles/r6_copy_lanes.txt).  `after`: an event the device-side data are complete at (else the caller has
+// synchronised).  Does not touch p->stream or the staging buffer: safe beside a solve that another host thread drives on this handle
+// (satba_reprojection_errors_fetch).
 constexpr size_t COPY_CHUNK = 4u << 20, COPY_BIG_MIN = 8u << 20;
-constexpr int COPY_LANES = 4;
+constexpr int COPY_LANES_MAX = 8;
+static int copy_lanes() {  // SATBA_COPY_LANES: 1 .. 8 (experiments; default 4)
+    static const int v = getenv("SATBA_COPY_LANES") ? std::max(1, std::min(COPY_LANES_MAX, atoi(getenv("SATBA_COPY_LANES")))) : 4;
+    return v;
+}
 static int copy_lanes_init(satba_problem* p) {
     if (p->lanes_ready) return 0;
-    for (int t = 0; t < COPY_LANES; ++t) {
-        HIP_TRY(hipStreamCreateWithFlags(&p->lanes[t].st, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&p->copy_stream, hipStreamNonBlocking));
+    for (int t = 0; t < copy_lanes(); ++t) {
         HIP_TRY(hipHostMalloc((void**)&p->lanes[t].pin, 2 * COPY_CHUNK));
+        for (int h = 0; h < 2; ++h) HIP_TRY(hipEventCreateWithFlags(&p->lanes[t].ev[h], hipEventDisableTiming));
     }
     p->lanes_ready = true;
     return 0;
 }
 static int copy_big(satba_problem* p, char* host, char* dev, size_t bytes, bool to_host, hipEvent_t after) {
     TRY(copy_lanes_init(p));
+    const int T = copy_lanes();
+    hipStream_t cs = p->copy_stream;
+    if (after) HIP_TRY(hipStreamWaitEvent(cs, after, 0));  // (before any lane queues a chunk)
     std::atomic<int> err{0};
-    const size_t per = (((bytes + COPY_LANES - 1) / COPY_LANES) + 4095) & ~(size_t)4095;
+    const size_t n_chunks = (bytes + COPY_CHUNK - 1) / COPY_CHUNK;
     auto work = [&](int t) {
         if (hipSetDevice(p->device) != hipSuccess) { err = 1; return; }
-        const size_t lo = std::min(bytes, per * t), hi = std::min(bytes, lo + per);
         auto& L = p->lanes[t];
-        if (after && hipStreamWaitEvent(L.st, after, 0) != hipSuccess) { err = 1; return; }
-        size_t off = lo, prev_off = 0, prev_len = 0;
-        for (int i = 0; off < hi || prev_len; ++i) {
-            const size_t len = off < hi ? std::min(COPY_CHUNK, hi - off) : 0;
+        // my chunks: t, t + T, ...; round i uses half i & 1
+        size_t prev_off = 0, prev_len = 0;
+        int i = 0;
+        for (size_t c = t;; c += T, ++i) {
+            const size_t off = c * COPY_CHUNK;
+            const size_t len = c < n_chunks ? std::min(COPY_CHUNK, bytes - off) : 0;
             char* cur = L.pin + (size_t)(i & 1) * COPY_CHUNK;
             char* prv = L.pin + (size_t)((i + 1) & 1) * COPY_CHUNK;
             if (to_host) {
-                if (len && hipMemcpyAsync(cur, dev + off, len, hipMemcpyDeviceToHost, L.st) != hipSuccess) err = 1;
-                if (prev_len) memcpy(host + prev_off, prv, prev_len);
-                if (len && hipStreamSynchronize(L.st) != hipSuccess) err = 1;
+                if (len && (hipMemcpyAsync(cur, dev + off, len, hipMemcpyDeviceToHost, cs) != hipSuccess || hipEventRecord(L.ev[i & 1], cs) != hipSuccess)) err = 1;
+                if (prev_len) memcpy(host + prev_off, prv, prev_len);  // (its event was waited for at the end of the previous round)
+                if (len && hipEventSynchronize(L.ev[i & 1]) != hipSuccess) err = 1;
             } else {
-                // chunk i is copied into its pinned half while the DMA of chunk i - 1 (other half) runs; the half is free again when the
-                // DMA of chunk i - 2 has finished: the synchronise at the end of the previous round
+                // chunk i goes into its pinned half while the DMA of chunk i - 1 (other half) runs; that half is free again when the DMA
+                // of chunk i - 2 has finished: its event, waited for here
+                if (len && i >= 2 && hipEventSynchronize(L.ev[i & 1]) != hipSuccess) err = 1;
                 if (len) memcpy(cur, host + off, len);
-                if (prev_len && hipStreamSynchronize(L.st) != hipSuccess) err = 1;
-                if (len && hipMemcpyAsync(dev + off, cur, len, hipMemcpyHostToDevice, L.st) != hipSuccess) err = 1;
+                if (len && (hipMemcpyAsync(dev + off, cur, len, hipMemcpyHostToDevice, cs) != hipSuccess || hipEventRecord(L.ev[i & 1], cs) != hipSuccess)) err = 1;
             }
-            prev_off = off; prev_len = len; off += len;
-            if (err) return;
+            prev_off = off; prev_len = len;
+            if (err || !len) break;
         }
-        if (!to_host && hipStreamSynchronize(L.st) != hipSuccess) err = 1;
     };
-    std::thread th[COPY_LANES - 1];
-    for (int t = 1; t < COPY_LANES; ++t) th[t - 1] = std::thread(work, t);
+    std::thread th[COPY_LANES_MAX];
+    for (int t = 1; t < T; ++t) th[t] = std::thread(work, t);
     work(0);
-    for (auto& t : th) t.join();
-    if (err) return fail(SATBA_E_HIP, "a slice of a large host transfer failed");
+    for (int t = 1; t < T; ++t) th[t].join();
+    if (!to_host && hipStreamSynchronize(cs) != hipSuccess) err = 1;  // every upload has landed
+    if (err) return fail(SATBA_E_HIP, "a chunk of a large host transfer failed");
     return 0;
 }
 static int copy_to_host(satba_problem* p, void* host, const void* dev, size_t bytes) {

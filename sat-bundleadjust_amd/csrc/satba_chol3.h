@@ -24,6 +24,7 @@
 // a workgroup only ever waits for tiles with smaller tickets (or for the chain, ticket 0), so the kernel makes progress whatever
 // part of the grid is resident.  Every spin is bounded (fail |= 2 after ~1 s).
 #pragma once
+#include <type_traits>
 
 namespace satba {
 
@@ -43,7 +44,8 @@ struct C3Args {
     int* fail;        // |= 1 not positive definite, |= 2 a wait timed out, |= 4 (with 2) it was a wait for the kernel that produces the matrix (c3_wait_arrive)
     int* flags;       // T x T tile flags (never cleared: epochs)
     int epoch;        // > 0, larger at every launch
-    double* Linv;     // T x 64 x 64: column-major inverses of the diagonal blocks
+    double* Linv;     // 2 T x 64 x 64: [0, T) column-major inverses of the diagonal blocks; [T, 2 T): tile (k+2, k) with every EARLIER panel
+                      // applied, column-major, from its owner (stage C3_S1 of that tile's flag) -- the chain solves it itself (c3_chain_rider)
     double* Cc;       // T x T x 64: L(i,j) y_j
     int* ctr;         // [0] ticket counter, [1] workgroups done; zero on entry, zero on exit
     double* dinv;     // 32 x 32 inverses of the diagonal blocks, [blk][r][c], for k_trsv_back_mw (or null)
@@ -69,6 +71,25 @@ struct C3Args {
     const double* rhs = nullptr;
 };
 constexpr int C3_ARRIVE_STRIDE = 32;  // (= SCHUR_ARRIVE_STRIDE)
+
+// The owner and mirror tasks are functions of their own (their registers are allocated apart from the chain's roles) and need most of the
+// argument block.  Passed by value it was copied to the stack in front of every call -- 576 of the kernel's 744 bytes of scratch per lane
+// in round 5 --; they re-read it from the kernel-argument segment instead (scalar loads: C3Args is k_chol_tiles' FIRST parameter, offset 0).
+typedef const __attribute__((address_space(4))) C3Args* c3_kargs;
+// (q: __builtin_amdgcn_kernarg_segment_ptr() taken IN THE KERNEL -- inside a callee the intrinsic folds to a null pointer -- and handed down;
+// the callee makes it uniform again, so that the reads are scalar loads)
+__device__ __forceinline__ C3Args c3_args_from_kernarg(c3_kargs q) {
+    {
+        const unsigned long long v = (unsigned long long)q;
+        const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+        q = (c3_kargs)(((unsigned long long)hi << 32) | lo);
+    }
+    C3Args g;
+    g.A = q->A; g.n = q->n; g.b = q->b; g.fail = q->fail; g.flags = q->flags; g.epoch = q->epoch; g.Linv = q->Linv; g.Cc = q->Cc; g.ctr = q->ctr;
+    g.dinv = q->dinv; g.ts = q->ts; g.mirror = q->mirror; g.arrive = q->arrive; g.arr_M = q->arr_M; g.np = q->np; g.arr_epoch = q->arr_epoch;
+    g.nap = q->nap; g.arr_timeout = q->arr_timeout; g.arr_extra = q->arr_extra; g.si = q->si; g.rhs = q->rhs;
+    return g;
+}
 
 struct C3Arrive { const int* arrive; int M, np, epoch, nap; long long timeout; int extra; };
 
@@ -110,14 +131,32 @@ __device__ __forceinline__ double c3_gld(const double* p) { return *(const c3_gd
 __device__ __forceinline__ void c3_gst(double* p, double v) { *(c3_gdouble*)p = v; }               // plain global store
 __device__ __forceinline__ int c3_ld_flag(const int* p) { return __hip_atomic_load((const c3_gint*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void c3_st_flag(int* p, int v) { __hip_atomic_store((c3_gint*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// Element idx of a (uniform) array as base + zero-extended 32-bit byte offset: the form a global access takes its base from scalar
+// registers in (one vector register of address instead of two, and no 64-bit vector arithmetic); the reduced system has at most
+// 6 000 x 6 000 entries, 288 MB: byte offsets fit 32 bits
+template <class T>
+__device__ __forceinline__ T* c3_at(T* base, unsigned idx) {
+    return reinterpret_cast<T*>(reinterpret_cast<char*>(const_cast<typename std::remove_const<T>::type*>(base)) + (size_t)(idx * (unsigned)sizeof(T)));
+}
 // element (row, col) of the n x n matrix if `ok`, else `other`: the load itself is unconditional (clamped address) -- a load under a
 // condition gets its own s_waitcnt, and sixteen of them in a row were ten microseconds on the chain's critical hand-over
 __device__ __forceinline__ double c3_ld_at(const double* A, int n, int row, int col, bool ok, double other = 0.0) {
     const int r = row < n ? row : n - 1, c = col < n ? col : n - 1;
-    const double v = c3_ld(A + (size_t)r + (size_t)c * n);
+    const double v = c3_ld(c3_at(A, (unsigned)(r + c * n)));
     return ok ? v : other;
 }
 __device__ __forceinline__ void c3_st(double* p, double v) { __hip_atomic_store((c3_gdouble*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// Arguments of the (non-inlined) role functions arrive in vector registers, whatever the caller knows about them: a value that is the
+// same in every lane is moved to scalar registers once, and the address arithmetic built on it stays off the vector file (round 6: the
+// riders kept 18 registers of uniform arguments and 24 spilled LDS addresses -- two scratch reloads in front of every operand read)
+__device__ __forceinline__ int c3_uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+template <class T>
+__device__ __forceinline__ T* c3_uni(T* q) {
+    const unsigned long long v = reinterpret_cast<unsigned long long>(q);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+    return reinterpret_cast<T*>(((unsigned long long)hi << 32) | lo);
+}
 
 // wait until a global flag word reaches `want` (wrap-safe); false after the time-out or when another wait has timed out
 __device__ __forceinline__ bool c3_wait(const int* f, int want, int* fail) {
@@ -354,6 +393,7 @@ __device__ __forceinline__ bool c3_dnext_blocks(const C3Lds& l, const double* A,
 // the four waves of the diagonal tile: one row per lane, column quarter q (c3_panel)
 __device__ __noinline__ void c3_chain_diag(int q, double* A, int n, int T, int* fail, int mirror, long long* ts) {
     extern __shared__ __attribute__((aligned(16))) double c3_lds[];  // (declared here, not passed: the pointers stay in the LDS address space)
+    q = c3_uni(q); A = c3_uni(A); n = c3_uni(n); T = c3_uni(T); fail = c3_uni(fail); mirror = c3_uni(mirror); ts = c3_uni(ts);
     const int tid = threadIdx.x, lane = tid & 63;
     const C3Lds l = c3_carve(c3_lds);
     double a[16];
@@ -381,7 +421,7 @@ __device__ __noinline__ void c3_chain_diag(int q, double* A, int n, int T, int* 
 #pragma unroll
         for (int c = 0; c < 16; ++c) {
             const int row = r0 + lane, col = r0 + 16 * q + c;
-            if (row < n && col <= row) c3_st(A + (size_t)row + (size_t)col * n, a[c]);
+            if (row < n && col <= row) c3_st(c3_at(A, (unsigned)(row + col * n)), a[c]);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (lane == 0) c3_lds_inc(l.pubD_cnt);
@@ -411,6 +451,8 @@ __device__ __noinline__ void c3_chain_diag(int q, double* A, int n, int T, int* 
 __device__ __noinline__ void c3_chain_rider(int set, int w, double* A, int n, int T, int* fail, const int* flags, int want1, double* Linv, double* dinv,
                                             int mirror, long long* ts) {
     extern __shared__ __attribute__((aligned(16))) double c3_lds[];
+    set = c3_uni(set); w = c3_uni(w); A = c3_uni(A); n = c3_uni(n); T = c3_uni(T); fail = c3_uni(fail); flags = c3_uni(flags); want1 = c3_uni(want1);
+    Linv = c3_uni(Linv); dinv = c3_uni(dinv); mirror = c3_uni(mirror); ts = c3_uni(ts);
     const int tid = threadIdx.x, lane = tid & 63;
     const int e16 = lane & 15, g4 = lane >> 4;
     const C3Lds l = c3_carve(c3_lds);
@@ -426,7 +468,7 @@ __device__ __noinline__ void c3_chain_rider(int set, int w, double* A, int n, in
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
                 const int cc = 16 * cb + g4 + 4 * reg, row = 64 + 16 * w + e16;
-                acc[cb][reg] = (row < n) ? c3_ld(A + (size_t)row + (size_t)cc * n) : 0.0;
+                acc[cb][reg] = c3_ld_at(A, n, row, cc, row < n);
             }
     }
     for (int k = 0; k < T; ++k) {
@@ -443,8 +485,9 @@ __device__ __noinline__ void c3_chain_rider(int set, int w, double* A, int n, in
         }
         if (!isR || has_r) {
             // the right-hand side's wave is done with this set's rows of the previous step, and so are the products of R's four waves
+            // (which read R's rows and, since round 6, the identity's: L_kk^-T for their own solve of tile (k+2, k))
             if (k > 0 && !c3_wait_lds(isR ? l.b_rdy : l.y_done, isR ? step1 : k, fail)) return;
-            if (isR && k > 0 && !c3_wait_lds(l.prod_cnt, 4 * k, fail)) return;
+            if (k > 0 && !c3_wait_lds(l.prod_cnt, 4 * (k < T - 2 ? k : T - 2), fail)) return;
 #pragma unroll
             for (int p = 0; p < 8; ++p) {
                 const int cb = p >> 1, h = p & 1;
@@ -492,7 +535,7 @@ __device__ __noinline__ void c3_chain_rider(int set, int w, double* A, int n, in
 #pragma unroll
                     for (int reg = 0; reg < 4; ++reg) {
                         const int row = r0 + 64 + 16 * w + e16, col = r0 + 16 * cb + g4 + 4 * reg;
-                        if (row < n) c3_st(A + (size_t)row + (size_t)col * n, acc[cb][reg]);
+                        if (row < n) c3_st(c3_at(A, (unsigned)(row + col * n)), acc[cb][reg]);
                     }
             }
         } else {
@@ -502,7 +545,7 @@ __device__ __noinline__ void c3_chain_rider(int set, int w, double* A, int n, in
 #pragma unroll
                 for (int reg = 0; reg < 4; ++reg) {
                     const int c = 16 * cb + g4 + 4 * reg;
-                    c3_st(Linv + (size_t)k * 4096 + (size_t)m * 64 + c, acc[cb][reg]);
+                    c3_st(c3_at(Linv, (unsigned)(k * 4096 + m * 64 + c)), acc[cb][reg]);
                 }
         }
         C3_STAMPI(ts, k * C3_TS + 8 + 8, !isR && lane == 0 && w == 3);
@@ -522,7 +565,7 @@ __device__ __noinline__ void c3_chain_rider(int set, int w, double* A, int n, in
 #pragma unroll
                     for (int reg = 0; reg < 4; ++reg) {
                         const int c = 16 * cb + g4 + 4 * reg;  // [blk][row of the inverse][column]; identity padding inverts to itself
-                        if ((cb >> 1) == hb) c3_gst(dinv + ((size_t)(2 * k + hb) * 32 + (c - 32 * hb)) * 32 + (m - 32 * hb), acc[cb][reg]);
+                        if ((cb >> 1) == hb) c3_gst(c3_at(dinv, (unsigned)(((2 * k + hb) * 32 + (c - 32 * hb)) * 32 + (m - 32 * hb))), acc[cb][reg]);
                     }
             }
         }
@@ -538,12 +581,39 @@ __device__ __noinline__ void c3_chain_rider(int set, int w, double* A, int n, in
                     const int cc = 16 * cb + g4 + 4 * reg, row = r0 + 128 + 16 * w + e16;
                     acc[cb][reg] = c3_ld_at(A, n, row, r0 + 64 + cc, row < n);
                 }
-            if (!c3_wait(flags + (k + 2) * T + k, 4 * (want1 >> 2) + C3_S2, fail)) return;
+            // L(k+2, k) = A'(k+2, k) L_kk^-T, my 16 rows: A' from its owner (stage 1 of the tile's flag, Linv + (T + k) tiles: every earlier
+            // panel applied -- at least half a step old), L_kk^-T from the identity's rows in LDS once its four waves are through.  The
+            // product comes out in the accumulator layout, which IS the operand layout of the update below (column 4 ks + lane / 16 =
+            // 16 cb + 4 reg + lane / 16 for ks = 4 cb + reg).  Its owner computes and publishes the same tile for everybody else.
+            if (!c3_wait(flags + (k + 2) * T + k, want1, fail)) return;
             double lv[16];
+            {
+                const double* A2 = Linv + (size_t)(T + k) * 4096;
 #pragma unroll
-            for (int ks = 0; ks < 16; ++ks) lv[ks] = c3_ld_at(A, n, r0 + 128 + 16 * w + e16, r0 + 4 * ks + g4, r0 + 128 + 16 * w + e16 < n);
+                for (int ks = 0; ks < 16; ++ks) lv[ks] = c3_ld(c3_at(A2, (unsigned)((4 * ks + g4) * 64 + 16 * w + e16)));
+            }
+            if (!c3_wait_lds(l.lf + 16 + 7, 4 * step1, fail)) return;  // L_kk^-T is complete
+            {
+                const double* panI = l.pan + 16 * C3_BLK;
+                chol_d4 X[4];
 #pragma unroll
-            for (int ks = 0; ks < 16; ++ks) lv[ks] = -lv[ks];
+                for (int cb = 0; cb < 4; ++cb) X[cb] = chol_d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int ks = 0; ks < 16; ++ks) {
+#pragma unroll
+                    for (int cb = 0; cb < 4; ++cb) {
+                        if (4 * cb + 3 >= ks) {  // (row m = 4 ks + .. of L^-T is zero left of column m: the 16-column blocks before m's are skipped)
+                            // (L^-T)[m = 4 ks + lane / 16][c = 16 cb + lane % 16] at [c / 8][m][c % 8] of the identity's micro-panel blocks
+                            const double iv = panI[(2 * cb + (e16 >> 3)) * C3_BLK + (4 * ks + g4) * C3_RS + (e16 & 7)];
+                            X[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(iv, lv[ks], X[cb], 0, 0, 0);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) lv[4 * cb + reg] = -X[cb][reg];
+            }
             if (!c3_wait_lds(cntS + 7, 4 * step1, fail)) return;  // every row of R is in LDS
 #pragma unroll
             for (int p = 0; p < 8; ++p) {
@@ -567,6 +637,7 @@ __device__ __noinline__ void c3_chain_rider(int set, int w, double* A, int n, in
 template <int Q>
 __device__ __noinline__ void c3_chain_dnext(double* A, int n, int T, int* fail, const int* flags, int want1, int mirror, long long* ts) {
     extern __shared__ __attribute__((aligned(16))) double c3_lds[];
+    A = c3_uni(A); n = c3_uni(n); T = c3_uni(T); fail = c3_uni(fail); flags = c3_uni(flags); want1 = c3_uni(want1); ts = c3_uni(ts);
     const int lane = threadIdx.x & 63;
     const C3Lds l = c3_carve(c3_lds);
     for (int k = 0; k < T; ++k) {
@@ -583,6 +654,7 @@ __device__ __noinline__ void c3_chain_dnext(double* A, int n, int T, int* fail, 
 // the step, and the two that form the next diagonal tile (c3_chain_dnext).
 __device__ __noinline__ void c3_chain_inv(int T, int* fail) {
     extern __shared__ __attribute__((aligned(16))) double c3_lds[];
+    T = c3_uni(T); fail = c3_uni(fail);
     const int lane = threadIdx.x & 63;
     const C3Lds l = c3_carve(c3_lds);
     for (int k = 0; k < T; ++k) {
@@ -620,6 +692,8 @@ __device__ __noinline__ void c3_chain_inv(int T, int* fail) {
 __device__ __noinline__ void c3_chain_aux(double* A, int n, int T, int* fail, int* flags, int want1, int want2, double* b, const double* Cc, long long* ts,
                                           const C3Arrive* arr, const double* rhs, const double* si) {
     extern __shared__ __attribute__((aligned(16))) double c3_lds[];
+    A = c3_uni(A); n = c3_uni(n); T = c3_uni(T); fail = c3_uni(fail); flags = c3_uni(flags); want1 = c3_uni(want1); want2 = c3_uni(want2);
+    b = c3_uni(b); Cc = c3_uni(Cc); ts = c3_uni(ts); arr = c3_uni(arr); rhs = c3_uni(rhs); si = c3_uni(si);
     const int lane = threadIdx.x & 63;
     const C3Lds l = c3_carve(c3_lds);
 
@@ -790,7 +864,8 @@ __device__ inline void c3_task(int T, int mirror, int idx, int& i, int& j, int& 
 // stores 64 consecutive addresses.  (Inside the chain's workgroup -- by the waves that form the next diagonal tile, by the diagonal
 // tile's own, by the inverter's -- it sat in front of the next step, which reuses the micro-panel blocks it was read from: 2 - 5 us
 // per step; a wave there gets an issue slot every ~13 cycles beside the MFMAs.)
-__device__ __noinline__ void c3_mirror_task(C3Args g, int T, int k) {
+__device__ __noinline__ void c3_mirror_task(c3_kargs kargs, int T, int k) {
+    const C3Args g = c3_args_from_kernarg(kargs);
     extern __shared__ __attribute__((aligned(16))) double c3_lds[];
     double* Xt = c3_lds;
     int* s_ok = reinterpret_cast<int*>(c3_lds + 3 * 8 * C3_BLK + 64 * C3_TBS + 64 + 64 + 128 + 512) + 61;
@@ -820,7 +895,8 @@ __device__ __noinline__ void c3_mirror_task(C3Args g, int T, int k) {
     }
 }
 
-__device__ __noinline__ void c3_owner(C3Args g, int T, int i, int j, int kind) {
+__device__ __noinline__ void c3_owner(c3_kargs kargs, int T, int i, int j, int kind) {
+    const C3Args g = c3_args_from_kernarg(kargs);
     extern __shared__ __attribute__((aligned(16))) double c3_lds[];  // (declared here, not passed: the pointers stay in the LDS address space)
     double* lds = c3_lds;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -922,6 +998,18 @@ __device__ __noinline__ void c3_owner(C3Args g, int T, int i, int j, int kind) {
         C3_STAMP(g.ts, (T + 1) * C3_TS + j, tid == 0 && kind == 0);
         return;
     }
+    // ---- the tile two below the diagonal also goes to the chain, BEFORE its panel solve (round 6): the chain needs L(j+2, j) for the
+    // input of its next step, and through this workgroup -- wait for L_jj^-1's publication, fetch, multiply, store, drain, flag, then
+    // the riders' fetch -- it arrived 11 us into that step (a two-step recurrence: every R started ~10 us late and caught up with the
+    // diagonal tile only at its last micro-panel).  The riders multiply by L_jj^-T themselves, from LDS, as soon as it exists.
+    if (i == j + 2) {
+        double* A2 = g.Linv + (size_t)(T + j) * 4096;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) c3_st(c3_at(A2, (unsigned)((16 * cb + g4 + 4 * reg) * 64 + rr)), old[reg] - acc[reg]);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) c3_st_flag(g.flags + i * T + j, want1);
+    }
     // ---- panel solve as a product: L(i,j) = A' L_jj^-T, X[r][c] = sum_m A'[r][m] Linv[c][m]
     __syncthreads();  // the last product is done with the operand tiles
 #pragma unroll
@@ -981,6 +1069,7 @@ __global__ __launch_bounds__(1024) void k_chol_tiles(C3Args g, const int* gate) 
     extern __shared__ __attribute__((aligned(16))) double c3_lds[];
     int* s_task = reinterpret_cast<int*>(c3_lds + 3 * 8 * C3_BLK + 64 * C3_TBS + 64 + 64 + 128 + 512) + 60;  // (all LDS in the dynamic region: 16-byte aligned base)
     const int T = (g.n + 63) / 64;
+    const c3_kargs kargs = (c3_kargs)__builtin_amdgcn_kernarg_segment_ptr();  // (C3Args is the first parameter: offset 0)
     const int n_tasks = c3_task_count(T, g.mirror);
     for (;;) {
         __syncthreads();
@@ -993,8 +1082,8 @@ __global__ __launch_bounds__(1024) void k_chol_tiles(C3Args g, const int* gate) 
         } else {
             int i, j, kind;
             c3_task(T, g.mirror, task, i, j, kind);
-            if (kind == 3) c3_mirror_task(g, T, j);
-            else c3_owner(g, T, i, j, kind);
+            if (kind == 3) c3_mirror_task(kargs, T, j);
+            else c3_owner(kargs, T, i, j, kind);
         }
     }
     __syncthreads();
