@@ -1035,7 +1035,7 @@ int satba_problem_create(const satba_problem_desc* d, satba_problem** out) {
         {   // scratch of the tile factorisation: tile flags (zeroed once: they carry epochs), inverted 64 x 64 diagonal blocks, the tiles'
             // shares of the forward substitution, ticket counters
             const size_t T = (size_t)(p->n_c + 63) / 64;
-            TRY(dev_alloc(p, &p->chol.flags, T * T + 1)); TRY(dev_alloc(p, &p->chol.Linv, 2 * T * 4096 + 1)); TRY(dev_alloc(p, &p->chol.Cc, T * T * 64 + 1));
+            TRY(dev_alloc(p, &p->chol.flags, T * T + 1)); TRY(dev_alloc(p, &p->chol.Linv, T * 4096 + 1)); TRY(dev_alloc(p, &p->chol.Cc, T * T * 64 + 1));
             TRY(dev_alloc(p, &p->chol.ctr, 4));
             HIP_TRY(hipMemset(p->chol.flags, 0, sizeof(int) * (T * T + 1)));
             HIP_TRY(hipMemset(p->chol.ctr, 0, sizeof(int) * 4));

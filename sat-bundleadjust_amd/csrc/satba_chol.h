@@ -245,7 +245,7 @@ inline hipError_t chol_work_alloc(CholWork& w, int n) {  // (tools; the library 
     const size_t T = (size_t)(n + 63) / 64;
     hipError_t e;
     if ((e = hipMalloc((void**)&w.flags, sizeof(int) * (T * T + 1))) != hipSuccess) return e;
-    if ((e = hipMalloc((void**)&w.Linv, sizeof(double) * (2 * T * 4096 + 1))) != hipSuccess) return e;  // (inverses | tiles (k+2, k) for the chain)
+    if ((e = hipMalloc((void**)&w.Linv, sizeof(double) * (T * 4096 + 1))) != hipSuccess) return e;
     if ((e = hipMalloc((void**)&w.Cc, sizeof(double) * (T * T * 64 + 1))) != hipSuccess) return e;
     if ((e = hipMalloc((void**)&w.ctr, sizeof(int) * 4)) != hipSuccess) return e;
     if ((e = hipMemset(w.flags, 0, sizeof(int) * (T * T + 1))) != hipSuccess) return e;

@@ -44,8 +44,7 @@ struct C3Args {
     int* fail;        // |= 1 not positive definite, |= 2 a wait timed out, |= 4 (with 2) it was a wait for the kernel that produces the matrix (c3_wait_arrive)
     int* flags;       // T x T tile flags (never cleared: epochs)
     int epoch;        // > 0, larger at every launch
-    double* Linv;     // 2 T x 64 x 64: [0, T) column-major inverses of the diagonal blocks; [T, 2 T): tile (k+2, k) with every EARLIER panel
-                      // applied, column-major, from its owner (stage C3_S1 of that tile's flag) -- the chain solves it itself (c3_chain_rider)
+    double* Linv;     // T x 64 x 64: column-major inverses of the diagonal blocks
     double* Cc;       // T x T x 64: L(i,j) y_j
     int* ctr;         // [0] ticket counter, [1] workgroups done; zero on entry, zero on exit
     double* dinv;     // 32 x 32 inverses of the diagonal blocks, [blk][r][c], for k_trsv_back_mw (or null)
@@ -485,9 +484,8 @@ __device__ __noinline__ void c3_chain_rider(int set, int w, double* A, int n, in
         }
         if (!isR || has_r) {
             // the right-hand side's wave is done with this set's rows of the previous step, and so are the products of R's four waves
-            // (which read R's rows and, since round 6, the identity's: L_kk^-T for their own solve of tile (k+2, k))
             if (k > 0 && !c3_wait_lds(isR ? l.b_rdy : l.y_done, isR ? step1 : k, fail)) return;
-            if (k > 0 && !c3_wait_lds(l.prod_cnt, 4 * (k < T - 2 ? k : T - 2), fail)) return;
+            if (isR && k > 0 && !c3_wait_lds(l.prod_cnt, 4 * k, fail)) return;
 #pragma unroll
             for (int p = 0; p < 8; ++p) {
                 const int cb = p >> 1, h = p & 1;
@@ -581,39 +579,12 @@ __device__ __noinline__ void c3_chain_rider(int set, int w, double* A, int n, in
                     const int cc = 16 * cb + g4 + 4 * reg, row = r0 + 128 + 16 * w + e16;
                     acc[cb][reg] = c3_ld_at(A, n, row, r0 + 64 + cc, row < n);
                 }
-            // L(k+2, k) = A'(k+2, k) L_kk^-T, my 16 rows: A' from its owner (stage 1 of the tile's flag, Linv + (T + k) tiles: every earlier
-            // panel applied -- at least half a step old), L_kk^-T from the identity's rows in LDS once its four waves are through.  The
-            // product comes out in the accumulator layout, which IS the operand layout of the update below (column 4 ks + lane / 16 =
-            // 16 cb + 4 reg + lane / 16 for ks = 4 cb + reg).  Its owner computes and publishes the same tile for everybody else.
-            if (!c3_wait(flags + (k + 2) * T + k, want1, fail)) return;
+            if (!c3_wait(flags + (k + 2) * T + k, 4 * (want1 >> 2) + C3_S2, fail)) return;
             double lv[16];
-            {
-                const double* A2 = Linv + (size_t)(T + k) * 4096;
 #pragma unroll
-                for (int ks = 0; ks < 16; ++ks) lv[ks] = c3_ld(c3_at(A2, (unsigned)((4 * ks + g4) * 64 + 16 * w + e16)));
-            }
-            if (!c3_wait_lds(l.lf + 16 + 7, 4 * step1, fail)) return;  // L_kk^-T is complete
-            {
-                const double* panI = l.pan + 16 * C3_BLK;
-                chol_d4 X[4];
+            for (int ks = 0; ks < 16; ++ks) lv[ks] = c3_ld_at(A, n, r0 + 128 + 16 * w + e16, r0 + 4 * ks + g4, r0 + 128 + 16 * w + e16 < n);
 #pragma unroll
-                for (int cb = 0; cb < 4; ++cb) X[cb] = chol_d4{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                for (int ks = 0; ks < 16; ++ks) {
-#pragma unroll
-                    for (int cb = 0; cb < 4; ++cb) {
-                        if (4 * cb + 3 >= ks) {  // (row m = 4 ks + .. of L^-T is zero left of column m: the 16-column blocks before m's are skipped)
-                            // (L^-T)[m = 4 ks + lane / 16][c = 16 cb + lane % 16] at [c / 8][m][c % 8] of the identity's micro-panel blocks
-                            const double iv = panI[(2 * cb + (e16 >> 3)) * C3_BLK + (4 * ks + g4) * C3_RS + (e16 & 7)];
-                            X[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(iv, lv[ks], X[cb], 0, 0, 0);
-                        }
-                    }
-                }
-#pragma unroll
-                for (int cb = 0; cb < 4; ++cb)
-#pragma unroll
-                    for (int reg = 0; reg < 4; ++reg) lv[4 * cb + reg] = -X[cb][reg];
-            }
+            for (int ks = 0; ks < 16; ++ks) lv[ks] = -lv[ks];
             if (!c3_wait_lds(cntS + 7, 4 * step1, fail)) return;  // every row of R is in LDS
 #pragma unroll
             for (int p = 0; p < 8; ++p) {
@@ -997,18 +968,6 @@ __device__ __noinline__ void c3_owner(c3_kargs kargs, int T, int i, int j, int k
         if (tid == 0) c3_st_flag(g.flags + i * T + j, want1);
         C3_STAMP(g.ts, (T + 1) * C3_TS + j, tid == 0 && kind == 0);
         return;
-    }
-    // ---- the tile two below the diagonal also goes to the chain, BEFORE its panel solve (round 6): the chain needs L(j+2, j) for the
-    // input of its next step, and through this workgroup -- wait for L_jj^-1's publication, fetch, multiply, store, drain, flag, then
-    // the riders' fetch -- it arrived 11 us into that step (a two-step recurrence: every R started ~10 us late and caught up with the
-    // diagonal tile only at its last micro-panel).  The riders multiply by L_jj^-T themselves, from LDS, as soon as it exists.
-    if (i == j + 2) {
-        double* A2 = g.Linv + (size_t)(T + j) * 4096;
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) c3_st(c3_at(A2, (unsigned)((16 * cb + g4 + 4 * reg) * 64 + rr)), old[reg] - acc[reg]);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) c3_st_flag(g.flags + i * T + j, want1);
     }
     // ---- panel solve as a product: L(i,j) = A' L_jj^-T, X[r][c] = sum_m A'[r][m] Linv[c][m]
     __syncthreads();  // the last product is done with the operand tiles

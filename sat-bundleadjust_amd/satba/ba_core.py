@@ -88,21 +88,36 @@ _SUM_POOL = None
 _SUM_CHUNK = 1 << 20  # elements
 
 
+def _pool():
+    global _SUM_POOL
+    if _SUM_POOL is None:
+        from concurrent.futures import ThreadPoolExecutor
+
+        _SUM_POOL = ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1), thread_name_prefix="satba-host")
+    return _SUM_POOL
+
+
 def _content_sum(a):
     """Sum of a contiguous array's entries, over fixed 8 MB chunks on a few threads (numpy releases the GIL inside a sum): the
     content part of the cache key below.  At 200 x 1M x 10M the three sums over 240 MB were 9 ms of a 45 ms call (round 5); the
     chunking is fixed, so the value is a function of the content alone."""
-    global _SUM_POOL
     a = np.asarray(a)
     if a.size < 4 * _SUM_CHUNK or not a.flags.c_contiguous:
         return float(a.sum())
-    if _SUM_POOL is None:
-        from concurrent.futures import ThreadPoolExecutor
-
-        _SUM_POOL = ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1), thread_name_prefix="satba-sum")
     flat = a.reshape(-1)
-    parts = list(_SUM_POOL.map(lambda i: float(flat[i:i + _SUM_CHUNK].sum()), range(0, flat.size, _SUM_CHUNK)))
+    parts = list(_pool().map(lambda i: float(flat[i:i + _SUM_CHUNK].sum()), range(0, flat.size, _SUM_CHUNK)))
     return float(np.sum(parts))
+
+
+def _big_copy(a):
+    """a.copy() for the large vectors of the drop-in call, in chunks on the threads of _content_sum (a 24 MB copy is 2.5 ms on one)."""
+    a = np.asarray(a)
+    if a.size < 2 * _SUM_CHUNK or not a.flags.c_contiguous or a.ndim != 1:
+        return a.copy()
+    out = np.empty_like(a)
+    step = _SUM_CHUNK // 2
+    list(_pool().map(lambda i: np.copyto(out[i:i + step], a[i:i + step]), range(0, a.size, step)))
+    return out
 
 
 def _fingerprint(p):
@@ -223,10 +238,16 @@ def run_ba_optimization(p, ls_params=None, verbose=False, plots=True):
     comm = _distributed()
     eng = get_engine(p, comm, rpc_f32=extra.get("rpc_store_f32", True))
     t_eng = clock()
-    vars_init = p.params_opt.copy()
-    x0 = _frozen_vars(np.array(vars_init, dtype=np.float64), p)
+    vars_init = _big_copy(p.params_opt)
+    # the frozen camera rows go into the vector that is uploaded, as the reference writes them into its caller's v; here that vector IS
+    # vars_init (no second 24 MB copy at 1 M points) and the few entries are put back behind the upload
+    n_fix = int(p.n_cam_fix) * int(p.n_params)
+    own = vars_init.dtype == np.float64 and vars_init.flags.c_contiguous and int(p.n_pts_fix) == 0
+    x0 = _frozen_vars(vars_init if own else np.array(vars_init, dtype=np.float64), p)
     eng.configure("linear", 1.0)
     eng.set_x(eng.shard.local_x(p, x0))
+    if own and n_fix:
+        vars_init[:n_fix] = np.asarray(p.params_opt[:n_fix])
     # The residual VECTORS are only needed for the figure and for return_result; the five values the reference returns need the
     # per-observation errors, which the device forms from its own residuals with the reference's operations and roundings
     # (satba_reprojection_errors): half the bytes over the bus and no numpy passes over 2 K doubles (C4: 0.2 -> 0.05 s per call)
