@@ -145,6 +145,9 @@ __device__ __forceinline__ double c3_ld_at(const double* A, int n, int row, int 
     return ok ? v : other;
 }
 __device__ __forceinline__ void c3_st(double* p, double v) { __hip_atomic_store((c3_gdouble*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// status word: a global (not flat) atomic -- a flat instruction in a role function makes every later write-through store of that function wait
+// for all outstanding memory operations (round 6: sixteen serialised stores in the diagonal tile's publication)
+__device__ __forceinline__ void c3_or_fail(int* fail, int bits) { __hip_atomic_fetch_or((c3_gint*)fail, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // Arguments of the (non-inlined) role functions arrive in vector registers, whatever the caller knows about them: a value that is the
 // same in every lane is moved to scalar registers once, and the address arithmetic built on it stays off the vector file (round 6: the
@@ -163,7 +166,7 @@ __device__ __forceinline__ bool c3_wait(const int* f, int want, int* fail) {
     while ((int)(c3_ld_flag(f) - want) < 0) {
         __builtin_amdgcn_s_sleep(1);
         if ((++spins & 1023) == 0) {
-            if (spins > C3_SPIN_LIMIT) { atomicOr(fail, 2); return false; }
+            if (spins > C3_SPIN_LIMIT) { c3_or_fail(fail, 2); return false; }
             if (c3_ld_flag(fail) & 2) return false;
         }
     }
@@ -179,7 +182,7 @@ __device__ __forceinline__ bool c3_wait_lds(const int* f, int want, int* fail) {
     while (c3_lds_get(f) < want) {
         __builtin_amdgcn_s_sleep(1);
         if ((++spins & 4095) == 0) {
-            if (spins > 4 * C3_SPIN_LIMIT) { atomicOr(fail, 2); return false; }
+            if (spins > 4 * C3_SPIN_LIMIT) { c3_or_fail(fail, 2); return false; }
             if (c3_ld_flag(fail) & 2) return false;
         }
     }
@@ -203,7 +206,7 @@ __device__ __forceinline__ bool c3_wait_arrive(const C3Arrive& r, int col_lo, in
         if (__all(ok)) return true;
         for (int t = 0; t < r.nap; ++t) __builtin_amdgcn_s_sleep(20);
         if ((++spins & 31) == 0) {
-            if (wall_clock64() - t0 > r.timeout) { if (lane == 0) atomicOr(fail, 2 | 4); return false; }  // bit 2: the wait was for the PRODUCING kernel
+            if (wall_clock64() - t0 > r.timeout) { if (lane == 0) c3_or_fail(fail, 2 | 4); return false; }  // bit 2: the wait was for the PRODUCING kernel
             if (c3_ld_flag(fail) & 2) return false;
         }
     }
@@ -392,7 +395,9 @@ __device__ __forceinline__ bool c3_dnext_blocks(const C3Lds& l, const double* A,
 // the four waves of the diagonal tile: one row per lane, column quarter q (c3_panel)
 __device__ __noinline__ void c3_chain_diag(int q, double* A, int n, int T, int* fail, int mirror, long long* ts) {
     extern __shared__ __attribute__((aligned(16))) double c3_lds[];  // (declared here, not passed: the pointers stay in the LDS address space)
-    q = c3_uni(q); A = c3_uni(A); n = c3_uni(n); T = c3_uni(T); fail = c3_uni(fail); mirror = c3_uni(mirror); ts = c3_uni(ts);
+    // (q stays in a vector register: with the column quarter in scalar registers every write-through store of L_kk below got an
+    // s_waitcnt vmcnt(0) lgkmcnt(0) of its own -- sixteen serialised stores in front of the step's publication)
+    A = c3_uni(A); n = c3_uni(n); T = c3_uni(T); fail = c3_uni(fail); mirror = c3_uni(mirror); ts = c3_uni(ts);
     const int tid = threadIdx.x, lane = tid & 63;
     const C3Lds l = c3_carve(c3_lds);
     double a[16];
@@ -411,7 +416,7 @@ __device__ __noinline__ void c3_chain_diag(int q, double* A, int n, int T, int* 
         if (k > 0 && !c3_wait_lds(l.lf + 16 + 7, 4 * k, fail)) return;
         C3_STAMP(ts, k * C3_TS + 0, tid == 0);
         const bool bad = c3_panel(a, q, lane, l.pan, l.pinv, l.lf, step1, fail, ts ? ts + k * C3_TS + 8 : nullptr);
-        if (bad && lane == 0) atomicOr(fail, 1);
+        if (bad && lane == 0) c3_or_fail(fail, 1);
         C3_STAMP(ts, k * C3_TS + 1, lane == 0 && q == 3);
         // ---- my 16 columns of L_kk, write-through and counted for the step's publication: the only reader in this launch is the
         // workgroup that writes L^T of the step's tiles for the back-substitution kernel (c3_mirror_task); the drain falls into the
@@ -423,6 +428,10 @@ __device__ __noinline__ void c3_chain_diag(int q, double* A, int n, int T, int* 
             if (row < n && col <= row) c3_st(c3_at(A, (unsigned)(row + col * n)), a[c]);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // (counted for THIS step only when every wave has counted the previous one: the counters are cumulative, and a wave that has
+        // run ahead into step k + 1 must not complete step k's count while a slower one is still storing -- round 6: with the stores
+        // of this function serialised by a flat instruction, the mirror task read L_kk's last columns before they had landed)
+        if (k > 0 && !c3_wait_lds(l.pubD_cnt, 4 * k, fail)) return;
         if (lane == 0) c3_lds_inc(l.pubD_cnt);
         // ---- the next diagonal tile, formed by two of the helper waves (c3_dnext_blocks), from LDS, one row per lane
         if (has_r) {
@@ -551,7 +560,12 @@ __device__ __noinline__ void c3_chain_rider(int set, int w, double* A, int n, in
         // (R's waves count only the steps in which they store: in the last step they have nothing to do, and a wave that ran ahead
         // into it would count twice before a slower one has drained the step before -- the last R would be flagged too early, which
         // its only reader, the workgroup that writes its transpose, showed as one wrong solve in a hundred at three tile rows)
-        if (lane == 0 && (!isR || has_r)) c3_lds_inc(isR ? l.pubR_cnt : l.pub_cnt);
+        if (!isR || has_r) {
+            // (as for the diagonal tile: this step's count only behind the complete count of the previous step -- R: 4 k, the identity and
+            // the right-hand side's wave: 5 k)
+            if (k > 0 && !c3_wait_lds(isR ? l.pubR_cnt : l.pub_cnt, (isR ? 4 : 5) * k, fail)) return;
+            if (lane == 0) c3_lds_inc(isR ? l.pubR_cnt : l.pub_cnt);
+        }
         C3_STAMPI(ts, k * C3_TS + 8 + 9, !isR && lane == 0 && w == 3);
         if (!isR) {
             // ---- plain stores for the back-substitution kernel: the 32 x 32 block inverses
@@ -715,6 +729,7 @@ __device__ __noinline__ void c3_chain_aux(double* A, int n, int T, int* fail, in
         if (lane == 0) c3_lds_set(l.y_done, step1);  // the identity's rows of this step have been read
         if (r0 + lane < n) c3_st(b + r0 + lane, y);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (k > 0 && !c3_wait_lds(l.pub_cnt, 5 * k, fail)) return;  // (this step's count behind the previous step's complete one)
         if (lane == 0) c3_lds_inc(l.pub_cnt);
         // ---- publish L_kk, L_kk^-1 and y_k as soon as their nine storing waves (4 + 4 + 1, counted per role) have drained: the panel solves of the tiles
         // below start while R is still on its way

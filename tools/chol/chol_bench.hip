@@ -151,7 +151,10 @@ int main(int argc, char** argv) {
             double ey = 0.0, ny = 0.0, em = 0.0, ed = 0.0;
             int wy = -1;
             for (int i = 0; i < n; ++i) { const double d = std::fabs(yg[i] - y[i]); if (!(d <= ey)) { ey = d; wy = i; } ny = std::max(ny, std::fabs(y[i])); }
-            for (int c = 0; c < n; ++c) for (int r = c + 1; r < n; ++r) { const double d = std::fabs(Lg[(size_t)c + (size_t)r * n] - L[(size_t)r + (size_t)c * n]); if (!(d <= em)) em = d; }
+            int mr = -1, mc = -1, nbad_m = 0;
+            for (int c = 0; c < n; ++c) for (int r = c + 1; r < n; ++r) { const double d = std::fabs(Lg[(size_t)c + (size_t)r * n] - L[(size_t)r + (size_t)c * n]); if (d > 1e-11) ++nbad_m; if (!(d <= em)) { em = d; mr = r; mc = c; } }
+            if (em > 1e-11) printf("   mirror: %d entries off, worst: upper (%d,%d) holds %.6f, L(%d,%d) = %.6f, input there %.6f, L as stored below %.6f\n", nbad_m, mc, mr,
+                                   Lg[(size_t)mc + (size_t)mr * n], mr, mc, L[(size_t)mr + (size_t)mc * n], A[(size_t)mc + (size_t)mr * n], Lg[(size_t)mr + (size_t)mc * n]);
             for (int kb = 0; kb * 32 < n; ++kb) {   // D_kb * dinv_kb = I
                 const int nb = std::min(32, n - 32 * kb);
                 for (int r = 0; r < nb; ++r) for (int c = 0; c < nb; ++c) {
