@@ -119,12 +119,30 @@ int satba_bind_exchange(satba_problem *p, double *device_ptr, int64_t len);
 
 /* The reduced camera system S is symmetric and only its lower triangle is formed and used: for the all-reduce between
  * ranks (no counterpart in the reference) the Schur payload [header | S (n_c^2) | rhs (n_c)] of the
- * exchange buffer is packed to [header | lower triangle, column-major, n_c (n_c + 1) / 2 | rhs] in caller-provided device
+ * exchange buffer is packed to [header | rhs | lower triangle, column-major, n_c (n_c + 1) / 2] in caller-provided device
  * memory (again typically a torch tensor), all-reduced there, and unpacked -- half the bytes over xGMI.
  * satba_packed_schur_len: length of that packed buffer in doubles. */
 int64_t satba_packed_schur_len(const satba_problem *p);
 int satba_pack_schur(satba_problem *p, double *packed_device_ptr);
 int satba_unpack_schur(satba_problem *p, const double *packed_device_ptr);
+
+/* The same exchange in MESSAGES, the dense factorisation beside it (round 6; replaces, for several ranks, the one LSMR call of
+ * scipy:optimize/_lsq/trf.py:479-480 on the all-reduced system): the packed payload is cut at camera boundaries into
+ * satba_solve_messages() pieces of about equal size -- bounds[m] .. bounds[m + 1] is the index range of message m, the first one
+ * carries header and right-hand side; returns 0 when this handle solves its system in one piece (fewer than 129 or more than 1 024
+ * unknowns: pack, all-reduce, unpack, satba_solve), -1 on a bad argument.  satba_solve_messages_begin packs the payload (unless
+ * packed_already: satba_pack_schur has been called and the messages have ALL been reduced -- for collectives that block the host or
+ * synchronise the device, e.g. gloo on device tensors, which would wait for the waiting factorisation) and launches
+ * the factorisation on a stream of the handle's own, where it waits for tile columns; after the all-reduce of message m (a library
+ * that queues it on the handle's stream: RCCL) satba_solve_messages_arrived unpacks its columns and releases the tiles they complete;
+ * satba_solve_messages_end queues the rest of the solve phase (what satba_solve leaves behind: step and header).  Same arithmetic in
+ * the same order as satba_solve on the unpacked system: the same bits.  _bind names the payload for the device-resident loop's parts
+ * 10 (begin), 11 (arrived; the message index travels in lam_floor) and 12 (end) of satba_lm_part. */
+int32_t satba_solve_messages(satba_problem *p, int64_t *bounds, int32_t cap);
+int satba_solve_messages_bind(satba_problem *p, double *packed_device_ptr);
+int satba_solve_messages_begin(satba_problem *p, double *packed_device_ptr, int32_t packed_already);
+int satba_solve_messages_arrived(satba_problem *p, const double *packed_device_ptr, int32_t m);
+int satba_solve_messages_end(satba_problem *p);
 
 /* loss and f_scale of least_squares (ba_core.py:292-293). */
 int satba_configure(satba_problem *p, int32_t loss, double f_scale);

@@ -162,6 +162,8 @@ struct satba_problem {
     int* d_dg_cnt = nullptr;   // ... and diagonal items finished per camera (SchurArgs::dg_cnt)
     long long* d_ts = nullptr; // (tools, -DC3_STAMPS: time stamps of the last factorisation beside the pair kernel, printed when the handle goes)
     int arrive_epoch = 0;      // != 0 while a front with the factorisation beside it is being queued (launch_schur)
+    int msg_epoch = 0;         // != 0 between satba_solve_messages_begin and _end: the epoch its factorisation waits for
+    double* msg_packed = nullptr;  // the caller's packed payload of that exchange (device-resident loop: parts 10 - 12)
     bool beside_last = false;  // the last front ran that way
     bool beside_off = false;   // ... and timed out waiting for the pair kernel (kernels serialised by a tool, one hardware queue for both streams)
     int beside_clean = 0;      // sequential fronts QUEUED since the time-out (the device-resident loop also queues fronts that pass gated off:
@@ -1167,23 +1169,39 @@ int satba_bind_exchange(satba_problem* p, double* device_ptr, int64_t len) {
     return 0;
 }
 
-// lower triangle of S (column-major, n x n) <-> packed columns; block j = column j, block n = header and rhs
-__global__ __launch_bounds__(256) void k_pack_lower(int n, int hdr, double* __restrict__ xb, double* __restrict__ packed, int unpack) {
+// lower triangle of S (column-major, n x n) <-> packed [header | rhs | column 0 | column 1 | ...]; block j = column j, block n = header and rhs.
+// (Round 6: the right-hand side in FRONT of the columns, so that the first message of the pipelined exchange carries it.)
+// c_lo, c_hi: only the columns in [c_lo, c_hi) (block n: only when c_lo == 0)
+__global__ __launch_bounds__(256) void k_pack_lower(int n, int hdr, double* __restrict__ xb, double* __restrict__ packed, int unpack, int c_lo, int c_hi,
+                                                    const int* gate) {
+    SATBA_GATE(gate);
     const int j = blockIdx.x;
-    const long long tri = (long long)n * (n + 1) / 2;
     if (j == n) {
+        if (c_lo != 0) return;
         for (int i = threadIdx.x; i < hdr + n; i += 256) {
             double* a = i < hdr ? xb + i : xb + hdr + (size_t)n * n + (i - hdr);
-            double* b = i < hdr ? packed + i : packed + hdr + tri + (i - hdr);
-            if (unpack) *a = *b; else *b = *a;
+            double* b = packed + i;
+            if (unpack) __hip_atomic_store(a, __hip_atomic_load(b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else *b = *a;
         }
         return;
     }
+    if (j < c_lo || j >= c_hi) return;
     double* col = xb + hdr + (size_t)j * n;
-    double* pk = packed + hdr + ((long long)j * n - (long long)j * (j - 1) / 2) - j;  // pk[r] for r >= j
+    double* pk = packed + hdr + n + ((long long)j * n - (long long)j * (j - 1) / 2) - j;  // pk[r] for r >= j
     for (int r = j + threadIdx.x; r < n; r += 256) {
-        if (unpack) col[r] = pk[r]; else pk[r] = col[r];
+        // (unpack: the payload may have come over a copy engine while kernels of this handle were running -- read past the caches,
+        // system scope --, and a factorisation that is already waiting on the other stream reads S: write through)
+        if (unpack) __hip_atomic_store(col + r, __hip_atomic_load(pk + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else pk[r] = col[r];
     }
+}
+// cameras [c_lo, c_hi) of the reduced system have arrived (k_chol_tiles waits for them: C3Args::arrive); first: the epoch word, too
+__global__ void k_mark_arrived(int* __restrict__ arrive, int c_lo, int c_hi, int M, int epoch, int first, const int* gate) {
+    SATBA_GATE(gate);
+    const int c = c_lo + blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < c_hi) __hip_atomic_store(arrive + (size_t)SCHUR_ARRIVE_STRIDE * c, M, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (first && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(arrive + (size_t)SCHUR_ARRIVE_STRIDE * M, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 int64_t satba_packed_schur_len(const satba_problem* p) {
@@ -1193,7 +1211,7 @@ int64_t satba_packed_schur_len(const satba_problem* p) {
 static int pack_schur_impl(satba_problem* p, double* packed, int unpack) {
     if (!p || !packed) return fail(SATBA_E_ARG, "null argument");
     HIP_TRY(hipSetDevice(p->device));
-    hipLaunchKernelGGL(k_pack_lower, dim3(p->n_c + 1), dim3(256), 0, p->stream, p->n_c, (int)p->hdr, p->d_xb, packed, unpack);
+    hipLaunchKernelGGL(k_pack_lower, dim3(p->n_c + 1), dim3(256), 0, p->stream, p->n_c, (int)p->hdr, p->d_xb, packed, unpack, 0, p->n_c, (const int*)nullptr);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -1540,6 +1558,71 @@ static bool beside_timed_out(satba_problem* p, const double* h) {
     beside_disable(p);
     return true;
 }
+// ---- the factorisation on a stream of its own, reading every tile of S when its producers have counted in (C3Args::arrive): beside the
+// pair kernel on one rank (front_schur_solve), beside the all-reduce of S cut into messages with several (satba_solve_messages_*)
+static int chol_front_streams(satba_problem* p) {
+    if (p->chol_stream) return 0;
+    // A priority of its own: streams of one priority share a small pool of hardware queues, and two streams on ONE queue run in
+    // submission order -- the factorisation, queued first, would wait for a pair kernel stuck behind it until its waits time out
+    // (seen once in a long test process, where the pool had been handed round many times).
+    int least = 0, greatest = 0, mine = 0;
+    HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    HIP_TRY(hipStreamGetPriority(p->stream, &mine));
+    HIP_TRY(hipStreamCreateWithPriority(&p->chol_stream, hipStreamNonBlocking, mine != greatest ? greatest : least));
+    HIP_TRY(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming));
+    TRY(dev_alloc(p, &p->d_arrive, (size_t)(p->M + 2) * SCHUR_ARRIVE_STRIDE));  // (+ k_schur_pairs' start word, + the solve's done word)
+    HIP_TRY(hipMemsetAsync(p->d_arrive, 0, sizeof(int) * (size_t)(p->M + 2) * SCHUR_ARRIVE_STRIDE, p->stream));
+    TRY(dev_alloc(p, &p->d_pair_cnt, (size_t)std::max<long long>(p->L.n_pairs, 1)));
+    HIP_TRY(hipMemsetAsync(p->d_pair_cnt, 0, sizeof(int) * (size_t)std::max<long long>(p->L.n_pairs, 1), p->stream));
+    TRY(dev_alloc(p, &p->d_dg_cnt, (size_t)p->M));
+    HIP_TRY(hipMemsetAsync(p->d_dg_cnt, 0, sizeof(int) * (size_t)p->M, p->stream));
+    return 0;
+}
+// k_chol_tiles (wgs workgroups) and the backward substitution on the other stream, behind everything queued on p->stream so far; leaves
+// the launch's epoch in p->arrive_epoch.  arr_extra: C3Args::arr_extra.
+static int chol_front_launch(satba_problem* p, int wgs, int arr_extra, long long arr_timeout) {
+    Range range_("satba:solve");
+    double* S = p->payload();
+    double* rhs = S + (size_t)p->n_c * p->n_c;
+    const int n = p->n_c;
+    HIP_TRY(hipEventRecord(p->ev_fork, p->stream));
+    HIP_TRY(hipStreamWaitEvent(p->chol_stream, p->ev_fork, 0));
+    HIP_TRY(hipMemsetAsync(p->d_fail, 0, sizeof(int) * (1 + CH_MAX_STEPS), p->chol_stream));
+    cholesky_init();
+    C3Args g;
+    g.A = S; g.n = n; g.b = p->d_dch; g.fail = p->d_fail; g.flags = p->chol.flags; g.epoch = ++p->chol.epoch; g.Linv = p->chol.Linv; g.Cc = p->chol.Cc;
+    g.ctr = p->chol.ctr; g.dinv = p->d_dinv; g.ts = nullptr; g.mirror = 1;
+#ifdef C3_STAMPS
+    if (!p->d_ts) { TRY(dev_alloc(p, &p->d_ts, (size_t)20 * C3_TS)); }
+    HIP_TRY(hipMemsetAsync(p->d_ts, 0, sizeof(long long) * 20 * C3_TS, p->chol_stream));
+    g.ts = p->d_ts;
+#endif
+    g.arrive = p->d_arrive; g.arr_M = p->M; g.np = p->NP; g.arr_epoch = g.epoch; g.si = p->d_scale_inv; g.rhs = rhs;
+    g.arr_extra = arr_extra;
+    g.arr_timeout = arr_timeout;
+    hipLaunchKernelGGL(k_chol_tiles, dim3(std::min(chol_tiles_grid(n, 1), wgs)), dim3(1024), c3_lds_bytes(), p->chol_stream, g, p->gate);
+    hipLaunchKernelGGL(k_trsv_back_mw, dim3((n + CH_SB - 1) / CH_SB), dim3(512), 0, p->chol_stream, S, p->d_dinv, n, p->d_dch,
+                       p->d_fail + 1 + CH_TRSV_FLAGS, p->gate, p->d_arrive + (size_t)SCHUR_ARRIVE_STRIDE * (p->M + 1), g.epoch);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(p->ev_join, p->chol_stream));
+    p->arrive_epoch = g.epoch;
+    return 0;
+}
+// the rest of the solve phase on p->stream: k_unscale waits for the word the backward substitution posts on the other stream (the event
+// only orders what follows), then the points' part of the step
+static int chol_front_finish(satba_problem* p, int epoch) {
+    const int nu = std::max(p->n_c, (int)p->hdr);
+    hipLaunchKernelGGL(k_unscale, dim3((nu + 255) / 256), dim3(256), 0, p->stream, p->n_c, p->d_scale_inv, p->d_dch, p->d_dc, (int)p->hdr,
+                       p->d_xb, p->d_fail, p->lead, p->d_keep, SATBA_HDR_KEEP, SATBA_KEEP_LEN, p->gate,
+                       p->d_arrive + (size_t)SCHUR_ARRIVE_STRIDE * (p->M + 1), epoch);
+    HIP_TRY(hipGetLastError());
+    TRY(launch_backsub_kernel(p));
+    HIP_TRY(hipStreamWaitEvent(p->stream, p->ev_join, 0));
+    p->have_step = true;
+    return 0;
+}
+
 static int front_schur_solve(satba_problem* p, bool automatic, double lam, double Delta, double lam_floor) {
     if (p->beside_off && ++p->beside_clean > p->beside_retry_after) p->beside_off = false;  // (chol_beside_ok decides whether it applies at all)
     p->beside_last = chol_beside_ok(p);
@@ -1551,58 +1634,18 @@ static int front_schur_solve(satba_problem* p, bool automatic, double lam, doubl
         return satba_solve(p);
     }
     HIP_TRY(hipSetDevice(p->device));
-    if (!p->chol_stream) {
-        // A priority of its own: streams of one priority share a small pool of hardware queues, and two streams on ONE queue run in
-        // submission order -- the factorisation, queued first, would wait for a pair kernel stuck behind it until its waits time out
-        // (seen once in a long test process, where the pool had been handed round many times).
-        int least = 0, greatest = 0, mine = 0;
-        HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
-        HIP_TRY(hipStreamGetPriority(p->stream, &mine));
-        HIP_TRY(hipStreamCreateWithPriority(&p->chol_stream, hipStreamNonBlocking, mine != greatest ? greatest : least));
-        HIP_TRY(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming));
-        TRY(dev_alloc(p, &p->d_arrive, (size_t)(p->M + 2) * SCHUR_ARRIVE_STRIDE));  // (+ k_schur_pairs' start word, + the solve's done word)
-        HIP_TRY(hipMemsetAsync(p->d_arrive, 0, sizeof(int) * (size_t)(p->M + 2) * SCHUR_ARRIVE_STRIDE, p->stream));
-        TRY(dev_alloc(p, &p->d_pair_cnt, (size_t)std::max<long long>(p->L.n_pairs, 1)));
-        HIP_TRY(hipMemsetAsync(p->d_pair_cnt, 0, sizeof(int) * (size_t)std::max<long long>(p->L.n_pairs, 1), p->stream));
-        TRY(dev_alloc(p, &p->d_dg_cnt, (size_t)p->M));
-        HIP_TRY(hipMemsetAsync(p->d_dg_cnt, 0, sizeof(int) * (size_t)p->M, p->stream));
-    }
+    TRY(chol_front_streams(p));
     const char* env_wgs = getenv("SATBA_CHOL_BESIDE_WGS");
     // workgroups (= CUs) lent to the factorisation, a multiple of the eight XCDs.  Measured at 200 cameras x 5 (round 5, LM it/s): beside the
     // unit-weight pair kernel (0.43 ms) 16: 777, 24: 819, 28: 820, 32: 841, 36: 793, 40: 788, 48: 783, 64: 802; beside the weighted one
     // (1.3 ms: the factorisation has three times as long, the pair kernel misses every CU longer) 8: 439, 12: 456, 16: 460, 20: 454,
-    // 24: 436, 32: 433 (the sequential front: 433)
+    // 24: 436, 32: 433 (the sequential front: 433).  Round 6 (faster chain): unit weights -: 865, 24: 846, 32: 865, 40: 809; soft_l1 8: 460, 16: 486, 24: 486
     const bool weighted_front = wmode(p) && p->L.wl_ready;
     const int wgs = (env_wgs && atoi(env_wgs) > 0) ? atoi(env_wgs) : (weighted_front ? 16 : 32);
-    double* S = p->payload();
-    double* rhs = S + (size_t)p->n_c * p->n_c;
-    const int n = p->n_c;
-    {
-        Range range_("satba:solve");
-        HIP_TRY(hipEventRecord(p->ev_fork, p->stream));
-        HIP_TRY(hipStreamWaitEvent(p->chol_stream, p->ev_fork, 0));
-        HIP_TRY(hipMemsetAsync(p->d_fail, 0, sizeof(int) * (1 + CH_MAX_STEPS), p->chol_stream));
-        cholesky_init();
-        C3Args g;
-        g.A = S; g.n = n; g.b = p->d_dch; g.fail = p->d_fail; g.flags = p->chol.flags; g.epoch = ++p->chol.epoch; g.Linv = p->chol.Linv; g.Cc = p->chol.Cc;
-        g.ctr = p->chol.ctr; g.dinv = p->d_dinv; g.ts = nullptr; g.mirror = 1;
-#ifdef C3_STAMPS
-        if (!p->d_ts) { TRY(dev_alloc(p, &p->d_ts, (size_t)20 * C3_TS)); }
-        HIP_TRY(hipMemsetAsync(p->d_ts, 0, sizeof(long long) * 20 * C3_TS, p->chol_stream));
-        g.ts = p->d_ts;
-#endif
-        g.arrive = p->d_arrive; g.arr_M = p->M; g.np = p->NP; g.arr_epoch = g.epoch; g.si = p->d_scale_inv; g.rhs = rhs;
-        g.arr_extra = weighted_front ? 1 : 0;  // (the pair kernel writes the diagonal blocks and the right-hand side, too: launch_schur)
-        // 5 ms + ~10 x what the kernels in front of a tile's last producer take at HBM speed (hit lists and records: ~100 bytes per hit)
-        g.arr_timeout = 500000 + (long long)((double)p->L.E * 100.0 / 6e12 * 1e8 * 10.0) + (long long)((double)p->K * 200.0 / 6e12 * 1e8 * 10.0);
-        hipLaunchKernelGGL(k_chol_tiles, dim3(std::min(chol_tiles_grid(n, 1), wgs)), dim3(1024), c3_lds_bytes(), p->chol_stream, g, p->gate);
-        hipLaunchKernelGGL(k_trsv_back_mw, dim3((n + CH_SB - 1) / CH_SB), dim3(512), 0, p->chol_stream, S, p->d_dinv, n, p->d_dch,
-                           p->d_fail + 1 + CH_TRSV_FLAGS, p->gate, p->d_arrive + (size_t)SCHUR_ARRIVE_STRIDE * (p->M + 1), g.epoch);
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipEventRecord(p->ev_join, p->chol_stream));
-        p->arrive_epoch = g.epoch;
-    }
+    // 5 ms + ~10 x what the kernels in front of a tile's last producer take at HBM speed (hit lists and records: ~100 bytes per hit)
+    const long long timeout = 500000 + (long long)((double)p->L.E * 100.0 / 6e12 * 1e8 * 10.0) + (long long)((double)p->K * 200.0 / 6e12 * 1e8 * 10.0);
+    // (the pair kernel of the weighted / robust runs writes the diagonal blocks and the right-hand side, too: launch_schur)
+    TRY(chol_front_launch(p, wgs, weighted_front ? 1 : 0, timeout));
     const int epoch = p->arrive_epoch;
     const int rc = automatic ? satba_schur_auto(p, Delta, lam_floor) : satba_schur(p, lam);
     p->arrive_epoch = 0;
@@ -1610,16 +1653,92 @@ static int front_schur_solve(satba_problem* p, bool automatic, double lam, doubl
         HIP_TRY(hipStreamWaitEvent(p->stream, p->ev_join, 0));  // (the other stream's work is bounded by its time-out)
         return rc;
     }
-    // k_unscale waits for the word the backward substitution posts on the other stream; the event only orders what follows
-    const int nu = std::max(p->n_c, (int)p->hdr);
-    hipLaunchKernelGGL(k_unscale, dim3((nu + 255) / 256), dim3(256), 0, p->stream, p->n_c, p->d_scale_inv, p->d_dch, p->d_dc, (int)p->hdr,
-                       p->d_xb, p->d_fail, p->lead, p->d_keep, SATBA_HDR_KEEP, SATBA_KEEP_LEN, p->gate,
-                       p->d_arrive + (size_t)SCHUR_ARRIVE_STRIDE * (p->M + 1), epoch);
+    return chol_front_finish(p, epoch);
+}
+
+// ---- several ranks: the all-reduce of S in messages, the factorisation beside it (round 6).  The packed payload
+// [header | rhs | columns of the lower triangle] is cut at camera boundaries into messages of about equal size; the caller all-reduces
+// message m and tells the handle (satba_solve_messages_arrived), which unpacks its columns and counts their cameras in; k_chol_tiles,
+// launched first on the other stream, takes tile column k when the cameras of its 64 columns are in -- the same arrival words, the same
+// scale-as-you-read arithmetic and therefore the same bits as beside the pair kernel on one rank and as the sequential front.
+// bounds: n_messages + 1 camera indices; the packed range of message m is [pk(bounds[m]), pk(bounds[m + 1])) with
+// pk(c) = hdr + n_c + col_ofs(c n_p) for c > 0 and pk(0) = 0 (the first message carries header and right-hand side).
+static int schur_message_cams(const satba_problem* p, std::vector<int>& cam_bounds) {
+    static const int want = getenv("SATBA_PIPELINE_MESSAGES") ? std::max(1, std::min(16, atoi(getenv("SATBA_PIPELINE_MESSAGES")))) : 4;
+    const long long n = p->n_c, np = p->NP;
+    const long long tri = n * (n + 1) / 2;
+    cam_bounds.assign(1, 0);
+    for (int m = 1; m < want; ++m) {
+        // first camera whose columns start at or behind the fraction m / want of the triangle's entries
+        const long long target = tri * m / want;
+        int c = cam_bounds.back();
+        while (c < p->M && (c * np) * n - (c * np) * ((c * np) - 1) / 2 < target) ++c;
+        if (c > cam_bounds.back() && c < p->M) cam_bounds.push_back(c);
+    }
+    cam_bounds.push_back(p->M);
+    return (int)cam_bounds.size() - 1;
+}
+static long long packed_col_ofs(const satba_problem* p, long long col) {  // index of column `col`'s diagonal entry in the packed payload
+    return p->hdr + p->n_c + col * p->n_c - col * (col - 1) / 2;
+}
+static bool solve_messages_ok(const satba_problem* p) {  // (the tile kernel with mirror and multi-workgroup substitution: as chol_beside_ok)
+    return p->n_c == p->M * p->NP && p->n_c > 128 && p->n_c <= 1024;
+}
+int32_t satba_solve_messages(satba_problem* p, int64_t* bounds, int32_t cap) {
+    if (!p) return -1;
+    if (!solve_messages_ok(p)) return 0;  // the caller all-reduces the whole payload and calls satba_solve
+    std::vector<int> cb;
+    const int nm = schur_message_cams(p, cb);
+    if (bounds) {
+        if (cap < nm + 1) return -1;
+        for (int m = 0; m <= nm; ++m) bounds[m] = m == 0 ? 0 : (m == nm ? satba_packed_schur_len(p) : packed_col_ofs(p, (long long)cb[m] * p->NP));
+    }
+    return nm;
+}
+// pack S | rhs | header into `packed` and launch the factorisation, which waits for the messages
+int satba_solve_messages_begin(satba_problem* p, double* packed, int32_t packed_already) {
+    if (!p || !packed) return fail(SATBA_E_ARG, "null argument");
+    if (!solve_messages_ok(p)) return fail(SATBA_E_ARG, "the reduced system of this handle is solved in one piece (satba_solve)");
+    HIP_TRY(hipSetDevice(p->device));
+    TRY(chol_front_streams(p));
+    if (!packed_already) hipLaunchKernelGGL(k_pack_lower, dim3(p->n_c + 1), dim3(256), 0, p->stream, p->n_c, (int)p->hdr, p->d_xb, packed, 0, 0, p->n_c, p->gate);
     HIP_TRY(hipGetLastError());
-    TRY(launch_backsub_kernel(p));
-    HIP_TRY(hipStreamWaitEvent(p->stream, p->ev_join, 0));
-    p->have_step = true;
+    // a message is a collective of the caller's library between host-side calls: the wait is sized for those, not for a kernel (2 s;
+    // SATBA_PIPELINE_TIMEOUT_MS); a time-out is reported like any failed factorisation
+    static const long long ms = getenv("SATBA_PIPELINE_TIMEOUT_MS") ? atoll(getenv("SATBA_PIPELINE_TIMEOUT_MS")) : 2000;
+    static const int wgs = getenv("SATBA_PIPELINE_WGS") ? std::max(8, atoi(getenv("SATBA_PIPELINE_WGS"))) : 64;
+    TRY(chol_front_launch(p, wgs, 0, ms * 100000));
+    p->msg_epoch = p->arrive_epoch;
+    p->arrive_epoch = 0;  // (no Schur kernel of this rank is a producer)
     return 0;
+}
+// message m has been all-reduced in `packed`: its columns into S (message 0: header and right-hand side, too), its cameras counted in
+int satba_solve_messages_arrived(satba_problem* p, const double* packed, int32_t m) {
+    if (!p || !packed) return fail(SATBA_E_ARG, "null argument");
+    std::vector<int> cb;
+    const int nm = schur_message_cams(p, cb);
+    if (m < 0 || m >= nm || !p->msg_epoch) return fail(SATBA_E_STATE, "no such message, or no satba_solve_messages_begin");
+    HIP_TRY(hipSetDevice(p->device));
+    const int c_lo = cb[m] * p->NP, c_hi = cb[m + 1] * p->NP;
+    hipLaunchKernelGGL(k_pack_lower, dim3(p->n_c + 1), dim3(256), 0, p->stream, p->n_c, (int)p->hdr, p->d_xb, const_cast<double*>(packed), 1, c_lo, c_hi, p->gate);
+    hipLaunchKernelGGL(k_mark_arrived, dim3((cb[m + 1] - cb[m] + 63) / 64), dim3(64), 0, p->stream, p->d_arrive, cb[m], cb[m + 1], p->M, p->msg_epoch, m == 0 ? 1 : 0,
+                       p->gate);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+// the packed payload the device-resident loop's parts 10 - 12 work on (satba_lm_part has no pointer argument)
+int satba_solve_messages_bind(satba_problem* p, double* packed) {
+    if (!p) return fail(SATBA_E_ARG, "null handle");
+    p->msg_packed = packed;
+    return 0;
+}
+int satba_solve_messages_end(satba_problem* p) {
+    if (!p) return fail(SATBA_E_ARG, "null handle");
+    if (!p->msg_epoch) return fail(SATBA_E_STATE, "satba_solve_messages_end before _begin");
+    HIP_TRY(hipSetDevice(p->device));
+    const int epoch = p->msg_epoch;
+    p->msg_epoch = 0;
+    return chol_front_finish(p, epoch);
 }
 
 int satba_schur(satba_problem* p, double lam) {
@@ -2023,7 +2142,7 @@ int satba_lm_begin(satba_problem* p, const satba_lm_opts* o, int32_t never_stop,
 }
 
 int satba_lm_part(satba_problem* p, int32_t part, double lam_floor) {
-    if (!p || part < 0 || part > 9) return fail(SATBA_E_ARG, "bad argument");
+    if (!p || part < 0 || part > 12) return fail(SATBA_E_ARG, "bad argument");
     HIP_TRY(hipSetDevice(p->device));
     LmDev* st = p->d_lm;
     LmArgsScope scope(p);
@@ -2036,6 +2155,10 @@ int satba_lm_part(satba_problem* p, int32_t part, double lam_floor) {
             p->decide_fused = true;  // k_lm_decide1a rides in the trial's first launch (launch_trial)
             p->gate = &st->run_trial;
             return satba_trial_gn(p, 0.0, 0.0);
+        // the solve phase with the all-reduce of S in messages (trf.drive_device_loop): 10 begin, 11 message lam_floor has arrived, 12 end
+        case 10: p->gate = &st->run_solve; return satba_solve_messages_begin(p, p->msg_packed, lam_floor != 0.0 ? 1 : 0);
+        case 11: p->gate = &st->run_solve; return satba_solve_messages_arrived(p, p->msg_packed, (int)lam_floor);
+        case 12: p->gate = &st->run_solve; return satba_solve_messages_end(p);
         case 6: p->gate = &st->run_sub; return satba_subspace(p, 0.0, 0.0);
         case 7:
             hipLaunchKernelGGL(k_lm_decide1b, dim3(1), dim3(1), 0, p->stream, st, p->d_xb);

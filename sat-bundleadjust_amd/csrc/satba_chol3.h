@@ -160,13 +160,24 @@ __device__ __forceinline__ T* c3_uni(T* q) {
     return reinterpret_cast<T*>(((unsigned long long)hi << 32) | lo);
 }
 
+// How long a wait inside k_chol_tiles may last, in polls: slots 62 (waits on global flag words, ~0.3 us per poll) and 63 (waits on LDS
+// words, ~0.06 us per poll) of the kernel's LDS words, written by thread 0 at the kernel's start -- about a second, plus the arrival
+// time-out when the launch waits for its input (C3Args::arrive): every wait for another tile or role is then, transitively, a wait
+// for a message or a producer (round 6: the fixed poll counts of round 4, ~1 s, cut a factorisation short whose messages came
+// through a slow collective).  (Counted in polls, not on the wall clock: a 64-bit start time alive across every inlined wait loop
+// cost the chain's roles 160 - 210 bytes of scratch.)
+constexpr int C3_LDS_INTS_AT = 3 * 8 * C3_BLK + 64 * C3_TBS + 64 + 64 + 128 + 512;  // (doubles in front of the LDS words: c3_carve, c3_lds_bytes)
+__device__ __forceinline__ int c3_poll_limit(int which) {
+    extern __shared__ __attribute__((aligned(16))) double c3_lds[];
+    return __hip_atomic_load(reinterpret_cast<const int*>(c3_lds + C3_LDS_INTS_AT) + 62 + which, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
 // wait until a global flag word reaches `want` (wrap-safe); false after the time-out or when another wait has timed out
 __device__ __forceinline__ bool c3_wait(const int* f, int want, int* fail) {
     int spins = 0;
     while ((int)(c3_ld_flag(f) - want) < 0) {
         __builtin_amdgcn_s_sleep(1);
         if ((++spins & 1023) == 0) {
-            if (spins > C3_SPIN_LIMIT) { c3_or_fail(fail, 2); return false; }
+            if (spins > c3_poll_limit(0)) { c3_or_fail(fail, 2); return false; }
             if (c3_ld_flag(fail) & 2) return false;
         }
     }
@@ -177,12 +188,13 @@ __device__ __forceinline__ bool c3_wait(const int* f, int want, int* fail) {
 __device__ __forceinline__ int c3_lds_get(const int* f) { return __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ void c3_lds_set(int* f, int v) { __hip_atomic_store(f, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ void c3_lds_inc(int* f) { __hip_atomic_fetch_add(f, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-__device__ __forceinline__ bool c3_wait_lds(const int* f, int want, int* fail) {
+// kernel_limit = false: k_solve_small (no slot of its own: the fixed count)
+__device__ __forceinline__ bool c3_wait_lds(const int* f, int want, int* fail, bool kernel_limit = true) {
     int spins = 0;
     while (c3_lds_get(f) < want) {
         __builtin_amdgcn_s_sleep(1);
         if ((++spins & 4095) == 0) {
-            if (spins > 4 * C3_SPIN_LIMIT) { c3_or_fail(fail, 2); return false; }
+            if (spins > (kernel_limit ? c3_poll_limit(1) : 4 * C3_SPIN_LIMIT)) { c3_or_fail(fail, 2); return false; }
             if (c3_ld_flag(fail) & 2) return false;
         }
     }
@@ -221,7 +233,8 @@ __device__ __forceinline__ bool c3_wait_arrive(const C3Arrive& r, int col_lo, in
 // 15 - j later columns, the last foreign micro-panel's share of columns 8 .. 15 issued inside the factorisation): the registers
 // ran out, five spills per column sat on the chain -- 7.6 us per pair of micro-panels against 3.7.
 // n_mp: micro-panels to factorise (8: the whole tile; k_solve_small: only those that hold columns of the system)
-__device__ __forceinline__ bool c3_panel(double (&a)[16], int q, int lane, double* pan, double* pinv, int* lf, int step1, int* fail, long long* tsp, int n_mp = 8) {
+__device__ __forceinline__ bool c3_panel(double (&a)[16], int q, int lane, double* pan, double* pinv, int* lf, int step1, int* fail, long long* tsp, int n_mp = 8,
+                                         bool kernel_limit = true) {
     bool bad = false;
     if (2 * q >= n_mp) return false;
     for (int pp = 0; pp < q; ++pp) {
@@ -229,7 +242,7 @@ __device__ __forceinline__ bool c3_panel(double (&a)[16], int q, int lane, doubl
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int p = 2 * pp + h;
-            if (!c3_wait_lds(lf + p, step1, fail)) return true;
+            if (!c3_wait_lds(lf + p, step1, fail, kernel_limit)) return true;
             const double2* row = reinterpret_cast<const double2*>(pan + p * C3_BLK + lane * C3_RS);
             double r[8];
 #pragma unroll
@@ -674,11 +687,17 @@ __device__ __noinline__ void c3_chain_inv(int T, int* fail) {
 // the right-hand side's wave (also publishes the step)
 // arr (arr->arrive != null and arr->extra): the right-hand side of tile row k + 1 >= 2 is read from rhs, scaled by si, once the producers
 // of that tile's columns have counted in (C3Args::arr_extra)
+// (the arrival parameters come as scalars: behind a pointer to the caller's local struct they were ten flat loads from scratch per step)
 __device__ __noinline__ void c3_chain_aux(double* A, int n, int T, int* fail, int* flags, int want1, int want2, double* b, const double* Cc, long long* ts,
-                                          const C3Arrive* arr, const double* rhs, const double* si) {
+                                          const int* arr_arrive, int arr_M, int arr_np, int arr_epoch, int arr_nap, long long arr_timeout, int arr_extra,
+                                          const double* rhs, const double* si) {
     extern __shared__ __attribute__((aligned(16))) double c3_lds[];
     A = c3_uni(A); n = c3_uni(n); T = c3_uni(T); fail = c3_uni(fail); flags = c3_uni(flags); want1 = c3_uni(want1); want2 = c3_uni(want2);
-    b = c3_uni(b); Cc = c3_uni(Cc); ts = c3_uni(ts); arr = c3_uni(arr); rhs = c3_uni(rhs); si = c3_uni(si);
+    b = c3_uni(b); Cc = c3_uni(Cc); ts = c3_uni(ts); rhs = c3_uni(rhs); si = c3_uni(si);
+    arr_arrive = c3_uni(arr_arrive); arr_M = c3_uni(arr_M); arr_np = c3_uni(arr_np); arr_epoch = c3_uni(arr_epoch); arr_nap = c3_uni(arr_nap); arr_extra = c3_uni(arr_extra);
+    arr_timeout = ((long long)c3_uni((int)(arr_timeout >> 32)) << 32) | (unsigned)c3_uni((int)arr_timeout);
+    const C3Arrive arr_v{arr_arrive, arr_M, arr_np, arr_epoch, arr_nap, arr_timeout, arr_extra};
+    const C3Arrive* arr = &arr_v;
     const int lane = threadIdx.x & 63;
     const C3Lds l = c3_carve(c3_lds);
 
@@ -808,8 +827,7 @@ __device__ __forceinline__ void c3_chain(const C3Args& g, int T) {
     else if (oth == 11) c3_chain_dnext<1>(g.A, g.n, T, g.fail, g.flags, want1, g.mirror, g.ts);
     else if (oth == 8) c3_chain_inv(T, g.fail);
     else {
-        const C3Arrive arr{g.arrive, g.arr_M, g.np, g.arr_epoch, g.nap, g.arr_timeout, g.arr_extra};
-        c3_chain_aux(g.A, g.n, T, g.fail, g.flags, want1, want2, g.b, g.Cc, g.ts, &arr, g.rhs, g.si);
+        c3_chain_aux(g.A, g.n, T, g.fail, g.flags, want1, want2, g.b, g.Cc, g.ts, g.arrive, g.arr_M, g.np, g.arr_epoch, g.nap, g.arr_timeout, g.arr_extra, g.rhs, g.si);
     }
 }
 
@@ -1042,6 +1060,13 @@ __global__ __launch_bounds__(1024) void k_chol_tiles(C3Args g, const int* gate) 
     SATBA_GATE(gate);
     extern __shared__ __attribute__((aligned(16))) double c3_lds[];
     int* s_task = reinterpret_cast<int*>(c3_lds + 3 * 8 * C3_BLK + 64 * C3_TBS + 64 + 64 + 128 + 512) + 60;  // (all LDS in the dynamic region: 16-byte aligned base)
+    if (threadIdx.x == 0) {
+        const long long extra = g.arrive ? g.arr_timeout : 0ll;  // ticks of 10 ns
+        const long long lg = (long long)C3_SPIN_LIMIT + extra / 20, ll = 4ll * C3_SPIN_LIMIT + extra / 4;
+        int* lim = reinterpret_cast<int*>(c3_lds + C3_LDS_INTS_AT) + 62;
+        c3_lds_set(lim, (int)(lg < 0x7fffffffll ? lg : 0x7fffffffll));
+        c3_lds_set(lim + 1, (int)(ll < 0x7fffffffll ? ll : 0x7fffffffll));
+    }
     const int T = (g.n + 63) / 64;
     const c3_kargs kargs = (c3_kargs)__builtin_amdgcn_kernarg_segment_ptr();  // (C3Args is the first parameter: offset 0)
     const int n_tasks = c3_task_count(T, g.mirror);
@@ -1111,7 +1136,7 @@ __global__ __launch_bounds__(256) void k_solve_small(int n, const double* __rest
         a[c] = v;
     }
     __syncthreads();
-    const bool bad = c3_panel(a, q, lane, s_pan, s_pinv, s_lf, 1, fail, nullptr, (n + 7) >> 3);  // (padding columns and the corner are not factorised)
+    const bool bad = c3_panel(a, q, lane, s_pan, s_pinv, s_lf, 1, fail, nullptr, (n + 7) >> 3, false);  // (padding columns and the corner are not factorised)
     if (bad && lane == 0) atomicOr(&s_bad, 1);
     __syncthreads();  // every micro-panel is in LDS
     if (q == 0) {

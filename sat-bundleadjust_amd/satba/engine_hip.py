@@ -29,7 +29,7 @@ SYMBOLS = [
     "satba_residuals", "satba_reprojection_errors", "satba_reprojection_errors_begin", "satba_reprojection_errors_fetch", "satba_linearize", "satba_prepare", "satba_schur", "satba_schur_auto", "satba_solve", "satba_subspace", "satba_subspace_products", "satba_trial", "satba_trial_gn",
     "satba_accept", "satba_camera_sums_fallback", "satba_read_header", "satba_get_blocks", "satba_get_jacobian", "satba_get_exchange",
     "satba_set_exchange", "satba_get_vector", "satba_time_kernel",
-    "satba_packed_schur_len", "satba_pack_schur", "satba_unpack_schur",
+    "satba_packed_schur_len", "satba_pack_schur", "satba_solve_messages", "satba_solve_messages_bind", "satba_solve_messages_begin", "satba_solve_messages_arrived", "satba_solve_messages_end", "satba_unpack_schur",
     "satba_solve_lm", "satba_lm_step", "satba_lm_run", "satba_lm_state", "satba_lm_begin", "satba_lm_part", "satba_lm_poll", "satba_profile_linearize", "satba_profile_read", "satba_outliers", "satba_layout_len", "satba_get_layout", "satba_get_info",
     "satba_triangulate_pairwise", "satba_init_pts3d", "satba_init_pts3d_resident", "satba_snapshot_x",
     "satba_rpc_fit", "satba_rpc_localization", "satba_rpc_refit",
@@ -116,6 +116,12 @@ def load_library(path=None):
     lib.satba_set_exchange.argtypes = [h, C.c_int64, C.c_int64, _dp]
     lib.satba_packed_schur_len.argtypes = [h]
     lib.satba_packed_schur_len.restype = C.c_int64
+    lib.satba_solve_messages.argtypes = [h, C.POINTER(C.c_int64), C.c_int32]
+    lib.satba_solve_messages.restype = C.c_int32
+    lib.satba_solve_messages_bind.argtypes = [h, C.c_void_p]
+    lib.satba_solve_messages_begin.argtypes = [h, C.c_void_p, C.c_int32]
+    lib.satba_solve_messages_arrived.argtypes = [h, C.c_void_p, C.c_int32]
+    lib.satba_solve_messages_end.argtypes = [h]
     lib.satba_pack_schur.argtypes = [h, C.c_void_p]
     lib.satba_unpack_schur.argtypes = [h, C.c_void_p]
     lib.satba_get_vector.argtypes = [h, C.c_int32, _dp]
@@ -230,7 +236,8 @@ class HipEngine:
                 self.use_stream(torch.cuda.current_stream(self.device))
         self._hdr_host = np.zeros(self.hdr)
         self._poll = np.zeros(5, dtype=np.int64)
-        self.xp = None  # packed Schur payload (header | lower triangle of S | rhs), allocated on first use
+        self.xp = None  # packed Schur payload (header | rhs | lower triangle of S), allocated on first use
+        self._messages = None  # schur_messages()
         self.len_schur_packed = int(self.lib.satba_packed_schur_len(self._h))
         self.set_x(sh.local_x(p, np.asarray(p.params_opt, dtype=np.float64)))
 
@@ -259,6 +266,33 @@ class HipEngine:
     def unpack_schur(self):
         """Copy the (all-reduced) packed payload back into the exchange buffer."""
         _check(self.lib, self.lib.satba_unpack_schur(self._h, C.c_void_p(self.xp.data_ptr())))
+
+    # -- the Schur exchange in messages, the factorisation beside it (satba_solve_messages_*; several ranks)
+    def schur_messages(self):
+        """Index ranges [(begin, end), ...] of the messages the packed payload `xp` is all-reduced in; [] when this engine solves its
+        reduced system in one piece (pack_schur / all-reduce / unpack_schur / solve)."""
+        if self._torch is None:
+            return []
+        if self._messages is None:
+            b = (C.c_int64 * 18)()
+            nm = int(self.lib.satba_solve_messages(self._h, b, 18))
+            if nm < 0:
+                raise SatbaError("satba_solve_messages failed")
+            self._messages = [(int(b[m]), int(b[m + 1])) for m in range(nm)]
+            if nm:
+                if self.xp is None:
+                    self.xp = self._torch.zeros(self.len_schur_packed, dtype=self._torch.float64, device="cuda:{}".format(self.device))
+                _check(self.lib, self.lib.satba_solve_messages_bind(self._h, C.c_void_p(self.xp.data_ptr())))
+        return self._messages
+
+    def solve_messages_begin(self, packed_already=False):
+        _check(self.lib, self.lib.satba_solve_messages_begin(self._h, C.c_void_p(self.xp.data_ptr()), 1 if packed_already else 0))
+
+    def solve_messages_arrived(self, m):
+        _check(self.lib, self.lib.satba_solve_messages_arrived(self._h, C.c_void_p(self.xp.data_ptr()), int(m)))
+
+    def solve_messages_end(self):
+        _check(self.lib, self.lib.satba_solve_messages_end(self._h))
 
     def use_torch_stream(self):
         """Launch on torch's current stream, so that the kernels order with the collectives torch.distributed queues there."""

@@ -87,6 +87,7 @@ class TorchComm:
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
         self.always = always  # issue the collectives even for a single rank (plumbing tests)
         self.pack = not os.environ.get("SATBA_NO_PACK")  # packed lower triangle for the Schur all-reduce
+        self.pipeline = self.pack and os.environ.get("SATBA_PIPELINE", "1") != "0"  # ... in messages, the factorisation beside it (solve_in_messages)
         # SATBA_ORDERED_REDUCE=1: sums in RANK ORDER, ((r0 + r1) + r2) + ..., formed by every rank from an all-gather -- the same
         # bits whatever algorithm, topology or channel count the collective library picks (a rank-ordered reduction
         # option).  world x the bytes of the all-reduce it replaces: 32 MB per rank for the packed Schur payload at 8 ranks.
@@ -114,6 +115,47 @@ class TorchComm:
         """Sum the first n doubles of the engine's exchange buffer over all ranks, in place."""
         if self.world > 1 or self.always:
             self._sum(engine.xb[:n])
+
+    def solve_in_messages(self, engine, lm_part=None):
+        """
+        The Schur exchange AND the dense solve of a front, pipelined (round 6): the packed payload is all-reduced in the few messages
+        engine.schur_messages() names -- tile columns of the reduced system from the left, the first one with header and right-hand
+        side -- while the factorisation, launched first on a stream of the engine's own, takes every tile column when its message has
+        landed (csrc: satba_solve_messages_*).  Replaces allreduce_schur + engine.solve(): same sums, same bits, but the all-reduce
+        (60 - 100 us of a 4 MB payload over xGMI at 8 ranks) and the first tile columns of the factorisation no longer wait for each
+        other.  lm_part: the device-resident loop's gated forms (engine.lm_part: parts 10 / 11 / 12).  Returns False when the engine
+        solves in one piece (the caller falls back to allreduce_schur + solve).  Every rank issues the same collectives in the same
+        order: the message table is a function of (n_cam, n_params) alone.
+        """
+        msgs = engine.schur_messages() if (self.pipeline and getattr(engine, "schur_messages", None) is not None) else []
+        if not msgs or not (self.world > 1 or self.always):
+            return False
+        # RCCL queues a collective on the stream and returns: the factorisation can be waiting on the engine's other stream while the
+        # messages are summed.  gloo (the two-process tests on one GPU) stages device tensors through the host and synchronises the
+        # DEVICE on the way -- it would wait for the waiting factorisation until that times out (measured: a one-rank gloo group fails
+        # with an arrival time-out where the one-rank RCCL group is bit-identical to the sequential front).  There the payload is packed
+        # and every message summed first, and the same protocol runs back to back behind them: same kernels, same bits, no overlap.
+        overlap = self.dist.get_backend(self.group) == "nccl" and not self.ordered
+        if not overlap:
+            engine.pack_schur()
+            for a, b in msgs:
+                self._sum(engine.xp[a:b])
+        if lm_part is None:
+            engine.solve_messages_begin(packed_already=not overlap)
+        else:
+            lm_part(10, 0.0 if overlap else 1.0)
+        for m, (a, b) in enumerate(msgs):
+            if overlap:
+                self._sum(engine.xp[a:b])
+            if lm_part is None:
+                engine.solve_messages_arrived(m)
+            else:
+                lm_part(11, float(m))
+        if lm_part is None:
+            engine.solve_messages_end()
+        else:
+            lm_part(12)
+        return True
 
     def allreduce_schur(self, engine):
         """
@@ -363,8 +405,9 @@ def drive_device_loop(engine, comm, lam_floor=0.0, max_patterns=None, watchdog_s
         engine.lm_part(1)
         comm.allreduce(engine, hdr)
         engine.lm_part(2, lam_floor)
-        comm.allreduce_schur(engine)
-        engine.lm_part(3)
+        if not (getattr(comm, "solve_in_messages", None) and comm.solve_in_messages(engine, engine.lm_part)):
+            comm.allreduce_schur(engine)
+            engine.lm_part(3)
         comm.allreduce(engine, hdr)
         engine.lm_part(4)
         comm.allreduce(engine, hdr)
@@ -490,8 +533,9 @@ def trf_solve(engine, comm=None, ftol=1e-8, xtol=1e-8, gtol=1e-8, max_nfev=None,
             engine.prepare(Delta is None)
             comm.allreduce(engine, hdr)
             engine.schur_auto(-1.0 if Delta is None else Delta, 0.0)
-            comm.allreduce_schur(engine)
-            engine.solve()
+            if not (getattr(comm, "solve_in_messages", None) and comm.solve_in_messages(engine)):
+                comm.allreduce_schur(engine)
+                engine.solve()
             h = exchange(hdr)
             # K_FX_BAD (summed over the ranks): a term of some shard's fixed-point camera sums left its range -- every rank
             # switches to the camera-major sums and repeats the iteration (include/satba.h, SATBA_HDR_FX_BAD)
@@ -541,8 +585,9 @@ def trf_solve(engine, comm=None, ftol=1e-8, xtol=1e-8, gtol=1e-8, max_nfev=None,
                 break
             reg = max(reg, 1e-16) * 100.0
             engine.schur(reg)
-            comm.allreduce_schur(engine)
-            engine.solve()
+            if not (getattr(comm, "solve_in_messages", None) and comm.solve_in_messages(engine)):
+                comm.allreduce_schur(engine)
+                engine.solve()
             h = exchange(hdr)
         else:
             raise RuntimeError("reduced camera system could not be factorised")

@@ -134,3 +134,61 @@ def test_rank_ordered_reduction_is_the_sum_in_rank_order(tmp_path):
         assert np.array_equal(got[: n - 3], want[: n - 3])      # bit for bit, on every rank
         assert np.array_equal(got[n - 3:], parts[r][n - 3:])     # beyond the prefix: untouched
         assert np.allclose(outs[r]["plain"][: n - 3], want[: n - 3], rtol=1e-12, atol=0)
+
+
+def _messages_worker(rank, world, port, out_dir):
+    import sys
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    root = os.path.dirname(here)
+    sys.path[:0] = [os.path.join(root, "sat-bundleadjust_amd"), root, here]
+    import torch
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from satba import trf
+
+    class Engine:  # what TorchComm.solve_in_messages needs of an engine: the packed payload, its message table, the three calls
+        def __init__(self):
+            self.xp = torch.arange(100, dtype=torch.float64) * (rank + 1)
+            self.log = []
+
+        def schur_messages(self):
+            return [(0, 40), (40, 65), (65, 100)]
+
+        def pack_schur(self):
+            self.log.append(("pack", self.xp.clone()))
+
+        def solve_messages_begin(self, packed_already=False):
+            self.log.append(("begin" if not packed_already else "begin-packed", self.xp.clone()))
+
+        def solve_messages_arrived(self, m):
+            self.log.append((m, self.xp.clone()))
+
+        def solve_messages_end(self):
+            self.log.append(("end", None))
+
+    comm, eng = trf.TorchComm(), Engine()
+    assert comm.solve_in_messages(eng)
+    total = torch.arange(100, dtype=torch.float64) * sum(r + 1 for r in range(world))
+    mine = torch.arange(100, dtype=torch.float64) * (rank + 1)
+    # gloo blocks the host (and, on device tensors, synchronises the device): the payload is packed and every message summed BEFORE the
+    # factorisation is launched, then the protocol runs back to back (TorchComm.solve_in_messages; RCCL: begin, then sum / arrived per message)
+    assert [e[0] for e in eng.log] == ["pack", "begin-packed", 0, 1, 2, "end"]
+    assert torch.equal(eng.log[0][1], mine)  # nothing reduced before the pack
+    assert all(torch.equal(e[1], total) for e in eng.log[1:5])  # every message summed over exactly its range: the ranges tile the payload
+    comm.pipeline = False
+    assert not comm.solve_in_messages(eng)  # the caller falls back to allreduce_schur + solve
+    np.save(os.path.join(out_dir, "ok{}.npy".format(rank)), np.ones(1))
+    dist.destroy_process_group()
+
+
+def test_schur_exchange_in_messages_order_and_sums(tmp_path):
+    """TorchComm.solve_in_messages (round 6; csrc: satba_solve_messages_*) with a stub engine on two gloo ranks: the messages are summed
+    over exactly their index ranges (they tile the payload), every one has landed on every rank when the engine is told so, and with a
+    host-blocking backend the factorisation is only launched behind them."""
+    import torch.multiprocessing as mp
+
+    mp.spawn(_messages_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    assert all(os.path.exists(os.path.join(str(tmp_path), "ok{}.npy".format(r))) for r in range(2))

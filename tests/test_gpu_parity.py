@@ -960,6 +960,11 @@ def _two_rank_worker(rank, world, port, name, loss, out_dir, backend="gloo", env
     if name == "C3":  # BASELINE shape 50 x 100 k x 1 M (rotations only, one frozen camera: a well-determined minimum)
         p = _c3_params()
         tol = dict(ftol=1e-12, xtol=1e-12, gtol=1e-12, max_nfev=40)
+    elif name == "M30":  # 30 cameras x (R, T): 150 camera unknowns, three tile columns -- the smallest shape whose Schur exchange goes in messages
+        from satba import synth as sy
+
+        p = sy.make_params(sy.make_scene("affine", 30, 4000, 6, seed=11), {"correction_params": ["R", "T"], "n_cam_fix": 1})
+        tol = dict(ftol=1e-12, xtol=1e-12, gtol=1e-12, max_nfev=30)
     else:
         _, make_p, _, _ = cs.solve_case(name)
         p = make_p()
@@ -1008,6 +1013,78 @@ def test_two_ranks_on_one_gpu(gpu, tmp_path, name, loss, loop):
     assert np.linalg.norm(outs[0]["r"] - g["tight_fun_" + loss]) < 5e-6 * np.linalg.norm(g["tight_fun_" + loss])
     st = g["tight_stats_" + loss]
     assert abs(float(outs[0]["cost"]) - st[0]) < 1e-9 * st[0]
+
+
+@pytest.mark.parametrize("loop", ["device", "host"])
+@pytest.mark.parametrize("loss", ["linear", "soft_l1"])
+def test_two_ranks_exchange_in_messages_is_the_sequential_front(gpu, tmp_path, loss, loop):
+    """
+    Round 6, several ranks: the all-reduce of the reduced camera system in messages with the factorisation beside it
+    (TorchComm.solve_in_messages, satba_solve_messages_*) against the sequential front (SATBA_PIPELINE=0: one all-reduce of the packed
+    payload, then satba_solve) -- two processes on this GPU, gloo.  Same sums and the same arithmetic in the same order: the solutions
+    are equal bit for bit, on both ranks, in the device-resident loop (parts 10 / 11 / 12) and in the host loop.
+    """
+    import torch.multiprocessing as mp
+
+    outs = {}
+    for mode in ("messages", "sequential"):
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        env = {"SATBA_PIPELINE": "1" if mode == "messages" else "0", "SATBA_PIPELINE_TIMEOUT_MS": "20000"}
+        if loop == "host":
+            env["SATBA_HOST_LOOP"] = "1"
+        d = tmp_path / mode
+        d.mkdir()
+        mp.spawn(_two_rank_worker, args=(2, port, "M30", loss, str(d), "gloo", env), nprocs=2, join=True)
+        outs[mode] = [np.load(os.path.join(str(d), "rank{}.npz".format(r))) for r in range(2)]
+    a, b = outs["messages"], outs["sequential"]
+    assert np.array_equal(a[0]["x"], a[1]["x"]) and np.array_equal(a[0]["x"], b[0]["x"]) and np.array_equal(a[0]["r"], b[0]["r"])
+    assert int(a[0]["nfev"]) == int(b[0]["nfev"]) and float(a[0]["cost"]) == float(b[0]["cost"]) and int(a[0]["nfev"]) > 2
+    assert (int(a[0]["ticks"]) > 0) == (loop == "device")
+
+
+def test_exchange_in_messages_over_rccl_single_rank(gpu):
+    """The same with RCCL's asynchronous collectives (a one-rank group: every message is a real ncclAllReduce queued on torch's stream
+    between the unpack / release kernels, the factorisation waiting on the handle's other stream): 40 cameras x (R, T) = 200 unknowns,
+    solution bit-identical to the sequential front, both loops."""
+    import torch
+    import torch.distributed as dist
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        scene = synth.make_scene("affine", 40, 6000, 6, seed=12)
+        xs = {}
+        for host_loop in (False, True):
+            for pipeline in (True, False):
+                p = synth.make_params(scene, {"correction_params": ["R", "T"], "n_cam_fix": 1})
+                comm = trf.TorchComm(always=True)
+                comm.pipeline = pipeline
+                eng = HipEngine(p)
+                if pipeline:
+                    msgs = eng.schur_messages()
+                    assert len(msgs) >= 2 and msgs[0][0] == 0 and msgs[-1][1] == eng.len_schur_packed
+                    assert all(msgs[i][1] == msgs[i + 1][0] for i in range(len(msgs) - 1))
+                if host_loop:
+                    os.environ["SATBA_HOST_LOOP"] = "1"
+                try:
+                    res = trf.trf_solve(eng, comm, ftol=1e-12, xtol=1e-12, gtol=1e-12, max_nfev=30)
+                finally:
+                    os.environ.pop("SATBA_HOST_LOOP", None)
+                assert res.nfev > 2 and eng.read_header()[trf.CHOL_FAIL] == 0
+                xs[(host_loop, pipeline)] = (eng.get_x(), res.cost, res.nfev)
+                eng.close()
+        for host_loop in (False, True):
+            (xa, ca, na), (xb, cb, nb) = xs[(host_loop, True)], xs[(host_loop, False)]
+            assert np.array_equal(xa, xb) and ca == cb and na == nb
+    finally:
+        dist.destroy_process_group()
 
 
 def test_two_ranks_fixed_point_overflow_switches_every_rank(gpu, tmp_path):
