@@ -88,6 +88,7 @@ class TorchComm:
         self.always = always  # issue the collectives even for a single rank (plumbing tests)
         self.pack = not os.environ.get("SATBA_NO_PACK")  # packed lower triangle for the Schur all-reduce
         self.pipeline = self.pack and os.environ.get("SATBA_PIPELINE", "1") != "0"  # ... in messages, the factorisation beside it (solve_in_messages)
+        self.pipeline_min = int(os.environ.get("SATBA_PIPELINE_MIN", str(500 * 501 // 2)))  # ... from this packed length on (~500 camera unknowns)
         # SATBA_ORDERED_REDUCE=1: sums in RANK ORDER, ((r0 + r1) + r2) + ..., formed by every rank from an all-gather -- the same
         # bits whatever algorithm, topology or channel count the collective library picks (a rank-ordered reduction
         # option).  world x the bytes of the all-reduce it replaces: 32 MB per rank for the packed Schur payload at 8 ranks.
@@ -116,34 +117,47 @@ class TorchComm:
         if self.world > 1 or self.always:
             self._sum(engine.xb[:n])
 
+    def _messages(self, engine):
+        if not (self.pipeline and (self.world > 1 or self.always) and getattr(engine, "schur_messages", None) is not None):
+            return []
+        msgs = engine.schur_messages()
+        # below ~500 camera unknowns the protocol costs more than the overlap can return (one rank, zero network latency, ms per front:
+        # 50 cameras x 5 0.369 against 0.309, 200 x 5 1.287 against 1.247 with the launch behind the Schur phase -- profiles/r6_messages.txt)
+        return msgs if (msgs and msgs[-1][1] >= self.pipeline_min) else []
+
+    def messages_overlap(self):
+        """RCCL queues a collective on the stream and returns: the factorisation can be waiting on the engine's other stream while the
+        messages are summed.  gloo (the two-process tests on one GPU) stages device tensors through the host and synchronises the
+        DEVICE on the way -- it would wait for the waiting factorisation until that times out (measured: a one-rank gloo group fails
+        with an arrival time-out where the one-rank RCCL group is bit-identical to the sequential front)."""
+        return self.dist.get_backend(self.group) == "nccl" and not self.ordered
+
     def solve_in_messages(self, engine, lm_part=None):
         """
         The Schur exchange AND the dense solve of a front, pipelined (round 6): the packed payload is all-reduced in the few messages
         engine.schur_messages() names -- tile columns of the reduced system from the left, the first one with header and right-hand
         side -- while the factorisation, launched first on a stream of the engine's own, takes every tile column when its message has
-        landed (csrc: satba_solve_messages_*).  Replaces allreduce_schur + engine.solve(): same sums, same bits, but the all-reduce
-        (60 - 100 us of a 4 MB payload over xGMI at 8 ranks) and the first tile columns of the factorisation no longer wait for each
-        other.  lm_part: the device-resident loop's gated forms (engine.lm_part: parts 10 / 11 / 12).  Returns False when the engine
-        solves in one piece (the caller falls back to allreduce_schur + solve).  Every rank issues the same collectives in the same
-        order: the message table is a function of (n_cam, n_params) alone.
+        landed (csrc: satba_solve_messages_*).  (Launching it even earlier, in front of the Schur kernels as on one rank, was measured and
+        dropped: the 64 CUs it holds cost the Schur phase more than the ~25 us of start-up it hides -- profiles/r6_messages.txt.)  Replaces allreduce_schur + engine.solve(): same sums, same
+        bits, but the all-reduce (60 - 100 us of a 4 MB payload over xGMI at 8 ranks) and the first tile columns of the factorisation
+        no longer wait for each other.  lm_part: the device-resident loop's gated forms (engine.lm_part: parts 10 / 11 / 12).  Returns
+        False when the engine solves in one piece (the caller falls back to allreduce_schur + solve).  Every rank issues the same
+        collectives in the same order: the message table is a function of (n_cam, n_params) alone.  With a host-blocking backend
+        (messages_overlap) the payload is packed and every message summed first, and the same protocol runs back to back behind them:
+        same kernels, same bits, no overlap.
         """
-        msgs = engine.schur_messages() if (self.pipeline and getattr(engine, "schur_messages", None) is not None) else []
-        if not msgs or not (self.world > 1 or self.always):
+        msgs = self._messages(engine)
+        if not msgs:
             return False
-        # RCCL queues a collective on the stream and returns: the factorisation can be waiting on the engine's other stream while the
-        # messages are summed.  gloo (the two-process tests on one GPU) stages device tensors through the host and synchronises the
-        # DEVICE on the way -- it would wait for the waiting factorisation until that times out (measured: a one-rank gloo group fails
-        # with an arrival time-out where the one-rank RCCL group is bit-identical to the sequential front).  There the payload is packed
-        # and every message summed first, and the same protocol runs back to back behind them: same kernels, same bits, no overlap.
-        overlap = self.dist.get_backend(self.group) == "nccl" and not self.ordered
+        overlap = self.messages_overlap()
+        engine.pack_schur()
         if not overlap:
-            engine.pack_schur()
             for a, b in msgs:
                 self._sum(engine.xp[a:b])
         if lm_part is None:
-            engine.solve_messages_begin(packed_already=not overlap)
+            engine.solve_messages_begin(packed_already=True)
         else:
-            lm_part(10, 0.0 if overlap else 1.0)
+            lm_part(10, 1.0)
         for m, (a, b) in enumerate(msgs):
             if overlap:
                 self._sum(engine.xp[a:b])

@@ -18,7 +18,9 @@ comm = tr.TorchComm(always=True)
 eng = Eng(p); eng.use_torch_stream(); eng.configure("linear", 1.0)
 out = {}
 for mode in ("sequential", "messages"):
-    eng.linearize(); comm.allreduce(eng, eng.len_lin); eng.prepare(True); comm.allreduce(eng, eng.hdr); eng.schur_auto(-1.0, 0.0)
+    comm.pipeline, comm.pipeline_min = mode == "messages", 0
+    eng.linearize(); comm.allreduce(eng, eng.len_lin); eng.prepare(True); comm.allreduce(eng, eng.hdr)
+    eng.schur_auto(-1.0, 0.0)
     if mode == "sequential":
         comm.allreduce_schur(eng); eng.solve()
     else:
@@ -27,4 +29,27 @@ for mode in ("sequential", "messages"):
     out[mode] = (eng.get_vector("gn_h")[: eng.n_c].copy(), eng.read_header().copy())
 d = np.abs(out["sequential"][0] - out["messages"][0])
 print(backend, "world 1: max |d dc|", d.max(), "of", np.abs(out["sequential"][0]).max(), "fail", out["messages"][1][tr.CHOL_FAIL], flush=True)
-eng.close(); dist.destroy_process_group()
+eng.close()
+if len(sys.argv) > 2:  # timing at a benchmark shape (argv[2]: C3, C4, ...): ms per front, HIP events, both exchanges -- zero network latency (one rank)
+    model, corr, n_cam, n_pts, opp = sy.CONFIGS[sys.argv[2]]
+    p = sy.make_params(sy.make_scene(model, n_cam, n_pts, opp, seed=1, sigma_theta=1e-4), {"correction_params": corr, "n_cam_fix": 1})
+    eng = Eng(p); eng.use_torch_stream(); eng.configure("linear", 1.0)
+    for mode in ("sequential", "messages", "sequential", "messages"):
+        comm.pipeline, comm.pipeline_min = mode == "messages", 0
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        t_front, t_solve = 0.0, 0.0
+        reps = 30
+        for it in range(reps + 3):
+            ev[0].record()
+            eng.linearize(); comm.allreduce(eng, eng.len_lin); eng.prepare(it == 0); comm.allreduce(eng, eng.hdr)
+            eng.schur_auto(-1.0, 1e-14)
+            ev[1].record()
+            if not comm.solve_in_messages(eng):
+                comm.allreduce_schur(eng); eng.solve()
+            ev[2].record()
+            torch.cuda.synchronize()
+            if it >= 3:
+                t_front += ev[0].elapsed_time(ev[2]); t_solve += ev[1].elapsed_time(ev[2])
+        print(sys.argv[2], mode, "ms per front %.4f, of it exchange + solve phase %.4f" % (t_front / reps, t_solve / reps), "fail", eng.read_header()[tr.CHOL_FAIL], flush=True)
+    eng.close()
+dist.destroy_process_group()
