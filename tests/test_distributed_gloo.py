@@ -170,6 +170,7 @@ def _messages_worker(rank, world, port, out_dir):
             self.log.append(("end", None))
 
     comm, eng = trf.TorchComm(), Engine()
+    comm.pipeline_min = 0  # (the product only cuts payloads of ~500 camera unknowns and more into messages)
     assert comm.solve_in_messages(eng)
     total = torch.arange(100, dtype=torch.float64) * sum(r + 1 for r in range(world))
     mine = torch.arange(100, dtype=torch.float64) * (rank + 1)
