@@ -186,7 +186,9 @@ def cpu_baseline(scene, n_pts_sample, corr, full_c3=False):
                           "of the benchmarked scene: {:.1f} s, scaled linearly to {} obs (a lower bound on the CPU time: LSMR "
                           "iterations grow with the problem); the scipy path uses one of the host's {} cores; full C2 solve "
                           "{:.1f} s / nfev {}".format(n_pts_sample, p.n_obs, dt, full, os.cpu_count(), t2, int(r2.nfev))})
-    c3_path = os.path.join(ROOT, "profiles", "r2_cpu_baseline_C3.json")
+    import glob
+    c3_files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_cpu_baseline_C3.json")), key=lambda f: int(os.path.basename(f)[1:].split("_")[0]))
+    c3_path = c3_files[-1] if c3_files else os.path.join(ROOT, "profiles", "r2_cpu_baseline_C3.json")  # the latest round's measured run
     if full_c3:
         model, c3corr, n_cam, n_pts, opp = synth.CONFIGS["C3"]
         sc3 = synth.make_scene(model, n_cam, n_pts, opp, seed=1, sigma_theta=1e-4)
@@ -199,13 +201,13 @@ def cpu_baseline(scene, n_pts_sample, corr, full_c3=False):
         out["C3_measured"] = c3
         try:
             os.makedirs(os.path.dirname(c3_path), exist_ok=True)
-            with open(os.path.join(ROOT, "gpurun_out", "r2_cpu_baseline_C3.json"), "w") as fh:
+            with open(os.path.join(ROOT, "gpurun_out", "cpu_baseline_C3.json"), "w") as fh:  # (copied to profiles/rN_cpu_baseline_C3.json by hand)
                 json.dump(c3, fh)
         except OSError:
             pass
     elif os.path.exists(c3_path):
         with open(c3_path) as fh:
-            out["C3_measured"] = dict(json.load(fh), quoted_from="profiles/r2_cpu_baseline_C3.json (taken with --cpu-c3 on an MI355X box's host)")
+            out["C3_measured"] = dict(json.load(fh), quoted_from="profiles/" + os.path.basename(c3_path) + " (taken with --cpu-c3 on an MI355X box's host)")
     if "C3_measured" in out and full > 0:
         c3 = out["C3_measured"]
         out["C4_extrapolated_from_C3"] = {"lm_iters_per_sec": c3["lm_iters_per_sec"] * c3["n_obs"] / full,

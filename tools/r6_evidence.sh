@@ -17,4 +17,5 @@ bash tools/gpu.sh $tag pmc C4 linear k_linearize > /dev/null; cp $out/pmc_summar
 bash tools/chol/run_stamps.sh $tag
 for s in C2 C3 C5 C4; do timeout 300 python tools/e2e_time.py $s > $out/e2e_$s.json 2>/dev/null; done
 timeout 300 python tools/e2e_time.py C4 soft_l1 > $out/e2e_C4_soft_l1.json 2>/dev/null
+timeout 1500 python bench.py --steps 20 --warmup 5 --cpu-c3 > $out/bench_cpu_c3.json 2> $out/bench_cpu_c3.err; cp gpurun_out/cpu_baseline_C3.json $out/ 2>/dev/null
 ls $out; head -30 $out/kernel_stats_C4.txt; cat $out/timeline_C4.txt; head -22 $out/kernel_stats_C2.txt; cat $out/pmc_loop_C4.txt
