@@ -446,10 +446,13 @@ def main():
         comp_bytes = compulsory_bytes(K_loc, N_loc, model, p.n_params, args.loss, bool(info["unit_weights"]), driver.startswith("native"))
         rate_as_built = comp_bytes / t_lin / 1e9
         rate_counter = (traffic / t_lin / 1e9) if traffic else None
-        # what bounds the kernel: it moves `compulsory_bytes_as_built` (the counters agree to a few %), and when that rate is below
-        # half the HBM peak the memory system is not the limit -- the LDS pipe is (fixed-point atomics and gathers of the per-camera
-        # tables on random rows, profiles/r3_pmc_kernels_*.txt)
-        bound = "hbm" if (rate_counter if rate_counter is not None else rate_as_built) >= 0.5 * HBM_PEAK_GBPS else "lds"
+        # `bound`: the roofline the kernel is priced against -- HBM (it streams observations; no matrix-core work).  `limiter`: what
+        # actually holds it below that roof.  The kernel moves `compulsory_bytes_as_built` (the counters agree to a few %); when that
+        # rate is below half the HBM peak the memory system is not the limit: round 6 measured the floor (profiles/r6_linearize_floor.txt:
+        # LDS atomics compiled out -3 %, all camera-sum work out -19 %, deeper prefetch nothing) -- vector issue at four waves per SIMD
+        # with the LDS pipe beside it.  (Rounds 3-5 wrote "lds" into `bound`.)
+        bound = "hbm"
+        limiter = "hbm" if (rate_counter if rate_counter is not None else rate_as_built) >= 0.5 * HBM_PEAK_GBPS else "vector issue + LDS pipe at 4 waves/SIMD"
         out = {
             "metric": "LM iters/sec at 200 cams x 1M pts x 10M obs (affine, R+T)" if args.shape == "C4" else
                       "LM iters/sec, config {}".format(args.shape),
@@ -475,7 +478,7 @@ def main():
             # achieved / frac: SURVEY 8d's algorithmic bytes (48 K + 96 N: a throughput-equivalent, the kernel no longer moves all
             # of them); *_as_built: the bytes this kernel has to move; achieved_counter: the bytes the PMC counters saw it move
             # (bound and the as-built fraction first: `frac` is the throughput equivalent and must not be read without them)
-            "roofline": {"bound": bound, "frac_as_built": rate_as_built / HBM_PEAK_GBPS,
+            "roofline": {"bound": bound, "limiter": limiter, "frac_as_built": rate_as_built / HBM_PEAK_GBPS,
                          "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "achieved_counter": rate_counter,
