@@ -40,7 +40,7 @@ HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is
 # PMC counters cannot be read from inside an unprofiled run, so the committed measurement is quoted for the (shape, loss) --
 # i.e. the kernel instantiation -- it was taken on (one GPU), and the field is null otherwise.
 def profiled_traffic(shape, loss, world):
-    path = os.path.join(ROOT, "profiles", "r5_pmc_hbm_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r6_pmc_hbm_traffic.json")
     if world != 1 or not os.path.exists(path):
         return None
     with open(path) as fh:

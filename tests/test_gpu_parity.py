@@ -228,7 +228,8 @@ def test_fixed_cameras_points_and_weights(gpu, model, corr, ref_w, loss):
 
 
 def test_packed_schur_exchange(gpu):
-    """The packed form of the Schur payload (what multi-rank runs all-reduce): header | lower triangle | rhs, and back."""
+    """The packed form of the Schur payload (what multi-rank runs all-reduce): header | rhs | lower triangle by columns (round 6: the
+    right-hand side in front, so that the first message of the exchange in messages carries it), and back."""
     _, p, g = cases.fun_case("affine_RT")
     dev = HipEngine(p)
     dev.configure("linear", 1.0)
@@ -239,7 +240,7 @@ def test_packed_schur_exchange(gpu):
     S = full[hdr: hdr + n_c * n_c].reshape(n_c, n_c)  # S[j, r]: column j of the column-major matrix
     xp = dev.pack_schur().cpu().numpy()
     assert xp.size == hdr + n_c * (n_c + 1) // 2 + n_c == dev.len_schur_packed
-    expect = np.concatenate([full[:hdr]] + [S[j, j:] for j in range(n_c)] + [full[hdr + n_c * n_c:]])
+    expect = np.concatenate([full[:hdr], full[hdr + n_c * n_c:]] + [S[j, j:] for j in range(n_c)])
     assert np.array_equal(xp, expect)
     dev.xp.mul_(2.0)  # what a two-rank all-reduce of identical shards would leave
     dev.unpack_schur()
