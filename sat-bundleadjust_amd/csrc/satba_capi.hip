@@ -162,6 +162,7 @@ struct satba_problem {
     int* d_dg_cnt = nullptr;   // ... and diagonal items finished per camera (SchurArgs::dg_cnt)
     long long* d_ts = nullptr; // (tools, -DC3_STAMPS: time stamps of the last factorisation beside the pair kernel, printed when the handle goes)
     int arrive_epoch = 0;      // != 0 while a front with the factorisation beside it is being queued (launch_schur)
+    bool decide2_fused = false;  // the launch of the trial that is being queued carries the loop's second decision (launch_trial)
     int msg_epoch = 0;         // != 0 between satba_solve_messages_begin and _end: the epoch its factorisation waits for
     double* msg_packed = nullptr;  // the caller's packed payload of that exchange (device-resident loop: parts 10 - 12)
     bool beside_last = false;  // the last front ran that way
@@ -360,7 +361,8 @@ static int launch_trial(satba_problem* p, double c0, double c1, const double* v0
     a.sh = slice_split(p);
     const int grid = slice_grid(p, RES_THREADS / 64, 2, a.sh);
     const size_t lds = table_bytes(p);
-    const TrialArgs t{p->d_x, v0, v1, p->d_scale_inv, p->d_xnew, c0, c1, p->lead, p->d_xb + 2, p->d_xb + 3, p->d_fxcost_new, p->coef_dev};
+    TrialArgs t{p->d_x, v0, v1, p->d_scale_inv, p->d_xnew, c0, c1, p->lead, p->d_xb + 2, p->d_xb + 3, p->d_fxcost_new, p->coef_dev};
+    if (p->decide2_fused) { t.lm_st = p->d_lm; t.lm_sum = p->h_lm_dev; }  // (lm_launch_tail: one rank, device-resident loop)
     p->fxcost_new_valid = true;
     double* cost = p->d_xb + 1;
     if (p->loss == 0 && p->unit_weights)
@@ -1985,8 +1987,13 @@ struct LmArgsScope {  // while a pattern is being queued the launchers read the 
 static int lm_launch_tail(satba_problem* p) {  // trial evaluation, decision, accepted point (or the kept one) into place
     LmDev* st = p->d_lm;
     p->gate = &st->run_trial;
-    TRY(satba_trial_gn(p, 0.0, 0.0));
-    hipLaunchKernelGGL(k_lm_decide2, dim3(1), dim3(1), 0, p->stream, st, p->d_xb, p->h_lm_dev);
+    // the second decision rides in the trial's residual kernel (TrialArgs::lm_st; SATBA_DECIDE2_FUSED=0: the launch of its own)
+    static const bool fuse2 = !(getenv("SATBA_DECIDE2_FUSED") && atoi(getenv("SATBA_DECIDE2_FUSED")) == 0);
+    p->decide2_fused = fuse2;
+    const int rc_trial = satba_trial_gn(p, 0.0, 0.0);
+    p->decide2_fused = false;
+    TRY(rc_trial);
+    if (!fuse2) hipLaunchKernelGGL(k_lm_decide2, dim3(1), dim3(1), 0, p->stream, st, p->d_xb, p->h_lm_dev);
     const double* x0 = p->d_x0;
     hipLaunchKernelGGL(k_lm_accept, dim3(grid_for(p->n / 2 + 1, 256, 1024)), dim3(256), 0, p->stream, st, (long long)p->n, p->d_x, p->d_xnew,
                        p->M * CAMC, p->d_camc, p->d_camc_new, p->d_fxcost, p->d_fxcost_new, x0, x0 ? x0 + p->n + 6 : nullptr, p->d_fxcost0, p->d_bbox);

@@ -269,8 +269,10 @@ __device__ inline double wave_max(double v) {
 // the last bits run-dependent in round 1), and same-address atomics (~12 ns each on gfx950) are down to one per workgroup.
 // Hand-off: sc1 (write-through) stores, vmcnt(0), agent-scope counter; the reader uses sc1 loads (MI355X_MICROARCH.md,
 // inter-workgroup visibility).  rb.part holds NV x gridDim.x doubles.
+// Returns true in the LAST workgroup (the one that formed the totals), false in every other one -- for a tail that may only run when the
+// whole grid is through (k_residual<..., TRIAL>: the loop's second decision).
 template <int NV>
-__device__ inline void grid_sum(double (&v)[NV], double* const (&dst)[NV], const RedBuf& rb) {
+__device__ inline bool grid_sum(double (&v)[NV], double* const (&dst)[NV], const RedBuf& rb) {
     __shared__ double s_part[NV][16];
     __shared__ int s_last;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
@@ -292,7 +294,7 @@ __device__ inline void grid_sum(double (&v)[NV], double* const (&dst)[NV], const
         s_last = (old == gridDim.x - 1) ? 1 : 0;
     }
     __syncthreads();
-    if (!s_last) return;
+    if (!s_last) return false;
     // the last workgroup: thread t adds the partials t, t + T, t + 2 T, ... (a fixed assignment, whatever the arrival order was),
     // then the same shuffle / LDS tree as above.  One thread adding all of them took ~0.12 us per workgroup of the grid.
 #pragma unroll
@@ -311,6 +313,7 @@ __device__ inline void grid_sum(double (&v)[NV], double* const (&dst)[NV], const
         *dst[threadIdx.x] = t;
     }
     if (threadIdx.x == 0) __hip_atomic_store(rb.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return true;
 }
 
 __device__ inline void atomic_max_pos(double* addr, double v) {  // v >= 0; a maximum does not depend on the order
@@ -439,10 +442,21 @@ struct TrialArgs {
     double* xx;
     double* cost2;                         // second copy of this shard's cost (bound of the fixed-point camera sums at x_new)
     const double* coef;                    // device-resident loop: c0, c1 are read from here (two doubles) instead of the arguments
+    // device-resident loop on one rank (round 6): the loop's second decision (k_lm_decide2: radius update, accept / reject, termination,
+    // report to the host) rides in this launch -- thread 0 of the LAST workgroup, on the totals it has just formed; a launch that is
+    // gated off takes it in workgroup 0.  One dependent launch less per tick (4.7 - 5.9 us; 4 % of a 10 x 5 k x 30 k iteration).
+    struct LmDev* lm_st = nullptr;
+    struct LmSummary* lm_sum = nullptr;
 };
+__device__ void lm_decide2_body(struct LmDev* gst, double cost_new, double step_sq, double x_sq, struct LmSummary* sum);  // satba_lmdev.h
 template <int MODEL, int NP, bool CL, bool RL, bool UNITW = false, bool TRIAL = false>
 __global__ __launch_bounds__(RES_THREADS) void k_residual(ObsArgs a, double2* __restrict__ f, RedBuf rb, double* __restrict__ cost, TrialArgs t) {
-    SATBA_GATE(a.gate);
+    if (a.gate != nullptr && *a.gate == 0) {  // (SATBA_GATE)
+        if constexpr (TRIAL) {
+            if (t.lm_st && blockIdx.x == 0 && threadIdx.x == 0) lm_decide2_body(t.lm_st, 0.0, 0.0, 0.0, t.lm_sum);  // (no trial: the values are not read)
+        }
+        return;
+    }
     if constexpr (TRIAL) { if (t.coef) { t.c0 = t.coef[0]; t.c1 = t.coef[1]; } }
     extern __shared__ double s_dyn_res[];
     CamTables<CL, RL> T;
@@ -499,7 +513,13 @@ __global__ __launch_bounds__(RES_THREADS) void k_residual(ObsArgs a, double2* __
     if constexpr (TRIAL) {
         double v[4] = {0.5 * acc, ss, xx, 0.5 * acc};
         double* const dst[4] = {cost, t.ss, t.xx, t.cost2};
-        grid_sum<4>(v, dst, rb);
+        const bool last = grid_sum<4>(v, dst, rb);
+        if (t.lm_st && last) {
+            __syncthreads();  // the totals are in place (threads 0 .. 3 of this workgroup stored them)
+            if (threadIdx.x == 0)
+                lm_decide2_body(t.lm_st, __hip_atomic_load(cost, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __hip_atomic_load(t.ss, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                                __hip_atomic_load(t.xx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), t.lm_sum);
+        }
     } else {
         double v[1] = {0.5 * acc};
         double* const dst[1] = {cost};

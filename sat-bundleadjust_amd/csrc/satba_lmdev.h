@@ -269,15 +269,16 @@ __global__ void k_lm_decide1c(LmDev* __restrict__ st, const double* __restrict__
 }
 
 // After the trial evaluation: radius update, accept / reject, termination (trf.py:497-534), and what the next tick does.
-__global__ void k_lm_decide2(LmDev* __restrict__ gst, const double* __restrict__ h, LmSummary* __restrict__ sum) {
+// (one thread; cost_new, step_sq, x_sq: the trial header's totals -- not read when no trial ran.  A function of its own: it rides in the
+// trial's residual kernel on one rank, TrialArgs::lm_st, and must not take part in that kernel's register allocation)
+__device__ __noinline__ void lm_decide2_body(LmDev* gst, double cost_new_in, double step_sq, double x_sq, LmSummary* sum) {
 #pragma clang fp contract(off)
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
     LmDev local = *gst;
     LmDev* st = &local;
     struct WriteBack { LmDev* g; LmDev* l; __device__ ~WriteBack() { *g = *l; } } wb{gst, st};
     if (st->phase != LM_RUN) { st->accept = 0; st->restore = 0; }  // a tick queued behind the end of the loop (or behind a pause)
     if (st->phase == LM_RUN && st->run_trial) {
-        const double cost_new = h[LMH_COST_NEW];
+        const double cost_new = cost_new_in;
         st->cost_new = cost_new;
         st->nfev += 1;
         bool end_inner = false;  // leave scipy's inner loop (while actual_reduction <= 0 and nfev < max_nfev)
@@ -289,8 +290,8 @@ __global__ void k_lm_decide2(LmDev* __restrict__ gst, const double* __restrict__
             double ratio;
             const double Delta_new = satba_lm::update_tr_radius(st->Delta, actual, st->predicted, st->step_h_norm,
                                                                 st->step_h_norm > 0.95 * st->Delta, ratio);
-            st->step_norm = sqrt(h[LMH_STEP_SQ]);
-            const int term = st->never_stop ? 0 : satba_lm::check_termination(actual, st->cost, st->step_norm, sqrt(h[LMH_X_SQ]), ratio, st->ftol, st->xtol);
+            st->step_norm = sqrt(step_sq);
+            const int term = st->never_stop ? 0 : satba_lm::check_termination(actual, st->cost, st->step_norm, sqrt(x_sq), ratio, st->ftol, st->xtol);
             if (term) { st->status = term; end_inner = true; }
             else st->Delta = Delta_new;
         }
@@ -333,6 +334,11 @@ __global__ void k_lm_decide2(LmDev* __restrict__ gst, const double* __restrict__
     __hip_atomic_store(&sum->end_tick, stamp | ((unsigned long long)st->end_tick & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __hip_atomic_store(&sum->sub_requests, stamp | ((unsigned long long)st->sub_requests & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __hip_atomic_store(&sum->word, ((unsigned long long)st->tick << 8) | (unsigned long long)st->phase, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+__global__ void k_lm_decide2(LmDev* __restrict__ gst, const double* __restrict__ h, LmSummary* __restrict__ sum) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    lm_decide2_body(gst, h[LMH_COST_NEW], h[LMH_STEP_SQ], h[LMH_X_SQ], sum);
 }
 
 // After LM_HOST_BESIDE the host has switched the handle to sequential fronts (and waited for the stream: nothing else touches the
