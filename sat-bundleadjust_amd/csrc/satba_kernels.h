@@ -38,7 +38,8 @@ constexpr int FX_LO_SHIFT = 40;  // the low limb of a g_c term holds its remaind
 // per term; the low limb is not: a term is at most 2^(FX_LO_SHIFT - 1) there, so its sum stays inside 63 bits for fewer than
 // 2^(63 - 39) = 2^24 observations of one camera.  Problems above this bound (with a factor 2 to spare) take the camera-major sums.
 constexpr long long FX_MAX_OBS_PER_CAM = 1ll << 23;
-__host__ __device__ constexpr size_t cam_sum_bytes(int np, size_t rows) { return rows * cam_sum_stride(np) * 8; }
+// (a multiple of 16 bytes: the camera-constant rows behind the table are read with ds_read_b128)
+__host__ __device__ constexpr size_t cam_sum_bytes(int np, size_t rows) { return (rows * cam_sum_stride(np) * 8 + 15) & ~(size_t)15; }
 
 constexpr int RPCS = 91;  // row stride of the LDS copy of the RPC tables (90 used, odd)
 // double -> 64-bit fixed point through one fma (k_linearize's camera sums): bits(t 2^e + 1.5 * 2^52) = FX_MAGIC_BITS + round(t 2^e)
@@ -248,7 +249,8 @@ struct CamTables {
         }
         if constexpr (CL || RL) __syncthreads();
     }
-    __device__ inline const double* cc(int cam) const { return cbase + (size_t)cam * CAMC; }
+    // (rows are 16-byte aligned in the LDS and in global memory: the pairs of a row are read as ds_read_b128 / global_load_dwordx4)
+    __device__ inline const double* cc(int cam) const { return static_cast<const double*>(__builtin_assume_aligned(cbase + (size_t)cam * CAMC, 16)); }
     __device__ inline const double* tab(int cam) const { return rbase + (size_t)cam * rstride; }  // only dereferenced for RPC
 };
 
@@ -458,7 +460,7 @@ __global__ __launch_bounds__(RES_THREADS) void k_residual(ObsArgs a, double2* __
         return;
     }
     if constexpr (TRIAL) { if (t.coef) { t.c0 = t.coef[0]; t.c1 = t.coef[1]; } }
-    extern __shared__ double s_dyn_res[];
+    extern __shared__ __attribute__((aligned(16))) double s_dyn_res[];
     CamTables<CL, RL> T;
     T.stage(a, s_dyn_res, RES_THREADS);
     const int lane = threadIdx.x & 63;
@@ -585,7 +587,7 @@ __global__ __launch_bounds__(LinCfg<(ROBUST && !SOFT) || MODEL == RPC>::THREADS)
     constexpr int CUS = cam_sum_stride(NP);
     using Cfg = LinCfg<(ROBUST && !SOFT) || MODEL == RPC>;
     constexpr int THREADS = Cfg::THREADS, WAVES = Cfg::WAVES;
-    extern __shared__ double s_lin[];
+    extern __shared__ __attribute__((aligned(16))) double s_lin[];
     unsigned long long* s_acc = reinterpret_cast<unsigned long long*>(s_lin);
     // With few cameras the 64 lanes of an atomic hit the same few addresses and serialise (10 cameras: 58 of the kernel's 75 us
     // at 10 x 5 k x 30 k): the table is replicated 2^rep_shift times, a lane adds to replica (lane mod replicas), the flush
@@ -786,7 +788,7 @@ __global__ __launch_bounds__(1024) void k_lin_finish(int M, int NP, int nblocks,
     }
     if (const_t && k >= 3) {  // lin_const_t: translation entries of diag(U_c) in closed form
         const double* cc = camc + (size_t)cam * CAMC;
-        const double fxx = cc[17], fy = cc[18], sk = cc[19];
+        const double fxx = cc[CAMX + 2], fy = cc[CAMX + 3], sk = cc[CAMX + 4];
         const double cnt = cam >= n_cam_fix ? (double)(cam_ofs[cam + 1] - cam_ofs[cam]) : 0.0;
         v = cnt * (k == 3 ? fxx * fxx : sk * sk + fy * fy);
     }
@@ -1091,22 +1093,34 @@ __global__ __launch_bounds__(256) void k_prepare_vec(int n, int n_c, int NP, int
 }
 
 // ------------------------------------------------------------------------------------------------ Jacobian-vector products
-constexpr int JVP_ROW = 15;  // per-camera constants of the affine form of k_jvp / k_backsub: B (6) | b (2) | A (6), odd stride
+// per-camera constants of the affine form of k_jvp / k_backsub: B (6) | b (2) | A (6) -- seven 16-byte slots, read as seven ds_read_b128
+// (DirRow).  Round 6: with an odd stride of 15 doubles the fourteen reads were ds_read2_b64 pairs (128 B / clk, banks modulo 32).
+constexpr int JVP_ROW = 14;
+struct DirRow {
+    double v[14];
+    __device__ inline void load(const double* __restrict__ tab, int cam) {
+        const double2* r = static_cast<const double2*>(__builtin_assume_aligned(tab + (size_t)cam * JVP_ROW, 16));
+#pragma unroll
+        for (int m = 0; m < 7; ++m) { const double2 t = r[m]; v[2 * m] = t.x; v[2 * m + 1] = t.y; }
+    }
+};
 #ifndef SATBA_JVP_THREADS
 #define SATBA_JVP_THREADS 512
 #endif
 constexpr int JVP_THREADS = SATBA_JVP_THREADS;
 // slots of a point whose camera index (and row scales) are in flight ahead of the one being worked on, in the table forms of k_jvp and
 // k_backsub.  Not what bounds them: depths 2 / 4 / 8 give 49.9 / 50.0 / 49.9 us (k_jvp) and 55.4 / 54.9 / 55.6 us (k_backsub) at
-// 200 x 1M x 10M (round 5).  Their time is the LDS: 14 eight-byte reads per observation from the table row of a random camera -- 64 lanes on
-// ~50 different rows, a measured ~3.5 passes per read -- i.e. ~197 cycles per wave and iteration and CU, which is what 50 us are
+// 200 x 1M x 10M (round 5).  Their time is the LDS: the table row of a random camera per observation -- 64 lanes on ~50 different rows.
+// Round 5 read it as fourteen 8-byte values, which the compiler paired into ds_read2_b64 (8 LDS cycles each, banks modulo 32, ~3 passes
+// on random rows: ~197 cycles per wave and iteration, which is what 50 us were); round 6 reads seven aligned ds_read_b128 (4 cycles
+// each, banks modulo 64): k_jvp 50 -> 37 us, k_backsub 56 -> 46 us in the loop (profiles/r6_b128_tables.txt)
 #ifndef SATBA_CAM_PF
 #define SATBA_CAM_PF 2
 #endif
 
 // affine cameras: J_c v_c = B_c X + b_c with B_c = sum_i v_ci D_ci, b_c = K-columns . v_cT, and J_p = A_c.  Every workgroup
 // derives the 14 constants of each camera once (three evaluations of the projector's Jacobian at the unit vectors) into an
-// LDS table with an odd row stride; an observation then costs 14 LDS reads and 14-18 multiply-adds instead of the Jacobian
+// LDS table of 112-byte rows; an observation then costs seven 16-byte LDS reads and 14-18 multiply-adds instead of the Jacobian
 // evaluation.  vc: the camera part of the vector (unscaled variables), n_c doubles.
 // vs (or null): vc is in scaled variables, the direction is vc / vs (as the generic path forms it: times the reciprocal)
 template <int NP>
@@ -1155,7 +1169,7 @@ template <int MODEL, int NP, int NV, bool CL, bool RL, bool PRE, bool DG = false
 __global__ __launch_bounds__(JVP_THREADS) void k_jvp(ObsArgs a, const double* __restrict__ q1, const double* __restrict__ q2,
                                                      const double* __restrict__ scale_inv, RedBuf rb, double* __restrict__ out) {
     SATBA_GATE(a.gate);
-    extern __shared__ double s_dyn_jvp[];
+    extern __shared__ __attribute__((aligned(16))) double s_dyn_jvp[];
     const int lane = threadIdx.x & 63;
     constexpr int WAVES = JVP_THREADS / 64;
     double s11 = 0.0, s12 = 0.0, s22 = 0.0;
@@ -1195,7 +1209,9 @@ __global__ __launch_bounds__(JVP_THREADS) void k_jvp(ObsArgs a, const double* __
                 const int c0 = cq[0];
                 const double2 s0 = sq[0];
                 if (k < cnt) {
-                    const double* row = tab + (size_t)c0 * JVP_ROW;
+                    DirRow R;
+                    R.load(tab, c0);
+                    const double* row = R.v;
                     const double j0 = s0.x * (row[0] * X + row[1] * Y + row[2] * Z + row[6] + row[8] * v0 + row[9] * v1 + row[10] * v2);
                     const double j1 = s0.y * (row[3] * X + row[4] * Y + row[5] * Z + row[7] + row[11] * v0 + row[12] * v1 + row[13] * v2);
                     s11 += j0 * j0 + j1 * j1;
@@ -1251,8 +1267,10 @@ __global__ __launch_bounds__(JVP_THREADS) void k_jvp(ObsArgs a, const double* __
                 const int c0 = cq[0];
                 const double2 s0 = sq[0];
                 if (k < cnt) {
-                    const double* r1 = tab1 + (size_t)c0 * JVP_ROW;
-                    const double* r2 = tab2 + (size_t)c0 * JVP_ROW;
+                    DirRow R1, R2;
+                    R1.load(tab1, c0);
+                    R2.load(tab2, c0);
+                    const double *r1 = R1.v, *r2 = R2.v;
                     const double a0 = r1[8], a1 = r1[9], a2 = r1[10], a3 = r1[11], a4 = r1[12], a5 = r1[13];  // J_p (the same in both tables)
                     const double u0 = s0.x * (r1[0] * X + r1[1] * Y + r1[2] * Z + r1[6] + a0 * p1[0] + a1 * p1[1] + a2 * p1[2]);
                     const double u1 = s0.y * (r1[3] * X + r1[4] * Y + r1[5] * Z + r1[7] + a3 * p1[0] + a4 * p1[1] + a5 * p1[2]);
@@ -1487,7 +1505,7 @@ __global__ __launch_bounds__(BS_THREADS) void k_backsub(ObsArgs a, const double*
                                                         const double* __restrict__ scale_inv, const double* __restrict__ gh,
                                                         double* __restrict__ gn, RedBuf rb, double* __restrict__ hdr) {
     SATBA_GATE(a.gate);
-    extern __shared__ double s_dyn_bs[];
+    extern __shared__ __attribute__((aligned(16))) double s_dyn_bs[];
     const int lane = threadIdx.x & 63;
     constexpr int WAVES = BS_THREADS / 64;
     double sa = 0.0, sb = 0.0, sc = 0.0;
@@ -1538,7 +1556,9 @@ __global__ __launch_bounds__(BS_THREADS) void k_backsub(ObsArgs a, const double*
                 for (int d = 0; d + 1 < D; ++d) { cq[d] = cq[d + 1]; sq[d] = sq[d + 1]; }
                 cq[D - 1] = cn; sq[D - 1] = sn;
                 if (k < cnt) {
-                    const double* row = tab + (size_t)cam * JVP_ROW;
+                    DirRow R;
+                    R.load(tab, cam);
+                    const double* row = R.v;
                     // both blocks of an observation carry its row scale
                     const double u0 = mp * s2.x * s2.x * (row[0] * X + row[1] * Y + row[2] * Z + row[6]);
                     const double u1 = mp * s2.y * s2.y * (row[3] * X + row[4] * Y + row[5] * Z + row[7]);

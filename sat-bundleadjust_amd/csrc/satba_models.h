@@ -21,8 +21,14 @@ enum { AFFINE = 0, PERSPECTIVE = 1, RPC = 2 };
 // per-camera constant record, rebuilt from x before every pass over the observations
 //   [0..5]   cos a, sin a, cos b, sin b, cos g, sin g
 //   [6..14]  R row-major
-//   [15..]   affine: t0 t1 fx fy skew | perspective: t0 t1 t2 fx fy skew cx cy | rpc: T(3) C(3)
-constexpr int CAMC = 25;  // odd: camera rows start in all 32 LDS bank pairs (24 folds them onto 4: 16-way conflicts of every gather)
+//   [15]     pad
+//   [16..]   affine: t0 t1 fx fy skew | perspective: t0 t1 t2 fx fy skew cx cy | rpc: T(3) C(3)
+// Rows are 13 sixteen-byte slots: every pair (2 k, 2 k + 1) of a row is one aligned ds_read_b128 (256 B / clk, four 16-lane groups),
+// and an odd slot count starts the rows of consecutive cameras in all 16 slots of the LDS's 256-byte bank row.  Round 6: with 25
+// doubles per row (8-byte alignment) the compiler paired the reads as ds_read2_b64 -- half the rate and banks modulo 32: the gathers
+// of a wave's ~50 different cameras were most of the LDS time of the lane = point kernels.
+constexpr int CAMC = 26;
+constexpr int CAMX = 16;  // first model-specific entry
 
 constexpr double WGS84_A = 6378137.0;
 constexpr double WGS84_E = 8.1819190842622e-2;  // as hard-coded at ref:bundle_adjust/geo_utils.py:241
@@ -37,8 +43,9 @@ __device__ inline void cam_constants(int model, const double* full, double* cc) 
     cc[9] = sg * cb;  cc[10] = sg * sb * sa + cg * ca;  cc[11] = sg * sb * ca - cg * sa;
     cc[12] = -sb;     cc[13] = cb * sa;                 cc[14] = cb * ca;
     const int n_extra = model == AFFINE ? 5 : (model == PERSPECTIVE ? 8 : 6);
-    for (int i = 0; i < n_extra; ++i) cc[15 + i] = full[3 + i];
-    for (int i = 15 + n_extra; i < CAMC; ++i) cc[i] = 0.0;
+    for (int i = 0; i < n_extra; ++i) cc[CAMX + i] = full[3 + i];
+    cc[15] = 0.0;
+    for (int i = CAMX + n_extra; i < CAMC; ++i) cc[i] = 0.0;
 }
 
 // y3 = Rz Ry Rx X and the three angle derivatives of y3
@@ -189,7 +196,7 @@ template <int NP>
 __device__ inline void rpc_jac_from_d(const double* __restrict__ cc, double X, double Y, double Z, const double (&D)[2][3], double Jc[2][NP],
                                       double Jp[2][3]) {
     Rot r;
-    rotate<true>(cc, X - cc[15] - cc[18], Y - cc[16] - cc[19], Z - cc[17] - cc[20], r);
+    rotate<true>(cc, X - cc[CAMX] - cc[CAMX + 3], Y - cc[CAMX + 1] - cc[CAMX + 4], Z - cc[CAMX + 2] - cc[CAMX + 5], r);
     const double* d[3] = {r.da, r.db, r.dg};
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
@@ -215,9 +222,9 @@ template <int NP, bool JAC, bool BLOCKS = true>
 __device__ inline void project_rpc_d(const double* __restrict__ cc, const double* __restrict__ rpc_tab, double X, double Y, double Z, bool f32,
                                      double& u, double& v, double Jc[2][NP], double Jp[2][3], double (&D)[2][3]) {
     // X' = R (X - T - C) + C   (ref:bundle_adjust/ba_core.py:126-130)
-    const double C0 = cc[18], C1 = cc[19], C2 = cc[20];
+    const double C0 = cc[CAMX + 3], C1 = cc[CAMX + 4], C2 = cc[CAMX + 5];
     Rot r;
-    rotate<JAC && BLOCKS>(cc, X - cc[15] - C0, Y - cc[16] - C1, Z - cc[17] - C2, r);
+    rotate<JAC && BLOCKS>(cc, X - cc[CAMX] - C0, Y - cc[CAMX + 1] - C1, Z - cc[CAMX + 2] - C2, r);
     rpc_project<JAC>(rpc_tab, r.y3[0] + C0, r.y3[1] + C1, r.y3[2] + C2, u, v, D);
     if (f32) {  // ref:bundle_adjust/ba_core.py:150 stores the projections in a float32 array
         u = (double)(float)u;
@@ -252,7 +259,7 @@ __device__ inline void project(const double* __restrict__ cc, const double* __re
     Rot r;
     if constexpr (MODEL == AFFINE) {
         rotate<JAC>(cc, X, Y, Z, r);
-        const double t0 = cc[15], t1 = cc[16], fx = cc[17], fy = cc[18], sk = cc[19];
+        const double t0 = cc[CAMX], t1 = cc[CAMX + 1], fx = cc[CAMX + 2], fy = cc[CAMX + 3], sk = cc[CAMX + 4];
         const double q0 = r.y3[0] + t0, q1 = r.y3[1] + t1;
         u = fx * q0 + sk * q1;
         v = fy * q1;
@@ -280,8 +287,8 @@ __device__ inline void project(const double* __restrict__ cc, const double* __re
         }
     } else if constexpr (MODEL == PERSPECTIVE) {
         rotate<JAC>(cc, X, Y, Z, r);
-        const double fx = cc[18], fy = cc[19], sk = cc[20], cx = cc[21], cy = cc[22];
-        const double q0 = r.y3[0] + cc[15], q1 = r.y3[1] + cc[16], q2 = r.y3[2] + cc[17];
+        const double fx = cc[CAMX + 3], fy = cc[CAMX + 4], sk = cc[CAMX + 5], cx = cc[CAMX + 6], cy = cc[CAMX + 7];
+        const double q0 = r.y3[0] + cc[CAMX], q1 = r.y3[1] + cc[CAMX + 1], q2 = r.y3[2] + cc[CAMX + 2];
         const double un = fx * q0 + sk * q1 + cx * q2;
         const double vn = fy * q1 + cy * q2;
         u = un / q2;

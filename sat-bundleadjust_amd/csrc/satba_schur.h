@@ -436,7 +436,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((MODEL == A
             return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(x)), __builtin_amdgcn_readfirstlane(__double2loint(x)));
         };
         auto cam_p = [&](const double* cc, double (&P)[2][3], double (&Au)[3]) {
-            const double fx = cc[17], fy = cc[18], sk = cc[19];
+            const double fx = cc[CAMX + 2], fy = cc[CAMX + 3], sk = cc[CAMX + 4];
             Au[0] = fx; Au[1] = sk; Au[2] = fy;
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
@@ -794,7 +794,7 @@ __device__ __forceinline__ void schur_diag_walk(const ObsArgs& a, const double2*
     // affine cameras (block-uniform): J_c = A [D(X) | I], J_p = A R  (see k_schur_pairs)
     double Pm[2][3], Au[3] = {0.0, 0.0, 0.0}, tr[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
     if constexpr (MODEL == AFFINE) {
-        const double fx = cc[17], fy = cc[18], sk = cc[19];
+        const double fx = cc[CAMX + 2], fy = cc[CAMX + 3], sk = cc[CAMX + 4];
         Au[0] = fx; Au[1] = sk; Au[2] = fy;
 #pragma unroll
         for (int k = 0; k < 3; ++k) { Pm[0][k] = fx * cc[6 + k] + sk * cc[9 + k]; Pm[1][k] = fy * cc[9 + k]; }
