@@ -41,7 +41,10 @@ constexpr long long FX_MAX_OBS_PER_CAM = 1ll << 23;
 // (a multiple of 16 bytes: the camera-constant rows behind the table are read with ds_read_b128)
 __host__ __device__ constexpr size_t cam_sum_bytes(int np, size_t rows) { return (rows * cam_sum_stride(np) * 8 + 15) & ~(size_t)15; }
 
-constexpr int RPCS = 91;  // row stride of the LDS copy of the RPC tables (90 used, odd)
+// row stride of the LDS copy of the RPC tables: 90 doubles used, 47 sixteen-byte slots (odd: the rows of consecutive cameras start in all
+// 16 slots of the bank row).  Round 6: with 91 doubles (8-byte alignment) the 90 reads of an evaluation were 45 ds_read2_b64 pairs -- half
+// the rate of the 45 aligned ds_read_b128 they are now (satba_models.h: CAMC)
+constexpr int RPCS = 94;
 // double -> 64-bit fixed point through one fma (k_linearize's camera sums): bits(t 2^e + 1.5 * 2^52) = FX_MAGIC_BITS + round(t 2^e)
 constexpr int SATBA_HDR_PREP_GH = 6, SATBA_HDR_PREP_XS = 7;  // linearize header: point sums of |g_h|^2, |x_h|^2 (prepare fused into k_linearize)
 constexpr int SATBA_HDR_FX = 5;  // linearize header: a term of the fixed-point camera sums exceeded its bound (summed over ranks)
@@ -251,7 +254,8 @@ struct CamTables {
     }
     // (rows are 16-byte aligned in the LDS and in global memory: the pairs of a row are read as ds_read_b128 / global_load_dwordx4)
     __device__ inline const double* cc(int cam) const { return static_cast<const double*>(__builtin_assume_aligned(cbase + (size_t)cam * CAMC, 16)); }
-    __device__ inline const double* tab(int cam) const { return rbase + (size_t)cam * rstride; }  // only dereferenced for RPC
+    // (only dereferenced for RPC; 16-byte aligned rows in both places: 94 doubles in the LDS, 90 in global memory)
+    __device__ inline const double* tab(int cam) const { return static_cast<const double*>(__builtin_assume_aligned(rbase + (size_t)cam * rstride, 16)); }
 };
 
 __device__ inline double wave_sum(double v) {
