@@ -45,6 +45,7 @@ __host__ __device__ constexpr size_t cam_sum_bytes(int np, size_t rows) { return
 // 16 slots of the bank row).  Round 6: with 91 doubles (8-byte alignment) the 90 reads of an evaluation were 45 ds_read2_b64 pairs -- half
 // the rate of the 45 aligned ds_read_b128 they are now (satba_models.h: CAMC)
 constexpr int RPCS = 94;
+static_assert(RPCS >= 90 && RPCS % 2 == 0 && (RPCS / 2) % 2 == 1, "RPC rows in the LDS: an odd number of 16-byte slots");
 // double -> 64-bit fixed point through one fma (k_linearize's camera sums): bits(t 2^e + 1.5 * 2^52) = FX_MAGIC_BITS + round(t 2^e)
 constexpr int SATBA_HDR_PREP_GH = 6, SATBA_HDR_PREP_XS = 7;  // linearize header: point sums of |g_h|^2, |x_h|^2 (prepare fused into k_linearize)
 constexpr int SATBA_HDR_FX = 5;  // linearize header: a term of the fixed-point camera sums exceeded its bound (summed over ranks)
@@ -1100,6 +1101,7 @@ __global__ __launch_bounds__(256) void k_prepare_vec(int n, int n_c, int NP, int
 // per-camera constants of the affine form of k_jvp / k_backsub: B (6) | b (2) | A (6) -- seven 16-byte slots, read as seven ds_read_b128
 // (DirRow).  Round 6: with an odd stride of 15 doubles the fourteen reads were ds_read2_b64 pairs (128 B / clk, banks modulo 32).
 constexpr int JVP_ROW = 14;
+static_assert(JVP_ROW % 2 == 0 && (JVP_ROW / 2) % 2 == 1, "direction-table rows: an odd number of 16-byte slots");
 struct DirRow {
     double v[14];
     __device__ inline void load(const double* __restrict__ tab, int cam) {

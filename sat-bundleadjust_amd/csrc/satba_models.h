@@ -29,6 +29,7 @@ enum { AFFINE = 0, PERSPECTIVE = 1, RPC = 2 };
 // of a wave's ~50 different cameras were most of the LDS time of the lane = point kernels.
 constexpr int CAMC = 26;
 constexpr int CAMX = 16;  // first model-specific entry
+static_assert(CAMC % 2 == 0 && (CAMC / 2) % 2 == 1 && CAMX % 2 == 0 && CAMX + 8 <= CAMC, "camera records: an odd number of 16-byte slots, model entries on a slot boundary");
 
 constexpr double WGS84_A = 6378137.0;
 constexpr double WGS84_E = 8.1819190842622e-2;  // as hard-coded at ref:bundle_adjust/geo_utils.py:241
