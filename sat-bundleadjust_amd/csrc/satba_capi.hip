@@ -493,11 +493,14 @@ static int launch_schur(satba_problem* p, const ObsArgs& a, double* S, double* r
     const bool pairs_run = n_pairs > 0 && p->L.E > 0;
     const bool dg_in_pairs = s.wmode && MODEL != RPC && pairs_run;
     int dchunks = (a.sc && MODEL != RPC) ? p->cm_chunks_w : p->cm_chunks;
+    // the factorisation BEHIND the Schur kernels (no arrival protocol): the diagonal pass and the pair kernel in one launch (k_schur_both)
+    static const bool one_launch_env = !(getenv("SATBA_SCHUR_ONE_LAUNCH") && atoi(getenv("SATBA_SCHUR_ONE_LAUNCH")) == 0);
+    const bool both = one_launch_env && !p->arrive_epoch && !dg_in_pairs && pairs_run;
     if (dg_in_pairs) dchunks = p->L.n_dg;
     else {
         if (s.wmode) cm.pt = p->L.cm_rec;  // (k_schur_diag on the merged records: piece offsets instead of point indices)
         s.diag_xcd = (dchunks % 8 == 0 && !getenv("SATBA_NO_DIAG_XCD")) ? 1 : 0;
-        hipLaunchKernelGGL((k_schur_diag<MODEL, NP>), dim3(p->M, dchunks), dim3(LINC_THREADS), 0, p->stream, a, cm, s, p->d_part3);
+        if (!both) hipLaunchKernelGGL((k_schur_diag<MODEL, NP>), dim3(p->M, dchunks), dim3(LINC_THREADS), 0, p->stream, a, cm, s, p->d_part3);
     }
     const int total = p->M * cam_acc_len(NP);
     const int nb_diag = (int)((std::max<long long>(8ll * total, p->hdr) + 255) / 256);
@@ -527,7 +530,13 @@ static int launch_schur(satba_problem* p, const ObsArgs& a, double* S, double* r
         const bool merged = a.unit && p->d_item_desc_merged;  // one item per pair: straight into S, no partials
         if (merged) { s.desc = p->d_item_desc_merged; s.items = p->d_items_merged; s.n_chunks = 1; }
         const dim3 igrid((unsigned)(merged ? p->n_item_blocks_merged : (s.wmode ? p->n_item_blocks_w : p->n_item_blocks)));
-        if (a.unit) hipLaunchKernelGGL((k_schur_pairs<MODEL, NP, true>), igrid, dim3(256), 0, p->stream, a, s, S);
+        if (both) {
+            const int n_diag = p->M * dchunks, n_diag_pad = (n_diag + 7) & ~7;
+            const dim3 bgrid(igrid.x + (unsigned)n_diag_pad);
+            if (a.unit) hipLaunchKernelGGL((k_schur_both<MODEL, NP, true>), bgrid, dim3(256), 0, p->stream, a, cm, s, p->d_part3, S, n_diag, n_diag_pad, p->M, dchunks);
+            else hipLaunchKernelGGL((k_schur_both<MODEL, NP, false>), bgrid, dim3(256), 0, p->stream, a, cm, s, p->d_part3, S, n_diag, n_diag_pad, p->M, dchunks);
+        }
+        else if (a.unit) hipLaunchKernelGGL((k_schur_pairs<MODEL, NP, true>), igrid, dim3(256), 0, p->stream, a, s, S);
         else hipLaunchKernelGGL((k_schur_pairs<MODEL, NP, false>), igrid, dim3(256), 0, p->stream, a, s, S);
         HIP_TRY(hipGetLastError());
         if (p->L.C > 1 && !merged) red_chunks = p->L.C;

@@ -346,14 +346,14 @@ __device__ __forceinline__ void schur_diag_walk(const ObsArgs& a, const double2*
 #define SATBA_PAIRS_OCC_MIN_O 1  // perspective / RPC kernels: least waves per SIMD the register allocator must leave room for (218 - 252 registers: two
                                  // waves.  Round 5, forced to 3 -- 168 registers, 88 - 340 bytes of scratch in the hit loop: C5 1 419 against 1 699 it/s, P3 1 209 / 2 324)
 #endif
+#define SATBA_PAIRS_WAVES_ATTR(MODEL, UNITW) __attribute__((amdgpu_waves_per_eu(((MODEL) == AFFINE) ? ((UNITW) ? SATBA_PAIRS_OCC_U : SATBA_PAIRS_OCC_W) : SATBA_PAIRS_OCC_MIN_O, ((MODEL) == AFFINE) ? ((UNITW) ? SATBA_PAIRS_OCC_U : SATBA_PAIRS_OCC_W) : 3)))
+// bidx: the workgroup's index among the pair workgroups of the launch; s_coop: 4 x 64 x 7 double2 of LDS -- per wave 64 records x 80 (112: with the
+// scales) bytes, or 64 Jacobian rows x 112 (the cooperative gathers are transposed here); s_idx: weighted / robust, the three gather indices of a wave's 64 hits
 template <int MODEL, int NP, bool UNITW>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((MODEL == AFFINE) ? (UNITW ? SATBA_PAIRS_OCC_U : SATBA_PAIRS_OCC_W) : SATBA_PAIRS_OCC_MIN_O, (MODEL == AFFINE) ? (UNITW ? SATBA_PAIRS_OCC_U : SATBA_PAIRS_OCC_W) : 3))) void k_schur_pairs(ObsArgs a, SchurArgs s, double* __restrict__ S) {
-    SATBA_GATE(a.gate);
-    __shared__ double2 s_coop[4 * 64 * 7];  // per wave: 64 records x 80 (112: with the scales) bytes, or 64 Jacobian rows x 112 (the cooperative gathers are transposed here)
-    __shared__ unsigned s_idx[4][3 * 64];   // weighted / robust: the three gather indices of a wave's 64 hits
+__device__ __forceinline__ void schur_pairs_body(const ObsArgs& a, const SchurArgs& s, double* __restrict__ S, const unsigned bidx, double2* s_coop, unsigned (*s_idx)[3 * 64]) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long long n_pairs = (long long)a.M * (a.M - 1) / 2;
-    const SchurItem* dp = s.desc + (blockIdx.x * 4u + (unsigned)wave);
+    const SchurItem* dp = s.desc + (bidx * 4u + (unsigned)wave);
     const int i = __builtin_amdgcn_readfirstlane(dp->i);  // wave-uniform by construction: lets the camera constants use scalar loads
     if (i < 0) return;
     const int j = __builtin_amdgcn_readfirstlane(dp->j);
@@ -381,7 +381,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((MODEL == A
             }
             if (writer) __hip_atomic_store(mine, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (blockIdx.x == 0 && threadIdx.x == 0)  // (the first item of the launch: everything in front of this kernel on the stream is complete)
+            if (bidx == 0 && threadIdx.x == 0)  // (the first item of the launch: everything in front of this kernel on the stream is complete)
                 __hip_atomic_store(s.arrive + (size_t)SCHUR_ARRIVE_STRIDE * a.M, s.arrive_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             int* cnt = s.dg_cnt + i;
             if (chunk + 1 < s.n_dg) {
@@ -717,7 +717,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((MODEL == A
     long long pair_ = pair;
     asm volatile("" : "+v"(e_), "+s"(i_), "+s"(j_), "+s"(chunk_), "+s"(pair_));
     // the first item tells the factorisation that this kernel runs: everything in front of it on the stream (diagonal blocks, right-hand side) is complete
-    if (s.arrive && blockIdx.x == 0 && threadIdx.x == 0)
+    if (s.arrive && bidx == 0 && threadIdx.x == 0)
         __hip_atomic_store(s.arrive + (size_t)SCHUR_ARRIVE_STRIDE * a.M, s.arrive_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     double* const s_out = S + (size_t)(j_ * NP + e_ % NP) + (size_t)(i_ * NP + e_ / NP) * a.n_c;  // S[(j,q), (i,r)] = (W_i Vinv W_j^T)[r][q], e = r NP + q
     if constexpr (!UNITW) {
@@ -736,6 +736,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((MODEL == A
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (lane == 0) __hip_atomic_fetch_add(s.arrive + (size_t)SCHUR_ARRIVE_STRIDE * i_, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+}
+template <int MODEL, int NP, bool UNITW>
+__global__ __launch_bounds__(256) SATBA_PAIRS_WAVES_ATTR(MODEL, UNITW) void k_schur_pairs(ObsArgs a, SchurArgs s, double* __restrict__ S) {
+    SATBA_GATE(a.gate);
+    __shared__ double2 s_coop[4 * 64 * 7];
+    __shared__ unsigned s_idx[4][3 * 64];
+    schur_pairs_body<MODEL, NP, UNITW>(a, s, S, blockIdx.x, s_coop, s_idx);
 }
 
 
@@ -932,23 +939,22 @@ __device__ __forceinline__ void schur_diag_walk(const ObsArgs& a, const double2*
 
 // grid (M, chunks): the workgroups of one chunk (the same slice of every camera's point-sorted list, i.e. about the same
 // point range) are dispatched together and share their point records in L2.  part [M][chunks][CU]
+// L: the workgroup's index among the M x n_chunks diagonal workgroups of the launch; s_coop: (LINC_THREADS / 64) x 64 x 7 double2, s_red: the waves' sums
 template <int MODEL, int NP>
-__global__ __launch_bounds__(LINC_THREADS) void k_schur_diag(ObsArgs a, CamMajor c, SchurArgs s, double* __restrict__ part) {
-    SATBA_GATE(a.gate);
+__device__ __forceinline__ void schur_diag_body(const ObsArgs& a, const CamMajor& c, const SchurArgs& s, double* __restrict__ part, const int L, const int M,
+                                                const int n_chunks, double2* s_coop, double (*s_red)[cam_acc_len(NP)]) {
     constexpr int CU = cam_acc_len(NP);
-    // s.diag_xcd (chunk count a multiple of 8): workgroup L = y M + x of the launch runs on XCD L % 8 (observed placement); XCD x takes
+    // s.diag_xcd (chunk count a multiple of 8): workgroup L of the launch runs on XCD L % 8 (observed placement); XCD x takes
     // the chunks = x (mod 8), every camera's slice of one chunk in a row, so that the records (and, weighted runs, the scale lines)
     // of a point range are fetched by ONE XCD instead of by the ~6 that hold one of the point's cameras
-    int cam = blockIdx.x, chunk = blockIdx.y;
-    const int n_chunks = gridDim.y;
+    int cam = L % M, chunk = L / M;
     if (s.diag_xcd) {
-        const int L = blockIdx.y * gridDim.x + blockIdx.x, x = L & 7, q = L >> 3, M = gridDim.x;
+        const int x = L & 7, q = L >> 3;
         cam = q % M; chunk = (q / M) * 8 + x;
     }
     const int b = c.cam_ofs[cam], e = c.cam_ofs[cam + 1];
     const long long len = e - b;
     const int lo = b + (int)(len * chunk / n_chunks), hi = b + (int)(len * (chunk + 1) / n_chunks);
-    __shared__ double2 s_coop[(LINC_THREADS / 64) * 64 * 7];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     double acc[CU];
 #pragma unroll
@@ -959,7 +965,6 @@ __global__ __launch_bounds__(LINC_THREADS) void k_schur_diag(ObsArgs a, CamMajor
 #pragma unroll
         for (int k = 0; k < CU; ++k) acc[k] = 0.0;
     }
-    __shared__ double s_red[LINC_THREADS / 64][CU];
 #pragma unroll
     for (int k = 0; k < CU; ++k) {
         const double t = wave_sum(acc[k]);
@@ -971,6 +976,31 @@ __global__ __launch_bounds__(LINC_THREADS) void k_schur_diag(ObsArgs a, CamMajor
         for (int wv = 0; wv < LINC_THREADS / 64; ++wv) t += s_red[wv][threadIdx.x];
         part[((size_t)cam * n_chunks + chunk) * CU + threadIdx.x] = t;
     }
+}
+template <int MODEL, int NP>
+__global__ __launch_bounds__(LINC_THREADS) void k_schur_diag(ObsArgs a, CamMajor c, SchurArgs s, double* __restrict__ part) {
+    SATBA_GATE(a.gate);
+    __shared__ double2 s_coop[(LINC_THREADS / 64) * 64 * 7];
+    __shared__ double s_red[LINC_THREADS / 64][cam_acc_len(NP)];
+    schur_diag_body<MODEL, NP>(a, c, s, part, (int)(blockIdx.y * gridDim.x + blockIdx.x), (int)gridDim.x, (int)gridDim.y, s_coop, s_red);
+}
+// Diagonal pass and pair kernel in ONE launch (round 6; fronts with the factorisation behind them, not beside them): the two are
+// independent -- both read k_vinv's records -- and below ~10 000 pairs neither fills the chip (50 cameras: 400 + 306 workgroups for 768
+// slots), so they run side by side where two launches ran one after the other.  Workgroups [0, n_diag_pad) are the diagonal ones
+// (n_diag_pad: n_diag rounded up to a multiple of 8, so that a pair workgroup's index keeps its XCD), the rest the pair kernel's.
+static_assert(LINC_THREADS == 256, "k_schur_both: both bodies run 256 threads");
+template <int MODEL, int NP, bool UNITW>
+__global__ __launch_bounds__(256) SATBA_PAIRS_WAVES_ATTR(MODEL, UNITW) void k_schur_both(ObsArgs a, CamMajor c, SchurArgs s, double* __restrict__ part, double* __restrict__ S,
+                                                                                      int n_diag, int n_diag_pad, int M, int n_chunks) {
+    SATBA_GATE(a.gate);
+    __shared__ double2 s_coop[4 * 64 * 7];
+    __shared__ unsigned s_idx[4][3 * 64];
+    __shared__ double s_red[4][cam_acc_len(NP)];
+    if ((int)blockIdx.x < n_diag_pad) {
+        if ((int)blockIdx.x < n_diag) schur_diag_body<MODEL, NP>(a, c, s, part, (int)blockIdx.x, M, n_chunks, s_coop, s_red);
+        return;
+    }
+    schur_pairs_body<MODEL, NP, UNITW>(a, s, S, blockIdx.x - (unsigned)n_diag_pad, s_coop, s_idx);
 }
 
 // End of the Schur phase, one launch (three in rounds 1-3: k_schur_init in front of the phase, k_schur_pairs_reduce and k_schur_diag_finish
