@@ -98,6 +98,8 @@ struct satba_problem {
     bool decide_fused = false;  // device-resident loop: the next launch_trial carries k_lm_decide1a in its first launch
     double w_max = 1.0, n_max_cam = 1.0, fx_shrink = 1.0;
     int fx_fallbacks = 0;
+    bool scales_by_tail = false;   // the last queued pattern ended with k_lm_accept_scales and the host has not touched the loop since (lm_launch_tick)
+    bool skip_lin_scales = false;  // ... so this satba_linearize does not launch k_lin_scales
     // device-resident LM loop (satba_lmdev.h): while a tick is being queued, `gate` points at the word of the loop's state that
     // switches the kernels of the current part of the pattern on or off, and the trust radius / first-iteration flag / trial
     // coefficients are read from the state instead of the launch arguments
@@ -1453,6 +1455,7 @@ int satba_linearize(satba_problem* p) {
             TRY(launch_residual(p, false, nullptr, p->d_fxcost));
             p->fxcost_valid = true;
         }
+        if (!p->skip_lin_scales)  // (device-resident loop on one rank: the previous tick's k_lm_accept_scales has done it)
         SATBA_DISPATCH(p, hipLaunchKernelGGL((k_lin_scales<MODEL, NP>), dim3(1), dim3(256), 0, p->stream, p->M, p->d_camc, p->d_rpc, p->d_bbox, p->w_max,
                                              p->loss, p->f_scale, p->d_fxcost, p->n_max_cam, p->fx_shrink, p->d_fx, p->d_fxe, p->d_fxflag, p->d_xb, n_clear, p->gate));
         HIP_TRY(hipGetLastError());
@@ -2004,8 +2007,22 @@ static int lm_launch_tail(satba_problem* p) {  // trial evaluation, decision, ac
     TRY(rc_trial);
     if (!fuse2) hipLaunchKernelGGL(k_lm_decide2, dim3(1), dim3(1), 0, p->stream, st, p->d_xb, p->h_lm_dev);
     const double* x0 = p->d_x0;
-    hipLaunchKernelGGL(k_lm_accept, dim3(grid_for(p->n / 2 + 1, 256, 1024)), dim3(256), 0, p->stream, st, (long long)p->n, p->d_x, p->d_xnew,
-                       p->M * CAMC, p->d_camc, p->d_camc_new, p->d_fxcost, p->d_fxcost_new, x0, x0 ? x0 + p->n + 6 : nullptr, p->d_fxcost0, p->d_bbox);
+    // the scales of the next tick's fixed-point camera sums ride in this launch (k_lm_accept_scales; SATBA_SCALES_IN_ACCEPT=0: k_lin_scales in every tick)
+    static const bool fuse_scales = !(getenv("SATBA_SCALES_IN_ACCEPT") && atoi(getenv("SATBA_SCALES_IN_ACCEPT")) == 0);
+    if (fuse_scales && p->cam_sums_lds && p->model != RPC) {  // (RPC: eight chains per camera in one workgroup outlast the copy -- C5 1 795 against 1 782 it/s)
+        LinScalesArgs q;
+        q.M = p->M; q.loss = p->loss; q.n_clear = (int)(p->hdr + (size_t)p->M * p->NP * p->NP + p->n_c);
+        q.w_max = p->w_max; q.f_scale = p->f_scale; q.n_max = p->n_max_cam; q.shrink = p->fx_shrink;
+        q.rpc = p->d_rpc; q.fx = p->d_fx; q.fxe = p->d_fxe; q.fx_flag = p->d_fxflag; q.clear = p->d_xb;
+        SATBA_DISPATCH(p, hipLaunchKernelGGL((k_lm_accept_scales<MODEL, NP>), dim3(grid_for(p->n / 2 + 1, 256, 1024) + 1), dim3(256), 0, p->stream, st, (long long)p->n,
+                                             p->d_x, p->d_xnew, p->M * CAMC, p->d_camc, p->d_camc_new, p->d_fxcost, p->d_fxcost_new, x0,
+                                             x0 ? x0 + p->n + 6 : nullptr, p->d_fxcost0, p->d_bbox, q));
+        p->scales_by_tail = true;
+    } else {
+        hipLaunchKernelGGL(k_lm_accept, dim3(grid_for(p->n / 2 + 1, 256, 1024)), dim3(256), 0, p->stream, st, (long long)p->n, p->d_x, p->d_xnew,
+                           p->M * CAMC, p->d_camc, p->d_camc_new, p->d_fxcost, p->d_fxcost_new, x0, x0 ? x0 + p->n + 6 : nullptr, p->d_fxcost0, p->d_bbox);
+        p->scales_by_tail = false;
+    }
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -2015,7 +2032,9 @@ static int lm_launch_tick(satba_problem* p, double lam_floor) {
     LmArgsScope scope(p);
     p->gate = &st->run_lin;
     p->fuse_prep = 0;  // (`first` comes from the loop's state)
+    p->skip_lin_scales = p->scales_by_tail && p->cam_sums_lds;
     const int rc_lin = satba_linearize(p);
+    p->skip_lin_scales = false;
     p->fuse_prep = -1;
     TRY(rc_lin);
     TRY(satba_prepare(p, 0));
@@ -2086,6 +2105,7 @@ static int lm_run_ahead_single() {
 // queue ticks until the device reports that the loop has left LM_RUN, lm_run_ahead_single() beyond its last report
 static int lm_drive(satba_problem* p, double lam_floor, long long max_ticks) {
     long long sub_served = 0;
+    p->scales_by_tail = false;  // the first tick of a run launches k_lin_scales itself
     for (;;) {
         // every evaluation and every repeated factorisation is one pattern: a loop that queues many more has lost track of the device
         if (p->lm_ticks_queued > max_ticks || p->lm_ticks_queued >= LM_MAX_TICKS) return fail(SATBA_E_STATE, "device-resident loop: %lld launch patterns queued without reaching the end", p->lm_ticks_queued);
@@ -2119,6 +2139,7 @@ static int lm_drive(satba_problem* p, double lam_floor, long long max_ticks) {
             HIP_TRY(hipGetLastError());
             __atomic_store_n(&p->h_lm->word, ((unsigned long long)st.tick << 8) | (unsigned long long)LM_RUN, __ATOMIC_RELEASE);
             p->lm_ticks_queued = st.tick;
+            p->scales_by_tail = false;  // (the repeated front's linearisation clears its header itself)
             continue;
         }
         if (phase != LM_RUN && phase != LM_NEED_SUB) return 0;

@@ -812,13 +812,13 @@ __global__ __launch_bounds__(1024) void k_lin_finish(int M, int NP, int nblocks,
 // terms, scaled by 2^(2 a_k), and the g terms, scaled by 2^(a_k + b), stay below 2^Q.
 // fxe: a_0 .. a_{NP-1} | b | c1 | c2  -- the range check of k_linearize is (hi32(y) + c1) <u c2, i.e. r >> 32 in [-L, L), L = 2^(Q-32);
 // fx:  [2 NP] inverse scales 2^-(2 a_k), 2^-(a_k + b).  The bounds need not be rigorous: every term is checked.
+// (the body: 256 threads of one workgroup; also run by a workgroup of k_lm_accept_scales, satba_lmdev.h)
 template <int MODEL, int NP>
-__global__ __launch_bounds__(256) void k_lin_scales(int M, const double* __restrict__ camc, const double* __restrict__ rpc,
-                                                    const double* __restrict__ bbox, double w_max, int loss, double f_scale,
-                                                    const double* __restrict__ cost, double n_max, double shrink,
-                                                    double* __restrict__ fx, int* __restrict__ fxe, int* __restrict__ fx_flag,
-                                                    double* __restrict__ clear, int n_clear, const int* gate) {
-    SATBA_GATE(gate);
+__device__ __forceinline__ void lin_scales_body(int M, const double* __restrict__ camc, const double* __restrict__ rpc,
+                                                const double* __restrict__ bbox, double w_max, int loss, double f_scale,
+                                                const double* __restrict__ cost, double n_max, double shrink,
+                                                double* __restrict__ fx, int* __restrict__ fxe, int* __restrict__ fx_flag,
+                                                double* __restrict__ clear, int n_clear) {
     __shared__ unsigned long long s_max[NP];
     __shared__ int s_a[NP + 1];
     for (int i = threadIdx.x; i < n_clear; i += 256) clear[i] = 0.0;
@@ -873,6 +873,15 @@ __global__ __launch_bounds__(256) void k_lin_scales(int M, const double* __restr
         fxe[NP + 1] = (int)((unsigned)L - 0x43380000u);
         fxe[NP + 2] = 2 * L;
     }
+}
+template <int MODEL, int NP>
+__global__ __launch_bounds__(256) void k_lin_scales(int M, const double* __restrict__ camc, const double* __restrict__ rpc,
+                                                    const double* __restrict__ bbox, double w_max, int loss, double f_scale,
+                                                    const double* __restrict__ cost, double n_max, double shrink,
+                                                    double* __restrict__ fx, int* __restrict__ fxe, int* __restrict__ fx_flag,
+                                                    double* __restrict__ clear, int n_clear, const int* gate) {
+    SATBA_GATE(gate);
+    lin_scales_body<MODEL, NP>(M, camc, rpc, bbox, w_max, loss, f_scale, cost, n_max, shrink, fx, fxe, fx_flag, clear, n_clear);
 }
 
 // bounding box of the points of x (lo xyz | hi xyz), one workgroup; no points: zeros

@@ -371,4 +371,46 @@ __global__ __launch_bounds__(256) void k_lm_accept(const LmDev* __restrict__ st,
     if (i0 == 0) *fxcost = *fxcost_new;
 }
 
+// k_lm_accept with one more workgroup (the last) that does k_lin_scales' work for the NEXT tick's linearisation (device-resident loop on one
+// rank, round 6: one launch per tick less).  The extra workgroup reads the point the loop ends up at from its SOURCE -- x0's record at a
+// restart, the trial's at an accepted step, the kept one otherwise -- while the other workgroups copy it, and works only when the decision
+// has asked for a linearisation (st->run_lin); the first tick of a run, and every tick behind a hand-over to the host, launch k_lin_scales
+// themselves (satba_capi.hip: lm_launch_tick).
+struct LinScalesArgs {
+    int M, loss, n_clear;
+    double w_max, f_scale, n_max, shrink;
+    const double* rpc;
+    double* fx;
+    int* fxe;
+    int* fx_flag;
+    double* clear;
+};
+template <int MODEL, int NP>
+__global__ __launch_bounds__(256) void k_lm_accept_scales(const LmDev* __restrict__ st, long long n, double* __restrict__ x, const double* __restrict__ x_new,
+                                                          int n_camc, double* __restrict__ camc, const double* __restrict__ camc_new,
+                                                          double* __restrict__ fxcost, const double* __restrict__ fxcost_new,
+                                                          const double* __restrict__ x0, const double* __restrict__ camc0,
+                                                          const double* __restrict__ fxcost0, double* __restrict__ bbox, LinScalesArgs q) {
+    const bool restore = st->restore != 0 && x0 != nullptr;
+    if (blockIdx.x + 1 == gridDim.x) {  // the scales of the next linearisation
+        if (st->run_lin == 0) return;
+        const bool acc = st->accept != 0;
+        lin_scales_body<MODEL, NP>(q.M, restore ? camc0 : (acc ? camc_new : camc), q.rpc, restore ? x0 + n : bbox, q.w_max, q.loss, q.f_scale,
+                                   restore ? fxcost0 : (acc ? fxcost_new : fxcost), q.n_max, q.shrink, q.fx, q.fxe, q.fx_flag, q.clear, q.n_clear);
+        return;
+    }
+    if (restore) {
+        x_new = x0; camc_new = camc0; fxcost_new = fxcost0;
+        if (blockIdx.x == 0 && threadIdx.x < 6) bbox[threadIdx.x] = x0[n + threadIdx.x];
+    } else if (st->accept == 0) return;
+    const long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x, stride = (long long)(gridDim.x - 1) * blockDim.x;
+    const long long n2 = n >> 1;
+    double2* x2 = reinterpret_cast<double2*>(x);
+    const double2* xn2 = reinterpret_cast<const double2*>(x_new);
+    for (long long i = i0; i < n2; i += stride) x2[i] = xn2[i];
+    if (i0 == 0 && (n & 1)) x[n - 1] = x_new[n - 1];
+    for (long long i = i0; i < n_camc; i += stride) camc[i] = camc_new[i];
+    if (i0 == 0) *fxcost = *fxcost_new;
+}
+
 }  // namespace satba
