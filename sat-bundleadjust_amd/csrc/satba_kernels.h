@@ -89,6 +89,7 @@ struct ObsArgs {
     int unit;                            // every weight is 1 and the loss is linear
     int rep_shift;                       // log2 of the number of replicas of k_linearize's LDS camera table (few cameras)
     int sh;                              // log2 of the lanes per point (slice_unit): 0 for large problems
+    int rev = 0;                         // for_each_slice: the slices in the opposite order in time
     double f_scale;
     const int* __restrict__ fxe;         // fixed-point scales of k_linearize's camera sums (k_lin_scales): exponents a_0 .. a_{NP-1}, b, then
                                          // the two constants of the range check
@@ -333,12 +334,16 @@ __device__ inline void atomic_max_pos(double* addr, double v) {  // v >= 0; a ma
 // the long end of the list: slice fi from the front, then slice n - 1 - fi from the back, with fi = wave, wave + G,
 // wave + 2 G, ...  Every wave gets about the same number of observations, and neighbouring waves still read neighbouring
 // slices.  body(g) is called with a wave-uniform slice index.
+// rev: the same pairs in the opposite order in time (from the middle of the list outwards).  Consecutive lane = point kernels of an
+// iteration alternate the direction, so that a kernel starts on the part of the ELL stream the one before it read last (what of its
+// 200 MB is still in the 256 MB memory-side cache) instead of on the part that has been out of it longest.
 template <class F>
-__device__ inline void for_each_slice(int n_slices, int waves_per_block, F&& body) {
+__device__ inline void for_each_slice(int n_slices, int waves_per_block, F&& body, const int rev = 0) {
     const int w = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * waves_per_block + (threadIdx.x >> 6)));
     const int G = gridDim.x * waves_per_block;
     const int half = (n_slices + 1) >> 1, rest = n_slices - half;
-    for (int fi = w; fi < half; fi += G) {
+    for (int i = w; i < half; i += G) {
+        const int fi = rev ? half - 1 - i : i;
         body(fi);
         if (fi < rest) body(n_slices - 1 - fi);
     }
@@ -516,7 +521,7 @@ __global__ __launch_bounds__(RES_THREADS) void k_residual(ObsArgs a, double2* __
 #pragma unroll
             for (int j = 0; j < SATBA_PF; ++j) r[j] = r[j + 1];
         }
-    });
+    }, a.rev);
     if constexpr (TRIAL) {
         double v[4] = {0.5 * acc, ss, xx, 0.5 * acc};
         double* const dst[4] = {cost, t.ss, t.xx, t.cost2};
@@ -727,7 +732,7 @@ __global__ __launch_bounds__(LinCfg<(ROBUST && !SOFT) || MODEL == RPC>::THREADS)
                 }
             }
         }
-    });
+    }, a.rev);
     // per-workgroup epilogue
     gmax = wave_max(gmax);
     if (lane == 0 && gmax > 0.0) atomic_max_pos(hdr_gpmax, gmax);
@@ -1235,7 +1240,7 @@ __global__ __launch_bounds__(JVP_THREADS) void k_jvp(ObsArgs a, const double* __
                 for (int d = 0; d + 1 < D; ++d) { cq[d] = cq[d + 1]; sq[d] = sq[d + 1]; }
                 cq[D - 1] = cn; sq[D - 1] = sn;
             }
-        });
+        }, a.rev);
     } else if constexpr (MODEL == AFFINE && !PRE && NV == 2) {
         // the two directions of the explicit-products pattern (g_h and gn_h parallel: 30 % of the soft_l1 iterations at 200 cameras):
         // two direction tables instead of a Jacobian evaluation per observation (208 -> ~110 us at 10 M observations)
@@ -1299,7 +1304,7 @@ __global__ __launch_bounds__(JVP_THREADS) void k_jvp(ObsArgs a, const double* __
                 for (int d = 0; d + 1 < D; ++d) { cq[d] = cq[d + 1]; sq[d] = sq[d + 1]; }
                 cq[D - 1] = cn; sq[D - 1] = sn;
             }
-        });
+        }, a.rev);
     } else {
         CamTables<CL, RL> T;
         T.stage(a, s_dyn_jvp, JVP_THREADS);
@@ -1356,7 +1361,7 @@ __global__ __launch_bounds__(JVP_THREADS) void k_jvp(ObsArgs a, const double* __
                     }
                 }
             }
-        });
+        }, a.rev);
     }
     if constexpr (NV == 2) {
         double v[3] = {s11, s12, s22};
@@ -1617,7 +1622,7 @@ __global__ __launch_bounds__(BS_THREADS) void k_backsub(ObsArgs a, const double*
                 sa += h * h; sb += h * v; sc += v * v;
             }
         }
-    });
+    }, a.rev);
     double v[3] = {sa, sb, sc};
     double* const dst[3] = {hdr + 1, hdr + 2, hdr + 3};
     grid_sum<3>(v, dst, rb);
